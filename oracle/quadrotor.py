@@ -1,0 +1,136 @@
+"""ctypes front-end of oracle/quadrotor_oracle.c — TEST INFRASTRUCTURE (see oracle/__init__.py)."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "libmetagym_oracle.so")
+
+TASK_NO_COLLISION = 0
+TASK_HOVERING = 2
+
+
+def build(force=False):
+    """Compile the oracle with gcc (seconds). Called by __graft_entry__.build() and on first use."""
+    srcs = [f for f in os.listdir(_HERE) if f.endswith(("_oracle.c", ".h")) or f == "Makefile"]
+    stale = force or not os.path.exists(_LIB_PATH) or any(
+        os.path.getmtime(os.path.join(_HERE, f)) > os.path.getmtime(_LIB_PATH) for f in srcs)
+    if stale:
+        subprocess.check_call(["make", "-s", "-C", _HERE, "-B"])
+    return _LIB_PATH
+
+
+class Consts(C.Structure):
+    _fields_ = [
+        ("precision", C.c_double), ("quality", C.c_double),
+        ("ct0", C.c_double), ("ct1", C.c_double), ("ct2", C.c_double),
+        ("mm", C.c_double), ("jm", C.c_double), ("ra", C.c_double), ("phi", C.c_double),
+        ("fail_velocity", C.c_double), ("fail_w", C.c_double), ("fail_range", C.c_double),
+        ("min_voltage", C.c_double), ("max_voltage", C.c_double),
+        ("dt", C.c_double), ("healthy_reward", C.c_double), ("z_offset", C.c_double),
+        ("x_offset", C.c_int64), ("y_offset", C.c_int64),
+        ("nt", C.c_int32), ("task", C.c_int32),
+        ("inertia_inv", C.c_float * 9), ("drag_m", C.c_float * 9), ("drag_f", C.c_float * 9),
+        ("gravity_center", C.c_float * 3), ("prop_coord", C.c_float * 12),
+        ("map", C.POINTER(C.c_int32)), ("map_h", C.c_int32), ("map_w", C.c_int32),
+    ]
+
+
+class State(C.Structure):
+    _fields_ = [
+        ("pos", C.c_float * 3), ("vel", C.c_double * 3), ("omega", C.c_double * 3),
+        ("propw", C.c_float * 4), ("R", C.c_float * 9), ("Rinv", C.c_float * 9),
+        ("power", C.c_float), ("pos0_z", C.c_float),
+    ]
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        _lib = C.CDLL(_LIB_PATH)
+        _lib.qo_sizeof_state.restype = C.c_size_t
+        _lib.qo_sizeof_consts.restype = C.c_size_t
+        assert _lib.qo_sizeof_state() == C.sizeof(State), "oracle State layout drifted"
+        assert _lib.qo_sizeof_consts() == C.sizeof(Consts), "oracle Consts layout drifted"
+    return _lib
+
+
+def default_consts(nt=1000, task=TASK_HOVERING):
+    c = Consts()
+    lib().qo_default_consts(C.byref(c))
+    c.nt = nt
+    c.task = task
+    return c
+
+
+def make_states(pos, vel, omega, propw, R):
+    """Arrays [n,3],[n,3],[n,3],[n,4],[n,9] -> ctypes array of State with Rinv = inv(R)."""
+    n = len(pos)
+    arr = (State * n)()
+    L = lib()
+    for e in range(n):
+        s = arr[e]
+        s.pos[:] = [float(x) for x in np.asarray(pos[e], np.float32)]
+        s.vel[:] = [float(x) for x in np.asarray(vel[e], np.float64)]
+        s.omega[:] = [float(x) for x in np.asarray(omega[e], np.float64)]
+        s.propw[:] = [float(x) for x in np.asarray(propw[e], np.float32)]
+        s.R[:] = [float(x) for x in np.asarray(R[e], np.float32).reshape(9)]
+        s.power = 0.0
+        s.pos0_z = 0.0
+        L.qo_refresh_inverse(C.byref(s))
+    return arr
+
+
+def states_to_arrays(arr):
+    n = len(arr)
+    out = dict(pos=np.zeros((n, 3), np.float32), vel=np.zeros((n, 3), np.float64),
+               omega=np.zeros((n, 3), np.float64), propw=np.zeros((n, 4), np.float32),
+               R=np.zeros((n, 9), np.float32), power=np.zeros(n, np.float32))
+    for e in range(n):
+        s = arr[e]
+        out["pos"][e] = s.pos[:]
+        out["vel"][e] = s.vel[:]
+        out["omega"][e] = s.omega[:]
+        out["propw"][e] = s.propw[:]
+        out["R"][e] = s.R[:]
+        out["power"][e] = s.power
+    return out
+
+
+def batch_env_step(consts, states, ct, actions):
+    """One env.step for every env. ct: int32[n] (updated in place). actions: f32[n,4].
+    Returns obs f32[n,16], reward f64[n], done i32[n], failed i32[n]."""
+    n = len(states)
+    actions = np.ascontiguousarray(actions, np.float32)
+    assert actions.shape == (n, 4) and ct.dtype == np.int32
+    obs = np.zeros((n, 16), np.float32)
+    reward = np.zeros(n, np.float64)
+    done = np.zeros(n, np.int32)
+    failed = np.zeros(n, np.int32)
+    lib().qo_batch_env_step(C.byref(consts), C.c_int(n), states, ct.ctypes.data_as(C.c_void_p),
+                            actions.ctypes.data_as(C.c_void_p), obs.ctypes.data_as(C.c_void_p),
+                            reward.ctypes.data_as(C.c_void_p), done.ctypes.data_as(C.c_void_p),
+                            failed.ctypes.data_as(C.c_void_p))
+    return obs, reward, done, failed
+
+
+def observe(consts, states):
+    n = len(states)
+    obs = np.zeros((n, 16), np.float32)
+    L = lib()
+    for e in range(n):
+        L.qo_observe(C.byref(consts), C.byref(states[e]), obs[e].ctypes.data_as(C.c_void_p))
+    return obs
+
+
+def inv3(A):
+    A = np.ascontiguousarray(A, np.float32).reshape(9)
+    out = np.zeros(9, np.float32)
+    lib().qo_inv3_f32(A.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p))
+    return out.reshape(3, 3)

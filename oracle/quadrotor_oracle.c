@@ -1,0 +1,370 @@
+/*
+ * oracle/quadrotor_oracle.c — CPU restatement of the reference Quadrotor hot path.
+ *
+ * TEST INFRASTRUCTURE. This file is the *checker*, never the product: only tests/,
+ * __graft_entry__.smoke() and bench.py's cpu_baseline leg may load the library built from it.
+ * metagym_amd/ never imports, links or falls back to it.
+ *
+ * What it restates (reference paths relative to /root/reference/metagym/quadrotor):
+ *   qo_substep()  <- QuadrotorSim._run_internal      quadrotorsim.py:122-210
+ *   qo_failed()   <- QuadrotorSim._check_failure     quadrotorsim.py:212-221
+ *   qo_sim_step() <- QuadrotorSim.step               quadrotorsim.py:295-304
+ *   qo_observe()  <- get_sensor/get_state/_get_pitch_roll_yaw + _convert_state_to_ndarray
+ *                                                    quadrotorsim.py:111-120,260-293; env.py:193-209
+ *   qo_env_step() <- Quadrotor.step (hovering_control / no_collision)   env.py:127-165
+ *                    with _check_collision env.py:248-260 and _get_reward env.py:211-246
+ *
+ * Pinning: tests/test_oracle_quadrotor.py checks this file against tests/golden/quadrotor_*.npz,
+ * which oracle/gen_golden.py produced by running the unmodified reference in the build container
+ * (python 3.10, numpy 2.2.6).
+ *
+ * Precision choreography. The reference mixes float32 arrays with python floats and float64
+ * arrays; under NumPy-2 promotion (NEP 50) a python float is "weak" (adopts the other operand's
+ * dtype) while numpy scalars/arrays are strong. Every expression below is annotated with the dtype
+ * NumPy evaluates it in. State dtypes after reset(): position f32, velocity f64, body rate f64,
+ * propeller speed f32, rotation matrix f32 (quadrotorsim.py:20-28,239-258).
+ * Compile with -ffp-contract=off: NumPy's elementwise ops never fuse a*b+c.
+ * The two places that cannot be restated bit-for-bit are BLAS/LAPACK internals (np.matmul ->
+ * OpenBLAS gemv/gemm summation order, np.linalg.inv -> sgesv) and libm's atan2f; they sit at the
+ * 1-ulp level and are covered by the 1e-5 relative tolerance the north star states.
+ */
+#include <math.h>
+#include <stdint.h>
+#include <string.h>
+
+#include "quadrotor_oracle.h"
+
+/* ---- small helpers, all without fused multiply-add -------------------------------------- */
+
+static void mat3_vec_f32f64(const float *M, const double *x, double *y) {
+    /* np.matmul(f32[3,3], f64[3]) -> f64: M is widened, plain dot, k = 0,1,2 */
+    for (int r = 0; r < 3; ++r)
+        y[r] = ((double)M[3 * r + 0] * x[0] + (double)M[3 * r + 1] * x[1]) + (double)M[3 * r + 2] * x[2];
+}
+
+static void mat3_vec_f32(const float *M, const float *x, float *y) {
+    for (int r = 0; r < 3; ++r)
+        y[r] = (M[3 * r + 0] * x[0] + M[3 * r + 1] * x[1]) + M[3 * r + 2] * x[2];
+}
+
+static void mat3_mul_f32(const float *A, const float *B, float *C) {
+    for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 3; ++c)
+            C[3 * r + c] = (A[3 * r + 0] * B[0 + c] + A[3 * r + 1] * B[3 + c]) + A[3 * r + 2] * B[6 + c];
+}
+
+static void cross_f32(const float *a, const float *b, float *c) {
+    /* numpy.cross for 3-vectors: each product rounded, then subtracted */
+    float t0 = a[1] * b[2], t1 = a[2] * b[1];
+    float t2 = a[2] * b[0], t3 = a[0] * b[2];
+    float t4 = a[0] * b[1], t5 = a[1] * b[0];
+    c[0] = t0 - t1;
+    c[1] = t2 - t3;
+    c[2] = t4 - t5;
+}
+
+static double norm3_f64(const double *x) { return sqrt((x[0] * x[0] + x[1] * x[1]) + x[2] * x[2]); }
+static float norm3_f32(const float *x) { return sqrtf((x[0] * x[0] + x[1] * x[1]) + x[2] * x[2]); }
+
+/* General 3x3 float32 inverse, restating what np.linalg.inv does (LAPACK sgesv = LU with partial
+ * pivoting, then solve against the identity), quadrotorsim.py:207. */
+void qo_inv3_f32(const float *A, float *Ainv) {
+    float lu[9];
+    int piv[3] = {0, 1, 2};
+    memcpy(lu, A, sizeof(lu));
+    for (int k = 0; k < 3; ++k) {
+        int p = k;
+        float best = fabsf(lu[3 * k + k]);
+        for (int r = k + 1; r < 3; ++r)
+            if (fabsf(lu[3 * r + k]) > best) { best = fabsf(lu[3 * r + k]); p = r; }
+        if (p != k) {
+            for (int c = 0; c < 3; ++c) { float t = lu[3 * k + c]; lu[3 * k + c] = lu[3 * p + c]; lu[3 * p + c] = t; }
+            int t = piv[k]; piv[k] = piv[p]; piv[p] = t;
+        }
+        float rcp = 1.0f / lu[3 * k + k];       /* sgetf2 scales the column by the reciprocal */
+        for (int r = k + 1; r < 3; ++r) {
+            lu[3 * r + k] = lu[3 * r + k] * rcp;
+            for (int c = k + 1; c < 3; ++c) lu[3 * r + c] = lu[3 * r + c] - lu[3 * r + k] * lu[3 * k + c];
+        }
+    }
+    for (int col = 0; col < 3; ++col) {
+        float y[3];
+        for (int r = 0; r < 3; ++r) y[r] = (piv[r] == col) ? 1.0f : 0.0f;
+        /* forward: L y' = y (unit lower) */
+        for (int r = 1; r < 3; ++r)
+            for (int k = 0; k < r; ++k) y[r] = y[r] - lu[3 * r + k] * y[k];
+        /* backward: U x = y' */
+        for (int r = 2; r >= 0; --r) {
+            for (int k = r + 1; k < 3; ++k) y[r] = y[r] - lu[3 * r + k] * y[k];
+            y[r] = y[r] / lu[3 * r + r];
+        }
+        for (int r = 0; r < 3; ++r) Ainv[3 * r + col] = y[r];
+    }
+}
+
+/* ---- constants -------------------------------------------------------------------------- */
+
+void qo_default_consts(qo_consts *c) {
+    /* metagym/quadrotor/config.json:1-59 as parsed by _parse_cfg quadrotorsim.py:50-109 */
+    memset(c, 0, sizeof(*c));
+    c->precision = 0.001;
+    c->quality = 0.5;
+    float inertia[9] = {0.0135f, 0, 0, 0, 0.0135f, 0, 0, 0, 0.024f};
+    qo_inv3_f32(inertia, c->inertia_inv);
+    c->drag_m[0] = 0.074f; c->drag_m[4] = 0.074f; c->drag_m[8] = 0.0506f;
+    c->drag_f[0] = 0.12f;  c->drag_f[4] = 0.12f;  c->drag_f[8] = 0.10f;
+    c->ct0 = 1.538e-5; c->ct1 = -2.5e-4; c->ct2 = 0.0;
+    c->mm = 0.010; c->jm = 2.573e-4; c->ra = 0.2010; c->phi = 0.017242179827506;
+    const float pc[12] = {0.18f, 0.18f, 0, -0.18f, 0.18f, 0, -0.18f, -0.18f, 0, 0.18f, -0.18f, 0};
+    memcpy(c->prop_coord, pc, sizeof(pc));
+    c->fail_velocity = 100.0; c->fail_w = 1000.0; c->fail_range = 1000.0;
+    c->min_voltage = 0.10; c->max_voltage = 15.0;
+    c->dt = 0.01; c->nt = 1000; c->healthy_reward = 1.0;
+    c->x_offset = 50; c->y_offset = 50; c->z_offset = 5.0;   /* env.py:104-114 default 100x100 map */
+    c->map = 0; c->map_h = 100; c->map_w = 100;
+    c->task = QO_TASK_HOVERING;
+}
+
+void qo_zero_state(qo_state *s) {
+    /* _zero_state quadrotorsim.py:20-28 */
+    memset(s, 0, sizeof(*s));
+    s->R[0] = s->R[4] = s->R[8] = 1.0f;
+    s->Rinv[0] = s->Rinv[4] = s->Rinv[8] = 1.0f;
+}
+
+void qo_refresh_inverse(qo_state *s) { qo_inv3_f32(s->R, s->Rinv); }
+
+/* ---- one 1 ms sub-step: quadrotorsim.py:122-210 ------------------------------------------ */
+
+int qo_failed(const qo_consts *c, const qo_state *s) {
+    /* quadrotorsim.py:212-221; norms in the array's own dtype */
+    if ((double)norm3_f32(s->pos) > c->fail_range) return 1;
+    if (norm3_f64(s->vel) > c->fail_velocity) return 2;
+    if (norm3_f64(s->omega) > c->fail_w) return 3;
+    return 0;
+}
+
+void qo_substep(const qo_consts *c, qo_state *s, const double act[4]) {
+    float prop_force_z = 0.0f;               /* prop_force[0], [1] stay 0 (:124,159) */
+    float prop_torque[3] = {0, 0, 0};
+    float prop_powers[4];
+    float me[4];
+
+    const float phi32 = (float)c->phi;                    /* python float -> weak -> f32 */
+    const float phi_over_ra32 = (float)(c->phi / c->ra);  /* python double division, then weak */
+    const float inv_jm32 = (float)(1.0 / c->jm);
+    const float mm32 = (float)c->mm;
+    const float prec32 = (float)c->precision;
+    const float ct0_32 = (float)c->ct0, ct1_32 = (float)c->ct1;
+
+    for (int i = 0; i < 4; ++i) {
+        double eff_act = act[i];                                           /* :130-134 */
+        if (eff_act > c->max_voltage) eff_act = c->max_voltage;
+        else if (eff_act < c->min_voltage) eff_act = c->min_voltage;
+        const float eff32 = (float)eff_act;
+
+        float phi_w = phi32 * s->propw[i];                                 /* :136 f32 */
+        me[i] = phi_over_ra32 * (eff32 - phi_w);                           /* :137-138 f32 */
+        prop_powers[i] = fabsf(me[i] / phi32 * eff32);                     /* :139 f32 */
+        float d_prop_w = inv_jm32 * (me[i] - mm32);                        /* :141-142 f32 */
+        float w_m = s->propw[i] + prec32 * d_prop_w;                       /* :144-145 f32 */
+        float l_m = norm3_f32(&c->prop_coord[3 * i]);                      /* :146 f32 */
+
+        double body_velocity[3];                                           /* :147-148 f64 */
+        mat3_vec_f32f64(s->Rinv, s->vel, body_velocity);
+        /* :149-150 np.cross(f64 omega, f32 coord)[2] * l_m -> f64 */
+        const float *pc = &c->prop_coord[3 * i];
+        double cz = s->omega[0] * (double)pc[1] - s->omega[1] * (double)pc[0];
+        double bw_to_v_z = cz * (double)l_m;
+        double v_1 = body_velocity[2] + bw_to_v_z;                         /* :151 */
+        double sign = v_1 > 0 ? 1.0 : -1.0;                                /* :152 */
+
+        /* :154-156: ct0*w*w is an f32 chain, ct1*w is f32 then widened, ct2 term all f64 */
+        float t0 = (ct0_32 * w_m) * w_m;
+        double t1 = (double)(ct1_32 * w_m) * v_1;
+        double t2 = ((c->ct2 * v_1) * v_1) * sign;
+        double thrust = ((double)t0 + t1) + t2;
+
+        s->propw[i] = w_m;                                                 /* :158 */
+        prop_force_z = (float)((double)prop_force_z + thrust);             /* :159 f64 add, f32 store */
+        float a[3] = {-0.0f, -0.0f, -(float)thrust};                       /* :160-162 */
+        float cr[3];
+        cross_f32(a, pc, cr);
+        prop_torque[0] += cr[0]; prop_torque[1] += cr[1]; prop_torque[2] += cr[2];
+    }
+    prop_torque[2] += ((-me[0] + me[1]) - me[2]) + me[3];                  /* :164 */
+
+    /* :166-170 f_drag = -||v|| * ((Df @ Rinv) @ v): f32 3x3 product, then f64 */
+    float DfRinv[9];
+    mat3_mul_f32(c->drag_f, s->Rinv, DfRinv);
+    double tmpv[3], f_drag[3], t_drag[3];
+    mat3_vec_f32f64(DfRinv, s->vel, tmpv);
+    double nv = -norm3_f64(s->vel);
+    for (int k = 0; k < 3; ++k) f_drag[k] = nv * tmpv[k];
+    /* :171-172 */
+    mat3_vec_f32f64(c->drag_m, s->omega, tmpv);
+    double nw = -norm3_f64(s->omega);
+    for (int k = 0; k < 3; ++k) t_drag[k] = nw * tmpv[k];
+
+    /* :174-178 gravity in the body frame, f32 */
+    const float gravity_acc[3] = {0.0f, 0.0f, -9.8f};
+    float f_grav[3], t_grav[3];
+    mat3_vec_f32(s->Rinv, gravity_acc, f_grav);
+    for (int k = 0; k < 3; ++k) f_grav[k] = f_grav[k] * (float)c->quality;
+    cross_f32(f_grav, c->gravity_center, t_grav);
+    for (int k = 0; k < 3; ++k) t_grav[k] = -t_grav[k];
+
+    /* :180-181 (f32 + f32) + f64 */
+    const float prop_force[3] = {0.0f, 0.0f, prop_force_z};
+    double f_all[3], t_all[3], body_acc[3], acc[3];
+    for (int k = 0; k < 3; ++k) {
+        f_all[k] = (double)(prop_force[k] + f_grav[k]) + f_drag[k];
+        t_all[k] = (double)(prop_torque[k] + t_grav[k]) + t_drag[k];
+        body_acc[k] = f_all[k] / c->quality;                               /* :183 */
+    }
+    mat3_vec_f32f64(s->R, body_acc, acc);                                  /* :184 */
+    const double half_dt2 = 0.5 * c->precision * c->precision;             /* python doubles */
+    for (int k = 0; k < 3; ++k) {
+        /* :185-186 f64 add, rounded into the f32 position array; uses the OLD velocity */
+        s->pos[k] = (float)((double)s->pos[k] + (s->vel[k] * c->precision + half_dt2 * acc[k]));
+    }
+    for (int k = 0; k < 3; ++k) s->vel[k] = s->vel[k] + c->precision * acc[k];   /* :187 */
+    /* :188 np.sum over 4 f32: add.reduce = a0 + (a1 + a2 + a3 accumulated left to right) */
+    s->power = ((prop_powers[0] + prop_powers[1]) + prop_powers[2]) + prop_powers[3];
+
+    double alpha[3], tmp_w[3];
+    mat3_vec_f32f64(c->inertia_inv, t_all, alpha);                         /* :190-191 */
+    const double half_dt = 0.5 * c->precision;
+    for (int k = 0; k < 3; ++k) tmp_w[k] = s->omega[k] + half_dt * alpha[k];
+    float S[9] = {0};                                                      /* :193-199 f32 */
+    S[1] = (float)(-tmp_w[2]); S[2] = (float)(tmp_w[1]);
+    S[3] = (float)(tmp_w[2]);  S[5] = (float)(-tmp_w[0]);
+    S[6] = (float)(-tmp_w[1]); S[7] = (float)(tmp_w[0]);
+    float RS[9];
+    mat3_mul_f32(s->R, S, RS);                                             /* :201-202 f32 */
+    for (int k = 0; k < 9; ++k) s->R[k] = s->R[k] + prec32 * RS[k];
+    for (int k = 0; k < 3; ++k) s->omega[k] = s->omega[k] + c->precision * alpha[k];  /* :203-204 */
+    qo_inv3_f32(s->R, s->Rinv);                                            /* :206-208 */
+}
+
+int qo_sim_step(const qo_consts *c, qo_state *s, const float act[4]) {
+    /* quadrotorsim.py:295-304; env.py:129,135 hands over f32 values widened to python floats */
+    double a[4] = {act[0], act[1], act[2], act[3]};
+    int times = (int)(c->dt / c->precision);
+    for (int t = 0; t < times; ++t) {
+        qo_substep(c, s, a);
+        int f = qo_failed(c, s);
+        if (f) return f;                     /* the reference raises here, state stays as is */
+    }
+    return 0;
+}
+
+/* ---- observation: quadrotorsim.py:260-293, :111-120; env.py:193-209 ---------------------- */
+
+void qo_observe(const qo_consts *c, const qo_state *s, float obs[16]) {
+    double b_v[3];
+    float b_pos[3], imu[3];
+    const float gravity_acc[3] = {0.0f, 0.0f, -9.8f};
+    mat3_vec_f32f64(s->Rinv, s->vel, b_v);        /* :261-262 f64 */
+    mat3_vec_f32(s->Rinv, s->pos, b_pos);         /* :263-264 f32 */
+    mat3_vec_f32(s->Rinv, gravity_acc, imu);      /* :277-278 body_acceleration is always 0 */
+    const float *R = s->R;
+    float roll = atan2f(R[7], R[8]);                                   /* :112-113 */
+    float pitch = atan2f(-R[6], sqrtf(R[7] * R[7] + R[8] * R[8]));     /* :114-117 */
+    float yaw = atan2f(R[3], R[0]);                                    /* :118-119 */
+    obs[0] = (float)b_v[0]; obs[1] = (float)b_v[1]; obs[2] = (float)b_v[2];
+    obs[3] = b_pos[0]; obs[4] = b_pos[1]; obs[5] = b_pos[2];
+    obs[6] = 0.0f + imu[0]; obs[7] = 0.0f + imu[1]; obs[8] = 0.0f + imu[2];
+    obs[9] = (float)s->omega[0]; obs[10] = (float)s->omega[1]; obs[11] = (float)s->omega[2];
+    obs[12] = pitch; obs[13] = roll; obs[14] = yaw;
+    obs[15] = s->pos[2] + (float)c->z_offset;     /* env.py:203-204 f32 + weak python float */
+}
+
+/* ---- collision: env.py:248-260 with python slice semantics ------------------------------- */
+
+static void py_slice(long a, long b, long len, long *lo, long *hi) {
+    /* normalise map[a:b] exactly like CPython (negative indices wrap once, then clamp) */
+    if (a < 0) { a += len; if (a < 0) a = 0; } else if (a > len) a = len;
+    if (b < 0) { b += len; if (b < 0) b = 0; } else if (b > len) b = len;
+    *lo = a; *hi = b;
+}
+
+static int collision(const qo_consts *c, const double old_pos[3], const double new_pos[3]) {
+    long mn[3], mx[3];
+    for (int i = 0; i < 3; ++i) {
+        double lo = old_pos[i] < new_pos[i] ? old_pos[i] : new_pos[i];  /* min(x[i], y[i]) */
+        double hi = old_pos[i] > new_pos[i] ? old_pos[i] : new_pos[i];
+        /* python min/max return the first argument on ties; values equal either way */
+        mn[i] = (long)floor(lo);
+        mx[i] = (long)ceil(hi);
+    }
+    int any = 0;
+    if (c->map) {
+        long y0, y1, x0, x1;
+        py_slice(mn[1], mx[1] + 1, c->map_h, &y0, &y1);
+        py_slice(mn[0], mx[0] + 1, c->map_w, &x0, &x1);
+        for (long y = y0; y < y1 && !any; ++y)
+            for (long x = x0; x < x1; ++x)
+                if (c->map[y * c->map_w + x] != 0) { any = 1; break; }
+    }
+    /* env.py:257 compares heights against the *bool* np.any(taken_pos) */
+    return (mn[2] < any) || (mx[2] < any);
+}
+
+/* ---- one env.step: env.py:127-165 -------------------------------------------------------- */
+
+int qo_env_step(const qo_consts *c, qo_state *s, int *ct, const float act[4],
+                float obs[16], double *reward, int *done) {
+    *ct += 1;                                                           /* :128 */
+    /* :131-133 f32 + np.int64 offset -> f64 for x,y; f32 + python float -> f32 for z */
+    double old_pos[3] = {(double)s->pos[0] + (double)c->x_offset, (double)s->pos[1] + (double)c->y_offset,
+                         (double)(s->pos[2] + (float)c->z_offset)};
+    int failed = qo_sim_step(c, s, act);                                /* :135 */
+    qo_observe(c, s, obs);                                              /* :136-138 */
+    if (failed) {               /* reference raises out of step(); batched engine reports a flag */
+        *reward = 0.0;
+        *done = 1;
+        *ct = 0;
+        return failed;
+    }
+    double new_pos[3] = {(double)s->pos[0] + (double)c->x_offset, (double)s->pos[1] + (double)c->y_offset,
+                         (double)(s->pos[2] + (float)c->z_offset)};
+    int is_collision = collision(c, old_pos, new_pos);                  /* :145 */
+
+    /* _get_reward env.py:211-246 */
+    float energy = (float)c->dt * s->power;                  /* python float * np.float32 -> f32 */
+    double r;
+    if ((double)energy < c->healthy_reward) r = -(double)energy;  /* min() keeps the f32 value */
+    else r = -c->healthy_reward;
+    double task_reward = is_collision ? 0.0 : c->healthy_reward;
+    if (c->task == QO_TASK_HOVERING) {
+        double velocity_norm = norm3_f64(s->vel);
+        double angular_velocity_norm = norm3_f64(s->omega);
+        task_reward -= 1.0 * velocity_norm + 1.0 * angular_velocity_norm;
+        float z_move = fabsf(s->pos0_z - s->pos[2]);         /* pos_0[2] - state['z'], f32 */
+        if (z_move < 0.5f) task_reward += 10;
+        else {
+            float o = 0.5f - z_move;                          /* weak 0.5 - f32 -> f32 */
+            task_reward += (-20.0 > (double)o) ? -20.0 : (double)o;   /* max(-20, o) */
+        }
+    }
+    r += task_reward;
+    *reward = r;
+
+    int reset = 0;
+    if (is_collision) { reset = 1; *ct = 0; }                           /* :147-149 */
+    if (*ct == c->nt) { reset = 1; *ct = 0; }                           /* :159-161 */
+    *done = reset;
+    return 0;
+}
+
+/* ---- batch drivers used by the tests and by bench.py's cpu_baseline leg ------------------ */
+
+void qo_batch_env_step(const qo_consts *c, int n, qo_state *states, int *ct, const float *actions,
+                       float *obs, double *reward, int *done, int *failed) {
+    for (int e = 0; e < n; ++e)
+        failed[e] = qo_env_step(c, &states[e], &ct[e], &actions[4 * e], &obs[16 * e], &reward[e], &done[e]);
+}
+
+size_t qo_sizeof_state(void) { return sizeof(qo_state); }
+size_t qo_sizeof_consts(void) { return sizeof(qo_consts); }

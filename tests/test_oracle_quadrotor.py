@@ -1,0 +1,95 @@
+"""Pin oracle/quadrotor_oracle.c against the golden vectors produced by the unmodified reference
+(oracle/gen_golden.py -> tests/golden/quadrotor_*.npz). CPU-only."""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+from oracle import quadrotor as qo
+from parity import REL_TOL, obs_rel_err, scalar_rel_err, vec_rel_err
+
+
+def _rollout(g):
+    c = qo.default_consts(nt=int(g["nt"]))
+    st = qo.make_states(g["init_pos"][None], g["init_vel"][None], g["init_omega"][None],
+                        g["init_propw"][None], g["init_R"][None])
+    ct = np.zeros(1, np.int32)
+    T = len(g["reward"])
+    rec = {k: [] for k in ("pos", "vel", "omega", "propw", "R", "power", "obs", "reward", "done", "ct")}
+    for t in range(T):
+        obs, rew, done, failed = qo.batch_env_step(c, st, ct, g["actions"][t][None])
+        assert failed[0] == 0
+        s = qo.states_to_arrays(st)
+        for k in ("pos", "vel", "omega", "propw", "R", "power"):
+            rec[k].append(s[k][0])
+        rec["obs"].append(obs[0])
+        rec["reward"].append(rew[0])
+        rec["done"].append(bool(done[0]))
+        rec["ct"].append(int(ct[0]))
+    return {k: np.asarray(v) for k, v in rec.items()}, c, st
+
+
+@pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden",
+                                                                "quadrotor_traj_*.npz"))))
+def test_oracle_matches_reference_rollout(path):
+    g = np.load(path)
+    assert str(g["numpy_version"]).startswith("2."), "goldens must come from the NEP-50 numpy"
+    rec, c, _ = _rollout(g)
+    # reset observation
+    st0 = qo.make_states(g["init_pos"][None], g["init_vel"][None], g["init_omega"][None],
+                         g["init_propw"][None], g["init_R"][None])
+    assert obs_rel_err(qo.observe(c, st0), g["obs0"][None]) < REL_TOL
+    # integer/boolean outputs are exact
+    assert np.array_equal(rec["done"], g["done"])
+    assert np.array_equal(rec["ct"], g["ct"])
+    # floating-point trajectory: whole rollout (400-1000 env steps = 4-10k Euler sub-steps)
+    errs = dict(
+        pos=vec_rel_err(rec["pos"], g["pos"]), vel=vec_rel_err(rec["vel"], g["vel"]),
+        omega=vec_rel_err(rec["omega"], g["omega"]), propw=vec_rel_err(rec["propw"], g["propw"]),
+        R=vec_rel_err(rec["R"], g["R"]), obs=obs_rel_err(rec["obs"], g["obs"]),
+        reward=scalar_rel_err(rec["reward"], g["reward"]), power=scalar_rel_err(rec["power"], g["power"]))
+    print(os.path.basename(path), {k: "%.2e" % v for k, v in errs.items()})
+    for k, v in errs.items():
+        assert v < REL_TOL, (k, v)
+
+
+def test_oracle_matches_reference_single_steps():
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "quadrotor_onestep.npz"))
+    c = qo.default_consts()
+    st = qo.make_states(g["in_pos"], g["in_vel"], g["in_omega"], g["in_propw"], g["in_R"])
+    ct = np.zeros(len(st), np.int32)
+    obs, rew, done, failed = qo.batch_env_step(c, st, ct, g["actions"])
+    s = qo.states_to_arrays(st)
+    assert not failed.any()
+    assert np.array_equal(done.astype(bool), g["done"])
+    # pure-f32 recurrences with no BLAS/LAPACK in the loop are bit-exact
+    assert np.array_equal(s["propw"], g["out_propw"])
+    assert np.array_equal(s["power"], g["power"])
+    for k in ("pos", "vel", "omega", "R"):
+        assert vec_rel_err(s[k], g["out_" + k]) < 1e-6, k
+    assert obs_rel_err(obs, g["obs"]) < 1e-6
+    assert scalar_rel_err(rew, g["reward"]) < 1e-6
+
+
+def test_oracle_failure_flags():
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "quadrotor_fail.npz"))
+    c = qo.default_consts()
+    st = qo.make_states(g["in_pos"], g["in_vel"], g["in_omega"], g["in_propw"], g["in_R"])
+    ct = np.zeros(len(st), np.int32)
+    obs, rew, done, failed = qo.batch_env_step(c, st, ct, g["actions"])
+    assert np.array_equal(failed != 0, g["failed"])
+    # the state at the raise (sub-step applied, then frozen) matches the reference's
+    s = qo.states_to_arrays(st)
+    for k in ("pos", "vel", "omega", "propw", "R"):
+        assert vec_rel_err(s[k], g["out_" + k]) < REL_TOL, k
+    assert done[g["failed"]].all()
+
+
+def test_inverse_close_to_lapack():
+    rs = np.random.RandomState(0)
+    worst = 0.0
+    for _ in range(500):
+        A = (np.eye(3) + rs.uniform(-0.3, 0.3, (3, 3))).astype(np.float32)
+        worst = max(worst, vec_rel_err(qo.inv3(A).reshape(1, 9), np.linalg.inv(A).reshape(1, 9)))
+    assert worst < 5e-6, worst
