@@ -1,0 +1,184 @@
+#!/usr/bin/env python3
+"""bench.py — env-steps/sec of the batched Quadrotor hot path on N MI355X GPUs of one node.
+
+    python bench.py --gpus 1 --steps 200 --warmup 20
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 \
+           --master-port 29500 bench.py --gpus 8 --steps 200 --warmup 20
+
+Workload (BASELINE.json configs[1]): Quadrotor `hovering_control`, 65 536 parallel
+envs per GPU, default config.json physics, dt=0.01 (10 Euler sub-steps per env step), nt=1000, flat
+map; synthetic actions U(0.1, 15.0) f32 already resident in HBM; fused auto-reset so finished
+episodes restart inside the launch. A "step" = ONE call of env.step() = one launch of the HIP
+kernel over the whole batch. Envs shard across GPUs with no collective (weak scaling: 65 536
+envs per GPU); torch.distributed (RCCL) is used only for the timing barrier and the max-over-ranks.
+
+Prints ONE JSON line on rank 0.
+  value        whole-job env-steps/s = n_gpus * 65536 * steps / max-over-ranks wall time
+  roofline     algorithmic bytes per launch (317 B/env-step) / average kernel-launch
+               duration measured with HIP events on the launching stream, vs the 8 TB/s HBM peak
+  cpu_baseline the CPU oracle (a C port of the reference algorithm) on the host cores, bounded sample
+"""
+import argparse
+import json
+import os
+import sys
+import threading
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+ENVS_PER_GPU = 65536
+BYTES_PER_ENV_STEP = 317          # state R+W 2x116 + action 16 + obs 64 + reward 4 + done 1
+HBM_PEAK_GBS = 8000.0             # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+N_ACTION_BATCHES = 8
+
+
+def cpu_baseline(seconds=12.0, n_envs_per_thread=256):
+    """Time the CPU oracle (oracle/quadrotor_oracle.c, a scalar C port of the reference algorithm) on
+    the same workload: every host core steps its own block of envs (ctypes releases the GIL)."""
+    from oracle import quadrotor as qo
+    cores = os.cpu_count() or 1
+    c = qo.default_consts()
+    rs = np.random.RandomState(0)
+    blocks = []
+    for t in range(cores):
+        n = n_envs_per_thread
+        u = rs.random_sample((n, 4, 3))
+        vel = (2.0 * u[:, 1]) * ((u[:, 0] > 0.5) * 2 - 1.0)
+        om = (5.0 * u[:, 3]) * ((u[:, 2] > 0.5) * 2 - 1.0)
+        st = qo.make_states(np.zeros((n, 3), np.float32), vel, om, np.zeros((n, 4), np.float32),
+                            np.tile(np.eye(3, dtype=np.float32).reshape(9), (n, 1)))
+        acts = rs.uniform(0.1, 15.0, (N_ACTION_BATCHES, n, 4)).astype(np.float32)
+        blocks.append((st, np.zeros(n, np.int32), acts))
+    counts = [0] * cores
+    stop = time.perf_counter() + seconds
+
+    def work(i):
+        st, ct, acts = blocks[i]
+        k = 0
+        while time.perf_counter() < stop:
+            qo.batch_env_step(c, st, ct, acts[k % N_ACTION_BATCHES])
+            k += 1
+        counts[i] = k * len(st)
+
+    t0 = time.perf_counter()
+    threads = [threading.Thread(target=work, args=(i,)) for i in range(cores)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    el = time.perf_counter() - t0
+    total = sum(counts)
+    return {"value": total / el, "unit": "env-steps/s", "cores": cores, "kind": "port",
+            "sample": "%d env-steps of the same hovering_control workload (%d envs/thread, no auto-reset), "
+                      "%.1f s wall, C oracle -O2 scalar" % (total, n_envs_per_thread, el)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--envs-per-gpu", type=int, default=ENVS_PER_GPU)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit("--gpus %d needs torch.distributed.run with --nproc-per-node %d" % (args.gpus, args.gpus))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    import metagym_amd
+    n = args.envs_per_gpu
+    env = metagym_amd.make("quadrotor-v0", num_envs=n, device=dev, task="hovering_control",
+                           auto_reset=True, seed=1000 + rank)
+    env.reset(seed=1000 + rank)
+    g = torch.Generator(device=dev)
+    g.manual_seed(2000 + rank)
+    actions = torch.rand(N_ACTION_BATCHES, n, 4, device=dev, generator=g) * 14.9 + 0.1
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+
+    for i in range(args.warmup):
+        env.step(actions[i % N_ACTION_BATCHES])
+    barrier()
+    torch.cuda.synchronize(dev)
+    ev0 = torch.cuda.Event(enable_timing=True)
+    ev1 = torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record()                      # torch's current stream == the stream the kernels are launched on
+    for i in range(args.steps):
+        env.step(actions[i % N_ACTION_BATCHES])
+    ev1.record()
+    torch.cuda.synchronize(dev)
+    t1 = time.perf_counter()
+    barrier()
+    wall = t1 - t0
+    dev_ms = ev0.elapsed_time(ev1)
+
+    wall_max = wall
+    if dist is not None:
+        t = torch.tensor([wall], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        wall_max = float(t.item())
+
+    done_frac = float(env._done.float().mean().item())
+    failed_any = int(env._failed.max().item())
+    if rank == 0:
+        launch_s = dev_ms * 1e-3 / args.steps
+        achieved = BYTES_PER_ENV_STEP * n / launch_s / 1e9
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "quadrotor_pmc.json")
+        if os.path.exists(pmc):
+            try:
+                traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "env-steps/sec (whole node) at 2^16 parallel envs per GPU",
+            "value": world * n * args.steps / wall_max,
+            "unit": "env-steps/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": wall_max / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32/f64 mixed (reference choreography)",
+            "data": "synthetic",
+            "config": {"workload": "Quadrotor hovering_control, %d envs/GPU, dt=0.01 (10 Euler sub-steps), "
+                                   "nt=1000, flat map, actions U(0.1,15) f32, fused auto-reset" % n,
+                       "launch": "one mg_quadrotor_step_autoreset launch per env.step()",
+                       "envs_per_gpu": n, "sharding": "env-sharded, no collective"},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "kernel": "quadrotor_step_kernel", "avg_launch_us": launch_s * 1e6,
+                         "algorithmic_bytes_per_launch": BYTES_PER_ENV_STEP * n},
+            "sanity": {"done_frac_last_step": done_frac, "failed_max": failed_any,
+                       "host_wall_ms_per_step": wall / args.steps * 1e3},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,158 @@
+/*
+ * metagym_hip.h — C ABI of libmetagym_hip.so, the MI355X (gfx950) batched environment engine.
+ *
+ * The reference (PaddlePaddle/MetaGym) has no native layer and no FFI: every env is a Python
+ * object simulating ONE environment. This ABI is therefore new; each entry point names the
+ * reference Python method whose body it replaces for N environments at once. The host-side
+ * mirror of the reference's gym.Env classes lives in metagym_amd/ and calls these through ctypes;
+ * INTEGRATION.md shows the stub a maintainer of the reference would add.
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes. No torch / HIP types in any signature; `stream` is a
+ *     hipStream_t passed as void* (NULL = the null stream).
+ *   - Every `*_d` / state / io pointer is a DEVICE pointer into caller-owned memory (torch-ROCm
+ *     tensors in practice). The library allocates nothing persistent: state_dict()/checkpointing
+ *     is a tensor clone on the caller's side.
+ *   - All state is structure-of-arrays: component c of env e is at base[c * n_envs + e], so
+ *     lane e of a wavefront touches consecutive addresses (coalesced HBM access).
+ *   - Calls are asynchronous: kernels are enqueued on `stream` and the call returns without
+ *     synchronising. Re-entrant; no global mutable state except the thread-local error string.
+ *   - Return value: MG_OK (0) or a negative error code. hipError_t values are returned negated;
+ *     argument errors are in the -1000 range. Nothing throws or aborts across the ABI.
+ *   - Per-environment simulation failures (the reference `raise`s out of step()) are DATA, not
+ *     errors: they come back in the `failed` byte array.
+ */
+#ifndef METAGYM_HIP_H
+#define METAGYM_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MG_ABI_VERSION 1
+
+#define MG_OK 0
+#define MG_ERR_NULL_POINTER (-1001)
+#define MG_ERR_BAD_SIZE (-1002)
+#define MG_ERR_BAD_CONFIG (-1003)
+#define MG_ERR_UNSUPPORTED (-1004)
+
+/* ABI version of the loaded library (== MG_ABI_VERSION of the header it was built from). */
+int mg_abi_version(void);
+/* Human-readable description of the last error on the calling thread ("" if none). */
+const char *mg_last_error(void);
+/* Name of the device architecture the kernels were compiled for ("gfx950"). */
+const char *mg_target_arch(void);
+
+/* ========================================================================================
+ * Quadrotor — replaces metagym/quadrotor/quadrotorsim.py + env.py for N envs
+ * ======================================================================================== */
+
+enum { MG_QUADROTOR_TASK_NO_COLLISION = 0, MG_QUADROTOR_TASK_VELOCITY_CONTROL = 1,
+       MG_QUADROTOR_TASK_HOVERING_CONTROL = 2 };
+
+/* Physical + task constants: the parsed metagym/quadrotor/config.json (quadrotorsim.py:50-109,
+ * "python floats" stay doubles, float32 matrices stay float32) and the Quadrotor.__init__
+ * arguments (env.py:46-114). Uniform across envs; passed to the kernel by value (scalar regs). */
+typedef struct mg_quadrotor_config {
+    double precision;        /* cfg['precision']: Euler sub-step, s (0.001) */
+    double quality;          /* cfg['quality']: mass, kg (0.5) */
+    double ct0, ct1, ct2;    /* cfg['thrust']['CT'] */
+    double mm, jm, ra, phi;  /* cfg['thrust'] Mm, Jm, RA, phi */
+    double fail_velocity, fail_w, fail_range;   /* cfg['fail'] */
+    double min_voltage, max_voltage;            /* cfg['electric'] */
+    double dt;               /* env step, s (0.01); sub-steps per step = int(dt / precision) */
+    double healthy_reward;   /* env.py:53 */
+    double z_offset;         /* env.py:113 (5.0) */
+    int64_t x_offset, y_offset;  /* start cell of the map, env.py:109-112 */
+    int32_t nt;              /* episode length, env.py:48 */
+    int32_t task;            /* MG_QUADROTOR_TASK_* */
+    float inertia[9];        /* row-major cfg['inertia'] (inverted in float32 by the library) */
+    float drag_m[9];         /* diag(cfg['drag'] m_xx, m_yy, m_zz) */
+    float drag_f[9];         /* diag(cfg['drag'] f_xx, f_yy, f_zz) */
+    float gravity_center[3];
+    float prop_coord[12];    /* 4 propellers x (x, y, z) */
+    const int32_t *map_d;    /* DEVICE int32[map_h][map_w] obstacle map, or NULL = flat floor */
+    int32_t map_h, map_w;
+} mg_quadrotor_config;
+
+/* Per-env simulator state (QuadrotorSim._zero_state quadrotorsim.py:20-28 + Quadrotor.ct env.py:66),
+ * in the dtypes the reference holds after reset(): position f32, velocity f64, body rate f64,
+ * propeller speed f32, rotation matrix f32. 116 bytes per env. The body<-world matrix
+ * (`_coordination_converter_to_body`) is not state: it is inv(R) and is recomputed on load. */
+typedef struct mg_quadrotor_state {
+    float *pos;      /* [3][n] global_position */
+    double *vel;     /* [3][n] global_velocity */
+    double *omega;   /* [3][n] body_angular_velocity */
+    float *propw;    /* [4][n] propeller_angular_velocity */
+    float *rot;      /* [9][n] rotation_matrix, row-major index */
+    int32_t *ct;     /* [n]    Quadrotor.ct step counter */
+} mg_quadrotor_state;
+
+/* Fill `cfg` with the values of the reference's default config.json + default constructor args
+ * (task hovering_control is NOT the reference default; set cfg->task yourself). */
+int mg_quadrotor_default_config(mg_quadrotor_config *cfg);
+
+/* Quadrotor.reset() env.py:116-125 + QuadrotorSim.reset() quadrotorsim.py:239-258 for every env
+ * with mask[e] != 0 (mask == NULL: all). State is zeroed, then
+ *   velocity  <- init_vel[c][e]   (f64 [3][n]; NULL: zeros)
+ *   body rate <- init_omega[c][e] (f64 [3][n]; NULL: zeros)
+ * The reference draws that noise from numpy's *global* RNG; the caller supplies it (the Python
+ * layer reproduces the reference's draw order). ct is NOT cleared (env.py:116-125 does not).
+ * obs (f32 [n][16], may be NULL) receives the reset observation for the selected envs. */
+int mg_quadrotor_reset(const mg_quadrotor_config *cfg, int32_t n_envs, const mg_quadrotor_state *state,
+                       const uint8_t *mask, const double *init_vel, const double *init_omega,
+                       float *obs, void *stream);
+
+/* Quadrotor.step(action) env.py:127-165 for all n envs: int(dt/precision) Euler sub-steps of
+ * QuadrotorSim._run_internal (quadrotorsim.py:122-210) with the failure check after each one,
+ * then sensors/state (quadrotorsim.py:260-293), collision (env.py:248-260), reward (env.py:211-246)
+ * and the done rule (env.py:144-161).
+ *   action   f32 [n][4]  motor voltages (clamped to [min_voltage, max_voltage] like the reference)
+ *   obs      f32 [n][16] env.py:193-209 key order
+ *   reward   f32 [n]     (may be NULL)
+ *   reward64 f64 [n]     the reference returns a python float; optional exact copy (may be NULL)
+ *   done     u8  [n]
+ *   failed   u8  [n]     0 = ok; 1/2/3 = position / velocity / body-rate limit exceeded
+ *                        (quadrotorsim.py:212-221). A failed env freezes at the failing sub-step,
+ *                        reports done=1, reward=0 and must be reset. (may be NULL)
+ * Only tasks NO_COLLISION and HOVERING_CONTROL are implemented (MG_ERR_UNSUPPORTED otherwise). */
+int mg_quadrotor_step(const mg_quadrotor_config *cfg, int32_t n_envs, const mg_quadrotor_state *state,
+                      const float *action, float *obs, float *reward, double *reward64,
+                      uint8_t *done, uint8_t *failed, void *stream);
+
+/* n_steps consecutive env steps in ONE launch (state stays in registers between steps).
+ *   action f32 [n_steps][n][4]; obs f32 [n_steps][n][16]; reward/done/failed [n_steps][n].
+ * Semantically identical to calling mg_quadrotor_step n_steps times without resets in between
+ * (the reference's own tests step on after done, tests/test_env.py). */
+int mg_quadrotor_rollout(const mg_quadrotor_config *cfg, int32_t n_envs, int32_t n_steps,
+                         const mg_quadrotor_state *state, const float *action, float *obs,
+                         float *reward, double *reward64, uint8_t *done, uint8_t *failed, void *stream);
+
+/* Fused episode management (NOT in the reference, where the user calls env.reset() after done):
+ * like mg_quadrotor_rollout, but an env whose step ended with done=1 is reset inside the same
+ * launch (QuadrotorSim.reset quadrotorsim.py:239-258: zero state + init noise) and the returned
+ * observation row is the first observation of its next episode; reward/done/failed still describe
+ * the step that ended. The noise is drawn on the device from Philox4x32-10 keyed by `seed` with
+ * counter (env index, step_index + t), so results are independent of how envs are sharded. */
+typedef struct mg_quadrotor_autoreset {
+    float init_velocity[3];            /* cfg['init_velocity'] x, y, z */
+    float init_angular_velocity[3];    /* cfg['init_angular_velocity'] x, y, z */
+    double init_velocity_noisy;        /* cfg['init_velocity']['noisy'] (2.0) */
+    double init_angular_velocity_noisy;/* cfg['init_angular_velocity']['noisy'] (5.0) */
+    uint64_t seed;
+    uint64_t step_index;               /* global index of the first step of this call */
+} mg_quadrotor_autoreset;
+
+int mg_quadrotor_step_autoreset(const mg_quadrotor_config *cfg, int32_t n_envs, int32_t n_steps,
+                                const mg_quadrotor_state *state, const mg_quadrotor_autoreset *ar,
+                                const float *action, float *obs, float *reward, double *reward64,
+                                uint8_t *done, uint8_t *failed, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* METAGYM_HIP_H */

@@ -1,0 +1,118 @@
+"""ctypes binding of libmetagym_hip.so (see include/metagym_hip.h).
+
+The HIP library IS the product: there is no CPU or PyTorch fallback. If the shared object is
+missing and cannot be built with hipcc, importing an environment raises.
+"""
+import ctypes as C
+import os
+
+from . import build as _build
+
+ABI_VERSION = 1
+
+MG_OK = 0
+
+
+class MetaGymHipError(RuntimeError):
+    pass
+
+
+class QuadrotorConfig(C.Structure):
+    """mg_quadrotor_config"""
+    _fields_ = [
+        ("precision", C.c_double), ("quality", C.c_double),
+        ("ct0", C.c_double), ("ct1", C.c_double), ("ct2", C.c_double),
+        ("mm", C.c_double), ("jm", C.c_double), ("ra", C.c_double), ("phi", C.c_double),
+        ("fail_velocity", C.c_double), ("fail_w", C.c_double), ("fail_range", C.c_double),
+        ("min_voltage", C.c_double), ("max_voltage", C.c_double),
+        ("dt", C.c_double), ("healthy_reward", C.c_double), ("z_offset", C.c_double),
+        ("x_offset", C.c_int64), ("y_offset", C.c_int64),
+        ("nt", C.c_int32), ("task", C.c_int32),
+        ("inertia", C.c_float * 9), ("drag_m", C.c_float * 9), ("drag_f", C.c_float * 9),
+        ("gravity_center", C.c_float * 3), ("prop_coord", C.c_float * 12),
+        ("map_d", C.c_void_p), ("map_h", C.c_int32), ("map_w", C.c_int32),
+    ]
+
+
+class QuadrotorState(C.Structure):
+    """mg_quadrotor_state (device pointers)"""
+    _fields_ = [("pos", C.c_void_p), ("vel", C.c_void_p), ("omega", C.c_void_p),
+                ("propw", C.c_void_p), ("rot", C.c_void_p), ("ct", C.c_void_p)]
+
+
+class QuadrotorAutoReset(C.Structure):
+    """mg_quadrotor_autoreset"""
+    _fields_ = [("init_velocity", C.c_float * 3), ("init_angular_velocity", C.c_float * 3),
+                ("init_velocity_noisy", C.c_double), ("init_angular_velocity_noisy", C.c_double),
+                ("seed", C.c_uint64), ("step_index", C.c_uint64)]
+
+
+# symbol -> (restype, argtypes); tests/test_abi.py checks this list against include/metagym_hip.h
+_P = C.c_void_p
+SIGNATURES = {
+    "mg_abi_version": (C.c_int, []),
+    "mg_last_error": (C.c_char_p, []),
+    "mg_target_arch": (C.c_char_p, []),
+    "mg_quadrotor_default_config": (C.c_int, [C.POINTER(QuadrotorConfig)]),
+    "mg_quadrotor_reset": (C.c_int, [C.POINTER(QuadrotorConfig), C.c_int32, C.POINTER(QuadrotorState),
+                                     _P, _P, _P, _P, _P]),
+    "mg_quadrotor_step": (C.c_int, [C.POINTER(QuadrotorConfig), C.c_int32, C.POINTER(QuadrotorState),
+                                    _P, _P, _P, _P, _P, _P, _P]),
+    "mg_quadrotor_step_autoreset": (C.c_int, [C.POINTER(QuadrotorConfig), C.c_int32, C.c_int32,
+                                              C.POINTER(QuadrotorState), C.POINTER(QuadrotorAutoReset),
+                                              _P, _P, _P, _P, _P, _P, _P]),
+    "mg_quadrotor_rollout": (C.c_int, [C.POINTER(QuadrotorConfig), C.c_int32, C.c_int32,
+                                       C.POINTER(QuadrotorState), _P, _P, _P, _P, _P, _P, _P]),
+}
+
+_lib = None
+
+
+def lib_path():
+    return os.environ.get("METAGYM_HIP_LIB", _build.LIB_PATH)
+
+
+def load():
+    """Load (building first if the in-tree .so is missing or stale and hipcc exists)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = lib_path()
+    if "METAGYM_HIP_LIB" not in os.environ and _build.is_stale():
+        if os.path.exists(_build.HIPCC):
+            _build.build(verbose=False)
+        elif not os.path.exists(path):
+            raise MetaGymHipError(
+                "libmetagym_hip.so is not built and hipcc (%s) is not available. Run "
+                "`python -m metagym_amd.build` on a ROCm machine. There is no CPU fallback." % _build.HIPCC)
+    try:
+        lib = C.CDLL(path)
+    except OSError as e:
+        raise MetaGymHipError("cannot load %s: %s (no CPU fallback exists)" % (path, e)) from e
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is missing: fail loudly
+        fn.restype = res
+        fn.argtypes = args
+    if lib.mg_abi_version() != ABI_VERSION:
+        raise MetaGymHipError("ABI mismatch: library %d, binding %d" % (lib.mg_abi_version(), ABI_VERSION))
+    _lib = lib
+    return lib
+
+
+def check(rc, what):
+    if rc != MG_OK:
+        msg = load().mg_last_error().decode("utf-8", "replace")
+        raise MetaGymHipError("%s failed (%d): %s" % (what, rc, msg))
+
+
+def ptr(t):
+    """Device pointer of a torch tensor (None -> NULL). The tensor must be contiguous."""
+    if t is None:
+        return None
+    assert t.is_contiguous(), "tensor handed to the C ABI must be contiguous"
+    return C.c_void_p(t.data_ptr())
+
+
+def current_stream(device):
+    import torch
+    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)

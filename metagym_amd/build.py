@@ -1,0 +1,54 @@
+"""Build recipe for libmetagym_hip.so (hipcc, gfx950 only, in-tree).
+
+    python -m metagym_amd.build [--force]
+
+The library is compiled into metagym_amd/lib/ so it travels with the source tree to the GPU box
+(it is git-ignored, not gpurun-ignored). hipcc cross-compiles gfx950 without a GPU present.
+"""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB_DIR = os.path.join(HERE, "lib")
+LIB_PATH = os.path.join(LIB_DIR, "libmetagym_hip.so")
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+
+# -ffp-contract=off: the reference is NumPy, which never fuses a*b+c; parity (bit-exact against the
+# CPU oracle for everything but libm calls) depends on the kernels not fusing either.
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
+         "-fno-fast-math", "-Wall", "-Wno-unused-function"]
+
+
+def sources():
+    return sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hip"))
+
+
+def _deps():
+    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)]
+    deps.append(os.path.join(os.path.dirname(HERE), "include", "metagym_hip.h"))
+    deps.append(os.path.abspath(__file__))
+    return deps
+
+
+def is_stale():
+    if not os.path.exists(LIB_PATH):
+        return True
+    t = os.path.getmtime(LIB_PATH)
+    return any(os.path.getmtime(d) > t for d in _deps())
+
+
+def build(force=False, verbose=True):
+    if not force and not is_stale():
+        return LIB_PATH
+    os.makedirs(LIB_DIR, exist_ok=True)
+    cmd = [HIPCC] + FLAGS + sources() + ["-o", LIB_PATH]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.check_call(cmd)
+    return LIB_PATH
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv)

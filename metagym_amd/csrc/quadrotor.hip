@@ -1,0 +1,735 @@
+// quadrotor.hip — batched Quadrotor engine for gfx950: one lane per environment.
+//
+// Replaces, for N environments per launch, the reference's per-object Python hot path
+//   QuadrotorSim._run_internal   metagym/quadrotor/quadrotorsim.py:122-210  (substep())
+//   QuadrotorSim._check_failure  quadrotorsim.py:212-221                    (fail test in substep loop)
+//   QuadrotorSim.step            quadrotorsim.py:295-304                    (sub-step loop)
+//   get_sensor / get_state / _get_pitch_roll_yaw  quadrotorsim.py:111-120,260-293  (observe())
+//   Quadrotor.step / _get_reward / _check_collision  env.py:127-165,211-260 (finish_step())
+//   Quadrotor.reset / QuadrotorSim.reset  env.py:116-125, quadrotorsim.py:239-258 (reset kernel)
+//
+// Design (MI355X): the state of one env is 116 B of SoA (pos f32x3, vel f64x3, omega f64x3,
+// propw f32x4, R f32x9, ct i32). A lane loads its env's state with 23 coalesced loads (lane e reads
+// base[c*N + e]), runs all int(dt/precision)=10 Euler sub-steps in registers, and writes state,
+// obs, reward and done back once. The 16-float observation row is transposed through LDS so the
+// wave stores 4 KiB contiguous as dwordx4. No MFMA: the work is ~4 kflop of small-vector f32/f64
+// algebra per env-step with no contraction dimension to tile.
+//
+// Precision: the reference mixes f32 arrays, f64 arrays and python floats; the dtype NumPy (NEP 50)
+// evaluates each expression in is mirrored exactly (see oracle/quadrotor_oracle.c for the annotated
+// restatement this kernel is tested against). The translation unit is compiled with
+// -ffp-contract=off so no a*b+c is fused — NumPy never fuses — which makes this kernel bit-identical
+// to the CPU oracle for everything except atan2f (OCML vs glibc, <= 2 ulp).
+#include "mg_common.h"
+
+namespace {
+
+constexpr int BLOCK = 256;
+constexpr int WAVES_PER_BLOCK = BLOCK / mg::WAVE;
+constexpr int OBS_DIM = 16;
+
+// Derived constants: everything the reference computes from python floats before touching an
+// array is folded on the host, in the same double arithmetic, then "weak"-cast where NumPy would.
+struct QuadK {
+    // weak python floats that meet f32 operands first (quadrotorsim.py:136-145,154-156)
+    float phi32, phi_over_ra32, inv_jm32, mm32, prec32, ct0_32, ct1_32;
+    float quality32, dt32, zoff32, healthy32, fail_range32;
+    float lm[4];        // ||prop_coord[i]||, quadrotorsim.py:146
+    float pc[12];       // prop_coord
+    float iinv[9];      // inverse inertia (f32), quadrotorsim.py:64
+    float df[9], dm[9]; // drag matrices
+    float cog[3];
+    // doubles used against f64 operands
+    double prec, half_dt2, half_dt, ct2, quality, inv_quality;
+    double min_v, max_v, fail_velocity, fail_w, healthy, xoff, yoff;
+    int quality_recip_exact;  // 1/quality is a power of two -> x / quality == x * inv_quality bit-for-bit
+    int times, nt, task;
+    // fused auto-reset (not in the reference: replaces the user's `if done: env.reset()` round trip)
+    int auto_reset;
+    float init_v_base[3], init_w_base[3];   // cfg['init_velocity'] / ['init_angular_velocity'] x,y,z (f32 arrays)
+    double init_v_noisy, init_w_noisy;      // ... ['noisy']
+    uint64_t seed, step_index;
+    const int32_t *map;
+    int map_h, map_w;
+};
+
+struct Lane {       // one environment, in registers
+    float p[3];
+    double v[3];
+    double w[3];
+    float pw[4];
+    float R[9];
+    float Ri[9];    // inv(R): _coordination_converter_to_body
+    double nv, nw;  // ||v||, ||w|| of the current state (shared by drag and the failure test)
+    float power;
+};
+
+// ---- f32 / f64 3x3 helpers; summation order ((a0*b0 + a1*b1) + a2*b2), no FMA -------------------
+
+__device__ __forceinline__ void mv_f32f64(const float *M, const double *x, double *y) {
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+        y[r] = ((double)M[3 * r] * x[0] + (double)M[3 * r + 1] * x[1]) + (double)M[3 * r + 2] * x[2];
+}
+
+__device__ __forceinline__ void mv_f32(const float *M, const float *x, float *y) {
+#pragma unroll
+    for (int r = 0; r < 3; ++r) y[r] = (M[3 * r] * x[0] + M[3 * r + 1] * x[1]) + M[3 * r + 2] * x[2];
+}
+
+__device__ __forceinline__ void mm_f32(const float *A, const float *B, float *C) {
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+            C[3 * r + c] = (A[3 * r] * B[c] + A[3 * r + 1] * B[3 + c]) + A[3 * r + 2] * B[6 + c];
+}
+
+__device__ __forceinline__ void cross_f32(const float *a, const float *b, float *c) {
+    // numpy.cross: every product rounded, then subtracted
+    float t0 = a[1] * b[2], t1 = a[2] * b[1];
+    float t2 = a[2] * b[0], t3 = a[0] * b[2];
+    float t4 = a[0] * b[1], t5 = a[1] * b[0];
+    c[0] = t0 - t1;
+    c[1] = t2 - t3;
+    c[2] = t4 - t5;
+}
+
+__device__ __forceinline__ double norm3(const double *x) {
+    return sqrt((x[0] * x[0] + x[1] * x[1]) + x[2] * x[2]);
+}
+__device__ __forceinline__ float norm3(const float *x) {
+    return sqrtf((x[0] * x[0] + x[1] * x[1]) + x[2] * x[2]);
+}
+
+// General f32 inverse by LU with partial pivoting + solve against I (np.linalg.inv -> sgesv,
+// quadrotorsim.py:207). Branch-free: row swaps are selects, every index is static after unrolling,
+// so the nine entries live in VGPRs. R drifts away from orthonormal (first-order update, never
+// re-normalised), so R^T is NOT a substitute.
+__device__ __forceinline__ void inv3(const float *A, float *Ainv) {
+    float lu[3][3];
+    int piv[3] = {0, 1, 2};
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) lu[r][c] = A[3 * r + c];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        int p = k;
+        float best = fabsf(lu[k][k]);
+#pragma unroll
+        for (int r = k + 1; r < 3; ++r) {
+            float v = fabsf(lu[r][k]);
+            bool g = v > best;
+            best = g ? v : best;
+            p = g ? r : p;
+        }
+#pragma unroll
+        for (int r = k + 1; r < 3; ++r) {
+            bool sw = (p == r);
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                float a = lu[k][c], b = lu[r][c];
+                lu[k][c] = sw ? b : a;
+                lu[r][c] = sw ? a : b;
+            }
+            int pa = piv[k], pb = piv[r];
+            piv[k] = sw ? pb : pa;
+            piv[r] = sw ? pa : pb;
+        }
+        float rcp = 1.0f / lu[k][k];
+#pragma unroll
+        for (int r = k + 1; r < 3; ++r) {
+            lu[r][k] = lu[r][k] * rcp;
+#pragma unroll
+            for (int c = k + 1; c < 3; ++c) lu[r][c] = lu[r][c] - lu[r][k] * lu[k][c];
+        }
+    }
+#pragma unroll
+    for (int col = 0; col < 3; ++col) {
+        float y[3];
+#pragma unroll
+        for (int r = 0; r < 3; ++r) y[r] = (piv[r] == col) ? 1.0f : 0.0f;
+#pragma unroll
+        for (int r = 1; r < 3; ++r)
+#pragma unroll
+            for (int k = 0; k < r; ++k) y[r] = y[r] - lu[r][k] * y[k];
+#pragma unroll
+        for (int r = 2; r >= 0; --r) {
+#pragma unroll
+            for (int k = r + 1; k < 3; ++k) y[r] = y[r] - lu[r][k] * y[k];
+            y[r] = y[r] / lu[r][r];
+        }
+#pragma unroll
+        for (int r = 0; r < 3; ++r) Ainv[3 * r + col] = y[r];
+    }
+}
+
+// ---- one 1 ms Euler sub-step, quadrotorsim.py:122-210 ------------------------------------------
+// eff32[i]: the clamped voltage already rounded to f32 (quadrotorsim.py:130-134 + weak cast).
+__device__ __forceinline__ void substep(const QuadK &k, Lane &s, const float *eff32) {
+    float prop_force_z = 0.0f;
+    float prop_torque[3] = {0.0f, 0.0f, 0.0f};
+    float me[4], pp[4];
+
+    // :147-148 body_velocity = Rinv @ v is identical for all four propellers; only [2] is used
+    const double bvz = ((double)s.Ri[6] * s.v[0] + (double)s.Ri[7] * s.v[1]) + (double)s.Ri[8] * s.v[2];
+
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float e32 = eff32[i];
+        float phi_w = k.phi32 * s.pw[i];                         // :136
+        me[i] = k.phi_over_ra32 * (e32 - phi_w);                 // :137-138
+        pp[i] = fabsf(me[i] / k.phi32 * e32);                    // :139
+        float d_prop_w = k.inv_jm32 * (me[i] - k.mm32);          // :141-142
+        float w_m = s.pw[i] + k.prec32 * d_prop_w;               // :144-145
+        const float *pc = &k.pc[3 * i];
+        // :149-151 (omega x coord)[2] * l_m, f64
+        double cz = s.w[0] * (double)pc[1] - s.w[1] * (double)pc[0];
+        double v_1 = bvz + cz * (double)k.lm[i];
+        double sign = v_1 > 0 ? 1.0 : -1.0;                      // :152
+        float t0 = (k.ct0_32 * w_m) * w_m;                       // :154 f32 chain
+        double t1 = (double)(k.ct1_32 * w_m) * v_1;              // :155 f32 product, widened
+        double t2 = ((k.ct2 * v_1) * v_1) * sign;                // :156 f64
+        double thrust = ((double)t0 + t1) + t2;
+        s.pw[i] = w_m;                                           // :158
+        prop_force_z = (float)((double)prop_force_z + thrust);   // :159 f64 add, f32 store
+        float a[3] = {-0.0f, -0.0f, -(float)thrust};             // :160-162
+        float cr[3];
+        cross_f32(a, pc, cr);
+        prop_torque[0] += cr[0];
+        prop_torque[1] += cr[1];
+        prop_torque[2] += cr[2];
+    }
+    prop_torque[2] += ((-me[0] + me[1]) - me[2]) + me[3];        // :164
+
+    // :166-172 drag
+    float DfRi[9];
+    mm_f32(k.df, s.Ri, DfRi);
+    double tmp[3], f_drag[3], t_drag[3];
+    mv_f32f64(DfRi, s.v, tmp);
+    const double mnv = -s.nv;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) f_drag[c] = mnv * tmp[c];
+    mv_f32f64(k.dm, s.w, tmp);
+    const double mnw = -s.nw;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) t_drag[c] = mnw * tmp[c];
+
+    // :174-178 gravity, f32
+    const float g[3] = {0.0f, 0.0f, -9.8f};
+    float f_grav[3], t_grav[3];
+    mv_f32(s.Ri, g, f_grav);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) f_grav[c] = f_grav[c] * k.quality32;
+    cross_f32(f_grav, k.cog, t_grav);
+
+    // :180-184
+    const float prop_force[3] = {0.0f, 0.0f, prop_force_z};
+    double t_all[3], body_acc[3], acc[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        double f_all = (double)(prop_force[c] + f_grav[c]) + f_drag[c];
+        t_all[c] = (double)(prop_torque[c] + (-t_grav[c])) + t_drag[c];
+        body_acc[c] = k.quality_recip_exact ? f_all * k.inv_quality : f_all / k.quality;
+    }
+    mv_f32f64(s.R, body_acc, acc);
+    // :185-188
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+        s.p[c] = (float)((double)s.p[c] + (s.v[c] * k.prec + k.half_dt2 * acc[c]));
+#pragma unroll
+    for (int c = 0; c < 3; ++c) s.v[c] = s.v[c] + k.prec * acc[c];
+    s.power = ((pp[0] + pp[1]) + pp[2]) + pp[3];
+
+    // :190-204 attitude
+    double alpha[3], tw[3];
+    mv_f32f64(k.iinv, t_all, alpha);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) tw[c] = s.w[c] + k.half_dt * alpha[c];
+    float S[9];
+    S[0] = 0.0f; S[1] = (float)(-tw[2]); S[2] = (float)(tw[1]);
+    S[3] = (float)(tw[2]); S[4] = 0.0f; S[5] = (float)(-tw[0]);
+    S[6] = (float)(-tw[1]); S[7] = (float)(tw[0]); S[8] = 0.0f;
+    float RS[9];
+    mm_f32(s.R, S, RS);
+#pragma unroll
+    for (int c = 0; c < 9; ++c) s.R[c] = s.R[c] + k.prec32 * RS[c];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) s.w[c] = s.w[c] + k.prec * alpha[c];
+    inv3(s.R, s.Ri);                                             // :206-208
+    s.nv = norm3(s.v);
+    s.nw = norm3(s.w);
+}
+
+// quadrotorsim.py:212-221
+__device__ __forceinline__ int failure_code(const QuadK &k, const Lane &s) {
+    if (norm3(s.p) > k.fail_range32) return 1;
+    if (s.nv > k.fail_velocity) return 2;
+    if (s.nw > k.fail_w) return 3;
+    return 0;
+}
+
+// quadrotorsim.py:260-293, :111-120; env.py:193-209
+__device__ __forceinline__ void observe(const QuadK &k, const Lane &s, float *obs) {
+    double b_v[3];
+    float b_pos[3], imu[3];
+    const float g[3] = {0.0f, 0.0f, -9.8f};
+    mv_f32f64(s.Ri, s.v, b_v);
+    mv_f32(s.Ri, s.p, b_pos);
+    mv_f32(s.Ri, g, imu);
+    float roll = atan2f(s.R[7], s.R[8]);
+    float pitch = atan2f(-s.R[6], sqrtf(s.R[7] * s.R[7] + s.R[8] * s.R[8]));
+    float yaw = atan2f(s.R[3], s.R[0]);
+    obs[0] = (float)b_v[0]; obs[1] = (float)b_v[1]; obs[2] = (float)b_v[2];
+    obs[3] = b_pos[0]; obs[4] = b_pos[1]; obs[5] = b_pos[2];
+    obs[6] = 0.0f + imu[0]; obs[7] = 0.0f + imu[1]; obs[8] = 0.0f + imu[2];
+    obs[9] = (float)s.w[0]; obs[10] = (float)s.w[1]; obs[11] = (float)s.w[2];
+    obs[12] = pitch; obs[13] = roll; obs[14] = yaw;
+    obs[15] = s.p[2] + k.zoff32;
+}
+
+// python slice normalisation map[a:b] for a dimension of length len
+__device__ __forceinline__ void py_slice(long a, long b, long len, long &lo, long &hi) {
+    if (a < 0) { a += len; if (a < 0) a = 0; } else if (a > len) a = len;
+    if (b < 0) { b += len; if (b < 0) b = 0; } else if (b > len) b = len;
+    lo = a; hi = b;
+}
+
+// env.py:248-260
+__device__ __forceinline__ bool collision(const QuadK &k, const double *op, const double *np_) {
+    long mn[3], mx[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        double lo = op[i] < np_[i] ? op[i] : np_[i];
+        double hi = op[i] > np_[i] ? op[i] : np_[i];
+        mn[i] = (long)floor(lo);
+        mx[i] = (long)ceil(hi);
+    }
+    int any = 0;
+    if (k.map != nullptr) {
+        long y0, y1, x0, x1;
+        py_slice(mn[1], mx[1] + 1, k.map_h, y0, y1);
+        py_slice(mn[0], mx[0] + 1, k.map_w, x0, x1);
+        for (long y = y0; y < y1; ++y)
+            for (long x = x0; x < x1; ++x) any |= (k.map[y * k.map_w + x] != 0);
+    }
+    return (mn[2] < any) || (mx[2] < any);  // heights compared with the *bool* np.any(...)
+}
+
+// ---- SoA load / store ----------------------------------------------------------------------------
+
+__device__ __forceinline__ void load_lane(const mg_quadrotor_state &st, int n, int e, Lane &s, int &ct) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) s.p[c] = st.pos[(size_t)c * n + e];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) s.v[c] = st.vel[(size_t)c * n + e];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) s.w[c] = st.omega[(size_t)c * n + e];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) s.pw[c] = st.propw[(size_t)c * n + e];
+#pragma unroll
+    for (int c = 0; c < 9; ++c) s.R[c] = st.rot[(size_t)c * n + e];
+    ct = st.ct[e];
+    inv3(s.R, s.Ri);
+    s.nv = norm3(s.v);
+    s.nw = norm3(s.w);
+    s.power = 0.0f;
+}
+
+__device__ __forceinline__ void store_lane(const mg_quadrotor_state &st, int n, int e, const Lane &s, int ct) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) st.pos[(size_t)c * n + e] = s.p[c];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) st.vel[(size_t)c * n + e] = s.v[c];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) st.omega[(size_t)c * n + e] = s.w[c];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) st.propw[(size_t)c * n + e] = s.pw[c];
+#pragma unroll
+    for (int c = 0; c < 9; ++c) st.rot[(size_t)c * n + e] = s.R[c];
+    st.ct[e] = ct;
+}
+
+// Transpose the wave's 64 x 16 observation rows through LDS and store them as 4 coalesced
+// dwordx4 sweeps (each wave instruction writes 1 KiB contiguous). Rows are padded to 17 floats so
+// the per-lane row writes hit distinct banks; a partial last wave falls back to per-row stores.
+__device__ __forceinline__ void store_obs_wave(float *tile, const float *obs, float *out, int n, int e) {
+    const int lane = threadIdx.x & (mg::WAVE - 1);
+    const int wave_base = e - lane;                 // first env of this wave
+    const bool full = (wave_base + mg::WAVE) <= n;  // wave-uniform
+    if (full) {
+#pragma unroll
+        for (int c = 0; c < OBS_DIM; ++c) tile[lane * (OBS_DIM + 1) + c] = obs[c];
+        __builtin_amdgcn_wave_barrier();
+        float4 *dst = reinterpret_cast<float4 *>(out + (size_t)wave_base * OBS_DIM);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int q = j * mg::WAVE + lane;      // float4 index inside the wave's 4 KiB block
+            const int row = q >> 2, col = (q & 3) * 4;
+            const float *src = &tile[row * (OBS_DIM + 1) + col];
+            dst[q] = make_float4(src[0], src[1], src[2], src[3]);
+        }
+        __builtin_amdgcn_wave_barrier();
+    } else if (e < n) {
+        float4 *dst = reinterpret_cast<float4 *>(out + (size_t)e * OBS_DIM);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) dst[j] = make_float4(obs[4 * j], obs[4 * j + 1], obs[4 * j + 2], obs[4 * j + 3]);
+    }
+}
+
+// ---- counter-based RNG for the fused auto-reset -------------------------------------------------
+// Philox4x32-10 (Salmon et al., SC'11): stateless, keyed by (seed), counter = (env, step, draw).
+// Every env/step/draw triple gets its own stream, so results do not depend on how envs are
+// sharded across GPUs.
+__device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0,
+                                              uint32_t k1, uint32_t *out) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c0;
+        const uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+        const uint32_t n1 = (uint32_t)p1;
+        const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+        const uint32_t n3 = (uint32_t)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+// QuadrotorSim.reset quadrotorsim.py:239-258 with the noise drawn on the device:
+// value = base + noisy * U[0,1) * (+1 if U' > 0.5 else -1), per component.
+__device__ __forceinline__ void reset_lane_random(const QuadK &k, Lane &s, int e, uint64_t step) {
+    uint32_t r[12];
+#pragma unroll
+    for (int d = 0; d < 3; ++d)
+        philox4x32_10((uint32_t)e, (uint32_t)step, (uint32_t)(step >> 32), (uint32_t)d, (uint32_t)k.seed,
+                      (uint32_t)(k.seed >> 32), &r[4 * d]);
+    const double inv32 = 1.0 / 4294967296.0;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        s.p[c] = 0.0f;
+        const double sv = (r[c] & 1u) ? 1.0 : -1.0;
+        const double sw = (r[c] & 2u) ? 1.0 : -1.0;
+        s.v[c] = (double)k.init_v_base[c] + (k.init_v_noisy * ((double)r[3 + c] * inv32)) * sv;
+        s.w[c] = (double)k.init_w_base[c] + (k.init_w_noisy * ((double)r[6 + c] * inv32)) * sw;
+    }
+#pragma unroll
+    for (int c = 0; c < 4; ++c) s.pw[c] = 0.0f;
+#pragma unroll
+    for (int c = 0; c < 9; ++c) {
+        s.R[c] = (c % 4 == 0) ? 1.0f : 0.0f;
+        s.Ri[c] = s.R[c];
+    }
+    s.nv = norm3(s.v);
+    s.nw = norm3(s.w);
+    s.power = 0.0f;
+}
+
+// ---- kernels ---------------------------------------------------------------------------------------
+
+struct StepIO {
+    const float *action;   // [T][n][4]
+    float *obs;            // [T][n][16]
+    float *reward;         // [T][n] or null
+    double *reward64;      // [T][n] or null
+    uint8_t *done;         // [T][n]
+    uint8_t *failed;       // [T][n] or null
+};
+
+__global__ __launch_bounds__(BLOCK) void quadrotor_step_kernel(QuadK k, mg_quadrotor_state st, StepIO io,
+                                                               int n, int n_steps) {
+    __shared__ float tiles[WAVES_PER_BLOCK][mg::WAVE * (OBS_DIM + 1)];
+    const int e = blockIdx.x * BLOCK + threadIdx.x;
+    const bool live = e < n;
+    const int el = live ? e : n - 1;  // out-of-range lanes shadow the last env, stores are masked
+    float *tile = tiles[threadIdx.x / mg::WAVE];
+
+    Lane s;
+    int ct;
+    load_lane(st, n, el, s, ct);
+
+    for (int t = 0; t < n_steps; ++t) {
+        const size_t off = (size_t)t * n;
+        const float4 a = reinterpret_cast<const float4 *>(io.action)[off + el];
+        // quadrotorsim.py:130-134: clamp the (f32-valued) python float against python floats
+        const float av[4] = {a.x, a.y, a.z, a.w};
+        float eff32[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            double d = (double)av[i];
+            d = d > k.max_v ? k.max_v : (d < k.min_v ? k.min_v : d);
+            eff32[i] = (float)d;
+        }
+        ct += 1;                                                            // env.py:128
+        const double old_pos[3] = {(double)s.p[0] + k.xoff, (double)s.p[1] + k.yoff,
+                                   (double)(s.p[2] + k.zoff32)};            // env.py:131-133
+        int fail = 0;
+        for (int it = 0; it < k.times; ++it) {                              // quadrotorsim.py:302-304
+            if (fail == 0) {      // a failed env freezes at the failing sub-step (reference raises)
+                substep(k, s, eff32);
+                fail = failure_code(k, s);
+            }
+        }
+        float obs[OBS_DIM];
+        observe(k, s, obs);
+        double reward = 0.0;
+        int done = 1;
+        if (fail == 0) {
+            const double new_pos[3] = {(double)s.p[0] + k.xoff, (double)s.p[1] + k.yoff,
+                                       (double)(s.p[2] + k.zoff32)};
+            const bool hit = collision(k, old_pos, new_pos);                // env.py:145
+            // _get_reward env.py:211-246
+            const float energy = k.dt32 * s.power;
+            double r = (k.healthy32 < energy) ? -k.healthy : -(double)energy;   // -min(energy, healthy)
+            double task_reward = hit ? 0.0 : k.healthy;
+            if (k.task == MG_QUADROTOR_TASK_HOVERING_CONTROL) {
+                task_reward -= 1.0 * s.nv + 1.0 * s.nw;
+                const float z_move = fabsf(0.0f - s.p[2]);   // pos_0 is the reset position = 0 (env.py:123)
+                if (z_move < 0.5f) task_reward += 10;
+                else {
+                    const float o = 0.5f - z_move;
+                    task_reward += (o > -20.0f) ? (double)o : -20.0;
+                }
+            }
+            reward = r + task_reward;
+            done = 0;
+            if (hit) { done = 1; ct = 0; }                                  // env.py:147-149
+            if (ct == k.nt) { done = 1; ct = 0; }                           // env.py:159-161
+        } else {
+            ct = 0;
+        }
+        if (k.auto_reset && done) {
+            // vector-env convention: the returned obs is the first observation of the next episode
+            reset_lane_random(k, s, el, k.step_index + (uint64_t)t);
+            observe(k, s, obs);
+        }
+        store_obs_wave(tile, obs, io.obs + off * OBS_DIM, n, e);
+        if (live) {
+            if (io.reward) io.reward[off + e] = (float)reward;
+            if (io.reward64) io.reward64[off + e] = reward;
+            io.done[off + e] = (uint8_t)done;
+            if (io.failed) io.failed[off + e] = (uint8_t)fail;
+        }
+    }
+    if (live) store_lane(st, n, e, s, ct);
+}
+
+__global__ __launch_bounds__(BLOCK) void quadrotor_reset_kernel(QuadK k, mg_quadrotor_state st,
+                                                                const uint8_t *mask, const double *init_vel,
+                                                                const double *init_omega, float *obs_out, int n) {
+    const int e = blockIdx.x * BLOCK + threadIdx.x;
+    if (e >= n) return;
+    if (mask != nullptr && mask[e] == 0) return;
+    Lane s;
+    // _zero_state quadrotorsim.py:20-28, then the injected noise :241-254
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        s.p[c] = 0.0f;
+        s.v[c] = init_vel ? init_vel[(size_t)c * n + e] : 0.0;
+        s.w[c] = init_omega ? init_omega[(size_t)c * n + e] : 0.0;
+    }
+#pragma unroll
+    for (int c = 0; c < 4; ++c) s.pw[c] = 0.0f;
+#pragma unroll
+    for (int c = 0; c < 9; ++c) s.R[c] = (c % 4 == 0) ? 1.0f : 0.0f;
+    inv3(s.R, s.Ri);
+    s.nv = norm3(s.v);
+    s.nw = norm3(s.w);
+    s.power = 0.0f;
+    store_lane(st, n, e, s, st.ct[e]);   // ct is not cleared by reset() (env.py:116-125)
+    if (obs_out != nullptr) {
+        float obs[OBS_DIM];
+        observe(k, s, obs);
+        float4 *dst = reinterpret_cast<float4 *>(obs_out + (size_t)e * OBS_DIM);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) dst[j] = make_float4(obs[4 * j], obs[4 * j + 1], obs[4 * j + 2], obs[4 * j + 3]);
+    }
+}
+
+// ---- host: fold the config into kernel constants ----------------------------------------------
+
+void host_inv3_f32(const float *A, float *Ainv) {
+    // same algorithm as the device inv3 (LU, partial pivoting), plain host code
+    float lu[9];
+    int piv[3] = {0, 1, 2};
+    for (int i = 0; i < 9; ++i) lu[i] = A[i];
+    for (int k = 0; k < 3; ++k) {
+        int p = k;
+        float best = fabsf(lu[3 * k + k]);
+        for (int r = k + 1; r < 3; ++r)
+            if (fabsf(lu[3 * r + k]) > best) { best = fabsf(lu[3 * r + k]); p = r; }
+        if (p != k) {
+            for (int c = 0; c < 3; ++c) { float t = lu[3 * k + c]; lu[3 * k + c] = lu[3 * p + c]; lu[3 * p + c] = t; }
+            int t = piv[k]; piv[k] = piv[p]; piv[p] = t;
+        }
+        float rcp = 1.0f / lu[3 * k + k];
+        for (int r = k + 1; r < 3; ++r) {
+            lu[3 * r + k] = lu[3 * r + k] * rcp;
+            for (int c = k + 1; c < 3; ++c) lu[3 * r + c] = lu[3 * r + c] - lu[3 * r + k] * lu[3 * k + c];
+        }
+    }
+    for (int col = 0; col < 3; ++col) {
+        float y[3];
+        for (int r = 0; r < 3; ++r) y[r] = (piv[r] == col) ? 1.0f : 0.0f;
+        for (int r = 1; r < 3; ++r)
+            for (int k = 0; k < r; ++k) y[r] = y[r] - lu[3 * r + k] * y[k];
+        for (int r = 2; r >= 0; --r) {
+            for (int k = r + 1; k < 3; ++k) y[r] = y[r] - lu[3 * r + k] * y[k];
+            y[r] = y[r] / lu[3 * r + r];
+        }
+        for (int r = 0; r < 3; ++r) Ainv[3 * r + col] = y[r];
+    }
+}
+
+int fold_config(const mg_quadrotor_config *c, QuadK *k) {
+    if (!(c->precision >= 1e-8) || c->precision > c->dt)   // quadrotorsim.py:299-300
+        return mg::set_error(MG_ERR_BAD_CONFIG, "precision %g must be in [1e-8, dt=%g]", c->precision, c->dt);
+    if (c->task != MG_QUADROTOR_TASK_NO_COLLISION && c->task != MG_QUADROTOR_TASK_HOVERING_CONTROL)
+        return mg::set_error(MG_ERR_UNSUPPORTED, "quadrotor task %d is not implemented", c->task);
+    if (c->map_d != nullptr && (c->map_h <= 0 || c->map_w <= 0))
+        return mg::set_error(MG_ERR_BAD_SIZE, "map shape %d x %d", c->map_h, c->map_w);
+    k->phi32 = (float)c->phi;
+    k->phi_over_ra32 = (float)(c->phi / c->ra);
+    k->inv_jm32 = (float)(1.0 / c->jm);
+    k->mm32 = (float)c->mm;
+    k->prec32 = (float)c->precision;
+    k->ct0_32 = (float)c->ct0;
+    k->ct1_32 = (float)c->ct1;
+    k->quality32 = (float)c->quality;
+    k->dt32 = (float)c->dt;
+    k->zoff32 = (float)c->z_offset;
+    k->healthy32 = (float)c->healthy_reward;
+    k->fail_range32 = (float)c->fail_range;
+    for (int i = 0; i < 4; ++i) {
+        const float *p = &c->prop_coord[3 * i];
+        k->lm[i] = sqrtf((p[0] * p[0] + p[1] * p[1]) + p[2] * p[2]);
+    }
+    for (int i = 0; i < 12; ++i) k->pc[i] = c->prop_coord[i];
+    host_inv3_f32(c->inertia, k->iinv);
+    for (int i = 0; i < 9; ++i) { k->df[i] = c->drag_f[i]; k->dm[i] = c->drag_m[i]; }
+    for (int i = 0; i < 3; ++i) k->cog[i] = c->gravity_center[i];
+    k->prec = c->precision;
+    k->half_dt2 = 0.5 * c->precision * c->precision;   // python: 0.5 * p * p, left to right
+    k->half_dt = 0.5 * c->precision;
+    k->ct2 = c->ct2;
+    k->quality = c->quality;
+    k->inv_quality = 1.0 / c->quality;
+    int ex = 0;
+    (void)frexp(c->quality, &ex);
+    k->quality_recip_exact = (frexp(c->quality, &ex) == 0.5) ? 1 : 0;   // power of two
+    k->min_v = c->min_voltage;
+    k->max_v = c->max_voltage;
+    k->fail_velocity = c->fail_velocity;
+    k->fail_w = c->fail_w;
+    k->healthy = c->healthy_reward;
+    k->xoff = (double)c->x_offset;
+    k->yoff = (double)c->y_offset;
+    k->times = (int)(c->dt / c->precision);            // quadrotorsim.py:302
+    k->nt = c->nt;
+    k->task = c->task;
+    k->map = c->map_d;
+    k->map_h = c->map_h;
+    k->map_w = c->map_w;
+    k->auto_reset = 0;
+    for (int i = 0; i < 3; ++i) { k->init_v_base[i] = 0.0f; k->init_w_base[i] = 0.0f; }
+    k->init_v_noisy = k->init_w_noisy = 0.0;
+    k->seed = k->step_index = 0;
+    return MG_OK;
+}
+
+int check_state(const mg_quadrotor_state *s) {
+    if (!s->pos || !s->vel || !s->omega || !s->propw || !s->rot || !s->ct)
+        return mg::set_error(MG_ERR_NULL_POINTER, "mg_quadrotor_state has a NULL array");
+    return MG_OK;
+}
+
+int launch_steps(const mg_quadrotor_config *cfg, int32_t n, int32_t n_steps, const mg_quadrotor_state *state,
+                 const float *action, float *obs, float *reward, double *reward64, uint8_t *done,
+                 uint8_t *failed, void *stream, const mg_quadrotor_autoreset *ar = nullptr) {
+    MG_REQUIRE_PTR(cfg);
+    MG_REQUIRE_PTR(state);
+    MG_REQUIRE_PTR(action);
+    MG_REQUIRE_PTR(obs);
+    MG_REQUIRE_PTR(done);
+    if (n <= 0 || n_steps <= 0) return mg::set_error(MG_ERR_BAD_SIZE, "n_envs=%d n_steps=%d", n, n_steps);
+    if (int rc = check_state(state)) return rc;
+    QuadK k;
+    if (int rc = fold_config(cfg, &k)) return rc;
+    if (ar != nullptr) {
+        k.auto_reset = 1;
+        for (int i = 0; i < 3; ++i) { k.init_v_base[i] = ar->init_velocity[i]; k.init_w_base[i] = ar->init_angular_velocity[i]; }
+        k.init_v_noisy = ar->init_velocity_noisy;
+        k.init_w_noisy = ar->init_angular_velocity_noisy;
+        k.seed = ar->seed;
+        k.step_index = ar->step_index;
+    }
+    StepIO io{action, obs, reward, reward64, done, failed};
+    const int grid = (n + BLOCK - 1) / BLOCK;
+    hipLaunchKernelGGL(quadrotor_step_kernel, dim3(grid), dim3(BLOCK), 0, (hipStream_t)stream, k, *state, io, n,
+                       n_steps);
+    return mg::check_launch("quadrotor_step_kernel");
+}
+
+}  // namespace
+
+extern "C" int mg_quadrotor_default_config(mg_quadrotor_config *c) {
+    MG_REQUIRE_PTR(c);
+    // metagym/quadrotor/config.json:1-59 and Quadrotor.__init__ defaults env.py:46-114
+    *c = mg_quadrotor_config{};
+    c->precision = 0.001;
+    c->quality = 0.5;
+    c->ct0 = 1.538e-5; c->ct1 = -2.5e-4; c->ct2 = 0.0;
+    c->mm = 0.010; c->jm = 2.573e-4; c->ra = 0.2010; c->phi = 0.017242179827506;
+    c->fail_velocity = 100.0; c->fail_w = 1000.0; c->fail_range = 1000.0;
+    c->min_voltage = 0.10; c->max_voltage = 15.0;
+    c->dt = 0.01; c->healthy_reward = 1.0; c->z_offset = 5.0;
+    c->x_offset = 50; c->y_offset = 50;
+    c->nt = 1000;
+    c->task = MG_QUADROTOR_TASK_NO_COLLISION;
+    c->inertia[0] = 0.0135f; c->inertia[4] = 0.0135f; c->inertia[8] = 0.024f;
+    c->drag_m[0] = 0.074f; c->drag_m[4] = 0.074f; c->drag_m[8] = 0.0506f;
+    c->drag_f[0] = 0.12f; c->drag_f[4] = 0.12f; c->drag_f[8] = 0.10f;
+    const float pc[12] = {0.18f, 0.18f, 0.f, -0.18f, 0.18f, 0.f, -0.18f, -0.18f, 0.f, 0.18f, -0.18f, 0.f};
+    for (int i = 0; i < 12; ++i) c->prop_coord[i] = pc[i];
+    c->map_d = nullptr; c->map_h = 100; c->map_w = 100;
+    return MG_OK;
+}
+
+extern "C" int mg_quadrotor_reset(const mg_quadrotor_config *cfg, int32_t n, const mg_quadrotor_state *state,
+                                  const uint8_t *mask, const double *init_vel, const double *init_omega,
+                                  float *obs, void *stream) {
+    MG_REQUIRE_PTR(cfg);
+    MG_REQUIRE_PTR(state);
+    if (n <= 0) return mg::set_error(MG_ERR_BAD_SIZE, "n_envs=%d", n);
+    if (int rc = check_state(state)) return rc;
+    QuadK k;
+    if (int rc = fold_config(cfg, &k)) return rc;
+    const int grid = (n + BLOCK - 1) / BLOCK;
+    hipLaunchKernelGGL(quadrotor_reset_kernel, dim3(grid), dim3(BLOCK), 0, (hipStream_t)stream, k, *state, mask,
+                       init_vel, init_omega, obs, n);
+    return mg::check_launch("quadrotor_reset_kernel");
+}
+
+extern "C" int mg_quadrotor_step(const mg_quadrotor_config *cfg, int32_t n, const mg_quadrotor_state *state,
+                                 const float *action, float *obs, float *reward, double *reward64,
+                                 uint8_t *done, uint8_t *failed, void *stream) {
+    return launch_steps(cfg, n, 1, state, action, obs, reward, reward64, done, failed, stream);
+}
+
+extern "C" int mg_quadrotor_step_autoreset(const mg_quadrotor_config *cfg, int32_t n, int32_t n_steps,
+                                           const mg_quadrotor_state *state, const mg_quadrotor_autoreset *ar,
+                                           const float *action, float *obs, float *reward, double *reward64,
+                                           uint8_t *done, uint8_t *failed, void *stream) {
+    MG_REQUIRE_PTR(ar);
+    return launch_steps(cfg, n, n_steps, state, action, obs, reward, reward64, done, failed, stream, ar);
+}
+
+extern "C" int mg_quadrotor_rollout(const mg_quadrotor_config *cfg, int32_t n, int32_t n_steps,
+                                    const mg_quadrotor_state *state, const float *action, float *obs,
+                                    float *reward, double *reward64, uint8_t *done, uint8_t *failed,
+                                    void *stream) {
+    return launch_steps(cfg, n, n_steps, state, action, obs, reward, reward64, done, failed, stream);
+}

@@ -1,0 +1,25 @@
+"""Id -> constructor table mirroring the reference's gym.register calls
+(metagym/quadrotor/__init__.py:20-32, metagym/metamaze/__init__.py:21-54)."""
+import importlib
+
+registry = {}
+
+
+def register(id, entry_point, kwargs=None):
+    registry[id] = (entry_point, dict(kwargs or {}))
+
+
+def make(id, **kwargs):
+    if id not in registry:
+        raise KeyError("unknown env id %r; known: %s" % (id, sorted(registry)))
+    entry_point, defaults = registry[id]
+    mod_name, cls_name = entry_point.split(":")
+    cls = getattr(importlib.import_module(mod_name), cls_name)
+    kw = dict(defaults)
+    kw.update(kwargs)
+    return cls(**kw)
+
+
+register("quadrotor-v0", "metagym_amd.quadrotor:Quadrotor",
+         kwargs={"dt": 0.01, "nt": 1000, "seed": 0, "task": "no_collision", "map_file": None,
+                 "simulator_conf": None, "healthy_reward": 1.0})

@@ -138,7 +138,8 @@ void qo_refresh_inverse(qo_state *s) { qo_inv3_f32(s->R, s->Rinv); }
 
 int qo_failed(const qo_consts *c, const qo_state *s) {
     /* quadrotorsim.py:212-221; norms in the array's own dtype */
-    if ((double)norm3_f32(s->pos) > c->fail_range) return 1;
+    /* np.float32 > python float: the python float is weak, the comparison runs in f32 */
+    if (norm3_f32(s->pos) > (float)c->fail_range) return 1;
     if (norm3_f64(s->vel) > c->fail_velocity) return 2;
     if (norm3_f64(s->omega) > c->fail_w) return 3;
     return 0;
@@ -334,8 +335,10 @@ int qo_env_step(const qo_consts *c, qo_state *s, int *ct, const float act[4],
     /* _get_reward env.py:211-246 */
     float energy = (float)c->dt * s->power;                  /* python float * np.float32 -> f32 */
     double r;
-    if ((double)energy < c->healthy_reward) r = -(double)energy;  /* min() keeps the f32 value */
-    else r = -c->healthy_reward;
+    /* -min(energy, healthy): python's min keeps `energy` unless `healthy < energy`, which NumPy
+       evaluates in f32 (weak python float); the picked object keeps its own precision */
+    if ((float)c->healthy_reward < energy) r = -c->healthy_reward;
+    else r = -(double)energy;
     double task_reward = is_collision ? 0.0 : c->healthy_reward;
     if (c->task == QO_TASK_HOVERING) {
         double velocity_norm = norm3_f64(s->vel);

