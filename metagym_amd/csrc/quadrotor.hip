@@ -33,7 +33,7 @@ constexpr int OBS_DIM = 16;
 struct QuadK {
     // weak python floats that meet f32 operands first (quadrotorsim.py:136-145,154-156)
     float phi32, phi_over_ra32, inv_jm32, mm32, prec32, ct0_32, ct1_32;
-    float quality32, dt32, zoff32, healthy32, fail_range32;
+    float quality32, dt32, zoff32, healthy32, fail_range_sq32;
     float lm[4];        // ||prop_coord[i]||, quadrotorsim.py:146
     float pc[12];       // prop_coord
     float iinv[9];      // inverse inertia (f32), quadrotorsim.py:64
@@ -64,12 +64,19 @@ struct Lane {       // one environment, in registers
     float power;
 };
 
-// ---- f32 / f64 3x3 helpers; summation order ((a0*b0 + a1*b1) + a2*b2), no FMA -------------------
+// ---- f32 / f64 3x3 helpers -------------------------------------------------------------------------
+// NumPy's elementwise ops never fuse, but np.matmul / np.linalg.norm run OpenBLAS kernels that do.
+// The associations below are the ones that reproduce NumPy bit-for-bit (oracle/quadrotor_oracle.c
+// documents the probe); the file is compiled with -ffp-contract=off so only these explicit FMAs fuse.
+
+__device__ __forceinline__ double dot_row_f32f64(const float *row, const double *x) {
+    // np.matmul(f32[3,3], f64[3]): matrix widened, dgemv association fma(M2,x2, fma(M0,x0, M1*x1))
+    return fma((double)row[2], x[2], fma((double)row[0], x[0], (double)row[1] * x[1]));
+}
 
 __device__ __forceinline__ void mv_f32f64(const float *M, const double *x, double *y) {
 #pragma unroll
-    for (int r = 0; r < 3; ++r)
-        y[r] = ((double)M[3 * r] * x[0] + (double)M[3 * r + 1] * x[1]) + (double)M[3 * r + 2] * x[2];
+    for (int r = 0; r < 3; ++r) y[r] = dot_row_f32f64(&M[3 * r], x);
 }
 
 __device__ __forceinline__ void mv_f32(const float *M, const float *x, float *y) {
@@ -78,11 +85,12 @@ __device__ __forceinline__ void mv_f32(const float *M, const float *x, float *y)
 }
 
 __device__ __forceinline__ void mm_f32(const float *A, const float *B, float *C) {
+    // sgemm association: left-to-right FMA chain over k
 #pragma unroll
     for (int r = 0; r < 3; ++r)
 #pragma unroll
         for (int c = 0; c < 3; ++c)
-            C[3 * r + c] = (A[3 * r] * B[c] + A[3 * r + 1] * B[3 + c]) + A[3 * r + 2] * B[6 + c];
+            C[3 * r + c] = fmaf(A[3 * r + 2], B[6 + c], fmaf(A[3 * r + 1], B[3 + c], A[3 * r] * B[c]));
 }
 
 __device__ __forceinline__ void cross_f32(const float *a, const float *b, float *c) {
@@ -96,84 +104,48 @@ __device__ __forceinline__ void cross_f32(const float *a, const float *b, float 
 }
 
 __device__ __forceinline__ double norm3(const double *x) {
-    return sqrt((x[0] * x[0] + x[1] * x[1]) + x[2] * x[2]);
+    return sqrt(fma(x[2], x[2], fma(x[1], x[1], x[0] * x[0])));
 }
-__device__ __forceinline__ float norm3(const float *x) {
-    return sqrtf((x[0] * x[0] + x[1] * x[1]) + x[2] * x[2]);
-}
+__device__ __forceinline__ float sumsq3(const float *x) { return fmaf(x[2], x[2], fmaf(x[1], x[1], x[0] * x[0])); }
 
-// General f32 inverse by LU with partial pivoting + solve against I (np.linalg.inv -> sgesv,
-// quadrotorsim.py:207). Branch-free: row swaps are selects, every index is static after unrolling,
-// so the nine entries live in VGPRs. R drifts away from orthonormal (first-order update, never
-// re-normalised), so R^T is NOT a substitute.
-__device__ __forceinline__ void inv3(const float *A, float *Ainv) {
-    float lu[3][3];
-    int piv[3] = {0, 1, 2};
+// np.linalg.inv on a float32 matrix (quadrotorsim.py:207): numpy promotes to float64, solves, and
+// casts back, i.e. it returns the correctly rounded f32 inverse. Same here: adjugate / det in f64
+// (branch-free, ~60 f64 ops, one division), rounded to f32. R drifts away from orthonormal (the
+// reference never re-normalises it), so R^T is NOT a substitute.
+__device__ __forceinline__ void inv3(const float *Af, float *Ainv) {
+    double A[9];
 #pragma unroll
-    for (int r = 0; r < 3; ++r)
-#pragma unroll
-        for (int c = 0; c < 3; ++c) lu[r][c] = A[3 * r + c];
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
-        int p = k;
-        float best = fabsf(lu[k][k]);
-#pragma unroll
-        for (int r = k + 1; r < 3; ++r) {
-            float v = fabsf(lu[r][k]);
-            bool g = v > best;
-            best = g ? v : best;
-            p = g ? r : p;
-        }
-#pragma unroll
-        for (int r = k + 1; r < 3; ++r) {
-            bool sw = (p == r);
-#pragma unroll
-            for (int c = 0; c < 3; ++c) {
-                float a = lu[k][c], b = lu[r][c];
-                lu[k][c] = sw ? b : a;
-                lu[r][c] = sw ? a : b;
-            }
-            int pa = piv[k], pb = piv[r];
-            piv[k] = sw ? pb : pa;
-            piv[r] = sw ? pa : pb;
-        }
-        float rcp = 1.0f / lu[k][k];
-#pragma unroll
-        for (int r = k + 1; r < 3; ++r) {
-            lu[r][k] = lu[r][k] * rcp;
-#pragma unroll
-            for (int c = k + 1; c < 3; ++c) lu[r][c] = lu[r][c] - lu[r][k] * lu[k][c];
-        }
-    }
-#pragma unroll
-    for (int col = 0; col < 3; ++col) {
-        float y[3];
-#pragma unroll
-        for (int r = 0; r < 3; ++r) y[r] = (piv[r] == col) ? 1.0f : 0.0f;
-#pragma unroll
-        for (int r = 1; r < 3; ++r)
-#pragma unroll
-            for (int k = 0; k < r; ++k) y[r] = y[r] - lu[r][k] * y[k];
-#pragma unroll
-        for (int r = 2; r >= 0; --r) {
-#pragma unroll
-            for (int k = r + 1; k < 3; ++k) y[r] = y[r] - lu[r][k] * y[k];
-            y[r] = y[r] / lu[r][r];
-        }
-#pragma unroll
-        for (int r = 0; r < 3; ++r) Ainv[3 * r + col] = y[r];
-    }
+    for (int i = 0; i < 9; ++i) A[i] = (double)Af[i];
+    const double c00 = A[4] * A[8] - A[5] * A[7];
+    const double c01 = A[5] * A[6] - A[3] * A[8];
+    const double c02 = A[3] * A[7] - A[4] * A[6];
+    const double det = (A[0] * c00 + A[1] * c01) + A[2] * c02;
+    const double r = 1.0 / det;
+    Ainv[0] = (float)(c00 * r);
+    Ainv[3] = (float)(c01 * r);
+    Ainv[6] = (float)(c02 * r);
+    Ainv[1] = (float)((A[2] * A[7] - A[1] * A[8]) * r);
+    Ainv[4] = (float)((A[0] * A[8] - A[2] * A[6]) * r);
+    Ainv[7] = (float)((A[1] * A[6] - A[0] * A[7]) * r);
+    Ainv[2] = (float)((A[1] * A[5] - A[2] * A[4]) * r);
+    Ainv[5] = (float)((A[2] * A[3] - A[0] * A[5]) * r);
+    Ainv[8] = (float)((A[0] * A[4] - A[1] * A[3]) * r);
 }
 
 // ---- one 1 ms Euler sub-step, quadrotorsim.py:122-210 ------------------------------------------
 // eff32[i]: the clamped voltage already rounded to f32 (quadrotorsim.py:130-134 + weak cast).
+// SIMPLE = the structure of the stock config.json: diagonal drag / inertia matrices, zero centre of
+// gravity offset, CT[2] == 0, propellers in the z = 0 plane. Multiplying by those structural zeros
+// only ever adds +-0 to a finite sum, so the SIMPLE path is bit-identical to the general one while
+// needing ~40 fewer scalar constants and ~70 fewer VALU ops per sub-step.
+template <bool SIMPLE>
 __device__ __forceinline__ void substep(const QuadK &k, Lane &s, const float *eff32) {
     float prop_force_z = 0.0f;
     float prop_torque[3] = {0.0f, 0.0f, 0.0f};
     float me[4], pp[4];
 
     // :147-148 body_velocity = Rinv @ v is identical for all four propellers; only [2] is used
-    const double bvz = ((double)s.Ri[6] * s.v[0] + (double)s.Ri[7] * s.v[1]) + (double)s.Ri[8] * s.v[2];
+    const double bvz = dot_row_f32f64(&s.Ri[6], s.v);
 
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -187,50 +159,74 @@ __device__ __forceinline__ void substep(const QuadK &k, Lane &s, const float *ef
         // :149-151 (omega x coord)[2] * l_m, f64
         double cz = s.w[0] * (double)pc[1] - s.w[1] * (double)pc[0];
         double v_1 = bvz + cz * (double)k.lm[i];
-        double sign = v_1 > 0 ? 1.0 : -1.0;                      // :152
         float t0 = (k.ct0_32 * w_m) * w_m;                       // :154 f32 chain
         double t1 = (double)(k.ct1_32 * w_m) * v_1;              // :155 f32 product, widened
-        double t2 = ((k.ct2 * v_1) * v_1) * sign;                // :156 f64
-        double thrust = ((double)t0 + t1) + t2;
+        double thrust = (double)t0 + t1;
+        if (!SIMPLE) {
+            double sign = v_1 > 0 ? 1.0 : -1.0;                  // :152
+            thrust = thrust + ((k.ct2 * v_1) * v_1) * sign;      // :156 f64
+        }
         s.pw[i] = w_m;                                           // :158
         prop_force_z = (float)((double)prop_force_z + thrust);   // :159 f64 add, f32 store
-        float a[3] = {-0.0f, -0.0f, -(float)thrust};             // :160-162
-        float cr[3];
-        cross_f32(a, pc, cr);
-        prop_torque[0] += cr[0];
-        prop_torque[1] += cr[1];
-        prop_torque[2] += cr[2];
+        const float T = (float)thrust;                           // :160-162 cross(-[0,0,T], coord)
+        if (SIMPLE) {
+            prop_torque[0] += T * pc[1];
+            prop_torque[1] += (-T) * pc[0];
+        } else {
+            float a[3] = {-0.0f, -0.0f, -T};
+            float cr[3];
+            cross_f32(a, pc, cr);
+            prop_torque[0] += cr[0];
+            prop_torque[1] += cr[1];
+            prop_torque[2] += cr[2];
+        }
     }
     prop_torque[2] += ((-me[0] + me[1]) - me[2]) + me[3];        // :164
 
-    // :166-172 drag
+    // :166-172 drag: -||v|| * ((Df @ Rinv) @ v), -||w|| * (Dm @ w)
     float DfRi[9];
-    mm_f32(k.df, s.Ri, DfRi);
     double tmp[3], f_drag[3], t_drag[3];
+    if (SIMPLE) {
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) DfRi[3 * r + c] = k.df[4 * r] * s.Ri[3 * r + c];
+    } else {
+        mm_f32(k.df, s.Ri, DfRi);
+    }
     mv_f32f64(DfRi, s.v, tmp);
     const double mnv = -s.nv;
 #pragma unroll
     for (int c = 0; c < 3; ++c) f_drag[c] = mnv * tmp[c];
-    mv_f32f64(k.dm, s.w, tmp);
+    if (SIMPLE) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) tmp[c] = (double)k.dm[4 * c] * s.w[c];
+    } else {
+        mv_f32f64(k.dm, s.w, tmp);
+    }
     const double mnw = -s.nw;
 #pragma unroll
     for (int c = 0; c < 3; ++c) t_drag[c] = mnw * tmp[c];
 
-    // :174-178 gravity, f32
-    const float g[3] = {0.0f, 0.0f, -9.8f};
-    float f_grav[3], t_grav[3];
-    mv_f32(s.Ri, g, f_grav);
+    // :174-178 gravity, f32: Rinv @ [0,0,-9.8] * quality
+    float f_grav[3];
 #pragma unroll
-    for (int c = 0; c < 3; ++c) f_grav[c] = f_grav[c] * k.quality32;
-    cross_f32(f_grav, k.cog, t_grav);
+    for (int c = 0; c < 3; ++c) f_grav[c] = (s.Ri[3 * c + 2] * -9.8f) * k.quality32;
 
     // :180-184
-    const float prop_force[3] = {0.0f, 0.0f, prop_force_z};
     double t_all[3], body_acc[3], acc[3];
+    float t_grav_neg[3] = {0.0f, 0.0f, 0.0f};
+    if (!SIMPLE) {
+        float t_grav[3];
+        cross_f32(f_grav, k.cog, t_grav);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) t_grav_neg[c] = -t_grav[c];
+    }
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
-        double f_all = (double)(prop_force[c] + f_grav[c]) + f_drag[c];
-        t_all[c] = (double)(prop_torque[c] + (-t_grav[c])) + t_drag[c];
+        const float pf = (c == 2) ? prop_force_z : 0.0f;
+        double f_all = (double)(pf + f_grav[c]) + f_drag[c];
+        t_all[c] = (double)(SIMPLE ? prop_torque[c] : prop_torque[c] + t_grav_neg[c]) + t_drag[c];
         body_acc[c] = k.quality_recip_exact ? f_all * k.inv_quality : f_all / k.quality;
     }
     mv_f32f64(s.R, body_acc, acc);
@@ -244,17 +240,29 @@ __device__ __forceinline__ void substep(const QuadK &k, Lane &s, const float *ef
 
     // :190-204 attitude
     double alpha[3], tw[3];
-    mv_f32f64(k.iinv, t_all, alpha);
+    if (SIMPLE) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) alpha[c] = (double)k.iinv[4 * c] * t_all[c];
+    } else {
+        mv_f32f64(k.iinv, t_all, alpha);
+    }
 #pragma unroll
     for (int c = 0; c < 3; ++c) tw[c] = s.w[c] + k.half_dt * alpha[c];
-    float S[9];
-    S[0] = 0.0f; S[1] = (float)(-tw[2]); S[2] = (float)(tw[1]);
-    S[3] = (float)(tw[2]); S[4] = 0.0f; S[5] = (float)(-tw[0]);
-    S[6] = (float)(-tw[1]); S[7] = (float)(tw[0]); S[8] = 0.0f;
-    float RS[9];
-    mm_f32(s.R, S, RS);
+    // skew(tw) rounded to f32 (:193-199); R += dt * (R @ S) with the sgemm FMA association, the
+    // structural zero of each S column folded away (0*x contributes +-0)
+    const float s01 = (float)(-tw[2]), s02 = (float)(tw[1]);
+    const float s10 = (float)(tw[2]), s12 = (float)(-tw[0]);
+    const float s20 = (float)(-tw[1]), s21 = (float)(tw[0]);
 #pragma unroll
-    for (int c = 0; c < 9; ++c) s.R[c] = s.R[c] + k.prec32 * RS[c];
+    for (int r = 0; r < 3; ++r) {
+        const float r0 = s.R[3 * r], r1 = s.R[3 * r + 1], r2 = s.R[3 * r + 2];
+        const float rs0 = fmaf(r2, s20, fmaf(r1, s10, r0 * 0.0f));
+        const float rs1 = fmaf(r2, s21, fmaf(r1, 0.0f, r0 * s01));
+        const float rs2 = fmaf(r2, 0.0f, fmaf(r1, s12, r0 * s02));
+        s.R[3 * r] = r0 + k.prec32 * rs0;
+        s.R[3 * r + 1] = r1 + k.prec32 * rs1;
+        s.R[3 * r + 2] = r2 + k.prec32 * rs2;
+    }
 #pragma unroll
     for (int c = 0; c < 3; ++c) s.w[c] = s.w[c] + k.prec * alpha[c];
     inv3(s.R, s.Ri);                                             // :206-208
@@ -264,7 +272,7 @@ __device__ __forceinline__ void substep(const QuadK &k, Lane &s, const float *ef
 
 // quadrotorsim.py:212-221
 __device__ __forceinline__ int failure_code(const QuadK &k, const Lane &s) {
-    if (norm3(s.p) > k.fail_range32) return 1;
+    if (sumsq3(s.p) > k.fail_range_sq32) return 1;   // == sqrtf(sumsq) > fail_range32, see fold_config
     if (s.nv > k.fail_velocity) return 2;
     if (s.nw > k.fail_w) return 3;
     return 0;
@@ -439,6 +447,7 @@ struct StepIO {
     uint8_t *failed;       // [T][n] or null
 };
 
+template <bool SIMPLE>
 __global__ __launch_bounds__(BLOCK) void quadrotor_step_kernel(QuadK k, mg_quadrotor_state st, StepIO io,
                                                                int n, int n_steps) {
     __shared__ float tiles[WAVES_PER_BLOCK][mg::WAVE * (OBS_DIM + 1)];
@@ -469,7 +478,7 @@ __global__ __launch_bounds__(BLOCK) void quadrotor_step_kernel(QuadK k, mg_quadr
         int fail = 0;
         for (int it = 0; it < k.times; ++it) {                              // quadrotorsim.py:302-304
             if (fail == 0) {      // a failed env freezes at the failing sub-step (reference raises)
-                substep(k, s, eff32);
+                substep<SIMPLE>(k, s, eff32);
                 fail = failure_code(k, s);
             }
         }
@@ -551,37 +560,20 @@ __global__ __launch_bounds__(BLOCK) void quadrotor_reset_kernel(QuadK k, mg_quad
 
 // ---- host: fold the config into kernel constants ----------------------------------------------
 
-void host_inv3_f32(const float *A, float *Ainv) {
-    // same algorithm as the device inv3 (LU, partial pivoting), plain host code
-    float lu[9];
-    int piv[3] = {0, 1, 2};
-    for (int i = 0; i < 9; ++i) lu[i] = A[i];
-    for (int k = 0; k < 3; ++k) {
-        int p = k;
-        float best = fabsf(lu[3 * k + k]);
-        for (int r = k + 1; r < 3; ++r)
-            if (fabsf(lu[3 * r + k]) > best) { best = fabsf(lu[3 * r + k]); p = r; }
-        if (p != k) {
-            for (int c = 0; c < 3; ++c) { float t = lu[3 * k + c]; lu[3 * k + c] = lu[3 * p + c]; lu[3 * p + c] = t; }
-            int t = piv[k]; piv[k] = piv[p]; piv[p] = t;
-        }
-        float rcp = 1.0f / lu[3 * k + k];
-        for (int r = k + 1; r < 3; ++r) {
-            lu[3 * r + k] = lu[3 * r + k] * rcp;
-            for (int c = k + 1; c < 3; ++c) lu[3 * r + c] = lu[3 * r + c] - lu[3 * r + k] * lu[3 * k + c];
-        }
-    }
-    for (int col = 0; col < 3; ++col) {
-        float y[3];
-        for (int r = 0; r < 3; ++r) y[r] = (piv[r] == col) ? 1.0f : 0.0f;
-        for (int r = 1; r < 3; ++r)
-            for (int k = 0; k < r; ++k) y[r] = y[r] - lu[3 * r + k] * y[k];
-        for (int r = 2; r >= 0; --r) {
-            for (int k = r + 1; k < 3; ++k) y[r] = y[r] - lu[3 * r + k] * y[k];
-            y[r] = y[r] / lu[3 * r + r];
-        }
-        for (int r = 0; r < 3; ++r) Ainv[3 * r + col] = y[r];
-    }
+void host_inv3_f32(const float *Af, float *Ainv) {
+    // np.linalg.inv(self._inertia) quadrotorsim.py:64: f64 solve, cast back to f32 (see device inv3)
+    double A[9];
+    for (int i = 0; i < 9; ++i) A[i] = (double)Af[i];
+    const double c00 = A[4] * A[8] - A[5] * A[7], c01 = A[5] * A[6] - A[3] * A[8], c02 = A[3] * A[7] - A[4] * A[6];
+    const double det = (A[0] * c00 + A[1] * c01) + A[2] * c02;
+    const double r = 1.0 / det;
+    Ainv[0] = (float)(c00 * r); Ainv[3] = (float)(c01 * r); Ainv[6] = (float)(c02 * r);
+    Ainv[1] = (float)((A[2] * A[7] - A[1] * A[8]) * r);
+    Ainv[4] = (float)((A[0] * A[8] - A[2] * A[6]) * r);
+    Ainv[7] = (float)((A[1] * A[6] - A[0] * A[7]) * r);
+    Ainv[2] = (float)((A[1] * A[5] - A[2] * A[4]) * r);
+    Ainv[5] = (float)((A[2] * A[3] - A[0] * A[5]) * r);
+    Ainv[8] = (float)((A[0] * A[4] - A[1] * A[3]) * r);
 }
 
 int fold_config(const mg_quadrotor_config *c, QuadK *k) {
@@ -602,10 +594,18 @@ int fold_config(const mg_quadrotor_config *c, QuadK *k) {
     k->dt32 = (float)c->dt;
     k->zoff32 = (float)c->z_offset;
     k->healthy32 = (float)c->healthy_reward;
-    k->fail_range32 = (float)c->fail_range;
+    {
+        // np.linalg.norm(pos) > fail_range, both f32 (quadrotorsim.py:213). sqrtf is monotone and
+        // correctly rounded, so  sqrtf(s) > T  <=>  s > S  with S = max{ x : sqrtf(x) <= T }.
+        const float T = (float)c->fail_range;
+        float S = T * T;
+        while (sqrtf(S) > T) S = nextafterf(S, 0.0f);
+        while (sqrtf(nextafterf(S, INFINITY)) <= T) S = nextafterf(S, INFINITY);
+        k->fail_range_sq32 = S;
+    }
     for (int i = 0; i < 4; ++i) {
         const float *p = &c->prop_coord[3 * i];
-        k->lm[i] = sqrtf((p[0] * p[0] + p[1] * p[1]) + p[2] * p[2]);
+        k->lm[i] = sqrtf(fmaf(p[2], p[2], fmaf(p[1], p[1], p[0] * p[0])));
     }
     for (int i = 0; i < 12; ++i) k->pc[i] = c->prop_coord[i];
     host_inv3_f32(c->inertia, k->iinv);
@@ -640,6 +640,20 @@ int fold_config(const mg_quadrotor_config *c, QuadK *k) {
     return MG_OK;
 }
 
+// structure test for the SIMPLE kernel specialisation (see substep<>)
+bool config_is_simple(const mg_quadrotor_config *c) {
+    for (int r = 0; r < 3; ++r)
+        for (int col = 0; col < 3; ++col)
+            if (r != col && (c->drag_f[3 * r + col] != 0.0f || c->drag_m[3 * r + col] != 0.0f ||
+                             c->inertia[3 * r + col] != 0.0f))
+                return false;
+    for (int i = 0; i < 3; ++i)
+        if (c->gravity_center[i] != 0.0f) return false;
+    for (int i = 0; i < 4; ++i)
+        if (c->prop_coord[3 * i + 2] != 0.0f) return false;
+    return c->ct2 == 0.0;
+}
+
 int check_state(const mg_quadrotor_state *s) {
     if (!s->pos || !s->vel || !s->omega || !s->propw || !s->rot || !s->ct)
         return mg::set_error(MG_ERR_NULL_POINTER, "mg_quadrotor_state has a NULL array");
@@ -668,8 +682,12 @@ int launch_steps(const mg_quadrotor_config *cfg, int32_t n, int32_t n_steps, con
     }
     StepIO io{action, obs, reward, reward64, done, failed};
     const int grid = (n + BLOCK - 1) / BLOCK;
-    hipLaunchKernelGGL(quadrotor_step_kernel, dim3(grid), dim3(BLOCK), 0, (hipStream_t)stream, k, *state, io, n,
-                       n_steps);
+    if (config_is_simple(cfg))
+        hipLaunchKernelGGL(quadrotor_step_kernel<true>, dim3(grid), dim3(BLOCK), 0, (hipStream_t)stream, k, *state,
+                           io, n, n_steps);
+    else
+        hipLaunchKernelGGL(quadrotor_step_kernel<false>, dim3(grid), dim3(BLOCK), 0, (hipStream_t)stream, k, *state,
+                           io, n, n_steps);
     return mg::check_launch("quadrotor_step_kernel");
 }
 

@@ -23,10 +23,12 @@
  * dtype) while numpy scalars/arrays are strong. Every expression below is annotated with the dtype
  * NumPy evaluates it in. State dtypes after reset(): position f32, velocity f64, body rate f64,
  * propeller speed f32, rotation matrix f32 (quadrotorsim.py:20-28,239-258).
- * Compile with -ffp-contract=off: NumPy's elementwise ops never fuse a*b+c.
- * The two places that cannot be restated bit-for-bit are BLAS/LAPACK internals (np.matmul ->
- * OpenBLAS gemv/gemm summation order, np.linalg.inv -> sgesv) and libm's atan2f; they sit at the
- * 1-ulp level and are covered by the 1e-5 relative tolerance the north star states.
+ * Compile with -ffp-contract=off: NumPy's elementwise ops never fuse a*b+c; the FMAs that the
+ * BLAS-backed ops do use are written out explicitly (see the helpers below).
+ * What could not be restated bit-for-bit: the association OpenBLAS uses for the f32 3x3@3 gemv
+ * (only feeds the body-position observation) and libm's atan2f; both sit at the 1-ulp level and are
+ * covered by the 1e-5 relative tolerance the north star states. The simulator STATE (pos, vel,
+ * omega, propw, R) is bit-identical to the reference over the 1000-step golden rollouts.
  */
 #include <math.h>
 #include <stdint.h>
@@ -34,12 +36,19 @@
 
 #include "quadrotor_oracle.h"
 
-/* ---- small helpers, all without fused multiply-add -------------------------------------- */
+/* ---- small helpers ---------------------------------------------------------------------------
+ * NumPy's elementwise ops never fuse a*b+c, but np.matmul / np.linalg.norm go through OpenBLAS,
+ * whose x86-64 kernels do. The association used below for each BLAS-backed op is the one that
+ * reproduced NumPy 2.2.6 + its bundled OpenBLAS bit-for-bit on 1000/1000 random inputs in the
+ * build container (probe recorded in DESIGN.md §Oracle): sgemm 3x3@3x3 and dnrm via ddot are
+ * left-to-right FMA chains; dgemv on a widened f32 matrix is fma(M2,x2, fma(M0,x0, M1*x1)).
+ * The f32 3x3@3 product did not match any single FMA association (plain order matched most
+ * often, 64 %), so it is kept plain. All of this is at the 1-ulp level. */
 
 static void mat3_vec_f32f64(const float *M, const double *x, double *y) {
-    /* np.matmul(f32[3,3], f64[3]) -> f64: M is widened, plain dot, k = 0,1,2 */
+    /* np.matmul(f32[3,3], f64[3]) -> f64: M is widened, then dgemv */
     for (int r = 0; r < 3; ++r)
-        y[r] = ((double)M[3 * r + 0] * x[0] + (double)M[3 * r + 1] * x[1]) + (double)M[3 * r + 2] * x[2];
+        y[r] = fma((double)M[3 * r + 2], x[2], fma((double)M[3 * r + 0], x[0], (double)M[3 * r + 1] * x[1]));
 }
 
 static void mat3_vec_f32(const float *M, const float *x, float *y) {
@@ -50,7 +59,7 @@ static void mat3_vec_f32(const float *M, const float *x, float *y) {
 static void mat3_mul_f32(const float *A, const float *B, float *C) {
     for (int r = 0; r < 3; ++r)
         for (int c = 0; c < 3; ++c)
-            C[3 * r + c] = (A[3 * r + 0] * B[0 + c] + A[3 * r + 1] * B[3 + c]) + A[3 * r + 2] * B[6 + c];
+            C[3 * r + c] = fmaf(A[3 * r + 2], B[6 + c], fmaf(A[3 * r + 1], B[3 + c], A[3 * r + 0] * B[0 + c]));
 }
 
 static void cross_f32(const float *a, const float *b, float *c) {
@@ -63,43 +72,33 @@ static void cross_f32(const float *a, const float *b, float *c) {
     c[2] = t4 - t5;
 }
 
-static double norm3_f64(const double *x) { return sqrt((x[0] * x[0] + x[1] * x[1]) + x[2] * x[2]); }
-static float norm3_f32(const float *x) { return sqrtf((x[0] * x[0] + x[1] * x[1]) + x[2] * x[2]); }
+static double norm3_f64(const double *x) { return sqrt(fma(x[2], x[2], fma(x[1], x[1], x[0] * x[0]))); }
+static float norm3_f32(const float *x) { return sqrtf(fmaf(x[2], x[2], fmaf(x[1], x[1], x[0] * x[0]))); }
 
-/* General 3x3 float32 inverse, restating what np.linalg.inv does (LAPACK sgesv = LU with partial
- * pivoting, then solve against the identity), quadrotorsim.py:207. */
-void qo_inv3_f32(const float *A, float *Ainv) {
-    float lu[9];
-    int piv[3] = {0, 1, 2};
-    memcpy(lu, A, sizeof(lu));
-    for (int k = 0; k < 3; ++k) {
-        int p = k;
-        float best = fabsf(lu[3 * k + k]);
-        for (int r = k + 1; r < 3; ++r)
-            if (fabsf(lu[3 * r + k]) > best) { best = fabsf(lu[3 * r + k]); p = r; }
-        if (p != k) {
-            for (int c = 0; c < 3; ++c) { float t = lu[3 * k + c]; lu[3 * k + c] = lu[3 * p + c]; lu[3 * p + c] = t; }
-            int t = piv[k]; piv[k] = piv[p]; piv[p] = t;
-        }
-        float rcp = 1.0f / lu[3 * k + k];       /* sgetf2 scales the column by the reciprocal */
-        for (int r = k + 1; r < 3; ++r) {
-            lu[3 * r + k] = lu[3 * r + k] * rcp;
-            for (int c = k + 1; c < 3; ++c) lu[3 * r + c] = lu[3 * r + c] - lu[3 * r + k] * lu[3 * k + c];
-        }
-    }
-    for (int col = 0; col < 3; ++col) {
-        float y[3];
-        for (int r = 0; r < 3; ++r) y[r] = (piv[r] == col) ? 1.0f : 0.0f;
-        /* forward: L y' = y (unit lower) */
-        for (int r = 1; r < 3; ++r)
-            for (int k = 0; k < r; ++k) y[r] = y[r] - lu[3 * r + k] * y[k];
-        /* backward: U x = y' */
-        for (int r = 2; r >= 0; --r) {
-            for (int k = r + 1; k < 3; ++k) y[r] = y[r] - lu[3 * r + k] * y[k];
-            y[r] = y[r] / lu[3 * r + r];
-        }
-        for (int r = 0; r < 3; ++r) Ainv[3 * r + col] = y[r];
-    }
+/* 3x3 inverse of a float32 matrix (np.linalg.inv, quadrotorsim.py:207).
+ * numpy.linalg.inv does NOT run LAPACK in float32: linalg._commonType promotes float32 input to
+ * float64, calls dgesv, and casts the result back to float32. The f64 result carries ~1e-16 of
+ * error, so what reaches the caller is the correctly rounded float32 inverse (up to rare
+ * double-rounding ties). Restated as the closed form adjugate/det evaluated in float64 and
+ * rounded to float32: bit-identical to the reference on every sub-step of every golden rollout
+ * (tests/test_oracle_quadrotor.py). */
+void qo_inv3_f32(const float *Af, float *Ainv) {
+    double A[9];
+    for (int i = 0; i < 9; ++i) A[i] = (double)Af[i];
+    const double c00 = A[4] * A[8] - A[5] * A[7];
+    const double c01 = A[5] * A[6] - A[3] * A[8];
+    const double c02 = A[3] * A[7] - A[4] * A[6];
+    const double det = (A[0] * c00 + A[1] * c01) + A[2] * c02;
+    const double r = 1.0 / det;
+    Ainv[0] = (float)(c00 * r);
+    Ainv[3] = (float)(c01 * r);
+    Ainv[6] = (float)(c02 * r);
+    Ainv[1] = (float)((A[2] * A[7] - A[1] * A[8]) * r);
+    Ainv[4] = (float)((A[0] * A[8] - A[2] * A[6]) * r);
+    Ainv[7] = (float)((A[1] * A[6] - A[0] * A[7]) * r);
+    Ainv[2] = (float)((A[1] * A[5] - A[2] * A[4]) * r);
+    Ainv[5] = (float)((A[2] * A[3] - A[0] * A[5]) * r);
+    Ainv[8] = (float)((A[0] * A[4] - A[1] * A[3]) * r);
 }
 
 /* ---- constants -------------------------------------------------------------------------- */
