@@ -152,6 +152,96 @@ int mg_quadrotor_step_autoreset(const mg_quadrotor_config *cfg, int32_t n_envs, 
                                 const float *action, float *obs, float *reward, double *reward64,
                                 uint8_t *done, uint8_t *failed, void *stream);
 
+/* ========================================================================================
+ * MetaMaze — replaces metagym/metamaze/envs/{maze_base,maze_2d,maze_discrete_3d,
+ *            maze_continuous_3d,dynamics,ray_caster_utils}.py for N envs
+ * ======================================================================================== */
+
+enum { MG_MAZE_ESCAPE = 0, MG_MAZE_SURVIVAL = 1 };
+
+/* Task table: T TaskConfig tuples (maze_task.py:15-17) of identical size n x n, uploaded once by
+ * the caller; env e plays task task_id[e]. Grids are [T][n][n] with the reference's index order
+ * (first index = x). Read-only for the kernels. */
+typedef struct mg_maze_tasks {
+    int32_t n;                     /* cells per side */
+    int32_t n_tasks;               /* T */
+    const int32_t *start;          /* [T][2] */
+    const int32_t *goal;           /* [T][2] */
+    const int8_t *walls;           /* [T][n*n] cell_walls (0 free, 1 wall) */
+    const uint8_t *texts;          /* [T][n*n] cell_texts (0 ground, 1.. wall textures) */
+    const double *food_rewards;    /* [T][n*n] */
+    const int32_t *food_interval;  /* [T][n*n] */
+    const double *scalars;         /* [T][8]: cell_size, wall_height, agent_height, initial_life,
+                                      max_life, step_reward, goal_reward, (pad) */
+} mg_maze_tasks;
+
+/* Per-env episode state (MazeBase.reset maze_base.py:40-63 + the 3-D cores). SURVIVAL arrays are
+ * [n_envs][n*n] (one contiguous row per env: the 3-D kernel gives a workgroup to each env);
+ * they may be NULL for ESCAPE. */
+typedef struct mg_maze_state {
+    int32_t *task_id;     /* [N] index into the task table */
+    int32_t *grid;        /* [2][N] _agent_grid */
+    int32_t *steps;       /* [N] */
+    int32_t *ori_idx;     /* [N] discrete-3D heading index 0..3 (maze_discrete_3d.py:46-48) */
+    double *ori;          /* [N] continuous-3D heading, rad */
+    float *loc;           /* [2][N] continuous-3D location (float32 like the reference array) */
+    double *life;         /* [N] SURVIVAL */
+    double *cur_food;     /* [N][n*n] SURVIVAL _cur_food_rewards (also the translucent-cell map) */
+    uint8_t *wait_refresh;/* [N][n*n] SURVIVAL _food_wait_refresh (0/1) */
+    int32_t *revival;     /* [N][n*n] SURVIVAL _food_revival_count */
+} mg_maze_state;
+
+/* First-person renderer constants (MazeCoreDiscrete3D.__init__ maze_discrete_3d.py:18-37 and the
+ * call at :113-117) plus caller-prepared tables. */
+typedef struct mg_maze_view {
+    int32_t res_h, res_v;          /* resolution_horizon (image axis 0), resolution_vertical (axis 1) */
+    double max_vision;             /* 12.0 */
+    double l_focal;                /* 0.20 */
+    double text_size;              /* 1.0 */
+    double tan_half_fov;           /* numpy.tan(fol_angle / 2), fol_angle = 0.6 * 3.1415926 */
+    double collision_dist;         /* 0.20 (continuous dynamics) */
+    const double *col_cos;         /* DEVICE [res_h] cos_hp per screen column, see mg_maze_view_tables */
+    const double *col_sin;         /* DEVICE [res_h] sin_hp */
+    float ori_sin[4], ori_cos[4];  /* float32 sin/cos of the four discrete headings, computed by the
+                                      caller with float32 numpy ufuncs like the reference */
+    const uint32_t *textures;      /* DEVICE [n_textures][tex][tex] texels packed r | g<<8 | b<<16;
+                                      texture 0 = ground, 1.. = walls (maze_task.py:19-36) */
+    const uint32_t *ceil_texture;  /* DEVICE [tex][tex] */
+    int32_t n_textures, tex_size;
+} mg_maze_view;
+
+/* Host helper: the per-column tables of ray_caster_utils.py:82-90 (tan_hp accumulated column by
+ * column exactly like the reference loop). Writes res_h doubles to each HOST array; the caller
+ * uploads them and points col_cos / col_sin at the device copies. */
+int mg_maze_view_tables(int32_t res_h, double tan_half_fov, double l_focal, double *col_cos_host,
+                        double *col_sin_host);
+
+/* MazeBase.reset for the envs with mask[e] != 0 (NULL = all): agent to the task's start cell,
+ * heading 0, steps 0, SURVIVAL food/life restored. */
+int mg_maze_reset(const mg_maze_tasks *tasks, int32_t task_type, int32_t n_envs, const mg_maze_state *state,
+                  const uint8_t *mask, void *stream);
+
+/* MetaMaze2D.step (maze_env.py:189-204 -> maze_2d.py:21-34 + maze_base.py:65-95) and
+ * update_observation (maze_2d.py:89-121).
+ *   action i32 [N] in 0..3 (DISCRETE_ACTIONS maze_env.py:14); NULL = observe only (reset obs)
+ *   obs f32 [N][2v+1][2v+1]; reward f32 [N] (may be NULL), reward64 f64 [N] (may be NULL), done u8 [N].
+ * auto_reset != 0: an env whose step ended the episode is reset (same task) inside the launch and
+ * its obs row is the first observation of the next episode. */
+int mg_maze2d_step(const mg_maze_tasks *tasks, int32_t task_type, int32_t max_steps, int32_t view_grid,
+                   int32_t auto_reset, int32_t n_envs, const mg_maze_state *state, const int32_t *action,
+                   float *obs, float *reward, double *reward64, uint8_t *done, void *stream);
+
+/* MetaMazeDiscrete3D.step (maze_env.py:59-75 -> maze_discrete_3d.py:51-81) or, with
+ * continuous != 0, MetaMazeContinuous3D.step (maze_env.py:129-145 -> maze_continuous_3d.py:47-56 ->
+ * dynamics.py:71-92), then evaluation_rule and the first-person render (ray_caster_utils.py:66-209)
+ * with the SURVIVAL life bar (maze_discrete_3d.py:118-126).
+ *   action: discrete i32 [N] in 0..3; continuous f32 [N][2] (turn, walk); NULL = observe only
+ *   obs i32 [N][res_h][res_v][3] (values exceed 255, like the reference) */
+int mg_maze3d_step(const mg_maze_tasks *tasks, const mg_maze_view *view, int32_t task_type, int32_t max_steps,
+                   int32_t continuous, int32_t auto_reset, int32_t n_envs, const mg_maze_state *state,
+                   const void *action, int32_t *obs, float *reward, double *reward64, uint8_t *done,
+                   void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -47,6 +47,29 @@ class QuadrotorAutoReset(C.Structure):
                 ("seed", C.c_uint64), ("step_index", C.c_uint64)]
 
 
+class MazeTasks(C.Structure):
+    """mg_maze_tasks (device pointers)"""
+    _fields_ = [("n", C.c_int32), ("n_tasks", C.c_int32), ("start", C.c_void_p), ("goal", C.c_void_p),
+                ("walls", C.c_void_p), ("texts", C.c_void_p), ("food_rewards", C.c_void_p),
+                ("food_interval", C.c_void_p), ("scalars", C.c_void_p)]
+
+
+class MazeState(C.Structure):
+    """mg_maze_state (device pointers)"""
+    _fields_ = [("task_id", C.c_void_p), ("grid", C.c_void_p), ("steps", C.c_void_p), ("ori_idx", C.c_void_p),
+                ("ori", C.c_void_p), ("loc", C.c_void_p), ("life", C.c_void_p), ("cur_food", C.c_void_p),
+                ("wait_refresh", C.c_void_p), ("revival", C.c_void_p)]
+
+
+class MazeView(C.Structure):
+    """mg_maze_view"""
+    _fields_ = [("res_h", C.c_int32), ("res_v", C.c_int32), ("max_vision", C.c_double), ("l_focal", C.c_double),
+                ("text_size", C.c_double), ("tan_half_fov", C.c_double), ("collision_dist", C.c_double),
+                ("col_cos", C.c_void_p), ("col_sin", C.c_void_p), ("ori_sin", C.c_float * 4),
+                ("ori_cos", C.c_float * 4), ("textures", C.c_void_p), ("ceil_texture", C.c_void_p),
+                ("n_textures", C.c_int32), ("tex_size", C.c_int32)]
+
+
 # symbol -> (restype, argtypes); tests/test_abi.py checks this list against include/metagym_hip.h
 _P = C.c_void_p
 SIGNATURES = {
@@ -63,6 +86,12 @@ SIGNATURES = {
                                               _P, _P, _P, _P, _P, _P, _P]),
     "mg_quadrotor_rollout": (C.c_int, [C.POINTER(QuadrotorConfig), C.c_int32, C.c_int32,
                                        C.POINTER(QuadrotorState), _P, _P, _P, _P, _P, _P, _P]),
+    "mg_maze_view_tables": (C.c_int, [C.c_int32, C.c_double, C.c_double, _P, _P]),
+    "mg_maze_reset": (C.c_int, [C.POINTER(MazeTasks), C.c_int32, C.c_int32, C.POINTER(MazeState), _P, _P]),
+    "mg_maze2d_step": (C.c_int, [C.POINTER(MazeTasks), C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
+                                 C.POINTER(MazeState), _P, _P, _P, _P, _P, _P]),
+    "mg_maze3d_step": (C.c_int, [C.POINTER(MazeTasks), C.POINTER(MazeView), C.c_int32, C.c_int32, C.c_int32,
+                                 C.c_int32, C.c_int32, C.POINTER(MazeState), _P, _P, _P, _P, _P, _P]),
 }
 
 _lib = None

@@ -1,0 +1,844 @@
+// maze.hip — batched MetaMaze engine for gfx950.
+//
+// Replaces, for N environments per launch, the reference's per-object Python/numba hot path
+// (paths relative to metagym/metamaze/envs):
+//   MazeBase.reset / evaluation_rule          maze_base.py:40-63, :65-95        (reset_env, eval_*)
+//   MazeCore2D.do_action / update_observation maze_2d.py:21-34, :89-121         (maze2d_step_kernel)
+//   MazeCoreDiscrete3D.turn / move            maze_discrete_3d.py:51-72         (transition_discrete)
+//   vector_move_with_collision & friends      dynamics.py:17-92                 (transition_continuous)
+//   DDA_2D / maze_view                        ray_caster_utils.py:11-62, :66-209 (column_pass, pixel_pass)
+//   life bar overlay                          maze_discrete_3d.py:118-126       (pixel_pass)
+//
+// Design (MI355X)
+//   * 2-D maze: integer grid logic + a (2v+1)^2 window -> one lane per env, SoA state.
+//   * 3-D mazes: the cost is the first-person image (12*H*V bytes of int32 per env-step, 786 KB at
+//     256x256), so one 256-thread workgroup renders one env. The task's wall / texture-id /
+//     translucency grids are staged in LDS. Rendering is two passes per wave over its 64 screen
+//     columns: (A) lane = column: column direction table + DDA grid traversal, results (wall span,
+//     texture row, fog, the ordered list of translucent cells crossed) parked in wave-private LDS;
+//     (B) lane = screen row: for each of the 64 columns every lane shades one pixel — floor or
+//     ceiling cast, wall overwrite, translucent blends in ray order — and the wave stores 64
+//     consecutive int32x3 pixels (768 contiguous bytes) per instruction. The reference paints
+//     floor, ceiling, walls and overlays in four sequential sweeps over an int32 frame buffer;
+//     because every sweep only touches the pixel it is visiting, the per-pixel composition here
+//     performs the same operations in the same order and is bit-identical.
+//   * Arithmetic mirrors numba's typing of the reference (float64 everywhere except the float32
+//     column tables and texture values; every frame-buffer store truncates toward zero); the file
+//     is compiled with -ffp-contract=off. Divisions by cell_size / text_size / text-to-cell ratio
+//     become multiplications only when the divisor is a power of two (bit-identical).
+//   * No MFMA (no contraction), no atomics, no inter-workgroup communication.
+#include "mg_common.h"
+
+namespace {
+
+constexpr int MZ_BLOCK = 256;
+constexpr int MZ_WAVES = MZ_BLOCK / mg::WAVE;
+
+// ------------------------------------------------------------------------------------------------
+// task / state access
+// ------------------------------------------------------------------------------------------------
+
+struct Task {   // one row of the task table, resolved for an env
+    int n, nn;
+    const int8_t *walls;
+    const uint8_t *texts;
+    const double *food;
+    const int32_t *interval;
+    int sx, sy, gx, gy;
+    double cell_size, wall_h, agent_h, init_life, max_life, step_reward, goal_reward;
+};
+
+__device__ __forceinline__ Task load_task(const mg_maze_tasks &T, int tid) {
+    Task t;
+    t.n = T.n;
+    t.nn = T.n * T.n;
+    const size_t off = (size_t)tid * t.nn;
+    t.walls = T.walls + off;
+    t.texts = T.texts + off;
+    t.food = T.food_rewards ? T.food_rewards + off : nullptr;
+    t.interval = T.food_interval ? T.food_interval + off : nullptr;
+    t.sx = T.start[2 * tid];
+    t.sy = T.start[2 * tid + 1];
+    t.gx = T.goal[2 * tid];
+    t.gy = T.goal[2 * tid + 1];
+    const double *s = T.scalars + (size_t)tid * 8;
+    t.cell_size = s[0]; t.wall_h = s[1]; t.agent_h = s[2]; t.init_life = s[3];
+    t.max_life = s[4]; t.step_reward = s[5]; t.goal_reward = s[6];
+    return t;
+}
+
+struct Agent {   // scalar per-env state
+    int gx, gy, steps, ori_idx;
+    double ori, life;
+    float lx, ly;
+};
+
+__device__ __forceinline__ Agent load_agent(const mg_maze_state &st, int n_envs, int e) {
+    Agent a;
+    a.gx = st.grid[e];
+    a.gy = st.grid[n_envs + e];
+    a.steps = st.steps[e];
+    a.ori_idx = st.ori_idx ? st.ori_idx[e] : 0;
+    a.ori = st.ori ? st.ori[e] : 0.0;
+    a.lx = st.loc ? st.loc[e] : 0.0f;
+    a.ly = st.loc ? st.loc[n_envs + e] : 0.0f;
+    a.life = st.life ? st.life[e] : 0.0;
+    return a;
+}
+
+__device__ __forceinline__ void store_agent(const mg_maze_state &st, int n_envs, int e, const Agent &a) {
+    st.grid[e] = a.gx;
+    st.grid[n_envs + e] = a.gy;
+    st.steps[e] = a.steps;
+    if (st.ori_idx) st.ori_idx[e] = a.ori_idx;
+    if (st.ori) st.ori[e] = a.ori;
+    if (st.loc) { st.loc[e] = a.lx; st.loc[n_envs + e] = a.ly; }
+    if (st.life) st.life[e] = a.life;
+}
+
+// MazeBase.reset maze_base.py:40-63 — scalar part
+__device__ __forceinline__ void reset_agent(const Task &t, int task_type, Agent &a) {
+    a.gx = t.sx;
+    a.gy = t.sy;
+    a.lx = (float)(t.sx * t.cell_size + 0.5 * t.cell_size);   // get_cell_center maze_base.py:194-197
+    a.ly = (float)(t.sy * t.cell_size + 0.5 * t.cell_size);
+    a.ori = 0.0;
+    a.ori_idx = 0;
+    a.steps = 0;
+    if (task_type == MG_MAZE_SURVIVAL) a.life = t.init_life;
+}
+
+// MazeBase.reset — per-cell part (SURVIVAL), cells c = first, first+stride, ...
+__device__ __forceinline__ void reset_cells(const Task &t, const mg_maze_state &st, int e, int first, int stride) {
+    const size_t base = (size_t)e * t.nn;
+    for (int c = first; c < t.nn; c += stride) {
+        st.wait_refresh[base + c] = 0;
+        st.cur_food[base + c] = t.food[c];
+        st.revival[base + c] = t.interval[c];
+    }
+}
+
+// evaluation_rule maze_base.py:65-95 — scalar part. Returns done; touches the agent's cell only.
+__device__ __forceinline__ int eval_scalar(const Task &t, const mg_maze_state &st, int e, int task_type,
+                                           int max_steps, Agent &a, double &reward) {
+    a.steps += 1;
+    if (task_type == MG_MAZE_SURVIVAL) {
+        const size_t g = (size_t)e * t.nn + (size_t)a.gx * t.n + a.gy;
+        double r = 0.0;
+        const double f = st.cur_food[g];
+        if (f > 1.0e-2) {                                   // :71-75
+            r = f;
+            st.wait_refresh[g] = 1;
+            st.cur_food[g] = 0.0;
+        }
+        a.life += r + t.step_reward;                        // :78
+        if (t.max_life < a.life) a.life = t.max_life;       // :79
+        reward = r;
+        return (a.life < 0.0) || (a.steps > max_steps - 1); // :80, :191-192
+    }
+    const int goal = (t.gx == a.gx) && (t.gy == a.gy);
+    reward = t.step_reward + goal * t.goal_reward;          // :92
+    return goal || (a.steps > max_steps - 1);
+}
+
+// evaluation_rule :83-88 — food revival over the cells c = first, first+stride, ...
+__device__ __forceinline__ void eval_cells(const Task &t, const mg_maze_state &st, int e, int first, int stride) {
+    const size_t base = (size_t)e * t.nn;
+    for (int c = first; c < t.nn; c += stride) {
+        int rv = st.revival[base + c] - (int)st.wait_refresh[base + c];
+        if (rv < 0) {
+            st.cur_food[base + c] = t.food[c];
+            rv = t.interval[c];
+            st.wait_refresh[base + c] = 0;
+        }
+        st.revival[base + c] = rv;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// MetaMaze2D: one lane per env
+// ------------------------------------------------------------------------------------------------
+
+__global__ __launch_bounds__(MZ_BLOCK) void maze2d_step_kernel(mg_maze_tasks T, mg_maze_state st, int task_type,
+                                                               int max_steps, int vg, int auto_reset, int n_envs,
+                                                               const int32_t *action, float *obs, float *reward,
+                                                               double *reward64, uint8_t *done) {
+    const int e = blockIdx.x * MZ_BLOCK + threadIdx.x;
+    if (e >= n_envs) return;
+    const Task t = load_task(T, st.task_id[e]);
+    Agent a = load_agent(st, n_envs, e);
+    if (action != nullptr) {
+        const int act = action[e] & 3;
+        // DISCRETE_ACTIONS maze_env.py:14 = [(-1,0),(1,0),(0,-1),(0,1)]; maze_2d.py:24-29
+        const int ti = a.gx + (act == 0 ? -1 : (act == 1 ? 1 : 0));
+        const int tj = a.gy + (act == 2 ? -1 : (act == 3 ? 1 : 0));
+        const int wi = ti < 0 ? ti + t.n : ti, wj = tj < 0 ? tj + t.n : tj;   // python negative index
+        if (wi < t.n && wj < t.n && t.walls[wi * t.n + wj] < 1) { a.gx = ti; a.gy = tj; }
+        double r;
+        int d = eval_scalar(t, st, e, task_type, max_steps, a, r);
+        if (task_type == MG_MAZE_SURVIVAL) eval_cells(t, st, e, 0, 1);
+        if (reward) reward[e] = (float)r;
+        if (reward64) reward64[e] = r;
+        done[e] = (uint8_t)d;
+        if (d && auto_reset) {
+            reset_agent(t, task_type, a);
+            if (task_type == MG_MAZE_SURVIVAL) reset_cells(t, st, e, 0, 1);
+        }
+        store_agent(st, n_envs, e, a);
+    }
+    // update_observation maze_2d.py:89-121
+    const int w = 2 * vg + 1;
+    float *o = obs + (size_t)e * w * w;
+    const size_t base = (size_t)e * t.nn;
+    for (int p = 0; p < w; ++p)
+        for (int q = 0; q < w; ++q) {
+            const int x = a.gx - vg + p, y = a.gy - vg + q;
+            float v = -1.0f;
+            if (x >= 0 && x < t.n && y >= 0 && y < t.n) {
+                v = (float)(-(int)t.walls[x * t.n + y]);                                   // :113
+                if (task_type == MG_MAZE_SURVIVAL) v = (float)((double)v + st.cur_food[base + x * t.n + y]);  // :117
+                else v = (float)((double)v + ((x == t.gx && y == t.gy) ? 1.0 : 0.0));       // :120
+            }
+            o[p * w + q] = v;
+        }
+    if (task_type == MG_MAZE_SURVIVAL) o[vg * w + vg] = (float)a.life;                      // :118
+}
+
+// ------------------------------------------------------------------------------------------------
+// 3-D transitions (executed by one thread of the env's workgroup)
+// ------------------------------------------------------------------------------------------------
+
+__device__ __forceinline__ void transition_discrete(const Task &t, int act, Agent &a) {
+    const int turn = act == 0 ? -1 : (act == 1 ? 1 : 0);      // maze_env.py:14
+    const int step = act == 2 ? -1 : (act == 3 ? 1 : 0);
+    a.ori_idx = (a.ori_idx + turn) & 3;                        // maze_discrete_3d.py:69-72
+    int g0 = a.gx, g1 = a.gy;                                  // :51-67
+    if (a.ori_idx == 0) g0 += step;
+    else if (a.ori_idx == 1) g1 += step;
+    else if (a.ori_idx == 2) g0 -= step;
+    else g1 -= step;
+    if (g0 >= 0 && g0 < t.n && g1 >= 0 && g1 < t.n && t.walls[g0 * t.n + g1] == 0) { a.gx = g0; a.gy = g1; }
+}
+
+__device__ __forceinline__ float nearest_point(const float *pos, const float *l1, const float *l2, float *np_out) {
+    // dynamics.py:17-29
+    float u0 = l2[0] - l1[0], u1 = l2[1] - l1[1];
+    const float edge_norm = sqrtf(u0 * u0 + u1 * u1);
+    const double m = (1.0e-6 > (double)edge_norm) ? 1.0e-6 : (double)edge_norm;
+    u0 = (float)((double)u0 / m);
+    u1 = (float)((double)u1 / m);
+    const float dist_1 = (pos[0] - l1[0]) * u0 + (pos[1] - l1[1]) * u1;
+    float p0, p1;
+    if (dist_1 > edge_norm) { p0 = l2[0]; p1 = l2[1]; }
+    else if (dist_1 < 0) { p0 = l1[0]; p1 = l1[1]; }
+    else { p0 = l1[0] + dist_1 * u0; p1 = l1[1] + dist_1 * u1; }
+    const float d0 = pos[0] - p0, d1 = pos[1] - p1;
+    np_out[0] = p0;
+    np_out[1] = p1;
+    return sqrtf(d0 * d0 + d1 * d1);
+}
+
+__device__ __forceinline__ void collision_force(const float *dv, double cell_size, double col_dist, float *out) {
+    // dynamics.py:32-56
+    const double dist = (double)sqrtf(dv[0] * dv[0] + dv[1] * dv[1]);
+    const double eff = col_dist / cell_size;
+    out[0] = out[1] = 0.0f;
+    if (dist > 0.708 + eff) return;
+    if (fabsf(dv[0]) < 0.5f && fabsf(dv[1]) < 0.5f) {
+        const double mx = dist > 1.0e-6 ? dist : 1.0e-6;
+        const float k = (float)(0.50 / mx * (0.708 + eff - dist) * cell_size);
+        out[0] = k * dv[0];
+        out[1] = k * dv[1];
+        return;
+    }
+    const bool x_pos = (dv[0] + dv[1]) > 0, y_pos = (dv[1] - dv[0]) > 0;
+    const float A[2] = {0.5f, 0.5f}, B[2] = {-0.5f, 0.5f}, C[2] = {-0.5f, -0.5f}, D[2] = {0.5f, -0.5f};
+    float np_[2], d;
+    if (x_pos && y_pos) d = nearest_point(dv, A, B, np_);
+    else if (!x_pos && y_pos) d = nearest_point(dv, B, C, np_);
+    else if (!x_pos && !y_pos) d = nearest_point(dv, C, D, np_);
+    else d = nearest_point(dv, D, A, np_);
+    if (eff < (double)d) return;
+    float o0 = dv[0] - np_[0], o1 = dv[1] - np_[1];
+    const float on = sqrtf(o0 * o0 + o1 * o1);
+    const double r = 1.0 / ((1.0e-6 > (double)on) ? 1.0e-6 : (double)on);
+    o0 = (float)((double)o0 * r);
+    o1 = (float)((double)o1 * r);
+    const float k = (float)(0.50 * (eff - (double)d) * cell_size);
+    out[0] = k * o0;
+    out[1] = k * o1;
+}
+
+__device__ __forceinline__ void transition_continuous(const Task &t, double col_dist, float turn, float walk,
+                                                      Agent &a) {
+    // maze_continuous_3d.py:47-56 + dynamics.py:59-92
+    const double PI = 3.1415926, t_PI = 6.2831852;
+    const double tr = (double)turn, ws = (double)walk;
+    const double turn_rate = (tr < -1 ? -1 : (tr > 1 ? 1 : tr)) * PI;
+    double walk_speed = ws < -1 ? -1 : (ws > 1 ? 1 : ws);
+    if (walk_speed < 0) walk_speed *= 0.50;
+    double ori = a.ori;
+    float p0 = a.lx, p1 = a.ly;
+    const float cs32 = (float)t.cell_size;
+    for (int it = 0; it < 10; ++it) {   // int(100 * 0.10)
+        double fin = ori + turn_rate * 0.01;
+        const double off_ori = 0.5 * (fin + ori);
+        const double off = walk_speed * 0.01;
+        const float d_x = (float)(cos(off_ori) * off), d_y = (float)(sin(off_ori) * off);
+        while (fin > t_PI) fin -= t_PI;
+        while (fin < 0) fin += t_PI;
+        ori = fin;
+        const float e0 = p0 + d_x, e1 = p1 + d_y;
+        const float c0 = e0 / cs32, c1 = e1 / cs32;
+        float col0 = 0.0f, col1 = 0.0f;
+        for (int i = -1; i < 2; ++i)
+            for (int j = -1; j < 2; ++j) {
+                const int w_i = i + (int)c0, w_j = j + (int)c1;
+                if (w_i > -1 && w_i < t.n && w_j > -1 && w_j < t.n && t.walls[w_i * t.n + w_j] > 0) {
+                    float cd[2], f[2];
+                    cd[0] = (c0 - floorf(c0)) - ((float)i + 0.5f);
+                    cd[1] = (c1 - floorf(c1)) - ((float)j + 0.5f);
+                    collision_force(cd, t.cell_size, col_dist, f);
+                    col0 += f[0];
+                    col1 += f[1];
+                }
+            }
+        p0 = col0 + e0;
+        p1 = col1 + e1;
+    }
+    a.ori = ori;
+    a.lx = p0;
+    a.ly = p1;
+    a.gx = (int)(p0 / cs32);   // get_loc_grid maze_base.py:199-202
+    a.gy = (int)(p1 / cs32);
+}
+
+// ------------------------------------------------------------------------------------------------
+// renderer
+// ------------------------------------------------------------------------------------------------
+
+struct ViewK {
+    int H, V, TS, t_max;
+    double max_vision, l_focal, text_size, inv_text_size, half_h, half_v, pixel_size;
+    double col_dist;
+    int text_size_pow2;
+    const double *col_cos, *col_sin;
+    float ori_sin[4], ori_cos[4];
+    const uint32_t *tex, *ceil_tex;
+};
+
+// int(x) truncation with python's unbounded ints replaced by clamping outside [lo-1, hi+1]
+__device__ __forceinline__ int to_int_clamped(double x, int lo, int hi) {
+    if (!(x > (double)lo - 1.0)) return lo;
+    if (x >= (double)hi + 1.0) return hi + 1;
+    return (int)x;
+}
+
+struct EnvShared {   // one per workgroup, LDS
+    Agent a;
+    double reward;
+    int done;
+    double pos[2], s_ori, c_ori;
+};
+
+// per-wave column records (pass A -> pass B), struct-of-arrays over the wave's 64 columns
+struct WaveCols {
+    float cos_hp[64], cos_abs[64], sin_abs[64];
+    double w_oma[64];      // 1 - alpha of the wall hit
+    double w_ratio[64];    // hit_dist * cos_hp / l_focal
+    double w_light[64];    // |cos| or |sin| (float32 value widened)
+    int w_tex[64];         // texel offset of (texture id, texture row)
+    int w_span[64];        // v_s | v_e << 16   (v_s >= v_e: no wall / beyond max_vision)
+    int n_tr[64];          // number of translucent records
+};
+
+// Pass A, lane = screen column: ray_caster_utils.py:84-90 (direction tables), :11-62 (DDA_2D) and the
+// per-column parts of :155-205.
+__device__ void column_pass(const ViewK &vk, const Task &t, const EnvShared &es, const int8_t *walls,
+                            const uint8_t *texts, const double *transp, int col, int lane, WaveCols &wc,
+                            uint2 *entries /* [t_max][64] */, double cs, double inv_cs, int cs_pow2) {
+    const int n = t.n;
+    const double chp = vk.col_cos[col], shp = vk.col_sin[col];
+    const float sin_abs = (float)(shp * es.c_ori + chp * es.s_ori);
+    const float cos_abs = (float)(chp * es.c_ori - shp * es.s_ori);
+    const float cos_hp = (float)chp;
+    wc.cos_hp[lane] = cos_hp;
+    wc.cos_abs[lane] = cos_abs;
+    wc.sin_abs[lane] = sin_abs;
+
+    const double vh = t.agent_h, ceil_h = t.wall_h;
+    const double px0 = es.pos[0], px1 = es.pos[1];
+    const int i0 = (int)(cs_pow2 ? px0 * inv_cs : px0 / cs), j0 = (int)(cs_pow2 ? px1 * inv_cs : px1 / cs);
+    const double c = (double)cos_abs, s = (double)sin_abs;
+    const bool cz = fabs(c) < 1.0e-6, sz = fabs(s) < 1.0e-6;
+    const double delta_x = cz ? 1.0e+6 : fabs(cs / c);
+    const double delta_y = sz ? 1.0e+6 : fabs(cs / s);
+    const double d_x = c > 0 ? ((i0 + 1) * cs - px0) : (i0 * cs - px0);
+    const double d_y = s > 0 ? ((j0 + 1) * cs - px1) : (j0 * cs - px1);
+    double side_x = cz ? 1.0e+6 : d_x / c;
+    double side_y = sz ? 1.0e+6 : d_y / s;
+    const int di = c > 0 ? 1 : -1, dj = s > 0 ? 1 : -1;
+    int hi = i0, hj = j0, side = 0, n_tr = 0;
+    double hit_dist = 0.0;
+
+    // translucent record: screen span of the cell boundary at distance `dist` (:195-203)
+    auto add_record = [&](double dist, int cell) {
+        if (n_tr >= vk.t_max) return;
+        const double r2 = dist * (double)cos_hp / vk.l_focal;
+        const double tv = (ceil_h - vh) / r2, bv = vh / r2;
+        int s2 = to_int_clamped((vk.half_v - tv) / vk.pixel_size, 0, vk.V);
+        int e2 = to_int_clamped((vk.half_v + bv) / vk.pixel_size, -1, vk.V - 1);
+        if (s2 < 0) s2 = 0;
+        if (e2 > vk.V) e2 = vk.V;
+        entries[n_tr * 64 + lane] = make_uint2((unsigned)s2 | ((unsigned)e2 << 16), (unsigned)cell);
+        ++n_tr;
+    };
+
+    if (hi >= 0 && hi < n && hj >= 0 && hj < n && transp[hi * n + hj] > 0.01)   // :25-29
+        add_record(side_x < side_y ? side_x : side_y, hi * n + hj);
+    while (hit_dist < vk.max_vision) {                                           // :31-61
+        const bool xs = side_x < side_y;
+        if (xs) { hi += di; side_y -= side_x; hit_dist += side_x; }
+        else { hj += dj; side_x -= side_y; hit_dist += side_y; }
+        if (hi < 0 || hi >= n) {
+            if (hj < 0 || hj >= n) { hit_dist = 1.0e+6; break; }
+        } else if (hj >= 0 && hj < n) {
+            const int cell = hi * n + hj;
+            if (transp[cell] > 0.01) add_record(hit_dist, cell);
+            if (walls[cell] > 0) { side = xs ? 0 : 1; break; }
+        }
+        if (xs) side_x = delta_x;
+        else side_y = delta_y;
+    }
+
+    int span = 0;   // empty
+    double oma = 0.0, ratio = 1.0, light = 0.0;
+    int texoff = 0;
+    const int ci = hi < 0 ? hi + n : hi, cj = hj < 0 ? hj + n : hj;
+    if (!(hit_dist > vk.max_vision) && ci >= 0 && ci < n && cj >= 0 && cj < n) {   // :160-161
+        double alpha = 2.0 * hit_dist / vk.max_vision - 1.0;
+        alpha = alpha > 0.0 ? alpha : 0.0;
+        alpha = alpha < 1.0 ? alpha : 1.0;
+        oma = 1.0 - alpha;
+        const int text_id = texts[ci * n + cj];
+        const double hpx = hit_dist * c + px0, hpy = hit_dist * s + px1;
+        double local_h = side == 0 ? hpy : hpx;                                    // :166-173
+        local_h = cs_pow2 ? local_h * inv_cs : local_h / cs;
+        local_h -= floor(local_h);
+        light = (double)fabsf(side == 0 ? cos_abs : sin_abs);
+        ratio = hit_dist * (double)cos_hp / vk.l_focal;                            // :175
+        const double top_v = (ceil_h - vh) / ratio, bot_v = vh / ratio;
+        int v_s = to_int_clamped((vk.half_v - top_v) / vk.pixel_size, 0, vk.V);
+        int v_e = to_int_clamped((vk.half_v + bot_v) / vk.pixel_size, -1, vk.V - 1);
+        if (v_s < 0) v_s = 0;
+        if (v_e > vk.V) v_e = vk.V;
+        span = v_s | (v_e << 16);
+        double d_i = vk.text_size_pow2 ? local_h * vk.inv_text_size : local_h / vk.text_size;   // :184-188
+        d_i -= floor(d_i);
+        const int ti = (int)(vk.TS * d_i);
+        texoff = (text_id * vk.TS + ti) * vk.TS;
+    } else {
+        n_tr = 0;   // `continue` at :160-161 also skips the overlays of this column
+    }
+    wc.w_oma[lane] = oma;
+    wc.w_ratio[lane] = ratio;
+    wc.w_light[lane] = light;
+    wc.w_tex[lane] = texoff;
+    wc.w_span[lane] = span;
+    wc.n_tr[lane] = n_tr;
+}
+
+struct RowK {   // per-lane constants of a screen row (they do not depend on the column)
+    int kind;   // 0 untouched, 1 floor, 2 ceiling
+    double distance, light, ys;
+};
+
+__device__ __forceinline__ RowK row_constants(const ViewK &vk, const Task &t, int d_v) {
+    RowK r;
+    r.kind = 0;
+    r.distance = 0.0;
+    r.light = 0.0;
+    const double yc = (d_v + 0.5) * vk.pixel_size;
+    r.ys = vk.half_v - yc;                                     // used by the wall texture lookup (:182)
+    if (d_v > vk.V / 2) {                                      // floor rows :95-101
+        const double v_screen = yc - vk.half_v;
+        r.distance = t.agent_h / v_screen * vk.l_focal;
+        r.light = v_screen / vk.l_focal;
+        r.kind = r.distance > vk.max_vision ? 0 : 1;
+    } else if (d_v < vk.V / 2) {                               // ceiling rows :129-134
+        const double v_screen = vk.half_v - yc;
+        r.distance = (t.wall_h - t.agent_h) / v_screen * vk.l_focal;
+        r.light = v_screen / vk.l_focal;
+        r.kind = r.distance > vk.max_vision ? 0 : 2;
+    }
+    return r;
+}
+
+// Pass B, lane = screen row d_v, for screen column `col` (slot `k` of the wave's 64): the floor /
+// ceiling cast (:102-126 / :135-153), then the wall column (:181-192), then the translucent
+// overlays in ray order (:194-205), then the life bar (maze_discrete_3d.py:118-126).
+__device__ __forceinline__ void pixel_pass(const ViewK &vk, const Task &t, const EnvShared &es, const RowK &rk,
+                                           const uint8_t *texts, const double *transp, const WaveCols &wc,
+                                           const uint2 *entries, int k, int d_v, double cs, double inv_cs,
+                                           int cs_pow2, double text_to_cell, double inv_ttc, int ttc_pow2,
+                                           int &R, int &G, int &B) {
+    const int n = t.n, TS = vk.TS;
+    R = G = B = 0;
+    bool tflag = false;
+    if (rk.kind != 0) {
+        const double eff = rk.distance / (double)wc.cos_hp[k];
+        double a = 2.0 * eff / vk.max_vision - 1.0;
+        a = a > 0.0 ? a : 0.0;
+        a = a < 1.0 ? a : 1.0;
+        const double hit_x = eff * (double)wc.cos_abs[k] + es.pos[0];
+        const double hit_y = eff * (double)wc.sin_abs[k] + es.pos[1];
+        const double fi = cs_pow2 ? hit_x * inv_cs : hit_x / cs;
+        const double fj = cs_pow2 ? hit_y * inv_cs : hit_y / cs;
+        const int i = to_int_clamped(fi, -2, n + 1), j = to_int_clamped(fj, -2, n + 1);
+        const bool inside = i < n && i >= 0 && j < n && j >= 0;
+        if (rk.kind == 1) {
+            if (inside) {
+                const double alpha = a * rk.light;
+                double d_i = fi - floor(fi), d_j = fj - floor(fj);
+                d_i = ttc_pow2 ? d_i * inv_ttc : d_i / text_to_cell;
+                d_j = ttc_pow2 ? d_j * inv_ttc : d_j / text_to_cell;
+                d_i -= floor(d_i);
+                d_j -= floor(d_j);
+                d_i *= TS;
+                d_j *= TS;
+                const uint32_t tx = vk.tex[((int)texts[i * n + j] * TS + (int)d_i) * TS + (int)d_j];
+                const double oma = 1.0 - alpha;
+                R = (int)(rk.light * (oma * (double)(tx & 255u)));
+                G = (int)(rk.light * (oma * (double)((tx >> 8) & 255u)));
+                B = (int)(rk.light * (oma * (double)((tx >> 16) & 255u)));
+                const double tr = transp[i * n + j];
+                if (tr > 0.01) {
+                    const double tf = tr * 0.50 + 0.10, om = 1.0 - tf;
+                    R = (int)(om * (double)R);
+                    G = (int)(om * (double)G + tf * 255.0);
+                    B = (int)(om * (double)B);
+                    tflag = true;
+                }
+            }
+        } else {
+            const double gi = vk.text_size_pow2 ? hit_x * vk.inv_text_size : hit_x / vk.text_size;
+            const double gj = vk.text_size_pow2 ? hit_y * vk.inv_text_size : hit_y / vk.text_size;
+            double d_i = gi - floor(gi), d_j = gj - floor(gj);
+            d_i *= TS;
+            d_j *= TS;
+            const uint32_t tx = vk.ceil_tex[(int)d_i * TS + (int)d_j];
+            const double oma = 1.0 - a;
+            R = (int)(rk.light * (oma * (double)(tx & 255u)));
+            G = (int)(rk.light * (oma * (double)((tx >> 8) & 255u)));
+            B = (int)(rk.light * (oma * (double)((tx >> 16) & 255u)));
+            if (inside) {
+                const double tr = transp[i * n + j];
+                if (tr > 0) {
+                    const double tf = tr * 0.50 + 0.10, om = 1.0 - tf;
+                    R = (int)(om * (double)R);
+                    G = (int)(om * (double)G + tf * 255.0);
+                    B = (int)(om * (double)B);
+                    tflag = true;
+                }
+            }
+        }
+    }
+    const int span = wc.w_span[k];
+    if (d_v >= (span & 0xffff) && d_v < (span >> 16)) {                       // :181-192
+        const double local_v = rk.ys * wc.w_ratio[k] + t.agent_h;
+        double d_j = vk.text_size_pow2 ? local_v * vk.inv_text_size : local_v / vk.text_size;
+        d_j -= floor(d_j);
+        const uint32_t tx = vk.tex[wc.w_tex[k] + (int)(TS * d_j)];
+        const double oma = wc.w_oma[k], light = wc.w_light[k];
+        R = (int)(light * (oma * (double)(tx & 255u)));
+        G = (int)(light * (oma * (double)((tx >> 8) & 255u)));
+        B = (int)(light * (oma * (double)((tx >> 16) & 255u)));
+    }
+    const int n_tr = wc.n_tr[k];
+    for (int q = 0; q < n_tr; ++q) {                                          // :194-205
+        const uint2 en = entries[q * 64 + k];
+        if (!tflag && d_v >= (int)(en.x & 0xffffu) && d_v < (int)(en.x >> 16)) {
+            const double tf = transp[en.y] * 0.50 + 0.10, om = 1.0 - tf;
+            R = (int)(om * (double)R);
+            G = (int)(om * (double)G + tf * 255.0);
+            B = (int)(om * (double)B);
+        }
+    }
+}
+
+__device__ __forceinline__ void py_slice(long a, long b, long len, int &lo, int &hi) {
+    if (a < 0) { a += len; if (a < 0) a = 0; } else if (a > len) a = len;
+    if (b < 0) { b += len; if (b < 0) b = 0; } else if (b > len) b = len;
+    lo = (int)a;
+    hi = (int)b;
+}
+
+struct int3s { int x, y, z; };   // 12-byte pixel, stored with one dwordx3
+
+__global__ __launch_bounds__(MZ_BLOCK) void maze3d_step_kernel(mg_maze_tasks T, mg_maze_state st, ViewK vk,
+                                                               int task_type, int max_steps, int continuous,
+                                                               int auto_reset, int n_envs, const void *action,
+                                                               int32_t *obs, float *reward, double *reward64,
+                                                               uint8_t *done) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int e = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const Task t = load_task(T, st.task_id[e]);
+    const int nn = t.nn;
+
+    // ---- LDS carve-up ---------------------------------------------------------------------------
+    EnvShared *es = reinterpret_cast<EnvShared *>(smem);
+    size_t off = (sizeof(EnvShared) + 15) & ~size_t(15);
+    double *transp = reinterpret_cast<double *>(smem + off);
+    off += sizeof(double) * nn;
+    WaveCols *wcs = reinterpret_cast<WaveCols *>(smem + off);
+    off += sizeof(WaveCols) * MZ_WAVES;
+    uint2 *entries_all = reinterpret_cast<uint2 *>(smem + off);
+    off += sizeof(uint2) * 64 * vk.t_max * MZ_WAVES;
+    int8_t *walls = reinterpret_cast<int8_t *>(smem + off);
+    off += (nn + 15) & ~15;
+    uint8_t *texts = reinterpret_cast<uint8_t *>(smem + off);
+
+    // ---- phase 0: transition + scalar part of evaluation_rule (one thread) ----------------------
+    if (tid == 0) {
+        Agent a = load_agent(st, n_envs, e);
+        es->done = 0;
+        es->reward = 0.0;
+        if (action != nullptr) {
+            if (continuous) {
+                const float *ac = static_cast<const float *>(action) + 2 * (size_t)e;
+                transition_continuous(t, vk.col_dist, ac[0], ac[1], a);
+            } else {
+                transition_discrete(t, static_cast<const int32_t *>(action)[e] & 3, a);
+            }
+            double r;
+            es->done = eval_scalar(t, st, e, task_type, max_steps, a, r);
+            es->reward = r;
+            if (reward) reward[e] = (float)r;
+            if (reward64) reward64[e] = r;
+            done[e] = (uint8_t)es->done;
+        }
+        es->a = a;
+    }
+    __syncthreads();
+    if (action != nullptr && task_type == MG_MAZE_SURVIVAL) eval_cells(t, st, e, tid, MZ_BLOCK);   // :83-88
+    if (es->done && auto_reset) {
+        if (task_type == MG_MAZE_SURVIVAL) reset_cells(t, st, e, tid, MZ_BLOCK);
+        __syncthreads();
+        if (tid == 0) reset_agent(t, task_type, es->a);
+    }
+    __syncthreads();
+    if (tid == 0) {
+        Agent &a = es->a;
+        if (action != nullptr) store_agent(st, n_envs, e, a);
+        if (continuous) {
+            es->pos[0] = (double)a.lx;
+            es->pos[1] = (double)a.ly;
+            es->s_ori = sin(a.ori);
+            es->c_ori = cos(a.ori);
+        } else {
+            es->pos[0] = a.gx * t.cell_size + 0.5 * t.cell_size;   // get_cell_center
+            es->pos[1] = a.gy * t.cell_size + 0.5 * t.cell_size;
+            es->s_ori = (double)vk.ori_sin[a.ori_idx];
+            es->c_ori = (double)vk.ori_cos[a.ori_idx];
+        }
+    }
+    // ---- phase 1: stage the task grids in LDS -----------------------------------------------------
+    for (int c = tid; c < nn; c += MZ_BLOCK) {
+        walls[c] = t.walls[c];
+        texts[c] = t.texts[c];
+        if (task_type == MG_MAZE_SURVIVAL) transp[c] = st.cur_food[(size_t)e * nn + c];   // alias maze_base.py:57
+        else transp[c] = (c == t.gx * t.n + t.gy) ? 1.0 : 0.0;                            // :59-60
+    }
+    __syncthreads();
+
+    // ---- phase 2: render ---------------------------------------------------------------------------
+    const double cs = t.cell_size;
+    int ex;
+    const int cs_pow2 = (frexp(cs, &ex) == 0.5);
+    const double inv_cs = 1.0 / cs;
+    const double text_to_cell = vk.text_size / cs;
+    const int ttc_pow2 = (frexp(text_to_cell, &ex) == 0.5);
+    const double inv_ttc = 1.0 / text_to_cell;
+
+    int lb_x0 = 0, lb_x1 = 0, lb_y0 = 0, lb_y1 = 0;   // life bar rectangle, maze_discrete_3d.py:118-126
+    if (task_type == MG_MAZE_SURVIVAL) {
+        const double lifebar_l = es->a.life / t.max_life * (0.80 * vk.V);
+        const double sx = 0.10 * vk.V, sy = 0.10 * vk.V;
+        py_slice((long)sx, (long)(sx + lifebar_l), vk.H, lb_x0, lb_x1);
+        py_slice((long)sy, (long)(sy + 0.05 * vk.H), vk.V, lb_y0, lb_y1);
+    }
+
+    WaveCols &wc = wcs[wave];
+    uint2 *entries = entries_all + (size_t)wave * 64 * vk.t_max;
+    int32_t *img = obs + (size_t)e * vk.H * vk.V * 3;
+    for (int cbase = wave * 64; cbase < vk.H; cbase += MZ_BLOCK) {
+        const int ncols = min(64, vk.H - cbase);
+        if (lane < ncols)
+            column_pass(vk, t, *es, walls, texts, transp, cbase + lane, lane, wc, entries, cs, inv_cs, cs_pow2);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        for (int rbase = 0; rbase < vk.V; rbase += 64) {
+            const int d_v = rbase + lane;
+            const bool row_ok = d_v < vk.V;
+            const RowK rk = row_constants(vk, t, row_ok ? d_v : 0);
+            const bool in_lb_y = d_v >= lb_y0 && d_v < lb_y1;
+            for (int k = 0; k < ncols; ++k) {
+                int R, G, B;
+                pixel_pass(vk, t, *es, rk, texts, transp, wc, entries, k, d_v, cs, inv_cs, cs_pow2, text_to_cell,
+                           inv_ttc, ttc_pow2, R, G, B);
+                const int col = cbase + k;
+                if (in_lb_y && col >= lb_x0 && col < lb_x1) { R = 255; G = 0; B = 0; }
+                if (row_ok) {
+                    int3s px{R, G, B};
+                    *reinterpret_cast<int3s *>(img + ((size_t)col * vk.V + d_v) * 3) = px;
+                }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+__global__ __launch_bounds__(MZ_BLOCK) void maze_reset_kernel(mg_maze_tasks T, mg_maze_state st, int task_type,
+                                                              int n_envs, const uint8_t *mask) {
+    // one wave per env so the SURVIVAL cell arrays are written coalesced
+    const int e = (blockIdx.x * MZ_BLOCK + threadIdx.x) >> 6;
+    const int lane = threadIdx.x & 63;
+    if (e >= n_envs) return;
+    if (mask != nullptr && mask[e] == 0) return;
+    const Task t = load_task(T, st.task_id[e]);
+    if (task_type == MG_MAZE_SURVIVAL) reset_cells(t, st, e, lane, 64);
+    if (lane == 0) {
+        Agent a = load_agent(st, n_envs, e);
+        reset_agent(t, task_type, a);
+        store_agent(st, n_envs, e, a);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------------
+
+int check_tasks(const mg_maze_tasks *T, int task_type) {
+    if (T->n < 3 || T->n > 255 || T->n_tasks < 1) return mg::set_error(MG_ERR_BAD_SIZE, "maze n=%d n_tasks=%d", T->n, T->n_tasks);
+    if (!T->start || !T->goal || !T->walls || !T->texts || !T->scalars)
+        return mg::set_error(MG_ERR_NULL_POINTER, "mg_maze_tasks has a NULL array");
+    if (task_type == MG_MAZE_SURVIVAL && (!T->food_rewards || !T->food_interval))
+        return mg::set_error(MG_ERR_NULL_POINTER, "SURVIVAL needs food_rewards and food_interval");
+    if (task_type != MG_MAZE_SURVIVAL && task_type != MG_MAZE_ESCAPE)
+        return mg::set_error(MG_ERR_BAD_CONFIG, "task_type %d", task_type);
+    return MG_OK;
+}
+
+int check_mstate(const mg_maze_state *s, int task_type) {
+    if (!s->task_id || !s->grid || !s->steps) return mg::set_error(MG_ERR_NULL_POINTER, "mg_maze_state has a NULL array");
+    if (task_type == MG_MAZE_SURVIVAL && (!s->life || !s->cur_food || !s->wait_refresh || !s->revival))
+        return mg::set_error(MG_ERR_NULL_POINTER, "SURVIVAL needs life / cur_food / wait_refresh / revival");
+    return MG_OK;
+}
+
+}  // namespace
+
+extern "C" int mg_maze_view_tables(int32_t res_h, double tan_half_fov, double l_focal, double *col_cos,
+                                   double *col_sin) {
+    MG_REQUIRE_PTR(col_cos);
+    MG_REQUIRE_PTR(col_sin);
+    if (res_h <= 0) return mg::set_error(MG_ERR_BAD_SIZE, "res_h=%d", res_h);
+    // ray_caster_utils.py:68-90, host doubles (sqrt and / are correctly rounded like numpy's)
+    const double half_h = tan_half_fov * l_focal;
+    const double pixel_size = 2.0 * half_h / res_h;
+    const double pixel_factor = pixel_size / l_focal;
+    double tan_hp = (-0.5 - res_h / 2.0) * pixel_factor;
+    for (int d_h = 0; d_h < res_h; ++d_h) {
+        tan_hp += pixel_factor;
+        const double chp = sqrt(1.0 / (1.0 + tan_hp * tan_hp));
+        col_cos[d_h] = chp;
+        col_sin[d_h] = tan_hp * chp;
+    }
+    return MG_OK;
+}
+
+extern "C" int mg_maze_reset(const mg_maze_tasks *T, int32_t task_type, int32_t n, const mg_maze_state *st,
+                             const uint8_t *mask, void *stream) {
+    MG_REQUIRE_PTR(T);
+    MG_REQUIRE_PTR(st);
+    if (n <= 0) return mg::set_error(MG_ERR_BAD_SIZE, "n_envs=%d", n);
+    if (int rc = check_tasks(T, task_type)) return rc;
+    if (int rc = check_mstate(st, task_type)) return rc;
+    const long threads = (long)n * 64;
+    hipLaunchKernelGGL(maze_reset_kernel, dim3((unsigned)((threads + MZ_BLOCK - 1) / MZ_BLOCK)), dim3(MZ_BLOCK), 0,
+                       (hipStream_t)stream, *T, *st, task_type, n, mask);
+    return mg::check_launch("maze_reset_kernel");
+}
+
+extern "C" int mg_maze2d_step(const mg_maze_tasks *T, int32_t task_type, int32_t max_steps, int32_t view_grid,
+                              int32_t auto_reset, int32_t n, const mg_maze_state *st, const int32_t *action,
+                              float *obs, float *reward, double *reward64, uint8_t *done, void *stream) {
+    MG_REQUIRE_PTR(T);
+    MG_REQUIRE_PTR(st);
+    MG_REQUIRE_PTR(obs);
+    if (action != nullptr) MG_REQUIRE_PTR(done);
+    if (n <= 0 || view_grid < 0) return mg::set_error(MG_ERR_BAD_SIZE, "n_envs=%d view_grid=%d", n, view_grid);
+    if (int rc = check_tasks(T, task_type)) return rc;
+    if (int rc = check_mstate(st, task_type)) return rc;
+    hipLaunchKernelGGL(maze2d_step_kernel, dim3((n + MZ_BLOCK - 1) / MZ_BLOCK), dim3(MZ_BLOCK), 0, (hipStream_t)stream,
+                       *T, *st, task_type, max_steps, view_grid, auto_reset, n, action, obs, reward, reward64, done);
+    return mg::check_launch("maze2d_step_kernel");
+}
+
+extern "C" int mg_maze3d_step(const mg_maze_tasks *T, const mg_maze_view *view, int32_t task_type, int32_t max_steps,
+                              int32_t continuous, int32_t auto_reset, int32_t n, const mg_maze_state *st,
+                              const void *action, int32_t *obs, float *reward, double *reward64, uint8_t *done,
+                              void *stream) {
+    MG_REQUIRE_PTR(T);
+    MG_REQUIRE_PTR(view);
+    MG_REQUIRE_PTR(st);
+    MG_REQUIRE_PTR(obs);
+    if (action != nullptr) MG_REQUIRE_PTR(done);
+    if (n <= 0) return mg::set_error(MG_ERR_BAD_SIZE, "n_envs=%d", n);
+    if (int rc = check_tasks(T, task_type)) return rc;
+    if (int rc = check_mstate(st, task_type)) return rc;
+    if (continuous && (!st->ori || !st->loc)) return mg::set_error(MG_ERR_NULL_POINTER, "continuous needs ori / loc");
+    if (!continuous && !st->ori_idx) return mg::set_error(MG_ERR_NULL_POINTER, "discrete needs ori_idx");
+    if (view->res_h <= 0 || view->res_v <= 0 || view->res_v > 32767 || view->res_h > 32767)
+        return mg::set_error(MG_ERR_BAD_SIZE, "resolution %d x %d", view->res_h, view->res_v);
+    if (!view->col_cos || !view->col_sin || !view->textures || !view->ceil_texture)
+        return mg::set_error(MG_ERR_NULL_POINTER, "mg_maze_view has a NULL table");
+    if (view->tex_size <= 0 || view->n_textures <= 0) return mg::set_error(MG_ERR_BAD_SIZE, "texture table");
+
+    ViewK vk;
+    vk.H = view->res_h;
+    vk.V = view->res_v;
+    vk.TS = view->tex_size;
+    vk.max_vision = view->max_vision;
+    vk.l_focal = view->l_focal;
+    vk.text_size = view->text_size;
+    vk.inv_text_size = 1.0 / view->text_size;
+    int ex;
+    vk.text_size_pow2 = (frexp(view->text_size, &ex) == 0.5);
+    vk.half_h = view->tan_half_fov * view->l_focal;              // ray_caster_utils.py:68
+    vk.half_v = vk.half_h * vk.V / vk.H;                         // :69
+    vk.pixel_size = 2.0 * vk.half_h / vk.H;                      // :70
+    vk.col_dist = view->collision_dist;
+    vk.col_cos = view->col_cos;
+    vk.col_sin = view->col_sin;
+    for (int i = 0; i < 4; ++i) { vk.ori_sin[i] = view->ori_sin[i]; vk.ori_cos[i] = view->ori_cos[i]; }
+    vk.tex = view->textures;
+    vk.ceil_tex = view->ceil_texture;
+    // bound on translucent records per ray: one per DDA step plus the start cell. A ray advances
+    // at least one cell per step and stops at max_vision or at the maze border.
+    vk.t_max = 2 * T->n + 1;
+    const size_t lds = ((sizeof(EnvShared) + 15) & ~size_t(15)) + sizeof(double) * T->n * T->n +
+                       sizeof(WaveCols) * MZ_WAVES + sizeof(uint2) * 64 * vk.t_max * MZ_WAVES +
+                       2 * ((size_t)(T->n * T->n + 15) & ~size_t(15));
+    if (lds > 160 * 1024) return mg::set_error(MG_ERR_BAD_SIZE, "maze n=%d needs %zu B of LDS (> 160 KiB)", T->n, lds);
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(maze3d_step_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return mg::check_hip(e, "hipFuncSetAttribute(maze3d_step_kernel)");
+    }
+    hipLaunchKernelGGL(maze3d_step_kernel, dim3(n), dim3(MZ_BLOCK), lds, (hipStream_t)stream, *T, *st, vk, task_type,
+                       max_steps, continuous, auto_reset, n, action, obs, reward, reward64, done);
+    return mg::check_launch("maze3d_step_kernel");
+}

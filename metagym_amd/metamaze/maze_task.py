@@ -1,0 +1,182 @@
+"""Host-side task generation for MetaMaze (the reference's L0 layer, metagym/metamaze/envs/maze_task.py).
+
+`TaskConfig` has exactly the reference's fields (maze_task.py:15-17) so task objects are
+interchangeable: a TaskConfig sampled by the reference can be handed to these envs and vice versa.
+
+`MazeTaskSampler` is a from-scratch generator with the same knobs and the same statistical
+structure (odd-cell lattice, spanning-tree corridors, optional loop digging down to `crowd_ratio`,
+random wall textures, sparse food) driven by a private numpy RandomState; it does NOT reproduce the
+reference's python-`random` stream (task generation stays host-side and is not
+part of the parity contract — parity tests feed both sides the same TaskConfig).
+
+Textures: the reference ships seven 64x64 PNGs. `MazeTaskManager(texture_dir=...)` loads any
+directory with the same naming rule (file names containing 'ground' / 'wall' / 'ceil', sorted);
+without one, deterministic procedural textures of the same shape are generated.
+"""
+import os
+from collections import namedtuple
+
+import numpy as np
+
+TaskConfig = namedtuple("TaskConfig", ["start", "goal", "cell_walls", "cell_texts", "cell_size", "wall_height",
+                                       "agent_height", "initial_life", "max_life", "step_reward", "goal_reward",
+                                       "food_rewards", "food_interval"])
+
+
+def _procedural_textures(n_walls=6, size=64):
+    rs = np.random.RandomState(20260925)
+    yy, xx = np.mgrid[0:size, 0:size]
+
+    def noise(scale):
+        return rs.randint(-scale, scale + 1, size=(size, size, 1))
+
+    texs = []
+    ground = 120 + noise(25) + ((xx // 16 + yy // 16) % 2 * 14)[..., None]
+    texs.append(np.repeat(ground, 3, axis=2))
+    palettes = [(150, 60, 50), (60, 80, 160), (130, 130, 120), (70, 120, 60), (170, 90, 60), (120, 60, 110)]
+    for k in range(n_walls):
+        base = np.array(palettes[k % len(palettes)])[None, None, :]
+        brick_h, brick_w = 8 + 2 * (k % 3), 16 + 4 * (k % 2)
+        row = yy // brick_h
+        mortar = ((yy % brick_h) == 0) | (((xx + (row % 2) * (brick_w // 2)) % brick_w) == 0)
+        t = base + noise(18)
+        t = np.where(mortar[..., None], 200 + noise(10), t)
+        texs.append(t)
+    grounds = np.clip(np.stack(texs), 0, 252).astype(np.uint8)
+    ceil = np.clip(np.array([110, 80, 50])[None, None, :] + noise(12) + ((xx // 8) % 2 * 18)[..., None], 0, 255)
+    return grounds, ceil.astype(np.uint8)
+
+
+def _load_texture_dir(texture_dir):
+    """Same selection rule as MazeTaskManager.__init__ (maze_task.py:19-36); images are returned in
+    pygame's surfarray convention (axis 0 = x)."""
+    from PIL import Image
+
+    def load(path):
+        im = Image.open(path).convert("RGB")
+        return np.transpose(np.asarray(im, dtype=np.uint8), (1, 0, 2)).copy()
+
+    grounds, ceil = [None], None
+    for name in sorted(os.listdir(texture_dir)):
+        path = os.path.join(texture_dir, name)
+        if name.find("wall") >= 0:
+            grounds.append(load(path))
+        if name.find("ground") >= 0:
+            grounds[0] = load(path)
+        if name.find("ceil") >= 0:
+            ceil = load(path)
+    if grounds[0] is None or ceil is None or len(grounds) < 2:
+        raise ValueError("texture dir %r needs ground*, wall* and ceil* images" % texture_dir)
+    return np.stack(grounds).astype(np.uint8), ceil
+
+
+class MazeTaskManager(object):
+    TaskConfig = TaskConfig
+
+    def __init__(self, texture_dir=None, verbose=False):
+        if texture_dir is None:
+            texture_dir = os.environ.get("METAGYM_MAZE_TEXTURES")
+        if texture_dir:
+            g, c = _load_texture_dir(texture_dir)
+        else:
+            g, c = _procedural_textures()
+        self.set_textures(g, c)
+        self.verbose = verbose
+        self._rs = np.random.RandomState()
+
+    def set_textures(self, grounds_u8, ceil_u8):
+        """grounds [n_texts, S, S, 3] uint8 (index 0 = floor), ceil [S, S, 3] uint8."""
+        g = np.ascontiguousarray(grounds_u8, dtype=np.uint8)
+        c = np.ascontiguousarray(ceil_u8, dtype=np.uint8)
+        assert g.ndim == 4 and g.shape[1] == g.shape[2] and g.shape[3] == 3
+        assert c.shape == g.shape[1:]
+        self.grounds = g.astype(np.float32)     # the reference keeps float32 (maze_task.py:36)
+        self.ceil = c
+        self.version = getattr(self, "version", 0) + 1
+
+    @property
+    def n_texts(self):
+        return self.grounds.shape[0]
+
+    def packed_textures(self):
+        """uint32 texels r | g<<8 | b<<16 for the device: ([n_texts,S,S], [S,S])."""
+        g = self.grounds.astype(np.uint32)
+        c = self.ceil.astype(np.uint32)
+        return (g[..., 0] | (g[..., 1] << 8) | (g[..., 2] << 16)).astype(np.uint32), \
+               (c[..., 0] | (c[..., 1] << 8) | (c[..., 2] << 16)).astype(np.uint32)
+
+    def seed(self, seed=None):
+        self._rs = np.random.RandomState(seed)
+
+    def sample_task(self, n=15, allow_loops=True, cell_size=2.0, wall_height=3.2, agent_height=1.6,
+                    step_reward=-0.01, goal_reward=None, food_reward=0.50, initial_life=1.0, max_life=2.0,
+                    food_density=0.010, food_interval=100, crowd_ratio=0.0, seed=None):
+        """Same signature as the reference sampler (maze_task.py:41-54) plus `seed`."""
+        assert n > 6, "Minimum required cells are 7"
+        assert n % 2 != 0, "Cell Numbers can only be odd"
+        rs = self._rs if seed is None else np.random.RandomState(seed)
+        m = (n - 1) // 2                                   # corridor lattice is m x m odd cells
+        walls = np.ones((n, n), dtype=np.int32)
+        walls[1::2, 1::2] = 0
+        texts = rs.randint(1, self.n_texts, size=(n, n))
+
+        # start / goal on odd cells, goal at least 0.45 n away when possible
+        sx, sy = (int(v) * 2 + 1 for v in rs.randint(0, m, size=2))
+        goal = (n - 2, n - 2)
+        for _ in range(m * m):
+            ex, ey = (int(v) * 2 + 1 for v in rs.randint(0, m, size=2))
+            if np.sqrt((ex - sx) ** 2 + (ey - sy) ** 2) > 0.45 * n:
+                goal = (ex, ey)
+                break
+
+        # spanning tree over the odd-cell lattice (randomised Kruskal with union-find)
+        parent = list(range(m * m))
+
+        def find(a):
+            while parent[a] != a:
+                parent[a] = parent[parent[a]]
+                a = parent[a]
+            return a
+
+        edges = [(i, j, 0) for i in range(m - 1) for j in range(m)] + [(i, j, 1) for i in range(m) for j in range(m - 1)]
+        order = rs.permutation(len(edges))
+        unused = []
+        for k in order:
+            i, j, d = edges[k]
+            a, b = i * m + j, (i + 1) * m + j if d == 0 else i * m + j + 1
+            ra, rb = find(a), find(b)
+            wall = (2 * i + 2, 2 * j + 1) if d == 0 else (2 * i + 1, 2 * j + 2)
+            if ra != rb:
+                parent[ra] = rb
+                walls[wall] = 0
+            else:
+                unused.append(wall)
+        if allow_loops:
+            # dig further walls (lattice edges first, then pillars) until the interior wall share
+            # drops to crowd_ratio; crowd_ratio=0 yields the reference's open room
+            interior = (n - 2) * (n - 2)
+            pillars = [(i, j) for i in range(2, n - 1, 2) for j in range(2, n - 1, 2)]
+            rs.shuffle(pillars)
+            for wall in unused + pillars:
+                if walls[1:-1, 1:-1].sum() <= interior * crowd_ratio:
+                    break
+                walls[wall] = 0
+        texts[1:-1, 1:-1][walls[1:-1, 1:-1] < 1] = 0        # corridors get the ground texture
+
+        assert step_reward < 0, "step_reward must be < 0"
+        def_goal_reward = -np.sqrt(n) * n * step_reward if goal_reward is None else goal_reward
+        assert def_goal_reward > 0, "goal reward must be > 0"
+
+        food = np.clip(rs.rand(n, n) * food_reward, 0.10, food_reward) * (1.0 - walls)
+        exp_food = (n - 1) * (n - 1) * food_density
+        while food.sum() > exp_food:
+            food = food * (rs.rand(n, n) < 0.90).astype("float32")
+        interval = food_interval * (food > 1.0e-3).astype("int32")
+        return TaskConfig(start=(sx, sy), goal=goal, cell_walls=walls, cell_texts=texts, cell_size=cell_size,
+                          step_reward=step_reward, goal_reward=def_goal_reward, wall_height=wall_height,
+                          agent_height=agent_height, initial_life=initial_life, max_life=max_life,
+                          food_rewards=food, food_interval=interval)
+
+
+MAZE_TASK_MANAGER = MazeTaskManager()
+MazeTaskSampler = MAZE_TASK_MANAGER.sample_task

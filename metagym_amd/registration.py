@@ -23,3 +23,13 @@ def make(id, **kwargs):
 register("quadrotor-v0", "metagym_amd.quadrotor:Quadrotor",
          kwargs={"dt": 0.01, "nt": 1000, "seed": 0, "task": "no_collision", "map_file": None,
                  "simulator_conf": None, "healthy_reward": 1.0})
+
+# metagym/metamaze/__init__.py:21-54 (enable_render defaults to False here: there is no viewer)
+register("meta-maze-continuous-3D-v0", "metagym_amd.metamaze:MetaMazeContinuous3D",
+         kwargs={"enable_render": False, "render_scale": 480, "resolution": (256, 256), "max_steps": 5000,
+                 "task_type": "SURVIVAL"})
+register("meta-maze-discrete-3D-v0", "metagym_amd.metamaze:MetaMazeDiscrete3D",
+         kwargs={"enable_render": False, "render_scale": 480, "resolution": (256, 256), "max_steps": 200,
+                 "task_type": "SURVIVAL"})
+register("meta-maze-2D-v0", "metagym_amd.metamaze:MetaMaze2D",
+         kwargs={"enable_render": False, "max_steps": 200, "view_grid": 1, "task_type": "SURVIVAL"})

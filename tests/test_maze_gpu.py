@@ -1,0 +1,268 @@
+"""Parity of the HIP MetaMaze kernels (through the C ABI / metagym_amd.metamaze) against
+  (a) the golden vectors recorded from the unmodified reference (tests/golden/maze*.npz): transitions,
+      reward (f64), done, steps, life and EVERY pixel of the recorded frames bit-exact for the
+      2-D and discrete 3-D mazes; continuous 3-D within 1e-5 / >= 99.9 % identical pixels, and
+  (b) the CPU oracle (oracle/maze_oracle.c) on batches of random tasks and actions.
+GPU box only (-m gpu)."""
+import glob
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import maze as mo
+
+pytestmark = pytest.mark.gpu
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def _files(pattern):
+    return sorted(glob.glob(os.path.join(GOLDEN, pattern)))
+
+
+def _tt(path):
+    return "SURVIVAL" if "survival" in os.path.basename(path) else "ESCAPE"
+
+
+@pytest.fixture(scope="module", autouse=True)
+def reference_textures():
+    """Render with the reference's textures (committed as uint8 in maze_textures.npz)."""
+    from metagym_amd.metamaze import MAZE_TASK_MANAGER
+    tex = np.load(os.path.join(GOLDEN, "maze_textures.npz"))
+    MAZE_TASK_MANAGER.set_textures(tex["grounds"], tex["ceil"])
+    yield
+
+
+def _task_from_golden(g):
+    from metagym_amd.metamaze import TaskConfig
+    return TaskConfig(**{k[5:]: (tuple(int(x) for x in g[k]) if k[5:] in ("start", "goal") else
+                                 (g[k] if g[k].ndim else g[k].item())) for k in g.files if k.startswith("task_")})
+
+
+def _replay(env, g, continuous=False):
+    """Drive a 1-env batch with the golden action stream, yield per-step outputs."""
+    env.set_task(_task_from_golden(g))
+    obs0 = env.reset().cpu().numpy()[0]
+    out = []
+    for t, a in enumerate(g["actions"]):
+        if g["reset_before"][t]:
+            env.reset()
+        act = torch.as_tensor(np.asarray(a)[None], dtype=torch.float32 if continuous else torch.int32)
+        obs, rew, done, info = env.step(act)
+        out.append(dict(obs=obs, reward=float(env.reward64[0]), done=bool(done[0]), steps=int(info["steps"][0]),
+                        grid=env.grid[:, 0].cpu().numpy(), life=float(env.life[0]), ori_idx=int(env.ori_idx[0]),
+                        ori=float(env.ori[0]), loc=env.loc[:, 0].cpu().numpy()))
+        out[-1]["obs_np"] = obs[0].cpu().numpy() if t in set(g["obs_step"].tolist()) else None
+    return obs0, out
+
+
+@pytest.mark.parametrize("path", _files("maze2d_*.npz"))
+def test_maze2d_matches_reference_bit_exact(path):
+    import metagym_amd
+    g = np.load(path)
+    env = metagym_amd.make("meta-maze-2D-v0", num_envs=1, device="cuda:0", max_steps=int(g["max_steps"]),
+                           view_grid=int(g["view_grid"]), task_type=_tt(path))
+    obs0, out = _replay(env, g)
+    assert np.array_equal(obs0, g["obs0"])
+    oi = 0
+    for t, o in enumerate(out):
+        assert list(o["grid"]) == list(g["grid"][t]), t
+        assert o["reward"] == g["reward"][t] and o["done"] == bool(g["done"][t]) and o["steps"] == g["steps"][t], t
+        if _tt(path) == "SURVIVAL":
+            assert o["life"] == g["life"][t], t
+        if o["obs_np"] is not None:
+            assert np.array_equal(o["obs_np"], g["obs"][oi]), t
+            oi += 1
+    assert oi == len(g["obs_step"])
+
+
+@pytest.mark.parametrize("path", _files("maze3d_disc_*.npz"))
+def test_maze3d_discrete_matches_reference_pixel_exact(path):
+    import metagym_amd
+    g = np.load(path)
+    res = tuple(int(x) for x in g["resolution"])
+    env = metagym_amd.make("meta-maze-discrete-3D-v0", num_envs=1, device="cuda:0", max_steps=int(g["max_steps"]),
+                           resolution=res, task_type=_tt(path))
+    obs0, out = _replay(env, g)
+    assert obs0.dtype == np.int32 and obs0.shape == res + (3,)
+    assert np.array_equal(obs0, g["obs0"]), "reset frame: %d values differ" % int((obs0 != g["obs0"]).sum())
+    oi = 0
+    for t, o in enumerate(out):
+        assert list(o["grid"]) == list(g["grid"][t]) and o["ori_idx"] == g["ori_idx"][t], t
+        assert o["reward"] == g["reward"][t] and o["done"] == bool(g["done"][t]) and o["steps"] == g["steps"][t], t
+        if _tt(path) == "SURVIVAL":
+            assert o["life"] == g["life"][t], t
+        if o["obs_np"] is not None:
+            bad = int((o["obs_np"] != g["obs"][oi]).sum())
+            assert bad == 0, "step %d: %d differing values, max |d| %d" % (t, bad, int(np.abs(o["obs_np"] - g["obs"][oi]).max()))
+            oi += 1
+    assert oi == len(g["obs_step"])
+
+
+@pytest.mark.parametrize("path", _files("maze3d_cont_*.npz"))
+def test_maze3d_continuous_matches_reference(path):
+    import metagym_amd
+    g = np.load(path)
+    res = tuple(int(x) for x in g["resolution"])
+    env = metagym_amd.make("meta-maze-continuous-3D-v0", num_envs=1, device="cuda:0", max_steps=int(g["max_steps"]),
+                           resolution=res, task_type=_tt(path))
+    obs0, out = _replay(env, g, continuous=True)
+    assert np.array_equal(obs0, g["obs0"])
+    oi, bad, total, worst = 0, 0, 0, 0
+    for t, o in enumerate(out):
+        assert list(o["grid"]) == list(g["grid"][t]), t
+        assert o["reward"] == g["reward"][t] and o["done"] == bool(g["done"][t]), t
+        assert np.allclose(o["loc"], g["loc"][t], rtol=1e-5, atol=1e-5), t        # north-star 1e-5
+        assert abs(o["ori"] - g["ori"][t]) <= 1e-5 * max(1.0, abs(g["ori"][t])), t
+        if o["obs_np"] is not None:
+            diff = o["obs_np"] != g["obs"][oi]
+            bad += int(diff.sum())
+            total += diff.size
+            if diff.any():
+                worst = max(worst, int(np.abs(o["obs_np"] - g["obs"][oi]).max()))
+            oi += 1
+    print(os.path.basename(path), "mismatching values %d / %d, max |d| %d" % (bad, total, worst))
+    assert bad <= 1e-3 * total
+
+
+# ---- batches against the oracle -------------------------------------------------------------------
+
+def _oracle_batch(tasks, task_ids, tt):
+    otasks = [mo.Task(**t._asdict()) for t in tasks]
+    states = [mo.State(otasks[i]) for i in task_ids]
+    for s, i in zip(states, task_ids):
+        mo.reset(otasks[i], tt, s)
+    return otasks, states
+
+
+def test_maze2d_batch_matches_oracle():
+    """BASELINE config C1 scaled out: 15x15 mazes, 8 tasks, 3000 envs (ragged), 80 steps with
+    masked resets of finished envs; everything bit-exact."""
+    import metagym_amd
+    from metagym_amd.metamaze import MazeTaskSampler
+    for task_type in ("ESCAPE", "SURVIVAL"):
+        tt = mo.TASK_TYPES[task_type]
+        tasks = [MazeTaskSampler(n=15, allow_loops=True, crowd_ratio=0.35, step_reward=-0.01, goal_reward=1.0,
+                                 food_density=0.08, food_interval=6, seed=s) for s in range(8)]
+        n = 3000 + 7
+        env = metagym_amd.make("meta-maze-2D-v0", num_envs=n, device="cuda:0", max_steps=25, view_grid=1,
+                               task_type=task_type)
+        env.set_task(tasks)
+        ids = env.task_id.cpu().numpy()
+        otasks, states = _oracle_batch(tasks, ids, tt)
+        obs = env.reset().cpu().numpy()
+        for e in range(0, n, 97):
+            assert np.array_equal(obs[e], mo.observe_2d(otasks[ids[e]], tt, states[e], 1))
+        rs = np.random.RandomState(5)
+        for t in range(80):
+            a = rs.randint(0, 4, n)
+            obs, rew, done, info = env.step(torch.as_tensor(a))
+            r64, d, ob = env.reward64.cpu().numpy(), done.cpu().numpy(), obs.cpu().numpy()
+            for e in range(n):
+                r, dd = mo.step_2d(otasks[ids[e]], tt, 25, states[e], a[e])
+                assert r == r64[e] and dd == d[e], (t, e)
+            for e in range(0, n, 61):
+                assert np.array_equal(ob[e], mo.observe_2d(otasks[ids[e]], tt, states[e], 1)), (t, e)
+            if d.any():
+                env.reset(mask=done)
+                for e in np.nonzero(d)[0]:
+                    mo.reset(otasks[ids[e]], tt, states[e])
+        assert np.array_equal(env.grid.cpu().numpy().T, np.asarray([list(s.c.grid) for s in states]))
+
+
+@pytest.mark.parametrize("continuous", [False, True])
+def test_maze3d_batch_matches_oracle(continuous):
+    """9x9 mazes (config C3 geometry), 6 tasks x 96 envs, 64x64 and 40x24 frames, both task types;
+    discrete frames must be identical to the oracle's, continuous >= 99.9 %."""
+    import metagym_amd
+    from metagym_amd.metamaze import MazeTaskSampler, MAZE_TASK_MANAGER
+    tex_u8 = MAZE_TASK_MANAGER.grounds.astype(np.uint8)
+    for task_type, res in (("SURVIVAL", (64, 64)), ("ESCAPE", (40, 24))):
+        tt = mo.TASK_TYPES[task_type]
+        tasks = [MazeTaskSampler(n=9, allow_loops=False, step_reward=-0.01, goal_reward=1.0, food_density=0.08,
+                                 food_interval=4, seed=10 + s) for s in range(6)]
+        n = 96
+        name = "meta-maze-continuous-3D-v0" if continuous else "meta-maze-discrete-3D-v0"
+        env = metagym_amd.make(name, num_envs=n, device="cuda:0", max_steps=12, resolution=res, task_type=task_type)
+        env.set_task(tasks)
+        ids = env.task_id.cpu().numpy()
+        otasks, states = _oracle_batch(tasks, ids, tt)
+        view = mo.View(tex_u8, MAZE_TASK_MANAGER.ceil, res[0], res[1])
+        obs = env.reset().cpu().numpy()
+        for e in range(0, n, 13):
+            assert np.array_equal(obs[e], mo.observe_3d(otasks[ids[e]], tt, view, states[e], int(continuous)))
+        rs = np.random.RandomState(9)
+        bad = total = 0
+        for t in range(20):
+            if continuous:
+                a = np.stack([rs.uniform(-1.2, 1.2, n), rs.uniform(-0.5, 1.2, n)], 1).astype(np.float32)
+            else:
+                a = rs.choice(4, size=n, p=[0.2, 0.2, 0.1, 0.5])
+            obs, rew, done, info = env.step(torch.as_tensor(a))
+            r64, d, ob = env.reward64.cpu().numpy(), done.cpu().numpy(), obs.cpu().numpy()
+            for e in range(n):
+                if continuous:
+                    r, dd = mo.step_cont3d(otasks[ids[e]], tt, 12, states[e], a[e][0], a[e][1])
+                else:
+                    r, dd = mo.step_disc3d(otasks[ids[e]], tt, 12, states[e], a[e])
+                assert r == r64[e] and dd == d[e], (t, e)
+            for e in range(t % 7, n, 7):
+                ref = mo.observe_3d(otasks[ids[e]], tt, view, states[e], int(continuous))
+                bad += int((ob[e] != ref).sum())
+                total += ref.size
+            if d.any():
+                env.reset(mask=done)
+                for e in np.nonzero(d)[0]:
+                    mo.reset(otasks[ids[e]], tt, states[e])
+        print(task_type, res, "continuous" if continuous else "discrete", "pixel mismatches", bad, "/", total)
+        assert bad == 0 if not continuous else bad <= 1e-3 * total
+
+
+def test_maze3d_full_size_properties():
+    """Config C3 size (16 384 envs, 9x9) at 32x32 frames: determinism, env-permutation equivariance
+    and auto-reset == explicit masked reset; plus one 256x256 batch checked against the oracle."""
+    import metagym_amd
+    from metagym_amd.metamaze import MazeTaskSampler, MAZE_TASK_MANAGER
+    tasks = [MazeTaskSampler(n=9, allow_loops=False, step_reward=-0.01, goal_reward=1.0, food_density=0.08,
+                             food_interval=4, seed=100 + s) for s in range(64)]
+    n = 16384
+    mk = lambda **kw: metagym_amd.make("meta-maze-discrete-3D-v0", num_envs=n, device="cuda:0", max_steps=6,
+                                       resolution=(32, 32), task_type="SURVIVAL", **kw)
+    a, b, c = mk(), mk(), mk(auto_reset=True)
+    ids = torch.arange(n, dtype=torch.int32) % 64
+    perm = torch.randperm(n)
+    a.set_task(tasks, ids)
+    b.set_task(tasks, ids[perm])
+    c.set_task(tasks, ids)
+    oa, ob, oc = a.reset(), b.reset(), c.reset()
+    assert torch.equal(oa[perm.cuda()], ob) and torch.equal(oa, oc)
+    g = torch.Generator().manual_seed(0)
+    for t in range(14):
+        act = torch.randint(0, 4, (n,), generator=g, dtype=torch.int32)
+        oa, ra, da, _ = a.step(act)
+        ob, rb, db, _ = b.step(act[perm])
+        oc, rc, dc, _ = c.step(act)
+        assert torch.equal(oa[perm.cuda()], ob) and torch.equal(ra[perm.cuda()], rb) and torch.equal(da[perm.cuda()], db)
+        assert torch.equal(ra, rc) and torch.equal(da, dc)
+        if bool(da.any()):
+            oa = a.reset(mask=da)
+            b.reset(mask=db)
+        assert torch.equal(oa, oc), "auto-reset differs from explicit reset at step %d" % t
+    # 256x256 (the registered default resolution), 32 envs, against the oracle
+    tt = mo.SURVIVAL
+    env = metagym_amd.make("meta-maze-discrete-3D-v0", num_envs=32, device="cuda:0", max_steps=50, task_type="SURVIVAL")
+    env.set_task(tasks[:8])
+    idl = env.task_id.cpu().numpy()
+    otasks, states = _oracle_batch(tasks[:8], idl, tt)
+    view = mo.View(MAZE_TASK_MANAGER.grounds.astype(np.uint8), MAZE_TASK_MANAGER.ceil, 256, 256)
+    env.reset()
+    rs = np.random.RandomState(1)
+    for t in range(5):
+        act = rs.choice(4, size=32, p=[0.2, 0.2, 0.1, 0.5])
+        obs, _, _, _ = env.step(torch.as_tensor(act))
+        for e in range(32):
+            mo.step_disc3d(otasks[idl[e]], tt, 50, states[e], act[e])
+    ob = obs.cpu().numpy()
+    for e in (0, 7, 19, 31):
+        assert np.array_equal(ob[e], mo.observe_3d(otasks[idl[e]], tt, view, states[e], 0)), e
