@@ -175,9 +175,11 @@ typedef struct mg_maze_tasks {
                                       max_life, step_reward, goal_reward, (pad) */
 } mg_maze_tasks;
 
-/* Per-env episode state (MazeBase.reset maze_base.py:40-63 + the 3-D cores). SURVIVAL arrays are
- * [n_envs][n*n] (one contiguous row per env: the 3-D kernel gives a workgroup to each env);
- * they may be NULL for ESCAPE. */
+/* Per-env episode state (MazeBase.reset maze_base.py:40-63 + the 3-D cores). The SURVIVAL arrays
+ * hold n*n cells per env; cell c of env e lives at index e*food_env_stride + c*food_cell_stride.
+ * Use [N][n*n] (env_stride n*n, cell_stride 1) with the 3-D kernel (a workgroup per env reads a
+ * contiguous row) and [n*n][N] (env_stride 1, cell_stride N) with the 2-D kernel (a lane per env).
+ * They may be NULL for ESCAPE. */
 typedef struct mg_maze_state {
     int32_t *task_id;     /* [N] index into the task table */
     int32_t *grid;        /* [2][N] _agent_grid */
@@ -189,6 +191,7 @@ typedef struct mg_maze_state {
     double *cur_food;     /* [N][n*n] SURVIVAL _cur_food_rewards (also the translucent-cell map) */
     uint8_t *wait_refresh;/* [N][n*n] SURVIVAL _food_wait_refresh (0/1) */
     int32_t *revival;     /* [N][n*n] SURVIVAL _food_revival_count */
+    int64_t food_env_stride, food_cell_stride;   /* element strides of the three SURVIVAL arrays */
 } mg_maze_state;
 
 /* First-person renderer constants (MazeCoreDiscrete3D.__init__ maze_discrete_3d.py:18-37 and the

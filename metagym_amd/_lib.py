@@ -58,7 +58,8 @@ class MazeState(C.Structure):
     """mg_maze_state (device pointers)"""
     _fields_ = [("task_id", C.c_void_p), ("grid", C.c_void_p), ("steps", C.c_void_p), ("ori_idx", C.c_void_p),
                 ("ori", C.c_void_p), ("loc", C.c_void_p), ("life", C.c_void_p), ("cur_food", C.c_void_p),
-                ("wait_refresh", C.c_void_p), ("revival", C.c_void_p)]
+                ("wait_refresh", C.c_void_p), ("revival", C.c_void_p),
+                ("food_env_stride", C.c_int64), ("food_cell_stride", C.c_int64)]
 
 
 class MazeView(C.Structure):

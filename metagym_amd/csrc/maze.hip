@@ -108,13 +108,19 @@ __device__ __forceinline__ void reset_agent(const Task &t, int task_type, Agent 
     if (task_type == MG_MAZE_SURVIVAL) a.life = t.init_life;
 }
 
+// index of cell c of env e in the SURVIVAL arrays: [N][n*n] (cell_stride 1) for the workgroup-per-env
+// 3-D kernel, [n*n][N] (env_stride 1) for the lane-per-env 2-D kernel, so both access them coalesced
+__device__ __forceinline__ size_t fidx(const mg_maze_state &st, int e, int c) {
+    return (size_t)e * st.food_env_stride + (size_t)c * st.food_cell_stride;
+}
+
 // MazeBase.reset — per-cell part (SURVIVAL), cells c = first, first+stride, ...
 __device__ __forceinline__ void reset_cells(const Task &t, const mg_maze_state &st, int e, int first, int stride) {
-    const size_t base = (size_t)e * t.nn;
     for (int c = first; c < t.nn; c += stride) {
-        st.wait_refresh[base + c] = 0;
-        st.cur_food[base + c] = t.food[c];
-        st.revival[base + c] = t.interval[c];
+        const size_t i = fidx(st, e, c);
+        st.wait_refresh[i] = 0;
+        st.cur_food[i] = t.food[c];
+        st.revival[i] = t.interval[c];
     }
 }
 
@@ -123,7 +129,7 @@ __device__ __forceinline__ int eval_scalar(const Task &t, const mg_maze_state &s
                                            int max_steps, Agent &a, double &reward) {
     a.steps += 1;
     if (task_type == MG_MAZE_SURVIVAL) {
-        const size_t g = (size_t)e * t.nn + (size_t)a.gx * t.n + a.gy;
+        const size_t g = fidx(st, e, a.gx * t.n + a.gy);
         double r = 0.0;
         const double f = st.cur_food[g];
         if (f > 1.0e-2) {                                   // :71-75
@@ -142,16 +148,21 @@ __device__ __forceinline__ int eval_scalar(const Task &t, const mg_maze_state &s
 }
 
 // evaluation_rule :83-88 — food revival over the cells c = first, first+stride, ...
+// A cell whose task entry has food_interval == 0 can never hold food (food_interval =
+// interval * (food_rewards > 1e-3), maze_task.py:172): its wait flag stays 0 and its counter stays
+// 0, so skipping it is exact and saves the HBM round trip for the ~95 % of cells that are empty.
 __device__ __forceinline__ void eval_cells(const Task &t, const mg_maze_state &st, int e, int first, int stride) {
-    const size_t base = (size_t)e * t.nn;
     for (int c = first; c < t.nn; c += stride) {
-        int rv = st.revival[base + c] - (int)st.wait_refresh[base + c];
+        const int interval = t.interval[c];
+        if (interval == 0 && !(t.food[c] > 1.0e-2)) continue;
+        const size_t i = fidx(st, e, c);
+        int rv = st.revival[i] - (int)st.wait_refresh[i];
         if (rv < 0) {
-            st.cur_food[base + c] = t.food[c];
-            rv = t.interval[c];
-            st.wait_refresh[base + c] = 0;
+            st.cur_food[i] = t.food[c];
+            rv = interval;
+            st.wait_refresh[i] = 0;
         }
-        st.revival[base + c] = rv;
+        st.revival[i] = rv;
     }
 }
 
@@ -189,14 +200,13 @@ __global__ __launch_bounds__(MZ_BLOCK) void maze2d_step_kernel(mg_maze_tasks T, 
     // update_observation maze_2d.py:89-121
     const int w = 2 * vg + 1;
     float *o = obs + (size_t)e * w * w;
-    const size_t base = (size_t)e * t.nn;
     for (int p = 0; p < w; ++p)
         for (int q = 0; q < w; ++q) {
             const int x = a.gx - vg + p, y = a.gy - vg + q;
             float v = -1.0f;
             if (x >= 0 && x < t.n && y >= 0 && y < t.n) {
                 v = (float)(-(int)t.walls[x * t.n + y]);                                   // :113
-                if (task_type == MG_MAZE_SURVIVAL) v = (float)((double)v + st.cur_food[base + x * t.n + y]);  // :117
+                if (task_type == MG_MAZE_SURVIVAL) v = (float)((double)v + st.cur_food[fidx(st, e, x * t.n + y)]);  // :117
                 else v = (float)((double)v + ((x == t.gx && y == t.gy) ? 1.0 : 0.0));       // :120
             }
             o[p * w + q] = v;
@@ -647,7 +657,7 @@ __global__ __launch_bounds__(MZ_BLOCK) void maze3d_step_kernel(mg_maze_tasks T, 
     for (int c = tid; c < nn; c += MZ_BLOCK) {
         walls[c] = t.walls[c];
         texts[c] = t.texts[c];
-        if (task_type == MG_MAZE_SURVIVAL) transp[c] = st.cur_food[(size_t)e * nn + c];   // alias maze_base.py:57
+        if (task_type == MG_MAZE_SURVIVAL) transp[c] = st.cur_food[fidx(st, e, c)];       // alias maze_base.py:57
         else transp[c] = (c == t.gx * t.n + t.gy) ? 1.0 : 0.0;                            // :59-60
     }
     __syncthreads();
@@ -672,8 +682,10 @@ __global__ __launch_bounds__(MZ_BLOCK) void maze3d_step_kernel(mg_maze_tasks T, 
     WaveCols &wc = wcs[wave];
     uint2 *entries = entries_all + (size_t)wave * 64 * vk.t_max;
     int32_t *img = obs + (size_t)e * vk.H * vk.V * 3;
-    for (int cbase = wave * 64; cbase < vk.H; cbase += MZ_BLOCK) {
-        const int ncols = min(64, vk.H - cbase);
+    // columns are dealt to the 4 waves in equal slabs (<= 64 each) so narrow images keep all waves busy
+    const int slab = min(64, (vk.H + MZ_WAVES - 1) / MZ_WAVES);
+    for (int cbase = wave * slab; cbase < vk.H; cbase += MZ_WAVES * slab) {
+        const int ncols = min(slab, vk.H - cbase);
         if (lane < ncols)
             column_pass(vk, t, *es, walls, texts, transp, cbase + lane, lane, wc, entries, cs, inv_cs, cs_pow2);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");

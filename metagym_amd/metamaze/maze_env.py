@@ -98,11 +98,14 @@ class _MazeBatch(object):
         st.ori_idx, st.ori, st.loc, st.life = (self.ori_idx.data_ptr(), self.ori.data_ptr(), self.loc.data_ptr(),
                                                self.life.data_ptr())
         if self._tt == TASK_TYPES["SURVIVAL"]:
-            self.cur_food = torch.zeros(N, nn, dtype=torch.float64, device=dev)
-            self.wait_refresh = torch.zeros(N, nn, dtype=torch.uint8, device=dev)
-            self.revival = torch.zeros(N, nn, dtype=torch.int32, device=dev)
+            # [N, nn] for the workgroup-per-env 3-D kernel, [nn, N] for the lane-per-env 2-D kernel
+            shape = (nn, N) if self._CELL_MAJOR else (N, nn)
+            self.cur_food = torch.zeros(*shape, dtype=torch.float64, device=dev)
+            self.wait_refresh = torch.zeros(*shape, dtype=torch.uint8, device=dev)
+            self.revival = torch.zeros(*shape, dtype=torch.int32, device=dev)
             st.cur_food, st.wait_refresh, st.revival = (self.cur_food.data_ptr(), self.wait_refresh.data_ptr(),
                                                         self.revival.data_ptr())
+            st.food_env_stride, st.food_cell_stride = (1, N) if self._CELL_MAJOR else (nn, 1)
         self._state_c = st
         self._on_set_task()
         self.need_set_task = False
@@ -111,6 +114,7 @@ class _MazeBatch(object):
     def _on_set_task(self):
         pass
 
+    _CELL_MAJOR = False
     _STATE_KEYS = ("grid", "steps", "ori_idx", "ori", "loc", "life", "cur_food", "wait_refresh", "revival")
 
     def state_dict(self):
@@ -152,6 +156,7 @@ class _MazeBatch(object):
 
 class MetaMaze2D(_MazeBatch):
     """maze_env.py:155-212. obs float32 [N, 2v+1, 2v+1]; action int in {0..3} per env."""
+    _CELL_MAJOR = True
 
     def __init__(self, num_envs=1, device="cuda", enable_render=False, render_scale=480, max_steps=5000,
                  task_type="SURVIVAL", view_grid=2, auto_reset=False):
