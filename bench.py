@@ -38,11 +38,14 @@ HBM_PEAK_GBS = 8000.0             # /opt/skills/guides/MI355X_MICROARCH.md: HBM3
 N_ACTION_BATCHES = 8
 
 
-def cpu_baseline(seconds=12.0, n_envs_per_thread=256):
+def cpu_baseline(seconds=12.0, n_envs_per_thread=256, max_threads=None):
     """Time the CPU oracle (oracle/quadrotor_oracle.c, a scalar C port of the reference algorithm) on
-    the same workload: every host core steps its own block of envs (ctypes releases the GIL)."""
+    the same workload. One thread per host core, each stepping its own block of envs; the timed loop
+    runs inside C (ctypes releases the GIL), 100 env-steps per env per call."""
     from oracle import quadrotor as qo
     cores = os.cpu_count() or 1
+    if max_threads:
+        cores = min(cores, max_threads)
     c = qo.default_consts()
     rs = np.random.RandomState(0)
     blocks = []
@@ -53,18 +56,19 @@ def cpu_baseline(seconds=12.0, n_envs_per_thread=256):
         om = (5.0 * u[:, 3]) * ((u[:, 2] > 0.5) * 2 - 1.0)
         st = qo.make_states(np.zeros((n, 3), np.float32), vel, om, np.zeros((n, 4), np.float32),
                             np.tile(np.eye(3, dtype=np.float32).reshape(9), (n, 1)))
+        init = qo.make_states(np.zeros((n, 3), np.float32), vel, om, np.zeros((n, 4), np.float32),
+                              np.tile(np.eye(3, dtype=np.float32).reshape(9), (n, 1)))
         acts = rs.uniform(0.1, 15.0, (N_ACTION_BATCHES, n, 4)).astype(np.float32)
-        blocks.append((st, np.zeros(n, np.int32), acts))
+        blocks.append((st, init, np.zeros(n, np.int32), acts))
     counts = [0] * cores
     stop = time.perf_counter() + seconds
 
     def work(i):
-        st, ct, acts = blocks[i]
-        k = 0
+        st, init, ct, acts = blocks[i]
+        total = 0
         while time.perf_counter() < stop:
-            qo.batch_env_step(c, st, ct, acts[k % N_ACTION_BATCHES])
-            k += 1
-        counts[i] = k * len(st)
+            total += qo.batch_run(c, st, init, ct, acts, 100)
+        counts[i] = total
 
     t0 = time.perf_counter()
     threads = [threading.Thread(target=work, args=(i,)) for i in range(cores)]
@@ -75,8 +79,26 @@ def cpu_baseline(seconds=12.0, n_envs_per_thread=256):
     el = time.perf_counter() - t0
     total = sum(counts)
     return {"value": total / el, "unit": "env-steps/s", "cores": cores, "kind": "port",
-            "sample": "%d env-steps of the same hovering_control workload (%d envs/thread, no auto-reset), "
-                      "%.1f s wall, C oracle -O2 scalar" % (total, n_envs_per_thread, el)}
+            "sample": "%d env-steps of the same hovering_control workload (%d envs per thread, finished episodes "
+                      "restart), %.1f s wall, C oracle gcc -O2 scalar, one thread per core"
+                      % (total, n_envs_per_thread, el)}
+
+
+def aggregate_throughput(dist, dev, wall, envs_per_rank, steps):
+    """Whole-job env-steps/s: every rank stepped `envs_per_rank` envs `steps` times; the job took as
+    long as its slowest rank. `dist` is torch.distributed (initialised) or None for one process."""
+    wall_max, world = wall, 1
+    if dist is not None:
+        t = torch.tensor([wall], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        wall_max = float(t.item())
+        world = dist.get_world_size()
+    return world * envs_per_rank * steps / wall_max, wall_max
+
+
+def shard_env_ids(rank, world, envs_per_rank):
+    """Global env ids owned by `rank` (contiguous shards)."""
+    return np.arange(rank * envs_per_rank, (rank + 1) * envs_per_rank, dtype=np.int64)
 
 
 def main():
@@ -104,7 +126,7 @@ def main():
     import metagym_amd
     n = args.envs_per_gpu
     env = metagym_amd.make("quadrotor-v0", num_envs=n, device=dev, task="hovering_control",
-                           auto_reset=True, seed=1000 + rank)
+                           auto_reset=True, seed=1000, env_id_base=int(shard_env_ids(rank, world, n)[0]))
     env.reset(seed=1000 + rank)
     g = torch.Generator(device=dev)
     g.manual_seed(2000 + rank)
@@ -131,11 +153,7 @@ def main():
     wall = t1 - t0
     dev_ms = ev0.elapsed_time(ev1)
 
-    wall_max = wall
-    if dist is not None:
-        t = torch.tensor([wall], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        wall_max = float(t.item())
+    value, wall_max = aggregate_throughput(dist, dev, wall, n, args.steps)
 
     done_frac = float(env._done.float().mean().item())
     failed_any = int(env._failed.max().item())
@@ -151,7 +169,7 @@ def main():
                 traffic = None
         out = {
             "metric": "env-steps/sec (whole node) at 2^16 parallel envs per GPU",
-            "value": world * n * args.steps / wall_max,
+            "value": value,
             "unit": "env-steps/s",
             "n_gpus": world,
             "steps": args.steps,

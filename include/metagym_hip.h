@@ -137,7 +137,8 @@ int mg_quadrotor_rollout(const mg_quadrotor_config *cfg, int32_t n_envs, int32_t
  * launch (QuadrotorSim.reset quadrotorsim.py:239-258: zero state + init noise) and the returned
  * observation row is the first observation of its next episode; reward/done/failed still describe
  * the step that ended. The noise is drawn on the device from Philox4x32-10 keyed by `seed` with
- * counter (env index, step_index + t), so results are independent of how envs are sharded. */
+ * counter (env_id_base + env index, step_index + t), so results are independent of how envs are
+ * sharded across GPUs. */
 typedef struct mg_quadrotor_autoreset {
     float init_velocity[3];            /* cfg['init_velocity'] x, y, z */
     float init_angular_velocity[3];    /* cfg['init_angular_velocity'] x, y, z */
@@ -145,6 +146,7 @@ typedef struct mg_quadrotor_autoreset {
     double init_angular_velocity_noisy;/* cfg['init_angular_velocity']['noisy'] (5.0) */
     uint64_t seed;
     uint64_t step_index;               /* global index of the first step of this call */
+    uint64_t env_id_base;              /* global id of env 0 of this shard (0 on a single GPU) */
 } mg_quadrotor_autoreset;
 
 int mg_quadrotor_step_autoreset(const mg_quadrotor_config *cfg, int32_t n_envs, int32_t n_steps,

@@ -44,7 +44,7 @@ class QuadrotorAutoReset(C.Structure):
     """mg_quadrotor_autoreset"""
     _fields_ = [("init_velocity", C.c_float * 3), ("init_angular_velocity", C.c_float * 3),
                 ("init_velocity_noisy", C.c_double), ("init_angular_velocity_noisy", C.c_double),
-                ("seed", C.c_uint64), ("step_index", C.c_uint64)]
+                ("seed", C.c_uint64), ("step_index", C.c_uint64), ("env_id_base", C.c_uint64)]
 
 
 class MazeTasks(C.Structure):

@@ -48,7 +48,7 @@ struct QuadK {
     int auto_reset;
     float init_v_base[3], init_w_base[3];   // cfg['init_velocity'] / ['init_angular_velocity'] x,y,z (f32 arrays)
     double init_v_noisy, init_w_noisy;      // ... ['noisy']
-    uint64_t seed, step_index;
+    uint64_t seed, step_index, env_id_base;
     const int32_t *map;
     int map_h, map_w;
 };
@@ -411,10 +411,11 @@ __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t
 // value = base + noisy * U[0,1) * (+1 if U' > 0.5 else -1), per component.
 __device__ __forceinline__ void reset_lane_random(const QuadK &k, Lane &s, int e, uint64_t step) {
     uint32_t r[12];
+    const uint64_t gid = k.env_id_base + (uint64_t)e;   // global env id: shard-invariant streams
 #pragma unroll
     for (int d = 0; d < 3; ++d)
-        philox4x32_10((uint32_t)e, (uint32_t)step, (uint32_t)(step >> 32), (uint32_t)d, (uint32_t)k.seed,
-                      (uint32_t)(k.seed >> 32), &r[4 * d]);
+        philox4x32_10((uint32_t)gid, (uint32_t)step, (uint32_t)(step >> 32) ^ ((uint32_t)(gid >> 32) << 8),
+                      (uint32_t)d, (uint32_t)k.seed, (uint32_t)(k.seed >> 32), &r[4 * d]);
     const double inv32 = 1.0 / 4294967296.0;
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
@@ -636,7 +637,7 @@ int fold_config(const mg_quadrotor_config *c, QuadK *k) {
     k->auto_reset = 0;
     for (int i = 0; i < 3; ++i) { k->init_v_base[i] = 0.0f; k->init_w_base[i] = 0.0f; }
     k->init_v_noisy = k->init_w_noisy = 0.0;
-    k->seed = k->step_index = 0;
+    k->seed = k->step_index = k->env_id_base = 0;
     return MG_OK;
 }
 
@@ -679,6 +680,7 @@ int launch_steps(const mg_quadrotor_config *cfg, int32_t n, int32_t n_steps, con
         k.init_w_noisy = ar->init_angular_velocity_noisy;
         k.seed = ar->seed;
         k.step_index = ar->step_index;
+        k.env_id_base = ar->env_id_base;
     }
     StepIO io{action, obs, reward, reward64, done, failed};
     const int grid = (n + BLOCK - 1) / BLOCK;

@@ -109,7 +109,8 @@ class Quadrotor(object):
     metadata = {"render.modes": []}
 
     def __init__(self, num_envs=1, device="cuda", dt=0.01, nt=1000, seed=0, task="no_collision",
-                 map_file=None, simulator_conf=None, healthy_reward=1.0, auto_reset=False, **kwargs):
+                 map_file=None, simulator_conf=None, healthy_reward=1.0, auto_reset=False, env_id_base=0,
+                 **kwargs):
         assert task in TASKS, "Invalid task setting"
         if task == "velocity_control":
             raise NotImplementedError("task 'velocity_control' is a later row of the scope table "
@@ -188,6 +189,7 @@ class Quadrotor(object):
         self._ar.init_velocity_noisy = float(cv["noisy"]) if cv else 0.0
         self._ar.init_angular_velocity_noisy = float(cw["noisy"]) if cw else 0.0
         self._ar.seed = int(seed) & 0xFFFFFFFFFFFFFFFF
+        self._ar.env_id_base = int(env_id_base)   # global id of env 0 when this batch is one shard of a larger job
 
     # ------------------------------------------------------------------ reference API
     def reset(self, mask=None, seed=None, init_velocity=None, init_angular_velocity=None):

@@ -134,3 +134,15 @@ def inv3(A):
     out = np.zeros(9, np.float32)
     lib().qo_inv3_f32(A.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p))
     return out.reshape(3, 3)
+
+
+def batch_run(consts, states, init_states, ct, actions, iters):
+    """iters env-steps per env inside one C call (actions f32 [B][n][4] cycled); finished episodes
+    restart from init_states. Returns the number of env-steps done."""
+    n = len(states)
+    actions = np.ascontiguousarray(actions, np.float32)
+    assert actions.ndim == 3 and actions.shape[1:] == (n, 4) and len(init_states) == n
+    fn = lib().qo_batch_run
+    fn.restype = C.c_long
+    return fn(C.byref(consts), C.c_int(n), states, init_states, ct.ctypes.data_as(C.c_void_p),
+              actions.ctypes.data_as(C.c_void_p), C.c_int(actions.shape[0]), C.c_int(iters))

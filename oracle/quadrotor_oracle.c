@@ -368,5 +368,26 @@ void qo_batch_env_step(const qo_consts *c, int n, qo_state *states, int *ct, con
         failed[e] = qo_env_step(c, &states[e], &ct[e], &actions[4 * e], &obs[16 * e], &reward[e], &done[e]);
 }
 
+/* iters env-steps for every env, cycling through n_batches action batches [n_batches][n][4];
+ * outputs are discarded. An env whose episode ends (collision, ct == nt, failure) restarts from
+ * its entry in `init` (the reset states), like the GPU bench's fused auto-reset, so the timed work
+ * per env-step stays the full 10 sub-steps. Used by bench.py's cpu_baseline. */
+long qo_batch_run(const qo_consts *c, int n, qo_state *states, const qo_state *init, int *ct,
+                  const float *actions, int n_batches, int iters) {
+    float obs[16];
+    double reward;
+    int done;
+    long count = 0;
+    for (int k = 0; k < iters; ++k) {
+        const float *a = actions + (size_t)(k % n_batches) * n * 4;
+        for (int e = 0; e < n; ++e) {
+            qo_env_step(c, &states[e], &ct[e], &a[4 * e], obs, &reward, &done);
+            if (done) states[e] = init[e];
+            ++count;
+        }
+    }
+    return count;
+}
+
 size_t qo_sizeof_state(void) { return sizeof(qo_state); }
 size_t qo_sizeof_consts(void) { return sizeof(qo_consts); }

@@ -50,6 +50,8 @@ int qo_env_step(const qo_consts *c, qo_state *s, int *ct, const float act[4],
                 float obs[16], double *reward, int *done);
 void qo_batch_env_step(const qo_consts *c, int n, qo_state *states, int *ct, const float *actions,
                        float *obs, double *reward, int *done, int *failed);
+long qo_batch_run(const qo_consts *c, int n, qo_state *states, const qo_state *init, int *ct,
+                  const float *actions, int n_batches, int iters);
 size_t qo_sizeof_state(void);
 size_t qo_sizeof_consts(void);
 
