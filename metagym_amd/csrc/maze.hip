@@ -329,7 +329,7 @@ __device__ __forceinline__ void transition_continuous(const Task &t, double col_
 
 struct ViewK {
     int H, V, TS, t_max;
-    double max_vision, l_focal, text_size, inv_text_size, half_h, half_v, pixel_size;
+    double max_vision, max_vision_lo, l_focal, text_size, inv_text_size, half_h, half_v, pixel_size;
     double col_dist;
     int text_size_pow2;
     const double *col_cos, *col_sin;
@@ -495,11 +495,22 @@ __device__ __forceinline__ void pixel_pass(const ViewK &vk, const Task &t, const
     const int n = t.n, TS = vk.TS;
     R = G = B = 0;
     bool tflag = false;
-    if (rk.kind != 0) {
+    const int span = wc.w_span[k];
+    const bool in_wall = d_v >= (span & 0xffff) && d_v < (span >> 16);
+    const int n_tr = wc.n_tr[k];
+    // A wall pixel overwrites whatever the floor / ceiling cast painted; the cast's only surviving
+    // side effect is the transparent_array flag, which is read by the overlays alone. So the cast
+    // can be skipped for wall pixels of columns without overlay records (bit-identical).
+    if (rk.kind != 0 && !(in_wall && n_tr == 0)) {
         const double eff = rk.distance / (double)wc.cos_hp[k];
-        double a = 2.0 * eff / vk.max_vision - 1.0;
-        a = a > 0.0 ? a : 0.0;
-        a = a < 1.0 ? a : 1.0;
+        // fog a = clamp(2*eff/max_vision - 1, 0, 1): when 2*eff is clearly below max_vision the
+        // rounded quotient cannot exceed 1, so a == 0 without performing the division
+        double a = 0.0;
+        if (2.0 * eff > vk.max_vision_lo) {
+            a = 2.0 * eff / vk.max_vision - 1.0;
+            a = a > 0.0 ? a : 0.0;
+            a = a < 1.0 ? a : 1.0;
+        }
         const double hit_x = eff * (double)wc.cos_abs[k] + es.pos[0];
         const double hit_y = eff * (double)wc.sin_abs[k] + es.pos[1];
         const double fi = cs_pow2 ? hit_x * inv_cs : hit_x / cs;
@@ -553,8 +564,7 @@ __device__ __forceinline__ void pixel_pass(const ViewK &vk, const Task &t, const
             }
         }
     }
-    const int span = wc.w_span[k];
-    if (d_v >= (span & 0xffff) && d_v < (span >> 16)) {                       // :181-192
+    if (in_wall) {                                                            // :181-192
         const double local_v = rk.ys * wc.w_ratio[k] + t.agent_h;
         double d_j = vk.text_size_pow2 ? local_v * vk.inv_text_size : local_v / vk.text_size;
         d_j -= floor(d_j);
@@ -564,7 +574,6 @@ __device__ __forceinline__ void pixel_pass(const ViewK &vk, const Task &t, const
         G = (int)(light * (oma * (double)((tx >> 8) & 255u)));
         B = (int)(light * (oma * (double)((tx >> 16) & 255u)));
     }
-    const int n_tr = wc.n_tr[k];
     for (int q = 0; q < n_tr; ++q) {                                          // :194-205
         const uint2 en = entries[q * 64 + k];
         if (!tflag && d_v >= (int)(en.x & 0xffffu) && d_v < (int)(en.x >> 16)) {
@@ -587,7 +596,8 @@ struct int3s { int x, y, z; };   // 12-byte pixel, stored with one dwordx3
 
 __global__ __launch_bounds__(MZ_BLOCK) void maze3d_step_kernel(mg_maze_tasks T, mg_maze_state st, ViewK vk,
                                                                int task_type, int max_steps, int continuous,
-                                                               int auto_reset, int n_envs, const void *action,
+                                                               int pre_moved, int auto_reset, int n_envs,
+                                                               const void *action,
                                                                int32_t *obs, float *reward, double *reward64,
                                                                uint8_t *done) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -616,8 +626,10 @@ __global__ __launch_bounds__(MZ_BLOCK) void maze3d_step_kernel(mg_maze_tasks T, 
         es->reward = 0.0;
         if (action != nullptr) {
             if (continuous) {
-                const float *ac = static_cast<const float *>(action) + 2 * (size_t)e;
-                transition_continuous(t, vk.col_dist, ac[0], ac[1], a);
+                if (!pre_moved) {   // otherwise maze_cont_move_kernel already advanced every env
+                    const float *ac = static_cast<const float *>(action) + 2 * (size_t)e;
+                    transition_continuous(t, vk.col_dist, ac[0], ac[1], a);
+                }
             } else {
                 transition_discrete(t, static_cast<const int32_t *>(action)[e] & 3, a);
             }
@@ -710,6 +722,23 @@ __global__ __launch_bounds__(MZ_BLOCK) void maze3d_step_kernel(mg_maze_tasks T, 
         }
         __builtin_amdgcn_wave_barrier();
     }
+}
+
+// The continuous transition is ~10 k dependent scalar ops per env (10 sub-steps x 9 neighbour cells
+// of soft collision, dynamics.py:71-92). Inside the render kernel it would run on one thread while
+// 255 wait; as its own lane-per-env launch all envs advance in parallel.
+__global__ __launch_bounds__(MZ_BLOCK) void maze_cont_move_kernel(mg_maze_tasks T, mg_maze_state st, double col_dist,
+                                                                  int n_envs, const float *action) {
+    const int e = blockIdx.x * MZ_BLOCK + threadIdx.x;
+    if (e >= n_envs) return;
+    const Task t = load_task(T, st.task_id[e]);
+    Agent a = load_agent(st, n_envs, e);
+    transition_continuous(t, col_dist, action[2 * (size_t)e], action[2 * (size_t)e + 1], a);
+    st.grid[e] = a.gx;
+    st.grid[n_envs + e] = a.gy;
+    st.ori[e] = a.ori;
+    st.loc[e] = a.lx;
+    st.loc[n_envs + e] = a.ly;
 }
 
 __global__ __launch_bounds__(MZ_BLOCK) void maze_reset_kernel(mg_maze_tasks T, mg_maze_state st, int task_type,
@@ -824,6 +853,7 @@ extern "C" int mg_maze3d_step(const mg_maze_tasks *T, const mg_maze_view *view, 
     vk.V = view->res_v;
     vk.TS = view->tex_size;
     vk.max_vision = view->max_vision;
+    vk.max_vision_lo = view->max_vision * (1.0 - 1.0e-12);   // see pixel_pass: below this, fog is exactly 0
     vk.l_focal = view->l_focal;
     vk.text_size = view->text_size;
     vk.inv_text_size = 1.0 / view->text_size;
@@ -850,7 +880,14 @@ extern "C" int mg_maze3d_step(const mg_maze_tasks *T, const mg_maze_view *view, 
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return mg::check_hip(e, "hipFuncSetAttribute(maze3d_step_kernel)");
     }
+    int pre_moved = 0;
+    if (continuous && action != nullptr) {
+        hipLaunchKernelGGL(maze_cont_move_kernel, dim3((n + MZ_BLOCK - 1) / MZ_BLOCK), dim3(MZ_BLOCK), 0,
+                           (hipStream_t)stream, *T, *st, vk.col_dist, n, static_cast<const float *>(action));
+        if (int rc = mg::check_launch("maze_cont_move_kernel")) return rc;
+        pre_moved = 1;
+    }
     hipLaunchKernelGGL(maze3d_step_kernel, dim3(n), dim3(MZ_BLOCK), lds, (hipStream_t)stream, *T, *st, vk, task_type,
-                       max_steps, continuous, auto_reset, n, action, obs, reward, reward64, done);
+                       max_steps, continuous, pre_moved, auto_reset, n, action, obs, reward, reward64, done);
     return mg::check_launch("maze3d_step_kernel");
 }
