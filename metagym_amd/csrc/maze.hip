@@ -351,30 +351,44 @@ struct EnvShared {   // one per workgroup, LDS
     double pos[2], s_ori, c_ori;
 };
 
-// per-wave column records (pass A -> pass B), struct-of-arrays over the wave's 64 columns
-struct WaveCols {
-    float cos_hp[64], cos_abs[64], sin_abs[64];
-    double w_oma[64];      // 1 - alpha of the wall hit
-    double w_ratio[64];    // hit_dist * cos_hp / l_focal
-    double w_light[64];    // |cos| or |sin| (float32 value widened)
-    int w_tex[64];         // texel offset of (texture id, texture row)
-    int w_span[64];        // v_s | v_e << 16   (v_s >= v_e: no wall / beyond max_vision)
-    int n_tr[64];          // number of translucent records
+// Column record produced by pass A. Each lane keeps the record of ITS column in registers; pass B
+// broadcasts column k's record to the whole wave with v_readlane (SGPR operands) — no LDS round trip.
+struct ColRec {
+    float cos_hp, cos_abs, sin_abs;
+    double w_oma;      // 1 - alpha of the wall hit
+    double w_ratio;    // hit_dist * cos_hp / l_focal
+    double w_light;    // |cos| or |sin| (float32 value widened)
+    int w_tex;         // texel offset of (texture id, texture row)
+    int w_span;        // v_s | v_e << 16   (v_s >= v_e: no wall / beyond max_vision)
+    int n_tr;          // number of translucent records
 };
+
+__device__ __forceinline__ float bcast(float v, int lane) {
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
+}
+__device__ __forceinline__ int bcast(int v, int lane) { return __builtin_amdgcn_readlane(v, lane); }
+__device__ __forceinline__ double bcast(double v, int lane) {
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), lane),
+                            __builtin_amdgcn_readlane(__double2loint(v), lane));
+}
+__device__ __forceinline__ ColRec bcast(const ColRec &r, int lane) {
+    ColRec o;
+    o.cos_hp = bcast(r.cos_hp, lane); o.cos_abs = bcast(r.cos_abs, lane); o.sin_abs = bcast(r.sin_abs, lane);
+    o.w_oma = bcast(r.w_oma, lane); o.w_ratio = bcast(r.w_ratio, lane); o.w_light = bcast(r.w_light, lane);
+    o.w_tex = bcast(r.w_tex, lane); o.w_span = bcast(r.w_span, lane); o.n_tr = bcast(r.n_tr, lane);
+    return o;
+}
 
 // Pass A, lane = screen column: ray_caster_utils.py:84-90 (direction tables), :11-62 (DDA_2D) and the
 // per-column parts of :155-205.
-__device__ void column_pass(const ViewK &vk, const Task &t, const EnvShared &es, const int8_t *walls,
-                            const uint8_t *texts, const double *transp, int col, int lane, WaveCols &wc,
-                            uint2 *entries /* [t_max][64] */, double cs, double inv_cs, int cs_pow2) {
+__device__ ColRec column_pass(const ViewK &vk, const Task &t, const EnvShared &es, const int8_t *walls,
+                              const uint8_t *texts, const double *transp, int col, int lane,
+                              uint2 *entries /* [t_max][64] */, double cs, double inv_cs, int cs_pow2) {
     const int n = t.n;
     const double chp = vk.col_cos[col], shp = vk.col_sin[col];
     const float sin_abs = (float)(shp * es.c_ori + chp * es.s_ori);
     const float cos_abs = (float)(chp * es.c_ori - shp * es.s_ori);
     const float cos_hp = (float)chp;
-    wc.cos_hp[lane] = cos_hp;
-    wc.cos_abs[lane] = cos_abs;
-    wc.sin_abs[lane] = sin_abs;
 
     const double vh = t.agent_h, ceil_h = t.wall_h;
     const double px0 = es.pos[0], px1 = es.pos[1];
@@ -450,12 +464,11 @@ __device__ void column_pass(const ViewK &vk, const Task &t, const EnvShared &es,
     } else {
         n_tr = 0;   // `continue` at :160-161 also skips the overlays of this column
     }
-    wc.w_oma[lane] = oma;
-    wc.w_ratio[lane] = ratio;
-    wc.w_light[lane] = light;
-    wc.w_tex[lane] = texoff;
-    wc.w_span[lane] = span;
-    wc.n_tr[lane] = n_tr;
+    ColRec rec;
+    rec.cos_hp = cos_hp; rec.cos_abs = cos_abs; rec.sin_abs = sin_abs;
+    rec.w_oma = oma; rec.w_ratio = ratio; rec.w_light = light;
+    rec.w_tex = texoff; rec.w_span = span; rec.n_tr = n_tr;
+    return rec;
 }
 
 struct RowK {   // per-lane constants of a screen row (they do not depend on the column)
@@ -488,21 +501,21 @@ __device__ __forceinline__ RowK row_constants(const ViewK &vk, const Task &t, in
 // ceiling cast (:102-126 / :135-153), then the wall column (:181-192), then the translucent
 // overlays in ray order (:194-205), then the life bar (maze_discrete_3d.py:118-126).
 __device__ __forceinline__ void pixel_pass(const ViewK &vk, const Task &t, const EnvShared &es, const RowK &rk,
-                                           const uint8_t *texts, const double *transp, const WaveCols &wc,
+                                           const uint8_t *texts, const double *transp, const ColRec &wc,
                                            const uint2 *entries, int k, int d_v, double cs, double inv_cs,
                                            int cs_pow2, double text_to_cell, double inv_ttc, int ttc_pow2,
                                            int &R, int &G, int &B) {
     const int n = t.n, TS = vk.TS;
     R = G = B = 0;
     bool tflag = false;
-    const int span = wc.w_span[k];
+    const int span = wc.w_span;
     const bool in_wall = d_v >= (span & 0xffff) && d_v < (span >> 16);
-    const int n_tr = wc.n_tr[k];
+    const int n_tr = wc.n_tr;
     // A wall pixel overwrites whatever the floor / ceiling cast painted; the cast's only surviving
     // side effect is the transparent_array flag, which is read by the overlays alone. So the cast
     // can be skipped for wall pixels of columns without overlay records (bit-identical).
     if (rk.kind != 0 && !(in_wall && n_tr == 0)) {
-        const double eff = rk.distance / (double)wc.cos_hp[k];
+        const double eff = rk.distance / (double)wc.cos_hp;
         // fog a = clamp(2*eff/max_vision - 1, 0, 1): when 2*eff is clearly below max_vision the
         // rounded quotient cannot exceed 1, so a == 0 without performing the division
         double a = 0.0;
@@ -511,8 +524,8 @@ __device__ __forceinline__ void pixel_pass(const ViewK &vk, const Task &t, const
             a = a > 0.0 ? a : 0.0;
             a = a < 1.0 ? a : 1.0;
         }
-        const double hit_x = eff * (double)wc.cos_abs[k] + es.pos[0];
-        const double hit_y = eff * (double)wc.sin_abs[k] + es.pos[1];
+        const double hit_x = eff * (double)wc.cos_abs + es.pos[0];
+        const double hit_y = eff * (double)wc.sin_abs + es.pos[1];
         const double fi = cs_pow2 ? hit_x * inv_cs : hit_x / cs;
         const double fj = cs_pow2 ? hit_y * inv_cs : hit_y / cs;
         const int i = to_int_clamped(fi, -2, n + 1), j = to_int_clamped(fj, -2, n + 1);
@@ -565,11 +578,11 @@ __device__ __forceinline__ void pixel_pass(const ViewK &vk, const Task &t, const
         }
     }
     if (in_wall) {                                                            // :181-192
-        const double local_v = rk.ys * wc.w_ratio[k] + t.agent_h;
+        const double local_v = rk.ys * wc.w_ratio + t.agent_h;
         double d_j = vk.text_size_pow2 ? local_v * vk.inv_text_size : local_v / vk.text_size;
         d_j -= floor(d_j);
-        const uint32_t tx = vk.tex[wc.w_tex[k] + (int)(TS * d_j)];
-        const double oma = wc.w_oma[k], light = wc.w_light[k];
+        const uint32_t tx = vk.tex[wc.w_tex + (int)(TS * d_j)];
+        const double oma = wc.w_oma, light = wc.w_light;
         R = (int)(light * (oma * (double)(tx & 255u)));
         G = (int)(light * (oma * (double)((tx >> 8) & 255u)));
         B = (int)(light * (oma * (double)((tx >> 16) & 255u)));
@@ -611,8 +624,6 @@ __global__ __launch_bounds__(MZ_BLOCK) void maze3d_step_kernel(mg_maze_tasks T, 
     size_t off = (sizeof(EnvShared) + 15) & ~size_t(15);
     double *transp = reinterpret_cast<double *>(smem + off);
     off += sizeof(double) * nn;
-    WaveCols *wcs = reinterpret_cast<WaveCols *>(smem + off);
-    off += sizeof(WaveCols) * MZ_WAVES;
     uint2 *entries_all = reinterpret_cast<uint2 *>(smem + off);
     off += sizeof(uint2) * 64 * vk.t_max * MZ_WAVES;
     int8_t *walls = reinterpret_cast<int8_t *>(smem + off);
@@ -691,15 +702,15 @@ __global__ __launch_bounds__(MZ_BLOCK) void maze3d_step_kernel(mg_maze_tasks T, 
         py_slice((long)sy, (long)(sy + 0.05 * vk.H), vk.V, lb_y0, lb_y1);
     }
 
-    WaveCols &wc = wcs[wave];
     uint2 *entries = entries_all + (size_t)wave * 64 * vk.t_max;
     int32_t *img = obs + (size_t)e * vk.H * vk.V * 3;
     // columns are dealt to the 4 waves in equal slabs (<= 64 each) so narrow images keep all waves busy
     const int slab = min(64, (vk.H + MZ_WAVES - 1) / MZ_WAVES);
     for (int cbase = wave * slab; cbase < vk.H; cbase += MZ_WAVES * slab) {
         const int ncols = min(slab, vk.H - cbase);
+        ColRec mine{};
         if (lane < ncols)
-            column_pass(vk, t, *es, walls, texts, transp, cbase + lane, lane, wc, entries, cs, inv_cs, cs_pow2);
+            mine = column_pass(vk, t, *es, walls, texts, transp, cbase + lane, lane, entries, cs, inv_cs, cs_pow2);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -710,6 +721,7 @@ __global__ __launch_bounds__(MZ_BLOCK) void maze3d_step_kernel(mg_maze_tasks T, 
             const bool in_lb_y = d_v >= lb_y0 && d_v < lb_y1;
             for (int k = 0; k < ncols; ++k) {
                 int R, G, B;
+                const ColRec wc = bcast(mine, k);
                 pixel_pass(vk, t, *es, rk, texts, transp, wc, entries, k, d_v, cs, inv_cs, cs_pow2, text_to_cell,
                            inv_ttc, ttc_pow2, R, G, B);
                 const int col = cbase + k;
@@ -872,7 +884,7 @@ extern "C" int mg_maze3d_step(const mg_maze_tasks *T, const mg_maze_view *view, 
     // at least one cell per step and stops at max_vision or at the maze border.
     vk.t_max = 2 * T->n + 1;
     const size_t lds = ((sizeof(EnvShared) + 15) & ~size_t(15)) + sizeof(double) * T->n * T->n +
-                       sizeof(WaveCols) * MZ_WAVES + sizeof(uint2) * 64 * vk.t_max * MZ_WAVES +
+                       sizeof(uint2) * 64 * vk.t_max * MZ_WAVES +
                        2 * ((size_t)(T->n * T->n + 15) & ~size_t(15));
     if (lds > 160 * 1024) return mg::set_error(MG_ERR_BAD_SIZE, "maze n=%d needs %zu B of LDS (> 160 KiB)", T->n, lds);
     if (lds > 64 * 1024) {
