@@ -247,6 +247,85 @@ int mg_maze3d_step(const mg_maze_tasks *tasks, const mg_maze_view *view, int32_t
                    const void *action, int32_t *obs, float *reward, double *reward64, uint8_t *done,
                    void *stream);
 
+/* ========================================================================================
+ * MetaLocomotion walkers (humanoid / ant) — replaces, for N envs, WalkerBaseEnv.step
+ * (metalocomotion/envs/utils/walker_base_env.py:43-82) including the physics the reference
+ * delegates to pybullet.stepSimulation() (scene_bases.py:45-50).
+ * PARITY UNPINNED for the physics: PyBullet is not part of the reference tree. The engine is a
+ * from-scratch reduced-coordinate multibody solver (joint-space inertia matrix + Newton-Euler bias,
+ * semi-implicit Euler, projected Gauss-Seidel contacts / joint limits) run with the reference's
+ * parameters; see DESIGN.md §3.5 for the stated assumptions. The Python-side rules (torques,
+ * observation, reward, done) follow the reference source exactly.
+ * ======================================================================================== */
+
+#define MG_WALKER_MAX_BODIES 16
+#define MG_WALKER_MAX_JOINTS 24
+#define MG_WALKER_MAX_SPHERES 40
+#define MG_WALKER_MAX_FEET 6
+
+/* Topology shared by every task of a batch (all MetaLocomotion variants of one robot share it). */
+typedef struct mg_walker_topology {
+    int32_t n_bodies, n_joints, n_spheres, n_feet;
+    int32_t body_parent[MG_WALKER_MAX_BODIES];     /* -1 for the floating base (body 0) */
+    int32_t joint_body[MG_WALKER_MAX_JOINTS];      /* non-decreasing; joints of a body act in order */
+    int32_t sphere_body[MG_WALKER_MAX_SPHERES];    /* collision spheres (capsule end caps, sphere geoms) */
+    int32_t foot_body[MG_WALKER_MAX_FEET];         /* bodies whose ground contact sets feet_contact */
+} mg_walker_topology;
+
+/* Per-task geometry / inertia table, doubles, one row of `model_stride` values per task:
+ *   body_pos[nb][3] body_rot[nb][9] body_mass[nb] body_com[nb][3] body_inertia[nb][9]
+ *   joint_anchor[nj][3] joint_axis[nj][3] joint_lo[nj] joint_hi[nj] joint_armature[nj]
+ *   joint_damping[nj] joint_stiffness[nj] motor_torque[nj] sphere_pos[ns][3] sphere_radius[ns]
+ * (motor_torque[j] = motor_power_j * power, the factor multiplying clip(a_j,-1,1): humanoids.py:50-54,
+ * walker_base.py:26-29). */
+typedef struct mg_walker_models {
+    const double *table;       /* DEVICE [n_tasks][model_stride] */
+    int32_t n_tasks, model_stride;
+} mg_walker_models;
+
+typedef struct mg_walker_params {
+    double time_step;          /* 0.005  walker_base_env.py:7 */
+    int32_t frame_skip;        /* 4      sub-steps per env step */
+    int32_t solver_iterations; /* 5      scene_bases.py:17 */
+    double erp;                /* 0.9    contact ERP, scene_bases.py:55 */
+    double limit_erp;          /* 0.2    joint-limit ERP (Bullet's default constraint ERP) */
+    double gravity;            /* 9.8    env_bases.py:48 */
+    double friction;           /* 0.64 = ground 0.8 (stadium.py:23) x geom 0.8 (humanoid.xml:5) */
+    double alive_z, alive_bonus, dead_bonus;   /* humanoids.py:56: +2 if z > 0.50 else -1 */
+    double initial_z;          /* humanoids.py:48: 0.8 */
+    double joints_at_limit_cost;   /* -0.1 walker_base_env.py:22 */
+    double walk_target_x, walk_target_y;       /* 1e3, 0 */
+    int32_t max_steps;
+    int32_t floor_in_parts;    /* 1: the floor link counts in the mean part position (walker_base_env.py:30-31) */
+} mg_walker_params;
+
+/* Per-env state, SoA doubles: component c of env e at base[c*N + e]. */
+typedef struct mg_walker_state {
+    int32_t *task_id;     /* [N] */
+    double *pos;          /* [3][N] base body origin (world) */
+    double *rot;          /* [9][N] base body orientation (row-major) */
+    double *vel;          /* [3][N] base origin velocity (world) */
+    double *omega;        /* [3][N] base angular velocity (world) */
+    double *q, *qd;       /* [nj][N] */
+    double *potential;    /* [N] */
+    float *feet_contact;  /* [nf][N] */
+    int32_t *steps;       /* [N] */
+} mg_walker_state;
+
+/* WalkerBaseEnv.reset: base to its model pose, joints to joint_noise (f64 [nj][N], the caller draws
+ * U(-0.1,0.1) like walker_base.py:15; NULL = zeros), velocities zero, for envs with mask != 0
+ * (NULL = all); writes the reset observation rows (obs may be NULL). */
+int mg_walker_reset(const mg_walker_topology *topo, const mg_walker_models *models, const mg_walker_params *prm,
+                    int32_t n_envs, const mg_walker_state *state, const uint8_t *mask, const double *joint_noise,
+                    float *obs, void *stream);
+
+/* WalkerBaseEnv.step for all envs: torques from action (f32 [N][nj]), frame_skip physics sub-steps,
+ * calc_state -> obs f32 [N][8 + 2 nj + nf], reward f32 [N], rewards5 f32 [N][5] (alive, progress,
+ * electricity, joints_at_limit, feet_collision; may be NULL), done u8 [N]. */
+int mg_walker_step(const mg_walker_topology *topo, const mg_walker_models *models, const mg_walker_params *prm,
+                   int32_t n_envs, const mg_walker_state *state, const float *action, float *obs, float *reward,
+                   float *rewards5, uint8_t *done, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

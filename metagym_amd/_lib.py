@@ -71,6 +71,38 @@ class MazeView(C.Structure):
                 ("n_textures", C.c_int32), ("tex_size", C.c_int32)]
 
 
+WALKER_MAX_BODIES, WALKER_MAX_JOINTS, WALKER_MAX_SPHERES, WALKER_MAX_FEET = 16, 24, 40, 6
+
+
+class WalkerTopology(C.Structure):
+    """mg_walker_topology"""
+    _fields_ = [("n_bodies", C.c_int32), ("n_joints", C.c_int32), ("n_spheres", C.c_int32), ("n_feet", C.c_int32),
+                ("body_parent", C.c_int32 * WALKER_MAX_BODIES), ("joint_body", C.c_int32 * WALKER_MAX_JOINTS),
+                ("sphere_body", C.c_int32 * WALKER_MAX_SPHERES), ("foot_body", C.c_int32 * WALKER_MAX_FEET)]
+
+
+class WalkerModels(C.Structure):
+    """mg_walker_models"""
+    _fields_ = [("table", C.c_void_p), ("n_tasks", C.c_int32), ("model_stride", C.c_int32)]
+
+
+class WalkerParams(C.Structure):
+    """mg_walker_params"""
+    _fields_ = [("time_step", C.c_double), ("frame_skip", C.c_int32), ("solver_iterations", C.c_int32),
+                ("erp", C.c_double), ("limit_erp", C.c_double), ("gravity", C.c_double), ("friction", C.c_double),
+                ("alive_z", C.c_double), ("alive_bonus", C.c_double), ("dead_bonus", C.c_double),
+                ("initial_z", C.c_double), ("joints_at_limit_cost", C.c_double),
+                ("walk_target_x", C.c_double), ("walk_target_y", C.c_double),
+                ("max_steps", C.c_int32), ("floor_in_parts", C.c_int32)]
+
+
+class WalkerState(C.Structure):
+    """mg_walker_state (device pointers)"""
+    _fields_ = [("task_id", C.c_void_p), ("pos", C.c_void_p), ("rot", C.c_void_p), ("vel", C.c_void_p),
+                ("omega", C.c_void_p), ("q", C.c_void_p), ("qd", C.c_void_p), ("potential", C.c_void_p),
+                ("feet_contact", C.c_void_p), ("steps", C.c_void_p)]
+
+
 # symbol -> (restype, argtypes); tests/test_abi.py checks this list against include/metagym_hip.h
 _P = C.c_void_p
 SIGNATURES = {
@@ -93,6 +125,10 @@ SIGNATURES = {
                                  C.POINTER(MazeState), _P, _P, _P, _P, _P, _P]),
     "mg_maze3d_step": (C.c_int, [C.POINTER(MazeTasks), C.POINTER(MazeView), C.c_int32, C.c_int32, C.c_int32,
                                  C.c_int32, C.c_int32, C.POINTER(MazeState), _P, _P, _P, _P, _P, _P]),
+    "mg_walker_reset": (C.c_int, [C.POINTER(WalkerTopology), C.POINTER(WalkerModels), C.POINTER(WalkerParams),
+                                  C.c_int32, C.POINTER(WalkerState), _P, _P, _P, _P]),
+    "mg_walker_step": (C.c_int, [C.POINTER(WalkerTopology), C.POINTER(WalkerModels), C.POINTER(WalkerParams),
+                                 C.c_int32, C.POINTER(WalkerState), _P, _P, _P, _P, _P, _P]),
 }
 
 _lib = None

@@ -1,0 +1,201 @@
+"""MJCF -> flat articulated-body model (host side, runs once per task file).
+
+The reference hands the MJCF file to PyBullet (`loadMJCF`, metalocomotion/envs/utils/robot_bases.py:119),
+whose importer is not available here; this module reads the subset of MJCF the MetaLocomotion
+assets use (metalocomotion/envs/assets/humanoids/*.xml, ants/*.xml) and follows MuJoCo's documented
+semantics for it:
+
+  * `<compiler angle="degree" inertiafromgeom="true">`: joint ranges are degrees; masses and inertia
+    come from the geoms at the default density 1000 kg/m^3 (exact solid capsule / sphere formulas).
+  * one `<default>` block without classes: attribute defaults for `joint` and `geom`.
+  * bodies form a tree; the first worldbody child is the floating base (its `free` joint is
+    commented out in the assets, PyBullet makes the root body floating anyway).
+  * a body may carry several hinge joints: they act in document order, each later joint's anchor
+    and axis being carried along by the earlier ones (MuJoCo kinematic-tree semantics).
+  * geoms: `capsule` with `fromto` + radius `size[0]`, `sphere` with `pos` + radius.
+
+Output: `Model` — plain numpy arrays, body/joint order = document (depth-first) order, which is
+also the order PyBullet enumerates links and therefore the order of `ordered_joints`
+(robot_bases.py:54-95) that fixes the observation layout (walker_base.py:32).
+"""
+import xml.etree.ElementTree as ET
+
+import numpy as np
+
+DENSITY = 1000.0     # MuJoCo default geom density
+
+
+def _floats(s, n=None):
+    v = [float(x) for x in s.split()]
+    assert n is None or len(v) == n, (s, n)
+    return v
+
+
+def _quat_to_mat(q):
+    w, x, y, z = np.asarray(q, float) / np.linalg.norm(q)
+    return np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y)],
+                     [2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x)],
+                     [2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)]])
+
+
+def _sphere_inertia(r, density=DENSITY):
+    m = density * 4.0 / 3.0 * np.pi * r ** 3
+    return m, np.eye(3) * (0.4 * m * r * r)
+
+
+def _capsule_inertia(p0, p1, r, density=DENSITY):
+    """Solid capsule (cylinder + two hemispherical caps). Returns mass, com, inertia about com
+    in the frame the endpoints are given in."""
+    p0, p1 = np.asarray(p0, float), np.asarray(p1, float)
+    h = np.linalg.norm(p1 - p0)
+    mc = density * np.pi * r * r * h
+    mh = density * 2.0 / 3.0 * np.pi * r ** 3          # one hemisphere
+    m = mc + 2 * mh
+    i_ax = 0.5 * mc * r * r + 2 * (0.4 * mh * r * r)
+    d = h / 2 + 3.0 * r / 8.0                           # hemisphere com from the capsule centre
+    i_tr = mc * (3 * r * r + h * h) / 12.0 + 2 * ((83.0 / 320.0) * mh * r * r + mh * d * d)
+    z = (p1 - p0) / h if h > 0 else np.array([0.0, 0.0, 1.0])
+    zz = np.outer(z, z)
+    inertia = i_ax * zz + i_tr * (np.eye(3) - zz)
+    return m, 0.5 * (p0 + p1), inertia
+
+
+class Model(object):
+    """Flat arrays describing one robot. nb bodies, nj hinge joints, ng collision spheres.
+
+    body_parent[nb]   parent body index (-1 for the floating base)
+    body_pos[nb,3], body_rot[nb,3,3]   body frame in the parent body frame at zero joint angles
+    body_mass[nb], body_com[nb,3] (body frame), body_inertia[nb,3,3] (about the com, body frame)
+    joint_body[nj]    body the joint belongs to (joints of a body are consecutive, in order)
+    joint_anchor[nj,3], joint_axis[nj,3]   in the body frame; axis normalised
+    joint_lo/hi[nj] (rad), joint_armature/damping/stiffness[nj]
+    geom_friction     lateral friction coefficient of the robot's geoms (first entry of `friction`)
+    sph_body[ng], sph_pos[ng,3] (body frame), sph_radius[ng]   collision proxies: every sphere geom
+        and both end caps of every capsule geom (a capsule touches a plane at its caps)
+    foot_sph[...]     indices of the spheres that belong to the foot bodies
+    """
+
+    def __init__(self):
+        self.body_names, self.joint_names, self.geom_names = [], [], []
+
+    def dof(self):
+        return 6 + len(self.joint_names)
+
+    def to_dict(self):
+        d = {k: np.asarray(v) for k, v in self.__dict__.items() if isinstance(v, np.ndarray)}
+        d["body_names"] = np.asarray(self.body_names)
+        d["joint_names"] = np.asarray(self.joint_names)
+        d["foot_names"] = np.asarray(self.foot_names)
+        return d
+
+    @classmethod
+    def from_dict(cls, d):
+        m = cls()
+        for k in d:
+            v = d[k]
+            if k in ("body_names", "joint_names", "foot_names"):
+                setattr(m, k, [str(x) for x in v])
+            else:
+                setattr(m, k, np.asarray(v))
+        return m
+
+
+def load_mjcf(path_or_string, foot_names=("right_foot", "left_foot")):
+    text = path_or_string
+    if "<mujoco" not in text:
+        with open(path_or_string, "r") as f:
+            text = f.read()
+    root = ET.fromstring(text)
+    comp = root.find("compiler")
+    degrees = comp is None or comp.get("angle", "degree") == "degree"
+    jdef, gdef = {}, {}
+    dflt = root.find("default")
+    if dflt is not None:
+        if dflt.find("joint") is not None:
+            jdef = dict(dflt.find("joint").attrib)
+        if dflt.find("geom") is not None:
+            gdef = dict(dflt.find("geom").attrib)
+
+    bodies, joints, spheres, frictions = [], [], [], []
+
+    def visit(elem, parent):
+        b = len(bodies)
+        pos = np.array(_floats(elem.get("pos", "0 0 0"), 3))
+        rot = _quat_to_mat(_floats(elem.get("quat", "1 0 0 0"), 4))
+        masses, coms, inertias = [], [], []
+        for g in elem.findall("geom"):
+            a = dict(gdef)
+            a.update(g.attrib)
+            size = _floats(a["size"])
+            density = float(a.get("density", DENSITY))
+            frictions.append(_floats(a.get("friction", "1 0.005 0.0001"))[0])
+            if a.get("type", "sphere") == "capsule":
+                ft = _floats(a["fromto"], 6)
+                m, c, inertia = _capsule_inertia(ft[:3], ft[3:], size[0], density)
+                spheres.append((b, np.array(ft[:3]), size[0], a.get("name", "")))
+                spheres.append((b, np.array(ft[3:]), size[0], a.get("name", "")))
+            elif a.get("type", "sphere") == "sphere":
+                c = np.array(_floats(a.get("pos", "0 0 0"), 3))
+                m, inertia = _sphere_inertia(size[0], density)
+                spheres.append((b, c, size[0], a.get("name", "")))
+            else:
+                raise ValueError("unsupported geom type %r" % a.get("type"))
+            masses.append(m)
+            coms.append(c)
+            inertias.append(inertia)
+        mass = float(sum(masses))
+        com = sum(m * c for m, c in zip(masses, coms)) / mass if mass > 0 else np.zeros(3)
+        inertia = np.zeros((3, 3))
+        for m, c, i3 in zip(masses, coms, inertias):
+            d = c - com
+            inertia += i3 + m * (np.dot(d, d) * np.eye(3) - np.outer(d, d))
+        bodies.append(dict(name=elem.get("name", "body%d" % b), parent=parent, pos=pos, rot=rot, mass=mass, com=com,
+                           inertia=inertia))
+        for j in elem.findall("joint"):
+            a = dict(jdef)
+            a.update(j.attrib)
+            if a.get("type", "hinge") != "hinge":
+                raise ValueError("only hinge joints are supported (got %r)" % a.get("type"))
+            axis = np.array(_floats(a.get("axis", "0 0 1"), 3))
+            lo, hi = _floats(a.get("range", "0 0"), 2)
+            if degrees:
+                lo, hi = np.deg2rad(lo), np.deg2rad(hi)
+            joints.append(dict(name=a.get("name", "joint%d" % len(joints)), body=b,
+                               anchor=np.array(_floats(a.get("pos", "0 0 0"), 3)), axis=axis / np.linalg.norm(axis),
+                               lo=lo, hi=hi, armature=float(a.get("armature", 0)), damping=float(a.get("damping", 0)),
+                               stiffness=float(a.get("stiffness", 0))))
+        for child in elem.findall("body"):
+            visit(child, b)
+
+    world = root.find("worldbody")
+    top = world.findall("body")
+    assert len(top) == 1, "expected exactly one root body"
+    visit(top[0], -1)
+
+    m = Model()
+    m.body_names = [b["name"] for b in bodies]
+    m.joint_names = [j["name"] for j in joints]
+    m.body_parent = np.array([b["parent"] for b in bodies], np.int32)
+    m.body_pos = np.array([b["pos"] for b in bodies])
+    m.body_rot = np.array([b["rot"] for b in bodies])
+    m.body_mass = np.array([b["mass"] for b in bodies])
+    m.body_com = np.array([b["com"] for b in bodies])
+    m.body_inertia = np.array([b["inertia"] for b in bodies])
+    m.joint_body = np.array([j["body"] for j in joints], np.int32)
+    m.joint_anchor = np.array([j["anchor"] for j in joints])
+    m.joint_axis = np.array([j["axis"] for j in joints])
+    m.joint_lo = np.array([j["lo"] for j in joints])
+    m.joint_hi = np.array([j["hi"] for j in joints])
+    m.joint_armature = np.array([j["armature"] for j in joints])
+    m.joint_damping = np.array([j["damping"] for j in joints])
+    m.joint_stiffness = np.array([j["stiffness"] for j in joints])
+    m.sph_body = np.array([s[0] for s in spheres], np.int32)
+    m.sph_pos = np.array([s[1] for s in spheres])
+    m.sph_radius = np.array([s[2] for s in spheres])
+    m.geom_friction = np.array(float(np.mean(frictions)) if frictions else 1.0)   # lateral friction of the geoms
+    m.foot_names = list(foot_names)
+    m.foot_body = np.array([m.body_names.index(f) for f in foot_names], np.int32)
+    # joints must be grouped by body in DFS order with parents before children
+    assert all(m.body_parent[i] < i for i in range(len(bodies)))
+    assert np.all(np.diff(m.joint_body) >= 0)
+    return m

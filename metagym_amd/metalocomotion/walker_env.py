@@ -1,0 +1,212 @@
+"""Batched walker envs — host-side mirror of metagym/metalocomotion/envs:
+`MetaHumanoidEnv` (meta_humanoids/meta_humanoids_env.py:7-40) and `MetaAntEnv`
+(meta_ants/meta_ants_env.py:7-40) on top of `WalkerBaseEnv` (utils/walker_base_env.py).
+
+Same surface: `sample_task(task_type)` returns a variant file name, `set_task(task_file)` loads it,
+`reset()` / `step(action)` return the 44- (humanoid) or 28-dimensional (ant) observation, the summed
+reward, done and `info = {"rewards": [N,5], "steps": [N]}`. Batched extensions: `set_task` also takes
+a list of task files (or parsed `Model`s) plus `task_ids`, so env e can run its own body variant.
+
+The reference ships 386 MJCF variants per robot under metalocomotion/envs/assets/; this package does
+not copy them. Point `assets_dir` (or $METAGYM_LOCOMOTION_ASSETS) at that directory, or pass
+`Model` objects (metagym_amd.metalocomotion.load_mjcf).
+
+Physics parity with the reference is UNPINNED (the reference calls PyBullet); see DESIGN.md §3.5.
+"""
+import os
+import random
+
+import numpy as np
+import torch
+
+from .. import _lib
+from ..spaces import Box
+from .mjcf import Model, load_mjcf
+
+
+def pack_model(m, motor_torque):
+    """One row of the mg_walker_models table (layout documented in include/metagym_hip.h)."""
+    parts = [m.body_pos, m.body_rot, m.body_mass, m.body_com, m.body_inertia, m.joint_anchor, m.joint_axis,
+             m.joint_lo, m.joint_hi, m.joint_armature, m.joint_damping, m.joint_stiffness, motor_torque,
+             m.sph_pos, m.sph_radius]
+    return np.concatenate([np.asarray(p, np.float64).reshape(-1) for p in parts])
+
+
+class WalkerBatchEnv(object):
+    """Generic batched walker; subclasses fix the robot constants."""
+
+    robot_dir = None
+    variant_prefix = None
+    foot_list = ()
+    power = 1.0
+    motor_power = None            # per joint, or None -> 100 (robot_bases.py:93 power_coef)
+    alive_z, alive_bonus = 0.0, 1.0
+    initial_z = None              # None -> height of the base at reset (walker_base.py:44-45)
+
+    def __init__(self, num_envs=1, device="cuda", frame_skip=4, time_step=0.005, enable_render=False,
+                 max_steps=2000, assets_dir=None, solver_iterations=5):
+        self._lib = _lib.load()
+        self.num_envs = int(num_envs)
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise _lib.MetaGymHipError("metagym_amd runs on an AMD GPU only (got device %r); there is no CPU "
+                                       "path" % (device,))
+        self.frame_skip, self.time_step, self.max_steps = int(frame_skip), float(time_step), int(max_steps)
+        self.solver_iterations = int(solver_iterations)
+        self.assets_dir = assets_dir or os.environ.get("METAGYM_LOCOMOTION_ASSETS")
+        self.tra_tasks, self.tst_tasks, self.ood_tasks = [], [], []
+        d = self._robot_assets()
+        if d and os.path.isdir(d):
+            for f in sorted(os.listdir(d)):          # meta_humanoids_env.py:18-27
+                if f.find(self.variant_prefix + "_var_tra") == 0:
+                    self.tra_tasks.append(f)
+                if f.find(self.variant_prefix + "_var_tst") == 0:
+                    self.tst_tasks.append(f)
+                if f.find(self.variant_prefix + "_var_ood") == 0:
+                    self.ood_tasks.append(f)
+        self._robot_set = False
+        self.np_random = np.random.RandomState()
+
+    def _robot_assets(self):
+        return os.path.join(self.assets_dir, self.robot_dir) if self.assets_dir else None
+
+    # ------------------------------------------------------------------ tasks
+    def sample_task(self, task_type=None):
+        """meta_humanoids_env.py:32-40"""
+        if task_type is None or task_type == "TRAIN":
+            return random.choice(self.tra_tasks)
+        elif task_type == "TEST":
+            return random.choice(self.tst_tasks)
+        elif task_type == "OOD":
+            return random.choice(self.ood_tasks)
+        raise Exception("Unexpected task_type: %s" % task_type)
+
+    def _to_model(self, t):
+        if isinstance(t, Model):
+            return t
+        path = t if os.path.isabs(t) or self._robot_assets() is None else os.path.join(self._robot_assets(), t)
+        return load_mjcf(path, foot_names=self.foot_list)
+
+    def set_task(self, task_file, task_ids=None):
+        tasks = task_file if isinstance(task_file, (list, tuple)) else [task_file]
+        models = [self._to_model(t) for t in tasks]
+        m0 = models[0]
+        nb, nj, ns, nf = len(m0.body_parent), len(m0.joint_body), len(m0.sph_body), len(m0.foot_body)
+        for m in models:
+            assert (np.array_equal(m.body_parent, m0.body_parent) and np.array_equal(m.joint_body, m0.joint_body)
+                    and np.array_equal(m.sph_body, m0.sph_body)), "all tasks of a batch must share one topology"
+        tp = _lib.WalkerTopology()
+        tp.n_bodies, tp.n_joints, tp.n_spheres, tp.n_feet = nb, nj, ns, nf
+        for i, v in enumerate(m0.body_parent): tp.body_parent[i] = int(v)
+        for i, v in enumerate(m0.joint_body): tp.joint_body[i] = int(v)
+        for i, v in enumerate(m0.sph_body): tp.sphere_body[i] = int(v)
+        for i, v in enumerate(m0.foot_body): tp.foot_body[i] = int(v)
+        self._topo = tp
+        mp = np.full(nj, 100.0) if self.motor_power is None else np.asarray(self.motor_power, float)
+        assert len(mp) == nj
+        torque = mp * self.power                                   # humanoids.py:50-54, walker_base.py:26-29
+        table = np.stack([pack_model(m, torque) for m in models])
+        N, dev = self.num_envs, self.device
+        self._table = torch.from_numpy(table).to(dev).contiguous()
+        ms = _lib.WalkerModels()
+        ms.table, ms.n_tasks, ms.model_stride = self._table.data_ptr(), len(models), table.shape[1]
+        self._models_c = ms
+        self.models = models
+        self.n_joints, self.n_feet = nj, nf
+        self.obs_dim = 8 + 2 * nj + nf
+        if task_ids is None:
+            task_ids = torch.arange(N, dtype=torch.int32) % len(models)
+        self.task_id = torch.as_tensor(task_ids, dtype=torch.int32).to(dev).contiguous()
+        f64 = lambda *s: torch.zeros(*s, dtype=torch.float64, device=dev)
+        self.pos, self.rot, self.vel, self.omega = f64(3, N), f64(9, N), f64(3, N), f64(3, N)
+        self.q, self.qd, self.potential = f64(nj, N), f64(nj, N), f64(N)
+        self.feet_contact = torch.zeros(nf, N, dtype=torch.float32, device=dev)
+        self.steps = torch.zeros(N, dtype=torch.int32, device=dev)
+        st = _lib.WalkerState()
+        for k in ("task_id", "pos", "rot", "vel", "omega", "q", "qd", "potential", "feet_contact", "steps"):
+            setattr(st, k, getattr(self, k).data_ptr())
+        self._state_c = st
+        p = _lib.WalkerParams()
+        p.time_step, p.frame_skip, p.solver_iterations = self.time_step, self.frame_skip, self.solver_iterations
+        # Bullet multiplies the two bodies' lateral friction: ground 0.8 (stadium.py:23) x geom friction (MJCF)
+        p.limit_erp = 0.2                                          # Bullet's default constraint ERP
+        p.erp, p.gravity, p.friction = 0.9, 9.8, 0.8 * float(m0.geom_friction)   # scene_bases.py:55, env_bases.py:48
+        p.alive_z, p.alive_bonus, p.dead_bonus = self.alive_z, self.alive_bonus, -1.0
+        p.initial_z = float(self.initial_z if self.initial_z is not None else m0.body_pos[0][2])
+        p.joints_at_limit_cost = -0.1                              # walker_base_env.py:22
+        p.walk_target_x, p.walk_target_y = 1e3, 0.0                # walker_base.py:9-10
+        p.max_steps, p.floor_in_parts = self.max_steps, 1
+        self._params_c = p
+        self._obs = torch.zeros(N, self.obs_dim, dtype=torch.float32, device=dev)
+        self._reward = torch.zeros(N, dtype=torch.float32, device=dev)
+        self._rewards5 = torch.zeros(N, 5, dtype=torch.float32, device=dev)
+        self._done = torch.zeros(N, dtype=torch.bool, device=dev)
+        high = np.ones([nj])
+        self.action_space = Box(-high, high, dtype=np.float32)
+        self.observation_space = Box(-np.inf * np.ones([self.obs_dim]), np.inf * np.ones([self.obs_dim]),
+                                     dtype=np.float32)
+        self._robot_set = True
+
+    _STATE_KEYS = ("pos", "rot", "vel", "omega", "q", "qd", "potential", "feet_contact", "steps")
+
+    def state_dict(self):
+        return {k: getattr(self, k).clone() for k in self._STATE_KEYS}
+
+    def load_state_dict(self, sd):
+        for k in self._STATE_KEYS:
+            getattr(self, k).copy_(torch.as_tensor(sd[k]).to(getattr(self, k).dtype))
+
+    # ------------------------------------------------------------------ episode control
+    def reset(self, mask=None, seed=None, joint_noise=None):
+        if not self._robot_set:
+            raise Exception("BaseBulletEnv::_reset: must call set_robot and set_scene first")   # env_bases.py:68-69
+        N, dev = self.num_envs, self.device
+        if seed is not None:
+            self.np_random = np.random.RandomState(seed)
+        if joint_noise is None:                                    # walker_base.py:15, per env in joint order
+            joint_noise = self.np_random.uniform(low=-0.1, high=0.1, size=(N, self.n_joints))
+        jn = torch.as_tensor(np.ascontiguousarray(np.asarray(joint_noise, np.float64).T), device=dev)
+        assert jn.shape == (self.n_joints, N)
+        m = None
+        if mask is not None:
+            m = torch.as_tensor(mask, device=dev).to(torch.uint8).contiguous()
+        rc = self._lib.mg_walker_reset(self._topo, self._models_c, self._params_c, N, self._state_c, _lib.ptr(m),
+                                       _lib.ptr(jn), _lib.ptr(self._obs), _lib.current_stream(dev))
+        _lib.check(rc, "mg_walker_reset")
+        return self._obs
+
+    def step(self, action):
+        a = torch.as_tensor(action, dtype=torch.float32, device=self.device).contiguous()
+        assert a.shape == (self.num_envs, self.n_joints), "action must be [num_envs, n_joints]"
+        rc = self._lib.mg_walker_step(self._topo, self._models_c, self._params_c, self.num_envs, self._state_c,
+                                      _lib.ptr(a), _lib.ptr(self._obs), _lib.ptr(self._reward),
+                                      _lib.ptr(self._rewards5), _lib.ptr(self._done),
+                                      _lib.current_stream(self.device))
+        _lib.check(rc, "mg_walker_step")
+        return self._obs, self._reward, self._done, {"rewards": self._rewards5, "steps": self.steps}
+
+    def render(self, mode="human", close=False):
+        raise NotImplementedError("rendering is out of scope for the batched engine")
+
+    def close(self):
+        pass
+
+
+class MetaHumanoidEnv(WalkerBatchEnv):
+    """meta_humanoids/humanoids.py:6-57: 17 actions / 44 observations."""
+    robot_dir, variant_prefix = "humanoids", "humanoid"
+    foot_list = ("right_foot", "left_foot")
+    power = 0.41
+    motor_power = [100, 100, 100, 100, 100, 300, 200, 100, 100, 300, 200, 75, 75, 75, 75, 75, 75]   # humanoids.py:19-28
+    alive_z, alive_bonus = 0.50, 2.0      # humanoids.py:56
+    initial_z = 0.8                       # humanoids.py:48
+
+
+class MetaAntEnv(WalkerBatchEnv):
+    """meta_ants/ant.py:6-14: 8 actions / 28 observations."""
+    robot_dir, variant_prefix = "ants", "ant"
+    foot_list = ("front_left_foot", "front_right_foot", "left_back_foot", "right_back_foot")
+    power = 2.5
+    motor_power = None
+    alive_z, alive_bonus = 0.26, 1.0      # ant.py:13
+    initial_z = None

@@ -33,3 +33,9 @@ register("meta-maze-discrete-3D-v0", "metagym_amd.metamaze:MetaMazeDiscrete3D",
                  "task_type": "SURVIVAL"})
 register("meta-maze-2D-v0", "metagym_amd.metamaze:MetaMaze2D",
          kwargs={"enable_render": False, "max_steps": 200, "view_grid": 1, "task_type": "SURVIVAL"})
+
+# metagym/metalocomotion/__init__.py:19-37
+register("meta-humanoid-v0", "metagym_amd.metalocomotion:MetaHumanoidEnv",
+         kwargs={"frame_skip": 4, "time_step": 0.005, "enable_render": False, "max_steps": 2000})
+register("meta-ant-v0", "metagym_amd.metalocomotion:MetaAntEnv",
+         kwargs={"frame_skip": 4, "time_step": 0.005, "enable_render": False, "max_steps": 2000})

@@ -1,0 +1,345 @@
+"""oracle/abd.py — numpy (float64) restatement of the articulated-body step used for MetaLocomotion.
+
+TEST INFRASTRUCTURE (see oracle/__init__.py). **Parity unpinned**: in the reference the arithmetic of
+this path is `pybullet.stepSimulation()` (metalocomotion/envs/utils/scene_bases.py:50;
+pybullet>=3.0.7, setup.py:57,59), a third-party C++ library that is neither vendored in the
+reference nor installable here, and the reference's tests at that boundary assert nothing
+(metalocomotion/test.py). What is restated is the *published algorithm family* Bullet's
+btMultiBodyDynamicsWorld implements, with the reference's own parameters:
+
+  * reduced-coordinate multibody dynamics, floating base + hinge joints (Featherstone, "Rigid Body
+    Dynamics Algorithms", 2008): joint-space inertia matrix M(q) and bias forces h(q, u) — built here
+    from world-frame body Jacobians and a Newton-Euler pass instead of ABA (same equations);
+  * semi-implicit Euler at 4 sub-steps of 5 ms per env step (walker_base_env.py:7, scene_bases.py:56);
+  * velocity-level contact / joint-limit constraints solved by projected Gauss-Seidel ("sequential
+    impulses", Catto 2005) on the Delassus matrix J M^-1 J^T, 5 iterations (scene_bases.py:17),
+    Baumgarte position correction with ERP 0.9 (scene_bases.py:55), gravity 9.8 (env_bases.py:48),
+    ground = plane z=0 with lateral friction 0.8 (stadium.py:23) combined multiplicatively with the
+    geoms' 0.8 (humanoid.xml:5) like Bullet does.
+
+Stated assumptions (Bullet internals that cannot be checked here): MJCF joint `damping`,
+`stiffness`, `armature` act as in MuJoCo's documentation (explicit damping/spring torque, armature
+added to the diagonal of M); link inertia from solid-capsule / sphere formulas at density 1000;
+TORQUE_CONTROL torques persist across the 4 internal sub-steps; only body-vs-ground contacts
+(self-collision, enabled in the reference by robot_bases.py:119, is not modelled yet).
+
+The Python-side rules around the physics ARE pinned by the reference source and are restated
+exactly: torque = power * 0.41 * clip(a) (humanoids.py:50-54), observation (walker_base.py:31-64),
+reward / done (walker_base_env.py:43-82), reset noise U(-0.1, 0.1) on every joint (walker_base.py:15).
+
+Pure numpy with python loops: fine for the handful of envs the tests push through it.
+"""
+import numpy as np
+
+GRAVITY = np.array([0.0, 0.0, -9.8])
+
+
+def skew(v):
+    return np.array([[0, -v[2], v[1]], [v[2], 0, -v[0]], [-v[1], v[0], 0]])
+
+
+def rodrigues(axis, angle):
+    k = skew(axis)
+    return np.eye(3) + np.sin(angle) * k + (1.0 - np.cos(angle)) * (k @ k)
+
+
+class State(object):
+    def __init__(self, model):
+        nj = len(model.joint_lo)
+        self.pos = np.array(model.body_pos[0], float)     # base body origin, world
+        self.rot = np.array(model.body_rot[0], float)     # base body orientation, world
+        self.v = np.zeros(3)                               # base origin velocity, world
+        self.w = np.zeros(3)                               # base angular velocity, world
+        self.q = np.zeros(nj)
+        self.qd = np.zeros(nj)
+
+    def copy(self):
+        s = State.__new__(State)
+        for k in ("pos", "rot", "v", "w", "q", "qd"):
+            setattr(s, k, getattr(self, k).copy())
+        return s
+
+    def u(self):
+        return np.concatenate([self.v, self.w, self.qd])
+
+
+def kinematics(m, s):
+    """World frames. Returns dict: R[b], o[b], c[b] (com), p[j] (anchor), a[j] (axis)."""
+    nb, nj = len(m.body_parent), len(m.joint_body)
+    R, o = [None] * nb, [None] * nb
+    p, a = np.zeros((nj, 3)), np.zeros((nj, 3))
+    for b in range(nb):
+        if m.body_parent[b] < 0:
+            Rc, oc = s.rot.copy(), s.pos.copy()
+        else:
+            pb = m.body_parent[b]
+            Rc = R[pb] @ m.body_rot[b]
+            oc = o[pb] + R[pb] @ m.body_pos[b]
+        for j in np.nonzero(m.joint_body == b)[0]:
+            p[j] = oc + Rc @ m.joint_anchor[j]
+            a[j] = Rc @ m.joint_axis[j]
+            Rn = Rc @ rodrigues(m.joint_axis[j], s.q[j])
+            oc = p[j] - Rn @ m.joint_anchor[j]
+            Rc = Rn
+        R[b], o[b] = Rc, oc
+    c = np.array([o[b] + R[b] @ m.body_com[b] for b in range(nb)])
+    return dict(R=np.array(R), o=np.array(o), c=c, p=p, a=a)
+
+
+def ancestors_joints(m, b):
+    """indices of every joint between the base and body b (inclusive of b's own joints)."""
+    out = []
+    while b >= 0:
+        out.extend(np.nonzero(m.joint_body == b)[0].tolist())
+        b = m.body_parent[b]
+    return sorted(out)
+
+
+def point_jacobian(m, kin, b, x):
+    """3 x n Jacobian of the world velocity of point x attached to body b w.r.t. u = [v0, w0, qd]."""
+    n = 6 + len(m.joint_body)
+    J = np.zeros((3, n))
+    J[:, 0:3] = np.eye(3)
+    J[:, 3:6] = -skew(x - kin["o"][0])
+    for j in ancestors_joints(m, b):
+        J[:, 6 + j] = np.cross(kin["a"][j], x - kin["p"][j])
+    return J
+
+
+def angular_jacobian(m, kin, b):
+    n = 6 + len(m.joint_body)
+    J = np.zeros((3, n))
+    J[:, 3:6] = np.eye(3)
+    for j in ancestors_joints(m, b):
+        J[:, 6 + j] = kin["a"][j]
+    return J
+
+
+def mass_matrix_and_bias(m, s, kin=None):
+    """M(q) (with armature) and h(q,u) such that M du/dt + h = tau_generalised (gravity inside h)."""
+    kin = kin or kinematics(m, s)
+    nb, nj = len(m.body_parent), len(m.joint_body)
+    n = 6 + nj
+    M = np.zeros((n, n))
+    h = np.zeros(n)
+    # velocity-product accelerations (du/dt = 0), body by body
+    frame = [None] * nb       # (w, alpha, x_ref, a_ref) after the body's own joints
+    for b in range(nb):
+        if m.body_parent[b] < 0:
+            w, al, xr, ar = s.w.copy(), np.zeros(3), kin["o"][0].copy(), np.zeros(3)
+        else:
+            w, al, xr, ar = [x.copy() for x in frame[m.body_parent[b]]]
+        for j in np.nonzero(m.joint_body == b)[0]:
+            r = kin["p"][j] - xr
+            ar = ar + np.cross(al, r) + np.cross(w, np.cross(w, r))
+            xr = kin["p"][j].copy()
+            wj = kin["a"][j] * s.qd[j]
+            al = al + np.cross(w, wj)
+            w = w + wj
+        frame[b] = (w, al, xr, ar)
+        r = kin["c"][b] - xr
+        a_c = ar + np.cross(al, r) + np.cross(w, np.cross(w, r))
+        Iw = kin["R"][b] @ m.body_inertia[b] @ kin["R"][b].T
+        Jv = point_jacobian(m, kin, b, kin["c"][b])
+        Jw = angular_jacobian(m, kin, b)
+        M += m.body_mass[b] * Jv.T @ Jv + Jw.T @ Iw @ Jw
+        h += Jv.T @ (m.body_mass[b] * (a_c - GRAVITY)) + Jw.T @ (Iw @ al + np.cross(w, Iw @ w))
+    M[np.arange(6, n), np.arange(6, n)] += m.joint_armature
+    return M, h, kin, frame
+
+
+def integrate_positions(s, dt):
+    s.pos = s.pos + dt * s.v
+    ang = np.linalg.norm(s.w) * dt
+    if ang > 0:
+        s.rot = rodrigues(s.w / np.linalg.norm(s.w), ang) @ s.rot
+    s.q = s.q + dt * s.qd
+
+
+class Params(object):
+    def __init__(self, dt=0.005, substeps=4, iterations=5, erp=0.9, friction=0.8 * 0.8, power=0.41, max_contacts=16,
+                 limit_erp=0.2):
+        self.dt, self.substeps, self.iterations, self.erp, self.friction, self.power = dt, substeps, iterations, erp, friction, power
+        self.limit_erp = limit_erp            # Bullet's default constraint ERP (btContactSolverInfo::m_erp2 = 0.2);
+        #                                       setDefaultContactERP(0.9) only changes the contact ERP
+        self.max_contacts = max_contacts      # engine limit: the first max_contacts penetrating spheres are kept
+
+
+def constraint_rows(m, s, kin, prm):
+    """Rows (J, bias, kind, partner): kind 0 = unilateral (lambda >= 0), 1/2 = friction rows whose
+    bound is friction * lambda[partner]. bias is the target velocity along the row."""
+    rows = []
+    n = 6 + len(m.joint_body)
+    for g in range(len(m.sph_body)):
+        b = m.sph_body[g]
+        x = kin["o"][b] + kin["R"][b] @ m.sph_pos[g]
+        depth = m.sph_radius[g] - x[2]
+        if depth > 0.0 and len(rows) < 3 * prm.max_contacts:
+            xc = np.array([x[0], x[1], 0.0])           # contact point on the ground plane
+            Jc = point_jacobian(m, kin, b, xc)
+            k = len(rows)
+            rows.append((Jc[2], prm.erp * depth / prm.dt, 0, -1, g))
+            rows.append((Jc[0], 0.0, 1, k, g))
+            rows.append((Jc[1], 0.0, 2, k, g))
+    for j in range(len(m.joint_body)):
+        e = np.zeros(n)
+        if s.q[j] < m.joint_lo[j]:
+            e[6 + j] = 1.0
+            rows.append((e, prm.limit_erp * (m.joint_lo[j] - s.q[j]) / prm.dt, 0, -1, -1))
+        elif s.q[j] > m.joint_hi[j]:
+            e[6 + j] = -1.0
+            rows.append((e, prm.limit_erp * (s.q[j] - m.joint_hi[j]) / prm.dt, 0, -1, -1))
+    return rows
+
+
+def pgs(A, rhs, rows, friction, iterations):
+    """Projected Gauss-Seidel on  w = A lam + rhs,  0 <= lam  _|_  w >= 0  (unilateral rows) and
+    |lam_t| <= friction * lam_n (friction rows), natural row order, zero warm start."""
+    lam = np.zeros(len(rows))
+    for _ in range(iterations):
+        for r, (_, _, kind, partner, _) in enumerate(rows):
+            if A[r, r] <= 0:
+                continue
+            x = lam[r] - (A[r] @ lam + rhs[r]) / A[r, r]
+            if kind == 0:
+                lam[r] = max(0.0, x)
+            else:
+                lim = friction * lam[partner]
+                lam[r] = min(lim, max(-lim, x))
+    return lam
+
+
+def substep(m, s, tau_motor, prm):
+    """One 5 ms sub-step. Returns the set of sphere indices in contact."""
+    M, h, kin, _ = mass_matrix_and_bias(m, s)
+    n = M.shape[0]
+    tau = np.zeros(n)
+    tau[6:] = tau_motor - m.joint_damping * s.qd - m.joint_stiffness * s.q
+    u = s.u()
+    L = np.linalg.cholesky(M)
+    solve = lambda rhs: np.linalg.solve(L.T, np.linalg.solve(L, rhs))
+    u_star = u + prm.dt * solve(tau - h)
+    rows = constraint_rows(m, s, kin, prm)
+    touching = set()
+    if rows:
+        J = np.array([r[0] for r in rows])
+        MinvJT = solve(J.T)
+        A = J @ MinvJT
+        rhs = J @ u_star - np.array([r[1] for r in rows])
+        lam = pgs(A, rhs, rows, prm.friction, prm.iterations)
+        u_star = u_star + MinvJT @ lam
+        touching = {r[4] for r in rows if r[2] == 0 and r[4] >= 0}
+    s.v, s.w, s.qd = u_star[0:3].copy(), u_star[3:6].copy(), u_star[6:].copy()
+    integrate_positions(s, prm.dt)
+    return touching
+
+
+def energy(m, s):
+    M, _, kin, _ = mass_matrix_and_bias(m, s)
+    u = s.u()
+    pot = -sum(m.body_mass[b] * GRAVITY @ kin["c"][b] for b in range(len(m.body_parent)))
+    return 0.5 * u @ M @ u, pot
+
+
+def momentum(m, s):
+    """total linear momentum and angular momentum about the world origin."""
+    kin = kinematics(m, s)
+    u = s.u()
+    P, Lw = np.zeros(3), np.zeros(3)
+    for b in range(len(m.body_parent)):
+        vc = point_jacobian(m, kin, b, kin["c"][b]) @ u
+        wb = angular_jacobian(m, kin, b) @ u
+        Iw = kin["R"][b] @ m.body_inertia[b] @ kin["R"][b].T
+        P += m.body_mass[b] * vc
+        Lw += np.cross(kin["c"][b], m.body_mass[b] * vc) + Iw @ wb
+    return P, Lw
+
+
+# ---- the pinned Python side: metalocomotion/envs/utils/walker_base.py, walker_base_env.py --------
+
+HUMANOID_MOTOR_POWER = np.array([100, 100, 100, 100, 100, 300, 200, 100, 100, 300, 200, 75, 75, 75, 75, 75, 75], float)
+
+
+def rot_to_rpy(R):
+    """pybullet.getEulerFromQuaternion convention (XYZ fixed-axis roll, pitch, yaw)."""
+    sy = -R[2, 0]
+    pitch = np.arcsin(np.clip(sy, -1.0, 1.0))
+    roll = np.arctan2(R[2, 1], R[2, 2])
+    yaw = np.arctan2(R[1, 0], R[0, 0])
+    return roll, pitch, yaw
+
+
+class WalkerEnv(object):
+    """calc_state / step bookkeeping of WalkerBase + WalkerBaseEnv around `substep`."""
+
+    def __init__(self, model, prm=None, motor_power=HUMANOID_MOTOR_POWER, alive_z=0.50, alive_bonus=2.0,
+                 max_steps=2000, initial_z=0.8, floor_in_parts=True):
+        self.m, self.prm = model, prm or Params()
+        self.motor_power, self.alive_z, self.alive_bonus = motor_power, alive_z, alive_bonus
+        self.max_steps, self.initial_z = max_steps, initial_z
+        # WalkerBaseEnv.reset re-runs addToScene on the ground bodies, so the floor link (at the
+        # origin) joins robot.parts (walker_base_env.py:30-31) and dilutes the mean part position
+        self.floor_in_parts = floor_in_parts
+        self.walk_target = np.array([1e3, 0.0])
+
+    def reset(self, joint_noise):
+        s = State(self.m)
+        s.q = np.asarray(joint_noise, float).copy()       # walker_base.py:15
+        self.s = s
+        self.steps = 0
+        self.feet_contact = np.zeros(len(self.m.foot_body))
+        obs = self.calc_state()
+        self.potential = self.calc_potential()
+        return obs
+
+    def calc_state(self):
+        m, s = self.m, self.s
+        kin = kinematics(m, s)
+        lo, hi = m.joint_lo, m.joint_hi
+        pos = 2 * (s.q - 0.5 * (lo + hi)) / (hi - lo)                      # robot_bases.py:317-323
+        vel = 0.1 * s.qd                                                    # :327-328 (revolute)
+        j = np.stack([pos, vel], 1).astype(np.float32).flatten()
+        self.joints_at_limit = int(np.count_nonzero(np.abs(j[0::2]) > 0.99))
+        parts = list(kin["o"])
+        if self.floor_in_parts:
+            parts = parts + [np.zeros(3)]
+        parts = np.array(parts)
+        self.body_xyz = (parts[:, 0].mean(), parts[:, 1].mean(), kin["o"][0][2])
+        roll, pitch, yaw = rot_to_rpy(kin["R"][0])
+        self.body_rpy = (roll, pitch, yaw)
+        z = self.body_xyz[2]
+        theta = np.arctan2(self.walk_target[1] - self.body_xyz[1], self.walk_target[0] - self.body_xyz[0])
+        self.walk_target_dist = np.linalg.norm([self.walk_target[1] - self.body_xyz[1],
+                                                self.walk_target[0] - self.body_xyz[0]])
+        ang = theta - yaw
+        c, sn = np.cos(-yaw), np.sin(-yaw)
+        rot_speed = np.array([[c, -sn, 0], [sn, c, 0], [0, 0, 1]])
+        vx, vy, vz = rot_speed @ s.v
+        more = np.array([z - self.initial_z, np.sin(ang), np.cos(ang), 0.3 * vx, 0.3 * vy, 0.3 * vz, roll, pitch],
+                        dtype=np.float32)
+        return np.clip(np.concatenate([more, j, self.feet_contact.astype(np.float32)]), -5, +5)
+
+    def calc_potential(self):
+        return -self.walk_target_dist / (self.prm.dt * self.prm.substeps)   # walker_base.py:66-82
+
+    def step(self, action):
+        m, prm = self.m, self.prm
+        a = np.clip(np.asarray(action, float), -1, 1)
+        tau = self.motor_power * prm.power * a                               # humanoids.py:50-54
+        touching = set()
+        for _ in range(prm.substeps):
+            touching = substep(m, self.s, tau, prm)
+        # the reference computes the state BEFORE refreshing feet_contact (walker_base_env.py:46 vs
+        # :57-63), so the observation carries the previous step's contact flags
+        state = self.calc_state()
+        for i, fb in enumerate(m.foot_body):                                 # walker_base_env.py:57-63
+            self.feet_contact[i] = 1.0 if any(m.sph_body[g] == fb for g in touching) else 0.0
+        alive = float(self.alive_bonus if state[0] + self.initial_z > self.alive_z else -1)
+        done = alive < 0 or not np.isfinite(state).all()
+        old = self.potential
+        self.potential = self.calc_potential()
+        progress = float(self.potential - old)
+        rewards = [alive, progress, 0.0, float(-0.1 * self.joints_at_limit), 0.0]
+        self.steps += 1
+        done = bool(done) or self.steps >= self.max_steps
+        return state, sum(rewards), done, {"rewards": rewards, "steps": self.steps}

@@ -1,0 +1,145 @@
+"""oracle/abd.py (numpy restatement of the articulated-body step) — physical invariants.
+The physics of this path cannot be pinned against the reference (PyBullet is not in the reference
+tree), so the oracle itself is validated by what any correct multibody step must satisfy."""
+import copy
+
+import numpy as np
+import pytest
+
+from oracle import abd
+from walker_fixtures import load_models
+
+MODELS = load_models()
+
+
+def _frictionless_free(m):
+    m = copy.deepcopy(m)
+    m.joint_damping[:] = 0
+    m.joint_stiffness[:] = 0
+    m.joint_lo[:] = -100
+    m.joint_hi[:] = 100
+    return m
+
+
+def _random_state(m, seed, z=10.0):
+    rs = np.random.RandomState(seed)
+    s = abd.State(m)
+    s.pos[2] = z
+    nj = len(m.joint_lo)
+    s.q = rs.uniform(-0.3, 0.3, nj)
+    s.qd = rs.uniform(-2, 2, nj)
+    s.w = rs.uniform(-1, 1, 3)
+    s.v = rs.uniform(-1, 1, 3)
+    return s
+
+
+def test_parsed_models_are_sane():
+    h = MODELS["humanoid"]
+    assert len(h.body_parent) == 13 and len(h.joint_body) == 17 and len(h.foot_body) == 2
+    assert h.joint_names[:4] == ["abdomen_z", "abdomen_y", "abdomen_x", "right_hip_x"]     # humanoids.py:18-28 order
+    assert 35 < h.body_mass.sum() < 55                   # ~42 kg of density-1000 capsules
+    assert abs(h.body_pos[0][2] - 1.4) < 1e-12           # humanoid.xml:16
+    a = MODELS["ant"]
+    assert len(a.joint_body) == 8 and len(a.foot_body) == 4 and abs(a.geom_friction - 1.5) < 1e-12
+    for m in MODELS.values():
+        for I in m.body_inertia:                          # symmetric positive definite
+            assert np.allclose(I, I.T) and np.all(np.linalg.eigvalsh(I) > 0)
+        assert np.allclose(np.linalg.norm(m.joint_axis, axis=1), 1.0)
+        assert np.all(m.joint_lo < m.joint_hi)
+
+
+@pytest.mark.parametrize("name", ["humanoid", "ant"])
+def test_mass_matrix_matches_kinetic_energy(name):
+    """0.5 u^T M u == sum_b 0.5 m |v_c|^2 + 0.5 w^T I w, and M is symmetric positive definite."""
+    m = _frictionless_free(MODELS[name])
+    s = _random_state(m, 1)
+    M, h, kin, _ = abd.mass_matrix_and_bias(m, s)
+    u = s.u()
+    ke = 0.0
+    for b in range(len(m.body_parent)):
+        vc = abd.point_jacobian(m, kin, b, kin["c"][b]) @ u
+        wb = abd.angular_jacobian(m, kin, b) @ u
+        Iw = kin["R"][b] @ m.body_inertia[b] @ kin["R"][b].T
+        ke += 0.5 * m.body_mass[b] * vc @ vc + 0.5 * wb @ Iw @ wb
+    ke += 0.5 * np.sum(m.joint_armature * s.qd ** 2)
+    assert abs(0.5 * u @ M @ u - ke) < 1e-9 * ke
+    assert np.allclose(M, M.T) and np.all(np.linalg.eigvalsh(M) > 0)
+
+
+@pytest.mark.parametrize("name", ["humanoid", "ant"])
+def test_free_flight_conserves_momentum_and_energy(name):
+    """No gravity, no damping, no limits: linear & angular momentum and energy are conserved; the
+    first-order integrator's drift halves when dt halves."""
+    m = _frictionless_free(MODELS[name])
+    g = abd.GRAVITY.copy()
+    abd.GRAVITY[:] = 0
+    try:
+        drifts = []
+        for dt in (0.001, 0.0005):
+            s = _random_state(m, 0)
+            T0, _ = abd.energy(m, s)
+            P0, L0 = abd.momentum(m, s)
+            prm = abd.Params(dt=dt)
+            for _ in range(int(round(0.05 / dt))):
+                abd.substep(m, s, np.zeros(len(m.joint_lo)), prm)
+            T1, _ = abd.energy(m, s)
+            P1, L1 = abd.momentum(m, s)
+            drifts.append((abs(T1 - T0) / T0, np.abs(P1 - P0).max() / np.abs(P0).max(),
+                           np.abs(L1 - L0).max() / np.abs(L0).max()))
+        for a, b in zip(*drifts):
+            assert a < 2e-3 and b < 0.6 * a + 1e-9, drifts
+    finally:
+        abd.GRAVITY[:] = g
+
+
+def test_free_fall_gains_momentum_mg_t():
+    m = _frictionless_free(MODELS["humanoid"])
+    s = _random_state(m, 3)
+    P0, _ = abd.momentum(m, s)
+    prm = abd.Params(dt=0.001)
+    for _ in range(100):
+        abd.substep(m, s, np.zeros(17), prm)
+    P1, _ = abd.momentum(m, s)
+    expect = -9.8 * m.body_mass.sum() * 0.1
+    assert abs((P1 - P0)[2] - expect) < 0.02 * abs(expect)
+    assert np.abs((P1 - P0)[:2]).max() < 0.02 * abs(expect)
+
+
+def test_instantaneous_momentum_balance():
+    """With du/dt = -M^-1 h (no torques) the total momentum changes at exactly m*g: checks the bias term."""
+    m = _frictionless_free(MODELS["humanoid"])
+    s = _random_state(m, 5)
+    M, h, _, _ = abd.mass_matrix_and_bias(m, s)
+    ud = -np.linalg.solve(M, h)
+    eps = 1e-6
+    s2 = s.copy()
+    u = s.u() + eps * ud
+    s2.v, s2.w, s2.qd = u[:3], u[3:6], u[6:]
+    abd.integrate_positions(s2, eps)
+    P0, L0 = abd.momentum(m, s)
+    P1, L1 = abd.momentum(m, s2)
+    dP = (P1 - P0) / eps
+    assert np.allclose(dP, [0, 0, -9.8 * m.body_mass.sum()], atol=2e-3 * 9.8 * m.body_mass.sum())
+
+
+@pytest.mark.parametrize("name,feet_z", [("humanoid", 0.0), ("ant", 0.0)])
+def test_drop_on_ground_settles_without_sinking(name, feet_z):
+    """Zero action from the reset pose: the robot falls / collapses onto the plane; no collision
+    sphere ends more than 5 mm below the ground, velocities stay bounded, and once at rest the
+    contact impulses carry the weight (vertical momentum stops changing)."""
+    m = MODELS[name]
+    env = abd.WalkerEnv(m, motor_power=np.full(len(m.joint_lo), 100.0) if name == "ant" else abd.HUMANOID_MOTOR_POWER,
+                        alive_z=-1.0)
+    env.reset(np.zeros(len(m.joint_lo)))
+    worst_pen, vmax = 0.0, 0.0
+    for t in range(150):
+        env.step(np.zeros(len(m.joint_lo)))
+        kin = abd.kinematics(m, env.s)
+        for g, b in enumerate(m.sph_body):
+            x = kin["o"][b] + kin["R"][b] @ m.sph_pos[g]
+            worst_pen = max(worst_pen, m.sph_radius[g] - x[2])
+        vmax = max(vmax, np.abs(env.s.u()).max())
+    assert worst_pen < 0.02, worst_pen
+    assert vmax < 80.0, vmax
+    P, _ = abd.momentum(m, env.s)
+    assert abs(P[2]) < 0.05 * 9.8 * m.body_mass.sum() * 0.02 * 50      # essentially at rest vertically
