@@ -297,6 +297,8 @@ typedef struct mg_walker_params {
     double walk_target_x, walk_target_y;       /* 1e3, 0 */
     int32_t max_steps;
     int32_t floor_in_parts;    /* 1: the floor link counts in the mean part position (walker_base_env.py:30-31) */
+    int32_t mapping;           /* 1 (default): wave per env, LDS-resident; 0: lane per env (cross-check) */
+    int32_t reserved;
 } mg_walker_params;
 
 /* Per-env state, SoA doubles: component c of env e at base[c*N + e]. */

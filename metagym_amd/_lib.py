@@ -93,7 +93,8 @@ class WalkerParams(C.Structure):
                 ("alive_z", C.c_double), ("alive_bonus", C.c_double), ("dead_bonus", C.c_double),
                 ("initial_z", C.c_double), ("joints_at_limit_cost", C.c_double),
                 ("walk_target_x", C.c_double), ("walk_target_y", C.c_double),
-                ("max_steps", C.c_int32), ("floor_in_parts", C.c_int32)]
+                ("max_steps", C.c_int32), ("floor_in_parts", C.c_int32), ("mapping", C.c_int32),
+                ("reserved", C.c_int32)]
 
 
 class WalkerState(C.Structure):

@@ -30,7 +30,7 @@ constexpr int NB = MG_WALKER_MAX_BODIES;
 constexpr int NJ = MG_WALKER_MAX_JOINTS;
 constexpr int NS = MG_WALKER_MAX_SPHERES;
 constexpr int ND = 6 + NJ;          // max generalized velocities
-constexpr int MAXC = 16;            // max simultaneous ground contacts per env (first MAXC penetrating spheres)
+constexpr int MAXC = 12;            // max simultaneous ground contacts per env (first MAXC penetrating spheres)
 constexpr int MAXR = 3 * MAXC + NJ; // max constraint rows
 
 struct ModelRef {   // offsets into one task's table row
@@ -473,6 +473,547 @@ __global__ __launch_bounds__(WK_BLOCK) void walker_reset_kernel(mg_walker_topolo
     store_env(st, n_envs, nj, e, s);
 }
 
+
+// ======================================================================================================
+// Wave-per-env mapping (default). One 64-lane wavefront owns one env; its whole work set lives in LDS
+// (~31 KB for the humanoid: kinematics, M, h, constraint Jacobians J and their images W = M^-1 J^T),
+// so five envs are resident per CU and nothing spills to scratch. Lanes are dealt
+//   * bodies (tree level by tree level) for kinematics and the Newton-Euler pass,
+//   * matrix entries for M, rows/columns for the Cholesky factorisation and the triangular solves,
+//   * collision spheres / joints for constraint detection (ballot + popcount gives every constraint
+//     its row index in sphere / joint order, the same order the oracle uses),
+//   * constraint rows for W = M^-1 J^T (each lane back-substitutes its own right-hand side),
+//   * generalized coordinates for the PGS sweep (J_r . u by a wave reduction, u += W_r dlambda per lane).
+// Same equations as the lane-per-env kernel above; only the summation order of the dot products differs.
+// ======================================================================================================
+
+constexpr int WV = 64;
+constexpr int W_MAXC = 12;   // ground contacts kept per env (first W_MAXC penetrating spheres)
+
+// Sum over the 64 lanes without LDS: four DPP steps fold each 16-lane row (quad_perm xor-1, xor-2,
+// row_half_mirror, row_mirror), then the four row totals are fetched with v_readlane.
+template <int CTRL>
+__device__ __forceinline__ double dpp_add(double v) {
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, false);
+    return v + __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double lane_value(double v, int lane) {
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), lane),
+                            __builtin_amdgcn_readlane(__double2loint(v), lane));
+}
+__device__ __forceinline__ double wave_sum(double v) {
+    v = dpp_add<0xB1>(v);    // quad_perm [1,0,3,2]
+    v = dpp_add<0x4E>(v);    // quad_perm [2,3,0,1]
+    v = dpp_add<0x141>(v);   // row_half_mirror
+    v = dpp_add<0x140>(v);   // row_mirror
+    return (lane_value(v, 0) + lane_value(v, 16)) + (lane_value(v, 32) + lane_value(v, 48));
+}
+
+// One wavefront = one workgroup: LDS operations of a wave retire in program order, so ordering between
+// lanes needs no s_barrier and no counter drain — only a compiler barrier so accesses are not reordered.
+#define WSYNC()                                                 \
+    do {                                                        \
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  \
+        __builtin_amdgcn_wave_barrier();                        \
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");  \
+    } while (0)
+
+struct WaveLds {   // pointers into the env's LDS slab
+    double *R, *o, *c, *p, *a;               // kinematics
+    double *fw, *fal, *fxr, *far_;           // frames after each body's joints
+    double *F, *Nn, *Iw;                     // per-body bias wrench and world inertia
+    double *M, *h, *x, *idg;                 // joint-space inertia (then its Cholesky factor), bias, scratch
+                                             // vector, reciprocal Cholesky diagonal
+    double *q, *qd, *tau;
+    double *base;                            // pos[3] rot[9] vel[3] omega[3]
+    double *J, *Wm, *bias, *diag, *lam;
+    double *cx;                              // contact points (x, y, depth) per contact
+    double *sc;                              // sin / cos of every joint angle
+    int *mask, *depth, *jstart, *jcount, *poff, *kind, *partner, *csphere, *misc;
+};
+
+__host__ __device__ inline size_t wave_lds_doubles(int nb, int nj, int maxr) {
+    const int n = 6 + nj;
+    return (size_t)nb * (9 + 3 + 3) + (size_t)nj * 6 + (size_t)nb * 12 + (size_t)nb * (3 + 3 + 9) + (size_t)n * n +
+           3 * (size_t)n + 3 * (size_t)nj + 18 + 2 * (size_t)maxr * n + 3 * (size_t)maxr + 3 * (size_t)W_MAXC +
+           2 * (size_t)nj;
+}
+__host__ __device__ inline size_t wave_lds_ints(int nb, int maxr) { return 5 * (size_t)nb + 2 * (size_t)maxr + W_MAXC + 8; }
+
+__device__ __forceinline__ WaveLds carve(unsigned char *smem, int nb, int nj, int maxr) {
+    const int n = 6 + nj;
+    WaveLds L;
+    double *d = reinterpret_cast<double *>(smem);
+    L.R = d; d += 9 * nb; L.o = d; d += 3 * nb; L.c = d; d += 3 * nb; L.p = d; d += 3 * nj; L.a = d; d += 3 * nj;
+    L.fw = d; d += 3 * nb; L.fal = d; d += 3 * nb; L.fxr = d; d += 3 * nb; L.far_ = d; d += 3 * nb;
+    L.F = d; d += 3 * nb; L.Nn = d; d += 3 * nb; L.Iw = d; d += 9 * nb;
+    L.M = d; d += n * n; L.h = d; d += n; L.x = d; d += n; L.idg = d; d += n;
+    L.q = d; d += nj; L.qd = d; d += nj; L.tau = d; d += nj;
+    L.base = d; d += 18;
+    L.J = d; d += (size_t)maxr * n; L.Wm = d; d += (size_t)maxr * n;
+    L.bias = d; d += maxr; L.diag = d; d += maxr; L.lam = d; d += maxr;
+    L.cx = d; d += 3 * W_MAXC;
+    L.sc = d; d += 2 * nj;
+    int *i = reinterpret_cast<int *>(d);
+    L.mask = i; i += nb; L.depth = i; i += nb; L.jstart = i; i += nb; L.jcount = i; i += nb; L.poff = i; i += nb;
+    L.kind = i; i += maxr; L.partner = i; i += maxr; L.csphere = i; i += W_MAXC; L.misc = i;
+    return L;
+}
+
+__device__ __forceinline__ V3 ldv(const double *p, int i) { return V3{p[3 * i], p[3 * i + 1], p[3 * i + 2]}; }
+__device__ __forceinline__ void stv(double *p, int i, V3 v) { p[3 * i] = v.x; p[3 * i + 1] = v.y; p[3 * i + 2] = v.z; }
+
+// Jacobian columns from LDS-resident kinematics
+__device__ __forceinline__ V3 wjac_lin(const WaveLds &L, unsigned mk, V3 x, int d) {
+    if (d < 3) return V3{d == 0 ? 1.0 : 0.0, d == 1 ? 1.0 : 0.0, d == 2 ? 1.0 : 0.0};
+    if (d < 6) {
+        const V3 e{d == 3 ? 1.0 : 0.0, d == 4 ? 1.0 : 0.0, d == 5 ? 1.0 : 0.0};
+        return cross(e, x - ldv(L.o, 0));
+    }
+    const int j = d - 6;
+    if (!((mk >> j) & 1u)) return V3{0, 0, 0};
+    return cross(ldv(L.a, j), x - ldv(L.p, j));
+}
+__device__ __forceinline__ V3 wjac_ang(const WaveLds &L, unsigned mk, int d) {
+    if (d < 3) return V3{0, 0, 0};
+    if (d < 6) return V3{d == 3 ? 1.0 : 0.0, d == 4 ? 1.0 : 0.0, d == 5 ? 1.0 : 0.0};
+    const int j = d - 6;
+    if (!((mk >> j) & 1u)) return V3{0, 0, 0};
+    return ldv(L.a, j);
+}
+
+// kinematics + velocity-product frames, bodies of one tree level in parallel (lane = body)
+__device__ __forceinline__ void rodrigues_sc(V3 k, double s, double c, double *R) {
+    const double v = 1.0 - c;
+    R[0] = c + k.x * k.x * v;       R[1] = k.x * k.y * v - k.z * s; R[2] = k.x * k.z * v + k.y * s;
+    R[3] = k.y * k.x * v + k.z * s; R[4] = c + k.y * k.y * v;       R[5] = k.y * k.z * v - k.x * s;
+    R[6] = k.z * k.x * v - k.y * s; R[7] = k.z * k.y * v + k.x * s; R[8] = c + k.z * k.z * v;
+}
+
+__device__ void wave_kinematics(const mg_walker_topology &tp, const ModelRef &m, const WaveLds &L, int lane,
+                                int max_depth, bool with_frames) {
+    const int nb = tp.n_bodies, nj = tp.n_joints;
+    // the f64 sin/cos of all joint angles at once (lane = joint): the level loop below is serial in the
+    // tree depth and must not carry ~300 instructions of range reduction per joint
+    if (lane < nj) {
+        const double qj = L.q[lane];
+        L.sc[2 * lane] = sin(qj);
+        L.sc[2 * lane + 1] = cos(qj);
+    }
+    WSYNC();
+    for (int level = 0; level <= max_depth; ++level) {
+        if (lane < nb && L.depth[lane] == level) {
+            const int b = lane, pb = tp.body_parent[b];
+            double Rc[9];
+            V3 oc, w, al, xr, ar;
+            unsigned mk = 0;
+            if (pb < 0) {
+                for (int i = 0; i < 9; ++i) Rc[i] = L.base[3 + i];
+                oc = ldv(L.base, 0);
+                w = V3{L.base[15], L.base[16], L.base[17]};
+                al = v3(0, 0, 0); xr = oc; ar = v3(0, 0, 0);
+            } else {
+                mulMM(L.R + 9 * pb, m.body_rot + 9 * b, Rc);
+                oc = ldv(L.o, pb) + mulMv(L.R + 9 * pb, ld3(m.body_pos + 3 * b));
+                mk = (unsigned)L.mask[pb];
+                w = ldv(L.fw, pb); al = ldv(L.fal, pb); xr = ldv(L.fxr, pb); ar = ldv(L.far_, pb);
+            }
+            const int j0 = L.jstart[b], j1 = j0 + L.jcount[b];
+            for (int j = j0; j < j1; ++j) {
+                const V3 anchor = ld3(m.joint_anchor + 3 * j), axis = ld3(m.joint_axis + 3 * j);
+                const V3 pj = oc + mulMv(Rc, anchor), aj = mulMv(Rc, axis);
+                stv(L.p, j, pj);
+                stv(L.a, j, aj);
+                double Rj[9], Rn[9];
+                rodrigues_sc(axis, L.sc[2 * j], L.sc[2 * j + 1], Rj);
+                mulMM(Rc, Rj, Rn);
+                oc = pj - mulMv(Rn, anchor);
+                for (int i = 0; i < 9; ++i) Rc[i] = Rn[i];
+                mk |= 1u << j;
+                if (with_frames) {
+                    const V3 r = pj - xr;
+                    ar = ar + cross(al, r) + cross(w, cross(w, r));
+                    xr = pj;
+                    const V3 wj = L.qd[j] * aj;
+                    al = al + cross(w, wj);
+                    w = w + wj;
+                }
+            }
+            for (int i = 0; i < 9; ++i) L.R[9 * b + i] = Rc[i];
+            stv(L.o, b, oc);
+            const V3 cb = oc + mulMv(Rc, ld3(m.body_com + 3 * b));
+            stv(L.c, b, cb);
+            L.mask[b] = (int)mk;
+            if (with_frames) {
+                stv(L.fw, b, w); stv(L.fal, b, al); stv(L.fxr, b, xr); stv(L.far_, b, ar);
+            }
+        }
+        WSYNC();
+    }
+}
+
+template <int NMAX>
+__device__ void wave_substep(const mg_walker_topology &tp, const ModelRef &m, const mg_walker_params &prm,
+                             const WaveLds &L, int lane, int max_depth, int maxr, unsigned long long &touch_mask) {
+    const int nb = tp.n_bodies, nj = tp.n_joints, ns = tp.n_spheres, n = 6 + nj;
+    const double dt = prm.time_step;
+    wave_kinematics(tp, m, L, lane, max_depth, true);
+    // ---- per-body world inertia and bias wrench (lane = body) ---------------------------------------
+    if (lane < nb) {
+        const int b = lane;
+        const V3 w = ldv(L.fw, b), al = ldv(L.fal, b), xr = ldv(L.fxr, b), ar = ldv(L.far_, b);
+        const V3 r = ldv(L.c, b) - xr;
+        const V3 a_c = ar + cross(al, r) + cross(w, cross(w, r));
+        double RI[9], Iw[9], Rt[9];
+        mulMM(L.R + 9 * b, m.body_inertia + 9 * b, RI);
+        for (int r0 = 0; r0 < 3; ++r0)
+            for (int c0 = 0; c0 < 3; ++c0) Rt[3 * r0 + c0] = L.R[9 * b + 3 * c0 + r0];
+        mulMM(RI, Rt, Iw);
+        for (int i = 0; i < 9; ++i) L.Iw[9 * b + i] = Iw[i];
+        const double mass = m.body_mass[b];
+        stv(L.F, b, mass * (a_c - v3(0, 0, -prm.gravity)));
+        stv(L.Nn, b, mulMv(Iw, al) + cross(w, mulMv(Iw, w)));
+    }
+    WSYNC();
+    // ---- Jacobian columns of every (body, active dof) pair, lane-strided; parked in the J region, which
+    //      the constraints only claim later in the sub-step -------------------------------------------
+    if (lane == 0) {
+        int off = 0;
+        for (int b = 0; b < nb; ++b) { L.poff[b] = off; off += 6 + __popc((unsigned)L.mask[b]); }
+        L.misc[1] = off;
+    }
+    WSYNC();
+    double *pairs = L.J;          // [n_pairs][6] = (jv, jw)
+    for (int b = 0; b < nb; ++b) {
+        const unsigned mk = (unsigned)L.mask[b];
+        const int cntb = 6 + __popc(mk);
+        if (lane < cntb) {
+            // lane-th active dof of body b: 0..5 = base, then the set bits of mk in ascending order
+            int d = lane;
+            if (lane >= 6) {
+                unsigned rem = mk;
+                for (int k = 6; k < lane; ++k) rem &= rem - 1;      // drop the lowest set bits
+                d = 6 + __ffs(rem) - 1;
+            }
+            const V3 jv = wjac_lin(L, mk, ldv(L.c, b), d), jw = wjac_ang(L, mk, d);
+            double *pp = pairs + (size_t)(L.poff[b] + lane) * 6;
+            pp[0] = jv.x; pp[1] = jv.y; pp[2] = jv.z; pp[3] = jw.x; pp[4] = jw.y; pp[5] = jw.z;
+        }
+    }
+    WSYNC();
+    auto pair_index = [&](int b, unsigned mk, int d) {
+        return L.poff[b] + (d < 6 ? d : 6 + __popc(mk & ((1u << (d - 6)) - 1u)));
+    };
+    // ---- M (lower triangle) and h: lane-strided over entries ----------------------------------------
+    for (int t = lane; t < n * n; t += WV) {
+        const int d = t / n, e = t % n;
+        if (e > d) continue;
+        double acc = 0.0;
+        for (int b = 0; b < nb; ++b) {
+            const unsigned mk = (unsigned)L.mask[b];
+            if (d >= 6 && !((mk >> (d - 6)) & 1u)) continue;
+            if (e >= 6 && !((mk >> (e - 6)) & 1u)) continue;
+            const double *pd = pairs + (size_t)pair_index(b, mk, d) * 6, *pe = pairs + (size_t)pair_index(b, mk, e) * 6;
+            const V3 jv{pd[0], pd[1], pd[2]}, jw{pd[3], pd[4], pd[5]}, ev{pe[0], pe[1], pe[2]}, ew{pe[3], pe[4], pe[5]};
+            acc += dot(m.body_mass[b] * jv, ev) + dot(mulMv(L.Iw + 9 * b, jw), ew);
+        }
+        if (d == e && d >= 6) acc += m.joint_arm[d - 6];
+        L.M[d * n + e] = acc;
+    }
+    if (lane < n) {
+        const int d = lane;
+        double acc = 0.0;
+        for (int b = 0; b < nb; ++b) {
+            const unsigned mk = (unsigned)L.mask[b];
+            if (d >= 6 && !((mk >> (d - 6)) & 1u)) continue;
+            const double *pd = pairs + (size_t)pair_index(b, mk, d) * 6;
+            acc += dot(V3{pd[0], pd[1], pd[2]}, ldv(L.F, b)) + dot(V3{pd[3], pd[4], pd[5]}, ldv(L.Nn, b));
+        }
+        L.h[d] = acc;
+    }
+    WSYNC();
+    // ---- Cholesky, column by column (lane = row; one dot-product loop per column, the pivot's square
+    //      root is broadcast with v_readlane and its reciprocal kept for every later division) --------
+    for (int c = 0; c < n; ++c) {
+        double v = 0.0;
+        if (lane >= c && lane < n) {
+            v = L.M[lane * n + c];
+            for (int k = 0; k < c; ++k) v -= L.M[lane * n + k] * L.M[c * n + k];
+        }
+        const double piv = sqrt(lane_value(v, c));
+        const double ipiv = 1.0 / piv;
+        if (lane == c) { L.M[c * n + c] = piv; L.idg[c] = ipiv; }
+        else if (lane > c && lane < n) L.M[lane * n + c] = v * ipiv;
+        WSYNC();
+    }
+    // ---- free motion u* = u + dt M^-1 (tau - h): column-oriented triangular solves, x in registers ---
+    double u_d = 0.0;   // lane d < n keeps its generalized velocity in a register
+    double x_d = 0.0;
+    if (lane < n) {
+        const int d = lane;
+        x_d = -L.h[d];
+        if (d >= 6) {
+            const int j = d - 6;
+            x_d += L.tau[j] - m.joint_damp[j] * L.qd[j] - m.joint_stiff[j] * L.q[j];
+            u_d = L.qd[j];
+        } else {
+            u_d = L.base[d < 3 ? 12 + d : 15 + (d - 3)];
+        }
+    }
+    for (int r = 0; r < n; ++r) {                      // L y = b
+        const double xr = lane_value(x_d, r) * L.idg[r];
+        if (lane == r) x_d = xr;
+        else if (lane > r && lane < n) x_d -= L.M[lane * n + r] * xr;
+    }
+    for (int r = n - 1; r >= 0; --r) {                 // L^T x = y
+        const double xr = lane_value(x_d, r) * L.idg[r];
+        if (lane == r) x_d = xr;
+        else if (lane < r) x_d -= L.M[r * n + lane] * xr;
+    }
+    if (lane < n) u_d += dt * x_d;
+    // ---- constraint detection ------------------------------------------------------------------------
+    bool hit = false;
+    double sx = 0, sy = 0, depth = 0;
+    if (lane < ns) {
+        const int b = tp.sphere_body[lane];
+        const V3 xw = ldv(L.o, b) + mulMv(L.R + 9 * b, ld3(m.sph_pos + 3 * lane));
+        depth = m.sph_r[lane] - xw.z;
+        hit = depth > 0.0;
+        sx = xw.x; sy = xw.y;
+    }
+    const unsigned long long hits = __ballot(hit);
+    const int rank = __popcll(hits & ((1ull << lane) - 1ull));
+    const int ncont = min(__popcll(hits), W_MAXC);
+    if (hit && rank < W_MAXC) {
+        L.cx[3 * rank] = sx; L.cx[3 * rank + 1] = sy; L.cx[3 * rank + 2] = depth;
+        L.csphere[rank] = lane;
+        L.bias[3 * rank] = prm.erp * depth / dt; L.kind[3 * rank] = 0; L.partner[3 * rank] = -1;
+        L.bias[3 * rank + 1] = 0.0; L.kind[3 * rank + 1] = 1; L.partner[3 * rank + 1] = 3 * rank;
+        L.bias[3 * rank + 2] = 0.0; L.kind[3 * rank + 2] = 2; L.partner[3 * rank + 2] = 3 * rank;
+    }
+    touch_mask = 0ull;
+    for (int g = 0; g < ns; ++g)
+        if (((hits >> g) & 1ull) && __popcll(hits & ((1ull << g) - 1ull)) < W_MAXC) touch_mask |= 1ull << g;
+    double lsgn = 0.0, viol = 0.0;
+    if (lane < nj) {
+        const double qj = L.q[lane];
+        if (qj < m.joint_lo[lane]) { lsgn = 1.0; viol = m.joint_lo[lane] - qj; }
+        else if (qj > m.joint_hi[lane]) { lsgn = -1.0; viol = qj - m.joint_hi[lane]; }
+    }
+    const unsigned long long lims = __ballot(lsgn != 0.0);
+    const int nr = 3 * ncont + __popcll(lims);
+    if (lsgn != 0.0) {
+        const int r = 3 * ncont + __popcll(lims & ((1ull << lane) - 1ull));
+        for (int d = 0; d < n; ++d) L.J[(size_t)r * n + d] = 0.0;
+        L.J[(size_t)r * n + 6 + lane] = lsgn;
+        L.bias[r] = prm.limit_erp * viol / dt; L.kind[r] = 0; L.partner[r] = -1;
+    }
+    WSYNC();
+    // contact Jacobian rows, lane-strided over (contact, column)
+    for (int t = lane; t < ncont * n; t += WV) {
+        const int c = t / n, d = t % n;
+        const int g = L.csphere[c];
+        const unsigned mk = (unsigned)L.mask[tp.sphere_body[g]];
+        const V3 jc = wjac_lin(L, mk, V3{L.cx[3 * c], L.cx[3 * c + 1], 0.0}, d);
+        L.J[(size_t)(3 * c) * n + d] = jc.z;
+        L.J[(size_t)(3 * c + 1) * n + d] = jc.x;
+        L.J[(size_t)(3 * c + 2) * n + d] = jc.y;
+    }
+    WSYNC();
+    // ---- W = M^-1 J^T: lane = row. The right-hand side lives in registers (a fully unrolled NMAX-slot
+    //      array): through LDS every step of the substitution would wait on its own previous store ------
+    for (int r = lane; r < nr; r += WV) {
+        double w[NMAX];
+        const double *jr = L.J + (size_t)r * n;
+#pragma unroll
+        for (int d = 0; d < NMAX; ++d) w[d] = d < n ? jr[d] : 0.0;
+#pragma unroll
+        for (int d = 0; d < NMAX; ++d) {
+            if (d < n) {
+                double v = w[d];
+#pragma unroll
+                for (int k = 0; k < d; ++k) v -= L.M[d * n + k] * w[k];
+                w[d] = v * L.idg[d];
+            }
+        }
+#pragma unroll
+        for (int d = NMAX - 1; d >= 0; --d) {
+            if (d < n) {
+                double v = w[d];
+#pragma unroll
+                for (int k = d + 1; k < NMAX; ++k)
+                    if (k < n) v -= L.M[k * n + d] * w[k];
+                w[d] = v * L.idg[d];
+            }
+        }
+        double dd = 0.0;
+        double *wo = L.Wm + (size_t)r * n;
+#pragma unroll
+        for (int d = 0; d < NMAX; ++d)
+            if (d < n) { dd += jr[d] * w[d]; wo[d] = w[d]; }
+        L.diag[r] = dd > 0.0 ? 1.0 / dd : 0.0;          // reciprocal: the sweep below multiplies
+        L.lam[r] = 0.0;
+    }
+    WSYNC();
+    // ---- projected Gauss-Seidel in velocity space (wave-uniform row loop) --------------------------
+    for (int it = 0; it < prm.solver_iterations; ++it)
+        for (int r = 0; r < nr; ++r) {
+            const double idg = L.diag[r];
+            if (!(idg > 0.0)) continue;
+            const double jv = wave_sum(lane < n ? L.J[(size_t)r * n + lane] * u_d : 0.0);
+            const double lr = L.lam[r];
+            double x = lr - (jv - L.bias[r]) * idg;
+            if (L.kind[r] == 0) x = x > 0.0 ? x : 0.0;
+            else {
+                const double lim = prm.friction * L.lam[L.partner[r]];
+                x = x < -lim ? -lim : (x > lim ? lim : x);
+            }
+            const double dl = x - lr;
+            if (lane < n) u_d += L.Wm[(size_t)r * n + lane] * dl;
+            // single-wave workgroup: LDS operations of one wavefront retire in program order, so every
+            // lane has read lam[r] / lam[partner] above before this store lands
+            if (lane == 0) L.lam[r] = x;
+        }
+    // ---- integrate -------------------------------------------------------------------------------------
+    if (lane < n) {
+        if (lane >= 6) {
+            const int j = lane - 6;
+            L.qd[j] = u_d;
+            L.q[j] += dt * u_d;
+        } else if (lane < 3) L.base[12 + lane] = u_d;
+        else L.base[15 + (lane - 3)] = u_d;
+    }
+    WSYNC();
+    if (lane == 0) {
+        const V3 vel{L.base[12], L.base[13], L.base[14]}, om{L.base[15], L.base[16], L.base[17]};
+        L.base[0] += dt * vel.x; L.base[1] += dt * vel.y; L.base[2] += dt * vel.z;
+        const double wn = sqrt(dot(om, om));
+        if (wn * dt > 0.0) {
+            double Rw[9], Rn[9], Ro[9];
+            for (int i = 0; i < 9; ++i) Ro[i] = L.base[3 + i];
+            rodrigues((1.0 / wn) * om, wn * dt, Rw);
+            mulMM(Rw, Ro, Rn);
+            for (int i = 0; i < 9; ++i) L.base[3 + i] = Rn[i];
+        }
+    }
+    WSYNC();
+}
+
+template <int NMAX>
+__global__ __launch_bounds__(WV) void walker_step_wave_kernel(mg_walker_topology tp, mg_walker_models ms,
+                                                              mg_walker_params prm, mg_walker_state st, int n_envs,
+                                                              int maxr, const float *action, float *obs, float *reward,
+                                                              float *rewards5, uint8_t *done) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int e = blockIdx.x, lane = threadIdx.x;
+    const int nb = tp.n_bodies, nj = tp.n_joints, nf = tp.n_feet, obs_dim = 8 + 2 * nj + nf;
+    const ModelRef m = model_ref(tp, ms, st.task_id[e]);
+    const WaveLds L = carve(smem, nb, nj, maxr);
+    // tree bookkeeping (lane 0) + state load (lanes)
+    if (lane == 0) {
+        int md = 0, j = 0;
+        for (int b = 0; b < nb; ++b) {
+            const int pb = tp.body_parent[b];
+            L.depth[b] = pb < 0 ? 0 : L.depth[pb] + 1;
+            md = max(md, L.depth[b]);
+            L.jstart[b] = j;
+            while (j < nj && tp.joint_body[j] == b) ++j;
+            L.jcount[b] = j - L.jstart[b];
+        }
+        L.misc[0] = md;
+    }
+    if (lane < 3) {
+        L.base[lane] = st.pos[(size_t)lane * n_envs + e];
+        L.base[12 + lane] = st.vel[(size_t)lane * n_envs + e];
+        L.base[15 + lane] = st.omega[(size_t)lane * n_envs + e];
+    }
+    if (lane < 9) L.base[3 + lane] = st.rot[(size_t)lane * n_envs + e];
+    if (lane < nj) {
+        L.q[lane] = st.q[(size_t)lane * n_envs + e];
+        L.qd[lane] = st.qd[(size_t)lane * n_envs + e];
+        float a = action[(size_t)e * nj + lane];
+        a = a < -1.0f ? -1.0f : (a > 1.0f ? 1.0f : a);                 // humanoids.py:50-54
+        L.tau[lane] = m.motor[lane] * (double)a;
+    }
+    WSYNC();
+    const int max_depth = L.misc[0];
+    unsigned long long touch = 0ull;
+    for (int it = 0; it < prm.frame_skip; ++it) wave_substep<NMAX>(tp, m, prm, L, lane, max_depth, maxr, touch);
+    // ---- calc_state (walker_base.py:31-64) on the post-step configuration -----------------------------
+    wave_kinematics(tp, m, L, lane, max_depth, false);
+    const double sxm = wave_sum(lane < nb ? L.o[3 * lane] : 0.0), sym = wave_sum(lane < nb ? L.o[3 * lane + 1] : 0.0);
+    float jp = 0.0f, jv = 0.0f;
+    bool lim = false;
+    if (lane < nj) {
+        const double lo = m.joint_lo[lane], hi = m.joint_hi[lane];
+        jp = (float)(2 * (L.q[lane] - 0.5 * (lo + hi)) / (hi - lo));
+        jv = (float)(0.1 * L.qd[lane]);
+        lim = fabsf(jp) > 0.99f;
+    }
+    const int at_limit = __popcll(__ballot(lim));
+    auto clip5 = [](float v) { return v < -5.0f ? -5.0f : (v > 5.0f ? 5.0f : v); };
+    float *ob = obs + (size_t)e * obs_dim;
+    if (lane < nj) { ob[8 + 2 * lane] = clip5(jp); ob[9 + 2 * lane] = clip5(jv); }
+    bool finite = isfinite(jp) && isfinite(jv);
+    if (lane < nf) {
+        const float prev = st.feet_contact[(size_t)lane * n_envs + e];   // flags of the previous step (:46 vs :57-63)
+        ob[8 + 2 * nj + lane] = clip5(prev);
+        float cnow = 0.0f;
+        for (int g = 0; g < tp.n_spheres; ++g)
+            if (((touch >> g) & 1ull) && tp.sphere_body[g] == tp.foot_body[lane]) cnow = 1.0f;
+        st.feet_contact[(size_t)lane * n_envs + e] = cnow;
+    }
+    float head[8];
+    double dist = 0.0;
+    if (lane == 0) {
+        const double cnt = (double)(nb + (prm.floor_in_parts ? 1 : 0));
+        const double bx = sxm / cnt, by = sym / cnt, z = L.o[2];
+        const double *R = L.R;
+        const double roll = atan2(R[7], R[8]);
+        double sp = -R[6];
+        sp = sp < -1.0 ? -1.0 : (sp > 1.0 ? 1.0 : sp);
+        const double pitch = asin(sp), yaw = atan2(R[3], R[0]);
+        const double dx = prm.walk_target_x - bx, dy = prm.walk_target_y - by;
+        const double theta = atan2(dy, dx);
+        dist = sqrt(dy * dy + dx * dx);
+        const double ang = theta - yaw, c = cos(-yaw), sn = sin(-yaw);
+        const double vx = c * L.base[12] - sn * L.base[13], vy = sn * L.base[12] + c * L.base[13], vz = L.base[14];
+        head[0] = clip5((float)(z - prm.initial_z)); head[1] = clip5((float)sin(ang)); head[2] = clip5((float)cos(ang));
+        head[3] = clip5((float)(0.3 * vx)); head[4] = clip5((float)(0.3 * vy)); head[5] = clip5((float)(0.3 * vz));
+        head[6] = clip5((float)roll); head[7] = clip5((float)pitch);
+        for (int i = 0; i < 8; ++i) { ob[i] = head[i]; finite = finite && isfinite(head[i]); }
+    }
+    const bool all_finite = __all(finite);
+    if (lane == 0) {
+        const double alive = ((double)head[0] + prm.initial_z > prm.alive_z) ? prm.alive_bonus : prm.dead_bonus;
+        const double pot_old = st.potential[e];
+        const double pot = -dist / (prm.time_step * prm.frame_skip);
+        const double progress = pot - pot_old;
+        const double limit_cost = prm.joints_at_limit_cost * at_limit;
+        st.potential[e] = pot;
+        const int steps = st.steps[e] + 1;
+        st.steps[e] = steps;
+        reward[e] = (float)(alive + progress + 0.0 + limit_cost + 0.0);
+        if (rewards5) {
+            float *r5 = rewards5 + (size_t)e * 5;
+            r5[0] = (float)alive; r5[1] = (float)progress; r5[2] = 0.0f; r5[3] = (float)limit_cost; r5[4] = 0.0f;
+        }
+        done[e] = (uint8_t)((alive < 0) || !all_finite || (steps >= prm.max_steps));
+    }
+    // ---- state store ----------------------------------------------------------------------------------
+    if (lane < 3) {
+        st.pos[(size_t)lane * n_envs + e] = L.base[lane];
+        st.vel[(size_t)lane * n_envs + e] = L.base[12 + lane];
+        st.omega[(size_t)lane * n_envs + e] = L.base[15 + lane];
+    }
+    if (lane < 9) st.rot[(size_t)lane * n_envs + e] = L.base[3 + lane];
+    if (lane < nj) {
+        st.q[(size_t)lane * n_envs + e] = L.q[lane];
+        st.qd[(size_t)lane * n_envs + e] = L.qd[lane];
+    }
+}
+
 int check_walker(const mg_walker_topology *tp, const mg_walker_models *ms, const mg_walker_params *prm,
                  const mg_walker_state *st, int n) {
     if (!tp || !ms || !prm || !st) return mg::set_error(MG_ERR_NULL_POINTER, "walker: NULL descriptor");
@@ -511,7 +1052,29 @@ extern "C" int mg_walker_step(const mg_walker_topology *tp, const mg_walker_mode
     MG_REQUIRE_PTR(obs);
     MG_REQUIRE_PTR(reward);
     MG_REQUIRE_PTR(done);
-    hipLaunchKernelGGL(walker_step_kernel, dim3((n + WK_BLOCK - 1) / WK_BLOCK), dim3(WK_BLOCK), 0, (hipStream_t)stream,
-                       *tp, *ms, *prm, *st, n, action, obs, reward, rewards5, done);
-    return mg::check_launch("walker_step_kernel");
+    if (prm->mapping == 0) {   // lane-per-env reference mapping (private-memory work set)
+        hipLaunchKernelGGL(walker_step_kernel, dim3((n + WK_BLOCK - 1) / WK_BLOCK), dim3(WK_BLOCK), 0,
+                           (hipStream_t)stream, *tp, *ms, *prm, *st, n, action, obs, reward, rewards5, done);
+        return mg::check_launch("walker_step_kernel");
+    }
+    if (tp->n_spheres > 64 || 6 + tp->n_joints > 64)
+        return mg::set_error(MG_ERR_BAD_SIZE, "wave mapping needs <= 64 spheres and <= 58 joints");
+    const int maxr = 3 * W_MAXC + tp->n_joints;
+    const size_t lds = wave_lds_doubles(tp->n_bodies, tp->n_joints, maxr) * sizeof(double) +
+                       wave_lds_ints(tp->n_bodies, maxr) * sizeof(int);
+    if (lds > 160 * 1024) return mg::set_error(MG_ERR_BAD_SIZE, "walker needs %zu B of LDS", lds);
+    if (lds > 64 * 1024) return mg::set_error(MG_ERR_BAD_SIZE, "walker needs %zu B of LDS (> 64 KiB)", lds);
+    const int ndof = 6 + tp->n_joints;
+    // the substitution keeps its vector in registers, so the dof count is a template parameter:
+    // 14 = ant, 23 = humanoid, 30 = the ABI maximum
+    if (ndof <= 14)
+        hipLaunchKernelGGL(walker_step_wave_kernel<14>, dim3(n), dim3(WV), lds, (hipStream_t)stream, *tp, *ms, *prm, *st,
+                           n, maxr, action, obs, reward, rewards5, done);
+    else if (ndof <= 23)
+        hipLaunchKernelGGL(walker_step_wave_kernel<23>, dim3(n), dim3(WV), lds, (hipStream_t)stream, *tp, *ms, *prm, *st,
+                           n, maxr, action, obs, reward, rewards5, done);
+    else
+        hipLaunchKernelGGL(walker_step_wave_kernel<ND>, dim3(n), dim3(WV), lds, (hipStream_t)stream, *tp, *ms, *prm, *st,
+                           n, maxr, action, obs, reward, rewards5, done);
+    return mg::check_launch("walker_step_wave_kernel");
 }

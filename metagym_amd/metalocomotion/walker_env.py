@@ -44,7 +44,7 @@ class WalkerBatchEnv(object):
     initial_z = None              # None -> height of the base at reset (walker_base.py:44-45)
 
     def __init__(self, num_envs=1, device="cuda", frame_skip=4, time_step=0.005, enable_render=False,
-                 max_steps=2000, assets_dir=None, solver_iterations=5):
+                 max_steps=2000, assets_dir=None, solver_iterations=5, mapping="wave"):
         self._lib = _lib.load()
         self.num_envs = int(num_envs)
         self.device = torch.device(device)
@@ -53,6 +53,8 @@ class WalkerBatchEnv(object):
                                        "path" % (device,))
         self.frame_skip, self.time_step, self.max_steps = int(frame_skip), float(time_step), int(max_steps)
         self.solver_iterations = int(solver_iterations)
+        assert mapping in ("wave", "lane")
+        self.mapping = mapping    # 'wave': one wavefront per env, LDS-resident (default); 'lane': one lane per env
         self.assets_dir = assets_dir or os.environ.get("METAGYM_LOCOMOTION_ASSETS")
         self.tra_tasks, self.tst_tasks, self.ood_tasks = [], [], []
         d = self._robot_assets()
@@ -136,6 +138,7 @@ class WalkerBatchEnv(object):
         p.joints_at_limit_cost = -0.1                              # walker_base_env.py:22
         p.walk_target_x, p.walk_target_y = 1e3, 0.0                # walker_base.py:9-10
         p.max_steps, p.floor_in_parts = self.max_steps, 1
+        p.mapping = 1 if self.mapping == "wave" else 0
         self._params_c = p
         self._obs = torch.zeros(N, self.obs_dim, dtype=torch.float32, device=dev)
         self._reward = torch.zeros(N, dtype=torch.float32, device=dev)

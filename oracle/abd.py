@@ -157,7 +157,7 @@ def integrate_positions(s, dt):
 
 
 class Params(object):
-    def __init__(self, dt=0.005, substeps=4, iterations=5, erp=0.9, friction=0.8 * 0.8, power=0.41, max_contacts=16,
+    def __init__(self, dt=0.005, substeps=4, iterations=5, erp=0.9, friction=0.8 * 0.8, power=0.41, max_contacts=12,
                  limit_erp=0.2):
         self.dt, self.substeps, self.iterations, self.erp, self.friction, self.power = dt, substeps, iterations, erp, friction, power
         self.limit_erp = limit_erp            # Bullet's default constraint ERP (btContactSolverInfo::m_erp2 = 0.2);

@@ -31,15 +31,16 @@ def _oracle_env(m, ant=False, **kw):
     return abd.WalkerEnv(m, prm=abd.Params(friction=0.8 * float(m.geom_friction)), **kw)
 
 
+@pytest.mark.parametrize("mapping", ["wave", "lane"])
 @pytest.mark.parametrize("robot", ["humanoid", "ant"])
-def test_gpu_matches_oracle_trajectory(robot):
+def test_gpu_matches_oracle_trajectory(robot, mapping):
     """4 body variants x 3 envs, 25 env steps (100 physics sub-steps incl. landing on the ground and
     joint-limit pushes): state, obs, reward terms and done agree with the oracle."""
     ant = robot == "ant"
     names = ["ant", "ant_tra_005"] if ant else ["humanoid", "humanoid_tra_000", "humanoid_tra_137", "humanoid_ood_003"]
     models = [MODELS[k] for k in names]
     n = 3 * len(models)
-    env = _make("MetaAntEnv" if ant else "MetaHumanoidEnv", models, n, max_steps=20)
+    env = _make("MetaAntEnv" if ant else "MetaHumanoidEnv", models, n, max_steps=20, mapping=mapping)
     ids = env.task_id.cpu().numpy()
     nj = env.n_joints
     rs = np.random.RandomState(0)
@@ -68,7 +69,7 @@ def test_gpu_matches_oracle_trajectory(robot):
             assert abs(rew[e] - r) < 1e-4 * max(1.0, abs(r)), (t, e)
             assert bool(done[e]) == d, (t, e)
             assert int(info["steps"][e]) == inf["steps"]
-    print(robot, "max |state diff| GPU vs oracle over 25 steps: %.2e" % worst)
+    print(robot, mapping, "max |state diff| GPU vs oracle over 25 steps: %.2e" % worst)
 
 
 def test_free_flight_invariants_on_gpu():
