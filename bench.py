@@ -38,12 +38,34 @@ HBM_PEAK_GBS = 8000.0             # /opt/skills/guides/MI355X_MICROARCH.md: HBM3
 N_ACTION_BATCHES = 8
 
 
+def usable_cpus():
+    """Host cores this process may really use: the affinity mask, capped by a cgroup CPU quota."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(float(txt[0]) / float(txt[1]))))
+            else:
+                q = int(txt[0])
+                per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                if q > 0:
+                    n = min(n, max(1, q // per))
+        except Exception:
+            pass
+    return n
+
+
 def cpu_baseline(seconds=12.0, n_envs_per_thread=256, max_threads=None):
     """Time the CPU oracle (oracle/quadrotor_oracle.c, a scalar C port of the reference algorithm) on
     the same workload. One thread per host core, each stepping its own block of envs; the timed loop
     runs inside C (ctypes releases the GIL), 100 env-steps per env per call."""
     from oracle import quadrotor as qo
-    cores = os.cpu_count() or 1
+    cores = usable_cpus()
     if max_threads:
         cores = min(cores, max_threads)
     c = qo.default_consts()
@@ -84,6 +106,75 @@ def cpu_baseline(seconds=12.0, n_envs_per_thread=256, max_threads=None):
                       % (total, n_envs_per_thread, el)}
 
 
+def _time_steps(step_fn, steps, warmup):
+    for i in range(warmup):
+        step_fn(i)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for i in range(steps):
+        step_fn(i)
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) * 1e-3 / steps
+
+
+def secondary_workloads(dev):
+    """The other BASELINE configs on this GPU, each a few dozen launches (reported next to the headline,
+    never folded into `value`): C3 MetaMazeDiscrete3D 9x9 at the registered 256x256 resolution with
+    16 384 envs, C1-scaled MetaMaze2D 15x15, C4 MetaLocomotion humanoid with 8 192 envs."""
+    import metagym_amd
+    from metagym_amd.metamaze import MazeTaskSampler
+    out = {}
+    try:
+        n, res = 16384, 256
+        tasks = [MazeTaskSampler(n=9, allow_loops=False, step_reward=-0.01, goal_reward=1.0, food_density=0.06,
+                                 food_interval=20, seed=s) for s in range(64)]
+        env = metagym_amd.make("meta-maze-discrete-3D-v0", num_envs=n, device=dev, max_steps=200,
+                               resolution=(res, res), task_type="SURVIVAL", auto_reset=True)
+        env.set_task(tasks)
+        env.reset()
+        acts = [torch.randint(0, 4, (n,), device=dev, dtype=torch.int32) for _ in range(4)]
+        s = _time_steps(lambda i: env.step(acts[i % 4]), 12, 3)
+        byt = (12 * res * res + 64) * n
+        out["C3_maze3d_discrete_9x9_256x256_16384envs"] = {
+            "env_steps_per_s": n / s, "ms_per_launch": s * 1e3,
+            "roofline": {"bound": "hbm", "achieved": byt / s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": byt / s / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes_per_env_step": 12 * res * res + 64}}
+        del env, acts
+        torch.cuda.empty_cache()
+        n2 = 1 << 20
+        tasks15 = [MazeTaskSampler(n=15, allow_loops=True, crowd_ratio=0.35, step_reward=-0.01, goal_reward=1.0,
+                                   seed=s) for s in range(64)]
+        env = metagym_amd.make("meta-maze-2D-v0", num_envs=n2, device=dev, max_steps=200, view_grid=1,
+                               task_type="ESCAPE", auto_reset=True)
+        env.set_task(tasks15)
+        env.reset()
+        acts = [torch.randint(0, 4, (n2,), device=dev, dtype=torch.int32) for _ in range(4)]
+        s = _time_steps(lambda i: env.step(acts[i % 4]), 30, 5)
+        out["C1_maze2d_15x15_escape_1048576envs"] = {"env_steps_per_s": n2 / s, "ms_per_launch": s * 1e3}
+        del env, acts
+        torch.cuda.empty_cache()
+    except Exception as e:  # secondary numbers must never break the headline line
+        out["maze_error"] = repr(e)
+    try:
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        from walker_fixtures import load_models
+        from metagym_amd.metalocomotion import MetaHumanoidEnv
+        M = load_models()
+        n = 8192
+        env = MetaHumanoidEnv(num_envs=n, device=dev)
+        env.set_task([M[k] for k in ("humanoid", "humanoid_tra_000", "humanoid_tra_137", "humanoid_ood_003")])
+        env.reset(seed=0)
+        acts = [torch.rand(n, env.n_joints, device=dev) * 2 - 1 for _ in range(4)]
+        s = _time_steps(lambda i: env.step(acts[i % 4]), 12, 3)
+        out["C4_humanoid_8192envs"] = {"env_steps_per_s": n / s, "ms_per_launch": s * 1e3,
+                                       "note": "physics parity unpinned (PyBullet is not in the reference tree)"}
+    except Exception as e:
+        out["walker_error"] = repr(e)
+    return out
+
+
 def aggregate_throughput(dist, dev, wall, envs_per_rank, steps):
     """Whole-job env-steps/s: every rank stepped `envs_per_rank` envs `steps` times; the job took as
     long as its slowest rank. `dist` is torch.distributed (initialised) or None for one process."""
@@ -108,6 +199,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--envs-per-gpu", type=int, default=ENVS_PER_GPU)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the C1/C3/C4 side measurements")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -118,7 +210,7 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or os.environ.get("BENCH_FORCE_DIST") == "1":   # the env var lets a 1-GPU box test the RCCL path
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
@@ -191,6 +283,10 @@ def main():
             "sanity": {"done_frac_last_step": done_frac, "failed_max": failed_any,
                        "host_wall_ms_per_step": wall / args.steps * 1e3},
         }
+        if world == 1 and not args.no_secondary:
+            del env
+            torch.cuda.empty_cache()
+            out["secondary"] = secondary_workloads(dev)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)

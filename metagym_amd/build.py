@@ -40,13 +40,25 @@ def is_stale():
 
 
 def build(force=False, verbose=True):
+    """Compile in-tree. Safe when several ranks of one job import the package at once: the build is
+    serialised by a file lock, re-checked under the lock, and the library appears by atomic rename."""
     if not force and not is_stale():
         return LIB_PATH
+    import fcntl
     os.makedirs(LIB_DIR, exist_ok=True)
-    cmd = [HIPCC] + FLAGS + sources() + ["-o", LIB_PATH]
-    if verbose:
-        print(" ".join(cmd), flush=True)
-    subprocess.check_call(cmd)
+    with open(os.path.join(LIB_DIR, ".build.lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            if not force and not is_stale():      # another process built it while we waited
+                return LIB_PATH
+            tmp = LIB_PATH + ".tmp.%d" % os.getpid()
+            cmd = [HIPCC] + FLAGS + sources() + ["-o", tmp]
+            if verbose:
+                print(" ".join(cmd), flush=True)
+            subprocess.check_call(cmd)
+            os.replace(tmp, LIB_PATH)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
     return LIB_PATH
 
 

@@ -58,7 +58,9 @@ json.dump(summary, open(os.path.join(P, "pmc_summary.json"), "w"), indent=1)
 print(json.dumps(summary, indent=1))
 for src, dst in (("quad_trace/q_kernel_stats.csv", "quadrotor_bench_kernel_stats.csv"),
                  ("maze_trace/m_kernel_stats.csv", "maze_bench_kernel_stats.csv"),
-                 ("bench.json", "bench.json"), ("bench_maze.jsonl", "bench_maze.jsonl")):
+                 ("walker_trace/w_kernel_stats.csv", "walker_bench_kernel_stats.csv"),
+                 ("bench.json", "bench.json"), ("bench_maze.jsonl", "bench_maze.jsonl"),
+                 ("bench_walker.jsonl", "bench_walker.jsonl")):
     if os.path.exists(os.path.join(R, src)):
         shutil.copy(os.path.join(R, src), os.path.join(P, dst))
 if "hbm_bytes_per_launch" in summary.get("quadrotor_step_kernel", {}):
