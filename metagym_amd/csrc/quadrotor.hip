@@ -504,7 +504,10 @@ __global__ __launch_bounds__(BLOCK) void quadrotor_step_kernel(QuadK k, mg_quadr
                     task_reward += (o > -20.0f) ? (double)o : -20.0;
                 }
             }
-            reward = r + task_reward;
+            if (k.task == MG_QUADROTOR_TASK_HOVERING_CONTROL || k.healthy32 < energy)
+                reward = r + task_reward;     // np.float64 task_reward, or python floats on both sides
+            else                              // no_collision: np.float32 + weak python float -> f32 add (env.py:220-221)
+                reward = (double)((float)r + (float)task_reward);
             done = 0;
             if (hit) { done = 1; ct = 0; }                                  // env.py:147-149
             if (ct == k.nt) { done = 1; ct = 0; }                           // env.py:159-161

@@ -192,6 +192,42 @@ def _quadrotor_fail(gym):
     return out
 
 
+def _quadrotor_no_collision(gym):
+    """task='no_collision' on the reference's own obstacle map (quadrotor/default_map.txt): pins the
+    map path of _check_collision (env.py:248-260: python slicing of the AABB, heights compared with the
+    bool np.any) and the no_collision reward branch (env.py:219-221). The map is stored in the file."""
+    map_file = os.path.join(REF, "metagym", "quadrotor", "default_map.txt")
+    out = {}
+    for k, (seed, lo, hi, T) in enumerate([(11, 1.8, 2.6, 250), (12, 0.1, 15.0, 250), (13, 0.1, 1.5, 120)]):
+        env = gym.make("quadrotor-v0", task="no_collision", map_file=map_file, nt=200)
+        np.random.seed(seed)
+        env.reset()
+        sim = env.simulator
+        if k == 0:
+            out["map"] = np.asarray(Quadrotor_map_with_start(env), np.int32)
+        init = _sim_state(sim)
+        actions = np.random.RandomState(seed + 1).uniform(lo, hi, size=(T, 4)).astype(np.float32)
+        rew, done, pos, obs = [], [], [], []
+        for t in range(T):
+            o, r, d, info = env.step(actions[t])
+            rew.append(np.float64(r)); done.append(bool(d)); pos.append(np.array(sim.global_position, np.float32))
+            obs.append(np.asarray(o, np.float32))
+        out["init_vel_%d" % k], out["init_omega_%d" % k] = init["vel"], init["omega"]
+        out["actions_%d" % k], out["reward_%d" % k] = actions, np.asarray(rew)
+        out["done_%d" % k], out["pos_%d" % k], out["obs_%d" % k] = np.asarray(done), np.asarray(pos), np.asarray(obs)
+        print("no_collision traj", k, "dones", int(np.sum(done)), "first", int(np.argmax(done)) if any(done) else -1)
+    out["nt"] = np.int64(200)
+    out["numpy_version"] = np.str_(np.__version__)
+    return out
+
+
+def Quadrotor_map_with_start(env):
+    """the map as load_map() read it: env.py:109-114 zeroes the start cell after locating it."""
+    m = np.array(env.map_matrix)
+    m[env.y_offset, env.x_offset] = -1
+    return m
+
+
 def gen_quadrotor(gym):
     # (name, seed, T, action range): the SURVEY §8(d) C2 streams — full-range U(0.1,15) and near-hover.
     # seed 3 with nt=50 exercises the `ct == nt` episode end (env.py:159-161).
@@ -207,6 +243,8 @@ def gen_quadrotor(gym):
     path = os.path.join(OUT, "quadrotor_onestep.npz")
     np.savez_compressed(path, **d)
     print("wrote", path, "done frac", d["done"].mean())
+    d = _quadrotor_no_collision(gym)
+    np.savez_compressed(os.path.join(OUT, "quadrotor_no_collision_map.npz"), **d)
     d = _quadrotor_fail(gym)
     path = os.path.join(OUT, "quadrotor_fail.npz")
     np.savez_compressed(path, **d)

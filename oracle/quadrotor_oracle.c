@@ -350,7 +350,12 @@ int qo_env_step(const qo_consts *c, qo_state *s, int *ct, const float act[4],
             task_reward += (-20.0 > (double)o) ? -20.0 : (double)o;   /* max(-20, o) */
         }
     }
-    r += task_reward;
+    if (c->task == QO_TASK_HOVERING || ((float)c->healthy_reward < energy)) {
+        r += task_reward;                 /* np.float64 task_reward (hovering) or python floats only */
+    } else {
+        /* no_collision: np.float32(-energy) + python float -> the python float is weak, f32 add */
+        r = (double)((float)r + (float)task_reward);
+    }
     *reward = r;
 
     int reset = 0;

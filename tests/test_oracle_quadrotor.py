@@ -104,3 +104,29 @@ def test_inverse_close_to_lapack():
         A = (R * (1 + rs.uniform(-2e-3, 2e-3, (3, 3)))).astype(np.float32)
         worst = max(worst, vec_rel_err(qo.inv3(A).reshape(1, 9), np.linalg.inv(A).reshape(1, 9)))
     assert worst == 0.0, worst      # correctly rounded, like numpy's dgesv-then-cast
+
+
+def test_oracle_no_collision_on_reference_map():
+    """task='no_collision' with the reference's obstacle map (golden recorded from the reference):
+    done / reward / position sequences are reproduced exactly."""
+    import ctypes as C
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "quadrotor_no_collision_map.npz"))
+    grid = np.array(g["map"], np.int32)
+    ys, xs = np.where(grid == -1)
+    grid[ys[0], xs[0]] = 0
+    grid = np.ascontiguousarray(grid)
+    for k in range(3):
+        c = qo.default_consts(nt=int(g["nt"]), task=qo.TASK_NO_COLLISION)
+        c.map = grid.ctypes.data_as(C.POINTER(C.c_int32))
+        c.map_h, c.map_w = grid.shape
+        c.x_offset, c.y_offset = int(xs[0]), int(ys[0])
+        st = qo.make_states(np.zeros((1, 3), np.float32), g["init_vel_%d" % k][None], g["init_omega_%d" % k][None],
+                            np.zeros((1, 4), np.float32), np.eye(3, dtype=np.float32).reshape(1, 9))
+        ct = np.zeros(1, np.int32)
+        acts = g["actions_%d" % k]
+        for t in range(len(acts)):
+            obs, rew, done, failed = qo.batch_env_step(c, st, ct, acts[t][None])
+            assert bool(done[0]) == bool(g["done_%d" % k][t]), (k, t)
+            assert rew[0] == g["reward_%d" % k][t], (k, t)
+            assert np.array_equal(qo.states_to_arrays(st)["pos"][0], g["pos_%d" % k][t]), (k, t)
+            assert obs_rel_err(obs, g["obs_%d" % k][t][None]) < REL_TOL

@@ -282,3 +282,32 @@ def test_masked_reset_only_touches_selected_envs():
         assert torch.equal(before[k][:, keep], after[k][:, keep]), k
     assert (after["pos"][:, mask.cuda()] == 0).all()
     assert torch.equal(before["ct"], after["ct"])     # reset() does not clear ct (env.py:116-125)
+
+
+def test_no_collision_on_reference_map_matches_golden(tmp_path):
+    """The reference's own obstacle map (recorded in the golden file) through map_file=...: done and
+    position sequences exact, reward within 1e-5 of the reference."""
+    import metagym_amd
+    g = np.load(os.path.join(GOLDEN, "quadrotor_no_collision_map.npz"))
+    p = tmp_path / "map.txt"
+    p.write_text("\n".join(" ".join("%d" % v for v in row) for row in g["map"]))
+    n = 3
+    env = metagym_amd.make("quadrotor-v0", num_envs=n, device="cuda:0", task="no_collision", map_file=str(p),
+                           nt=int(g["nt"]))
+    iv = np.stack([g["init_vel_%d" % k] for k in range(n)])
+    iw = np.stack([g["init_omega_%d" % k] for k in range(n)])
+    env.reset(init_velocity=iv, init_angular_velocity=iw)
+    lens = [len(g["actions_%d" % k]) for k in range(n)]
+    seen_done = False
+    for t in range(max(lens)):
+        a = np.stack([g["actions_%d" % k][t] if t < lens[k] else np.full(4, 2.0, np.float32) for k in range(n)])
+        obs, rew, done, info = env.step(torch.as_tensor(a))
+        pos = env.pos.T.cpu().numpy()
+        for k in range(n):
+            if t >= lens[k]:
+                continue            # this recorded trajectory is shorter; the env just idles
+            assert bool(done[k]) == bool(g["done_%d" % k][t]), (k, t)
+            assert np.array_equal(pos[k], g["pos_%d" % k][t]), (k, t)
+            assert abs(float(env.reward64[k]) - g["reward_%d" % k][t]) <= 1e-5 * max(1.0, abs(g["reward_%d" % k][t]))
+            seen_done = seen_done or bool(done[k])
+    assert seen_done
