@@ -77,6 +77,8 @@ typedef struct mg_quadrotor_config {
     float prop_coord[12];    /* 4 propellers x (x, y, z) */
     const int32_t *map_d;    /* DEVICE int32[map_h][map_w] obstacle map, or NULL = flat floor */
     int32_t map_h, map_w;
+    const float *velocity_targets_d;   /* DEVICE f32 [nt][3], task VELOCITY_CONTROL only: the trajectory
+                                          of mg_quadrotor_velocity_targets (env.py:99-102) */
 } mg_quadrotor_config;
 
 /* Per-env simulator state (QuadrotorSim._zero_state quadrotorsim.py:20-28 + Quadrotor.ct env.py:66),
@@ -112,17 +114,27 @@ int mg_quadrotor_reset(const mg_quadrotor_config *cfg, int32_t n_envs, const mg_
  * then sensors/state (quadrotorsim.py:260-293), collision (env.py:248-260), reward (env.py:211-246)
  * and the done rule (env.py:144-161).
  *   action   f32 [n][4]  motor voltages (clamped to [min_voltage, max_voltage] like the reference)
- *   obs      f32 [n][16] env.py:193-209 key order
+ *   obs      f32 [n][16] env.py:193-209 key order; [n][19] for VELOCITY_CONTROL (+ next_target_g_v_x/y/z)
  *   reward   f32 [n]     (may be NULL)
  *   reward64 f64 [n]     the reference returns a python float; optional exact copy (may be NULL)
  *   done     u8  [n]
  *   failed   u8  [n]     0 = ok; 1/2/3 = position / velocity / body-rate limit exceeded
  *                        (quadrotorsim.py:212-221). A failed env freezes at the failing sub-step,
  *                        reports done=1, reward=0 and must be reset. (may be NULL)
- * Only tasks NO_COLLISION and HOVERING_CONTROL are implemented (MG_ERR_UNSUPPORTED otherwise). */
+ * VELOCITY_CONTROL (env.py:150-157) has no map / collision test; its reward is
+ * -min(dt*power, healthy) - 0.001 * |Rinv @ target[ct-1] - body velocity|_1 and needs
+ * cfg->velocity_targets_d. */
 int mg_quadrotor_step(const mg_quadrotor_config *cfg, int32_t n_envs, const mg_quadrotor_state *state,
                       const float *action, float *obs, float *reward, double *reward64,
                       uint8_t *done, uint8_t *failed, void *stream);
+
+/* QuadrotorSim.define_velocity_control_task (quadrotorsim.py:306-319): nt env steps from the pre-reset
+ * zero state, in which every simulator array is still float32 (so the whole sub-step runs in float32,
+ * unlike after reset()), with the caller's action stream (DEVICE f32 [nt][4]; the reference draws
+ * np.random.seed(seed); uniform(min_voltage, max_voltage, 4).astype(f32) per step). Writes the global
+ * velocity after every step to targets_d (DEVICE f32 [nt][3]). One-off setup work, single lane. */
+int mg_quadrotor_velocity_targets(const mg_quadrotor_config *cfg, int32_t nt, const float *actions_d,
+                                  float *targets_d, void *stream);
 
 /* n_steps consecutive env steps in ONE launch (state stays in registers between steps).
  *   action f32 [n_steps][n][4]; obs f32 [n_steps][n][16]; reward/done/failed [n_steps][n].

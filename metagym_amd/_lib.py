@@ -31,6 +31,7 @@ class QuadrotorConfig(C.Structure):
         ("inertia", C.c_float * 9), ("drag_m", C.c_float * 9), ("drag_f", C.c_float * 9),
         ("gravity_center", C.c_float * 3), ("prop_coord", C.c_float * 12),
         ("map_d", C.c_void_p), ("map_h", C.c_int32), ("map_w", C.c_int32),
+        ("velocity_targets_d", C.c_void_p),
     ]
 
 
@@ -111,6 +112,7 @@ SIGNATURES = {
     "mg_last_error": (C.c_char_p, []),
     "mg_target_arch": (C.c_char_p, []),
     "mg_quadrotor_default_config": (C.c_int, [C.POINTER(QuadrotorConfig)]),
+    "mg_quadrotor_velocity_targets": (C.c_int, [C.POINTER(QuadrotorConfig), C.c_int32, _P, _P, _P]),
     "mg_quadrotor_reset": (C.c_int, [C.POINTER(QuadrotorConfig), C.c_int32, C.POINTER(QuadrotorState),
                                      _P, _P, _P, _P, _P]),
     "mg_quadrotor_step": (C.c_int, [C.POINTER(QuadrotorConfig), C.c_int32, C.POINTER(QuadrotorState),

@@ -51,6 +51,8 @@ struct QuadK {
     uint64_t seed, step_index, env_id_base;
     const int32_t *map;
     int map_h, map_w;
+    const float *vtargets;   // velocity_control target trajectory [nt][3]
+    int obs_dim;             // 16, or 19 for velocity_control
 };
 
 struct Lane {       // one environment, in registers
@@ -325,6 +327,89 @@ __device__ __forceinline__ bool collision(const QuadK &k, const double *op, cons
     return (mn[2] < any) || (mx[2] < any);  // heights compared with the *bool* np.any(...)
 }
 
+// ---- pre-reset, all-float32 sub-step: define_velocity_control_task, quadrotorsim.py:306-319 -------
+// Before reset() every simulator array is float32 (quadrotorsim.py:20-28), so _run_internal runs
+// entirely in float32 there (python floats are weak). Only used once per env object to roll the
+// velocity_control target trajectory; general (non-specialised) formulation, one lane.
+struct Lane32 {
+    float p[3], v[3], w[3], pw[4], R[9], Ri[9];
+};
+
+__device__ void substep_f32state(const QuadK &k, Lane32 &s, const float *eff32) {
+    float prop_force_z = 0.0f, prop_torque[3] = {0.0f, 0.0f, 0.0f}, me[4];
+    const float ct2_32 = (float)k.ct2;
+    for (int i = 0; i < 4; ++i) {
+        const float e32 = eff32[i];
+        float phi_w = k.phi32 * s.pw[i];
+        me[i] = k.phi_over_ra32 * (e32 - phi_w);
+        float d_prop_w = k.inv_jm32 * (me[i] - k.mm32);
+        float w_m = s.pw[i] + k.prec32 * d_prop_w;
+        const float *pc = &k.pc[3 * i];
+        float bv[3], cr[3];
+        mv_f32(s.Ri, s.v, bv);
+        cross_f32(s.w, pc, cr);
+        float v_1 = bv[2] + cr[2] * k.lm[i];
+        float sign = v_1 > 0 ? 1.0f : -1.0f;
+        float thrust = ((k.ct0_32 * w_m) * w_m + (k.ct1_32 * w_m) * v_1) + ((ct2_32 * v_1) * v_1) * sign;
+        s.pw[i] = w_m;
+        prop_force_z = prop_force_z + thrust;
+        float a[3] = {-0.0f, -0.0f, -thrust};
+        cross_f32(a, pc, cr);
+        prop_torque[0] += cr[0]; prop_torque[1] += cr[1]; prop_torque[2] += cr[2];
+    }
+    prop_torque[2] += ((-me[0] + me[1]) - me[2]) + me[3];
+    float DfRi[9], tmp[3], f_drag[3], t_drag[3];
+    mm_f32(k.df, s.Ri, DfRi);
+    mv_f32(DfRi, s.v, tmp);
+    const float nv = -sqrtf(sumsq3(s.v));
+    for (int c = 0; c < 3; ++c) f_drag[c] = nv * tmp[c];
+    mv_f32(k.dm, s.w, tmp);
+    const float nw = -sqrtf(sumsq3(s.w));
+    for (int c = 0; c < 3; ++c) t_drag[c] = nw * tmp[c];
+    const float g[3] = {0.0f, 0.0f, -9.8f};
+    float f_grav[3], t_grav[3], body_acc[3], t_all[3], acc[3];
+    mv_f32(s.Ri, g, f_grav);
+    for (int c = 0; c < 3; ++c) f_grav[c] = f_grav[c] * k.quality32;
+    cross_f32(f_grav, k.cog, t_grav);
+    for (int c = 0; c < 3; ++c) {
+        const float pf = (c == 2) ? prop_force_z : 0.0f;
+        const float f_all = (pf + f_grav[c]) + f_drag[c];
+        t_all[c] = (prop_torque[c] + (-t_grav[c])) + t_drag[c];
+        body_acc[c] = f_all / k.quality32;
+    }
+    mv_f32(s.R, body_acc, acc);
+    const float half_dt2 = (float)k.half_dt2, half_dt = (float)k.half_dt;
+    for (int c = 0; c < 3; ++c) s.p[c] = s.p[c] + (s.v[c] * k.prec32 + half_dt2 * acc[c]);
+    for (int c = 0; c < 3; ++c) s.v[c] = s.v[c] + k.prec32 * acc[c];
+    float alpha[3], tw[3];
+    mv_f32(k.iinv, t_all, alpha);
+    for (int c = 0; c < 3; ++c) tw[c] = s.w[c] + half_dt * alpha[c];
+    float S[9] = {0.0f, -tw[2], tw[1], tw[2], 0.0f, -tw[0], -tw[1], tw[0], 0.0f};
+    float RS[9];
+    mm_f32(s.R, S, RS);
+    for (int c = 0; c < 9; ++c) s.R[c] = s.R[c] + k.prec32 * RS[c];
+    for (int c = 0; c < 3; ++c) s.w[c] = s.w[c] + k.prec32 * alpha[c];
+    inv3(s.R, s.Ri);
+}
+
+__global__ void quadrotor_targets_kernel(QuadK k, int nt, const float *actions, float *targets) {
+    if (blockIdx.x != 0 || threadIdx.x != 0) return;
+    Lane32 s;
+    for (int c = 0; c < 3; ++c) { s.p[c] = 0.0f; s.v[c] = 0.0f; s.w[c] = 0.0f; }
+    for (int c = 0; c < 4; ++c) s.pw[c] = 0.0f;
+    for (int c = 0; c < 9; ++c) { s.R[c] = (c % 4 == 0) ? 1.0f : 0.0f; s.Ri[c] = s.R[c]; }
+    for (int t = 0; t < nt; ++t) {
+        float eff32[4];
+        for (int i = 0; i < 4; ++i) {
+            double d = (double)actions[4 * t + i];
+            d = d > k.max_v ? k.max_v : (d < k.min_v ? k.min_v : d);
+            eff32[i] = (float)d;
+        }
+        for (int it = 0; it < k.times; ++it) substep_f32state(k, s, eff32);
+        targets[3 * t] = s.v[0]; targets[3 * t + 1] = s.v[1]; targets[3 * t + 2] = s.v[2];
+    }
+}
+
 // ---- SoA load / store ----------------------------------------------------------------------------
 
 __device__ __forceinline__ void load_lane(const mg_quadrotor_state &st, int n, int e, Lane &s, int &ct) {
@@ -362,7 +447,12 @@ __device__ __forceinline__ void store_lane(const mg_quadrotor_state &st, int n, 
 // Transpose the wave's 64 x 16 observation rows through LDS and store them as 4 coalesced
 // dwordx4 sweeps (each wave instruction writes 1 KiB contiguous). Rows are padded to 17 floats so
 // the per-lane row writes hit distinct banks; a partial last wave falls back to per-row stores.
-__device__ __forceinline__ void store_obs_wave(float *tile, const float *obs, float *out, int n, int e) {
+__device__ __forceinline__ void store_obs_wave(float *tile, const float *obs, float *out, int n, int e, int obs_dim) {
+    if (obs_dim != OBS_DIM) {   // velocity_control rows (19 floats) are not 16-byte aligned: plain row stores
+        if (e < n)
+            for (int c = 0; c < obs_dim; ++c) out[(size_t)e * obs_dim + c] = obs[c];
+        return;
+    }
     const int lane = threadIdx.x & (mg::WAVE - 1);
     const int wave_base = e - lane;                 // first env of this wave
     const bool full = (wave_base + mg::WAVE) <= n;  // wave-uniform
@@ -483,11 +573,28 @@ __global__ __launch_bounds__(BLOCK) void quadrotor_step_kernel(QuadK k, mg_quadr
                 fail = failure_code(k, s);
             }
         }
-        float obs[OBS_DIM];
+        float obs[OBS_DIM + 3];
         observe(k, s, obs);
+        const bool vel_task = k.task == MG_QUADROTOR_TASK_VELOCITY_CONTROL;
+        if (vel_task) {          // _update_state env.py:262-273: next target at min(ct, nt-1), ct already incremented
+            const int tn = ct < k.nt - 1 ? ct : k.nt - 1;
+            obs[16] = k.vtargets[3 * tn]; obs[17] = k.vtargets[3 * tn + 1]; obs[18] = k.vtargets[3 * tn + 2];
+        }
         double reward = 0.0;
         int done = 1;
-        if (fail == 0) {
+        if (fail == 0 && vel_task) {
+            // env.py:150-157: body-frame target = Rinv(f32) @ target(f32); reward -0.001 * L1 difference
+            float bt[3];
+            mv_f32(s.Ri, &k.vtargets[3 * (ct - 1)], bt);
+            double b_v[3];
+            mv_f32f64(s.Ri, s.v, b_v);
+            const double diff = (fabs((double)bt[0] - b_v[0]) + fabs((double)bt[1] - b_v[1])) + fabs((double)bt[2] - b_v[2]);
+            const float energy = k.dt32 * s.power;
+            const double r = (k.healthy32 < energy) ? -k.healthy : -(double)energy;
+            reward = r + (-0.001 * diff);
+            done = 0;
+            if (ct == k.nt) { done = 1; ct = 0; }
+        } else if (fail == 0) {
             const double new_pos[3] = {(double)s.p[0] + k.xoff, (double)s.p[1] + k.yoff,
                                        (double)(s.p[2] + k.zoff32)};
             const bool hit = collision(k, old_pos, new_pos);                // env.py:145
@@ -518,8 +625,12 @@ __global__ __launch_bounds__(BLOCK) void quadrotor_step_kernel(QuadK k, mg_quadr
             // vector-env convention: the returned obs is the first observation of the next episode
             reset_lane_random(k, s, el, k.step_index + (uint64_t)t);
             observe(k, s, obs);
+            if (vel_task) {
+                const int tn = ct < k.nt - 1 ? ct : k.nt - 1;
+                obs[16] = k.vtargets[3 * tn]; obs[17] = k.vtargets[3 * tn + 1]; obs[18] = k.vtargets[3 * tn + 2];
+            }
         }
-        store_obs_wave(tile, obs, io.obs + off * OBS_DIM, n, e);
+        store_obs_wave(tile, obs, io.obs + off * k.obs_dim, n, e, k.obs_dim);
         if (live) {
             if (io.reward) io.reward[off + e] = (float)reward;
             if (io.reward64) io.reward64[off + e] = reward;
@@ -552,13 +663,16 @@ __global__ __launch_bounds__(BLOCK) void quadrotor_reset_kernel(QuadK k, mg_quad
     s.nv = norm3(s.v);
     s.nw = norm3(s.w);
     s.power = 0.0f;
-    store_lane(st, n, e, s, st.ct[e]);   // ct is not cleared by reset() (env.py:116-125)
+    const int ct = st.ct[e];
+    store_lane(st, n, e, s, ct);   // ct is not cleared by reset() (env.py:116-125)
     if (obs_out != nullptr) {
-        float obs[OBS_DIM];
+        float obs[OBS_DIM + 3];
         observe(k, s, obs);
-        float4 *dst = reinterpret_cast<float4 *>(obs_out + (size_t)e * OBS_DIM);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) dst[j] = make_float4(obs[4 * j], obs[4 * j + 1], obs[4 * j + 2], obs[4 * j + 3]);
+        if (k.task == MG_QUADROTOR_TASK_VELOCITY_CONTROL) {
+            const int tn = ct < k.nt - 1 ? ct : k.nt - 1;
+            obs[16] = k.vtargets[3 * tn]; obs[17] = k.vtargets[3 * tn + 1]; obs[18] = k.vtargets[3 * tn + 2];
+        }
+        for (int c = 0; c < k.obs_dim; ++c) obs_out[(size_t)e * k.obs_dim + c] = obs[c];
     }
 }
 
@@ -580,11 +694,14 @@ void host_inv3_f32(const float *Af, float *Ainv) {
     Ainv[8] = (float)((A[0] * A[4] - A[1] * A[3]) * r);
 }
 
-int fold_config(const mg_quadrotor_config *c, QuadK *k) {
+int fold_config(const mg_quadrotor_config *c, QuadK *k, bool need_targets = true) {
     if (!(c->precision >= 1e-8) || c->precision > c->dt)   // quadrotorsim.py:299-300
         return mg::set_error(MG_ERR_BAD_CONFIG, "precision %g must be in [1e-8, dt=%g]", c->precision, c->dt);
-    if (c->task != MG_QUADROTOR_TASK_NO_COLLISION && c->task != MG_QUADROTOR_TASK_HOVERING_CONTROL)
+    if (c->task != MG_QUADROTOR_TASK_NO_COLLISION && c->task != MG_QUADROTOR_TASK_HOVERING_CONTROL &&
+        c->task != MG_QUADROTOR_TASK_VELOCITY_CONTROL)
         return mg::set_error(MG_ERR_UNSUPPORTED, "quadrotor task %d is not implemented", c->task);
+    if (c->task == MG_QUADROTOR_TASK_VELOCITY_CONTROL && need_targets && c->velocity_targets_d == nullptr)
+        return mg::set_error(MG_ERR_NULL_POINTER, "velocity_control needs cfg->velocity_targets_d");
     if (c->map_d != nullptr && (c->map_h <= 0 || c->map_w <= 0))
         return mg::set_error(MG_ERR_BAD_SIZE, "map shape %d x %d", c->map_h, c->map_w);
     k->phi32 = (float)c->phi;
@@ -637,6 +754,8 @@ int fold_config(const mg_quadrotor_config *c, QuadK *k) {
     k->map = c->map_d;
     k->map_h = c->map_h;
     k->map_w = c->map_w;
+    k->vtargets = c->velocity_targets_d;
+    k->obs_dim = c->task == MG_QUADROTOR_TASK_VELOCITY_CONTROL ? 19 : 16;
     k->auto_reset = 0;
     for (int i = 0; i < 3; ++i) { k->init_v_base[i] = 0.0f; k->init_w_base[i] = 0.0f; }
     k->init_v_noisy = k->init_w_noisy = 0.0;
@@ -687,7 +806,7 @@ int launch_steps(const mg_quadrotor_config *cfg, int32_t n, int32_t n_steps, con
     }
     StepIO io{action, obs, reward, reward64, done, failed};
     const int grid = (n + BLOCK - 1) / BLOCK;
-    if (config_is_simple(cfg))
+    if (config_is_simple(cfg) && cfg->task != MG_QUADROTOR_TASK_VELOCITY_CONTROL)
         hipLaunchKernelGGL(quadrotor_step_kernel<true>, dim3(grid), dim3(BLOCK), 0, (hipStream_t)stream, k, *state,
                            io, n, n_steps);
     else
@@ -719,6 +838,18 @@ extern "C" int mg_quadrotor_default_config(mg_quadrotor_config *c) {
     for (int i = 0; i < 12; ++i) c->prop_coord[i] = pc[i];
     c->map_d = nullptr; c->map_h = 100; c->map_w = 100;
     return MG_OK;
+}
+
+extern "C" int mg_quadrotor_velocity_targets(const mg_quadrotor_config *cfg, int32_t nt, const float *actions_d,
+                                             float *targets_d, void *stream) {
+    MG_REQUIRE_PTR(cfg);
+    MG_REQUIRE_PTR(actions_d);
+    MG_REQUIRE_PTR(targets_d);
+    if (nt <= 0) return mg::set_error(MG_ERR_BAD_SIZE, "nt=%d", nt);
+    QuadK k;
+    if (int rc = fold_config(cfg, &k, false)) return rc;
+    hipLaunchKernelGGL(quadrotor_targets_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, k, nt, actions_d, targets_d);
+    return mg::check_launch("quadrotor_targets_kernel");
 }
 
 extern "C" int mg_quadrotor_reset(const mg_quadrotor_config *cfg, int32_t n, const mg_quadrotor_state *state,

@@ -43,7 +43,8 @@ DEFAULT_SIM_CONFIG = {
 }
 
 OBS_KEYS = ["b_v_x", "b_v_y", "b_v_z", "b_x", "b_y", "b_z", "acc_x", "acc_y", "acc_z",
-            "gyro_x", "gyro_y", "gyro_z", "pitch", "roll", "yaw", "z"]   # env.py:78-84,193-196
+            "gyro_x", "gyro_y", "gyro_z", "pitch", "roll", "yaw", "z",           # env.py:78-84,193-196
+            "next_target_g_v_x", "next_target_g_v_y", "next_target_g_v_z"]       # velocity_control only, env.py:85-86
 
 
 def _fill_config(cfg, sim, dt, nt, task, healthy_reward):
@@ -88,13 +89,16 @@ class _LazyInfo(Mapping):
     def __getitem__(self, k):
         if k == "failed":
             return self._failed
-        return self._obs[:, OBS_KEYS.index(k)]
+        i = OBS_KEYS.index(k)
+        if i >= self._obs.shape[1]:
+            raise KeyError(k)
+        return self._obs[:, i]
 
     def __iter__(self):
-        return iter(OBS_KEYS + ["failed"])
+        return iter(OBS_KEYS[:self._obs.shape[1]] + ["failed"])
 
     def __len__(self):
-        return len(OBS_KEYS) + 1
+        return self._obs.shape[1] + 1
 
 
 class Quadrotor(object):
@@ -112,10 +116,6 @@ class Quadrotor(object):
                  map_file=None, simulator_conf=None, healthy_reward=1.0, auto_reset=False, env_id_base=0,
                  **kwargs):
         assert task in TASKS, "Invalid task setting"
-        if task == "velocity_control":
-            raise NotImplementedError("task 'velocity_control' is a later row of the scope table "
-                                      "(SURVEY.md §8f-3); this engine implements no_collision and "
-                                      "hovering_control")
         self._lib = _lib.load()
         self.num_envs = int(num_envs)
         self.device = torch.device(device)
@@ -142,7 +142,8 @@ class Quadrotor(object):
         self._state = _lib.QuadrotorState(*[_lib.ptr(t) for t in
                                             (self.pos, self.vel, self.omega, self.propw, self.rot, self.ct)])
         # --- outputs ------------------------------------------------------------------------
-        self._obs = torch.zeros(N, 16, dtype=torch.float32, device=dev)
+        self.obs_dim = 19 if task == "velocity_control" else 16          # env.py:87-95
+        self._obs = torch.zeros(N, self.obs_dim, dtype=torch.float32, device=dev)
         self._reward = torch.zeros(N, dtype=torch.float32, device=dev)
         self._reward64 = torch.zeros(N, dtype=torch.float64, device=dev)
         self._done = torch.zeros(N, dtype=torch.bool, device=dev)    # kernel writes 0/1 bytes
@@ -156,25 +157,42 @@ class Quadrotor(object):
         self.x_offset = self.y_offset = 0
         self.z_offset = 0.0
         self._map_t = None
-        self.map_matrix = Quadrotor.load_map(map_file)             # env.py:104
-        ys, xs = np.where(self.map_matrix == -1)
-        assert len(ys) == 1
-        self.y_offset, self.x_offset = int(ys[0]), int(xs[0])
-        self.z_offset = 5.0                                        # env.py:113
-        self.map_matrix[self.y_offset, self.x_offset] = 0
-        if map_file is not None or self.map_matrix.any():
-            self._map_t = torch.from_numpy(self.map_matrix.astype(np.int32)).to(dev).contiguous()
-            self._cfg.map_d = self._map_t.data_ptr()
+        self.velocity_targets = None
+        if task == "velocity_control":
+            # env.py:99-102 -> QuadrotorSim.define_velocity_control_task(dt, nt, seed), quadrotorsim.py:306-319:
+            # nt random-action steps from the pre-reset all-float32 zero state; same stream as
+            # np.random.seed(seed) (a private RandomState: the reference reseeds numpy's global RNG here)
+            rs = np.random.RandomState(seed)
+            acts = np.stack([rs.uniform(low=self._cfg.min_voltage, high=self._cfg.max_voltage, size=4)
+                             .astype(np.float32) for _ in range(int(nt))])
+            a_t = torch.from_numpy(acts).to(dev).contiguous()
+            self.velocity_targets = torch.zeros(int(nt), 3, dtype=torch.float32, device=dev)
+            self._cfg.map_d, self._cfg.map_h, self._cfg.map_w = None, 0, 0
+            rc = self._lib.mg_quadrotor_velocity_targets(self._cfg, int(nt), _lib.ptr(a_t),
+                                                         _lib.ptr(self.velocity_targets), _lib.current_stream(dev))
+            _lib.check(rc, "mg_quadrotor_velocity_targets")
+            self._cfg.velocity_targets_d = self.velocity_targets.data_ptr()
+            self.map_matrix = None
         else:
-            self._cfg.map_d = None                                 # flat floor fast path
-        self._cfg.map_h, self._cfg.map_w = self.map_matrix.shape
+            self.map_matrix = Quadrotor.load_map(map_file)             # env.py:104
+            ys, xs = np.where(self.map_matrix == -1)
+            assert len(ys) == 1
+            self.y_offset, self.x_offset = int(ys[0]), int(xs[0])
+            self.z_offset = 5.0                                        # env.py:113
+            self.map_matrix[self.y_offset, self.x_offset] = 0
+            if map_file is not None or self.map_matrix.any():
+                self._map_t = torch.from_numpy(self.map_matrix.astype(np.int32)).to(dev).contiguous()
+                self._cfg.map_d = self._map_t.data_ptr()
+            else:
+                self._cfg.map_d = None                                 # flat floor fast path
+            self._cfg.map_h, self._cfg.map_w = self.map_matrix.shape
         self._cfg.x_offset, self._cfg.y_offset, self._cfg.z_offset = self.x_offset, self.y_offset, self.z_offset
 
         self.valid_range = float(self.sim_config["fail"]["range"])
         lo, hi = self._cfg.min_voltage, self._cfg.max_voltage
         self.action_space = Box(low=np.array([lo] * 4, dtype="float32"),
                                 high=np.array([hi] * 4, dtype="float32"), shape=[4])
-        self.observation_space = Space(shape=[16], dtype="float32")
+        self.observation_space = Space(shape=[self.obs_dim], dtype="float32")
         self.np_random = np.random.RandomState(seed)
         self.seed_value = seed
         # fused auto-reset: done envs restart inside the step launch, noise from device-side Philox
@@ -256,7 +274,7 @@ class Quadrotor(object):
         T, N = a.shape[0], self.num_envs
         assert a.shape == (T, N, 4)
         dev = self.device
-        obs = torch.empty(T, N, 16, dtype=torch.float32, device=dev)
+        obs = torch.empty(T, N, self.obs_dim, dtype=torch.float32, device=dev)
         rew = torch.empty(T, N, dtype=torch.float32, device=dev)
         rew64 = torch.empty(T, N, dtype=torch.float64, device=dev)
         done = torch.empty(T, N, dtype=torch.bool, device=dev)

@@ -228,6 +228,26 @@ def Quadrotor_map_with_start(env):
     return m
 
 
+def _quadrotor_velocity(gym, seed=7, nt=200, T=260):
+    """task='velocity_control': the target trajectory rolled at __init__ in the all-float32 pre-reset
+    state (quadrotorsim.py:306-319) and a rollout crossing the ct == nt episode end twice."""
+    env = gym.make("quadrotor-v0", task="velocity_control", nt=nt, seed=seed)
+    out = {"targets": np.asarray(env.velocity_targets, np.float32), "seed": np.int64(seed), "nt": np.int64(nt)}
+    np.random.seed(seed + 100)
+    obs0 = env.reset()
+    init = _sim_state(env.simulator)
+    actions = np.random.RandomState(seed + 1).uniform(1.0, 4.0, size=(T, 4)).astype(np.float32)
+    obs, rew, done, ct = [], [], [], []
+    for t in range(T):
+        o, r, d, info = env.step(actions[t])
+        obs.append(np.asarray(o, np.float32)); rew.append(np.float64(r)); done.append(bool(d)); ct.append(int(env.ct))
+        assert "next_target_g_v_x" in info
+    out.update(obs0=np.asarray(obs0, np.float32), init_vel=init["vel"], init_omega=init["omega"], actions=actions,
+               obs=np.asarray(obs), reward=np.asarray(rew), done=np.asarray(done), ct=np.asarray(ct),
+               numpy_version=np.str_(np.__version__))
+    return out
+
+
 def gen_quadrotor(gym):
     # (name, seed, T, action range): the SURVEY §8(d) C2 streams — full-range U(0.1,15) and near-hover.
     # seed 3 with nt=50 exercises the `ct == nt` episode end (env.py:159-161).
@@ -243,6 +263,9 @@ def gen_quadrotor(gym):
     path = os.path.join(OUT, "quadrotor_onestep.npz")
     np.savez_compressed(path, **d)
     print("wrote", path, "done frac", d["done"].mean())
+    d = _quadrotor_velocity(gym)
+    np.savez_compressed(os.path.join(OUT, "quadrotor_velocity_control.npz"), **d)
+    print("wrote quadrotor_velocity_control.npz dones", int(d["done"].sum()))
     d = _quadrotor_no_collision(gym)
     np.savez_compressed(os.path.join(OUT, "quadrotor_no_collision_map.npz"), **d)
     d = _quadrotor_fail(gym)

@@ -9,6 +9,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.path.join(_HERE, "libmetagym_oracle.so")
 
 TASK_NO_COLLISION = 0
+TASK_VELOCITY = 1
 TASK_HOVERING = 2
 
 
@@ -35,6 +36,7 @@ class Consts(C.Structure):
         ("inertia_inv", C.c_float * 9), ("drag_m", C.c_float * 9), ("drag_f", C.c_float * 9),
         ("gravity_center", C.c_float * 3), ("prop_coord", C.c_float * 12),
         ("map", C.POINTER(C.c_int32)), ("map_h", C.c_int32), ("map_w", C.c_int32),
+        ("velocity_targets", C.POINTER(C.c_float)),
     ]
 
 
@@ -146,3 +148,28 @@ def batch_run(consts, states, init_states, ct, actions, iters):
     fn.restype = C.c_long
     return fn(C.byref(consts), C.c_int(n), states, init_states, ct.ctypes.data_as(C.c_void_p),
               actions.ctypes.data_as(C.c_void_p), C.c_int(actions.shape[0]), C.c_int(iters))
+
+
+def velocity_target_actions(seed, nt, lo=0.10, hi=15.0):
+    """The action stream define_velocity_control_task draws (quadrotorsim.py:306-315):
+    np.random.seed(seed), then nt calls of uniform(low, high, size=4).astype(float32)."""
+    rs = np.random.RandomState(seed)
+    return np.stack([rs.uniform(low=lo, high=hi, size=4).astype(np.float32) for _ in range(nt)])
+
+
+def velocity_targets(consts, actions):
+    actions = np.ascontiguousarray(actions, np.float32)
+    out = np.zeros((len(actions), 3), np.float32)
+    lib().qo_velocity_targets(C.byref(consts), C.c_int(len(actions)), actions.ctypes.data_as(C.c_void_p),
+                              out.ctypes.data_as(C.c_void_p))
+    return out
+
+
+def env_step_velocity(consts, state, ct, action):
+    """One velocity_control env.step for ONE env (state: State, ct: c_int). Returns obs[19], reward, done, failed."""
+    obs = np.zeros(19, np.float32)
+    r, d = C.c_double(), C.c_int()
+    a = np.ascontiguousarray(action, np.float32)
+    f = lib().qo_env_step_velocity(C.byref(consts), C.byref(state), C.byref(ct), a.ctypes.data_as(C.c_void_p),
+                                   obs.ctypes.data_as(C.c_void_p), C.byref(r), C.byref(d))
+    return obs, r.value, bool(d.value), int(f)

@@ -122,6 +122,7 @@ void qo_default_consts(qo_consts *c) {
     c->x_offset = 50; c->y_offset = 50; c->z_offset = 5.0;   /* env.py:104-114 default 100x100 map */
     c->map = 0; c->map_h = 100; c->map_w = 100;
     c->task = QO_TASK_HOVERING;
+    c->velocity_targets = 0;
 }
 
 void qo_zero_state(qo_state *s) {
@@ -247,6 +248,96 @@ void qo_substep(const qo_consts *c, qo_state *s, const double act[4]) {
     qo_inv3_f32(s->R, s->Rinv);                                            /* :206-208 */
 }
 
+/* ---- the same sub-step while the simulator is still in its pre-reset, ALL-float32 state -----------
+ * QuadrotorSim._zero_state (quadrotorsim.py:20-28) makes every array float32; only reset() turns
+ * velocity and body rate into float64. define_velocity_control_task (quadrotorsim.py:306-319) rolls
+ * the target trajectory from that state at Quadrotor.__init__ time (env.py:99-102), so there every
+ * expression of _run_internal is float32 (python floats are weak). vel32 / omega32 carry the state. */
+typedef struct { float pos[3], vel[3], omega[3], propw[4], R[9], Rinv[9]; } qo_state32;
+
+static void mat3_vec_f32_plain(const float *M, const float *x, float *y) { mat3_vec_f32(M, x, y); }
+
+static void qo_substep_f32state(const qo_consts *c, qo_state32 *s, const float act[4]) {
+    float prop_force_z = 0.0f, prop_torque[3] = {0, 0, 0}, prop_powers[4], me[4];
+    const float phi32 = (float)c->phi, phi_over_ra32 = (float)(c->phi / c->ra), inv_jm32 = (float)(1.0 / c->jm);
+    const float mm32 = (float)c->mm, prec32 = (float)c->precision, ct0_32 = (float)c->ct0, ct1_32 = (float)c->ct1;
+    const float ct2_32 = (float)c->ct2;
+    for (int i = 0; i < 4; ++i) {
+        double eff_act = act[i];
+        if (eff_act > c->max_voltage) eff_act = c->max_voltage;
+        else if (eff_act < c->min_voltage) eff_act = c->min_voltage;
+        const float eff32 = (float)eff_act;
+        float phi_w = phi32 * s->propw[i];
+        me[i] = phi_over_ra32 * (eff32 - phi_w);
+        prop_powers[i] = fabsf(me[i] / phi32 * eff32);
+        float d_prop_w = inv_jm32 * (me[i] - mm32);
+        float w_m = s->propw[i] + prec32 * d_prop_w;
+        const float *pc = &c->prop_coord[3 * i];
+        float l_m = norm3_f32(pc);
+        float bv[3], cr[3];
+        mat3_vec_f32_plain(s->Rinv, s->vel, bv);
+        cross_f32(s->omega, pc, cr);
+        float v_1 = bv[2] + cr[2] * l_m;
+        float sign = v_1 > 0 ? 1.0f : -1.0f;
+        float thrust = ((ct0_32 * w_m) * w_m + (ct1_32 * w_m) * v_1) + ((ct2_32 * v_1) * v_1) * sign;
+        s->propw[i] = w_m;
+        prop_force_z = prop_force_z + thrust;
+        float a[3] = {-0.0f, -0.0f, -thrust};
+        cross_f32(a, pc, cr);
+        prop_torque[0] += cr[0]; prop_torque[1] += cr[1]; prop_torque[2] += cr[2];
+    }
+    prop_torque[2] += ((-me[0] + me[1]) - me[2]) + me[3];
+    float DfRinv[9], tmp[3], f_drag[3], t_drag[3];
+    mat3_mul_f32(c->drag_f, s->Rinv, DfRinv);
+    mat3_vec_f32_plain(DfRinv, s->vel, tmp);
+    float nv = -norm3_f32(s->vel);
+    for (int k = 0; k < 3; ++k) f_drag[k] = nv * tmp[k];
+    mat3_vec_f32_plain(c->drag_m, s->omega, tmp);
+    float nw = -norm3_f32(s->omega);
+    for (int k = 0; k < 3; ++k) t_drag[k] = nw * tmp[k];
+    const float gravity_acc[3] = {0.0f, 0.0f, -9.8f};
+    float f_grav[3], t_grav[3];
+    mat3_vec_f32(s->Rinv, gravity_acc, f_grav);
+    for (int k = 0; k < 3; ++k) f_grav[k] = f_grav[k] * (float)c->quality;
+    cross_f32(f_grav, c->gravity_center, t_grav);
+    const float prop_force[3] = {0.0f, 0.0f, prop_force_z};
+    float f_all[3], t_all[3], body_acc[3], acc[3];
+    for (int k = 0; k < 3; ++k) {
+        f_all[k] = (prop_force[k] + f_grav[k]) + f_drag[k];
+        t_all[k] = (prop_torque[k] + (-t_grav[k])) + t_drag[k];
+        body_acc[k] = f_all[k] / (float)c->quality;
+    }
+    mat3_vec_f32_plain(s->R, body_acc, acc);
+    const float half_dt2 = (float)(0.5 * c->precision * c->precision);
+    for (int k = 0; k < 3; ++k) s->pos[k] = s->pos[k] + (s->vel[k] * prec32 + half_dt2 * acc[k]);
+    for (int k = 0; k < 3; ++k) s->vel[k] = s->vel[k] + prec32 * acc[k];
+    float alpha[3], tmp_w[3];
+    mat3_vec_f32_plain(c->inertia_inv, t_all, alpha);
+    const float half_dt = (float)(0.5 * c->precision);
+    for (int k = 0; k < 3; ++k) tmp_w[k] = s->omega[k] + half_dt * alpha[k];
+    float S[9] = {0};
+    S[1] = -tmp_w[2]; S[2] = tmp_w[1]; S[3] = tmp_w[2]; S[5] = -tmp_w[0]; S[6] = -tmp_w[1]; S[7] = tmp_w[0];
+    float RS[9];
+    mat3_mul_f32(s->R, S, RS);
+    for (int k = 0; k < 9; ++k) s->R[k] = s->R[k] + prec32 * RS[k];
+    for (int k = 0; k < 3; ++k) s->omega[k] = s->omega[k] + prec32 * alpha[k];
+    qo_inv3_f32(s->R, s->Rinv);
+}
+
+/* define_velocity_control_task quadrotorsim.py:306-319: nt steps from the zero state with the given
+ * (already float32) random actions; records global_velocity after every step. */
+void qo_velocity_targets(const qo_consts *c, int nt, const float *actions, float *targets) {
+    qo_state32 s;
+    memset(&s, 0, sizeof(s));
+    s.R[0] = s.R[4] = s.R[8] = 1.0f;
+    s.Rinv[0] = s.Rinv[4] = s.Rinv[8] = 1.0f;
+    const int times = (int)(c->dt / c->precision);
+    for (int t = 0; t < nt; ++t) {
+        for (int k = 0; k < times; ++k) qo_substep_f32state(c, &s, &actions[4 * t]);
+        targets[3 * t] = s.vel[0]; targets[3 * t + 1] = s.vel[1]; targets[3 * t + 2] = s.vel[2];
+    }
+}
+
 int qo_sim_step(const qo_consts *c, qo_state *s, const float act[4]) {
     /* quadrotorsim.py:295-304; env.py:129,135 hands over f32 values widened to python floats */
     double a[4] = {act[0], act[1], act[2], act[3]};
@@ -361,6 +452,33 @@ int qo_env_step(const qo_consts *c, qo_state *s, int *ct, const float act[4],
     int reset = 0;
     if (is_collision) { reset = 1; *ct = 0; }                           /* :147-149 */
     if (*ct == c->nt) { reset = 1; *ct = 0; }                           /* :159-161 */
+    *done = reset;
+    return 0;
+}
+
+/* Quadrotor.step for task='velocity_control' (env.py:127-165 with the :150-157 branch). obs has 19
+ * entries: the 16 of qo_observe (z_offset is 0 for this task) + next_target_g_v (env.py:262-273). */
+int qo_env_step_velocity(const qo_consts *c, qo_state *s, int *ct, const float act[4], float obs[19],
+                         double *reward, int *done) {
+    *ct += 1;
+    int failed = qo_sim_step(c, s, act);
+    qo_observe(c, s, obs);
+    const int tn = *ct < c->nt - 1 ? *ct : c->nt - 1;                   /* _update_state :268-269 */
+    for (int k = 0; k < 3; ++k) obs[16 + k] = c->velocity_targets[3 * tn + k];
+    if (failed) { *reward = 0.0; *done = 1; *ct = 0; return failed; }
+    /* :152-157 body-frame target = Rinv(f32) @ target(f32) -> f32 gemv */
+    float bt[3];
+    mat3_vec_f32(s->Rinv, &c->velocity_targets[3 * (*ct - 1)], bt);
+    double b_v[3];
+    mat3_vec_f32f64(s->Rinv, s->vel, b_v);
+    /* _get_velocity_diff env.py:275-280: np.float32 - np.float64 -> f64 */
+    double diff = (fabs((double)bt[0] - b_v[0]) + fabs((double)bt[1] - b_v[1])) + fabs((double)bt[2] - b_v[2]);
+    float energy = (float)c->dt * s->power;
+    double r = ((float)c->healthy_reward < energy) ? -c->healthy_reward : -(double)energy;
+    r += -0.001 * diff;                                                  /* :222-224 */
+    *reward = r;
+    int reset = 0;
+    if (*ct == c->nt) { reset = 1; *ct = 0; }
     *done = reset;
     return 0;
 }

@@ -8,7 +8,7 @@
 extern "C" {
 #endif
 
-enum { QO_TASK_NO_COLLISION = 0, QO_TASK_HOVERING = 2 };
+enum { QO_TASK_NO_COLLISION = 0, QO_TASK_VELOCITY = 1, QO_TASK_HOVERING = 2 };
 
 typedef struct {
     /* python floats (doubles) exactly as _parse_cfg keeps them, quadrotorsim.py:50-109 */
@@ -25,6 +25,8 @@ typedef struct {
     /* height map (row-major [map_h][map_w]); NULL = the default all-zero 100x100 map */
     const int32_t *map;
     int32_t map_h, map_w;
+    /* velocity_control: target trajectory float32 [nt][3] (define_velocity_control_task) */
+    const float *velocity_targets;
 } qo_consts;
 
 typedef struct {
@@ -50,6 +52,9 @@ int qo_env_step(const qo_consts *c, qo_state *s, int *ct, const float act[4],
                 float obs[16], double *reward, int *done);
 void qo_batch_env_step(const qo_consts *c, int n, qo_state *states, int *ct, const float *actions,
                        float *obs, double *reward, int *done, int *failed);
+void qo_velocity_targets(const qo_consts *c, int nt, const float *actions, float *targets);
+int qo_env_step_velocity(const qo_consts *c, qo_state *s, int *ct, const float act[4], float obs[19],
+                         double *reward, int *done);
 long qo_batch_run(const qo_consts *c, int n, qo_state *states, const qo_state *init, int *ct,
                   const float *actions, int n_batches, int iters);
 size_t qo_sizeof_state(void);

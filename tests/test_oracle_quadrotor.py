@@ -130,3 +130,27 @@ def test_oracle_no_collision_on_reference_map():
             assert rew[0] == g["reward_%d" % k][t], (k, t)
             assert np.array_equal(qo.states_to_arrays(st)["pos"][0], g["pos_%d" % k][t]), (k, t)
             assert obs_rel_err(obs, g["obs_%d" % k][t][None]) < REL_TOL
+
+
+def test_oracle_velocity_control_matches_reference():
+    """task='velocity_control': the target trajectory (rolled by the reference at __init__ in its
+    all-float32 pre-reset state, quadrotorsim.py:306-319) and a 260-step rollout across ct == nt."""
+    import ctypes as C
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "quadrotor_velocity_control.npz"))
+    nt = int(g["nt"])
+    c = qo.default_consts(nt=nt, task=qo.TASK_VELOCITY)
+    c.x_offset = c.y_offset = 0
+    c.z_offset = 0.0
+    tg = qo.velocity_targets(c, qo.velocity_target_actions(int(g["seed"]), nt))
+    assert vec_rel_err(tg, g["targets"]) < REL_TOL           # measured 1.5e-7
+    c.velocity_targets = tg.ctypes.data_as(C.POINTER(C.c_float))
+    st = qo.make_states(np.zeros((1, 3), np.float32), g["init_vel"][None], g["init_omega"][None],
+                        np.zeros((1, 4), np.float32), np.eye(3, dtype=np.float32).reshape(1, 9))
+    ct = C.c_int(0)
+    for t in range(len(g["actions"])):
+        obs, r, d, f = qo.env_step_velocity(c, st[0], ct, g["actions"][t])
+        assert f == 0 and d == bool(g["done"][t]) and ct.value == g["ct"][t], t
+        assert obs_rel_err(obs[None, :16], g["obs"][t][None, :16], z_offset=1.0) < REL_TOL, t
+        assert vec_rel_err(obs[None, 16:], g["obs"][t][None, 16:]) < REL_TOL, t
+        assert scalar_rel_err(r, g["reward"][t]) < REL_TOL, t
+    assert g["done"].sum() == 1
