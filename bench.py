@@ -158,6 +158,48 @@ def secondary_workloads(dev):
     except Exception as e:  # secondary numbers must never break the headline line
         out["maze_error"] = repr(e)
     try:
+        # C5 (mixed, 2^20 envs over 8 GPUs): one GPU's share = 65 536 quadrotors + 65 536 MetaMaze3D envs
+        # (64x64 frames so the batch stays resident). The two families are independent,
+        # so they are co-scheduled on two HIP streams: the VALU-bound quadrotor kernel and the
+        # store-heavy raycaster overlap instead of queueing behind each other.
+        nq = nm = 65536
+        tasks = [MazeTaskSampler(n=9, allow_loops=False, step_reward=-0.01, goal_reward=1.0, food_density=0.06,
+                                 food_interval=20, seed=s) for s in range(64)]
+        quad = metagym_amd.make("quadrotor-v0", num_envs=nq, device=dev, task="hovering_control", auto_reset=True)
+        maze = metagym_amd.make("meta-maze-discrete-3D-v0", num_envs=nm, device=dev, max_steps=200,
+                                resolution=(64, 64), task_type="SURVIVAL", auto_reset=True)
+        maze.set_task(tasks)
+        quad.reset(seed=0)
+        maze.reset()
+        qa = [torch.rand(nq, 4, device=dev) * 14.9 + 0.1 for _ in range(4)]
+        ma = [torch.randint(0, 4, (nm,), device=dev, dtype=torch.int32) for _ in range(4)]
+        s_q = _time_steps(lambda i: quad.step(qa[i % 4]), 40, 5)
+        s_m = _time_steps(lambda i: maze.step(ma[i % 4]), 40, 5)
+        st_q, st_m = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)
+
+        def both(i):
+            with torch.cuda.stream(st_q):
+                quad.step(qa[i % 4])
+            with torch.cuda.stream(st_m):
+                maze.step(ma[i % 4])
+        torch.cuda.synchronize()
+        for i in range(5):
+            both(i)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(40):
+            both(i)
+        torch.cuda.synchronize()
+        s_b = (time.perf_counter() - t0) / 40
+        out["C5_mixed_share_65536quad_plus_65536maze3d_64x64"] = {
+            "env_steps_per_s_two_streams": (nq + nm) / s_b, "ms_per_mixed_step_two_streams": s_b * 1e3,
+            "ms_quadrotor_alone": s_q * 1e3, "ms_maze3d_alone": s_m * 1e3,
+            "overlap_gain": (s_q + s_m) / s_b}
+        del quad, maze, qa, ma
+        torch.cuda.empty_cache()
+    except Exception as e:
+        out["mixed_error"] = repr(e)
+    try:
         sys.path.insert(0, os.path.join(ROOT, "tests"))
         from walker_fixtures import load_models
         from metagym_amd.metalocomotion import MetaHumanoidEnv
@@ -260,7 +302,7 @@ def main():
             except Exception:
                 traffic = None
         out = {
-            "metric": "env-steps/sec (whole node) at 2^16 parallel envs per GPU",
+            "metric": "env-steps/sec (whole node) at 2^16 parallel envs; 1/2/4/8-GPU scaling",
             "value": value,
             "unit": "env-steps/s",
             "n_gpus": world,
