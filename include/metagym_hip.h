@@ -225,6 +225,9 @@ typedef struct mg_maze_view {
                                       texture 0 = ground, 1.. = walls (maze_task.py:19-36) */
     const uint32_t *ceil_texture;  /* DEVICE [tex][tex] */
     int32_t n_textures, tex_size;
+    int32_t max_ray_records;       /* optional bound on translucent records per ray (0 = 2n+1). A ray crosses
+                                      at most 2*floor(max_vision / min cell_size) + 4 cells before it stops */
+    int32_t reserved;
 } mg_maze_view;
 
 /* Host helper: the per-column tables of ray_caster_utils.py:82-90 (tan_hp accumulated column by

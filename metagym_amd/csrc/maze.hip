@@ -883,6 +883,7 @@ extern "C" int mg_maze3d_step(const mg_maze_tasks *T, const mg_maze_view *view, 
     // bound on translucent records per ray: one per DDA step plus the start cell. A ray advances
     // at least one cell per step and stops at max_vision or at the maze border.
     vk.t_max = 2 * T->n + 1;
+    if (view->max_ray_records > 0 && view->max_ray_records < vk.t_max) vk.t_max = view->max_ray_records;
     const size_t lds = ((sizeof(EnvShared) + 15) & ~size_t(15)) + sizeof(double) * T->n * T->n +
                        sizeof(uint2) * 64 * vk.t_max * MZ_WAVES +
                        2 * ((size_t)(T->n * T->n + 15) & ~size_t(15));

@@ -223,6 +223,11 @@ class _Maze3D(_MazeBatch):
         self._ceil_t = torch.from_numpy(ceil.view(np.int32).copy()).to(dev).contiguous()
         v.textures, v.ceil_texture = self._tex_t.data_ptr(), self._ceil_t.data_ptr()
         v.n_textures, v.tex_size = tex.shape[0], tex.shape[1]
+        # DDA_2D (ray_caster_utils.py:31) stops once hit_dist >= max_vision: a ray crosses at most
+        # floor(max_vision / cell_size) + 1 cell boundaries per axis plus the final overshoot, so it can
+        # record at most 2*floor(mv/cs) + 4 translucent cells (incl. the start cell) whatever n is
+        min_cs = min(float(t.cell_size) for t in self.tasks)
+        v.max_ray_records = 2 * int(self.max_vision_range / min_cs) + 5
         self._view_c = v
         self._tex_version = MAZE_TASK_MANAGER.version
 

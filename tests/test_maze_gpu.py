@@ -266,3 +266,34 @@ def test_maze3d_full_size_properties():
     ob = obs.cpu().numpy()
     for e in (0, 7, 19, 31):
         assert np.array_equal(ob[e], mo.observe_3d(otasks[idl[e]], tt, view, states[e], 0)), e
+
+
+@pytest.mark.parametrize("n,res,cell", [(15, (64, 48), 2.0), (21, (32, 32), 2.0), (15, (32, 32), 0.75)])
+def test_maze3d_larger_mazes_match_oracle(n, res, cell):
+    """The reference's default maze size is 15x15 (maze_task.py:42); larger grids and a small cell size
+    (many cells inside the vision range, so many overlay records per ray and > 64 KiB of LDS) must
+    render identically to the oracle too. Dense food so most rays cross translucent cells."""
+    import metagym_amd
+    from metagym_amd.metamaze import MazeTaskSampler, MAZE_TASK_MANAGER
+    tt = mo.SURVIVAL
+    tasks = [MazeTaskSampler(n=n, allow_loops=True, crowd_ratio=0.25, cell_size=cell, wall_height=1.6 * cell,
+                             agent_height=0.8 * cell, step_reward=-0.01, goal_reward=1.0, food_density=0.3,
+                             food_interval=3, seed=40 + s) for s in range(3)]
+    env = metagym_amd.make("meta-maze-discrete-3D-v0", num_envs=12, device="cuda:0", max_steps=30, resolution=res,
+                           task_type="SURVIVAL")
+    env.set_task(tasks)
+    ids = env.task_id.cpu().numpy()
+    otasks, states = _oracle_batch(tasks, ids, tt)
+    view = mo.View(MAZE_TASK_MANAGER.grounds.astype(np.uint8), MAZE_TASK_MANAGER.ceil, res[0], res[1])
+    obs = env.reset().cpu().numpy()
+    assert np.array_equal(obs[0], mo.observe_3d(otasks[ids[0]], tt, view, states[0], 0))
+    rs = np.random.RandomState(n)
+    for t in range(10):
+        a = rs.choice(4, size=12, p=[0.2, 0.2, 0.1, 0.5])
+        obs, _, done, _ = env.step(torch.as_tensor(a))
+        ob = obs.cpu().numpy()
+        for e in range(12):
+            mo.step_disc3d(otasks[ids[e]], tt, 30, states[e], a[e])
+        for e in range(t % 3, 12, 3):
+            ref = mo.observe_3d(otasks[ids[e]], tt, view, states[e], 0)
+            assert np.array_equal(ob[e], ref), (t, e, int((ob[e] != ref).sum()))
