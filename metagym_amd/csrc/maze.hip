@@ -33,6 +33,7 @@ namespace {
 
 constexpr int MZ_BLOCK = 256;
 constexpr int MZ_WAVES = MZ_BLOCK / mg::WAVE;
+constexpr int SLAB = 32;   // screen columns a wave handles per pass (<= 64); sets the per-wave overlay-record LDS
 
 // ------------------------------------------------------------------------------------------------
 // task / state access
@@ -383,7 +384,7 @@ __device__ __forceinline__ ColRec bcast(const ColRec &r, int lane) {
 // per-column parts of :155-205.
 __device__ ColRec column_pass(const ViewK &vk, const Task &t, const EnvShared &es, const int8_t *walls,
                               const uint8_t *texts, const double *transp, int col, int lane,
-                              uint2 *entries /* [t_max][64] */, double cs, double inv_cs, int cs_pow2) {
+                              uint2 *entries /* [t_max][SLAB] */, double cs, double inv_cs, int cs_pow2) {
     const int n = t.n;
     const double chp = vk.col_cos[col], shp = vk.col_sin[col];
     const float sin_abs = (float)(shp * es.c_ori + chp * es.s_ori);
@@ -414,7 +415,7 @@ __device__ ColRec column_pass(const ViewK &vk, const Task &t, const EnvShared &e
         int e2 = to_int_clamped((vk.half_v + bv) / vk.pixel_size, -1, vk.V - 1);
         if (s2 < 0) s2 = 0;
         if (e2 > vk.V) e2 = vk.V;
-        entries[n_tr * 64 + lane] = make_uint2((unsigned)s2 | ((unsigned)e2 << 16), (unsigned)cell);
+        entries[n_tr * SLAB + lane] = make_uint2((unsigned)s2 | ((unsigned)e2 << 16), (unsigned)cell);
         ++n_tr;
     };
 
@@ -588,7 +589,7 @@ __device__ __forceinline__ void pixel_pass(const ViewK &vk, const Task &t, const
         B = (int)(light * (oma * (double)((tx >> 16) & 255u)));
     }
     for (int q = 0; q < n_tr; ++q) {                                          // :194-205
-        const uint2 en = entries[q * 64 + k];
+        const uint2 en = entries[q * SLAB + k];
         if (!tflag && d_v >= (int)(en.x & 0xffffu) && d_v < (int)(en.x >> 16)) {
             const double tf = transp[en.y] * 0.50 + 0.10, om = 1.0 - tf;
             R = (int)(om * (double)R);
@@ -625,7 +626,7 @@ __global__ __launch_bounds__(MZ_BLOCK) void maze3d_step_kernel(mg_maze_tasks T, 
     double *transp = reinterpret_cast<double *>(smem + off);
     off += sizeof(double) * nn;
     uint2 *entries_all = reinterpret_cast<uint2 *>(smem + off);
-    off += sizeof(uint2) * 64 * vk.t_max * MZ_WAVES;
+    off += sizeof(uint2) * SLAB * vk.t_max * MZ_WAVES;
     int8_t *walls = reinterpret_cast<int8_t *>(smem + off);
     off += (nn + 15) & ~15;
     uint8_t *texts = reinterpret_cast<uint8_t *>(smem + off);
@@ -702,10 +703,10 @@ __global__ __launch_bounds__(MZ_BLOCK) void maze3d_step_kernel(mg_maze_tasks T, 
         py_slice((long)sy, (long)(sy + 0.05 * vk.H), vk.V, lb_y0, lb_y1);
     }
 
-    uint2 *entries = entries_all + (size_t)wave * 64 * vk.t_max;
+    uint2 *entries = entries_all + (size_t)wave * SLAB * vk.t_max;
     int32_t *img = obs + (size_t)e * vk.H * vk.V * 3;
     // columns are dealt to the 4 waves in equal slabs (<= 64 each) so narrow images keep all waves busy
-    const int slab = min(64, (vk.H + MZ_WAVES - 1) / MZ_WAVES);
+    const int slab = min(SLAB, (vk.H + MZ_WAVES - 1) / MZ_WAVES);
     for (int cbase = wave * slab; cbase < vk.H; cbase += MZ_WAVES * slab) {
         const int ncols = min(slab, vk.H - cbase);
         ColRec mine{};
@@ -885,7 +886,7 @@ extern "C" int mg_maze3d_step(const mg_maze_tasks *T, const mg_maze_view *view, 
     vk.t_max = 2 * T->n + 1;
     if (view->max_ray_records > 0 && view->max_ray_records < vk.t_max) vk.t_max = view->max_ray_records;
     const size_t lds = ((sizeof(EnvShared) + 15) & ~size_t(15)) + sizeof(double) * T->n * T->n +
-                       sizeof(uint2) * 64 * vk.t_max * MZ_WAVES +
+                       sizeof(uint2) * SLAB * vk.t_max * MZ_WAVES +
                        2 * ((size_t)(T->n * T->n + 15) & ~size_t(15));
     if (lds > 160 * 1024) return mg::set_error(MG_ERR_BAD_SIZE, "maze n=%d needs %zu B of LDS (> 160 KiB)", T->n, lds);
     if (lds > 64 * 1024) {
