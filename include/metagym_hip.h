@@ -277,6 +277,8 @@ int mg_maze3d_step(const mg_maze_tasks *tasks, const mg_maze_view *view, int32_t
 #define MG_WALKER_MAX_JOINTS 24
 #define MG_WALKER_MAX_SPHERES 40
 #define MG_WALKER_MAX_FEET 6
+#define MG_WALKER_MAX_GEOMS 24
+#define MG_WALKER_MAX_PAIRS 128
 
 /* Topology shared by every task of a batch (all MetaLocomotion variants of one robot share it). */
 typedef struct mg_walker_topology {
@@ -285,12 +287,18 @@ typedef struct mg_walker_topology {
     int32_t joint_body[MG_WALKER_MAX_JOINTS];      /* non-decreasing; joints of a body act in order */
     int32_t sphere_body[MG_WALKER_MAX_SPHERES];    /* collision spheres (capsule end caps, sphere geoms) */
     int32_t foot_body[MG_WALKER_MAX_FEET];         /* bodies whose ground contact sets feet_contact */
+    /* self-collision (robot_bases.py:119: URDF_USE_SELF_COLLISION | ..._EXCLUDE_ALL_PARENTS): capsule
+     * geoms and the geom pairs to test (bodies distinct, not ancestor-related, not welded together) */
+    int32_t n_geoms, n_pairs;
+    int32_t geom_body[MG_WALKER_MAX_GEOMS];
+    uint8_t pair_a[MG_WALKER_MAX_PAIRS], pair_b[MG_WALKER_MAX_PAIRS];
 } mg_walker_topology;
 
 /* Per-task geometry / inertia table, doubles, one row of `model_stride` values per task:
  *   body_pos[nb][3] body_rot[nb][9] body_mass[nb] body_com[nb][3] body_inertia[nb][9]
  *   joint_anchor[nj][3] joint_axis[nj][3] joint_lo[nj] joint_hi[nj] joint_armature[nj]
  *   joint_damping[nj] joint_stiffness[nj] motor_torque[nj] sphere_pos[ns][3] sphere_radius[ns]
+ *   geom_p0[ng][3] geom_p1[ng][3] geom_radius[ng]      (capsule end points in the body frame)
  * (motor_torque[j] = motor_power_j * power, the factor multiplying clip(a_j,-1,1): humanoids.py:50-54,
  * walker_base.py:26-29). */
 typedef struct mg_walker_models {
@@ -313,7 +321,8 @@ typedef struct mg_walker_params {
     int32_t max_steps;
     int32_t floor_in_parts;    /* 1: the floor link counts in the mean part position (walker_base_env.py:30-31) */
     int32_t mapping;           /* 1 (default): wave per env, LDS-resident; 0: lane per env (cross-check) */
-    int32_t reserved;
+    int32_t self_collision;    /* 1: capsule-capsule contacts between the topology's geom pairs */
+    double self_friction;      /* geom friction squared (Bullet multiplies the two coefficients) */
 } mg_walker_params;
 
 /* Per-env state, SoA doubles: component c of env e at base[c*N + e]. */

@@ -74,13 +74,16 @@ class MazeView(C.Structure):
 
 
 WALKER_MAX_BODIES, WALKER_MAX_JOINTS, WALKER_MAX_SPHERES, WALKER_MAX_FEET = 16, 24, 40, 6
+WALKER_MAX_GEOMS, WALKER_MAX_PAIRS = 24, 128
 
 
 class WalkerTopology(C.Structure):
     """mg_walker_topology"""
     _fields_ = [("n_bodies", C.c_int32), ("n_joints", C.c_int32), ("n_spheres", C.c_int32), ("n_feet", C.c_int32),
                 ("body_parent", C.c_int32 * WALKER_MAX_BODIES), ("joint_body", C.c_int32 * WALKER_MAX_JOINTS),
-                ("sphere_body", C.c_int32 * WALKER_MAX_SPHERES), ("foot_body", C.c_int32 * WALKER_MAX_FEET)]
+                ("sphere_body", C.c_int32 * WALKER_MAX_SPHERES), ("foot_body", C.c_int32 * WALKER_MAX_FEET),
+                ("n_geoms", C.c_int32), ("n_pairs", C.c_int32), ("geom_body", C.c_int32 * WALKER_MAX_GEOMS),
+                ("pair_a", C.c_uint8 * WALKER_MAX_PAIRS), ("pair_b", C.c_uint8 * WALKER_MAX_PAIRS)]
 
 
 class WalkerModels(C.Structure):
@@ -96,7 +99,7 @@ class WalkerParams(C.Structure):
                 ("initial_z", C.c_double), ("joints_at_limit_cost", C.c_double),
                 ("walk_target_x", C.c_double), ("walk_target_y", C.c_double),
                 ("max_steps", C.c_int32), ("floor_in_parts", C.c_int32), ("mapping", C.c_int32),
-                ("reserved", C.c_int32)]
+                ("self_collision", C.c_int32), ("self_friction", C.c_double)]
 
 
 class WalkerState(C.Structure):

@@ -37,6 +37,7 @@ struct ModelRef {   // offsets into one task's table row
     const double *body_pos, *body_rot, *body_mass, *body_com, *body_inertia;
     const double *joint_anchor, *joint_axis, *joint_lo, *joint_hi, *joint_arm, *joint_damp, *joint_stiff, *motor;
     const double *sph_pos, *sph_r;
+    const double *geom_p0, *geom_p1, *geom_r;
 };
 
 __device__ __forceinline__ ModelRef model_ref(const mg_walker_topology &tp, const mg_walker_models &ms, int task) {
@@ -57,7 +58,10 @@ __device__ __forceinline__ ModelRef model_ref(const mg_walker_topology &tp, cons
     r.joint_stiff = p; p += nj;
     r.motor = p; p += nj;
     r.sph_pos = p; p += 3 * ns;
-    r.sph_r = p;
+    r.sph_r = p; p += ns;
+    r.geom_p0 = p; p += 3 * tp.n_geoms;
+    r.geom_p1 = p; p += 3 * tp.n_geoms;
+    r.geom_r = p;
     return r;
 }
 
@@ -85,6 +89,34 @@ __device__ __forceinline__ void rodrigues(V3 k, double t, double *R) {
     R[0] = c + k.x * k.x * v;       R[1] = k.x * k.y * v - k.z * s; R[2] = k.x * k.z * v + k.y * s;
     R[3] = k.y * k.x * v + k.z * s; R[4] = c + k.y * k.y * v;       R[5] = k.y * k.z * v - k.x * s;
     R[6] = k.z * k.x * v - k.y * s; R[7] = k.z * k.y * v + k.x * s; R[8] = c + k.z * k.z * v;
+}
+
+// Closest points of two segments (Ericson, Real-Time Collision Detection 5.1.9), spheres included.
+__device__ __forceinline__ void segment_closest(V3 p1, V3 q1, V3 p2, V3 q2, V3 &c1, V3 &c2) {
+    const V3 d1 = q1 - p1, d2 = q2 - p2, r = p1 - p2;
+    const double a = dot(d1, d1), e = dot(d2, d2), f = dot(d2, r), eps = 1e-12;
+    double sc, tc;
+    if (a <= eps && e <= eps) { c1 = p1; c2 = p2; return; }
+    if (a <= eps) { sc = 0.0; tc = fmin(fmax(f / e, 0.0), 1.0); }
+    else {
+        const double c = dot(d1, r);
+        if (e <= eps) { tc = 0.0; sc = fmin(fmax(-c / a, 0.0), 1.0); }
+        else {
+            const double b = dot(d1, d2), den = a * e - b * b;
+            sc = den > eps ? fmin(fmax((b * f - c * e) / den, 0.0), 1.0) : 0.0;
+            tc = (b * sc + f) / e;
+            if (tc < 0.0) { tc = 0.0; sc = fmin(fmax(-c / a, 0.0), 1.0); }
+            else if (tc > 1.0) { tc = 1.0; sc = fmin(fmax((b - c) / a, 0.0), 1.0); }
+        }
+    }
+    c1 = p1 + sc * d1;
+    c2 = p2 + tc * d2;
+}
+__device__ __forceinline__ void tangent_basis(V3 n, V3 &t1, V3 &t2) {
+    const V3 ref = fabs(n.x) < 0.9 ? V3{1.0, 0.0, 0.0} : V3{0.0, 1.0, 0.0};
+    t1 = cross(n, ref);
+    t1 = (1.0 / sqrt(dot(t1, t1))) * t1;
+    t2 = cross(n, t1);
 }
 
 struct Env {   // per-lane simulation state
@@ -281,6 +313,33 @@ __device__ void substep(const mg_walker_topology &tp, const ModelRef &m, const m
             touch_mask |= 1ull << g;
         }
     }
+    if (prm.self_collision)
+        for (int pr = 0; pr < tp.n_pairs && ncontacts < MAXC; ++pr) {
+            const int ga = tp.pair_a[pr], gb = tp.pair_b[pr], ba = tp.geom_body[ga], bb = tp.geom_body[gb];
+            V3 ca, cb;
+            segment_closest(k.o[ba] + mulMv(k.R[ba], ld3(m.geom_p0 + 3 * ga)), k.o[ba] + mulMv(k.R[ba], ld3(m.geom_p1 + 3 * ga)),
+                            k.o[bb] + mulMv(k.R[bb], ld3(m.geom_p0 + 3 * gb)), k.o[bb] + mulMv(k.R[bb], ld3(m.geom_p1 + 3 * gb)),
+                            ca, cb);
+            const V3 dv = ca - cb;
+            const double dist = sqrt(dot(dv, dv)), depth = m.geom_r[ga] + m.geom_r[gb] - dist;
+            if (depth > 0.0 && dist > 1e-9) {
+                const V3 nrm = (1.0 / dist) * dv;
+                const V3 xc = 0.5 * ((ca - m.geom_r[ga] * nrm) + (cb + m.geom_r[gb] * nrm));
+                V3 t1, t2;
+                tangent_basis(nrm, t1, t2);
+                for (int d = 0; d < n; ++d) {
+                    const V3 jd = jac_lin(k, k.mask[ba], xc, d) - jac_lin(k, k.mask[bb], xc, d);
+                    J[nr][d] = dot(nrm, jd);
+                    J[nr + 1][d] = dot(t1, jd);
+                    J[nr + 2][d] = dot(t2, jd);
+                }
+                bias[nr] = prm.erp * depth / dt; kind[nr] = 0; partner[nr] = -1;
+                bias[nr + 1] = 0.0; kind[nr + 1] = 3; partner[nr + 1] = nr;
+                bias[nr + 2] = 0.0; kind[nr + 2] = 3; partner[nr + 2] = nr;
+                nr += 3;
+                ++ncontacts;
+            }
+        }
     for (int j = 0; j < nj; ++j) {
         double sgn = 0.0, viol = 0.0;
         if (s.q[j] < m.joint_lo[j]) { sgn = 1.0; viol = m.joint_lo[j] - s.q[j]; }
@@ -309,7 +368,7 @@ __device__ void substep(const mg_walker_topology &tp, const ModelRef &m, const m
             double x = lam[r] - (jv - bias[r]) / diag[r];
             if (kind[r] == 0) x = x > 0.0 ? x : 0.0;
             else {
-                const double lim = prm.friction * lam[partner[r]];
+                const double lim = (kind[r] == 3 ? prm.self_friction : prm.friction) * lam[partner[r]];
                 x = x < -lim ? -lim : (x > lim ? lim : x);
             }
             const double dl = x - lam[r];
@@ -528,7 +587,7 @@ struct WaveLds {   // pointers into the env's LDS slab
     double *q, *qd, *tau;
     double *base;                            // pos[3] rot[9] vel[3] omega[3]
     double *J, *Wm, *bias, *diag, *lam;
-    double *cx;                              // contact points (x, y, depth) per contact
+    double *cx;                              // per contact: ground (x, y, depth) or self (point xc, normal)
     double *sc;                              // sin / cos of every joint angle
     int *mask, *depth, *jstart, *jcount, *poff, *kind, *partner, *csphere, *misc;
 };
@@ -536,10 +595,10 @@ struct WaveLds {   // pointers into the env's LDS slab
 __host__ __device__ inline size_t wave_lds_doubles(int nb, int nj, int maxr) {
     const int n = 6 + nj;
     return (size_t)nb * (9 + 3 + 3) + (size_t)nj * 6 + (size_t)nb * 12 + (size_t)nb * (3 + 3 + 9) + (size_t)n * n +
-           3 * (size_t)n + 3 * (size_t)nj + 18 + 2 * (size_t)maxr * n + 3 * (size_t)maxr + 3 * (size_t)W_MAXC +
+           3 * (size_t)n + 3 * (size_t)nj + 18 + 2 * (size_t)maxr * n + 3 * (size_t)maxr + 6 * (size_t)W_MAXC +
            2 * (size_t)nj;
 }
-__host__ __device__ inline size_t wave_lds_ints(int nb, int maxr) { return 5 * (size_t)nb + 2 * (size_t)maxr + W_MAXC + 8; }
+__host__ __device__ inline size_t wave_lds_ints(int nb, int maxr) { return 5 * (size_t)nb + 2 * (size_t)maxr + 2 * W_MAXC + 8; }
 
 __device__ __forceinline__ WaveLds carve(unsigned char *smem, int nb, int nj, int maxr) {
     const int n = 6 + nj;
@@ -553,11 +612,11 @@ __device__ __forceinline__ WaveLds carve(unsigned char *smem, int nb, int nj, in
     L.base = d; d += 18;
     L.J = d; d += (size_t)maxr * n; L.Wm = d; d += (size_t)maxr * n;
     L.bias = d; d += maxr; L.diag = d; d += maxr; L.lam = d; d += maxr;
-    L.cx = d; d += 3 * W_MAXC;
+    L.cx = d; d += 6 * W_MAXC;
     L.sc = d; d += 2 * nj;
     int *i = reinterpret_cast<int *>(d);
     L.mask = i; i += nb; L.depth = i; i += nb; L.jstart = i; i += nb; L.jcount = i; i += nb; L.poff = i; i += nb;
-    L.kind = i; i += maxr; L.partner = i; i += maxr; L.csphere = i; i += W_MAXC; L.misc = i;
+    L.kind = i; i += maxr; L.partner = i; i += maxr; L.csphere = i; i += 2 * W_MAXC; L.misc = i;
     return L;
 }
 
@@ -784,10 +843,10 @@ __device__ void wave_substep(const mg_walker_topology &tp, const ModelRef &m, co
     }
     const unsigned long long hits = __ballot(hit);
     const int rank = __popcll(hits & ((1ull << lane) - 1ull));
-    const int ncont = min(__popcll(hits), W_MAXC);
+    int ncont = min(__popcll(hits), W_MAXC);
     if (hit && rank < W_MAXC) {
-        L.cx[3 * rank] = sx; L.cx[3 * rank + 1] = sy; L.cx[3 * rank + 2] = depth;
-        L.csphere[rank] = lane;
+        L.cx[6 * rank] = sx; L.cx[6 * rank + 1] = sy; L.cx[6 * rank + 2] = depth;
+        L.csphere[2 * rank] = lane; L.csphere[2 * rank + 1] = -1;       // ground contact of sphere `lane`
         L.bias[3 * rank] = prm.erp * depth / dt; L.kind[3 * rank] = 0; L.partner[3 * rank] = -1;
         L.bias[3 * rank + 1] = 0.0; L.kind[3 * rank + 1] = 1; L.partner[3 * rank + 1] = 3 * rank;
         L.bias[3 * rank + 2] = 0.0; L.kind[3 * rank + 2] = 2; L.partner[3 * rank + 2] = 3 * rank;
@@ -795,6 +854,44 @@ __device__ void wave_substep(const mg_walker_topology &tp, const ModelRef &m, co
     touch_mask = 0ull;
     for (int g = 0; g < ns; ++g)
         if (((hits >> g) & 1ull) && __popcll(hits & ((1ull << g) - 1ull)) < W_MAXC) touch_mask |= 1ull << g;
+    // self-collision: lane = geom pair (in pair order, 64 at a time); slots after the ground contacts
+    if (prm.self_collision)
+        for (int base = 0; base < tp.n_pairs && ncont < W_MAXC; base += WV) {
+            const int pr = base + lane;
+            bool sh = false;
+            V3 xc{0, 0, 0}, nrm{0, 0, 1};
+            double sdepth = 0.0;
+            int ba = 0, bb = 0;
+            if (pr < tp.n_pairs) {
+                const int ga = tp.pair_a[pr], gb = tp.pair_b[pr];
+                ba = tp.geom_body[ga];
+                bb = tp.geom_body[gb];
+                V3 ca, cb;
+                segment_closest(ldv(L.o, ba) + mulMv(L.R + 9 * ba, ld3(m.geom_p0 + 3 * ga)),
+                                ldv(L.o, ba) + mulMv(L.R + 9 * ba, ld3(m.geom_p1 + 3 * ga)),
+                                ldv(L.o, bb) + mulMv(L.R + 9 * bb, ld3(m.geom_p0 + 3 * gb)),
+                                ldv(L.o, bb) + mulMv(L.R + 9 * bb, ld3(m.geom_p1 + 3 * gb)), ca, cb);
+                const V3 dv = ca - cb;
+                const double dist = sqrt(dot(dv, dv));
+                sdepth = m.geom_r[ga] + m.geom_r[gb] - dist;
+                sh = sdepth > 0.0 && dist > 1e-9;
+                if (sh) {
+                    nrm = (1.0 / dist) * dv;
+                    xc = 0.5 * ((ca - m.geom_r[ga] * nrm) + (cb + m.geom_r[gb] * nrm));
+                }
+            }
+            const unsigned long long sh_mask = __ballot(sh);
+            const int slot = ncont + __popcll(sh_mask & ((1ull << lane) - 1ull));
+            if (sh && slot < W_MAXC) {
+                double *cc = L.cx + 6 * slot;
+                cc[0] = xc.x; cc[1] = xc.y; cc[2] = xc.z; cc[3] = nrm.x; cc[4] = nrm.y; cc[5] = nrm.z;
+                L.csphere[2 * slot] = ba; L.csphere[2 * slot + 1] = bb;
+                L.bias[3 * slot] = prm.erp * sdepth / dt; L.kind[3 * slot] = 0; L.partner[3 * slot] = -1;
+                L.bias[3 * slot + 1] = 0.0; L.kind[3 * slot + 1] = 3; L.partner[3 * slot + 1] = 3 * slot;
+                L.bias[3 * slot + 2] = 0.0; L.kind[3 * slot + 2] = 3; L.partner[3 * slot + 2] = 3 * slot;
+            }
+            ncont = min(ncont + __popcll(sh_mask), W_MAXC);
+        }
     double lsgn = 0.0, viol = 0.0;
     if (lane < nj) {
         const double qj = L.q[lane];
@@ -813,12 +910,23 @@ __device__ void wave_substep(const mg_walker_topology &tp, const ModelRef &m, co
     // contact Jacobian rows, lane-strided over (contact, column)
     for (int t = lane; t < ncont * n; t += WV) {
         const int c = t / n, d = t % n;
-        const int g = L.csphere[c];
-        const unsigned mk = (unsigned)L.mask[tp.sphere_body[g]];
-        const V3 jc = wjac_lin(L, mk, V3{L.cx[3 * c], L.cx[3 * c + 1], 0.0}, d);
-        L.J[(size_t)(3 * c) * n + d] = jc.z;
-        L.J[(size_t)(3 * c + 1) * n + d] = jc.x;
-        L.J[(size_t)(3 * c + 2) * n + d] = jc.y;
+        const double *cc = L.cx + 6 * c;
+        if (L.csphere[2 * c + 1] < 0) {          // ground: point on the plane under the sphere
+            const unsigned mk = (unsigned)L.mask[tp.sphere_body[L.csphere[2 * c]]];
+            const V3 jc = wjac_lin(L, mk, V3{cc[0], cc[1], 0.0}, d);
+            L.J[(size_t)(3 * c) * n + d] = jc.z;
+            L.J[(size_t)(3 * c + 1) * n + d] = jc.x;
+            L.J[(size_t)(3 * c + 2) * n + d] = jc.y;
+        } else {                                 // self contact: relative velocity of the two bodies at xc
+            const V3 xc{cc[0], cc[1], cc[2]}, nrm{cc[3], cc[4], cc[5]};
+            const V3 jd = wjac_lin(L, (unsigned)L.mask[L.csphere[2 * c]], xc, d) -
+                          wjac_lin(L, (unsigned)L.mask[L.csphere[2 * c + 1]], xc, d);
+            V3 t1, t2;
+            tangent_basis(nrm, t1, t2);
+            L.J[(size_t)(3 * c) * n + d] = dot(nrm, jd);
+            L.J[(size_t)(3 * c + 1) * n + d] = dot(t1, jd);
+            L.J[(size_t)(3 * c + 2) * n + d] = dot(t2, jd);
+        }
     }
     WSYNC();
     // ---- W = M^-1 J^T: lane = row. The right-hand side lives in registers (a fully unrolled NMAX-slot
@@ -866,7 +974,7 @@ __device__ void wave_substep(const mg_walker_topology &tp, const ModelRef &m, co
             double x = lr - (jv - L.bias[r]) * idg;
             if (L.kind[r] == 0) x = x > 0.0 ? x : 0.0;
             else {
-                const double lim = prm.friction * L.lam[L.partner[r]];
+                const double lim = (L.kind[r] == 3 ? prm.self_friction : prm.friction) * L.lam[L.partner[r]];
                 x = x < -lim ? -lim : (x > lim ? lim : x);
             }
             const double dl = x - lr;
@@ -1022,7 +1130,9 @@ int check_walker(const mg_walker_topology *tp, const mg_walker_models *ms, const
         tp->n_spheres > NS || tp->n_feet < 0 || tp->n_feet > MG_WALKER_MAX_FEET)
         return mg::set_error(MG_ERR_BAD_SIZE, "walker topology out of range (bodies %d joints %d spheres %d feet %d)",
                              tp->n_bodies, tp->n_joints, tp->n_spheres, tp->n_feet);
-    const int need = 25 * tp->n_bodies + 12 * tp->n_joints + 4 * tp->n_spheres;
+    if (tp->n_geoms < 0 || tp->n_geoms > MG_WALKER_MAX_GEOMS || tp->n_pairs < 0 || tp->n_pairs > MG_WALKER_MAX_PAIRS)
+        return mg::set_error(MG_ERR_BAD_SIZE, "walker topology: geoms %d pairs %d", tp->n_geoms, tp->n_pairs);
+    const int need = 25 * tp->n_bodies + 12 * tp->n_joints + 4 * tp->n_spheres + 7 * tp->n_geoms;
     if (!ms->table || ms->n_tasks < 1 || ms->model_stride < need)
         return mg::set_error(MG_ERR_BAD_SIZE, "walker model table: stride %d < %d", ms->model_stride, need);
     if (!st->task_id || !st->pos || !st->rot || !st->vel || !st->omega || !st->q || !st->qd || !st->potential ||

@@ -72,7 +72,9 @@ class Model(object):
     geom_friction     lateral friction coefficient of the robot's geoms (first entry of `friction`)
     sph_body[ng], sph_pos[ng,3] (body frame), sph_radius[ng]   collision proxies: every sphere geom
         and both end caps of every capsule geom (a capsule touches a plane at its caps)
-    foot_sph[...]     indices of the spheres that belong to the foot bodies
+    geom_body/p0/p1/radius[ngeo]   the geoms as capsules (sphere: p0 == p1), body frame
+    pair_a/pair_b[npair]           geom pairs tested for self-collision (bodies distinct and not
+                                   ancestor-related: PyBullet's EXCLUDE_ALL_PARENTS rule)
     """
 
     def __init__(self):
@@ -116,7 +118,7 @@ def load_mjcf(path_or_string, foot_names=("right_foot", "left_foot")):
         if dflt.find("geom") is not None:
             gdef = dict(dflt.find("geom").attrib)
 
-    bodies, joints, spheres, frictions = [], [], [], []
+    bodies, joints, spheres, frictions, geoms = [], [], [], [], []
 
     def visit(elem, parent):
         b = len(bodies)
@@ -134,10 +136,12 @@ def load_mjcf(path_or_string, foot_names=("right_foot", "left_foot")):
                 m, c, inertia = _capsule_inertia(ft[:3], ft[3:], size[0], density)
                 spheres.append((b, np.array(ft[:3]), size[0], a.get("name", "")))
                 spheres.append((b, np.array(ft[3:]), size[0], a.get("name", "")))
+                geoms.append((b, np.array(ft[:3]), np.array(ft[3:]), size[0]))
             elif a.get("type", "sphere") == "sphere":
                 c = np.array(_floats(a.get("pos", "0 0 0"), 3))
                 m, inertia = _sphere_inertia(size[0], density)
                 spheres.append((b, c, size[0], a.get("name", "")))
+                geoms.append((b, c, c, size[0]))
             else:
                 raise ValueError("unsupported geom type %r" % a.get("type"))
             masses.append(m)
@@ -192,6 +196,33 @@ def load_mjcf(path_or_string, foot_names=("right_foot", "left_foot")):
     m.sph_body = np.array([s[0] for s in spheres], np.int32)
     m.sph_pos = np.array([s[1] for s in spheres])
     m.sph_radius = np.array([s[2] for s in spheres])
+    # capsule geoms (a sphere is a capsule with p0 == p1) for the self-collision narrow phase, and the
+    # body pairs PyBullet's URDF_USE_SELF_COLLISION | URDF_USE_SELF_COLLISION_EXCLUDE_ALL_PARENTS
+    # (robot_bases.py:119) leaves active: distinct bodies, neither an ancestor of the other
+    m.geom_body = np.array([g[0] for g in geoms], np.int32)
+    m.geom_p0 = np.array([g[1] for g in geoms])
+    m.geom_p1 = np.array([g[2] for g in geoms])
+    m.geom_radius = np.array([g[3] for g in geoms])
+
+    def ancestors(b):
+        out = set()
+        while m.body_parent[b] >= 0:
+            b = int(m.body_parent[b])
+            out.add(b)
+        return out
+    anc = [ancestors(b) for b in range(len(bodies))]
+    has_joint = [bool(np.any(m.joint_body == b)) for b in range(len(bodies))]
+
+    def rigid_group(b):     # bodies welded together (no joint in between) can never move relative to each other
+        while m.body_parent[b] >= 0 and not has_joint[b]:
+            b = int(m.body_parent[b])
+        return b
+    grp = [rigid_group(b) for b in range(len(bodies))]
+    pairs = [(ga, gb) for ga in range(len(geoms)) for gb in range(ga + 1, len(geoms))
+             if grp[geoms[ga][0]] != grp[geoms[gb][0]] and geoms[ga][0] not in anc[geoms[gb][0]]
+             and geoms[gb][0] not in anc[geoms[ga][0]]]
+    m.pair_a = np.array([p[0] for p in pairs], np.int32)
+    m.pair_b = np.array([p[1] for p in pairs], np.int32)
     m.geom_friction = np.array(float(np.mean(frictions)) if frictions else 1.0)   # lateral friction of the geoms
     m.foot_names = list(foot_names)
     m.foot_body = np.array([m.body_names.index(f) for f in foot_names], np.int32)

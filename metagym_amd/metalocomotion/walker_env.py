@@ -28,7 +28,7 @@ def pack_model(m, motor_torque):
     """One row of the mg_walker_models table (layout documented in include/metagym_hip.h)."""
     parts = [m.body_pos, m.body_rot, m.body_mass, m.body_com, m.body_inertia, m.joint_anchor, m.joint_axis,
              m.joint_lo, m.joint_hi, m.joint_armature, m.joint_damping, m.joint_stiffness, motor_torque,
-             m.sph_pos, m.sph_radius]
+             m.sph_pos, m.sph_radius, m.geom_p0, m.geom_p1, m.geom_radius]
     return np.concatenate([np.asarray(p, np.float64).reshape(-1) for p in parts])
 
 
@@ -44,7 +44,7 @@ class WalkerBatchEnv(object):
     initial_z = None              # None -> height of the base at reset (walker_base.py:44-45)
 
     def __init__(self, num_envs=1, device="cuda", frame_skip=4, time_step=0.005, enable_render=False,
-                 max_steps=2000, assets_dir=None, solver_iterations=5, mapping="wave"):
+                 max_steps=2000, assets_dir=None, solver_iterations=5, mapping="wave", self_collision=True):
         self._lib = _lib.load()
         self.num_envs = int(num_envs)
         self.device = torch.device(device)
@@ -53,6 +53,7 @@ class WalkerBatchEnv(object):
                                        "path" % (device,))
         self.frame_skip, self.time_step, self.max_steps = int(frame_skip), float(time_step), int(max_steps)
         self.solver_iterations = int(solver_iterations)
+        self.self_collision = bool(self_collision)     # the reference loads the MJCF with URDF_USE_SELF_COLLISION
         assert mapping in ("wave", "lane")
         self.mapping = mapping    # 'wave': one wavefront per env, LDS-resident (default); 'lane': one lane per env
         self.assets_dir = assets_dir or os.environ.get("METAGYM_LOCOMOTION_ASSETS")
@@ -96,13 +97,18 @@ class WalkerBatchEnv(object):
         nb, nj, ns, nf = len(m0.body_parent), len(m0.joint_body), len(m0.sph_body), len(m0.foot_body)
         for m in models:
             assert (np.array_equal(m.body_parent, m0.body_parent) and np.array_equal(m.joint_body, m0.joint_body)
-                    and np.array_equal(m.sph_body, m0.sph_body)), "all tasks of a batch must share one topology"
+                    and np.array_equal(m.sph_body, m0.sph_body) and np.array_equal(m.geom_body, m0.geom_body)
+                    and np.array_equal(m.pair_a, m0.pair_a)), "all tasks of a batch must share one topology"
         tp = _lib.WalkerTopology()
         tp.n_bodies, tp.n_joints, tp.n_spheres, tp.n_feet = nb, nj, ns, nf
         for i, v in enumerate(m0.body_parent): tp.body_parent[i] = int(v)
         for i, v in enumerate(m0.joint_body): tp.joint_body[i] = int(v)
         for i, v in enumerate(m0.sph_body): tp.sphere_body[i] = int(v)
         for i, v in enumerate(m0.foot_body): tp.foot_body[i] = int(v)
+        tp.n_geoms, tp.n_pairs = len(m0.geom_body), len(m0.pair_a)
+        assert tp.n_geoms <= _lib.WALKER_MAX_GEOMS and tp.n_pairs <= _lib.WALKER_MAX_PAIRS
+        for i, v in enumerate(m0.geom_body): tp.geom_body[i] = int(v)
+        for i, (a, b) in enumerate(zip(m0.pair_a, m0.pair_b)): tp.pair_a[i], tp.pair_b[i] = int(a), int(b)
         self._topo = tp
         mp = np.full(nj, 100.0) if self.motor_power is None else np.asarray(self.motor_power, float)
         assert len(mp) == nj
@@ -139,6 +145,8 @@ class WalkerBatchEnv(object):
         p.walk_target_x, p.walk_target_y = 1e3, 0.0                # walker_base.py:9-10
         p.max_steps, p.floor_in_parts = self.max_steps, 1
         p.mapping = 1 if self.mapping == "wave" else 0
+        p.self_collision = int(self.self_collision)
+        p.self_friction = float(m0.geom_friction) ** 2            # Bullet multiplies the two geoms' friction
         self._params_c = p
         self._obs = torch.zeros(N, self.obs_dim, dtype=torch.float32, device=dev)
         self._reward = torch.zeros(N, dtype=torch.float32, device=dev)

@@ -20,8 +20,8 @@ btMultiBodyDynamicsWorld implements, with the reference's own parameters:
 Stated assumptions (Bullet internals that cannot be checked here): MJCF joint `damping`,
 `stiffness`, `armature` act as in MuJoCo's documentation (explicit damping/spring torque, armature
 added to the diagonal of M); link inertia from solid-capsule / sphere formulas at density 1000;
-TORQUE_CONTROL torques persist across the 4 internal sub-steps; only body-vs-ground contacts
-(self-collision, enabled in the reference by robot_bases.py:119, is not modelled yet).
+TORQUE_CONTROL torques persist across the 4 internal sub-steps; self-collision (robot_bases.py:119
+flags) as capsule-capsule contacts between bodies that are neither ancestor-related nor welded.
 
 The Python-side rules around the physics ARE pinned by the reference source and are restated
 exactly: torque = power * 0.41 * clip(a) (humanoids.py:50-54), observation (walker_base.py:31-64),
@@ -158,11 +158,46 @@ def integrate_positions(s, dt):
 
 class Params(object):
     def __init__(self, dt=0.005, substeps=4, iterations=5, erp=0.9, friction=0.8 * 0.8, power=0.41, max_contacts=12,
-                 limit_erp=0.2):
+                 limit_erp=0.2, self_collision=True, self_friction=0.8 * 0.8):
         self.dt, self.substeps, self.iterations, self.erp, self.friction, self.power = dt, substeps, iterations, erp, friction, power
         self.limit_erp = limit_erp            # Bullet's default constraint ERP (btContactSolverInfo::m_erp2 = 0.2);
         #                                       setDefaultContactERP(0.9) only changes the contact ERP
-        self.max_contacts = max_contacts      # engine limit: the first max_contacts penetrating spheres are kept
+        self.self_collision, self.self_friction = self_collision, self_friction   # geom friction squared
+        self.max_contacts = max_contacts      # engine limit (ground contacts first, then self contacts): the first max_contacts penetrating spheres are kept
+
+
+def segment_closest(p1, q1, p2, q2):
+    """Closest points of segments [p1,q1] and [p2,q2] (Ericson, Real-Time Collision Detection 5.1.9);
+    degenerate segments (spheres) included."""
+    d1, d2, r = q1 - p1, q2 - p2, p1 - p2
+    a, e, f = d1 @ d1, d2 @ d2, d2 @ r
+    eps = 1e-12
+    if a <= eps and e <= eps:
+        return p1, p2
+    if a <= eps:
+        sc, tc = 0.0, min(max(f / e, 0.0), 1.0)
+    else:
+        c = d1 @ r
+        if e <= eps:
+            tc, sc = 0.0, min(max(-c / a, 0.0), 1.0)
+        else:
+            b = d1 @ d2
+            den = a * e - b * b
+            sc = min(max((b * f - c * e) / den, 0.0), 1.0) if den > eps else 0.0
+            tc = (b * sc + f) / e
+            if tc < 0.0:
+                tc, sc = 0.0, min(max(-c / a, 0.0), 1.0)
+            elif tc > 1.0:
+                tc, sc = 1.0, min(max((b - c) / a, 0.0), 1.0)
+    return p1 + sc * d1, p2 + tc * d2
+
+
+def tangent_basis(nrm):
+    """Two unit tangents orthogonal to nrm (deterministic choice shared with the kernels)."""
+    ref = np.array([1.0, 0.0, 0.0]) if abs(nrm[0]) < 0.9 else np.array([0.0, 1.0, 0.0])
+    t1 = np.cross(nrm, ref)
+    t1 = t1 / np.linalg.norm(t1)
+    return t1, np.cross(nrm, t1)
 
 
 def constraint_rows(m, s, kin, prm):
@@ -181,6 +216,32 @@ def constraint_rows(m, s, kin, prm):
             rows.append((Jc[2], prm.erp * depth / prm.dt, 0, -1, g))
             rows.append((Jc[0], 0.0, 1, k, g))
             rows.append((Jc[1], 0.0, 2, k, g))
+    # self-collision between the capsule geoms of bodies that are neither ancestor-related nor welded
+    # (PyBullet flags at robot_bases.py:119); friction = geom friction squared (Bullet multiplies)
+    if prm.self_collision and hasattr(m, "pair_a"):
+        for ga, gb in zip(m.pair_a, m.pair_b):
+            if len(rows) >= 3 * prm.max_contacts:
+                break
+            ba, bb = m.geom_body[ga], m.geom_body[gb]
+            a0 = kin["o"][ba] + kin["R"][ba] @ m.geom_p0[ga]
+            a1 = kin["o"][ba] + kin["R"][ba] @ m.geom_p1[ga]
+            b0 = kin["o"][bb] + kin["R"][bb] @ m.geom_p0[gb]
+            b1 = kin["o"][bb] + kin["R"][bb] @ m.geom_p1[gb]
+            ca, cb = segment_closest(a0, a1, b0, b1)
+            dvec = ca - cb
+            dist = np.linalg.norm(dvec)
+            depth = m.geom_radius[ga] + m.geom_radius[gb] - dist
+            if depth > 0.0 and dist > 1e-9:
+                nrm = dvec / dist                                   # from b towards a
+                # one contact point for both bodies (middle of the overlap): equal and opposite forces at
+                # the same point change neither the linear nor the angular momentum of the robot
+                xc = 0.5 * ((ca - m.geom_radius[ga] * nrm) + (cb + m.geom_radius[gb] * nrm))
+                Jd = point_jacobian(m, kin, ba, xc) - point_jacobian(m, kin, bb, xc)
+                t1, t2 = tangent_basis(nrm)
+                k = len(rows)
+                rows.append((nrm @ Jd, prm.erp * depth / prm.dt, 0, -1, -2))
+                rows.append((t1 @ Jd, 0.0, 3, k, -2))
+                rows.append((t2 @ Jd, 0.0, 3, k, -2))
     for j in range(len(m.joint_body)):
         e = np.zeros(n)
         if s.q[j] < m.joint_lo[j]:
@@ -194,7 +255,8 @@ def constraint_rows(m, s, kin, prm):
 
 def pgs(A, rhs, rows, friction, iterations):
     """Projected Gauss-Seidel on  w = A lam + rhs,  0 <= lam  _|_  w >= 0  (unilateral rows) and
-    |lam_t| <= friction * lam_n (friction rows), natural row order, zero warm start."""
+    |lam_t| <= mu * lam_n (friction rows; mu = friction[0] for ground rows (kind 1/2), friction[1] for
+    self-contact rows (kind 3)), natural row order, zero warm start."""
     lam = np.zeros(len(rows))
     for _ in range(iterations):
         for r, (_, _, kind, partner, _) in enumerate(rows):
@@ -204,7 +266,7 @@ def pgs(A, rhs, rows, friction, iterations):
             if kind == 0:
                 lam[r] = max(0.0, x)
             else:
-                lim = friction * lam[partner]
+                lim = (friction[1] if kind == 3 else friction[0]) * lam[partner]
                 lam[r] = min(lim, max(-lim, x))
     return lam
 
@@ -226,7 +288,7 @@ def substep(m, s, tau_motor, prm):
         MinvJT = solve(J.T)
         A = J @ MinvJT
         rhs = J @ u_star - np.array([r[1] for r in rows])
-        lam = pgs(A, rhs, rows, prm.friction, prm.iterations)
+        lam = pgs(A, rhs, rows, (prm.friction, prm.self_friction), prm.iterations)
         u_star = u_star + MinvJT @ lam
         touching = {r[4] for r in rows if r[2] == 0 and r[4] >= 0}
     s.v, s.w, s.qd = u_star[0:3].copy(), u_star[3:6].copy(), u_star[6:].copy()

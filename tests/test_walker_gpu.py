@@ -25,10 +25,12 @@ def _make(cls_name, models, n, task_ids=None, **kw):
 
 def _oracle_env(m, ant=False, **kw):
     if ant:
-        return abd.WalkerEnv(m, prm=abd.Params(friction=0.8 * float(m.geom_friction), power=2.5),
+        return abd.WalkerEnv(m, prm=abd.Params(friction=0.8 * float(m.geom_friction), power=2.5,
+                                               self_friction=float(m.geom_friction) ** 2),
                              motor_power=np.full(len(m.joint_lo), 100.0), alive_z=0.26, alive_bonus=1.0,
                              initial_z=float(m.body_pos[0][2]), **kw)
-    return abd.WalkerEnv(m, prm=abd.Params(friction=0.8 * float(m.geom_friction)), **kw)
+    return abd.WalkerEnv(m, prm=abd.Params(friction=0.8 * float(m.geom_friction),
+                                           self_friction=float(m.geom_friction) ** 2), **kw)
 
 
 @pytest.mark.parametrize("mapping", ["wave", "lane"])
@@ -139,3 +141,46 @@ def test_full_size_properties_8192():
     for k in ("pos", "q", "qd", "vel"):
         assert torch.equal(before[k][:, keep], after[k][:, keep]), k
     assert (after["steps"][mask.cuda()] == 0).all() and (after["qd"][:, mask.cuda()] == 0).all()
+
+
+@pytest.mark.parametrize("mapping", ["wave", "lane"])
+def test_self_collision_matches_oracle(mapping):
+    """Legs swung into each other (and an arm into the torso side) in mid-air: the capsule-capsule
+    self-contact rows (robot_bases.py:119 flags) must act exactly like the oracle's — and switching
+    them off must change the outcome (the scenario really exercises them)."""
+    m = MODELS["humanoid"]
+    n = 4
+    outcomes = {}
+    for self_on in (True, False):
+        env = _make("MetaHumanoidEnv", [m], n, mapping=mapping, self_collision=self_on)
+        env.reset(joint_noise=np.zeros((n, 17)))
+        sd = env.state_dict()
+        sd["pos"][2] += 5.0
+        qd = np.zeros((17, n))
+        for e in range(n):
+            qd[m.joint_names.index("right_hip_x"), e] = 1.5 + 0.5 * e
+            qd[m.joint_names.index("left_hip_x"), e] = 1.5 + 0.5 * e
+            qd[m.joint_names.index("right_shoulder1"), e] = 1.0 * e
+        sd["qd"] = torch.as_tensor(qd)
+        env.load_state_dict(sd)
+        oenvs = []
+        for e in range(n):
+            oe = _oracle_env(m)
+            oe.prm.self_collision = self_on
+            oe.reset(np.zeros(17))
+            oe.s.pos[2] += 5.0
+            oe.s.qd = qd[:, e].copy()
+            oenvs.append(oe)
+        saw_self = False
+        for t in range(6):
+            env.step(torch.zeros(n, 17))
+            q = env.q.cpu().numpy().T
+            for e in range(n):
+                for _ in range(4):
+                    kin = abd.kinematics(m, oenvs[e].s)
+                    saw_self = saw_self or any(r[4] == -2 for r in abd.constraint_rows(m, oenvs[e].s, kin, oenvs[e].prm))
+                    abd.substep(m, oenvs[e].s, np.zeros(17), oenvs[e].prm)
+                assert np.allclose(q[e], oenvs[e].s.q, rtol=0, atol=1e-7), (self_on, t, e, np.abs(q[e] - oenvs[e].s.q).max())
+        outcomes[self_on] = env.q.cpu().numpy().copy()
+        assert saw_self == self_on
+    assert np.abs(outcomes[True] - outcomes[False]).max() > 1e-2
