@@ -589,7 +589,7 @@ struct WaveLds {   // pointers into the env's LDS slab
     double *J, *Wm, *bias, *diag, *lam;
     double *cx;                              // per contact: ground (x, y, depth) or self (point xc, normal)
     double *sc;                              // sin / cos of every joint angle
-    int *mask, *depth, *jstart, *jcount, *poff, *kind, *partner, *csphere, *misc;
+    int *mask, *depth, *jstart, *jcount, *poff, *kind, *partner, *csphere, *misc, *bod;
 };
 
 __host__ __device__ inline size_t wave_lds_doubles(int nb, int nj, int maxr) {
@@ -598,7 +598,7 @@ __host__ __device__ inline size_t wave_lds_doubles(int nb, int nj, int maxr) {
            3 * (size_t)n + 3 * (size_t)nj + 18 + 2 * (size_t)maxr * n + 3 * (size_t)maxr + 6 * (size_t)W_MAXC +
            2 * (size_t)nj;
 }
-__host__ __device__ inline size_t wave_lds_ints(int nb, int maxr) { return 5 * (size_t)nb + 2 * (size_t)maxr + 2 * W_MAXC + 8; }
+__host__ __device__ inline size_t wave_lds_ints(int nb, int maxr) { return 5 * (size_t)nb + 2 * (size_t)maxr + 2 * W_MAXC + 8 + 64; }
 
 __device__ __forceinline__ WaveLds carve(unsigned char *smem, int nb, int nj, int maxr) {
     const int n = 6 + nj;
@@ -616,7 +616,7 @@ __device__ __forceinline__ WaveLds carve(unsigned char *smem, int nb, int nj, in
     L.sc = d; d += 2 * nj;
     int *i = reinterpret_cast<int *>(d);
     L.mask = i; i += nb; L.depth = i; i += nb; L.jstart = i; i += nb; L.jcount = i; i += nb; L.poff = i; i += nb;
-    L.kind = i; i += maxr; L.partner = i; i += maxr; L.csphere = i; i += 2 * W_MAXC; L.misc = i;
+    L.kind = i; i += maxr; L.partner = i; i += maxr; L.csphere = i; i += 2 * W_MAXC; L.misc = i; i += 8; L.bod = i;
     return L;
 }
 
@@ -742,6 +742,12 @@ __device__ void wave_substep(const mg_walker_topology &tp, const ModelRef &m, co
         for (int b = 0; b < nb; ++b) { L.poff[b] = off; off += 6 + __popc((unsigned)L.mask[b]); }
         L.misc[1] = off;
     }
+    if (lane < n) {   // bodies each dof moves, as a bitmask: M[d][e] only sums bodies in bod[d] & bod[e]
+        unsigned bm = 0;
+        for (int b = 0; b < nb; ++b)
+            if (lane < 6 || (((unsigned)L.mask[b] >> (lane - 6)) & 1u)) bm |= 1u << b;
+        L.bod[lane] = (int)bm;
+    }
     WSYNC();
     double *pairs = L.J;          // [n_pairs][6] = (jv, jw)
     for (int b = 0; b < nb; ++b) {
@@ -769,10 +775,9 @@ __device__ void wave_substep(const mg_walker_topology &tp, const ModelRef &m, co
         const int d = t / n, e = t % n;
         if (e > d) continue;
         double acc = 0.0;
-        for (int b = 0; b < nb; ++b) {
+        for (unsigned bm = (unsigned)L.bod[d] & (unsigned)L.bod[e]; bm != 0; bm &= bm - 1) {
+            const int b = __ffs(bm) - 1;
             const unsigned mk = (unsigned)L.mask[b];
-            if (d >= 6 && !((mk >> (d - 6)) & 1u)) continue;
-            if (e >= 6 && !((mk >> (e - 6)) & 1u)) continue;
             const double *pd = pairs + (size_t)pair_index(b, mk, d) * 6, *pe = pairs + (size_t)pair_index(b, mk, e) * 6;
             const V3 jv{pd[0], pd[1], pd[2]}, jw{pd[3], pd[4], pd[5]}, ev{pe[0], pe[1], pe[2]}, ew{pe[3], pe[4], pe[5]};
             acc += dot(m.body_mass[b] * jv, ev) + dot(mulMv(L.Iw + 9 * b, jw), ew);
@@ -783,9 +788,9 @@ __device__ void wave_substep(const mg_walker_topology &tp, const ModelRef &m, co
     if (lane < n) {
         const int d = lane;
         double acc = 0.0;
-        for (int b = 0; b < nb; ++b) {
+        for (unsigned bm = (unsigned)L.bod[d]; bm != 0; bm &= bm - 1) {
+            const int b = __ffs(bm) - 1;
             const unsigned mk = (unsigned)L.mask[b];
-            if (d >= 6 && !((mk >> (d - 6)) & 1u)) continue;
             const double *pd = pairs + (size_t)pair_index(b, mk, d) * 6;
             acc += dot(V3{pd[0], pd[1], pd[2]}, ldv(L.F, b)) + dot(V3{pd[3], pd[4], pd[5]}, ldv(L.Nn, b));
         }
