@@ -329,7 +329,7 @@ __device__ __forceinline__ void transition_continuous(const Task &t, double col_
 // ------------------------------------------------------------------------------------------------
 
 struct ViewK {
-    int H, V, TS, t_max;
+    int H, V, TS, t_max, obs_u8;
     double max_vision, max_vision_lo, l_focal, text_size, inv_text_size, half_h, half_v, pixel_size;
     double col_dist;
     int text_size_pow2;
@@ -612,7 +612,7 @@ __global__ __launch_bounds__(MZ_BLOCK) void maze3d_step_kernel(mg_maze_tasks T, 
                                                                int task_type, int max_steps, int continuous,
                                                                int pre_moved, int auto_reset, int n_envs,
                                                                const void *action,
-                                                               int32_t *obs, float *reward, double *reward64,
+                                                               void *obs, float *reward, double *reward64,
                                                                uint8_t *done) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int e = blockIdx.x;
@@ -704,7 +704,8 @@ __global__ __launch_bounds__(MZ_BLOCK) void maze3d_step_kernel(mg_maze_tasks T, 
     }
 
     uint2 *entries = entries_all + (size_t)wave * SLAB * vk.t_max;
-    int32_t *img = obs + (size_t)e * vk.H * vk.V * 3;
+    int32_t *img = static_cast<int32_t *>(obs) + (size_t)e * vk.H * vk.V * 3;
+    uint8_t *img8 = static_cast<uint8_t *>(obs) + (size_t)e * vk.H * vk.V * 3;
     // columns are dealt to the 4 waves in equal slabs (<= 64 each) so narrow images keep all waves busy
     const int slab = min(SLAB, (vk.H + MZ_WAVES - 1) / MZ_WAVES);
     for (int cbase = wave * slab; cbase < vk.H; cbase += MZ_WAVES * slab) {
@@ -728,8 +729,15 @@ __global__ __launch_bounds__(MZ_BLOCK) void maze3d_step_kernel(mg_maze_tasks T, 
                 const int col = cbase + k;
                 if (in_lb_y && col >= lb_x0 && col < lb_x1) { R = 255; G = 0; B = 0; }
                 if (row_ok) {
-                    int3s px{R, G, B};
-                    *reinterpret_cast<int3s *>(img + ((size_t)col * vk.V + d_v) * 3) = px;
+                    if (vk.obs_u8) {      // non-parity fast path: saturate to a byte
+                        uint8_t *q = img8 + ((size_t)col * vk.V + d_v) * 3;
+                        q[0] = (uint8_t)min(max(R, 0), 255);
+                        q[1] = (uint8_t)min(max(G, 0), 255);
+                        q[2] = (uint8_t)min(max(B, 0), 255);
+                    } else {
+                        int3s px{R, G, B};
+                        *reinterpret_cast<int3s *>(img + ((size_t)col * vk.V + d_v) * 3) = px;
+                    }
                 }
             }
         }
@@ -843,7 +851,7 @@ extern "C" int mg_maze2d_step(const mg_maze_tasks *T, int32_t task_type, int32_t
 
 extern "C" int mg_maze3d_step(const mg_maze_tasks *T, const mg_maze_view *view, int32_t task_type, int32_t max_steps,
                               int32_t continuous, int32_t auto_reset, int32_t n, const mg_maze_state *st,
-                              const void *action, int32_t *obs, float *reward, double *reward64, uint8_t *done,
+                              const void *action, void *obs, float *reward, double *reward64, uint8_t *done,
                               void *stream) {
     MG_REQUIRE_PTR(T);
     MG_REQUIRE_PTR(view);
@@ -865,6 +873,7 @@ extern "C" int mg_maze3d_step(const mg_maze_tasks *T, const mg_maze_view *view, 
     vk.H = view->res_h;
     vk.V = view->res_v;
     vk.TS = view->tex_size;
+    vk.obs_u8 = view->obs_format == 1;
     vk.max_vision = view->max_vision;
     vk.max_vision_lo = view->max_vision * (1.0 - 1.0e-12);   // see pixel_pass: below this, fog is exactly 0
     vk.l_focal = view->l_focal;

@@ -188,14 +188,18 @@ class MetaMaze2D(_MazeBatch):
 
 class _Maze3D(_MazeBatch):
     def __init__(self, num_envs, device, resolution, max_steps, task_type, auto_reset, collision_dist=0.20,
-                 max_vision_range=12.0, fol_angle=0.6 * PI):
+                 max_vision_range=12.0, fol_angle=0.6 * PI, obs_dtype=torch.int32):
         super().__init__(num_envs, device, max_steps, task_type, auto_reset)
         self.resolution_horizon, self.resolution_vertical = int(resolution[0]), int(resolution[1])
         self.collision_dist, self.max_vision_range, self.fol_angle = collision_dist, max_vision_range, fol_angle
         H, V = self.resolution_horizon, self.resolution_vertical
         self.observation_space = Box(low=np.zeros((H, V, 3), np.float32), high=np.full((H, V, 3), 256, np.float32),
                                      dtype=np.float32)      # declared like the reference (maze_env.py:38-40)
-        self._obs = torch.zeros(self.num_envs, H, V, 3, dtype=torch.int32, device=self.device)
+        # int32 is the reference's frame dtype (values exceed 255: ray_caster_utils.py light > 1);
+        # torch.uint8 selects the saturating fast path (not reference-exact where the reference exceeds 255)
+        assert obs_dtype in (torch.int32, torch.uint8)
+        self.obs_dtype = obs_dtype
+        self._obs = torch.zeros(self.num_envs, H, V, 3, dtype=obs_dtype, device=self.device)
         self._tex_version = None
 
     def _on_set_task(self):
@@ -223,6 +227,7 @@ class _Maze3D(_MazeBatch):
         self._ceil_t = torch.from_numpy(ceil.view(np.int32).copy()).to(dev).contiguous()
         v.textures, v.ceil_texture = self._tex_t.data_ptr(), self._ceil_t.data_ptr()
         v.n_textures, v.tex_size = tex.shape[0], tex.shape[1]
+        v.obs_format = 1 if self.obs_dtype == torch.uint8 else 0
         # DDA_2D (ray_caster_utils.py:31) stops once hit_dist >= max_vision: a ray crosses at most
         # floor(max_vision / cell_size) + 1 cell boundaries per axis plus the final overshoot, so it can
         # record at most 2*floor(mv/cs) + 4 translucent cells (incl. the start cell) whatever n is
@@ -245,8 +250,8 @@ class MetaMazeDiscrete3D(_Maze3D):
     """maze_env.py:16-83. action int in {0..3}: turn left / right, step back / forward."""
 
     def __init__(self, num_envs=1, device="cuda", enable_render=False, render_scale=480, resolution=(320, 320),
-                 max_steps=5000, task_type="SURVIVAL", auto_reset=False):
-        super().__init__(num_envs, device, resolution, max_steps, task_type, auto_reset)
+                 max_steps=5000, task_type="SURVIVAL", auto_reset=False, obs_dtype=torch.int32):
+        super().__init__(num_envs, device, resolution, max_steps, task_type, auto_reset, obs_dtype=obs_dtype)
         self.action_space = Discrete(4)
 
     def _observe(self):
@@ -265,8 +270,8 @@ class MetaMazeContinuous3D(_Maze3D):
     """maze_env.py:85-153. action float32 [N,2] = (turn rate, walk speed), each clipped to [-1,1]."""
 
     def __init__(self, num_envs=1, device="cuda", enable_render=False, render_scale=480, resolution=(320, 320),
-                 max_steps=5000, task_type="SURVIVAL", auto_reset=False):
-        super().__init__(num_envs, device, resolution, max_steps, task_type, auto_reset)
+                 max_steps=5000, task_type="SURVIVAL", auto_reset=False, obs_dtype=torch.int32):
+        super().__init__(num_envs, device, resolution, max_steps, task_type, auto_reset, obs_dtype=obs_dtype)
         self.action_space = Box(low=np.array([-1.0, -1.0]), high=np.array([1.0, 1.0]), dtype=np.float32)
 
     def _observe(self):

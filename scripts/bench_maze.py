@@ -65,6 +65,18 @@ def main():
                       flush=True)
                 del env
                 torch.cuda.empty_cache()
+    for res in args.res:      # the uint8 fast path (non-parity): same renderer, 3 bytes per pixel
+        if n * res * res * 3 > 40e9:
+            continue
+        env = metagym_amd.make("meta-maze-discrete-3D-v0", num_envs=n, device=dev, max_steps=200,
+                               resolution=(res, res), task_type="SURVIVAL", auto_reset=True, obs_dtype=torch.uint8)
+        env.set_task(tasks9)
+        env.reset()
+        s = timed(env, lambda: torch.randint(0, 4, (n,), device=dev, dtype=torch.int32), args.steps, args.warmup)
+        print(json.dumps({"workload": "meta-maze-discrete-3D-v0 9x9 SURVIVAL %dx%d uint8 fast path, %d envs" % (res, res, n),
+                          "env_steps_per_s": n / s, "avg_launch_ms": s * 1e3}), flush=True)
+        del env
+        torch.cuda.empty_cache()
     if not args.skip2d:
         tasks15 = [MazeTaskSampler(n=15, allow_loops=True, crowd_ratio=0.35, step_reward=-0.01, goal_reward=1.0,
                                    food_density=0.02, food_interval=20, seed=s) for s in range(64)]

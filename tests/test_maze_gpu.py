@@ -297,3 +297,24 @@ def test_maze3d_larger_mazes_match_oracle(n, res, cell):
         for e in range(t % 3, 12, 3):
             ref = mo.observe_3d(otasks[ids[e]], tt, view, states[e], 0)
             assert np.array_equal(ob[e], ref), (t, e, int((ob[e] != ref).sum()))
+
+
+def test_maze3d_uint8_fast_path_is_the_clamped_reference_frame():
+    """obs_dtype=torch.uint8 (non-parity fast path): every byte equals min(int32 frame, 255)."""
+    import metagym_amd
+    from metagym_amd.metamaze import MazeTaskSampler
+    tasks = [MazeTaskSampler(n=9, allow_loops=False, food_density=0.08, food_interval=4, seed=70 + s) for s in range(4)]
+    mk = lambda dt: metagym_amd.make("meta-maze-discrete-3D-v0", num_envs=40, device="cuda:0", max_steps=30,
+                                     resolution=(48, 64), task_type="SURVIVAL", obs_dtype=dt)
+    a, b = mk(torch.int32), mk(torch.uint8)
+    a.set_task(tasks)
+    b.set_task(tasks)
+    oa, ob = a.reset(), b.reset()
+    assert ob.dtype == torch.uint8 and torch.equal(oa.clamp(0, 255).to(torch.uint8), ob)
+    g = torch.Generator().manual_seed(1)
+    for _ in range(6):
+        act = torch.randint(0, 4, (40,), generator=g, dtype=torch.int32)
+        oa, ra, da, _ = a.step(act)
+        ob, rb, db, _ = b.step(act)
+        assert torch.equal(oa.clamp(0, 255).to(torch.uint8), ob) and torch.equal(ra, rb) and torch.equal(da, db)
+    assert int(oa.max()) > 255          # the int32 frames really do exceed a byte
