@@ -330,7 +330,7 @@ __device__ __forceinline__ void transition_continuous(const Task &t, double col_
 
 struct ViewK {
     int H, V, TS, t_max, obs_u8;
-    double max_vision, max_vision_lo, l_focal, text_size, inv_text_size, half_h, half_v, pixel_size;
+    double max_vision, max_vision_lo, inv_max_vision, l_focal, text_size, inv_text_size, half_h, half_v, pixel_size;
     double col_dist;
     int text_size_pow2;
     const double *col_cos, *col_sin;
@@ -344,6 +344,10 @@ __device__ __forceinline__ int to_int_clamped(double x, int lo, int hi) {
     if (x >= (double)hi + 1.0) return hi + 1;
     return (int)x;
 }
+// int(x) for a cell index: v_cvt_i32_f64 truncates toward zero and SATURATES out-of-range inputs (NaN -> 0),
+// so one instruction gives python's int() wherever the result can matter (|x| < 2^31) and a harmless
+// out-of-grid value elsewhere; `(unsigned)i < n` then tests 0 <= i < n with one compare.
+__device__ __forceinline__ int cell_index(double x) { return __double2int_rz(x); }
 
 struct EnvShared {   // one per workgroup, LDS
     Agent a;
@@ -354,14 +358,36 @@ struct EnvShared {   // one per workgroup, LDS
 
 // Column record produced by pass A. Each lane keeps the record of ITS column in registers; pass B
 // broadcasts column k's record to the whole wave with v_readlane (SGPR operands) — no LDS round trip.
+// a / b, correctly rounded, from rb = RN(1/b) computed once (Markstein 1990: q = RN(a*rb), exact residual
+// r = a - b*q by FMA, result RN(q + r*rb) == RN(a/b) for normal-range operands whose divisor's significand
+// is not all ones — here b is a float32-valued cos_hp or the constant max_vision). Bit-identical to the
+// IEEE division the reference performs, at 3 VALU ops instead of ~28 per pixel.
+__device__ __forceinline__ double div_by(double a, double b, double rb) {
+    const double q = a * rb;
+    const double r = fma(-b, q, a);
+    return fma(r, rb, q);
+}
+
+// texel channels of a packed r | g<<8 | b<<16 word as doubles: v_cvt_f32_ubyteN + v_cvt_f64_f32 (exact)
+__device__ __forceinline__ double tex_r(uint32_t tx) {
+    float f; asm("v_cvt_f32_ubyte0 %0, %1" : "=v"(f) : "v"(tx)); return (double)f;
+}
+__device__ __forceinline__ double tex_g(uint32_t tx) {
+    float f; asm("v_cvt_f32_ubyte1 %0, %1" : "=v"(f) : "v"(tx)); return (double)f;
+}
+__device__ __forceinline__ double tex_b(uint32_t tx) {
+    float f; asm("v_cvt_f32_ubyte2 %0, %1" : "=v"(f) : "v"(tx)); return (double)f;
+}
+
 struct ColRec {
     float cos_hp, cos_abs, sin_abs;
+    double rcos_hp;    // RN(1 / cos_hp)
     double w_oma;      // 1 - alpha of the wall hit
     double w_ratio;    // hit_dist * cos_hp / l_focal
-    double w_light;    // |cos| or |sin| (float32 value widened)
+    float w_light;     // |cos| or |sin| (a float32 value in the reference too)
     int w_tex;         // texel offset of (texture id, texture row)
-    int w_span;        // v_s | v_e << 16   (v_s >= v_e: no wall / beyond max_vision)
-    int n_tr;          // number of translucent records
+    int w_span;        // v_s | v_e << 12 | n_tr << 24   (v_s >= v_e: no wall / beyond max_vision;
+                       // n_tr = number of translucent records of the column)
 };
 
 __device__ __forceinline__ float bcast(float v, int lane) {
@@ -375,8 +401,9 @@ __device__ __forceinline__ double bcast(double v, int lane) {
 __device__ __forceinline__ ColRec bcast(const ColRec &r, int lane) {
     ColRec o;
     o.cos_hp = bcast(r.cos_hp, lane); o.cos_abs = bcast(r.cos_abs, lane); o.sin_abs = bcast(r.sin_abs, lane);
+    o.rcos_hp = bcast(r.rcos_hp, lane);
     o.w_oma = bcast(r.w_oma, lane); o.w_ratio = bcast(r.w_ratio, lane); o.w_light = bcast(r.w_light, lane);
-    o.w_tex = bcast(r.w_tex, lane); o.w_span = bcast(r.w_span, lane); o.n_tr = bcast(r.n_tr, lane);
+    o.w_tex = bcast(r.w_tex, lane); o.w_span = bcast(r.w_span, lane);
     return o;
 }
 
@@ -437,7 +464,8 @@ __device__ ColRec column_pass(const ViewK &vk, const Task &t, const EnvShared &e
     }
 
     int span = 0;   // empty
-    double oma = 0.0, ratio = 1.0, light = 0.0;
+    double oma = 0.0, ratio = 1.0;
+    float light = 0.0f;
     int texoff = 0;
     const int ci = hi < 0 ? hi + n : hi, cj = hj < 0 ? hj + n : hj;
     if (!(hit_dist > vk.max_vision) && ci >= 0 && ci < n && cj >= 0 && cj < n) {   // :160-161
@@ -450,14 +478,14 @@ __device__ ColRec column_pass(const ViewK &vk, const Task &t, const EnvShared &e
         double local_h = side == 0 ? hpy : hpx;                                    // :166-173
         local_h = cs_pow2 ? local_h * inv_cs : local_h / cs;
         local_h -= floor(local_h);
-        light = (double)fabsf(side == 0 ? cos_abs : sin_abs);
+        light = fabsf(side == 0 ? cos_abs : sin_abs);
         ratio = hit_dist * (double)cos_hp / vk.l_focal;                            // :175
         const double top_v = (ceil_h - vh) / ratio, bot_v = vh / ratio;
         int v_s = to_int_clamped((vk.half_v - top_v) / vk.pixel_size, 0, vk.V);
         int v_e = to_int_clamped((vk.half_v + bot_v) / vk.pixel_size, -1, vk.V - 1);
         if (v_s < 0) v_s = 0;
         if (v_e > vk.V) v_e = vk.V;
-        span = v_s | (v_e << 16);
+        span = v_s | (v_e << 12);
         double d_i = vk.text_size_pow2 ? local_h * vk.inv_text_size : local_h / vk.text_size;   // :184-188
         d_i -= floor(d_i);
         const int ti = (int)(vk.TS * d_i);
@@ -467,8 +495,9 @@ __device__ ColRec column_pass(const ViewK &vk, const Task &t, const EnvShared &e
     }
     ColRec rec;
     rec.cos_hp = cos_hp; rec.cos_abs = cos_abs; rec.sin_abs = sin_abs;
+    rec.rcos_hp = 1.0 / (double)cos_hp;
     rec.w_oma = oma; rec.w_ratio = ratio; rec.w_light = light;
-    rec.w_tex = texoff; rec.w_span = span; rec.n_tr = n_tr;
+    rec.w_tex = texoff; rec.w_span = span | (n_tr << 24);
     return rec;
 }
 
@@ -510,18 +539,18 @@ __device__ __forceinline__ void pixel_pass(const ViewK &vk, const Task &t, const
     R = G = B = 0;
     bool tflag = false;
     const int span = wc.w_span;
-    const bool in_wall = d_v >= (span & 0xffff) && d_v < (span >> 16);
-    const int n_tr = wc.n_tr;
+    const bool in_wall = d_v >= (span & 0xfff) && d_v < ((span >> 12) & 0xfff);
+    const int n_tr = (int)((unsigned)span >> 24);
     // A wall pixel overwrites whatever the floor / ceiling cast painted; the cast's only surviving
     // side effect is the transparent_array flag, which is read by the overlays alone. So the cast
     // can be skipped for wall pixels of columns without overlay records (bit-identical).
     if (rk.kind != 0 && !(in_wall && n_tr == 0)) {
-        const double eff = rk.distance / (double)wc.cos_hp;
+        const double eff = div_by(rk.distance, (double)wc.cos_hp, wc.rcos_hp);
         // fog a = clamp(2*eff/max_vision - 1, 0, 1): when 2*eff is clearly below max_vision the
         // rounded quotient cannot exceed 1, so a == 0 without performing the division
         double a = 0.0;
         if (2.0 * eff > vk.max_vision_lo) {
-            a = 2.0 * eff / vk.max_vision - 1.0;
+            a = div_by(2.0 * eff, vk.max_vision, vk.inv_max_vision) - 1.0;
             a = a > 0.0 ? a : 0.0;
             a = a < 1.0 ? a : 1.0;
         }
@@ -529,8 +558,8 @@ __device__ __forceinline__ void pixel_pass(const ViewK &vk, const Task &t, const
         const double hit_y = eff * (double)wc.sin_abs + es.pos[1];
         const double fi = cs_pow2 ? hit_x * inv_cs : hit_x / cs;
         const double fj = cs_pow2 ? hit_y * inv_cs : hit_y / cs;
-        const int i = to_int_clamped(fi, -2, n + 1), j = to_int_clamped(fj, -2, n + 1);
-        const bool inside = i < n && i >= 0 && j < n && j >= 0;
+        const int i = cell_index(fi), j = cell_index(fj);
+        const bool inside = (unsigned)i < (unsigned)n && (unsigned)j < (unsigned)n;
         if (rk.kind == 1) {
             if (inside) {
                 const double alpha = a * rk.light;
@@ -541,12 +570,13 @@ __device__ __forceinline__ void pixel_pass(const ViewK &vk, const Task &t, const
                 d_j -= floor(d_j);
                 d_i *= TS;
                 d_j *= TS;
-                const uint32_t tx = vk.tex[((int)texts[i * n + j] * TS + (int)d_i) * TS + (int)d_j];
+                // 24-bit multiplies are full rate (v_mad_u32_u24); texture rows and cells are far below 2^24
+                const uint32_t tx = vk.tex[__umul24(__umul24((uint32_t)texts[__umul24(i, n) + j], TS) + (uint32_t)(int)d_i, TS) + (uint32_t)(int)d_j];
                 const double oma = 1.0 - alpha;
-                R = (int)(rk.light * (oma * (double)(tx & 255u)));
-                G = (int)(rk.light * (oma * (double)((tx >> 8) & 255u)));
-                B = (int)(rk.light * (oma * (double)((tx >> 16) & 255u)));
-                const double tr = transp[i * n + j];
+                R = (int)(rk.light * (oma * tex_r(tx)));
+                G = (int)(rk.light * (oma * tex_g(tx)));
+                B = (int)(rk.light * (oma * tex_b(tx)));
+                const double tr = transp[__umul24(i, n) + j];
                 if (tr > 0.01) {
                     const double tf = tr * 0.50 + 0.10, om = 1.0 - tf;
                     R = (int)(om * (double)R);
@@ -561,13 +591,13 @@ __device__ __forceinline__ void pixel_pass(const ViewK &vk, const Task &t, const
             double d_i = gi - floor(gi), d_j = gj - floor(gj);
             d_i *= TS;
             d_j *= TS;
-            const uint32_t tx = vk.ceil_tex[(int)d_i * TS + (int)d_j];
+            const uint32_t tx = vk.ceil_tex[__umul24((uint32_t)(int)d_i, TS) + (uint32_t)(int)d_j];
             const double oma = 1.0 - a;
-            R = (int)(rk.light * (oma * (double)(tx & 255u)));
-            G = (int)(rk.light * (oma * (double)((tx >> 8) & 255u)));
-            B = (int)(rk.light * (oma * (double)((tx >> 16) & 255u)));
+            R = (int)(rk.light * (oma * tex_r(tx)));
+            G = (int)(rk.light * (oma * tex_g(tx)));
+            B = (int)(rk.light * (oma * tex_b(tx)));
             if (inside) {
-                const double tr = transp[i * n + j];
+                const double tr = transp[__umul24(i, n) + j];
                 if (tr > 0) {
                     const double tf = tr * 0.50 + 0.10, om = 1.0 - tf;
                     R = (int)(om * (double)R);
@@ -582,11 +612,11 @@ __device__ __forceinline__ void pixel_pass(const ViewK &vk, const Task &t, const
         const double local_v = rk.ys * wc.w_ratio + t.agent_h;
         double d_j = vk.text_size_pow2 ? local_v * vk.inv_text_size : local_v / vk.text_size;
         d_j -= floor(d_j);
-        const uint32_t tx = vk.tex[wc.w_tex + (int)(TS * d_j)];
-        const double oma = wc.w_oma, light = wc.w_light;
-        R = (int)(light * (oma * (double)(tx & 255u)));
-        G = (int)(light * (oma * (double)((tx >> 8) & 255u)));
-        B = (int)(light * (oma * (double)((tx >> 16) & 255u)));
+        const uint32_t tx = vk.tex[(uint32_t)(wc.w_tex + (int)(TS * d_j))];
+        const double oma = wc.w_oma, light = (double)wc.w_light;
+        R = (int)(light * (oma * tex_r(tx)));
+        G = (int)(light * (oma * tex_g(tx)));
+        B = (int)(light * (oma * tex_b(tx)));
     }
     for (int q = 0; q < n_tr; ++q) {                                          // :194-205
         const uint2 en = entries[q * SLAB + k];
@@ -721,22 +751,28 @@ __global__ __launch_bounds__(MZ_BLOCK) void maze3d_step_kernel(mg_maze_tasks T, 
             const bool row_ok = d_v < vk.V;
             const RowK rk = row_constants(vk, t, row_ok ? d_v : 0);
             const bool in_lb_y = d_v >= lb_y0 && d_v < lb_y1;
-            for (int k = 0; k < ncols; ++k) {
+            // frame-relative 32-bit byte offset of this lane's pixel in column cbase, advanced by one
+            // column per k: scalar frame base + one VGPR add per store (frames are < 4 GiB)
+            const uint32_t px_bytes = vk.obs_u8 ? 3u : 12u;
+            uint32_t off = (uint32_t)(cbase * vk.V + d_v) * px_bytes;
+            const uint32_t col_bytes = (uint32_t)vk.V * px_bytes;
+            for (int k = 0; k < ncols; ++k, off += col_bytes) {
                 int R, G, B;
                 const ColRec wc = bcast(mine, k);
                 pixel_pass(vk, t, *es, rk, texts, transp, wc, entries, k, d_v, cs, inv_cs, cs_pow2, text_to_cell,
                            inv_ttc, ttc_pow2, R, G, B);
                 const int col = cbase + k;
                 if (in_lb_y && col >= lb_x0 && col < lb_x1) { R = 255; G = 0; B = 0; }
+                asm volatile("" : "+v"(off));      // keep the running offset (no per-pixel index multiply)
                 if (row_ok) {
                     if (vk.obs_u8) {      // non-parity fast path: saturate to a byte
-                        uint8_t *q = img8 + ((size_t)col * vk.V + d_v) * 3;
+                        uint8_t *q = img8 + off;
                         q[0] = (uint8_t)min(max(R, 0), 255);
                         q[1] = (uint8_t)min(max(G, 0), 255);
                         q[2] = (uint8_t)min(max(B, 0), 255);
                     } else {
                         int3s px{R, G, B};
-                        *reinterpret_cast<int3s *>(img + ((size_t)col * vk.V + d_v) * 3) = px;
+                        *reinterpret_cast<int3s *>(reinterpret_cast<char *>(img) + off) = px;
                     }
                 }
             }
@@ -863,7 +899,7 @@ extern "C" int mg_maze3d_step(const mg_maze_tasks *T, const mg_maze_view *view, 
     if (int rc = check_mstate(st, task_type)) return rc;
     if (continuous && (!st->ori || !st->loc)) return mg::set_error(MG_ERR_NULL_POINTER, "continuous needs ori / loc");
     if (!continuous && !st->ori_idx) return mg::set_error(MG_ERR_NULL_POINTER, "discrete needs ori_idx");
-    if (view->res_h <= 0 || view->res_v <= 0 || view->res_v > 32767 || view->res_h > 32767)
+    if (view->res_h <= 0 || view->res_v <= 0 || view->res_v > 4095 || view->res_h > 32767)
         return mg::set_error(MG_ERR_BAD_SIZE, "resolution %d x %d", view->res_h, view->res_v);
     if (!view->col_cos || !view->col_sin || !view->textures || !view->ceil_texture)
         return mg::set_error(MG_ERR_NULL_POINTER, "mg_maze_view has a NULL table");
@@ -875,6 +911,7 @@ extern "C" int mg_maze3d_step(const mg_maze_tasks *T, const mg_maze_view *view, 
     vk.TS = view->tex_size;
     vk.obs_u8 = view->obs_format == 1;
     vk.max_vision = view->max_vision;
+    vk.inv_max_vision = 1.0 / view->max_vision;
     vk.max_vision_lo = view->max_vision * (1.0 - 1.0e-12);   // see pixel_pass: below this, fog is exactly 0
     vk.l_focal = view->l_focal;
     vk.text_size = view->text_size;
