@@ -61,8 +61,8 @@ def _sim_state(sim):
     )
 
 
-def _quadrotor_traj(gym, seed, T, lo, hi, nt=1000):
-    env = gym.make("quadrotor-v0", task="hovering_control", nt=nt)
+def _quadrotor_traj(gym, seed, T, lo, hi, nt=1000, simulator_conf=None):
+    env = gym.make("quadrotor-v0", task="hovering_control", nt=nt, simulator_conf=simulator_conf)
     np.random.seed(seed)
     obs0 = env.reset()
     sim = env.simulator
@@ -259,6 +259,13 @@ def gen_quadrotor(gym):
         np.savez_compressed(path, **d)
         print("wrote", path, "steps", len(d["reward"]), "failed_at", int(d["failed_at"]),
               "first done", int(np.argmax(d["done"])) if d["done"].any() else -1)
+    # a non-stock simulator config (tests/golden/quadrotor_custom_config.json: off-diagonal inertia,
+    # shifted centre of gravity, asymmetric propellers, 3-term thrust polynomial, precision 0.002 ->
+    # 5 sub-steps) — pins the general (non-specialised) code path
+    d = _quadrotor_traj(gym, 11, 300, 0.2, 14.0, 1000, os.path.join(OUT, "quadrotor_custom_config.json"))
+    np.savez_compressed(os.path.join(OUT, "quadrotor_traj_custom_s11.npz"), **d)
+    print("wrote quadrotor_traj_custom_s11.npz steps", len(d["reward"]), "failed_at", int(d["failed_at"]),
+          "first done", int(np.argmax(d["done"])) if d["done"].any() else -1)
     d = _quadrotor_onestep(gym)
     path = os.path.join(OUT, "quadrotor_onestep.npz")
     np.savez_compressed(path, **d)

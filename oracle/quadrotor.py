@@ -71,6 +71,32 @@ def default_consts(nt=1000, task=TASK_HOVERING):
     return c
 
 
+def consts_from_config(cfg, nt=1000, task=TASK_HOVERING, dt=0.01):
+    """`_parse_cfg` (quadrotorsim.py:50-109) for a config dict with the config.json schema: scalars stay
+    python floats (doubles), the matrices are float32, inverse inertia = inv of the float32 matrix."""
+    c = default_consts(nt=nt, task=task)
+    c.precision, c.quality, c.dt = float(cfg["precision"]), float(cfg["quality"]), float(dt)
+    i = cfg["inertia"]
+    inertia = np.array([[i["xx"], i["xy"], i["xz"]], [i["xy"], i["yy"], i["yz"]], [i["xz"], i["yz"], i["zz"]]],
+                       np.float32)
+    c.inertia_inv[:] = inv3(inertia).reshape(9).tolist()
+    d = cfg["drag"]
+    for k in range(9):
+        c.drag_m[k] = c.drag_f[k] = 0.0
+    c.drag_m[0], c.drag_m[4], c.drag_m[8] = float(d["m_xx"]), float(d["m_yy"]), float(d["m_zz"])
+    c.drag_f[0], c.drag_f[4], c.drag_f[8] = float(d["f_xx"]), float(d["f_yy"]), float(d["f_zz"])
+    g = cfg["gravity_center"]
+    c.gravity_center[:] = [float(g["x"]), float(g["y"]), float(g["z"])]
+    t = cfg["thrust"]
+    c.ct0, c.ct1, c.ct2 = float(t["CT"][0]), float(t["CT"][1]), float(t["CT"][2])
+    c.mm, c.jm, c.phi, c.ra = float(t["Mm"]), float(t["Jm"]), float(t["phi"]), float(t["RA"])
+    f = cfg["fail"]
+    c.fail_velocity, c.fail_range, c.fail_w = float(f["velocity"]), float(f["range"]), float(f["w"])
+    c.prop_coord[:] = [float(cfg["propeller"][p][ax]) for p in range(4) for ax in "xyz"]
+    c.max_voltage, c.min_voltage = float(cfg["electric"]["max_voltage"]), float(cfg["electric"]["min_voltage"])
+    return c
+
+
 def make_states(pos, vel, omega, propw, R):
     """Arrays [n,3],[n,3],[n,3],[n,4],[n,9] -> ctypes array of State with Rinv = inv(R)."""
     n = len(pos)

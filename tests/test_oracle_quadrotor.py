@@ -1,6 +1,7 @@
 """Pin oracle/quadrotor_oracle.c against the golden vectors produced by the unmodified reference
 (oracle/gen_golden.py -> tests/golden/quadrotor_*.npz). CPU-only."""
 import glob
+import json
 import os
 
 import numpy as np
@@ -10,8 +11,16 @@ from oracle import quadrotor as qo
 from parity import REL_TOL, obs_rel_err, scalar_rel_err, vec_rel_err
 
 
-def _rollout(g):
-    c = qo.default_consts(nt=int(g["nt"]))
+def consts_for(path, g):
+    """Golden files named *_custom_* were generated with tests/golden/quadrotor_custom_config.json."""
+    if "_custom_" in os.path.basename(path):
+        with open(os.path.join(os.path.dirname(path), "quadrotor_custom_config.json")) as f:
+            return qo.consts_from_config(json.load(f), nt=int(g["nt"]))
+    return qo.default_consts(nt=int(g["nt"]))
+
+
+def _rollout(g, path=""):
+    c = consts_for(path, g)
     st = qo.make_states(g["init_pos"][None], g["init_vel"][None], g["init_omega"][None],
                         g["init_propw"][None], g["init_R"][None])
     ct = np.zeros(1, np.int32)
@@ -35,7 +44,7 @@ def _rollout(g):
 def test_oracle_matches_reference_rollout(path):
     g = np.load(path)
     assert str(g["numpy_version"]).startswith("2."), "goldens must come from the NEP-50 numpy"
-    rec, c, _ = _rollout(g)
+    rec, c, _ = _rollout(g, path)
     # reset observation
     st0 = qo.make_states(g["init_pos"][None], g["init_vel"][None], g["init_omega"][None],
                          g["init_propw"][None], g["init_R"][None])
