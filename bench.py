@@ -155,6 +155,30 @@ def secondary_workloads(dev):
         out["C1_maze2d_15x15_escape_1048576envs"] = {"env_steps_per_s": n2 / s, "ms_per_launch": s * 1e3}
         del env, acts
         torch.cuda.empty_cache()
+        # C1 as BASELINE.json states it: ONE 15x15 env. Pure launch latency — eager, and 100 steps
+        # captured as one hipGraph (the C ABI only enqueues kernels, so torch.cuda.graph can capture it).
+        env = metagym_amd.make("meta-maze-2D-v0", num_envs=1, device=dev, max_steps=10 ** 9, view_grid=1,
+                               task_type="ESCAPE")
+        env.set_task(tasks15[0])
+        env.reset()
+        a1 = torch.randint(0, 4, (100, 1), device=dev, dtype=torch.int32)
+        s_eager = _time_steps(lambda i: env.step(a1[i % 100]), 200, 20)
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):
+            env.step(a1[0])
+        torch.cuda.current_stream(dev).wait_stream(side)
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            for k in range(100):
+                env.step(a1[k])
+        s_graph = _time_steps(lambda i: graph.replay(), 20, 3) / 100
+        out["C1_maze2d_15x15_escape_1env"] = {"us_per_step_eager": s_eager * 1e6,
+                                              "us_per_step_hipgraph_100": s_graph * 1e6,
+                                              "env_steps_per_s_hipgraph": 1.0 / s_graph}
+        del env, graph
+        torch.cuda.empty_cache()
     except Exception as e:  # secondary numbers must never break the headline line
         out["maze_error"] = repr(e)
     try:
