@@ -242,6 +242,29 @@ int mg_maze_view_tables(int32_t res_h, double tan_half_fov, double l_focal, doub
 int mg_maze_reset(const mg_maze_tasks *tasks, int32_t task_type, int32_t n_envs, const mg_maze_state *state,
                   const uint8_t *mask, void *stream);
 
+/* On-device task generation — MazeTaskManager.sample_task (maze_task.py:41-190) for a whole task
+ * table. Row t of every table array receives, bit for bit, the TaskConfig the reference returns after
+ *     random.seed(seed_t); numpy.random.seed(seed_t); sample_task(n, allow_loops, ...)
+ * (both MT19937 streams and numpy's pairwise float64 sum are reproduced on the device; the CPU
+ * restatement is oracle/maze_sampler.py). seed_t = seeds[t] (DEVICE array) or seed_base + t when
+ * seeds is NULL; seeds are 32-bit like numpy.random.seed's integer argument.
+ * The outputs are the arrays an mg_maze_tasks table points at ([T][2], [T][n*n], [T][8]). */
+typedef struct mg_maze_sample_params {
+    int32_t n;               /* odd, 7..63 */
+    int32_t allow_loops;
+    int32_t n_texts;         /* MazeTaskManager.n_texts: ground + wall textures (7 for the shipped set) */
+    int32_t food_interval;
+    int32_t has_goal_reward; /* 0: goal_reward=None -> -sqrt(n)*n*step_reward (maze_task.py:163) */
+    double cell_size, wall_height, agent_height;
+    double step_reward, goal_reward, food_reward;
+    double initial_life, max_life;
+    double food_density, crowd_ratio;
+} mg_maze_sample_params;
+
+int mg_maze_sample_tasks(const mg_maze_sample_params *params, int32_t n_tasks, uint32_t seed_base,
+                         const uint32_t *seeds, int32_t *start, int32_t *goal, int8_t *walls, uint8_t *texts,
+                         double *food_rewards, int32_t *food_interval, double *scalars, void *stream);
+
 /* MetaMaze2D.step (maze_env.py:189-204 -> maze_2d.py:21-34 + maze_base.py:65-95) and
  * update_observation (maze_2d.py:89-121).
  *   action i32 [N] in 0..3 (DISCRETE_ACTIONS maze_env.py:14); NULL = observe only (reset obs)

@@ -55,6 +55,16 @@ class MazeTasks(C.Structure):
                 ("food_interval", C.c_void_p), ("scalars", C.c_void_p)]
 
 
+class MazeSampleParams(C.Structure):
+    """mg_maze_sample_params"""
+    _fields_ = [("n", C.c_int32), ("allow_loops", C.c_int32), ("n_texts", C.c_int32), ("food_interval", C.c_int32),
+                ("has_goal_reward", C.c_int32),
+                ("cell_size", C.c_double), ("wall_height", C.c_double), ("agent_height", C.c_double),
+                ("step_reward", C.c_double), ("goal_reward", C.c_double), ("food_reward", C.c_double),
+                ("initial_life", C.c_double), ("max_life", C.c_double),
+                ("food_density", C.c_double), ("crowd_ratio", C.c_double)]
+
+
 class MazeState(C.Structure):
     """mg_maze_state (device pointers)"""
     _fields_ = [("task_id", C.c_void_p), ("grid", C.c_void_p), ("steps", C.c_void_p), ("ori_idx", C.c_void_p),
@@ -127,6 +137,8 @@ SIGNATURES = {
     "mg_quadrotor_rollout": (C.c_int, [C.POINTER(QuadrotorConfig), C.c_int32, C.c_int32,
                                        C.POINTER(QuadrotorState), _P, _P, _P, _P, _P, _P, _P]),
     "mg_maze_view_tables": (C.c_int, [C.c_int32, C.c_double, C.c_double, _P, _P]),
+    "mg_maze_sample_tasks": (C.c_int, [C.POINTER(MazeSampleParams), C.c_int32, C.c_uint32, _P, _P, _P, _P, _P, _P,
+                                       _P, _P, _P]),
     "mg_maze_reset": (C.c_int, [C.POINTER(MazeTasks), C.c_int32, C.c_int32, C.POINTER(MazeState), _P, _P]),
     "mg_maze2d_step": (C.c_int, [C.POINTER(MazeTasks), C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                  C.POINTER(MazeState), _P, _P, _P, _P, _P, _P]),

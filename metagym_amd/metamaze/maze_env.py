@@ -23,7 +23,7 @@ import torch
 
 from .. import _lib
 from ..spaces import Box, Discrete
-from .maze_task import MAZE_TASK_MANAGER, TaskConfig
+from .maze_task import MAZE_TASK_MANAGER, DeviceTaskTable, TaskConfig
 
 PI = 3.1415926                      # dynamics.py:6
 DISCRETE_ACTIONS = [(-1, 0), (1, 0), (0, -1), (0, 1)]   # maze_env.py:14
@@ -55,27 +55,41 @@ class _MazeBatch(object):
 
     # ------------------------------------------------------------------ tasks
     def set_task(self, task_config, task_ids=None):
-        tasks = [task_config] if isinstance(task_config, tuple) and hasattr(task_config, "cell_walls") else list(task_config)
-        assert len(tasks) >= 1
-        n = int(np.shape(tasks[0].cell_walls)[0])
-        T, N, dev = len(tasks), self.num_envs, self.device
-        for t in tasks:   # maze_base.py:35-38
-            assert np.shape(t.cell_walls) == (n, n), "all tasks of one batch must have the same size"
-            assert 0 < t.agent_height < t.wall_height, "the agent height must be > 0 and < wall height"
-            assert np.shape(t.cell_walls) == np.shape(t.cell_texts), "the dimension of walls must be equal to textures"
+        """task_config: one TaskConfig, a list of T TaskConfigs (uploaded once), or a DeviceTaskTable from
+        `MazeTaskManager.sample_tasks_device` (already on the GPU). Env e plays task task_ids[e]
+        (default e mod T)."""
+        N, dev = self.num_envs, self.device
+        if isinstance(task_config, DeviceTaskTable):
+            n, T = task_config.n, task_config.n_tasks
+            assert all(v.device == dev or (v.device.type == dev.type and (v.device.index or 0) == (dev.index or 0))
+                       for v in task_config.tensors.values()), "task table lives on another device"
+            self._task_t = task_config.tensors
+            self.tasks = task_config
+            self._min_cell_size = float(task_config.cell_size)
+            host = task_config.tensors
+        else:
+            tasks = [task_config] if isinstance(task_config, tuple) and hasattr(task_config, "cell_walls") else list(task_config)
+            assert len(tasks) >= 1
+            n = int(np.shape(tasks[0].cell_walls)[0])
+            T = len(tasks)
+            for t in tasks:   # maze_base.py:35-38
+                assert np.shape(t.cell_walls) == (n, n), "all tasks of one batch must have the same size"
+                assert 0 < t.agent_height < t.wall_height, "the agent height must be > 0 and < wall height"
+                assert np.shape(t.cell_walls) == np.shape(t.cell_texts), "the dimension of walls must be equal to textures"
+            host = dict(
+                start=np.asarray([t.start for t in tasks], np.int32).reshape(T, 2),
+                goal=np.asarray([t.goal for t in tasks], np.int32).reshape(T, 2),
+                walls=np.clip(np.asarray([t.cell_walls for t in tasks]), -1, 1).astype(np.int8).reshape(T, n * n),
+                texts=np.asarray([t.cell_texts for t in tasks]).astype(np.uint8).reshape(T, n * n),
+                food_rewards=np.asarray([t.food_rewards for t in tasks], np.float64).reshape(T, n * n),
+                food_interval=np.asarray([t.food_interval for t in tasks], np.int32).reshape(T, n * n),
+                scalars=np.asarray([[t.cell_size, t.wall_height, t.agent_height, t.initial_life, t.max_life,
+                                     t.step_reward, t.goal_reward, 0.0] for t in tasks], np.float64))
+            assert int(host["texts"].max()) < MAZE_TASK_MANAGER.n_texts, "cell_texts refers to a missing texture"
+            self._task_t = {k: torch.from_numpy(np.ascontiguousarray(v)).to(dev) for k, v in host.items()}
+            self.tasks = tasks
+            self._min_cell_size = min(float(t.cell_size) for t in tasks)
         nn = n * n
-        host = dict(
-            start=np.asarray([t.start for t in tasks], np.int32).reshape(T, 2),
-            goal=np.asarray([t.goal for t in tasks], np.int32).reshape(T, 2),
-            walls=np.clip(np.asarray([t.cell_walls for t in tasks]), -1, 1).astype(np.int8).reshape(T, nn),
-            texts=np.asarray([t.cell_texts for t in tasks]).astype(np.uint8).reshape(T, nn),
-            food_rewards=np.asarray([t.food_rewards for t in tasks], np.float64).reshape(T, nn),
-            food_interval=np.asarray([t.food_interval for t in tasks], np.int32).reshape(T, nn),
-            scalars=np.asarray([[t.cell_size, t.wall_height, t.agent_height, t.initial_life, t.max_life,
-                                 t.step_reward, t.goal_reward, 0.0] for t in tasks], np.float64))
-        assert int(host["texts"].max()) < MAZE_TASK_MANAGER.n_texts, "cell_texts refers to a missing texture"
-        self._task_t = {k: torch.from_numpy(np.ascontiguousarray(v)).to(dev) for k, v in host.items()}
-        self.tasks = tasks
         self.n = n
         c = _lib.MazeTasks()
         c.n, c.n_tasks = n, T
@@ -231,7 +245,7 @@ class _Maze3D(_MazeBatch):
         # DDA_2D (ray_caster_utils.py:31) stops once hit_dist >= max_vision: a ray crosses at most
         # floor(max_vision / cell_size) + 1 cell boundaries per axis plus the final overshoot, so it can
         # record at most 2*floor(mv/cs) + 4 translucent cells (incl. the start cell) whatever n is
-        min_cs = min(float(t.cell_size) for t in self.tasks)
+        min_cs = self._min_cell_size
         v.max_ray_records = 2 * int(self.max_vision_range / min_cs) + 5
         self._view_c = v
         self._tex_version = MAZE_TASK_MANAGER.version

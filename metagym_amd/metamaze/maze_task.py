@@ -23,6 +23,37 @@ TaskConfig = namedtuple("TaskConfig", ["start", "goal", "cell_walls", "cell_text
                                        "food_rewards", "food_interval"])
 
 
+class DeviceTaskTable(object):
+    """T tasks of one size resident on the GPU — the arrays `mg_maze_tasks` points at. Produced by
+    `MazeTaskManager.sample_tasks_device` (no host round trip) and accepted by `env.set_task`."""
+
+    KEYS = ("start", "goal", "walls", "texts", "food_rewards", "food_interval", "scalars")
+
+    def __init__(self, n, tensors, cell_size):
+        self.n = int(n)
+        self.cell_size = float(cell_size)      # uniform over the table (a sampler parameter)
+        self.tensors = tensors
+        self.n_tasks = int(tensors["start"].shape[0])
+
+    def __len__(self):
+        return self.n_tasks
+
+    def to_task_configs(self):
+        """Copy to host as reference-style TaskConfig tuples (inspection / tests)."""
+        h = {k: v.cpu().numpy() for k, v in self.tensors.items()}
+        n, out = self.n, []
+        for t in range(self.n_tasks):
+            sc = h["scalars"][t]
+            out.append(TaskConfig(start=tuple(int(x) for x in h["start"][t]), goal=tuple(int(x) for x in h["goal"][t]),
+                                  cell_walls=h["walls"][t].reshape(n, n).astype(np.int32),
+                                  cell_texts=h["texts"][t].reshape(n, n).astype(np.int64),
+                                  cell_size=float(sc[0]), wall_height=float(sc[1]), agent_height=float(sc[2]),
+                                  initial_life=float(sc[3]), max_life=float(sc[4]), step_reward=float(sc[5]),
+                                  goal_reward=float(sc[6]), food_rewards=h["food_rewards"][t].reshape(n, n),
+                                  food_interval=h["food_interval"][t].reshape(n, n)))
+        return out
+
+
 def _procedural_textures(n_walls=6, size=64):
     rs = np.random.RandomState(20260925)
     yy, xx = np.mgrid[0:size, 0:size]
@@ -176,6 +207,47 @@ class MazeTaskManager(object):
                           step_reward=step_reward, goal_reward=def_goal_reward, wall_height=wall_height,
                           agent_height=agent_height, initial_life=initial_life, max_life=max_life,
                           food_rewards=food, food_interval=interval)
+
+
+    def sample_tasks_device(self, num_tasks, device="cuda", seed=0, seeds=None, n=15, allow_loops=True,
+                            cell_size=2.0, wall_height=3.2, agent_height=1.6, step_reward=-0.01, goal_reward=None,
+                            food_reward=0.50, initial_life=1.0, max_life=2.0, food_density=0.010, food_interval=100,
+                            crowd_ratio=0.0):
+        """`num_tasks` tasks drawn ON THE GPU by `mg_maze_sample_tasks` (one wave per task). Task t is
+        bit-identical to the reference's
+            random.seed(s_t); numpy.random.seed(s_t); MazeTaskSampler(n=..., ...)
+        with s_t = seeds[t] (uint32 tensor / array) or seed + t. Returns a DeviceTaskTable for
+        `env.set_task`; nothing is copied to the host."""
+        import torch
+        from .. import _lib
+        lib = _lib.load()
+        dev = torch.device(device)
+        T, nn = int(num_tasks), int(n) * int(n)
+        tens = dict(start=torch.empty(T, 2, dtype=torch.int32, device=dev),
+                    goal=torch.empty(T, 2, dtype=torch.int32, device=dev),
+                    walls=torch.empty(T, nn, dtype=torch.int8, device=dev),
+                    texts=torch.empty(T, nn, dtype=torch.uint8, device=dev),
+                    food_rewards=torch.empty(T, nn, dtype=torch.float64, device=dev),
+                    food_interval=torch.empty(T, nn, dtype=torch.int32, device=dev),
+                    scalars=torch.empty(T, 8, dtype=torch.float64, device=dev))
+        p = _lib.MazeSampleParams()
+        p.n, p.allow_loops, p.n_texts, p.food_interval = int(n), int(bool(allow_loops)), self.n_texts, int(food_interval)
+        p.has_goal_reward = int(goal_reward is not None)
+        p.cell_size, p.wall_height, p.agent_height = float(cell_size), float(wall_height), float(agent_height)
+        p.step_reward, p.goal_reward = float(step_reward), float(goal_reward if goal_reward is not None else 0.0)
+        p.food_reward, p.initial_life, p.max_life = float(food_reward), float(initial_life), float(max_life)
+        p.food_density, p.crowd_ratio = float(food_density), float(crowd_ratio)
+        seeds_t = None
+        if seeds is not None:
+            # uint32 values carried in an int64 -> int32-bit-pattern tensor (torch has no uint32 arithmetic)
+            arr = np.asarray(seeds.cpu().numpy() if hasattr(seeds, "cpu") else seeds, dtype=np.int64)
+            assert arr.shape == (T,) and arr.min() >= 0 and arr.max() < 2 ** 32, "seeds must be T values in [0, 2^32)"
+            seeds_t = torch.from_numpy(arr.astype(np.uint32).view(np.int32)).to(dev)
+        assert 0 <= int(seed) and int(seed) + T <= 2 ** 32, "seeds are 32-bit (numpy.random.seed's integer range)"
+        rc = lib.mg_maze_sample_tasks(p, T, int(seed), _lib.ptr(seeds_t), *[_lib.ptr(tens[k]) for k in DeviceTaskTable.KEYS],
+                                      _lib.current_stream(dev))
+        _lib.check(rc, "mg_maze_sample_tasks")
+        return DeviceTaskTable(n, tens, cell_size)
 
 
 MAZE_TASK_MANAGER = MazeTaskManager()

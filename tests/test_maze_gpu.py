@@ -318,3 +318,71 @@ def test_maze3d_uint8_fast_path_is_the_clamped_reference_frame():
         ob, rb, db, _ = b.step(act)
         assert torch.equal(oa.clamp(0, 255).to(torch.uint8), ob) and torch.equal(ra, rb) and torch.equal(da, db)
     assert int(oa.max()) > 255          # the int32 frames really do exceed a byte
+
+
+def test_device_task_sampler_matches_reference_tasks_bit_exact(reference_textures):
+    """mg_maze_sample_tasks (one wave per task, MT19937 streams on the device) against tasks drawn by the
+    unmodified reference sampler: every field of every task, bit for bit (floats included)."""
+    import json
+    from metagym_amd.metamaze import MAZE_TASK_MANAGER
+    g = np.load(os.path.join(GOLDEN, "maze_tasks.npz"))
+    assert MAZE_TASK_MANAGER.n_texts == int(g["n_texts"])
+    seeds = [int(s) for s in g["seeds"]]
+    for c, kw in enumerate(json.loads(str(g["cases"]))):
+        table = MAZE_TASK_MANAGER.sample_tasks_device(len(seeds), device="cuda:0", seeds=seeds, **kw)
+        tasks = table.to_task_configs()
+        for t, seed in zip(tasks, seeds):
+            k = "c%d_s%d_" % (c, seed)
+            assert t.start == tuple(g[k + "start"]) and t.goal == tuple(g[k + "goal"]), k
+            assert np.array_equal(t.cell_walls, g[k + "walls"]), k
+            assert np.array_equal(t.cell_texts, g[k + "texts"]), k
+            assert np.array_equal(t.food_rewards, g[k + "food"]), k
+            assert np.array_equal(t.food_interval, g[k + "interval"]), k
+            assert np.array_equal(np.asarray([t.cell_size, t.wall_height, t.agent_height, t.initial_life,
+                                              t.max_life, t.step_reward, t.goal_reward]), g[k + "scalars"]), k
+
+
+def test_device_sampled_table_drives_envs_like_host_tasks(reference_textures):
+    """A DeviceTaskTable handed to set_task gives the same episode as the same tasks uploaded from the
+    host; seed_base + t addressing equals an explicit seed list; big tables are valid mazes."""
+    import metagym_amd
+    from metagym_amd.metamaze import MAZE_TASK_MANAGER
+    kw = dict(n=9, allow_loops=False, step_reward=-0.01, goal_reward=1.0, food_density=0.06, food_interval=20)
+    T, n_envs = 16, 64
+    table = MAZE_TASK_MANAGER.sample_tasks_device(T, device="cuda:0", seed=100, **kw)
+    table2 = MAZE_TASK_MANAGER.sample_tasks_device(T, device="cuda:0", seeds=list(range(100, 100 + T)), **kw)
+    for k in table.tensors:
+        assert torch.equal(table.tensors[k], table2.tensors[k]), k
+    mk = lambda: metagym_amd.make("meta-maze-discrete-3D-v0", num_envs=n_envs, device="cuda:0", max_steps=40,
+                                  resolution=(32, 32), task_type="SURVIVAL")
+    a, b = mk(), mk()
+    a.set_task(table)
+    b.set_task(table.to_task_configs())
+    oa, ob = a.reset(), b.reset()
+    assert torch.equal(oa, ob)
+    rs = np.random.RandomState(0)
+    for _ in range(30):
+        act = torch.as_tensor(rs.randint(0, 4, n_envs).astype(np.int32)).cuda()
+        ra, rb = a.step(act), b.step(act)
+        assert torch.equal(ra[0], rb[0]) and torch.equal(ra[1], rb[1]) and torch.equal(ra[2], rb[2])
+    # 4096 tasks of the C1 shape: every maze is one connected corridor system containing start and goal
+    big = MAZE_TASK_MANAGER.sample_tasks_device(4096, device="cuda:0", seed=0, n=15, allow_loops=True,
+                                                crowd_ratio=0.35, step_reward=-0.01, goal_reward=1.0)
+    w = big.tensors["walls"].cpu().numpy().reshape(4096, 15, 15)
+    st, go = big.tensors["start"].cpu().numpy(), big.tensors["goal"].cpu().numpy()
+    assert (w[:, 0, :] == 1).all() and (w[:, -1, :] == 1).all() and (w[:, :, 0] == 1).all() and (w[:, :, -1] == 1).all()
+    for t in range(0, 4096, 97):
+        free = w[t] == 0
+        assert free[st[t, 0], st[t, 1]] and free[go[t, 0], go[t, 1]]
+        seen = np.zeros_like(free)
+        stack = [tuple(st[t])]
+        seen[tuple(st[t])] = True
+        while stack:
+            i, j = stack.pop()
+            for di, dj in ((1, 0), (-1, 0), (0, 1), (0, -1)):
+                p = (i + di, j + dj)
+                if free[p] and not seen[p]:
+                    seen[p] = True
+                    stack.append(p)
+        assert seen.sum() == free.sum(), "maze %d is not connected" % t
+        assert free[1:-1, 1:-1].size - free[1:-1, 1:-1].sum() <= 13 * 13 * 0.35
