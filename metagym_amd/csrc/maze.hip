@@ -27,13 +27,15 @@
 //     is compiled with -ffp-contract=off. Divisions by cell_size / text_size / text-to-cell ratio
 //     become multiplications only when the divisor is a power of two (bit-identical).
 //   * No MFMA (no contraction), no atomics, no inter-workgroup communication.
+#include <cstdlib>
+
 #include "mg_common.h"
 
 namespace {
 
 constexpr int MZ_BLOCK = 256;
 constexpr int MZ_WAVES = MZ_BLOCK / mg::WAVE;
-constexpr int SLAB = 32;   // screen columns a wave handles per pass (<= 64); sets the per-wave overlay-record LDS
+constexpr int SLAB = 32;   // default screen columns a wave handles per pass (ViewK::slab, <= 64); sets the per-wave overlay-record LDS
 
 // ------------------------------------------------------------------------------------------------
 // task / state access
@@ -330,6 +332,7 @@ __device__ __forceinline__ void transition_continuous(const Task &t, double col_
 
 struct ViewK {
     int H, V, TS, t_max, obs_u8;
+    int slab;          // screen columns a wave handles per pass (32 or 64)
     double max_vision, max_vision_lo, inv_max_vision, l_focal, text_size, inv_text_size, half_h, half_v, pixel_size;
     double col_dist;
     int text_size_pow2;
@@ -442,7 +445,7 @@ __device__ ColRec column_pass(const ViewK &vk, const Task &t, const EnvShared &e
         int e2 = to_int_clamped((vk.half_v + bv) / vk.pixel_size, -1, vk.V - 1);
         if (s2 < 0) s2 = 0;
         if (e2 > vk.V) e2 = vk.V;
-        entries[n_tr * SLAB + lane] = make_uint2((unsigned)s2 | ((unsigned)e2 << 16), (unsigned)cell);
+        entries[n_tr * vk.slab + lane] = make_uint2((unsigned)s2 | ((unsigned)e2 << 16), (unsigned)cell);
         ++n_tr;
     };
 
@@ -619,7 +622,7 @@ __device__ __forceinline__ void pixel_pass(const ViewK &vk, const Task &t, const
         B = (int)(light * (oma * tex_b(tx)));
     }
     for (int q = 0; q < n_tr; ++q) {                                          // :194-205
-        const uint2 en = entries[q * SLAB + k];
+        const uint2 en = entries[q * vk.slab + k];
         if (!tflag && d_v >= (int)(en.x & 0xffffu) && d_v < (int)(en.x >> 16)) {
             const double tf = transp[en.y] * 0.50 + 0.10, om = 1.0 - tf;
             R = (int)(om * (double)R);
@@ -647,6 +650,7 @@ __global__ __launch_bounds__(MZ_BLOCK) void maze3d_step_kernel(mg_maze_tasks T, 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int e = blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n_threads = blockDim.x, n_waves = n_threads >> 6;   // 1, 2 or 4 waves per env (host picks by frame size)
     const Task t = load_task(T, st.task_id[e]);
     const int nn = t.nn;
 
@@ -656,7 +660,7 @@ __global__ __launch_bounds__(MZ_BLOCK) void maze3d_step_kernel(mg_maze_tasks T, 
     double *transp = reinterpret_cast<double *>(smem + off);
     off += sizeof(double) * nn;
     uint2 *entries_all = reinterpret_cast<uint2 *>(smem + off);
-    off += sizeof(uint2) * SLAB * vk.t_max * MZ_WAVES;
+    off += sizeof(uint2) * vk.slab * vk.t_max * n_waves;
     int8_t *walls = reinterpret_cast<int8_t *>(smem + off);
     off += (nn + 15) & ~15;
     uint8_t *texts = reinterpret_cast<uint8_t *>(smem + off);
@@ -685,9 +689,9 @@ __global__ __launch_bounds__(MZ_BLOCK) void maze3d_step_kernel(mg_maze_tasks T, 
         es->a = a;
     }
     __syncthreads();
-    if (action != nullptr && task_type == MG_MAZE_SURVIVAL) eval_cells(t, st, e, tid, MZ_BLOCK);   // :83-88
+    if (action != nullptr && task_type == MG_MAZE_SURVIVAL) eval_cells(t, st, e, tid, n_threads);   // :83-88
     if (es->done && auto_reset) {
-        if (task_type == MG_MAZE_SURVIVAL) reset_cells(t, st, e, tid, MZ_BLOCK);
+        if (task_type == MG_MAZE_SURVIVAL) reset_cells(t, st, e, tid, n_threads);
         __syncthreads();
         if (tid == 0) reset_agent(t, task_type, es->a);
     }
@@ -708,7 +712,7 @@ __global__ __launch_bounds__(MZ_BLOCK) void maze3d_step_kernel(mg_maze_tasks T, 
         }
     }
     // ---- phase 1: stage the task grids in LDS -----------------------------------------------------
-    for (int c = tid; c < nn; c += MZ_BLOCK) {
+    for (int c = tid; c < nn; c += n_threads) {
         walls[c] = t.walls[c];
         texts[c] = t.texts[c];
         if (task_type == MG_MAZE_SURVIVAL) transp[c] = st.cur_food[fidx(st, e, c)];       // alias maze_base.py:57
@@ -733,12 +737,12 @@ __global__ __launch_bounds__(MZ_BLOCK) void maze3d_step_kernel(mg_maze_tasks T, 
         py_slice((long)sy, (long)(sy + 0.05 * vk.H), vk.V, lb_y0, lb_y1);
     }
 
-    uint2 *entries = entries_all + (size_t)wave * SLAB * vk.t_max;
+    uint2 *entries = entries_all + (size_t)wave * vk.slab * vk.t_max;
     int32_t *img = static_cast<int32_t *>(obs) + (size_t)e * vk.H * vk.V * 3;
     uint8_t *img8 = static_cast<uint8_t *>(obs) + (size_t)e * vk.H * vk.V * 3;
-    // columns are dealt to the 4 waves in equal slabs (<= 64 each) so narrow images keep all waves busy
-    const int slab = min(SLAB, (vk.H + MZ_WAVES - 1) / MZ_WAVES);
-    for (int cbase = wave * slab; cbase < vk.H; cbase += MZ_WAVES * slab) {
+    // columns are dealt to the waves in equal slabs (<= vk.slab each) so narrow images keep all waves busy
+    const int slab = min(vk.slab, (vk.H + n_waves - 1) / n_waves);
+    for (int cbase = wave * slab; cbase < vk.H; cbase += n_waves * slab) {
         const int ncols = min(slab, vk.H - cbase);
         ColRec mine{};
         if (lane < ncols)
@@ -931,8 +935,21 @@ extern "C" int mg_maze3d_step(const mg_maze_tasks *T, const mg_maze_view *view, 
     // at least one cell per step and stops at max_vision or at the maze border.
     vk.t_max = 2 * T->n + 1;
     if (view->max_ray_records > 0 && view->max_ray_records < vk.t_max) vk.t_max = view->max_ray_records;
+    // Waves per env (measured on MI355X, 16 384 envs, profiles/r01/maze3d_waves_sweep.txt): frames up to
+    // 128x128 run ~10 % faster with 2 waves per env (less per-env fixed work per pixel, more independent
+    // envs resident per CU), 256x256 is fastest with 4. 32-column slabs beat 64 everywhere (half the
+    // overlay-record LDS, more workgroups per CU).
+    int n_waves = ((long)vk.H * vk.V <= 128L * 128L) ? 2 : MZ_WAVES;
+    vk.slab = SLAB;
+    if (const char *ev = getenv("MG_MAZE3D_WAVES")) {          // tuning override: "<waves>[,<slab>]"
+        int w = 0, sl = 0;
+        if (sscanf(ev, "%d,%d", &w, &sl) >= 1 && (w == 1 || w == 2 || w == 4)) {
+            n_waves = w;
+            vk.slab = (sl == 32 || sl == 64) ? sl : SLAB;
+        }
+    }
     const size_t lds = ((sizeof(EnvShared) + 15) & ~size_t(15)) + sizeof(double) * T->n * T->n +
-                       sizeof(uint2) * SLAB * vk.t_max * MZ_WAVES +
+                       sizeof(uint2) * vk.slab * vk.t_max * n_waves +
                        2 * ((size_t)(T->n * T->n + 15) & ~size_t(15));
     if (lds > 160 * 1024) return mg::set_error(MG_ERR_BAD_SIZE, "maze n=%d needs %zu B of LDS (> 160 KiB)", T->n, lds);
     if (lds > 64 * 1024) {
@@ -947,7 +964,7 @@ extern "C" int mg_maze3d_step(const mg_maze_tasks *T, const mg_maze_view *view, 
         if (int rc = mg::check_launch("maze_cont_move_kernel")) return rc;
         pre_moved = 1;
     }
-    hipLaunchKernelGGL(maze3d_step_kernel, dim3(n), dim3(MZ_BLOCK), lds, (hipStream_t)stream, *T, *st, vk, task_type,
+    hipLaunchKernelGGL(maze3d_step_kernel, dim3(n), dim3(n_waves * mg::WAVE), lds, (hipStream_t)stream, *T, *st, vk, task_type,
                        max_steps, continuous, pre_moved, auto_reset, n, action, obs, reward, reward64, done);
     return mg::check_launch("maze3d_step_kernel");
 }

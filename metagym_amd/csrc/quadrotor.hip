@@ -140,8 +140,10 @@ __device__ __forceinline__ void inv3(const float *Af, float *Ainv) {
 // gravity offset, CT[2] == 0, propellers in the z = 0 plane. Multiplying by those structural zeros
 // only ever adds +-0 to a finite sum, so the SIMPLE path is bit-identical to the general one while
 // needing ~40 fewer scalar constants and ~70 fewer VALU ops per sub-step.
+// want_power: self.power (:139,:188) is overwritten by every sub-step and read only by the reward
+// after the last one (env.py:217), so the four f32 divisions behind it run in the last sub-step only.
 template <bool SIMPLE>
-__device__ __forceinline__ void substep(const QuadK &k, Lane &s, const float *eff32) {
+__device__ __forceinline__ void substep(const QuadK &k, Lane &s, const float *eff32, bool want_power) {
     float prop_force_z = 0.0f;
     float prop_torque[3] = {0.0f, 0.0f, 0.0f};
     float me[4], pp[4];
@@ -154,7 +156,7 @@ __device__ __forceinline__ void substep(const QuadK &k, Lane &s, const float *ef
         const float e32 = eff32[i];
         float phi_w = k.phi32 * s.pw[i];                         // :136
         me[i] = k.phi_over_ra32 * (e32 - phi_w);                 // :137-138
-        pp[i] = fabsf(me[i] / k.phi32 * e32);                    // :139
+        if (want_power) pp[i] = fabsf(me[i] / k.phi32 * e32);    // :139
         float d_prop_w = k.inv_jm32 * (me[i] - k.mm32);          // :141-142
         float w_m = s.pw[i] + k.prec32 * d_prop_w;               // :144-145
         const float *pc = &k.pc[3 * i];
@@ -238,7 +240,7 @@ __device__ __forceinline__ void substep(const QuadK &k, Lane &s, const float *ef
         s.p[c] = (float)((double)s.p[c] + (s.v[c] * k.prec + k.half_dt2 * acc[c]));
 #pragma unroll
     for (int c = 0; c < 3; ++c) s.v[c] = s.v[c] + k.prec * acc[c];
-    s.power = ((pp[0] + pp[1]) + pp[2]) + pp[3];
+    if (want_power) s.power = ((pp[0] + pp[1]) + pp[2]) + pp[3];
 
     // :190-204 attitude
     double alpha[3], tw[3];
@@ -569,7 +571,7 @@ __global__ __launch_bounds__(BLOCK) void quadrotor_step_kernel(QuadK k, mg_quadr
         int fail = 0;
         for (int it = 0; it < k.times; ++it) {                              // quadrotorsim.py:302-304
             if (fail == 0) {      // a failed env freezes at the failing sub-step (reference raises)
-                substep<SIMPLE>(k, s, eff32);
+                substep<SIMPLE>(k, s, eff32, it == k.times - 1);
                 fail = failure_code(k, s);
             }
         }
