@@ -533,7 +533,7 @@ __device__ __forceinline__ RowK row_constants(const ViewK &vk, const Task &t, in
 // Pass B, lane = screen row d_v, for screen column `col` (slot `k` of the wave's 64): the floor /
 // ceiling cast (:102-126 / :135-153), then the wall column (:181-192), then the translucent
 // overlays in ray order (:194-205), then the life bar (maze_discrete_3d.py:118-126).
-__device__ __forceinline__ void pixel_pass(const ViewK &vk, const Task &t, const EnvShared &es, const RowK &rk,
+__device__ __forceinline__ void pixel_pass(const ViewK &vk, const Task &t, double pos_x, double pos_y, const RowK &rk,
                                            const uint8_t *texts, const double *transp, const ColRec &wc,
                                            const uint2 *entries, int k, int d_v, double cs, double inv_cs,
                                            int cs_pow2, double text_to_cell, double inv_ttc, int ttc_pow2,
@@ -557,8 +557,8 @@ __device__ __forceinline__ void pixel_pass(const ViewK &vk, const Task &t, const
             a = a > 0.0 ? a : 0.0;
             a = a < 1.0 ? a : 1.0;
         }
-        const double hit_x = eff * (double)wc.cos_abs + es.pos[0];
-        const double hit_y = eff * (double)wc.sin_abs + es.pos[1];
+        const double hit_x = eff * (double)wc.cos_abs + pos_x;
+        const double hit_y = eff * (double)wc.sin_abs + pos_y;
         const double fi = cs_pow2 ? hit_x * inv_cs : hit_x / cs;
         const double fj = cs_pow2 ? hit_y * inv_cs : hit_y / cs;
         const int i = cell_index(fi), j = cell_index(fj);
@@ -664,6 +664,10 @@ __global__ __launch_bounds__(MZ_BLOCK) void maze3d_step_kernel(mg_maze_tasks T, 
     int8_t *walls = reinterpret_cast<int8_t *>(smem + off);
     off += (nn + 15) & ~15;
     uint8_t *texts = reinterpret_cast<uint8_t *>(smem + off);
+    off += (nn + 15) & ~15;
+    double *row_tab = reinterpret_cast<double *>(smem + off);      // [V][3]: distance, light, ys of a screen row
+    off += sizeof(double) * 3 * vk.V;
+    int8_t *row_kind = reinterpret_cast<int8_t *>(smem + off);     // [V]
 
     // ---- phase 0: transition + scalar part of evaluation_rule (one thread) ----------------------
     if (tid == 0) {
@@ -711,7 +715,14 @@ __global__ __launch_bounds__(MZ_BLOCK) void maze3d_step_kernel(mg_maze_tasks T, 
             es->c_ori = (double)vk.ori_cos[a.ori_idx];
         }
     }
-    // ---- phase 1: stage the task grids in LDS -----------------------------------------------------
+    // ---- phase 1: stage the task grids and the per-row constants in LDS ----------------------------
+    for (int r = tid; r < vk.V; r += n_threads) {
+        const RowK rk = row_constants(vk, t, r);
+        row_tab[3 * r] = rk.distance;
+        row_tab[3 * r + 1] = rk.light;
+        row_tab[3 * r + 2] = rk.ys;
+        row_kind[r] = (int8_t)rk.kind;
+    }
     for (int c = tid; c < nn; c += n_threads) {
         walls[c] = t.walls[c];
         texts[c] = t.texts[c];
@@ -738,6 +749,7 @@ __global__ __launch_bounds__(MZ_BLOCK) void maze3d_step_kernel(mg_maze_tasks T, 
     }
 
     uint2 *entries = entries_all + (size_t)wave * vk.slab * vk.t_max;
+    const double pos_x = es->pos[0], pos_y = es->pos[1];   // registers: the pixel loop must not re-read LDS for them
     int32_t *img = static_cast<int32_t *>(obs) + (size_t)e * vk.H * vk.V * 3;
     uint8_t *img8 = static_cast<uint8_t *>(obs) + (size_t)e * vk.H * vk.V * 3;
     // columns are dealt to the waves in equal slabs (<= vk.slab each) so narrow images keep all waves busy
@@ -750,24 +762,28 @@ __global__ __launch_bounds__(MZ_BLOCK) void maze3d_step_kernel(mg_maze_tasks T, 
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        for (int rbase = 0; rbase < vk.V; rbase += 64) {
-            const int d_v = rbase + lane;
-            const bool row_ok = d_v < vk.V;
-            const RowK rk = row_constants(vk, t, row_ok ? d_v : 0);
-            const bool in_lb_y = d_v >= lb_y0 && d_v < lb_y1;
-            // frame-relative 32-bit byte offset of this lane's pixel in column cbase, advanced by one
-            // column per k: scalar frame base + one VGPR add per store (frames are < 4 GiB)
-            const uint32_t px_bytes = vk.obs_u8 ? 3u : 12u;
-            uint32_t off = (uint32_t)(cbase * vk.V + d_v) * px_bytes;
-            const uint32_t col_bytes = (uint32_t)vk.V * px_bytes;
-            for (int k = 0; k < ncols; ++k, off += col_bytes) {
+        // column-major walk: column k's record is broadcast ONCE (11 v_readlane + 4 converts) and then
+        // reused by all V/64 row chunks; the per-row constants come from the LDS row table
+        const uint32_t px_bytes = vk.obs_u8 ? 3u : 12u;
+        for (int k = 0; k < ncols; ++k) {
+            const ColRec wc = bcast(mine, k);
+            const int col = cbase + k;
+            const bool in_lb_x = col >= lb_x0 && col < lb_x1;
+            const uint32_t col_off = (uint32_t)(col * vk.V) * px_bytes;      // frame-relative bytes (< 4 GiB)
+            for (int rbase = 0; rbase < vk.V; rbase += 64) {
+                const int d_v = rbase + lane;
+                const bool row_ok = d_v < vk.V;
+                const int d_r = row_ok ? d_v : 0;
+                RowK rk;
+                rk.kind = row_kind[d_r];
+                rk.distance = row_tab[3 * d_r];
+                rk.light = row_tab[3 * d_r + 1];
+                rk.ys = row_tab[3 * d_r + 2];
                 int R, G, B;
-                const ColRec wc = bcast(mine, k);
-                pixel_pass(vk, t, *es, rk, texts, transp, wc, entries, k, d_v, cs, inv_cs, cs_pow2, text_to_cell,
+                pixel_pass(vk, t, pos_x, pos_y, rk, texts, transp, wc, entries, k, d_v, cs, inv_cs, cs_pow2, text_to_cell,
                            inv_ttc, ttc_pow2, R, G, B);
-                const int col = cbase + k;
-                if (in_lb_y && col >= lb_x0 && col < lb_x1) { R = 255; G = 0; B = 0; }
-                asm volatile("" : "+v"(off));      // keep the running offset (no per-pixel index multiply)
+                if (in_lb_x && d_v >= lb_y0 && d_v < lb_y1) { R = 255; G = 0; B = 0; }
+                const uint32_t off = col_off + (uint32_t)d_v * px_bytes;
                 if (row_ok) {
                     if (vk.obs_u8) {      // non-parity fast path: saturate to a byte
                         uint8_t *q = img8 + off;
@@ -950,7 +966,7 @@ extern "C" int mg_maze3d_step(const mg_maze_tasks *T, const mg_maze_view *view, 
     }
     const size_t lds = ((sizeof(EnvShared) + 15) & ~size_t(15)) + sizeof(double) * T->n * T->n +
                        sizeof(uint2) * vk.slab * vk.t_max * n_waves +
-                       2 * ((size_t)(T->n * T->n + 15) & ~size_t(15));
+                       2 * ((size_t)(T->n * T->n + 15) & ~size_t(15)) + (sizeof(double) * 3 + 1) * (size_t)vk.V + 16;
     if (lds > 160 * 1024) return mg::set_error(MG_ERR_BAD_SIZE, "maze n=%d needs %zu B of LDS (> 160 KiB)", T->n, lds);
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(maze3d_step_kernel),
