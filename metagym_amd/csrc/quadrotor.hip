@@ -549,13 +549,30 @@ __global__ __launch_bounds__(BLOCK) void quadrotor_step_kernel(QuadK k, mg_quadr
     const int el = live ? e : n - 1;  // out-of-range lanes shadow the last env, stores are masked
     float *tile = tiles[threadIdx.x / mg::WAVE];
 
+    // Latency, not bandwidth, bounds a 65 536-env launch (one wave per SIMD). Three round trips used to
+    // run back to back: state loads, then ~9 scalar kernarg-line misses scattered through the prologue,
+    // then the action load. Issue them together: touch every 64-byte line of the 560-byte kernarg
+    // segment now (later s_loads hit the scalar cache) and fetch the first action before the state.
+    {
+        const uint32_t *ka = (const uint32_t *)__builtin_amdgcn_kernarg_segment_ptr();
+        uint32_t touch = 0;
+#pragma unroll
+        for (int line = 0; line < (int)((sizeof(QuadK) + sizeof(mg_quadrotor_state) + sizeof(StepIO) + 8 + 63) / 64); ++line)
+            touch |= ka[line * 16];
+        asm volatile("" ::"s"(touch));
+    }
+    float4 a_next = reinterpret_cast<const float4 *>(io.action)[el];
+    __builtin_amdgcn_sched_barrier(0);   // keep this load ahead of the state loads (it would be sunk to its first use)
+
     Lane s;
     int ct;
     load_lane(st, n, el, s, ct);
 
     for (int t = 0; t < n_steps; ++t) {
         const size_t off = (size_t)t * n;
-        const float4 a = reinterpret_cast<const float4 *>(io.action)[off + el];
+        const float4 a = a_next;
+        if (t + 1 < n_steps)      // prefetch the next step's action behind this step's arithmetic
+            a_next = reinterpret_cast<const float4 *>(io.action)[off + n + el];
         // quadrotorsim.py:130-134: clamp the (f32-valued) python float against python floats
         const float av[4] = {a.x, a.y, a.z, a.w};
         float eff32[4];
