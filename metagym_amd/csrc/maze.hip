@@ -951,11 +951,11 @@ extern "C" int mg_maze3d_step(const mg_maze_tasks *T, const mg_maze_view *view, 
     // at least one cell per step and stops at max_vision or at the maze border.
     vk.t_max = 2 * T->n + 1;
     if (view->max_ray_records > 0 && view->max_ray_records < vk.t_max) vk.t_max = view->max_ray_records;
-    // Waves per env (measured on MI355X, 16 384 envs, profiles/r01/maze3d_waves_sweep.txt): frames up to
-    // 128x128 run ~10 % faster with 2 waves per env (less per-env fixed work per pixel, more independent
-    // envs resident per CU), 256x256 is fastest with 4. 32-column slabs beat 64 everywhere (half the
-    // overlay-record LDS, more workgroups per CU).
-    int n_waves = ((long)vk.H * vk.V <= 128L * 128L) ? 2 : MZ_WAVES;
+    // Waves per env (measured on MI355X, 16 384 envs, profiles/r01/maze3d_waves_sweep.txt): 64x64 frames
+    // run ~9 % faster with 2 waves per env (less per-env fixed work per pixel, more independent envs
+    // resident per CU), 128x128 is a tie, 256x256 is fastest with 4. 32-column slabs beat 64 everywhere
+    // (half the overlay-record LDS, more workgroups per CU).
+    int n_waves = ((long)vk.H * vk.V < 128L * 128L) ? 2 : MZ_WAVES;
     vk.slab = SLAB;
     if (const char *ev = getenv("MG_MAZE3D_WAVES")) {          // tuning override: "<waves>[,<slab>]"
         int w = 0, sl = 0;
