@@ -38,6 +38,7 @@ def main():
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--skip2d", action="store_true")
+    ap.add_argument("--no-u8", action="store_true", help="skip the uint8 fast-path runs (profiling passes)")
     args = ap.parse_args()
     dev = "cuda:0"
     tasks9 = [MazeTaskSampler(n=9, allow_loops=False, step_reward=-0.01, goal_reward=1.0, food_density=0.06,
@@ -66,7 +67,7 @@ def main():
                 del env
                 torch.cuda.empty_cache()
     for res in args.res:      # the uint8 fast path (non-parity): same renderer, 3 bytes per pixel
-        if n * res * res * 3 > 40e9:
+        if args.no_u8 or n * res * res * 3 > 40e9:
             continue
         env = metagym_amd.make("meta-maze-discrete-3D-v0", num_envs=n, device=dev, max_steps=200,
                                resolution=(res, res), task_type="SURVIVAL", auto_reset=True, obs_dtype=torch.uint8)
@@ -90,6 +91,22 @@ def main():
             s = timed(env, mk, 50, 5)
             print(json.dumps({"workload": "meta-maze-2D-v0 15x15 %s view_grid=1, %d envs" % (tt, n2),
                               "env_steps_per_s": n2 / s, "avg_launch_ms": s * 1e3}), flush=True)
+        # on-device task generation (mg_maze_sample_tasks, one wave per task, bit-exact vs the reference sampler)
+        from metagym_amd.metamaze import MAZE_TASK_MANAGER
+        for nt, kw in ((4096, dict(n=15, allow_loops=True, crowd_ratio=0.35, step_reward=-0.01, goal_reward=1.0)),
+                       (4096, dict(n=9, allow_loops=False, step_reward=-0.01, goal_reward=1.0, food_density=0.06,
+                                   food_interval=20))):
+            MAZE_TASK_MANAGER.sample_tasks_device(nt, device=dev, seed=0, **kw)
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for r in range(3):
+                MAZE_TASK_MANAGER.sample_tasks_device(nt, device=dev, seed=r * nt, **kw)
+            e1.record()
+            torch.cuda.synchronize()
+            ms = e0.elapsed_time(e1) / 3
+            print(json.dumps({"workload": "mg_maze_sample_tasks %d tasks n=%d allow_loops=%s" % (nt, kw["n"], kw["allow_loops"]),
+                              "ms_per_table": ms, "tasks_per_s": nt / ms * 1e3}), flush=True)
 
 
 if __name__ == "__main__":

@@ -11,7 +11,7 @@ rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_I
           --output-format csv -d $OUT/quad_pmc_sq -o q -- $B > $OUT/quad_pmc_sq.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/quad_pmc_fetch -o q -- $B > $OUT/quad_pmc_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/quad_pmc_write -o q -- $B > $OUT/quad_pmc_write.log 2>&1
-M="python scripts/bench_maze.py --skip2d --res 256 --steps 10 --warmup 2"
+M="python scripts/bench_maze.py --skip2d --no-u8 --res 256 --steps 10 --warmup 2"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/maze_trace -o m -- $M > $OUT/maze_trace.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/maze_pmc_fetch -o m -- $M > $OUT/maze_pmc_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/maze_pmc_write -o m -- $M > $OUT/maze_pmc_write.log 2>&1
@@ -21,4 +21,7 @@ python bench.py > $OUT/bench.json 2> $OUT/bench.err
 python scripts/bench_maze.py > $OUT/bench_maze.jsonl 2> $OUT/bench_maze.err
 python scripts/bench_walker.py > $OUT/bench_walker.jsonl 2> $OUT/bench_walker.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/walker_trace -o w -- python scripts/bench_walker.py > $OUT/walker_trace.log 2>&1
-ls -R $OUT | head -50
+W="python scripts/bench_walker.py"
+rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_INSTS_LDS SQ_INSTS_SALU \
+          --output-format csv -d $OUT/walker_pmc_sq -o w -- $W > $OUT/walker_pmc_sq.log 2>&1
+ls -R $OUT | head -60

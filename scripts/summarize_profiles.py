@@ -35,7 +35,8 @@ def agg(path, key):
 
 
 summary = {}
-for kernel, prefix, stem in (("quadrotor_step_kernel", "quad", "q"), ("maze3d_step_kernel", "maze", "m")):
+for kernel, prefix, stem in (("quadrotor_step_kernel", "quad", "q"), ("maze3d_step_kernel", "maze", "m"),
+                             ("walker_step_wave_kernel", "walker", "w")):
     merged, meta = {}, {}
     for d in ("pmc_sq", "pmc_fetch", "pmc_write"):
         a, m = agg(os.path.join(R, "%s_%s" % (prefix, d), "%s_counter_collection.csv" % stem), kernel)
