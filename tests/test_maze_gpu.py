@@ -268,7 +268,10 @@ def test_maze3d_full_size_properties():
         assert np.array_equal(ob[e], mo.observe_3d(otasks[idl[e]], tt, view, states[e], 0)), e
 
 
-@pytest.mark.parametrize("n,res,cell", [(15, (64, 48), 2.0), (21, (32, 32), 2.0), (15, (32, 32), 0.75)])
+@pytest.mark.parametrize("n,res,cell", [(15, (64, 48), 2.0), (21, (32, 32), 2.0), (15, (32, 32), 0.75),
+                                        # ragged frame on the 4-waves-per-env path: 136 columns = 4 slabs of 32 + 8,
+                                        # 150 rows = 64 + 64 + 22; cell size not a power of two (true divisions)
+                                        (15, (136, 150), 1.5), (9, (70, 200), 2.0)])
 def test_maze3d_larger_mazes_match_oracle(n, res, cell):
     """The reference's default maze size is 15x15 (maze_task.py:42); larger grids and a small cell size
     (many cells inside the vision range, so many overlay records per ray and > 64 KiB of LDS) must
