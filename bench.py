@@ -325,6 +325,22 @@ def main():
                 traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
+        # The kernel is VALU-issue-bound, not HBM-bound: report how close the launch is to
+        # the SIMDs' issue limit too. VALU instructions per wave come from the committed PMC pass
+        # (profiles/<round>/pmc_summary.json, SQ_INSTS_VALU / SQ_WAVES); one wave-instruction occupies a
+        # SIMD for >= 4 cycles, 1024 SIMDs at 2.4 GHz.
+        valu = None
+        try:
+            rounds = sorted(d for d in os.listdir(os.path.join(ROOT, "profiles")) if d.startswith("r"))
+            q = json.load(open(os.path.join(ROOT, "profiles", rounds[-1], "pmc_summary.json")))["quadrotor_step_kernel"]
+            ipw = float(q["valu_insts_per_wave"])
+            waves = (n + 63) // 64
+            peak_issue = 1024 * 2.4e9 / 4.0
+            valu = {"valu_insts_per_wave": ipw, "waves_per_launch": waves,
+                    "achieved_wave_insts_per_s": ipw * waves / launch_s, "peak_wave_insts_per_s": peak_issue,
+                    "frac": ipw * waves / launch_s / peak_issue, "source": "profiles/%s/pmc_summary.json" % rounds[-1]}
+        except Exception:
+            valu = None
         out = {
             "metric": "env-steps/sec (whole node) at 2^16 parallel envs; 1/2/4/8-GPU scaling",
             "value": value,
@@ -345,7 +361,8 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": "quadrotor_step_kernel", "avg_launch_us": launch_s * 1e6,
-                         "algorithmic_bytes_per_launch": BYTES_PER_ENV_STEP * n},
+                         "algorithmic_bytes_per_launch": BYTES_PER_ENV_STEP * n,
+                         "valu_issue": valu},
             "sanity": {"done_frac_last_step": done_frac, "failed_max": failed_any,
                        "host_wall_ms_per_step": wall / args.steps * 1e3},
         }
