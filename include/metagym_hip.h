@@ -347,6 +347,14 @@ typedef struct mg_walker_params {
     int32_t mapping;           /* 1 (default): wave per env, LDS-resident; 0: lane per env (cross-check) */
     int32_t self_collision;    /* 1: capsule-capsule contacts between the topology's geom pairs */
     double self_friction;      /* geom friction squared (Bullet multiplies the two coefficients) */
+    /* Fused auto-reset (not in the reference: replaces the user's `if done: env.reset()` round trip).
+     * An env whose step ended the episode is reset inside the launch — robot_specific_reset
+     * (walker_base.py:13-24): base pose from the model, every joint at U(-0.1, 0.1) with zero velocity —
+     * and its obs row is the first observation of the next episode. Joint noise comes from
+     * Philox4x32-10 keyed by `seed`, counter (env_id_base + env, step_index, joint/4), so it does not
+     * depend on how envs are sharded. The caller advances step_index by one per launch. */
+    int32_t auto_reset;
+    uint64_t seed, step_index, env_id_base;
 } mg_walker_params;
 
 /* Per-env state, SoA doubles: component c of env e at base[c*N + e]. */

@@ -109,7 +109,9 @@ class WalkerParams(C.Structure):
                 ("initial_z", C.c_double), ("joints_at_limit_cost", C.c_double),
                 ("walk_target_x", C.c_double), ("walk_target_y", C.c_double),
                 ("max_steps", C.c_int32), ("floor_in_parts", C.c_int32), ("mapping", C.c_int32),
-                ("self_collision", C.c_int32), ("self_friction", C.c_double)]
+                ("self_collision", C.c_int32), ("self_friction", C.c_double),
+                ("auto_reset", C.c_int32), ("seed", C.c_uint64), ("step_index", C.c_uint64),
+                ("env_id_base", C.c_uint64)]
 
 
 class WalkerState(C.Structure):

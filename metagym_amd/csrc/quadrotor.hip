@@ -21,6 +21,7 @@
 // -ffp-contract=off so no a*b+c is fused — NumPy never fuses — which makes this kernel bit-identical
 // to the CPU oracle for everything except atan2f (OCML vs glibc, <= 2 ulp).
 #include "mg_common.h"
+#include "mg_philox.h"
 
 namespace {
 
@@ -476,27 +477,6 @@ __device__ __forceinline__ void store_obs_wave(float *tile, const float *obs, fl
 #pragma unroll
         for (int j = 0; j < 4; ++j) dst[j] = make_float4(obs[4 * j], obs[4 * j + 1], obs[4 * j + 2], obs[4 * j + 3]);
     }
-}
-
-// ---- counter-based RNG for the fused auto-reset -------------------------------------------------
-// Philox4x32-10 (Salmon et al., SC'11): stateless, keyed by (seed), counter = (env, step, draw).
-// Every env/step/draw triple gets its own stream, so results do not depend on how envs are
-// sharded across GPUs.
-__device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0,
-                                              uint32_t k1, uint32_t *out) {
-#pragma unroll
-    for (int r = 0; r < 10; ++r) {
-        const uint64_t p0 = (uint64_t)0xD2511F53u * c0;
-        const uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
-        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
-        const uint32_t n1 = (uint32_t)p1;
-        const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
-        const uint32_t n3 = (uint32_t)p0;
-        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
-        k0 += 0x9E3779B9u;
-        k1 += 0xBB67AE85u;
-    }
-    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
 }
 
 // QuadrotorSim.reset quadrotorsim.py:239-258 with the noise drawn on the device:

@@ -22,6 +22,7 @@
 // same element index is a coalesced access. This is a first, correctness-oriented mapping
 // (DESIGN.md §3.5 lists what a wave-per-env LDS version would change).
 #include "mg_common.h"
+#include "mg_philox.h"
 
 namespace {
 
@@ -124,6 +125,16 @@ struct Env {   // per-lane simulation state
     double rot[9];
     double q[NJ], qd[NJ];
 };
+
+// Joint noise of the fused auto-reset: numpy's uniform(low=-0.1, high=0.1) = low + (high - low) * u
+// (walker_base.py:15) with u from Philox4x32-10, counter (global env id, step, joint / 4).
+__device__ __forceinline__ double reset_joint_noise(const mg_walker_params &prm, int e, int j) {
+    uint32_t r[4];
+    const uint64_t gid = prm.env_id_base + (uint64_t)e, step = prm.step_index;
+    philox4x32_10((uint32_t)gid, (uint32_t)step, (uint32_t)(step >> 32) ^ ((uint32_t)(gid >> 32) << 8),
+                  0x57414c4bu + (uint32_t)(j >> 2), (uint32_t)prm.seed, (uint32_t)(prm.seed >> 32), r);
+    return -0.1 + 0.2 * ((double)r[j & 3] * (1.0 / 4294967296.0));
+}
 
 struct Kin {   // world-frame kinematics of the current configuration
     double R[NB][9];
@@ -491,6 +502,18 @@ __global__ __launch_bounds__(WK_BLOCK) void walker_step_kernel(mg_walker_topolog
     const int steps = st.steps[e] + 1;
     st.steps[e] = steps;
     const bool d = (alive < 0) || !finite || (steps >= prm.max_steps);
+    if (prm.auto_reset && d) {
+        // vector-env convention: the returned obs is the first observation of the next episode
+        s.pos = ld3(m.body_pos);
+        for (int i = 0; i < 9; ++i) s.rot[i] = m.body_rot[i];
+        s.vel = v3(0, 0, 0);
+        s.omega = v3(0, 0, 0);
+        for (int j = 0; j < nj; ++j) { s.q[j] = reset_joint_noise(prm, e, j); s.qd[j] = 0.0; }
+        for (int f = 0; f < nf; ++f) { fc[f] = 0.0f; st.feet_contact[(size_t)f * n_envs + e] = 0.0f; }
+        observe(tp, m, prm, s, fc, ob, dist, at_limit);
+        st.potential[e] = -dist / (prm.time_step * prm.frame_skip);
+        st.steps[e] = 0;
+    }
     for (int i = 0; i < obs_dim; ++i) obs[(size_t)e * obs_dim + i] = ob[i];
     reward[e] = (float)(alive + progress + 0.0 + limit_cost + 0.0);      // :69-77
     if (rewards5) {
@@ -1053,51 +1076,66 @@ __global__ __launch_bounds__(WV) void walker_step_wave_kernel(mg_walker_topology
     const int max_depth = L.misc[0];
     unsigned long long touch = 0ull;
     for (int it = 0; it < prm.frame_skip; ++it) wave_substep<NMAX>(tp, m, prm, L, lane, max_depth, maxr, touch);
-    // ---- calc_state (walker_base.py:31-64) on the post-step configuration -----------------------------
-    wave_kinematics(tp, m, L, lane, max_depth, false);
-    const double sxm = wave_sum(lane < nb ? L.o[3 * lane] : 0.0), sym = wave_sum(lane < nb ? L.o[3 * lane + 1] : 0.0);
-    float jp = 0.0f, jv = 0.0f;
-    bool lim = false;
-    if (lane < nj) {
-        const double lo = m.joint_lo[lane], hi = m.joint_hi[lane];
-        jp = (float)(2 * (L.q[lane] - 0.5 * (lo + hi)) / (hi - lo));
-        jv = (float)(0.1 * L.qd[lane]);
-        lim = fabsf(jp) > 0.99f;
-    }
-    const int at_limit = __popcll(__ballot(lim));
+    // ---- calc_state (walker_base.py:31-64) on the current configuration ------------------------------
+    // after_reset = false: post-step state; the obs carries the PREVIOUS step's feet flags and the flags
+    // are then refreshed from this step's contacts (walker_base_env.py:46 vs :57-63).
+    // after_reset = true: first observation of a new episode; feet flags are zero (walker_base.py:18).
     auto clip5 = [](float v) { return v < -5.0f ? -5.0f : (v > 5.0f ? 5.0f : v); };
     float *ob = obs + (size_t)e * obs_dim;
-    if (lane < nj) { ob[8 + 2 * lane] = clip5(jp); ob[9 + 2 * lane] = clip5(jv); }
-    bool finite = isfinite(jp) && isfinite(jv);
-    if (lane < nf) {
-        const float prev = st.feet_contact[(size_t)lane * n_envs + e];   // flags of the previous step (:46 vs :57-63)
-        ob[8 + 2 * nj + lane] = clip5(prev);
-        float cnow = 0.0f;
-        for (int g = 0; g < tp.n_spheres; ++g)
-            if (((touch >> g) & 1ull) && tp.sphere_body[g] == tp.foot_body[lane]) cnow = 1.0f;
-        st.feet_contact[(size_t)lane * n_envs + e] = cnow;
-    }
     float head[8];
-    double dist = 0.0;
-    if (lane == 0) {
-        const double cnt = (double)(nb + (prm.floor_in_parts ? 1 : 0));
-        const double bx = sxm / cnt, by = sym / cnt, z = L.o[2];
-        const double *R = L.R;
-        const double roll = atan2(R[7], R[8]);
-        double sp = -R[6];
-        sp = sp < -1.0 ? -1.0 : (sp > 1.0 ? 1.0 : sp);
-        const double pitch = asin(sp), yaw = atan2(R[3], R[0]);
-        const double dx = prm.walk_target_x - bx, dy = prm.walk_target_y - by;
-        const double theta = atan2(dy, dx);
-        dist = sqrt(dy * dy + dx * dx);
-        const double ang = theta - yaw, c = cos(-yaw), sn = sin(-yaw);
-        const double vx = c * L.base[12] - sn * L.base[13], vy = sn * L.base[12] + c * L.base[13], vz = L.base[14];
-        head[0] = clip5((float)(z - prm.initial_z)); head[1] = clip5((float)sin(ang)); head[2] = clip5((float)cos(ang));
-        head[3] = clip5((float)(0.3 * vx)); head[4] = clip5((float)(0.3 * vy)); head[5] = clip5((float)(0.3 * vz));
-        head[6] = clip5((float)roll); head[7] = clip5((float)pitch);
-        for (int i = 0; i < 8; ++i) { ob[i] = head[i]; finite = finite && isfinite(head[i]); }
-    }
-    const bool all_finite = __all(finite);
+    auto calc_state = [&](bool after_reset, double &dist, int &at_limit, bool &all_finite) {
+        wave_kinematics(tp, m, L, lane, max_depth, false);
+        const double sxm = wave_sum(lane < nb ? L.o[3 * lane] : 0.0), sym = wave_sum(lane < nb ? L.o[3 * lane + 1] : 0.0);
+        float jp = 0.0f, jv = 0.0f;
+        bool lim = false;
+        if (lane < nj) {
+            const double lo = m.joint_lo[lane], hi = m.joint_hi[lane];
+            jp = (float)(2 * (L.q[lane] - 0.5 * (lo + hi)) / (hi - lo));
+            jv = (float)(0.1 * L.qd[lane]);
+            lim = fabsf(jp) > 0.99f;
+        }
+        at_limit = __popcll(__ballot(lim));
+        if (lane < nj) { ob[8 + 2 * lane] = clip5(jp); ob[9 + 2 * lane] = clip5(jv); }
+        bool finite = isfinite(jp) && isfinite(jv);
+        if (lane < nf) {
+            if (after_reset) {
+                ob[8 + 2 * nj + lane] = 0.0f;
+                st.feet_contact[(size_t)lane * n_envs + e] = 0.0f;
+            } else {
+                const float prev = st.feet_contact[(size_t)lane * n_envs + e];
+                ob[8 + 2 * nj + lane] = clip5(prev);
+                float cnow = 0.0f;
+                for (int g = 0; g < tp.n_spheres; ++g)
+                    if (((touch >> g) & 1ull) && tp.sphere_body[g] == tp.foot_body[lane]) cnow = 1.0f;
+                st.feet_contact[(size_t)lane * n_envs + e] = cnow;
+            }
+        }
+        dist = 0.0;
+        if (lane == 0) {
+            const double cnt = (double)(nb + (prm.floor_in_parts ? 1 : 0));
+            const double bx = sxm / cnt, by = sym / cnt, z = L.o[2];
+            const double *R = L.R;
+            const double roll = atan2(R[7], R[8]);
+            double sp = -R[6];
+            sp = sp < -1.0 ? -1.0 : (sp > 1.0 ? 1.0 : sp);
+            const double pitch = asin(sp), yaw = atan2(R[3], R[0]);
+            const double dx = prm.walk_target_x - bx, dy = prm.walk_target_y - by;
+            const double theta = atan2(dy, dx);
+            dist = sqrt(dy * dy + dx * dx);
+            const double ang = theta - yaw, c = cos(-yaw), sn = sin(-yaw);
+            const double vx = c * L.base[12] - sn * L.base[13], vy = sn * L.base[12] + c * L.base[13], vz = L.base[14];
+            head[0] = clip5((float)(z - prm.initial_z)); head[1] = clip5((float)sin(ang)); head[2] = clip5((float)cos(ang));
+            head[3] = clip5((float)(0.3 * vx)); head[4] = clip5((float)(0.3 * vy)); head[5] = clip5((float)(0.3 * vz));
+            head[6] = clip5((float)roll); head[7] = clip5((float)pitch);
+            for (int i = 0; i < 8; ++i) { ob[i] = head[i]; finite = finite && isfinite(head[i]); }
+        }
+        all_finite = __all(finite);
+    };
+    double dist;
+    int at_limit;
+    bool all_finite;
+    calc_state(false, dist, at_limit, all_finite);
+    int ended = 0;
     if (lane == 0) {
         const double alive = ((double)head[0] + prm.initial_z > prm.alive_z) ? prm.alive_bonus : prm.dead_bonus;
         const double pot_old = st.potential[e];
@@ -1112,7 +1150,30 @@ __global__ __launch_bounds__(WV) void walker_step_wave_kernel(mg_walker_topology
             float *r5 = rewards5 + (size_t)e * 5;
             r5[0] = (float)alive; r5[1] = (float)progress; r5[2] = 0.0f; r5[3] = (float)limit_cost; r5[4] = 0.0f;
         }
-        done[e] = (uint8_t)((alive < 0) || !all_finite || (steps >= prm.max_steps));
+        ended = (alive < 0) || !all_finite || (steps >= prm.max_steps);
+        done[e] = (uint8_t)ended;
+    }
+    ended = __builtin_amdgcn_readfirstlane(ended);
+    if (prm.auto_reset && ended) {
+        // fused auto-reset: robot_specific_reset (walker_base.py:13-24) with device-side joint noise; the
+        // returned obs row is the first observation of the next episode (vector-env convention)
+        WSYNC();
+        if (lane < 3) {
+            L.base[lane] = m.body_pos[lane];
+            L.base[12 + lane] = 0.0;
+            L.base[15 + lane] = 0.0;
+        }
+        if (lane < 9) L.base[3 + lane] = m.body_rot[lane];
+        if (lane < nj) {
+            L.q[lane] = reset_joint_noise(prm, e, lane);
+            L.qd[lane] = 0.0;
+        }
+        WSYNC();
+        calc_state(true, dist, at_limit, all_finite);
+        if (lane == 0) {
+            st.potential[e] = -dist / (prm.time_step * prm.frame_skip);
+            st.steps[e] = 0;
+        }
     }
     // ---- state store ----------------------------------------------------------------------------------
     if (lane < 3) {

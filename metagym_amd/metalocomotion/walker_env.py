@@ -44,7 +44,8 @@ class WalkerBatchEnv(object):
     initial_z = None              # None -> height of the base at reset (walker_base.py:44-45)
 
     def __init__(self, num_envs=1, device="cuda", frame_skip=4, time_step=0.005, enable_render=False,
-                 max_steps=2000, assets_dir=None, solver_iterations=5, mapping="wave", self_collision=True):
+                 max_steps=2000, assets_dir=None, solver_iterations=5, mapping="wave", self_collision=True,
+                 auto_reset=False, seed=0, env_id_base=0):
         self._lib = _lib.load()
         self.num_envs = int(num_envs)
         self.device = torch.device(device)
@@ -69,6 +70,10 @@ class WalkerBatchEnv(object):
                     self.ood_tasks.append(f)
         self._robot_set = False
         self.np_random = np.random.RandomState()
+        # fused auto-reset: finished envs restart inside the step launch with device-side (Philox) joint
+        # noise keyed by (seed, env_id_base + env, step), so a sharded job reproduces the unsharded one
+        self.auto_reset, self.seed_value, self.env_id_base = bool(auto_reset), int(seed), int(env_id_base)
+        self.global_step = 0
 
     def _robot_assets(self):
         return os.path.join(self.assets_dir, self.robot_dir) if self.assets_dir else None
@@ -147,6 +152,8 @@ class WalkerBatchEnv(object):
         p.mapping = 1 if self.mapping == "wave" else 0
         p.self_collision = int(self.self_collision)
         p.self_friction = float(m0.geom_friction) ** 2            # Bullet multiplies the two geoms' friction
+        p.auto_reset = int(self.auto_reset)
+        p.seed, p.env_id_base = self.seed_value & 0xFFFFFFFFFFFFFFFF, self.env_id_base
         self._params_c = p
         self._obs = torch.zeros(N, self.obs_dim, dtype=torch.float32, device=dev)
         self._reward = torch.zeros(N, dtype=torch.float32, device=dev)
@@ -189,6 +196,8 @@ class WalkerBatchEnv(object):
     def step(self, action):
         a = torch.as_tensor(action, dtype=torch.float32, device=self.device).contiguous()
         assert a.shape == (self.num_envs, self.n_joints), "action must be [num_envs, n_joints]"
+        self._params_c.step_index = self.global_step
+        self.global_step += 1
         rc = self._lib.mg_walker_step(self._topo, self._models_c, self._params_c, self.num_envs, self._state_c,
                                       _lib.ptr(a), _lib.ptr(self._obs), _lib.ptr(self._reward),
                                       _lib.ptr(self._rewards5), _lib.ptr(self._done),

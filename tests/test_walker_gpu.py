@@ -184,3 +184,52 @@ def test_self_collision_matches_oracle(mapping):
         outcomes[self_on] = env.q.cpu().numpy().copy()
         assert saw_self == self_on
     assert np.abs(outcomes[True] - outcomes[False]).max() > 1e-2
+
+
+@pytest.mark.parametrize("mapping", ["wave", "lane"])
+def test_auto_reset_equals_explicit_masked_reset(mapping):
+    """Fused auto-reset: an env that ends its episode restarts inside the launch. Against a
+    twin env driven with explicit `reset(mask=done, joint_noise=<the noise the kernel drew>)`: identical
+    state and observations afterwards; the drawn joint angles are U(-0.1, 0.1); reward/done of the
+    ending step are unaffected; noise is keyed by global env id (shard invariance)."""
+    models = [MODELS[k] for k in ("humanoid", "humanoid_tra_000")]
+    n, T = 24, 12
+    auto = _make("MetaHumanoidEnv", models, n, max_steps=5, mapping=mapping, auto_reset=True, seed=11)
+    twin = _make("MetaHumanoidEnv", models, n, max_steps=5, mapping=mapping)
+    rs = np.random.RandomState(3)
+    noise = rs.uniform(-0.1, 0.1, (n, auto.n_joints))
+    o0, o1 = auto.reset(joint_noise=noise), twin.reset(joint_noise=noise)
+    assert torch.equal(o0, o1)
+    ended_total = 0
+    for t in range(T):
+        a = torch.as_tensor(rs.uniform(-1, 1, (n, auto.n_joints)).astype(np.float32)).cuda()
+        oa, ra, da, _ = auto.step(a)
+        ob, rb, db, _ = twin.step(a)
+        assert torch.equal(ra, rb) and torch.equal(da, db)
+        d = db.clone()
+        if bool(d.any()):
+            ended_total += int(d.sum())
+            q_new = auto.q.T[d].cpu().numpy()                  # the joint noise the kernel drew
+            assert (np.abs(q_new) <= 0.1).all() and np.abs(q_new).max() > 0.01
+            jn = auto.q.T.cpu().numpy().copy()
+            ob = twin.reset(mask=d, joint_noise=jn).clone()
+        else:
+            ob = ob.clone()
+        assert torch.equal(oa[d], ob[d])                       # first obs of the new episode
+        assert torch.equal(oa[~d], ob[~d])
+        sa, sb = auto.state_dict(), twin.state_dict()
+        for k in sa:
+            assert torch.equal(sa[k], sb[k]), (t, k)
+    assert ended_total >= n                                    # max_steps=5: everyone restarted at least once
+    # shard invariance: envs 12..23 run as their own shard draw the same noise
+    full = _make("MetaHumanoidEnv", models, n, max_steps=2, mapping=mapping, auto_reset=True, seed=5)
+    half = _make("MetaHumanoidEnv", models, n // 2, task_ids=full.task_id[n // 2:].cpu(), max_steps=2, mapping=mapping,
+                 auto_reset=True, seed=5, env_id_base=n // 2)
+    full.reset(joint_noise=noise)
+    half.reset(joint_noise=noise[n // 2:])
+    for t in range(3):
+        a = torch.as_tensor(rs.uniform(-1, 1, (n, full.n_joints)).astype(np.float32)).cuda()
+        of, _, df, _ = full.step(a)
+        oh, _, dh, _ = half.step(a[n // 2:])
+        assert torch.equal(of[n // 2:], oh) and torch.equal(df[n // 2:], dh)
+    assert torch.equal(full.q[:, n // 2:], half.q)
