@@ -336,6 +336,7 @@ struct ViewK {
     double max_vision, max_vision_lo, inv_max_vision, l_focal, text_size, inv_text_size, half_h, half_v, pixel_size;
     double col_dist;
     int text_size_pow2;
+    double eff_max;    // bound on the floor / ceiling cast distance: max_vision / cos(fov / 2)
     const double *col_cos, *col_sin;
     float ori_sin[4], ori_cos[4];
     const uint32_t *tex, *ceil_tex;
@@ -537,7 +538,7 @@ __device__ __forceinline__ void pixel_pass(const ViewK &vk, const Task &t, doubl
                                            const uint8_t *texts, const double *transp, const ColRec &wc,
                                            const uint2 *entries, int k, int d_v, double cs, double inv_cs,
                                            int cs_pow2, double text_to_cell, double inv_ttc, int ttc_pow2,
-                                           int &R, int &G, int &B) {
+                                           int fast_tex, double tex_scale, int cell_shift, int &R, int &G, int &B) {
     const int n = t.n, TS = vk.TS;
     R = G = B = 0;
     bool tflag = false;
@@ -559,27 +560,53 @@ __device__ __forceinline__ void pixel_pass(const ViewK &vk, const Task &t, doubl
         }
         const double hit_x = eff * (double)wc.cos_abs + pos_x;
         const double hit_y = eff * (double)wc.sin_abs + pos_y;
-        const double fi = cs_pow2 ? hit_x * inv_cs : hit_x / cs;
-        const double fj = cs_pow2 ? hit_y * inv_cs : hit_y / cs;
-        const int i = cell_index(fi), j = cell_index(fj);
-        const bool inside = (unsigned)i < (unsigned)n && (unsigned)j < (unsigned)n;
-        if (rk.kind == 1) {
-            if (inside) {
-                const double alpha = a * rk.light;
-                double d_i = fi - floor(fi), d_j = fj - floor(fj);
+        // Cell (i, j) and texel (ti, tj) of the hit point. When cell size, texture size and texture
+        // resolution are powers of two (the stock task: 2.0, 1.0, 64) every scaling below is exact and
+        // frac(frac(x / cs) * cs / ts) == frac(x / ts), so for x >= 0
+        //     floor(x * TS / ts) = (cell index << cell_shift) | (texel index)
+        // and one multiply + one convert + two integer ops per axis replace the chain of
+        // divide / floor / subtract / scale steps (bit-identical; the general chain stays for other sizes).
+        int i, j, ti, tj;
+        if (fast_tex && hit_x >= 0.0 && hit_y >= 0.0) {
+            const int xi = cell_index(hit_x * tex_scale), xj = cell_index(hit_y * tex_scale);
+            i = xi >> cell_shift;
+            j = xj >> cell_shift;
+            ti = xi & (TS - 1);
+            tj = xj & (TS - 1);
+        } else {
+            const double fi = cs_pow2 ? hit_x * inv_cs : hit_x / cs;
+            const double fj = cs_pow2 ? hit_y * inv_cs : hit_y / cs;
+            i = cell_index(fi);
+            j = cell_index(fj);
+            double d_i, d_j;
+            if (rk.kind == 1) {                                               // floor :107-116
+                d_i = fi - floor(fi);
+                d_j = fj - floor(fj);
                 d_i = ttc_pow2 ? d_i * inv_ttc : d_i / text_to_cell;
                 d_j = ttc_pow2 ? d_j * inv_ttc : d_j / text_to_cell;
                 d_i -= floor(d_i);
                 d_j -= floor(d_j);
-                d_i *= TS;
-                d_j *= TS;
-                // 24-bit multiplies are full rate (v_mad_u32_u24); texture rows and cells are far below 2^24
-                const uint32_t tx = vk.tex[__umul24(__umul24((uint32_t)texts[__umul24(i, n) + j], TS) + (uint32_t)(int)d_i, TS) + (uint32_t)(int)d_j];
+            } else {                                                          // ceiling :139-143
+                const double gi = vk.text_size_pow2 ? hit_x * vk.inv_text_size : hit_x / vk.text_size;
+                const double gj = vk.text_size_pow2 ? hit_y * vk.inv_text_size : hit_y / vk.text_size;
+                d_i = gi - floor(gi);
+                d_j = gj - floor(gj);
+            }
+            ti = cell_index(d_i * TS);
+            tj = cell_index(d_j * TS);
+        }
+        const bool inside = (unsigned)i < (unsigned)n && (unsigned)j < (unsigned)n;
+        // 24-bit multiplies are full rate (v_mad_u32_u24); cells and texture rows are far below 2^24
+        const uint32_t cell = __umul24(i, n) + j;
+        if (rk.kind == 1) {
+            if (inside) {
+                const double alpha = a * rk.light;
+                const uint32_t tx = vk.tex[__umul24(__umul24((uint32_t)texts[cell], TS) + (uint32_t)ti, TS) + (uint32_t)tj];
                 const double oma = 1.0 - alpha;
                 R = (int)(rk.light * (oma * tex_r(tx)));
                 G = (int)(rk.light * (oma * tex_g(tx)));
                 B = (int)(rk.light * (oma * tex_b(tx)));
-                const double tr = transp[__umul24(i, n) + j];
+                const double tr = transp[cell];
                 if (tr > 0.01) {
                     const double tf = tr * 0.50 + 0.10, om = 1.0 - tf;
                     R = (int)(om * (double)R);
@@ -589,18 +616,13 @@ __device__ __forceinline__ void pixel_pass(const ViewK &vk, const Task &t, doubl
                 }
             }
         } else {
-            const double gi = vk.text_size_pow2 ? hit_x * vk.inv_text_size : hit_x / vk.text_size;
-            const double gj = vk.text_size_pow2 ? hit_y * vk.inv_text_size : hit_y / vk.text_size;
-            double d_i = gi - floor(gi), d_j = gj - floor(gj);
-            d_i *= TS;
-            d_j *= TS;
-            const uint32_t tx = vk.ceil_tex[__umul24((uint32_t)(int)d_i, TS) + (uint32_t)(int)d_j];
+            const uint32_t tx = vk.ceil_tex[__umul24((uint32_t)ti, TS) + (uint32_t)tj];
             const double oma = 1.0 - a;
             R = (int)(rk.light * (oma * tex_r(tx)));
             G = (int)(rk.light * (oma * tex_g(tx)));
             B = (int)(rk.light * (oma * tex_b(tx)));
             if (inside) {
-                const double tr = transp[__umul24(i, n) + j];
+                const double tr = transp[cell];
                 if (tr > 0) {
                     const double tf = tr * 0.50 + 0.10, om = 1.0 - tf;
                     R = (int)(om * (double)R);
@@ -739,6 +761,13 @@ __global__ __launch_bounds__(MZ_BLOCK) void maze3d_step_kernel(mg_maze_tasks T, 
     const double text_to_cell = vk.text_size / cs;
     const int ttc_pow2 = (frexp(text_to_cell, &ex) == 0.5);
     const double inv_ttc = 1.0 / text_to_cell;
+    // integer texel / cell addressing (see pixel_pass): all three sizes powers of two, cells at least one
+    // texture wide, and every reachable coordinate times TS / text_size far below 2^31
+    const double tex_scale = (double)vk.TS * vk.inv_text_size;
+    const int ts_pow2 = (vk.TS & (vk.TS - 1)) == 0;
+    const int fast_tex = cs_pow2 && ttc_pow2 && vk.text_size_pow2 && ts_pow2 && inv_ttc >= 1.0 &&
+                         (vk.eff_max + cs * (double)t.n) * tex_scale < 1073741824.0;
+    const int cell_shift = fast_tex ? ilogb(inv_ttc * (double)vk.TS) : 0;
 
     int lb_x0 = 0, lb_x1 = 0, lb_y0 = 0, lb_y1 = 0;   // life bar rectangle, maze_discrete_3d.py:118-126
     if (task_type == MG_MAZE_SURVIVAL) {
@@ -781,7 +810,7 @@ __global__ __launch_bounds__(MZ_BLOCK) void maze3d_step_kernel(mg_maze_tasks T, 
                 rk.ys = row_tab[3 * d_r + 2];
                 int R, G, B;
                 pixel_pass(vk, t, pos_x, pos_y, rk, texts, transp, wc, entries, k, d_v, cs, inv_cs, cs_pow2, text_to_cell,
-                           inv_ttc, ttc_pow2, R, G, B);
+                           inv_ttc, ttc_pow2, fast_tex, tex_scale, cell_shift, R, G, B);
                 if (in_lb_x && d_v >= lb_y0 && d_v < lb_y1) { R = 255; G = 0; B = 0; }
                 const uint32_t off = col_off + (uint32_t)d_v * px_bytes;
                 if (row_ok) {
@@ -938,6 +967,7 @@ extern "C" int mg_maze3d_step(const mg_maze_tasks *T, const mg_maze_view *view, 
     vk.inv_text_size = 1.0 / view->text_size;
     int ex;
     vk.text_size_pow2 = (frexp(view->text_size, &ex) == 0.5);
+    vk.eff_max = view->max_vision * sqrt(1.0 + view->tan_half_fov * view->tan_half_fov) * 1.0001;
     vk.half_h = view->tan_half_fov * view->l_focal;              // ray_caster_utils.py:68
     vk.half_v = vk.half_h * vk.V / vk.H;                         // :69
     vk.pixel_size = 2.0 * vk.half_h / vk.H;                      // :70
