@@ -572,13 +572,10 @@ __global__ __launch_bounds__(BLOCK) void quadrotor_step_kernel(QuadK k, mg_quadr
                 fail = failure_code(k, s);
             }
         }
-        float obs[OBS_DIM + 3];
-        observe(k, s, obs);
         const bool vel_task = k.task == MG_QUADROTOR_TASK_VELOCITY_CONTROL;
-        if (vel_task) {          // _update_state env.py:262-273: next target at min(ct, nt-1), ct already incremented
-            const int tn = ct < k.nt - 1 ? ct : k.nt - 1;
-            obs[16] = k.vtargets[3 * tn]; obs[17] = k.vtargets[3 * tn + 1]; obs[18] = k.vtargets[3 * tn + 2];
-        }
+        // _update_state env.py:262-273: the observation's target entries come from min(ct, nt-1) with ct
+        // already incremented and not yet cleared by the episode end
+        const int tn_step = ct < k.nt - 1 ? ct : k.nt - 1;
         double reward = 0.0;
         int done = 1;
         if (fail == 0 && vel_task) {
@@ -620,15 +617,17 @@ __global__ __launch_bounds__(BLOCK) void quadrotor_step_kernel(QuadK k, mg_quadr
         } else {
             ct = 0;
         }
+        // Reward / done above read the stepped state only, so the observation is computed ONCE, after the
+        // optional in-place reset: stepped state for running envs, and — vector-env convention — the first
+        // observation of the next episode for the envs that just finished.
+        int tn = tn_step;
         if (k.auto_reset && done) {
-            // vector-env convention: the returned obs is the first observation of the next episode
             reset_lane_random(k, s, el, k.step_index + (uint64_t)t);
-            observe(k, s, obs);
-            if (vel_task) {
-                const int tn = ct < k.nt - 1 ? ct : k.nt - 1;
-                obs[16] = k.vtargets[3 * tn]; obs[17] = k.vtargets[3 * tn + 1]; obs[18] = k.vtargets[3 * tn + 2];
-            }
+            tn = ct < k.nt - 1 ? ct : k.nt - 1;
         }
+        float obs[OBS_DIM + 3];
+        observe(k, s, obs);
+        if (vel_task) { obs[16] = k.vtargets[3 * tn]; obs[17] = k.vtargets[3 * tn + 1]; obs[18] = k.vtargets[3 * tn + 2]; }
         store_obs_wave(tile, obs, io.obs + off * k.obs_dim, n, e, k.obs_dim);
         if (live) {
             if (io.reward) io.reward[off + e] = (float)reward;
