@@ -258,7 +258,7 @@ typedef struct { float pos[3], vel[3], omega[3], propw[4], R[9], Rinv[9]; } qo_s
 static void mat3_vec_f32_plain(const float *M, const float *x, float *y) { mat3_vec_f32(M, x, y); }
 
 static void qo_substep_f32state(const qo_consts *c, qo_state32 *s, const float act[4]) {
-    float prop_force_z = 0.0f, prop_torque[3] = {0, 0, 0}, prop_powers[4], me[4];
+    float prop_force_z = 0.0f, prop_torque[3] = {0, 0, 0}, me[4];   /* self.power is not part of the recorded targets */
     const float phi32 = (float)c->phi, phi_over_ra32 = (float)(c->phi / c->ra), inv_jm32 = (float)(1.0 / c->jm);
     const float mm32 = (float)c->mm, prec32 = (float)c->precision, ct0_32 = (float)c->ct0, ct1_32 = (float)c->ct1;
     const float ct2_32 = (float)c->ct2;
@@ -269,7 +269,6 @@ static void qo_substep_f32state(const qo_consts *c, qo_state32 *s, const float a
         const float eff32 = (float)eff_act;
         float phi_w = phi32 * s->propw[i];
         me[i] = phi_over_ra32 * (eff32 - phi_w);
-        prop_powers[i] = fabsf(me[i] / phi32 * eff32);
         float d_prop_w = inv_jm32 * (me[i] - mm32);
         float w_m = s->propw[i] + prec32 * d_prop_w;
         const float *pc = &c->prop_coord[3 * i];
