@@ -118,6 +118,28 @@ def gen_maze(gym):
         np.savez_compressed(os.path.join(OUT, name), **d)
         print("wrote", name, "dones", int(d["done"].sum()), "obs max", int(d["obs"].max()))
 
+    # ---- non-default renderer parameters ---------------------------------------------------------
+    # MazeCoreDiscrete3D takes max_vision_range / fol_angle (maze_discrete_3d.py:18-37); the gym wrapper only
+    # forwards the resolution, so the core of the registered env is swapped for one built with other
+    # values (unmodified reference classes). 11x11 maze with 1.5-wide cells (not a power of two), dense food.
+    from metagym.metamaze.envs.maze_discrete_3d import MazeCoreDiscrete3D
+    for task_type, seed, res, vision, fov in (("SURVIVAL", 7, (90, 50), 6.0, 0.80), ("ESCAPE", 8, (37, 150), 20.0, 0.40)):
+        task = _sample_task(seed, n=11, allow_loops=True, crowd_ratio=0.3, cell_size=1.5, wall_height=2.7,
+                            agent_height=1.0, step_reward=-0.01, goal_reward=1.0, food_density=0.15, food_interval=4)
+        env = gym.make("meta-maze-discrete-3D-v0", max_steps=40, enable_render=False, task_type=task_type,
+                       resolution=res)
+        env.maze_core = MazeCoreDiscrete3D(max_vision_range=vision, fol_angle=fov * 3.1415926, resolution_horizon=res[0],
+                                           resolution_vertical=res[1], max_steps=40, task_type=task_type)
+        actions = np.random.RandomState(seed + 1).choice(4, size=40, p=[0.25, 0.25, 0.1, 0.4])
+        d = _run(env, task, actions, "disc", 2)
+        d["resolution"] = np.asarray(res, np.int32)
+        d["max_steps"] = np.int32(40)
+        d["max_vision"] = np.float64(vision)
+        d["fol_angle"] = np.float64(fov * 3.1415926)
+        name = "maze3d_disc_%s_s%d_%dx%d.npz" % (task_type.lower(), seed, res[0], res[1])
+        np.savez_compressed(os.path.join(OUT, name), **d)
+        print("wrote", name, "dones", int(d["done"].sum()), "obs max", int(d["obs"].max()))
+
     # ---- MetaMazeContinuous3D ---------------------------------------------------------------------
     for task_type, seed in (("ESCAPE", 5), ("SURVIVAL", 6)):
         task = _sample_task(seed, n=9, allow_loops=False, step_reward=-0.001, goal_reward=1.0,

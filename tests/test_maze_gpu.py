@@ -84,6 +84,8 @@ def test_maze3d_discrete_matches_reference_pixel_exact(path):
     res = tuple(int(x) for x in g["resolution"])
     env = metagym_amd.make("meta-maze-discrete-3D-v0", num_envs=1, device="cuda:0", max_steps=int(g["max_steps"]),
                            resolution=res, task_type=_tt(path))
+    if "max_vision" in g.files:      # goldens recorded with non-default renderer parameters
+        env.max_vision_range, env.fol_angle = float(g["max_vision"]), float(g["fol_angle"])
     obs0, out = _replay(env, g)
     assert obs0.dtype == np.int32 and obs0.shape == res + (3,)
     assert np.array_equal(obs0, g["obs0"]), "reset frame: %d values differ" % int((obs0 != g["obs0"]).sum())

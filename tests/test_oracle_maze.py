@@ -48,7 +48,10 @@ def test_maze2d_bit_exact(path):
 def _view(g):
     tex = np.load(os.path.join(GOLDEN, "maze_textures.npz"))
     H, V = (int(x) for x in g["resolution"])
-    return mo.View(tex["grounds"], tex["ceil"], H, V)
+    kw = {}
+    if "max_vision" in g.files:      # goldens recorded with non-default renderer parameters
+        kw = dict(max_vision=float(g["max_vision"]), fov=float(g["fol_angle"]))
+    return mo.View(tex["grounds"], tex["ceil"], H, V, **kw)
 
 
 @pytest.mark.parametrize("path", _files("maze3d_disc_*.npz"))
