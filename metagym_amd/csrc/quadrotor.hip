@@ -83,8 +83,11 @@ __device__ __forceinline__ void mv_f32f64(const float *M, const double *x, doubl
 }
 
 __device__ __forceinline__ void mv_f32(const float *M, const float *x, float *y) {
+    // np.matmul(f32[3,3], f32[3]) -> OpenBLAS sgemv: rows 0 and 1 (a SIMD pair) are the plain sum without
+    // FMA, row 2 (scalar tail) uses the dgemv-style association (oracle/quadrotor_oracle.c documents the probe)
 #pragma unroll
-    for (int r = 0; r < 3; ++r) y[r] = (M[3 * r] * x[0] + M[3 * r + 1] * x[1]) + M[3 * r + 2] * x[2];
+    for (int r = 0; r < 2; ++r) y[r] = (M[3 * r] * x[0] + M[3 * r + 1] * x[1]) + M[3 * r + 2] * x[2];
+    y[2] = fmaf(M[8], x[2], fmaf(M[6], x[0], M[7] * x[1]));
 }
 
 __device__ __forceinline__ void mm_f32(const float *A, const float *B, float *C) {
@@ -109,7 +112,12 @@ __device__ __forceinline__ void cross_f32(const float *a, const float *b, float 
 __device__ __forceinline__ double norm3(const double *x) {
     return sqrt(fma(x[2], x[2], fma(x[1], x[1], x[0] * x[0])));
 }
-__device__ __forceinline__ float sumsq3(const float *x) { return fmaf(x[2], x[2], fmaf(x[1], x[1], x[0] * x[0])); }
+// np.linalg.norm(f32[3])^2 = OpenBLAS sdot(x, x): every product rounded to float32, the three products
+// accumulated in double, the sum rounded to float32
+__device__ __forceinline__ float sumsq3(const float *x) {
+    const float p0 = x[0] * x[0], p1 = x[1] * x[1], p2 = x[2] * x[2];
+    return (float)(((double)p0 + (double)p1) + (double)p2);
+}
 
 // np.linalg.inv on a float32 matrix (quadrotorsim.py:207): numpy promotes to float64, solves, and
 // casts back, i.e. it returns the correctly rounded f32 inverse. Same here: adjugate / det in f64
@@ -724,7 +732,8 @@ int fold_config(const mg_quadrotor_config *c, QuadK *k, bool need_targets = true
     }
     for (int i = 0; i < 4; ++i) {
         const float *p = &c->prop_coord[3 * i];
-        k->lm[i] = sqrtf(fmaf(p[2], p[2], fmaf(p[1], p[1], p[0] * p[0])));
+        const float p0 = p[0] * p[0], p1 = p[1] * p[1], p2 = p[2] * p[2];      // sdot: f32 products, double sum
+        k->lm[i] = sqrtf((float)(((double)p0 + (double)p1) + (double)p2));
     }
     for (int i = 0; i < 12; ++i) k->pc[i] = c->prop_coord[i];
     host_inv3_f32(c->inertia, k->iinv);

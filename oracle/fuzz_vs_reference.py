@@ -1,0 +1,143 @@
+#!/usr/bin/env python3
+"""Differential fuzz of the CPU oracles against the LIVE, unmodified reference (build container only:
+needs /root/reference). TEST INFRASTRUCTURE. Complements the committed golden vectors: random simulator
+configs / view parameters are pushed through both the reference and the oracle and compared.
+
+    python oracle/fuzz_vs_reference.py [--quad 60] [--maze 40] [--seed 0]
+
+The summary of the run committed for this round is profiles/r01/fuzz_oracle_vs_reference.txt."""
+import argparse
+import json
+import os
+import random
+import sys
+import tempfile
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, HERE)
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "scripts"))
+import gen_golden  # noqa: E402
+
+
+def fuzz_quadrotor(gym, n_cfg, seed):
+    from fuzz_quadrotor import random_config
+    from oracle import quadrotor as qo
+    bad_cfg = 0
+    worst_obs = 0.0
+    nonang = [i for i in range(16) if i not in (12, 13, 14)]
+    nonang_bad = 0
+    for c in range(n_cfg):
+        rs = np.random.RandomState(seed * 100003 + c)      # every config reproducible on its own
+        cfg = random_config(rs, stock_shape=bool(rs.rand() < 0.3))
+        cfg["fail"] = {"velocity": 100.0, "w": 1000.0, "range": 1000.0}     # the reference raises on failure
+        with tempfile.NamedTemporaryFile("w", suffix=".json", delete=False) as f:
+            json.dump(cfg, f)
+            path = f.name
+        env = gym.make("quadrotor-v0", task="hovering_control", nt=1000, simulator_conf=path)
+        os.unlink(path)
+        np.random.seed(int(rs.randint(1 << 30)))
+        env.reset()
+        sim = env.simulator
+        st0 = gen_golden._sim_state(sim)
+        oc = qo.consts_from_config(cfg, nt=1000)
+        st = qo.make_states(st0["pos"][None], st0["vel"][None], st0["omega"][None], st0["propw"][None], st0["R"][None])
+        ct = np.zeros(1, np.int32)
+        ok = True
+        for t in range(25):
+            a = rs.uniform(0.0, 16.0, 4).astype(np.float32)
+            obs, reward, done, info = env.step(a)
+            o_obs, o_rew, o_done, o_failed = qo.batch_env_step(oc, st, ct, a[None])
+            r = gen_golden._sim_state(sim)
+            o = qo.states_to_arrays(st)
+            for k in ("pos", "vel", "omega", "propw", "R"):
+                ok = ok and np.array_equal(o[k][0], r[k])
+            ok = ok and float(o_rew[0]) == float(reward) and bool(o_done[0]) == bool(done)
+            ok = ok and np.float32(o["power"][0]) == np.float32(sim.power)
+            nonang_bad += int((o_obs[0][nonang] != np.asarray(obs, np.float32)[nonang]).sum())
+            worst_obs = max(worst_obs, float(np.max(np.abs(o_obs[0] - np.asarray(obs, np.float32))
+                                                    / np.maximum(1.0, np.abs(np.asarray(obs, np.float32))))))
+            if done:
+                break
+        bad_cfg += 0 if ok else 1
+        if not ok:
+            print("  quadrotor cfg", c, "NOT bit-identical (precision %g, off-diagonal inertia %s, stock shape %s)"
+                  % (cfg["precision"], cfg["inertia"]["xy"] != 0, cfg["thrust"]["CT"][2] == "0.0"))
+    print("quadrotor: %d / %d random configs with a state / reward / done / power difference; %d differing "
+          "observation entries outside the three atan2f angles; worst relative angle difference %.2e"
+          % (bad_cfg, n_cfg, nonang_bad, worst_obs))
+    return bad_cfg
+
+
+def fuzz_maze(gym, n_cfg, seed):
+    from metagym.metamaze import MazeTaskSampler
+    from metagym.metamaze.envs.maze_discrete_3d import MazeCoreDiscrete3D
+    from metagym.metamaze.envs.maze_task import MAZE_TASK_MANAGER
+    from oracle import maze as mo
+    tex = np.asarray(MAZE_TASK_MANAGER.grounds).astype(np.uint8)
+    ceil = np.asarray(MAZE_TASK_MANAGER.ceil, np.uint8)
+    bad_cfg = tot_bad = tot = 0
+    for c in range(n_cfg):
+        rs = np.random.RandomState(seed * 100003 + 50000 + c)
+        n = int(rs.choice([7, 9, 11, 15]))
+        cell = float(rs.choice([0.75, 1.0, 1.5, 2.0, 3.0]))
+        wall_h = cell * float(rs.choice([1.0, 1.6, 2.5]))
+        agent_h = wall_h * float(rs.choice([0.3, 0.5, 0.7]))
+        H, V = int(rs.randint(6, 40)), int(rs.randint(6, 40))
+        fov = float(rs.uniform(0.3, 0.85)) * 3.1415926
+        vision = float(rs.choice([3.0, 6.0, 12.0, 25.0]))
+        task_type = "SURVIVAL" if rs.rand() < 0.6 else "ESCAPE"
+        task_seed = int(rs.randint(1 << 30))
+        random.seed(task_seed)
+        np.random.seed(task_seed)
+        task = MazeTaskSampler(n=n, allow_loops=bool(rs.rand() < 0.5), crowd_ratio=float(rs.uniform(0.1, 0.5)),
+                               cell_size=cell, wall_height=wall_h, agent_height=agent_h, step_reward=-0.01,
+                               goal_reward=1.0, food_density=float(rs.choice([0.0, 0.05, 0.3])), food_interval=3)
+        env = gym.make("meta-maze-discrete-3D-v0", max_steps=30, enable_render=False, task_type=task_type, resolution=(H, V))
+        env.maze_core = MazeCoreDiscrete3D(max_vision_range=vision, fol_angle=fov, resolution_horizon=H,
+                                           resolution_vertical=V, max_steps=30, task_type=task_type)
+        env.set_task(task)
+        obs = np.asarray(env.reset())
+        tt = mo.TASK_TYPES[task_type]
+        ot = mo.Task(**task._asdict())
+        st = mo.State(ot)
+        mo.reset(ot, tt, st)
+        view = mo.View(tex, ceil, H, V, max_vision=vision, fov=fov)
+        bad = int((mo.observe_3d(ot, tt, view, st, 0) != obs).sum())
+        px = obs.size
+        trans_ok = True
+        for t in range(8):
+            a = int(rs.choice(4, p=[0.25, 0.25, 0.1, 0.4]))
+            obs, reward, done, info = env.step(a)
+            r, d = mo.step_disc3d(ot, tt, 30, st, a)
+            trans_ok = trans_ok and r == reward and d == bool(done)
+            bad += int((mo.observe_3d(ot, tt, view, st, 0) != np.asarray(obs)).sum())
+            px += np.asarray(obs).size
+            if done:
+                break
+        tot_bad += bad
+        tot += px
+        if bad or not trans_ok:
+            bad_cfg += 1
+            print("  maze cfg %d n=%d cell=%.2f %dx%d fov=%.3f vision=%.1f %s: %d differing values, transitions %s"
+                  % (c, n, cell, H, V, fov, vision, task_type, bad, "ok" if trans_ok else "DIFFER"))
+    print("maze3d: %d / %d random configs differ; %d / %d pixel values differ" % (bad_cfg, n_cfg, tot_bad, tot))
+    return bad_cfg
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--quad", type=int, default=60)
+    ap.add_argument("--maze", type=int, default=40)
+    ap.add_argument("--seed", type=int, default=0)
+    args = ap.parse_args()
+    gym = gen_golden._import_reference()
+    bad = fuzz_quadrotor(gym, args.quad, args.seed) + fuzz_maze(gym, args.maze, args.seed)
+    sys.exit(1 if bad else 0)
+
+
+if __name__ == "__main__":
+    main()

@@ -25,10 +25,10 @@
  * propeller speed f32, rotation matrix f32 (quadrotorsim.py:20-28,239-258).
  * Compile with -ffp-contract=off: NumPy's elementwise ops never fuse a*b+c; the FMAs that the
  * BLAS-backed ops do use are written out explicitly (see the helpers below).
- * What could not be restated bit-for-bit: the association OpenBLAS uses for the f32 3x3@3 gemv
- * (only feeds the body-position observation) and libm's atan2f; both sit at the 1-ulp level and are
- * covered by the 1e-5 relative tolerance the north star states. The simulator STATE (pos, vel,
- * omega, propw, R) is bit-identical to the reference over the 1000-step golden rollouts.
+ * What is not restated bit-for-bit: libm's atan2f (three observation angles, <= 1 ulp). Everything
+ * else — the simulator STATE (pos, vel, omega, propw, R), power, reward, done, the other 13
+ * observation entries and the velocity_control target trajectory — is bit-identical to the reference
+ * over the golden rollouts and over 300 random simulator configs (oracle/fuzz_vs_reference.py).
  */
 #include <math.h>
 #include <stdint.h>
@@ -42,8 +42,13 @@
  * reproduced NumPy 2.2.6 + its bundled OpenBLAS bit-for-bit on 1000/1000 random inputs in the
  * build container (probe recorded in DESIGN.md §Oracle): sgemm 3x3@3x3 and dnrm via ddot are
  * left-to-right FMA chains; dgemv on a widened f32 matrix is fma(M2,x2, fma(M0,x0, M1*x1)).
- * The f32 3x3@3 product did not match any single FMA association (plain order matched most
- * often, 64 %), so it is kept plain. All of this is at the 1-ulp level. */
+ * sgemv 3x3@3 (OpenBLAS 0.3.29 Haswell kernel) treats the rows differently: rows 0 and 1 (a SIMD
+ * pair) are the plain (M0*x0 + M1*x1) + M2*x2 without FMA, row 2 (scalar tail) is
+ * fmaf(M2,x2, fmaf(M0,x0, M1*x1)) — 2000/2000 per row. np.linalg.norm of a float32 vector is
+ * sqrt(x.dot(x)) with OpenBLAS sdot, which rounds each product to float32 and accumulates the
+ * products in DOUBLE before rounding the sum to float32 (5000/5000). Both were found by
+ * oracle/fuzz_vs_reference.py (random propeller geometry makes the arm length l_m sensitive to it;
+ * the stock +-0.18 arms are not). All of this is at the 1-ulp level. */
 
 static void mat3_vec_f32f64(const float *M, const double *x, double *y) {
     /* np.matmul(f32[3,3], f64[3]) -> f64: M is widened, then dgemv */
@@ -52,8 +57,10 @@ static void mat3_vec_f32f64(const float *M, const double *x, double *y) {
 }
 
 static void mat3_vec_f32(const float *M, const float *x, float *y) {
-    for (int r = 0; r < 3; ++r)
+    /* np.matmul(f32[3,3], f32[3]) -> sgemv: rows 0, 1 plain; row 2 with the dgemv-style FMA association */
+    for (int r = 0; r < 2; ++r)
         y[r] = (M[3 * r + 0] * x[0] + M[3 * r + 1] * x[1]) + M[3 * r + 2] * x[2];
+    y[2] = fmaf(M[8], x[2], fmaf(M[6], x[0], M[7] * x[1]));
 }
 
 static void mat3_mul_f32(const float *A, const float *B, float *C) {
@@ -73,7 +80,11 @@ static void cross_f32(const float *a, const float *b, float *c) {
 }
 
 static double norm3_f64(const double *x) { return sqrt(fma(x[2], x[2], fma(x[1], x[1], x[0] * x[0]))); }
-static float norm3_f32(const float *x) { return sqrtf(fmaf(x[2], x[2], fmaf(x[1], x[1], x[0] * x[0]))); }
+static float norm3_f32(const float *x) {
+    /* np.linalg.norm(f32[3]) = sqrt(sdot(x, x)): float32 products summed in double, sum rounded to float32 */
+    const float p0 = x[0] * x[0], p1 = x[1] * x[1], p2 = x[2] * x[2];
+    return sqrtf((float)(((double)p0 + (double)p1) + (double)p2));
+}
 
 /* 3x3 inverse of a float32 matrix (np.linalg.inv, quadrotorsim.py:207).
  * numpy.linalg.inv does NOT run LAPACK in float32: linalg._commonType promotes float32 input to

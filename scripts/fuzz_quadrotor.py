@@ -12,13 +12,10 @@ import sys
 import tempfile
 
 import numpy as np
-import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
-import metagym_amd  # noqa: E402
-from oracle import quadrotor as qo  # noqa: E402
 
 
 def random_config(rs, stock_shape):
@@ -46,6 +43,9 @@ def random_config(rs, stock_shape):
 
 
 def main():
+    import torch
+    import metagym_amd
+    from oracle import quadrotor as qo
     ap = argparse.ArgumentParser()
     ap.add_argument("--configs", type=int, default=80)
     ap.add_argument("--seed", type=int, default=0)
