@@ -72,6 +72,83 @@ def fuzz_quadrotor(gym, n_cfg, seed):
     return bad_cfg
 
 
+def fuzz_quadrotor_tasks(gym, n_cfg, seed):
+    """no_collision on random obstacle maps (env.py:248-260 incl. its python-slice semantics) and
+    velocity_control with random (config, seed, nt) (quadrotorsim.py:306-319, env.py:150-157)."""
+    import ctypes as C
+    from fuzz_quadrotor import random_config
+    from oracle import quadrotor as qo
+    bad = 0
+    n_done = 0
+    for c in range(n_cfg):
+        rs = np.random.RandomState(seed * 100003 + 70000 + c)
+        cfg = random_config(rs, stock_shape=bool(rs.rand() < 0.5))
+        cfg["fail"] = {"velocity": 100.0, "w": 1000.0, "range": 1000.0}
+        with tempfile.NamedTemporaryFile("w", suffix=".json", delete=False) as f:
+            json.dump(cfg, f)
+            conf = f.name
+        ok = True
+        if c % 2 == 0:
+            h, w = int(rs.randint(5, 30)), int(rs.randint(5, 30))
+            grid = (rs.randint(0, 4, (h, w)) * (rs.rand(h, w) < 0.4)).astype(np.int32)
+            sy, sx = int(rs.randint(h)), int(rs.randint(w))
+            grid[sy, sx] = -1
+            with tempfile.NamedTemporaryFile("w", suffix=".txt", delete=False) as f:
+                f.write("\n".join(" ".join("%d" % v for v in row) for row in grid))
+                mp = f.name
+            env = gym.make("quadrotor-v0", task="no_collision", map_file=mp, nt=int(rs.choice([4, 1000])),
+                           simulator_conf=conf)
+            os.unlink(mp)
+            np.random.seed(int(rs.randint(1 << 30)))
+            env.reset()
+            sim = env.simulator
+            st0 = gen_golden._sim_state(sim)
+            oc = qo.consts_from_config(cfg, nt=env.nt, task=qo.TASK_NO_COLLISION)
+            g2 = np.ascontiguousarray(np.where(grid == -1, 0, grid).astype(np.int32))
+            oc.map = g2.ctypes.data_as(C.POINTER(C.c_int32))
+            oc.map_h, oc.map_w = g2.shape
+            oc.x_offset, oc.y_offset = sx, sy
+            st = qo.make_states(st0["pos"][None], st0["vel"][None], st0["omega"][None], st0["propw"][None], st0["R"][None])
+            ct = np.zeros(1, np.int32)
+            for t in range(40):
+                a = rs.uniform(0.0, 6.0, 4).astype(np.float32)           # low thrust: the craft sinks into the map
+                obs, reward, done, info = env.step(a)
+                o_obs, o_rew, o_done, o_failed = qo.batch_env_step(oc, st, ct, a[None])
+                ok = ok and float(o_rew[0]) == float(reward) and bool(o_done[0]) == bool(done) and int(ct[0]) == env.ct
+                ok = ok and np.array_equal(qo.states_to_arrays(st)["pos"][0], np.array(sim.global_position, np.float32))
+                n_done += int(done)
+        else:
+            nt, vseed = int(rs.randint(3, 40)), int(rs.randint(1 << 20))
+            env = gym.make("quadrotor-v0", task="velocity_control", nt=nt, seed=vseed, simulator_conf=conf)
+            oc = qo.consts_from_config(cfg, nt=nt, task=qo.TASK_VELOCITY)
+            oc.x_offset = oc.y_offset = 0
+            oc.z_offset = 0.0
+            tg = qo.velocity_targets(oc, qo.velocity_target_actions(vseed, nt, lo=oc.min_voltage, hi=oc.max_voltage))
+            ok = ok and np.array_equal(tg, np.asarray(env.velocity_targets, np.float32))
+            oc.velocity_targets = tg.ctypes.data_as(C.POINTER(C.c_float))
+            np.random.seed(int(rs.randint(1 << 30)))
+            env.reset()
+            sim = env.simulator
+            st0 = gen_golden._sim_state(sim)
+            st = qo.make_states(st0["pos"][None], st0["vel"][None], st0["omega"][None], st0["propw"][None], st0["R"][None])
+            ct = C.c_int(0)
+            nonang = [i for i in range(19) if i not in (12, 13, 14)]
+            for t in range(nt + 5):
+                a = rs.uniform(0.0, 16.0, 4).astype(np.float32)
+                obs, reward, done, info = env.step(a)
+                o_obs, r, d, fl = qo.env_step_velocity(oc, st[0], ct, a)
+                ok = ok and r == float(reward) and d == bool(done) and ct.value == env.ct
+                ok = ok and np.array_equal(o_obs[nonang], np.asarray(obs, np.float32)[nonang])
+                n_done += int(done)
+        os.unlink(conf)
+        bad += 0 if ok else 1
+        if not ok:
+            print("  quadrotor task cfg", c, "no_collision" if c % 2 == 0 else "velocity_control", "DIFFERS")
+    print("quadrotor no_collision (random maps) / velocity_control (random config, seed, nt): %d / %d configs differ "
+          "(%d episode ends seen)" % (bad, n_cfg, n_done))
+    return bad
+
+
 def fuzz_maze(gym, n_cfg, seed):
     from metagym.metamaze import MazeTaskSampler
     from metagym.metamaze.envs.maze_discrete_3d import MazeCoreDiscrete3D
@@ -128,14 +205,94 @@ def fuzz_maze(gym, n_cfg, seed):
     return bad_cfg
 
 
+def fuzz_maze_2d_and_continuous(gym, n_cfg, seed):
+    """MetaMaze2D (random view_grid, both task types) — exact; MetaMazeContinuous3D (random collision-free and
+    colliding walks) — grid / reward / done exact, location / heading to 1e-5 (numpy's vs glibc's sin / cos)."""
+    from metagym.metamaze import MazeTaskSampler
+    from metagym.metamaze.envs.maze_task import MAZE_TASK_MANAGER
+    from oracle import maze as mo
+    tex = np.asarray(MAZE_TASK_MANAGER.grounds).astype(np.uint8)
+    ceil = np.asarray(MAZE_TASK_MANAGER.ceil, np.uint8)
+    bad2d = badc = 0
+    worst_loc = 0.0
+    px_bad = px_tot = 0
+    for c in range(n_cfg):
+        rs = np.random.RandomState(seed * 100003 + 90000 + c)
+        n = int(rs.choice([7, 9, 15]))
+        task_type = "SURVIVAL" if rs.rand() < 0.6 else "ESCAPE"
+        tt = mo.TASK_TYPES[task_type]
+        task_seed = int(rs.randint(1 << 30))
+        random.seed(task_seed)
+        np.random.seed(task_seed)
+        cell = float(rs.choice([1.0, 1.5, 2.0]))
+        task = MazeTaskSampler(n=n, allow_loops=bool(rs.rand() < 0.5), crowd_ratio=float(rs.uniform(0.1, 0.5)),
+                               cell_size=cell, wall_height=1.6 * cell, agent_height=0.8 * cell, step_reward=-0.01,
+                               goal_reward=1.0, food_density=float(rs.choice([0.05, 0.3])), food_interval=3)
+        ot = mo.Task(**task._asdict())
+        if c % 2 == 0:
+            vg = int(rs.randint(1, 4))
+            env = gym.make("meta-maze-2D-v0", max_steps=25, enable_render=False, view_grid=vg, task_type=task_type)
+            env.set_task(task)
+            obs = np.asarray(env.reset())
+            st = mo.State(ot)
+            mo.reset(ot, tt, st)
+            ok = np.array_equal(mo.observe_2d(ot, tt, st, vg), obs)
+            for t in range(40):
+                a = int(rs.randint(4))
+                obs, reward, done, info = env.step(a)
+                r, d = mo.step_2d(ot, tt, 25, st, a)
+                ok = ok and r == reward and d == bool(done) and np.array_equal(mo.observe_2d(ot, tt, st, vg), np.asarray(obs))
+                if done:
+                    obs = env.reset()
+                    mo.reset(ot, tt, st)
+            bad2d += 0 if ok else 1
+            if not ok:
+                print("  maze2d cfg", c, "DIFFERS")
+        else:
+            H, V = int(rs.randint(6, 30)), int(rs.randint(6, 30))
+            env = gym.make("meta-maze-continuous-3D-v0", max_steps=25, enable_render=False, task_type=task_type,
+                           resolution=(H, V))
+            env.set_task(task)
+            obs = np.asarray(env.reset())
+            st = mo.State(ot)
+            mo.reset(ot, tt, st)
+            view = mo.View(tex, ceil, H, V)
+            ok = True
+            px_bad += int((mo.observe_3d(ot, tt, view, st, 1) != obs).sum())
+            px_tot += obs.size
+            for t in range(20):
+                a = (float(rs.uniform(-1.3, 1.3)), float(rs.uniform(-0.6, 1.3)))
+                obs, reward, done, info = env.step(a)
+                r, d = mo.step_cont3d(ot, tt, 25, st, a[0], a[1])
+                core = env.maze_core
+                ok = ok and r == reward and d == bool(done) and list(st.c.grid) == [int(x) for x in core._agent_grid]
+                dl = float(np.max(np.abs(np.asarray(list(st.c.loc)) - np.asarray(core._agent_loc, float))))
+                do = abs(st.c.ori - float(core._agent_ori))
+                worst_loc = max(worst_loc, dl, do)
+                px_bad += int((mo.observe_3d(ot, tt, view, st, 1) != np.asarray(obs)).sum())
+                px_tot += np.asarray(obs).size
+                if done:
+                    break
+            ok = ok and worst_loc <= 1e-5
+            badc += 0 if ok else 1
+            if not ok:
+                print("  maze continuous cfg", c, "DIFFERS")
+    print("maze2d: %d configs differ; continuous-3D: %d configs differ (grid/reward/done exact, worst |loc, heading| "
+          "difference %.2e, %d / %d pixel values differ)" % (bad2d, badc, worst_loc, px_bad, px_tot))
+    return bad2d + badc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--quad", type=int, default=60)
     ap.add_argument("--maze", type=int, default=40)
+    ap.add_argument("--tasks", type=int, default=40)
+    ap.add_argument("--maze2", type=int, default=40)
     ap.add_argument("--seed", type=int, default=0)
     args = ap.parse_args()
     gym = gen_golden._import_reference()
-    bad = fuzz_quadrotor(gym, args.quad, args.seed) + fuzz_maze(gym, args.maze, args.seed)
+    bad = (fuzz_quadrotor(gym, args.quad, args.seed) + fuzz_quadrotor_tasks(gym, args.tasks, args.seed) +
+           fuzz_maze(gym, args.maze, args.seed) + fuzz_maze_2d_and_continuous(gym, args.maze2, args.seed))
     sys.exit(1 if bad else 0)
 
 
