@@ -282,17 +282,48 @@ def fuzz_maze_2d_and_continuous(gym, n_cfg, seed):
     return bad2d + badc
 
 
+def fuzz_sampler(gym, n_cfg, seed):
+    """oracle/maze_sampler.py (own MT19937 streams) against the live MazeTaskSampler under random parameters."""
+    from metagym.metamaze import MazeTaskSampler
+    from metagym.metamaze.envs.maze_task import MAZE_TASK_MANAGER
+    from oracle import maze_sampler as ms
+    bad = 0
+    for c in range(n_cfg):
+        rs = np.random.RandomState(seed * 100003 + 95000 + c)
+        kw = dict(n=int(rs.choice([7, 9, 11, 13, 15, 17, 21])), allow_loops=bool(rs.rand() < 0.5),
+                  crowd_ratio=float(rs.choice([0.0, 0.1, 0.25, 0.35, 0.6])), cell_size=float(rs.choice([1.0, 2.0, 1.5])),
+                  step_reward=-float(rs.uniform(0.001, 0.05)), goal_reward=None if rs.rand() < 0.5 else float(rs.uniform(0.5, 3)),
+                  food_reward=float(rs.uniform(0.1, 1.0)), food_density=float(rs.choice([0.0, 0.01, 0.05, 0.2])),
+                  food_interval=int(rs.randint(1, 200)))
+        task_seed = int(rs.randint(1 << 31))
+        random.seed(task_seed)
+        np.random.seed(task_seed)
+        r = MazeTaskSampler(**kw)
+        o = ms.sample_task(task_seed, MAZE_TASK_MANAGER.n_texts, **kw)
+        ok = (tuple(r.start) == tuple(o.start) and tuple(r.goal) == tuple(o.goal)
+              and np.array_equal(r.cell_walls, o.cell_walls) and np.array_equal(r.cell_texts, o.cell_texts)
+              and np.array_equal(r.food_rewards, o.food_rewards) and np.array_equal(r.food_interval, o.food_interval)
+              and r.goal_reward == o.goal_reward)
+        bad += 0 if ok else 1
+        if not ok:
+            print("  sampler cfg", c, kw, "seed", task_seed, "DIFFERS")
+    print("maze task sampler: %d / %d random (parameters, seed) differ" % (bad, n_cfg))
+    return bad
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--quad", type=int, default=60)
     ap.add_argument("--maze", type=int, default=40)
     ap.add_argument("--tasks", type=int, default=40)
     ap.add_argument("--maze2", type=int, default=40)
+    ap.add_argument("--sampler", type=int, default=40)
     ap.add_argument("--seed", type=int, default=0)
     args = ap.parse_args()
     gym = gen_golden._import_reference()
     bad = (fuzz_quadrotor(gym, args.quad, args.seed) + fuzz_quadrotor_tasks(gym, args.tasks, args.seed) +
-           fuzz_maze(gym, args.maze, args.seed) + fuzz_maze_2d_and_continuous(gym, args.maze2, args.seed))
+           fuzz_maze(gym, args.maze, args.seed) + fuzz_maze_2d_and_continuous(gym, args.maze2, args.seed) +
+           fuzz_sampler(gym, args.sampler, args.seed))
     sys.exit(1 if bad else 0)
 
 
