@@ -673,7 +673,9 @@ __device__ __forceinline__ void rodrigues_sc(V3 k, double s, double c, double *R
     R[6] = k.z * k.x * v - k.y * s; R[7] = k.z * k.y * v + k.x * s; R[8] = c + k.z * k.z * v;
 }
 
-__device__ void wave_kinematics(const mg_walker_topology &tp, const ModelRef &m, const WaveLds &L, int lane,
+// forceinline: with three call sites the compiler would otherwise emit a real call, which pushes the
+// kernels into scratch (ant: 1.04 -> 1.92 ms)
+__device__ __forceinline__ void wave_kinematics(const mg_walker_topology &tp, const ModelRef &m, const WaveLds &L, int lane,
                                 int max_depth, bool with_frames) {
     const int nb = tp.n_bodies, nj = tp.n_joints;
     // the f64 sin/cos of all joint angles at once (lane = joint): the level loop below is serial in the
@@ -1131,30 +1133,41 @@ __global__ __launch_bounds__(WV) void walker_step_wave_kernel(mg_walker_topology
         }
         all_finite = __all(finite);
     };
-    double dist;
-    int at_limit;
-    bool all_finite;
-    calc_state(false, dist, at_limit, all_finite);
-    int ended = 0;
-    if (lane == 0) {
-        const double alive = ((double)head[0] + prm.initial_z > prm.alive_z) ? prm.alive_bonus : prm.dead_bonus;
-        const double pot_old = st.potential[e];
-        const double pot = -dist / (prm.time_step * prm.frame_skip);
-        const double progress = pot - pot_old;
-        const double limit_cost = prm.joints_at_limit_cost * at_limit;
-        st.potential[e] = pot;
-        const int steps = st.steps[e] + 1;
-        st.steps[e] = steps;
-        reward[e] = (float)(alive + progress + 0.0 + limit_cost + 0.0);
-        if (rewards5) {
-            float *r5 = rewards5 + (size_t)e * 5;
-            r5[0] = (float)alive; r5[1] = (float)progress; r5[2] = 0.0f; r5[3] = (float)limit_cost; r5[4] = 0.0f;
+    // One call site for calc_state (it inlines the kinematics pass; a second copy pushed the kernel into
+    // scratch): pass 0 observes the stepped state and scores it, pass 1 — only for an env that ended with
+    // auto_reset on — observes the freshly reset state.
+    for (int pass = 0; pass < 2; ++pass) {
+        double dist;
+        int at_limit;
+        bool all_finite;
+        calc_state(pass == 1, dist, at_limit, all_finite);
+        if (pass == 1) {
+            if (lane == 0) {
+                st.potential[e] = -dist / (prm.time_step * prm.frame_skip);
+                st.steps[e] = 0;
+            }
+            break;
         }
-        ended = (alive < 0) || !all_finite || (steps >= prm.max_steps);
-        done[e] = (uint8_t)ended;
-    }
-    ended = __builtin_amdgcn_readfirstlane(ended);
-    if (prm.auto_reset && ended) {
+        int ended = 0;
+        if (lane == 0) {
+            const double alive = ((double)head[0] + prm.initial_z > prm.alive_z) ? prm.alive_bonus : prm.dead_bonus;
+            const double pot_old = st.potential[e];
+            const double pot = -dist / (prm.time_step * prm.frame_skip);
+            const double progress = pot - pot_old;
+            const double limit_cost = prm.joints_at_limit_cost * at_limit;
+            st.potential[e] = pot;
+            const int steps = st.steps[e] + 1;
+            st.steps[e] = steps;
+            reward[e] = (float)(alive + progress + 0.0 + limit_cost + 0.0);
+            if (rewards5) {
+                float *r5 = rewards5 + (size_t)e * 5;
+                r5[0] = (float)alive; r5[1] = (float)progress; r5[2] = 0.0f; r5[3] = (float)limit_cost; r5[4] = 0.0f;
+            }
+            ended = (alive < 0) || !all_finite || (steps >= prm.max_steps);
+            done[e] = (uint8_t)ended;
+        }
+        ended = __builtin_amdgcn_readfirstlane(ended);
+        if (!(prm.auto_reset && ended)) break;
         // fused auto-reset: robot_specific_reset (walker_base.py:13-24) with device-side joint noise; the
         // returned obs row is the first observation of the next episode (vector-env convention)
         WSYNC();
@@ -1169,11 +1182,6 @@ __global__ __launch_bounds__(WV) void walker_step_wave_kernel(mg_walker_topology
             L.qd[lane] = 0.0;
         }
         WSYNC();
-        calc_state(true, dist, at_limit, all_finite);
-        if (lane == 0) {
-            st.potential[e] = -dist / (prm.time_step * prm.frame_skip);
-            st.steps[e] = 0;
-        }
     }
     // ---- state store ----------------------------------------------------------------------------------
     if (lane < 3) {
