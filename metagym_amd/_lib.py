@@ -172,6 +172,11 @@ def load():
             raise MetaGymHipError(
                 "libmetagym_hip.so is not built and hipcc (%s) is not available. Run "
                 "`python -m metagym_amd.build` on a ROCm machine. There is no CPU fallback." % _build.HIPCC)
+    # torch-ROCm ships its own libamdhip64 / libhsa-runtime64 with the same SONAME as /opt/rocm's. The
+    # process must end up with ONE HIP runtime, and it has to be the one that owns the torch tensors we are
+    # handed: import torch first so the library binds to that copy (loading ours first pulls /opt/rocm's
+    # runtime in and torch then fails with "no ROCm-capable device").
+    import torch  # noqa: F401
     try:
         lib = C.CDLL(path)
     except OSError as e:
