@@ -558,8 +558,10 @@ __global__ __launch_bounds__(WK_BLOCK) void walker_reset_kernel(mg_walker_topolo
 
 // ======================================================================================================
 // Wave-per-env mapping (default). One 64-lane wavefront owns one env; its whole work set lives in LDS
-// (~31 KB for the humanoid: kinematics, M, h, constraint Jacobians J and their images W = M^-1 J^T),
-// so five envs are resident per CU and nothing spills to scratch. Lanes are dealt
+// (26 KB for the humanoid: kinematics, M, h, contact Jacobian rows J and the constraint images W = M^-1 J^T;
+// blocks whose lifetimes do not overlap share storage, see carve()), so six envs are resident per CU —
+// the kernel is LDS-latency-bound at ~1 wave per SIMD, occupancy is what buys time (4 -> 6 envs per CU:
+// 3.62 -> 2.72 ms at 8 192 envs) — and nothing spills to scratch. Lanes are dealt
 //   * bodies (tree level by tree level) for kinematics and the Newton-Euler pass,
 //   * matrix entries for M, rows/columns for the Cholesky factorisation and the triangular solves,
 //   * collision spheres / joints for constraint detection (ballot + popcount gives every constraint
@@ -620,14 +622,19 @@ struct WaveLds {   // pointers into the env's LDS slab
 // are only written after that — so the temporaries live INSIDE the Wm block whenever they fit. For the
 // humanoid this takes the env's LDS slab from 33.2 KB to 30.4 KB: five envs per CU instead of four.
 __host__ __device__ inline bool wave_lds_alias(int nb, int nj, int maxr) { return 27 * (size_t)nb <= (size_t)maxr * (6 + nj); }
+// second overlay: the reciprocal diagonals and multipliers of the solver (diag, lam: 2 maxr doubles) are
+// first written after the constraint Jacobian is complete, when the body frames R / o / c (15 doubles per
+// body) are dead until the next kinematics pass
+__host__ __device__ inline bool wave_lds_alias2(int nb, int maxr) { return 2 * (size_t)maxr <= 15 * (size_t)nb; }
 __host__ __device__ inline size_t wave_lds_doubles(int nb, int nj, int maxr) {
     const int n = 6 + nj;
     const size_t ne = wave_lds_alias(nb, nj, maxr) ? 0 : 27 * (size_t)nb;
     return (size_t)nb * (9 + 3 + 3) + (size_t)nj * 6 + ne + (size_t)n * n +
-           3 * (size_t)n + 3 * (size_t)nj + 18 + 2 * (size_t)maxr * n + 3 * (size_t)maxr + 6 * (size_t)W_MAXC +
-           2 * (size_t)nj;
+           3 * (size_t)n + 3 * (size_t)nj + 18 + (size_t)(3 * W_MAXC) * n + (size_t)maxr * n +
+           (wave_lds_alias2(nb, maxr) ? 1 : 3) * (size_t)maxr + 6 * (size_t)W_MAXC +
+           (2 * (size_t)nj <= 6 * (size_t)W_MAXC ? 0 : 2 * (size_t)nj);
 }
-__host__ __device__ inline size_t wave_lds_ints(int nb, int maxr) { return 5 * (size_t)nb + 2 * (size_t)maxr + 2 * W_MAXC + 8 + 64; }
+__host__ __device__ inline size_t wave_lds_ints(int nb, int maxr) { return 5 * (size_t)nb + 2 * (size_t)maxr + 2 * W_MAXC + 8 + ND; }
 
 __device__ __forceinline__ WaveLds carve(unsigned char *smem, int nb, int nj, int maxr) {
     const int n = 6 + nj;
@@ -640,13 +647,21 @@ __device__ __forceinline__ WaveLds carve(unsigned char *smem, int nb, int nj, in
     L.M = d; d += n * n; L.h = d; d += n; L.x = d; d += n; L.idg = d; d += n;
     L.q = d; d += nj; L.qd = d; d += nj; L.tau = d; d += nj;
     L.base = d; d += 18;
-    L.J = d; d += (size_t)maxr * n; L.Wm = d; d += (size_t)maxr * n;
-    if (alias) ne = L.Wm;
+    L.J = d; d += (size_t)(3 * W_MAXC) * n;      // contact rows only: a joint-limit row is +-e_(6+j), never stored
+    L.Wm = d; d += (size_t)maxr * n;
+    // [J | Wm] doubles as scratch while M and h are assembled: the (body, dof) Jacobian pairs grow from its
+    // start, the Newton-Euler temporaries sit at its end (mg_walker_step checks that they cannot meet)
+    if (alias) ne = d - 27 * nb;
     L.fw = ne; ne += 3 * nb; L.fal = ne; ne += 3 * nb; L.fxr = ne; ne += 3 * nb; L.far_ = ne; ne += 3 * nb;
     L.F = ne; ne += 3 * nb; L.Nn = ne; ne += 3 * nb; L.Iw = ne;
-    L.bias = d; d += maxr; L.diag = d; d += maxr; L.lam = d; d += maxr;
+    L.bias = d; d += maxr;
+    if (wave_lds_alias2(nb, maxr)) { L.diag = L.R; L.lam = L.R + maxr; }
+    else { L.diag = d; d += maxr; L.lam = d; d += maxr; }
     L.cx = d; d += 6 * W_MAXC;
-    L.sc = d; d += 2 * nj;
+    // sin / cos of the joint angles live only inside the kinematics pass, the contact points only between
+    // detection and the Jacobian rows: one block serves both
+    if (2 * nj <= 6 * W_MAXC) L.sc = L.cx;
+    else { L.sc = d; d += 2 * nj; }
     int *i = reinterpret_cast<int *>(d);
     L.mask = i; i += nb; L.depth = i; i += nb; L.jstart = i; i += nb; L.jcount = i; i += nb; L.poff = i; i += nb;
     L.kind = i; i += maxr; L.partner = i; i += maxr; L.csphere = i; i += 2 * W_MAXC; L.misc = i; i += 8; L.bod = i;
@@ -942,9 +957,8 @@ __device__ void wave_substep(const mg_walker_topology &tp, const ModelRef &m, co
     const int nr = 3 * ncont + __popcll(lims);
     if (lsgn != 0.0) {
         const int r = 3 * ncont + __popcll(lims & ((1ull << lane) - 1ull));
-        for (int d = 0; d < n; ++d) L.J[(size_t)r * n + d] = 0.0;
-        L.J[(size_t)r * n + 6 + lane] = lsgn;
-        L.bias[r] = prm.limit_erp * viol / dt; L.kind[r] = 0; L.partner[r] = -1;
+        // J_r = lsgn * e_(6+joint): kept as (kind 4 / 5 = sign, partner = joint), not as a dense row
+        L.bias[r] = prm.limit_erp * viol / dt; L.kind[r] = lsgn > 0.0 ? 4 : 5; L.partner[r] = lane;
     }
     WSYNC();
     // contact Jacobian rows, lane-strided over (contact, column)
@@ -973,9 +987,13 @@ __device__ void wave_substep(const mg_walker_topology &tp, const ModelRef &m, co
     //      array): through LDS every step of the substitution would wait on its own previous store ------
     for (int r = lane; r < nr; r += WV) {
         double w[NMAX];
-        const double *jr = L.J + (size_t)r * n;
+        const int rkind = L.kind[r];
+        const bool is_limit = rkind >= 4;
+        const int ldof = is_limit ? 6 + L.partner[r] : -1;
+        const double lsg = rkind == 4 ? 1.0 : -1.0;
+        const double *jr = L.J + (size_t)(is_limit ? 0 : r) * n;
 #pragma unroll
-        for (int d = 0; d < NMAX; ++d) w[d] = d < n ? jr[d] : 0.0;
+        for (int d = 0; d < NMAX; ++d) w[d] = d < n ? (is_limit ? (d == ldof ? lsg : 0.0) : jr[d]) : 0.0;
 #pragma unroll
         for (int d = 0; d < NMAX; ++d) {
             if (d < n) {
@@ -999,7 +1017,7 @@ __device__ void wave_substep(const mg_walker_topology &tp, const ModelRef &m, co
         double *wo = L.Wm + (size_t)r * n;
 #pragma unroll
         for (int d = 0; d < NMAX; ++d)
-            if (d < n) { dd += jr[d] * w[d]; wo[d] = w[d]; }
+            if (d < n) { dd += (is_limit ? (d == ldof ? lsg : 0.0) : jr[d]) * w[d]; wo[d] = w[d]; }
         L.diag[r] = dd > 0.0 ? 1.0 / dd : 0.0;          // reciprocal: the sweep below multiplies
         L.lam[r] = 0.0;
     }
@@ -1009,12 +1027,15 @@ __device__ void wave_substep(const mg_walker_topology &tp, const ModelRef &m, co
         for (int r = 0; r < nr; ++r) {
             const double idg = L.diag[r];
             if (!(idg > 0.0)) continue;
-            const double jv = wave_sum(lane < n ? L.J[(size_t)r * n + lane] * u_d : 0.0);
+            const int rkind = L.kind[r];
+            double jv;
+            if (rkind >= 4) jv = (rkind == 4 ? 1.0 : -1.0) * lane_value(u_d, 6 + L.partner[r]);   // J_r = +-e_(6+j)
+            else jv = wave_sum(lane < n ? L.J[(size_t)r * n + lane] * u_d : 0.0);
             const double lr = L.lam[r];
             double x = lr - (jv - L.bias[r]) * idg;
-            if (L.kind[r] == 0) x = x > 0.0 ? x : 0.0;
+            if (rkind == 0 || rkind >= 4) x = x > 0.0 ? x : 0.0;
             else {
-                const double lim = (L.kind[r] == 3 ? prm.self_friction : prm.friction) * L.lam[L.partner[r]];
+                const double lim = (rkind == 3 ? prm.self_friction : prm.friction) * L.lam[L.partner[r]];
                 x = x < -lim ? -lim : (x > lim ? lim : x);
             }
             const double dl = x - lr;
@@ -1206,6 +1227,8 @@ __global__ __launch_bounds__(WV) void walker_step_wave_kernel(mg_walker_topology
     }
 }
 
+inline size_t ndof_of(const mg_walker_topology *tp) { return 6 + (size_t)tp->n_joints; }
+
 int check_walker(const mg_walker_topology *tp, const mg_walker_models *ms, const mg_walker_params *prm,
                  const mg_walker_state *st, int n) {
     if (!tp || !ms || !prm || !st) return mg::set_error(MG_ERR_NULL_POINTER, "walker: NULL descriptor");
@@ -1256,6 +1279,24 @@ extern "C" int mg_walker_step(const mg_walker_topology *tp, const mg_walker_mode
     const int maxr = 3 * W_MAXC + tp->n_joints;
     const size_t lds = wave_lds_doubles(tp->n_bodies, tp->n_joints, maxr) * sizeof(double) +
                        wave_lds_ints(tp->n_bodies, maxr) * sizeof(int);
+    {
+        // scratch use of the [J | Wm] block during the M / h assembly: 6 doubles per (body, dof-on-its-chain)
+        // pair from the front, 27 doubles per body of Newton-Euler temporaries from the back
+        int chain[MG_WALKER_MAX_BODIES];
+        size_t pairs = 0;
+        for (int b = 0; b < tp->n_bodies; ++b) {
+            int own = 0;
+            for (int j = 0; j < tp->n_joints; ++j) own += tp->joint_body[j] == b;
+            const int pb = tp->body_parent[b];
+            chain[b] = own + (pb >= 0 && pb < b ? chain[pb] : 0);
+            pairs += 6 + chain[b];
+        }
+        const size_t block = (size_t)(3 * W_MAXC + maxr) * ndof_of(tp);
+        const size_t ne = wave_lds_alias(tp->n_bodies, tp->n_joints, maxr) ? 27 * (size_t)tp->n_bodies : 0;
+        if (6 * pairs + ne > block)
+            return mg::set_error(MG_ERR_UNSUPPORTED, "walker topology needs %zu scratch doubles for the mass-matrix "
+                                 "assembly, the wave mapping has %zu: use mapping = lane", 6 * pairs + ne, block);
+    }
     if (lds > 160 * 1024) return mg::set_error(MG_ERR_BAD_SIZE, "walker needs %zu B of LDS", lds);
     if (lds > 64 * 1024) return mg::set_error(MG_ERR_BAD_SIZE, "walker needs %zu B of LDS (> 64 KiB)", lds);
     const int ndof = 6 + tp->n_joints;
