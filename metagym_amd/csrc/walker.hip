@@ -558,10 +558,10 @@ __global__ __launch_bounds__(WK_BLOCK) void walker_reset_kernel(mg_walker_topolo
 
 // ======================================================================================================
 // Wave-per-env mapping (default). One 64-lane wavefront owns one env; its whole work set lives in LDS
-// (26 KB for the humanoid: kinematics, M, h, contact Jacobian rows J and the constraint images W = M^-1 J^T;
-// blocks whose lifetimes do not overlap share storage, see carve()), so six envs are resident per CU —
-// the kernel is LDS-latency-bound at ~1 wave per SIMD, occupancy is what buys time (4 -> 6 envs per CU:
-// 3.62 -> 2.72 ms at 8 192 envs) — and nothing spills to scratch. Lanes are dealt
+// (22.6 KB for the humanoid: kinematics, M, h, contact Jacobian rows J and the constraint images W = M^-1 J^T;
+// blocks whose lifetimes do not overlap share storage, see carve()), so seven envs are resident per CU —
+// the kernel is LDS-latency-bound at ~1 wave per SIMD, occupancy is what buys time (4 -> 7 envs per CU:
+// 3.62 -> 2.36 ms at 8 192 envs) — and nothing spills to scratch. Lanes are dealt
 //   * bodies (tree level by tree level) for kinematics and the Newton-Euler pass,
 //   * matrix entries for M, rows/columns for the Cholesky factorisation and the triangular solves,
 //   * collision spheres / joints for constraint detection (ballot + popcount gives every constraint
@@ -572,6 +572,8 @@ __global__ __launch_bounds__(WK_BLOCK) void walker_reset_kernel(mg_walker_topolo
 // ======================================================================================================
 
 constexpr int WV = 64;
+// the joint-space inertia matrix and its Cholesky factor are only ever touched in the lower triangle: packed
+#define TRI(r, c) ((r) * ((r) + 1) / 2 + (c))
 constexpr int W_MAXC = 12;   // ground contacts kept per env (first W_MAXC penetrating spheres)
 
 // Sum over the 64 lanes without LDS: four DPP steps fold each 16-lane row (quad_perm xor-1, xor-2,
@@ -626,25 +628,36 @@ __host__ __device__ inline bool wave_lds_alias(int nb, int nj, int maxr) { retur
 // first written after the constraint Jacobian is complete, when the body frames R / o / c (15 doubles per
 // body) are dead until the next kinematics pass
 __host__ __device__ inline bool wave_lds_alias2(int nb, int maxr) { return 2 * (size_t)maxr <= 15 * (size_t)nb; }
-__host__ __device__ inline size_t wave_lds_doubles(int nb, int nj, int maxr) {
+// third overlay: the joint anchors / axes p, a (6 doubles per joint) and the contact points cx (shared with
+// the sin / cos table) are last read while the Jacobian rows are written, i.e. before the first store to Wm:
+// they sit at the START of Wm (the Newton-Euler temporaries sit at its end)
+__host__ __device__ inline bool wave_lds_alias3(int nb, int nj, int maxr, bool allow) {
+    if (!allow) return false;   // the host turns it off when the assembly's Jacobian pairs do not fit in J alone
+    const size_t head = 6 * (size_t)nj + 6 * (size_t)W_MAXC + (2 * (size_t)nj <= 6 * (size_t)W_MAXC ? 0 : 2 * (size_t)nj);
+    return head + (wave_lds_alias(nb, nj, maxr) ? 27 * (size_t)nb : 0) <= (size_t)maxr * (6 + nj);
+}
+__host__ __device__ inline size_t wave_lds_doubles(int nb, int nj, int maxr, bool allow3) {
     const int n = 6 + nj;
     const size_t ne = wave_lds_alias(nb, nj, maxr) ? 0 : 27 * (size_t)nb;
-    return (size_t)nb * (9 + 3 + 3) + (size_t)nj * 6 + ne + (size_t)n * n +
+    const size_t pa_cx = wave_lds_alias3(nb, nj, maxr, allow3)
+                             ? 0
+                             : (size_t)nj * 6 + 6 * (size_t)W_MAXC + (2 * (size_t)nj <= 6 * (size_t)W_MAXC ? 0 : 2 * (size_t)nj);
+    return (size_t)nb * (9 + 3 + 3) + pa_cx + ne + (size_t)n * (n + 1) / 2 +
            3 * (size_t)n + 3 * (size_t)nj + 18 + (size_t)(3 * W_MAXC) * n + (size_t)maxr * n +
-           (wave_lds_alias2(nb, maxr) ? 1 : 3) * (size_t)maxr + 6 * (size_t)W_MAXC +
-           (2 * (size_t)nj <= 6 * (size_t)W_MAXC ? 0 : 2 * (size_t)nj);
+           (wave_lds_alias2(nb, maxr) ? 1 : 3) * (size_t)maxr;
 }
 __host__ __device__ inline size_t wave_lds_ints(int nb, int maxr) { return 5 * (size_t)nb + 2 * (size_t)maxr + 2 * W_MAXC + 8 + ND; }
 
-__device__ __forceinline__ WaveLds carve(unsigned char *smem, int nb, int nj, int maxr) {
+__device__ __forceinline__ WaveLds carve(unsigned char *smem, int nb, int nj, int maxr, bool allow3) {
     const int n = 6 + nj;
     WaveLds L;
     double *d = reinterpret_cast<double *>(smem);
-    L.R = d; d += 9 * nb; L.o = d; d += 3 * nb; L.c = d; d += 3 * nb; L.p = d; d += 3 * nj; L.a = d; d += 3 * nj;
-    const bool alias = wave_lds_alias(nb, nj, maxr);
+    L.R = d; d += 9 * nb; L.o = d; d += 3 * nb; L.c = d; d += 3 * nb;
+    const bool alias = wave_lds_alias(nb, nj, maxr), alias3 = wave_lds_alias3(nb, nj, maxr, allow3);
+    if (!alias3) { L.p = d; d += 3 * nj; L.a = d; d += 3 * nj; }
     double *ne = d;                       // Newton-Euler temporaries: own block, or inside Wm (see above)
     if (!alias) d += 27 * nb;
-    L.M = d; d += n * n; L.h = d; d += n; L.x = d; d += n; L.idg = d; d += n;
+    L.M = d; d += n * (n + 1) / 2; L.h = d; d += n; L.x = d; d += n; L.idg = d; d += n;
     L.q = d; d += nj; L.qd = d; d += nj; L.tau = d; d += nj;
     L.base = d; d += 18;
     L.J = d; d += (size_t)(3 * W_MAXC) * n;      // contact rows only: a joint-limit row is +-e_(6+j), never stored
@@ -652,16 +665,19 @@ __device__ __forceinline__ WaveLds carve(unsigned char *smem, int nb, int nj, in
     // [J | Wm] doubles as scratch while M and h are assembled: the (body, dof) Jacobian pairs grow from its
     // start, the Newton-Euler temporaries sit at its end (mg_walker_step checks that they cannot meet)
     if (alias) ne = d - 27 * nb;
+    double *hd = L.Wm;                    // p, a, cx (+ sc): own blocks, or the head of Wm (third overlay)
+    if (alias3) { L.p = hd; hd += 3 * nj; L.a = hd; hd += 3 * nj; }
     L.fw = ne; ne += 3 * nb; L.fal = ne; ne += 3 * nb; L.fxr = ne; ne += 3 * nb; L.far_ = ne; ne += 3 * nb;
     L.F = ne; ne += 3 * nb; L.Nn = ne; ne += 3 * nb; L.Iw = ne;
     L.bias = d; d += maxr;
     if (wave_lds_alias2(nb, maxr)) { L.diag = L.R; L.lam = L.R + maxr; }
     else { L.diag = d; d += maxr; L.lam = d; d += maxr; }
-    L.cx = d; d += 6 * W_MAXC;
     // sin / cos of the joint angles live only inside the kinematics pass, the contact points only between
     // detection and the Jacobian rows: one block serves both
+    double *&cur = alias3 ? hd : d;
+    L.cx = cur; cur += 6 * W_MAXC;
     if (2 * nj <= 6 * W_MAXC) L.sc = L.cx;
-    else { L.sc = d; d += 2 * nj; }
+    else { L.sc = cur; cur += 2 * nj; }
     int *i = reinterpret_cast<int *>(d);
     L.mask = i; i += nb; L.depth = i; i += nb; L.jstart = i; i += nb; L.jcount = i; i += nb; L.poff = i; i += nb;
     L.kind = i; i += maxr; L.partner = i; i += maxr; L.csphere = i; i += 2 * W_MAXC; L.misc = i; i += 8; L.bod = i;
@@ -833,7 +849,7 @@ __device__ void wave_substep(const mg_walker_topology &tp, const ModelRef &m, co
             acc += dot(m.body_mass[b] * jv, ev) + dot(mulMv(L.Iw + 9 * b, jw), ew);
         }
         if (d == e && d >= 6) acc += m.joint_arm[d - 6];
-        L.M[d * n + e] = acc;
+        L.M[TRI(d, e)] = acc;
     }
     if (lane < n) {
         const int d = lane;
@@ -852,13 +868,13 @@ __device__ void wave_substep(const mg_walker_topology &tp, const ModelRef &m, co
     for (int c = 0; c < n; ++c) {
         double v = 0.0;
         if (lane >= c && lane < n) {
-            v = L.M[lane * n + c];
-            for (int k = 0; k < c; ++k) v -= L.M[lane * n + k] * L.M[c * n + k];
+            v = L.M[TRI(lane, c)];
+            for (int k = 0; k < c; ++k) v -= L.M[TRI(lane, k)] * L.M[TRI(c, k)];
         }
         const double piv = sqrt(lane_value(v, c));
         const double ipiv = 1.0 / piv;
-        if (lane == c) { L.M[c * n + c] = piv; L.idg[c] = ipiv; }
-        else if (lane > c && lane < n) L.M[lane * n + c] = v * ipiv;
+        if (lane == c) { L.M[TRI(c, c)] = piv; L.idg[c] = ipiv; }
+        else if (lane > c && lane < n) L.M[TRI(lane, c)] = v * ipiv;
         WSYNC();
     }
     // ---- free motion u* = u + dt M^-1 (tau - h): column-oriented triangular solves, x in registers ---
@@ -878,12 +894,12 @@ __device__ void wave_substep(const mg_walker_topology &tp, const ModelRef &m, co
     for (int r = 0; r < n; ++r) {                      // L y = b
         const double xr = lane_value(x_d, r) * L.idg[r];
         if (lane == r) x_d = xr;
-        else if (lane > r && lane < n) x_d -= L.M[lane * n + r] * xr;
+        else if (lane > r && lane < n) x_d -= L.M[TRI(lane, r)] * xr;
     }
     for (int r = n - 1; r >= 0; --r) {                 // L^T x = y
         const double xr = lane_value(x_d, r) * L.idg[r];
         if (lane == r) x_d = xr;
-        else if (lane < r) x_d -= L.M[r * n + lane] * xr;
+        else if (lane < r) x_d -= L.M[TRI(r, lane)] * xr;
     }
     if (lane < n) u_d += dt * x_d;
     // ---- constraint detection ------------------------------------------------------------------------
@@ -999,7 +1015,7 @@ __device__ void wave_substep(const mg_walker_topology &tp, const ModelRef &m, co
             if (d < n) {
                 double v = w[d];
 #pragma unroll
-                for (int k = 0; k < d; ++k) v -= L.M[d * n + k] * w[k];
+                for (int k = 0; k < d; ++k) v -= L.M[TRI(d, k)] * w[k];
                 w[d] = v * L.idg[d];
             }
         }
@@ -1009,7 +1025,7 @@ __device__ void wave_substep(const mg_walker_topology &tp, const ModelRef &m, co
                 double v = w[d];
 #pragma unroll
                 for (int k = d + 1; k < NMAX; ++k)
-                    if (k < n) v -= L.M[k * n + d] * w[k];
+                    if (k < n) v -= L.M[TRI(k, d)] * w[k];
                 w[d] = v * L.idg[d];
             }
         }
@@ -1072,13 +1088,15 @@ __device__ void wave_substep(const mg_walker_topology &tp, const ModelRef &m, co
 template <int NMAX>
 __global__ __launch_bounds__(WV) void walker_step_wave_kernel(mg_walker_topology tp, mg_walker_models ms,
                                                               mg_walker_params prm, mg_walker_state st, int n_envs,
-                                                              int maxr, const float *action, float *obs, float *reward,
-                                                              float *rewards5, uint8_t *done) {
+                                                              int maxr_flags, const float *action, float *obs,
+                                                              float *reward, float *rewards5, uint8_t *done) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int e = blockIdx.x, lane = threadIdx.x;
     const int nb = tp.n_bodies, nj = tp.n_joints, nf = tp.n_feet, obs_dim = 8 + 2 * nj + nf;
     const ModelRef m = model_ref(tp, ms, st.task_id[e]);
-    const WaveLds L = carve(smem, nb, nj, maxr);
+    const bool allow3 = maxr_flags < 0;          // sign bit of the row-count argument = third LDS overlay on
+    const int maxr = maxr_flags < 0 ? -maxr_flags : maxr_flags;
+    const WaveLds L = carve(smem, nb, nj, maxr, allow3);
     // tree bookkeeping (lane 0) + state load (lanes)
     if (lane == 0) {
         int md = 0, j = 0;
@@ -1277,11 +1295,11 @@ extern "C" int mg_walker_step(const mg_walker_topology *tp, const mg_walker_mode
     if (tp->n_spheres > 64 || 6 + tp->n_joints > 64)
         return mg::set_error(MG_ERR_BAD_SIZE, "wave mapping needs <= 64 spheres and <= 58 joints");
     const int maxr = 3 * W_MAXC + tp->n_joints;
-    const size_t lds = wave_lds_doubles(tp->n_bodies, tp->n_joints, maxr) * sizeof(double) +
-                       wave_lds_ints(tp->n_bodies, maxr) * sizeof(int);
+    // scratch use of the [J | Wm] block during the M / h assembly: 6 doubles per (body, dof-on-its-chain) pair
+    // from the front, 27 doubles per body of Newton-Euler temporaries from the back; with the third overlay
+    // (joint frames and contact points at the head of Wm) the pairs must stay inside J
+    bool allow3 = false;
     {
-        // scratch use of the [J | Wm] block during the M / h assembly: 6 doubles per (body, dof-on-its-chain)
-        // pair from the front, 27 doubles per body of Newton-Euler temporaries from the back
         int chain[MG_WALKER_MAX_BODIES];
         size_t pairs = 0;
         for (int b = 0; b < tp->n_bodies; ++b) {
@@ -1291,12 +1309,17 @@ extern "C" int mg_walker_step(const mg_walker_topology *tp, const mg_walker_mode
             chain[b] = own + (pb >= 0 && pb < b ? chain[pb] : 0);
             pairs += 6 + chain[b];
         }
-        const size_t block = (size_t)(3 * W_MAXC + maxr) * ndof_of(tp);
-        const size_t ne = wave_lds_alias(tp->n_bodies, tp->n_joints, maxr) ? 27 * (size_t)tp->n_bodies : 0;
+        allow3 = 6 * pairs <= (size_t)(3 * W_MAXC) * ndof_of(tp);
+        const bool a3 = wave_lds_alias3(tp->n_bodies, tp->n_joints, maxr, allow3);
+        const size_t block = a3 ? (size_t)(3 * W_MAXC) * ndof_of(tp) : (size_t)(3 * W_MAXC + maxr) * ndof_of(tp);
+        const size_t ne = (!a3 && wave_lds_alias(tp->n_bodies, tp->n_joints, maxr)) ? 27 * (size_t)tp->n_bodies : 0;
         if (6 * pairs + ne > block)
             return mg::set_error(MG_ERR_UNSUPPORTED, "walker topology needs %zu scratch doubles for the mass-matrix "
                                  "assembly, the wave mapping has %zu: use mapping = lane", 6 * pairs + ne, block);
     }
+    const size_t lds = wave_lds_doubles(tp->n_bodies, tp->n_joints, maxr, allow3) * sizeof(double) +
+                       wave_lds_ints(tp->n_bodies, maxr) * sizeof(int);
+    const int maxr_flags = allow3 ? -maxr : maxr;
     if (lds > 160 * 1024) return mg::set_error(MG_ERR_BAD_SIZE, "walker needs %zu B of LDS", lds);
     if (lds > 64 * 1024) return mg::set_error(MG_ERR_BAD_SIZE, "walker needs %zu B of LDS (> 64 KiB)", lds);
     const int ndof = 6 + tp->n_joints;
@@ -1304,12 +1327,12 @@ extern "C" int mg_walker_step(const mg_walker_topology *tp, const mg_walker_mode
     // 14 = ant, 23 = humanoid, 30 = the ABI maximum
     if (ndof <= 14)
         hipLaunchKernelGGL(walker_step_wave_kernel<14>, dim3(n), dim3(WV), lds, (hipStream_t)stream, *tp, *ms, *prm, *st,
-                           n, maxr, action, obs, reward, rewards5, done);
+                           n, maxr_flags, action, obs, reward, rewards5, done);
     else if (ndof <= 23)
         hipLaunchKernelGGL(walker_step_wave_kernel<23>, dim3(n), dim3(WV), lds, (hipStream_t)stream, *tp, *ms, *prm, *st,
-                           n, maxr, action, obs, reward, rewards5, done);
+                           n, maxr_flags, action, obs, reward, rewards5, done);
     else
         hipLaunchKernelGGL(walker_step_wave_kernel<ND>, dim3(n), dim3(WV), lds, (hipStream_t)stream, *tp, *ms, *prm, *st,
-                           n, maxr, action, obs, reward, rewards5, done);
+                           n, maxr_flags, action, obs, reward, rewards5, done);
     return mg::check_launch("walker_step_wave_kernel");
 }
