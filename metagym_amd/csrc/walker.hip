@@ -558,10 +558,10 @@ __global__ __launch_bounds__(WK_BLOCK) void walker_reset_kernel(mg_walker_topolo
 
 // ======================================================================================================
 // Wave-per-env mapping (default). One 64-lane wavefront owns one env; its whole work set lives in LDS
-// (22.6 KB for the humanoid: kinematics, M, h, contact Jacobian rows J and the constraint images W = M^-1 J^T;
-// blocks whose lifetimes do not overlap share storage, see carve()), so seven envs are resident per CU —
-// the kernel is LDS-latency-bound at ~1 wave per SIMD, occupancy is what buys time (4 -> 7 envs per CU:
-// 3.62 -> 2.36 ms at 8 192 envs) — and nothing spills to scratch. Lanes are dealt
+// (17.4 KB for the humanoid: kinematics, packed M, h, the whitened constraint rows Jh = J L^-T; blocks whose
+// lifetimes do not overlap share storage, see carve()), so eight envs are resident per CU — the kernel is
+// LDS-latency-bound at ~1 wave per SIMD, occupancy is what buys time (4 -> 8 envs per CU: 3.62 -> 1.86 ms at
+// 8 192 envs) — and nothing spills to scratch. Lanes are dealt
 //   * bodies (tree level by tree level) for kinematics and the Newton-Euler pass,
 //   * matrix entries for M, rows/columns for the Cholesky factorisation and the triangular solves,
 //   * collision spheres / joints for constraint detection (ballot + popcount gives every constraint
@@ -613,71 +613,57 @@ struct WaveLds {   // pointers into the env's LDS slab
                                              // vector, reciprocal Cholesky diagonal
     double *q, *qd, *tau;
     double *base;                            // pos[3] rot[9] vel[3] omega[3]
-    double *J, *Wm, *bias, *diag, *lam;
+    double *J, *bias, *diag, *lam;            // J: constraint rows, whitened in place (Jh = J L^-T)
     double *cx;                              // per contact: ground (x, y, depth) or self (point xc, normal)
     double *sc;                              // sin / cos of every joint angle
     int *mask, *depth, *jstart, *jcount, *poff, *kind, *partner, *csphere, *misc, *bod;
 };
 
-// The Newton-Euler temporaries (velocity-product frames fw/fal/fxr/far, body wrenches F/Nn, world inertias
-// Iw: 27 doubles per body) are dead once M and h are assembled, and the constraint images Wm = M^-1 J^T
-// are only written after that — so the temporaries live INSIDE the Wm block whenever they fit. For the
-// humanoid this takes the env's LDS slab from 33.2 KB to 30.4 KB: five envs per CU instead of four.
-__host__ __device__ inline bool wave_lds_alias(int nb, int nj, int maxr) { return 27 * (size_t)nb <= (size_t)maxr * (6 + nj); }
-// second overlay: the reciprocal diagonals and multipliers of the solver (diag, lam: 2 maxr doubles) are
-// first written after the constraint Jacobian is complete, when the body frames R / o / c (15 doubles per
-// body) are dead until the next kinematics pass
+// LDS layout. The solver works in Cholesky-whitened velocities y = L^T u (M = L L^T): with Jh = J L^-T
+//     J M^-1 J^T = Jh Jh^T,   J u = Jh y,   u += M^-1 J^T dl  <=>  y += Jh^T dl,
+// so ONE constraint matrix Jh (maxr rows of n doubles) replaces both J and W = M^-1 J^T, and a row costs one
+// forward substitution instead of a forward and a backward one. Blocks with disjoint lifetimes share storage:
+//  * the Jh block is scratch while M and h are assembled: the (body, dof) Jacobian pairs grow from its start,
+//    the Newton-Euler temporaries (velocity-product frames fw/fal/fxr/far, body wrenches F/Nn, world
+//    inertias Iw: 27 doubles per body) sit at its end — both dead before the first constraint row is written
+//    (`overlay` says whether they fit; mg_walker_step computes it from the topology);
+//  * the solver's reciprocal diagonals and multipliers (diag, lam: 2 maxr doubles) are first written after the
+//    constraint rows are complete, when the body frames R / o / c (15 doubles per body) are dead until the
+//    next kinematics pass;
+//  * sin / cos of the joint angles live only inside the kinematics pass, the contact points only between
+//    detection and the Jacobian rows: one block serves both;
+//  * M and its Cholesky factor are only ever touched in the lower triangle: packed.
+// Humanoid: 33.2 KB in the first layout (4 envs per CU) -> 17.4 KB; the register file (2 waves per SIMD)
+// then caps the kernel at 8 envs per CU.
 __host__ __device__ inline bool wave_lds_alias2(int nb, int maxr) { return 2 * (size_t)maxr <= 15 * (size_t)nb; }
-// third overlay: the joint anchors / axes p, a (6 doubles per joint) and the contact points cx (shared with
-// the sin / cos table) are last read while the Jacobian rows are written, i.e. before the first store to Wm:
-// they sit at the START of Wm (the Newton-Euler temporaries sit at its end)
-__host__ __device__ inline bool wave_lds_alias3(int nb, int nj, int maxr, bool allow) {
-    if (!allow) return false;   // the host turns it off when the assembly's Jacobian pairs do not fit in J alone
-    const size_t head = 6 * (size_t)nj + 6 * (size_t)W_MAXC + (2 * (size_t)nj <= 6 * (size_t)W_MAXC ? 0 : 2 * (size_t)nj);
-    return head + (wave_lds_alias(nb, nj, maxr) ? 27 * (size_t)nb : 0) <= (size_t)maxr * (6 + nj);
-}
-__host__ __device__ inline size_t wave_lds_doubles(int nb, int nj, int maxr, bool allow3) {
+__host__ __device__ inline size_t wave_lds_doubles(int nb, int nj, int maxr, bool overlay) {
     const int n = 6 + nj;
-    const size_t ne = wave_lds_alias(nb, nj, maxr) ? 0 : 27 * (size_t)nb;
-    const size_t pa_cx = wave_lds_alias3(nb, nj, maxr, allow3)
-                             ? 0
-                             : (size_t)nj * 6 + 6 * (size_t)W_MAXC + (2 * (size_t)nj <= 6 * (size_t)W_MAXC ? 0 : 2 * (size_t)nj);
-    return (size_t)nb * (9 + 3 + 3) + pa_cx + ne + (size_t)n * (n + 1) / 2 +
-           3 * (size_t)n + 3 * (size_t)nj + 18 + (size_t)(3 * W_MAXC) * n + (size_t)maxr * n +
-           (wave_lds_alias2(nb, maxr) ? 1 : 3) * (size_t)maxr;
+    return (size_t)nb * 15 + (size_t)nj * 6 + (overlay ? 0 : 27 * (size_t)nb) + (size_t)n * (n + 1) / 2 + 3 * (size_t)n +
+           3 * (size_t)nj + 18 + (size_t)maxr * n + (wave_lds_alias2(nb, maxr) ? 1 : 3) * (size_t)maxr +
+           6 * (size_t)W_MAXC + (2 * (size_t)nj <= 6 * (size_t)W_MAXC ? 0 : 2 * (size_t)nj);
 }
 __host__ __device__ inline size_t wave_lds_ints(int nb, int maxr) { return 5 * (size_t)nb + 2 * (size_t)maxr + 2 * W_MAXC + 8 + ND; }
 
-__device__ __forceinline__ WaveLds carve(unsigned char *smem, int nb, int nj, int maxr, bool allow3) {
+__device__ __forceinline__ WaveLds carve(unsigned char *smem, int nb, int nj, int maxr, bool overlay) {
     const int n = 6 + nj;
     WaveLds L;
     double *d = reinterpret_cast<double *>(smem);
-    L.R = d; d += 9 * nb; L.o = d; d += 3 * nb; L.c = d; d += 3 * nb;
-    const bool alias = wave_lds_alias(nb, nj, maxr), alias3 = wave_lds_alias3(nb, nj, maxr, allow3);
-    if (!alias3) { L.p = d; d += 3 * nj; L.a = d; d += 3 * nj; }
-    double *ne = d;                       // Newton-Euler temporaries: own block, or inside Wm (see above)
-    if (!alias) d += 27 * nb;
+    L.R = d; d += 9 * nb; L.o = d; d += 3 * nb; L.c = d; d += 3 * nb; L.p = d; d += 3 * nj; L.a = d; d += 3 * nj;
+    double *ne = d;                       // Newton-Euler temporaries: own block, or the tail of the Jh block
+    if (!overlay) d += 27 * nb;
     L.M = d; d += n * (n + 1) / 2; L.h = d; d += n; L.x = d; d += n; L.idg = d; d += n;
     L.q = d; d += nj; L.qd = d; d += nj; L.tau = d; d += nj;
     L.base = d; d += 18;
-    L.J = d; d += (size_t)(3 * W_MAXC) * n;      // contact rows only: a joint-limit row is +-e_(6+j), never stored
-    L.Wm = d; d += (size_t)maxr * n;
-    // [J | Wm] doubles as scratch while M and h are assembled: the (body, dof) Jacobian pairs grow from its
-    // start, the Newton-Euler temporaries sit at its end (mg_walker_step checks that they cannot meet)
-    if (alias) ne = d - 27 * nb;
-    double *hd = L.Wm;                    // p, a, cx (+ sc): own blocks, or the head of Wm (third overlay)
-    if (alias3) { L.p = hd; hd += 3 * nj; L.a = hd; hd += 3 * nj; }
+    L.J = d; d += (size_t)maxr * n;       // constraint rows, whitened in place (Jh)
+    if (overlay) ne = d - 27 * nb;
     L.fw = ne; ne += 3 * nb; L.fal = ne; ne += 3 * nb; L.fxr = ne; ne += 3 * nb; L.far_ = ne; ne += 3 * nb;
     L.F = ne; ne += 3 * nb; L.Nn = ne; ne += 3 * nb; L.Iw = ne;
     L.bias = d; d += maxr;
     if (wave_lds_alias2(nb, maxr)) { L.diag = L.R; L.lam = L.R + maxr; }
     else { L.diag = d; d += maxr; L.lam = d; d += maxr; }
-    // sin / cos of the joint angles live only inside the kinematics pass, the contact points only between
-    // detection and the Jacobian rows: one block serves both
-    double *&cur = alias3 ? hd : d;
-    L.cx = cur; cur += 6 * W_MAXC;
+    L.cx = d; d += 6 * W_MAXC;
     if (2 * nj <= 6 * W_MAXC) L.sc = L.cx;
-    else { L.sc = cur; cur += 2 * nj; }
+    else { L.sc = d; d += 2 * nj; }
     int *i = reinterpret_cast<int *>(d);
     L.mask = i; i += nb; L.depth = i; i += nb; L.jstart = i; i += nb; L.jcount = i; i += nb; L.poff = i; i += nb;
     L.kind = i; i += maxr; L.partner = i; i += maxr; L.csphere = i; i += 2 * W_MAXC; L.misc = i; i += 8; L.bod = i;
@@ -877,8 +863,9 @@ __device__ void wave_substep(const mg_walker_topology &tp, const ModelRef &m, co
         else if (lane > c && lane < n) L.M[TRI(lane, c)] = v * ipiv;
         WSYNC();
     }
-    // ---- free motion u* = u + dt M^-1 (tau - h): column-oriented triangular solves, x in registers ---
-    double u_d = 0.0;   // lane d < n keeps its generalized velocity in a register
+    // ---- free motion in whitened coordinates: y* = L^T u + dt L^-1 (tau - h) (one forward solve; the
+    //      backward solve happens once, after the constraint solver) ------------------------------------
+    double u_d = 0.0;   // lane d < n: generalized velocity on entry, whitened velocity y_d from here on
     double x_d = 0.0;
     if (lane < n) {
         const int d = lane;
@@ -891,17 +878,15 @@ __device__ void wave_substep(const mg_walker_topology &tp, const ModelRef &m, co
             u_d = L.base[d < 3 ? 12 + d : 15 + (d - 3)];
         }
     }
-    for (int r = 0; r < n; ++r) {                      // L y = b
-        const double xr = lane_value(x_d, r) * L.idg[r];
+    double y_d = 0.0;
+    for (int r = 0; r < n; ++r) {
+        const double xr = lane_value(x_d, r) * L.idg[r];           // L z = b
         if (lane == r) x_d = xr;
         else if (lane > r && lane < n) x_d -= L.M[TRI(lane, r)] * xr;
+        const double ur = lane_value(u_d, r);                       // y = L^T u: y_d = sum_{r >= d} L[r][d] u_r
+        if (lane <= r) y_d += L.M[TRI(r, lane)] * ur;
     }
-    for (int r = n - 1; r >= 0; --r) {                 // L^T x = y
-        const double xr = lane_value(x_d, r) * L.idg[r];
-        if (lane == r) x_d = xr;
-        else if (lane < r) x_d -= L.M[TRI(r, lane)] * xr;
-    }
-    if (lane < n) u_d += dt * x_d;
+    u_d = lane < n ? y_d + dt * x_d : 0.0;
     // ---- constraint detection ------------------------------------------------------------------------
     bool hit = false;
     double sx = 0, sy = 0, depth = 0;
@@ -973,7 +958,7 @@ __device__ void wave_substep(const mg_walker_topology &tp, const ModelRef &m, co
     const int nr = 3 * ncont + __popcll(lims);
     if (lsgn != 0.0) {
         const int r = 3 * ncont + __popcll(lims & ((1ull << lane) - 1ull));
-        // J_r = lsgn * e_(6+joint): kept as (kind 4 / 5 = sign, partner = joint), not as a dense row
+        // J_r = lsgn * e_(6+joint): kept as (kind 4 / 5 = sign, partner = joint) until the whitening pass builds it
         L.bias[r] = prm.limit_erp * viol / dt; L.kind[r] = lsgn > 0.0 ? 4 : 5; L.partner[r] = lane;
     }
     WSYNC();
@@ -999,17 +984,19 @@ __device__ void wave_substep(const mg_walker_topology &tp, const ModelRef &m, co
         }
     }
     WSYNC();
-    // ---- W = M^-1 J^T: lane = row. The right-hand side lives in registers (a fully unrolled NMAX-slot
-    //      array): through LDS every step of the substitution would wait on its own previous store ------
+    // ---- Jh = J L^-T, lane = row, in place. The right-hand side lives in registers (a fully unrolled
+    //      NMAX-slot array): through LDS every step of the substitution would wait on its own previous store.
+    //      A joint-limit row starts as +-e_(6+j) and is never materialised before this point -------------------
     for (int r = lane; r < nr; r += WV) {
         double w[NMAX];
         const int rkind = L.kind[r];
         const bool is_limit = rkind >= 4;
         const int ldof = is_limit ? 6 + L.partner[r] : -1;
         const double lsg = rkind == 4 ? 1.0 : -1.0;
-        const double *jr = L.J + (size_t)(is_limit ? 0 : r) * n;
+        double *jr = L.J + (size_t)r * n;
 #pragma unroll
         for (int d = 0; d < NMAX; ++d) w[d] = d < n ? (is_limit ? (d == ldof ? lsg : 0.0) : jr[d]) : 0.0;
+        double dd = 0.0;
 #pragma unroll
         for (int d = 0; d < NMAX; ++d) {
             if (d < n) {
@@ -1017,36 +1004,22 @@ __device__ void wave_substep(const mg_walker_topology &tp, const ModelRef &m, co
 #pragma unroll
                 for (int k = 0; k < d; ++k) v -= L.M[TRI(d, k)] * w[k];
                 w[d] = v * L.idg[d];
+                dd += w[d] * w[d];
+                jr[d] = w[d];
             }
         }
-#pragma unroll
-        for (int d = NMAX - 1; d >= 0; --d) {
-            if (d < n) {
-                double v = w[d];
-#pragma unroll
-                for (int k = d + 1; k < NMAX; ++k)
-                    if (k < n) v -= L.M[TRI(k, d)] * w[k];
-                w[d] = v * L.idg[d];
-            }
-        }
-        double dd = 0.0;
-        double *wo = L.Wm + (size_t)r * n;
-#pragma unroll
-        for (int d = 0; d < NMAX; ++d)
-            if (d < n) { dd += (is_limit ? (d == ldof ? lsg : 0.0) : jr[d]) * w[d]; wo[d] = w[d]; }
-        L.diag[r] = dd > 0.0 ? 1.0 / dd : 0.0;          // reciprocal: the sweep below multiplies
+        L.diag[r] = dd > 0.0 ? 1.0 / dd : 0.0;          // reciprocal of Jh_r . Jh_r = J_r M^-1 J_r^T
         L.lam[r] = 0.0;
     }
     WSYNC();
-    // ---- projected Gauss-Seidel in velocity space (wave-uniform row loop) --------------------------
+    // ---- projected Gauss-Seidel on the whitened velocity y (wave-uniform row loop) --------------------
     for (int it = 0; it < prm.solver_iterations; ++it)
         for (int r = 0; r < nr; ++r) {
             const double idg = L.diag[r];
             if (!(idg > 0.0)) continue;
             const int rkind = L.kind[r];
-            double jv;
-            if (rkind >= 4) jv = (rkind == 4 ? 1.0 : -1.0) * lane_value(u_d, 6 + L.partner[r]);   // J_r = +-e_(6+j)
-            else jv = wave_sum(lane < n ? L.J[(size_t)r * n + lane] * u_d : 0.0);
+            const double jh = lane < n ? L.J[(size_t)r * n + lane] : 0.0;
+            const double jv = wave_sum(jh * u_d);                    // J_r u = Jh_r . y
             const double lr = L.lam[r];
             double x = lr - (jv - L.bias[r]) * idg;
             if (rkind == 0 || rkind >= 4) x = x > 0.0 ? x : 0.0;
@@ -1055,11 +1028,17 @@ __device__ void wave_substep(const mg_walker_topology &tp, const ModelRef &m, co
                 x = x < -lim ? -lim : (x > lim ? lim : x);
             }
             const double dl = x - lr;
-            if (lane < n) u_d += L.Wm[(size_t)r * n + lane] * dl;
+            u_d += jh * dl;                                          // y += Jh_r^T dlambda
             // single-wave workgroup: LDS operations of one wavefront retire in program order, so every
             // lane has read lam[r] / lam[partner] above before this store lands
             if (lane == 0) L.lam[r] = x;
         }
+    // ---- back to generalized velocities: u = L^-T y ---------------------------------------------------
+    for (int r = n - 1; r >= 0; --r) {
+        const double xr = lane_value(u_d, r) * L.idg[r];
+        if (lane == r) u_d = xr;
+        else if (lane < r) u_d -= L.M[TRI(r, lane)] * xr;
+    }
     // ---- integrate -------------------------------------------------------------------------------------
     if (lane < n) {
         if (lane >= 6) {
@@ -1094,9 +1073,9 @@ __global__ __launch_bounds__(WV) void walker_step_wave_kernel(mg_walker_topology
     const int e = blockIdx.x, lane = threadIdx.x;
     const int nb = tp.n_bodies, nj = tp.n_joints, nf = tp.n_feet, obs_dim = 8 + 2 * nj + nf;
     const ModelRef m = model_ref(tp, ms, st.task_id[e]);
-    const bool allow3 = maxr_flags < 0;          // sign bit of the row-count argument = third LDS overlay on
+    const bool overlay = maxr_flags < 0;         // sign of the row-count argument: assembly scratch overlaid on Jh
     const int maxr = maxr_flags < 0 ? -maxr_flags : maxr_flags;
-    const WaveLds L = carve(smem, nb, nj, maxr, allow3);
+    const WaveLds L = carve(smem, nb, nj, maxr, overlay);
     // tree bookkeeping (lane 0) + state load (lanes)
     if (lane == 0) {
         int md = 0, j = 0;
@@ -1295,10 +1274,9 @@ extern "C" int mg_walker_step(const mg_walker_topology *tp, const mg_walker_mode
     if (tp->n_spheres > 64 || 6 + tp->n_joints > 64)
         return mg::set_error(MG_ERR_BAD_SIZE, "wave mapping needs <= 64 spheres and <= 58 joints");
     const int maxr = 3 * W_MAXC + tp->n_joints;
-    // scratch use of the [J | Wm] block during the M / h assembly: 6 doubles per (body, dof-on-its-chain) pair
-    // from the front, 27 doubles per body of Newton-Euler temporaries from the back; with the third overlay
-    // (joint frames and contact points at the head of Wm) the pairs must stay inside J
-    bool allow3 = false;
+    // scratch use of the Jh block during the M / h assembly: 6 doubles per (body, dof-on-its-chain) pair from the
+    // front and, when they also fit, 27 doubles per body of Newton-Euler temporaries from the back
+    bool overlay = false;
     {
         int chain[MG_WALKER_MAX_BODIES];
         size_t pairs = 0;
@@ -1309,17 +1287,15 @@ extern "C" int mg_walker_step(const mg_walker_topology *tp, const mg_walker_mode
             chain[b] = own + (pb >= 0 && pb < b ? chain[pb] : 0);
             pairs += 6 + chain[b];
         }
-        allow3 = 6 * pairs <= (size_t)(3 * W_MAXC) * ndof_of(tp);
-        const bool a3 = wave_lds_alias3(tp->n_bodies, tp->n_joints, maxr, allow3);
-        const size_t block = a3 ? (size_t)(3 * W_MAXC) * ndof_of(tp) : (size_t)(3 * W_MAXC + maxr) * ndof_of(tp);
-        const size_t ne = (!a3 && wave_lds_alias(tp->n_bodies, tp->n_joints, maxr)) ? 27 * (size_t)tp->n_bodies : 0;
-        if (6 * pairs + ne > block)
+        const size_t block = (size_t)maxr * ndof_of(tp);
+        if (6 * pairs > block)
             return mg::set_error(MG_ERR_UNSUPPORTED, "walker topology needs %zu scratch doubles for the mass-matrix "
-                                 "assembly, the wave mapping has %zu: use mapping = lane", 6 * pairs + ne, block);
+                                 "assembly, the wave mapping has %zu: use mapping = lane", 6 * pairs, block);
+        overlay = 6 * pairs + 27 * (size_t)tp->n_bodies <= block;
     }
-    const size_t lds = wave_lds_doubles(tp->n_bodies, tp->n_joints, maxr, allow3) * sizeof(double) +
+    const size_t lds = wave_lds_doubles(tp->n_bodies, tp->n_joints, maxr, overlay) * sizeof(double) +
                        wave_lds_ints(tp->n_bodies, maxr) * sizeof(int);
-    const int maxr_flags = allow3 ? -maxr : maxr;
+    const int maxr_flags = overlay ? -maxr : maxr;
     if (lds > 160 * 1024) return mg::set_error(MG_ERR_BAD_SIZE, "walker needs %zu B of LDS", lds);
     if (lds > 64 * 1024) return mg::set_error(MG_ERR_BAD_SIZE, "walker needs %zu B of LDS (> 64 KiB)", lds);
     const int ndof = 6 + tp->n_joints;
