@@ -566,9 +566,10 @@ __global__ __launch_bounds__(WK_BLOCK) void walker_reset_kernel(mg_walker_topolo
 //   * matrix entries for M, rows/columns for the Cholesky factorisation and the triangular solves,
 //   * collision spheres / joints for constraint detection (ballot + popcount gives every constraint
 //     its row index in sphere / joint order, the same order the oracle uses),
-//   * constraint rows for W = M^-1 J^T (each lane back-substitutes its own right-hand side),
-//   * generalized coordinates for the PGS sweep (J_r . u by a wave reduction, u += W_r dlambda per lane).
-// Same equations as the lane-per-env kernel above; only the summation order of the dot products differs.
+//   * constraint rows for the whitening Jh = J L^-T (each lane forward-substitutes its own right-hand side),
+//   * whitened coordinates for the PGS sweep (Jh_r . y by a wave reduction, y += Jh_r dlambda per lane).
+// Same physics as the lane-per-env kernel above (which keeps the plain J / W = M^-1 J^T solver); the two
+// agree to round-off.
 // ======================================================================================================
 
 constexpr int WV = 64;
