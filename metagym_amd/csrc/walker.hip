@@ -610,7 +610,7 @@ struct WaveLds {   // pointers into the env's LDS slab
     double *R, *o, *c, *p, *a;               // kinematics
     double *fw, *fal, *fxr, *far_;           // frames after each body's joints
     double *F, *Nn, *Iw;                     // per-body bias wrench and world inertia
-    double *M, *h, *x, *idg;                 // joint-space inertia (then its Cholesky factor), bias, scratch
+    double *M, *h, *idg;                     // joint-space inertia (then its packed Cholesky factor), bias, 1/diag(L)
                                              // vector, reciprocal Cholesky diagonal
     double *q, *qd, *tau;
     double *base;                            // pos[3] rot[9] vel[3] omega[3]
@@ -639,7 +639,7 @@ struct WaveLds {   // pointers into the env's LDS slab
 __host__ __device__ inline bool wave_lds_alias2(int nb, int maxr) { return 2 * (size_t)maxr <= 15 * (size_t)nb; }
 __host__ __device__ inline size_t wave_lds_doubles(int nb, int nj, int maxr, bool overlay) {
     const int n = 6 + nj;
-    return (size_t)nb * 15 + (size_t)nj * 6 + (overlay ? 0 : 27 * (size_t)nb) + (size_t)n * (n + 1) / 2 + 3 * (size_t)n +
+    return (size_t)nb * 15 + (size_t)nj * 6 + (overlay ? 0 : 27 * (size_t)nb) + (size_t)n * (n + 1) / 2 + 2 * (size_t)n +
            3 * (size_t)nj + 18 + (size_t)maxr * n + (wave_lds_alias2(nb, maxr) ? 1 : 3) * (size_t)maxr +
            6 * (size_t)W_MAXC + (2 * (size_t)nj <= 6 * (size_t)W_MAXC ? 0 : 2 * (size_t)nj);
 }
@@ -652,7 +652,7 @@ __device__ __forceinline__ WaveLds carve(unsigned char *smem, int nb, int nj, in
     L.R = d; d += 9 * nb; L.o = d; d += 3 * nb; L.c = d; d += 3 * nb; L.p = d; d += 3 * nj; L.a = d; d += 3 * nj;
     double *ne = d;                       // Newton-Euler temporaries: own block, or the tail of the Jh block
     if (!overlay) d += 27 * nb;
-    L.M = d; d += n * (n + 1) / 2; L.h = d; d += n; L.x = d; d += n; L.idg = d; d += n;
+    L.M = d; d += n * (n + 1) / 2; L.h = d; d += n; L.idg = d; d += n;
     L.q = d; d += nj; L.qd = d; d += nj; L.tau = d; d += nj;
     L.base = d; d += 18;
     L.J = d; d += (size_t)maxr * n;       // constraint rows, whitened in place (Jh)
