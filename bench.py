@@ -106,6 +106,46 @@ def cpu_baseline(seconds=12.0, n_envs_per_thread=256, max_threads=None):
                       % (total, n_envs_per_thread, el)}
 
 
+def cpu_baseline_maze3d(seconds=4.0, res=256):
+    """Secondary CPU figure for C3: the C oracle's MetaMazeDiscrete3D step + 256x256 render
+    (oracle/maze_oracle.c, the scalar restatement of the un-jitted reference; the real numba timing is not
+    available offline), one env per host core, for a few seconds."""
+    from oracle import maze as mo
+    from metagym_amd.metamaze import MAZE_TASK_MANAGER, MazeTaskSampler
+    cores = usable_cpus()
+    tt = mo.TASK_TYPES["SURVIVAL"]
+    tex = MAZE_TASK_MANAGER.grounds.astype(np.uint8)
+    counts = [0] * cores
+    stop = time.perf_counter() + seconds
+
+    def work(i):
+        task = mo.Task(**MazeTaskSampler(n=9, allow_loops=False, step_reward=-0.01, goal_reward=1.0, food_density=0.06,
+                                         food_interval=20, seed=i)._asdict())
+        st = mo.State(task)
+        mo.reset(task, tt, st)
+        view = mo.View(tex, MAZE_TASK_MANAGER.ceil, res, res)
+        rs = np.random.RandomState(i)
+        n = 0
+        while time.perf_counter() < stop:
+            r, d = mo.step_disc3d(task, tt, 200, st, int(rs.randint(4)))
+            mo.observe_3d(task, tt, view, st, 0)
+            if d:
+                mo.reset(task, tt, st)
+            n += 1
+        counts[i] = n
+
+    t0 = time.perf_counter()
+    threads = [threading.Thread(target=work, args=(i,)) for i in range(cores)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    el = time.perf_counter() - t0
+    return {"value": sum(counts) / el, "unit": "env-steps/s", "cores": cores, "kind": "port",
+            "sample": "%d steps + %dx%d frames, %.1f s wall, C oracle gcc -O2 scalar, one env per core"
+                      % (sum(counts), res, res, el)}
+
+
 def _time_steps(step_fn, steps, warmup):
     for i in range(warmup):
         step_fn(i)
@@ -372,6 +412,11 @@ def main():
             out["secondary"] = secondary_workloads(dev)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
+            if "secondary" in out and "C3_maze3d_discrete_9x9_256x256_16384envs" in out["secondary"]:
+                try:
+                    out["secondary"]["C3_maze3d_discrete_9x9_256x256_16384envs"]["cpu_baseline"] = cpu_baseline_maze3d()
+                except Exception as e:
+                    out["secondary"]["C3_maze3d_discrete_9x9_256x256_16384envs"]["cpu_baseline_error"] = repr(e)
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.destroy_process_group()
