@@ -187,6 +187,13 @@ typedef struct mg_maze_tasks {
     const int32_t *food_interval;  /* [T][n*n] */
     const double *scalars;         /* [T][8]: cell_size, wall_height, agent_height, initial_life,
                                       max_life, step_reward, goal_reward, (pad) */
+    /* Optional accelerator for SURVIVAL (NULL / 0 = sweep all n*n cells): per task, the cells that can ever
+     * hold food — those with food_interval > 0 or food_rewards > 1e-2 — in ascending order. Every other cell's
+     * wait flag, counter and food value never change (maze_base.py:83-88 only acts on cells whose counter
+     * drops below 0 after a wait flag was set), so visiting just this list is exact. */
+    const int16_t *food_cells;     /* [T][max_food] */
+    const int32_t *n_food;         /* [T] */
+    int32_t max_food;
 } mg_maze_tasks;
 
 /* Per-env episode state (MazeBase.reset maze_base.py:40-63 + the 3-D cores). The SURVIVAL arrays

@@ -52,7 +52,8 @@ class MazeTasks(C.Structure):
     """mg_maze_tasks (device pointers)"""
     _fields_ = [("n", C.c_int32), ("n_tasks", C.c_int32), ("start", C.c_void_p), ("goal", C.c_void_p),
                 ("walls", C.c_void_p), ("texts", C.c_void_p), ("food_rewards", C.c_void_p),
-                ("food_interval", C.c_void_p), ("scalars", C.c_void_p)]
+                ("food_interval", C.c_void_p), ("scalars", C.c_void_p),
+                ("food_cells", C.c_void_p), ("n_food", C.c_void_p), ("max_food", C.c_int32)]
 
 
 class MazeSampleParams(C.Structure):

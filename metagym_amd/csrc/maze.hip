@@ -47,6 +47,8 @@ struct Task {   // one row of the task table, resolved for an env
     const uint8_t *texts;
     const double *food;
     const int32_t *interval;
+    const int16_t *food_cells;   // optional compact list of the cells that can hold food (NULL = all cells)
+    int n_food;
     int sx, sy, gx, gy;
     double cell_size, wall_h, agent_h, init_life, max_life, step_reward, goal_reward;
 };
@@ -60,6 +62,8 @@ __device__ __forceinline__ Task load_task(const mg_maze_tasks &T, int tid) {
     t.texts = T.texts + off;
     t.food = T.food_rewards ? T.food_rewards + off : nullptr;
     t.interval = T.food_interval ? T.food_interval + off : nullptr;
+    t.food_cells = (T.food_cells != nullptr && T.n_food != nullptr) ? T.food_cells + (size_t)tid * T.max_food : nullptr;
+    t.n_food = t.food_cells ? T.n_food[tid] : t.nn;
     t.sx = T.start[2 * tid];
     t.sy = T.start[2 * tid + 1];
     t.gx = T.goal[2 * tid];
@@ -118,8 +122,15 @@ __device__ __forceinline__ size_t fidx(const mg_maze_state &st, int e, int c) {
 }
 
 // MazeBase.reset — per-cell part (SURVIVAL), cells c = first, first+stride, ...
-__device__ __forceinline__ void reset_cells(const Task &t, const mg_maze_state &st, int e, int first, int stride) {
-    for (int c = first; c < t.nn; c += stride) {
+// full = true (mg_maze_reset): every cell is written. full = false (fused auto-reset): with a food-cell list
+// only those cells are rewritten — the others still hold the values the last full reset gave them, because
+// nothing ever changes a cell whose food is <= 1e-2 and whose interval is 0.
+__device__ __forceinline__ void reset_cells(const Task &t, const mg_maze_state &st, int e, int first, int stride,
+                                            bool full) {
+    const bool listed = !full && t.food_cells != nullptr;
+    const int count = listed ? t.n_food : t.nn;
+    for (int k = first; k < count; k += stride) {
+        const int c = listed ? (int)t.food_cells[k] : k;
         const size_t i = fidx(st, e, c);
         st.wait_refresh[i] = 0;
         st.cur_food[i] = t.food[c];
@@ -155,7 +166,8 @@ __device__ __forceinline__ int eval_scalar(const Task &t, const mg_maze_state &s
 // interval * (food_rewards > 1e-3), maze_task.py:172): its wait flag stays 0 and its counter stays
 // 0, so skipping it is exact and saves the HBM round trip for the ~95 % of cells that are empty.
 __device__ __forceinline__ void eval_cells(const Task &t, const mg_maze_state &st, int e, int first, int stride) {
-    for (int c = first; c < t.nn; c += stride) {
+    for (int k = first; k < t.n_food; k += stride) {
+        const int c = t.food_cells ? (int)t.food_cells[k] : k;
         const int interval = t.interval[c];
         if (interval == 0 && !(t.food[c] > 1.0e-2)) continue;
         const size_t i = fidx(st, e, c);
@@ -196,7 +208,7 @@ __global__ __launch_bounds__(MZ_BLOCK) void maze2d_step_kernel(mg_maze_tasks T, 
         done[e] = (uint8_t)d;
         if (d && auto_reset) {
             reset_agent(t, task_type, a);
-            if (task_type == MG_MAZE_SURVIVAL) reset_cells(t, st, e, 0, 1);
+            if (task_type == MG_MAZE_SURVIVAL) reset_cells(t, st, e, 0, 1, false);
         }
         store_agent(st, n_envs, e, a);
     }
@@ -717,7 +729,7 @@ __global__ __launch_bounds__(MZ_BLOCK) void maze3d_step_kernel(mg_maze_tasks T, 
     __syncthreads();
     if (action != nullptr && task_type == MG_MAZE_SURVIVAL) eval_cells(t, st, e, tid, n_threads);   // :83-88
     if (es->done && auto_reset) {
-        if (task_type == MG_MAZE_SURVIVAL) reset_cells(t, st, e, tid, n_threads);
+        if (task_type == MG_MAZE_SURVIVAL) reset_cells(t, st, e, tid, n_threads, false);
         __syncthreads();
         if (tid == 0) reset_agent(t, task_type, es->a);
     }
@@ -855,7 +867,7 @@ __global__ __launch_bounds__(MZ_BLOCK) void maze_reset_kernel(mg_maze_tasks T, m
     if (e >= n_envs) return;
     if (mask != nullptr && mask[e] == 0) return;
     const Task t = load_task(T, st.task_id[e]);
-    if (task_type == MG_MAZE_SURVIVAL) reset_cells(t, st, e, lane, 64);
+    if (task_type == MG_MAZE_SURVIVAL) reset_cells(t, st, e, lane, 64, true);
     if (lane == 0) {
         Agent a = load_agent(st, n_envs, e);
         reset_agent(t, task_type, a);

@@ -95,6 +95,16 @@ class _MazeBatch(object):
         c.n, c.n_tasks = n, T
         for k in host:
             setattr(c, k, self._task_t[k].data_ptr())
+        # compact list of the cells that can ever hold food (exact shortcut for the SURVIVAL sweeps, see
+        # include/metagym_hip.h); built with device ops so a DeviceTaskTable never visits the host
+        tt_food, tt_int = self._task_t["food_rewards"], self._task_t["food_interval"]
+        can = (tt_int > 0) | (tt_food > 1.0e-2)                                  # [T, nn]
+        n_food = can.sum(dim=1).to(torch.int32)
+        max_food = max(1, int(n_food.max().item()))
+        order = torch.argsort((~can).to(torch.int8), dim=1, stable=True)[:, :max_food]   # food cells first, ascending
+        self._food_cells_t = order.to(torch.int16).contiguous()
+        self._n_food_t = n_food.contiguous()
+        c.food_cells, c.n_food, c.max_food = self._food_cells_t.data_ptr(), self._n_food_t.data_ptr(), max_food
         self._tasks_c = c
         if task_ids is None:
             task_ids = torch.arange(N, dtype=torch.int32) % T
