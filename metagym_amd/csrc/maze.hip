@@ -816,10 +816,11 @@ __global__ __launch_bounds__(MZ_BLOCK) void maze3d_step_kernel(mg_maze_tasks T, 
                 const bool row_ok = d_v < vk.V;
                 const int d_r = row_ok ? d_v : 0;
                 RowK rk;
+                const uint32_t rt = __umul24((uint32_t)d_r, 3u);      // full-rate 24-bit multiply
                 rk.kind = row_kind[d_r];
-                rk.distance = row_tab[3 * d_r];
-                rk.light = row_tab[3 * d_r + 1];
-                rk.ys = row_tab[3 * d_r + 2];
+                rk.distance = row_tab[rt];
+                rk.light = row_tab[rt + 1];
+                rk.ys = row_tab[rt + 2];
                 int R, G, B;
                 pixel_pass(vk, t, pos_x, pos_y, rk, texts, transp, wc, entries, k, d_v, cs, inv_cs, cs_pow2, text_to_cell,
                            inv_ttc, ttc_pow2, fast_tex, tex_scale, cell_shift, R, G, B);
