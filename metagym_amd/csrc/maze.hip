@@ -829,12 +829,16 @@ __global__ __launch_bounds__(MZ_BLOCK) void maze3d_step_kernel(mg_maze_tasks T, 
                 if (row_ok) {
                     if (vk.obs_u8) {      // non-parity fast path: saturate to a byte
                         uint8_t *q = img8 + off;
-                        q[0] = (uint8_t)min(max(R, 0), 255);
-                        q[1] = (uint8_t)min(max(G, 0), 255);
-                        q[2] = (uint8_t)min(max(B, 0), 255);
+                        __builtin_nontemporal_store((uint8_t)min(max(R, 0), 255), q);
+                        __builtin_nontemporal_store((uint8_t)min(max(G, 0), 255), q + 1);
+                        __builtin_nontemporal_store((uint8_t)min(max(B, 0), 255), q + 2);
                     } else {
-                        int3s px{R, G, B};
-                        *reinterpret_cast<int3s *>(reinterpret_cast<char *>(img) + off) = px;
+                        // streaming stores: a 12.9 GB frame batch can never stay in the 32 MB of L2, but the
+                        // textures and task tables it would evict are re-read by every pixel (-7 % at 256x256)
+                        int *q = reinterpret_cast<int *>(reinterpret_cast<char *>(img) + off);
+                        __builtin_nontemporal_store(R, q);
+                        __builtin_nontemporal_store(G, q + 1);
+                        __builtin_nontemporal_store(B, q + 2);
                     }
                 }
             }
