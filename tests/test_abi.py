@@ -119,3 +119,21 @@ def test_walker_wave_mapping_rejects_topologies_its_lds_scratch_cannot_hold():
     rc = lib.mg_walker_step(tp, ms, prm, 4, st, p, p, p, None, p, None)
     assert rc == -1004, rc                                       # MG_ERR_UNSUPPORTED
     assert b"mapping = lane" in lib.mg_last_error()
+
+
+def test_public_header_is_plain_c99(tmp_path):
+    """The boundary is a C ABI: include/metagym_hip.h must compile as C99 (no C++-isms, no HIP or torch types)
+    and a C program must be able to link the shared library's symbols."""
+    import shutil
+    import subprocess
+    gcc = shutil.which("gcc")
+    if gcc is None:
+        pytest.skip("gcc not available")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = tmp_path / "use_header.c"
+    src.write_text('#include "metagym_hip.h"\n'
+                   'int probe(void) { mg_quadrotor_config c; mg_maze_tasks t; mg_walker_params p;\n'
+                   '  (void)t; (void)p; return mg_quadrotor_default_config(&c) + mg_abi_version(); }\n')
+    out = subprocess.run([gcc, "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", os.path.join(root, "include"),
+                          "-c", str(src), "-o", str(tmp_path / "use_header.o")], capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr
