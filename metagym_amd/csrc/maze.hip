@@ -28,6 +28,7 @@
 //     become multiplications only when the divisor is a power of two (bit-identical).
 //   * No MFMA (no contraction), no atomics, no inter-workgroup communication.
 #include <cstdlib>
+#include <cstring>
 
 #include "mg_common.h"
 
@@ -977,6 +978,14 @@ extern "C" int mg_maze3d_step(const mg_maze_tasks *T, const mg_maze_view *view, 
     vk.TS = view->tex_size;
     vk.obs_u8 = view->obs_format == 1;
     vk.max_vision = view->max_vision;
+    {
+        // div_by()'s correctly-rounded quotient (Markstein) needs a divisor whose significand is not all ones;
+        // cos_hp is float32-valued, so only a pathological max_vision could violate it
+        uint64_t bits;
+        memcpy(&bits, &view->max_vision, sizeof(bits));
+        if ((bits & 0xFFFFFFFFFFFFFull) == 0xFFFFFFFFFFFFFull)
+            return mg::set_error(MG_ERR_UNSUPPORTED, "max_vision = %.17g has an all-ones significand", view->max_vision);
+    }
     vk.inv_max_vision = 1.0 / view->max_vision;
     vk.max_vision_lo = view->max_vision * (1.0 - 1.0e-12);   // see pixel_pass: below this, fog is exactly 0
     vk.l_focal = view->l_focal;
