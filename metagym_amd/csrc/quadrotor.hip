@@ -490,20 +490,22 @@ __device__ __forceinline__ void store_obs_wave(float *tile, const float *obs, fl
 // QuadrotorSim.reset quadrotorsim.py:239-258 with the noise drawn on the device:
 // value = base + noisy * U[0,1) * (+1 if U' > 0.5 else -1), per component.
 __device__ __forceinline__ void reset_lane_random(const QuadK &k, Lane &s, int e, uint64_t step) {
-    uint32_t r[12];
+    // two Philox calls = 8 words: six 32-bit magnitudes and one word of sign bits (the reset sits on the
+    // critical path of every wave that holds a finished env, so a third call is worth avoiding)
+    uint32_t r[8];
     const uint64_t gid = k.env_id_base + (uint64_t)e;   // global env id: shard-invariant streams
 #pragma unroll
-    for (int d = 0; d < 3; ++d)
+    for (int d = 0; d < 2; ++d)
         philox4x32_10((uint32_t)gid, (uint32_t)step, (uint32_t)(step >> 32) ^ ((uint32_t)(gid >> 32) << 8),
                       (uint32_t)d, (uint32_t)k.seed, (uint32_t)(k.seed >> 32), &r[4 * d]);
     const double inv32 = 1.0 / 4294967296.0;
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
         s.p[c] = 0.0f;
-        const double sv = (r[c] & 1u) ? 1.0 : -1.0;
-        const double sw = (r[c] & 2u) ? 1.0 : -1.0;
-        s.v[c] = (double)k.init_v_base[c] + (k.init_v_noisy * ((double)r[3 + c] * inv32)) * sv;
-        s.w[c] = (double)k.init_w_base[c] + (k.init_w_noisy * ((double)r[6 + c] * inv32)) * sw;
+        const double sv = ((r[6] >> c) & 1u) ? 1.0 : -1.0;
+        const double sw = ((r[6] >> (3 + c)) & 1u) ? 1.0 : -1.0;
+        s.v[c] = (double)k.init_v_base[c] + (k.init_v_noisy * ((double)r[c] * inv32)) * sv;
+        s.w[c] = (double)k.init_w_base[c] + (k.init_w_noisy * ((double)r[3 + c] * inv32)) * sw;
     }
 #pragma unroll
     for (int c = 0; c < 4; ++c) s.pw[c] = 0.0f;
