@@ -803,21 +803,24 @@ __device__ void wave_substep(const mg_walker_topology &tp, const ModelRef &m, co
     }
     WSYNC();
     double *pairs = L.J;          // [n_pairs][6] = (jv, jw)
-    for (int b = 0; b < nb; ++b) {
+    // flat over all (body, dof) pairs — 133 for the humanoid, three passes of the wave — instead of one pass
+    // per body with a dozen active lanes
+    const int n_pairs_tot = L.misc[1];
+    for (int q = lane; q < n_pairs_tot; q += WV) {
+        int b = 0;
+        while (b + 1 < nb && L.poff[b + 1] <= q) ++b;
         const unsigned mk = (unsigned)L.mask[b];
-        const int cntb = 6 + __popc(mk);
-        if (lane < cntb) {
-            // lane-th active dof of body b: 0..5 = base, then the set bits of mk in ascending order
-            int d = lane;
-            if (lane >= 6) {
-                unsigned rem = mk;
-                for (int k = 6; k < lane; ++k) rem &= rem - 1;      // drop the lowest set bits
-                d = 6 + __ffs(rem) - 1;
-            }
-            const V3 jv = wjac_lin(L, mk, ldv(L.c, b), d), jw = wjac_ang(L, mk, d);
-            double *pp = pairs + (size_t)(L.poff[b] + lane) * 6;
-            pp[0] = jv.x; pp[1] = jv.y; pp[2] = jv.z; pp[3] = jw.x; pp[4] = jw.y; pp[5] = jw.z;
+        const int l = q - L.poff[b];
+        // l-th active dof of body b: 0..5 = base, then the set bits of mk in ascending order
+        int d = l;
+        if (l >= 6) {
+            unsigned rem = mk;
+            for (int k = 6; k < l; ++k) rem &= rem - 1;          // drop the lowest set bits
+            d = 6 + __ffs(rem) - 1;
         }
+        const V3 jv = wjac_lin(L, mk, ldv(L.c, b), d), jw = wjac_ang(L, mk, d);
+        double *pp = pairs + (size_t)q * 6;
+        pp[0] = jv.x; pp[1] = jv.y; pp[2] = jv.z; pp[3] = jw.x; pp[4] = jw.y; pp[5] = jw.z;
     }
     WSYNC();
     auto pair_index = [&](int b, unsigned mk, int d) {
