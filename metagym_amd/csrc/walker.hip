@@ -853,20 +853,32 @@ __device__ void wave_substep(const mg_walker_topology &tp, const ModelRef &m, co
         L.h[d] = acc;
     }
     WSYNC();
-    // ---- Cholesky, column by column (lane = row; one dot-product loop per column, the pivot's square
-    //      root is broadcast with v_readlane and its reciprocal kept for every later division) --------
-    for (int c = 0; c < n; ++c) {
-        double v = 0.0;
-        if (lane >= c && lane < n) {
-            v = L.M[TRI(lane, c)];
-            for (int k = 0; k < c; ++k) v -= L.M[TRI(lane, k)] * L.M[TRI(c, k)];
+    // ---- Cholesky in registers: lane i keeps row i of the lower triangle in a fully unrolled NMAX-slot
+    //      array, so column c needs no LDS at all — L[i][k] is the lane's own slot k and L[c][k] is lane c's
+    //      slot k, read with v_readlane (a scalar operand of the FMA). Through LDS every step of the dot
+    //      products waited on two dependent reads (22 % of the sub-step). Slots above the diagonal hold
+    //      garbage that never reaches a valid entry. ---------------------------------------------------------
+    {
+        double row[NMAX];
+#pragma unroll
+        for (int k = 0; k < NMAX; ++k) row[k] = (lane < n && k <= lane) ? L.M[TRI(lane, k)] : 0.0;
+#pragma unroll
+        for (int c = 0; c < NMAX; ++c) {
+            if (c < n) {
+                double v = row[c];
+#pragma unroll
+                for (int k = 0; k < c; ++k) v -= row[k] * lane_value(row[k], c);
+                const double piv = sqrt(lane_value(v, c));
+                const double ipiv = 1.0 / piv;
+                row[c] = lane == c ? piv : v * ipiv;
+                if (lane == c) L.idg[c] = ipiv;
+            }
         }
-        const double piv = sqrt(lane_value(v, c));
-        const double ipiv = 1.0 / piv;
-        if (lane == c) { L.M[TRI(c, c)] = piv; L.idg[c] = ipiv; }
-        else if (lane > c && lane < n) L.M[TRI(lane, c)] = v * ipiv;
-        WSYNC();
+#pragma unroll
+        for (int k = 0; k < NMAX; ++k)
+            if (lane < n && k <= lane) L.M[TRI(lane, k)] = row[k];
     }
+    WSYNC();
     // ---- free motion in whitened coordinates: y* = L^T u + dt L^-1 (tau - h) (one forward solve; the
     //      backward solve happens once, after the constraint solver) ------------------------------------
     double u_d = 0.0;   // lane d < n: generalized velocity on entry, whitened velocity y_d from here on
