@@ -827,9 +827,11 @@ __device__ void wave_substep(const mg_walker_topology &tp, const ModelRef &m, co
         return L.poff[b] + (d < 6 ? d : 6 + __popc(mk & ((1u << (d - 6)) - 1u)));
     };
     // ---- M (lower triangle) and h: lane-strided over entries ----------------------------------------
-    for (int t = lane; t < n * n; t += WV) {
-        const int d = t / n, e = t % n;
-        if (e > d) continue;
+    for (int t = lane; t < n * (n + 1) / 2; t += WV) {      // packed lower triangle: every lane has an entry
+        int d = (int)((sqrtf(8.0f * (float)t + 1.0f) - 1.0f) * 0.5f);
+        while ((d + 1) * (d + 2) / 2 <= t) ++d;
+        while (d * (d + 1) / 2 > t) --d;
+        const int e = t - d * (d + 1) / 2;
         double acc = 0.0;
         for (unsigned bm = (unsigned)L.bod[d] & (unsigned)L.bod[e]; bm != 0; bm &= bm - 1) {
             const int b = __ffs(bm) - 1;
@@ -839,7 +841,7 @@ __device__ void wave_substep(const mg_walker_topology &tp, const ModelRef &m, co
             acc += dot(m.body_mass[b] * jv, ev) + dot(mulMv(L.Iw + 9 * b, jw), ew);
         }
         if (d == e && d >= 6) acc += m.joint_arm[d - 6];
-        L.M[TRI(d, e)] = acc;
+        L.M[t] = acc;                                       // t == TRI(d, e)
     }
     if (lane < n) {
         const int d = lane;
