@@ -561,7 +561,7 @@ __global__ __launch_bounds__(WK_BLOCK) void walker_reset_kernel(mg_walker_topolo
 // (17.4 KB for the humanoid: kinematics, packed M, h, the whitened constraint rows Jh = J L^-T; blocks whose
 // lifetimes do not overlap share storage, see carve()), so eight envs are resident per CU — the kernel is
 // LDS-latency-bound at ~1 wave per SIMD, occupancy is what buys time (4 -> 8 envs per CU: 3.62 -> 1.86 ms at
-// 8 192 envs) — and nothing spills to scratch. Lanes are dealt
+// 8 192 envs; register Cholesky and tighter assembly loops then took it to 1.46 ms) — and nothing spills to scratch. Lanes are dealt
 //   * bodies (tree level by tree level) for kinematics and the Newton-Euler pass,
 //   * matrix entries for M, rows/columns for the Cholesky factorisation and the triangular solves,
 //   * collision spheres / joints for constraint detection (ballot + popcount gives every constraint
