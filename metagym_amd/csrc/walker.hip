@@ -596,6 +596,14 @@ __device__ __forceinline__ double wave_sum(double v) {
     v = dpp_add<0x140>(v);   // row_mirror
     return (lane_value(v, 0) + lane_value(v, 16)) + (lane_value(v, 32) + lane_value(v, 48));
 }
+// same when only lanes 0..31 can hold non-zero terms (at most 32 generalized coordinates)
+__device__ __forceinline__ double wave_sum32(double v) {
+    v = dpp_add<0xB1>(v);
+    v = dpp_add<0x4E>(v);
+    v = dpp_add<0x141>(v);
+    v = dpp_add<0x140>(v);
+    return lane_value(v, 0) + lane_value(v, 16);
+}
 
 // One wavefront = one workgroup: LDS operations of a wave retire in program order, so ordering between
 // lanes needs no s_barrier and no counter drain — only a compiler barrier so accesses are not reordered.
@@ -1031,26 +1039,35 @@ __device__ void wave_substep(const mg_walker_topology &tp, const ModelRef &m, co
     }
     WSYNC();
     // ---- projected Gauss-Seidel on the whitened velocity y (wave-uniform row loop) --------------------
-    for (int it = 0; it < prm.solver_iterations; ++it)
-        for (int r = 0; r < nr; ++r) {
-            const double idg = L.diag[r];
+    //      The row's Jacobian element and scalars are fetched one row AHEAD, so their LDS latency hides behind
+    //      the previous row's reduction; the reduction itself only spans the lanes that hold coordinates.
+    if (nr > 0) {
+        double jh_n = lane < n ? L.J[lane] : 0.0, idg_n = L.diag[0], bias_n = L.bias[0];
+        int kind_n = L.kind[0], partner_n = L.partner[0];
+        const int sweeps = prm.solver_iterations * nr;
+        int r = 0;
+        for (int s = 0; s < sweeps; ++s) {
+            const double jh = jh_n, idg = idg_n, bias = bias_n;
+            const int rkind = kind_n, partner = partner_n, rr = r;
+            r = r + 1 < nr ? r + 1 : 0;
+            jh_n = lane < n ? L.J[(size_t)r * n + lane] : 0.0;       // next row (wraps to row 0 of the next sweep)
+            idg_n = L.diag[r]; bias_n = L.bias[r]; kind_n = L.kind[r]; partner_n = L.partner[r];
             if (!(idg > 0.0)) continue;
-            const int rkind = L.kind[r];
-            const double jh = lane < n ? L.J[(size_t)r * n + lane] : 0.0;
-            const double jv = wave_sum(jh * u_d);                    // J_r u = Jh_r . y
-            const double lr = L.lam[r];
-            double x = lr - (jv - L.bias[r]) * idg;
+            const double jv = NMAX <= 32 ? wave_sum32(jh * u_d) : wave_sum(jh * u_d);   // J_r u = Jh_r . y
+            const double lr = L.lam[rr];
+            double x = lr - (jv - bias) * idg;
             if (rkind == 0 || rkind >= 4) x = x > 0.0 ? x : 0.0;
             else {
-                const double lim = (rkind == 3 ? prm.self_friction : prm.friction) * L.lam[L.partner[r]];
+                const double lim = (rkind == 3 ? prm.self_friction : prm.friction) * L.lam[partner];
                 x = x < -lim ? -lim : (x > lim ? lim : x);
             }
             const double dl = x - lr;
             u_d += jh * dl;                                          // y += Jh_r^T dlambda
             // single-wave workgroup: LDS operations of one wavefront retire in program order, so every
             // lane has read lam[r] / lam[partner] above before this store lands
-            if (lane == 0) L.lam[r] = x;
+            if (lane == 0) L.lam[rr] = x;
         }
+    }
     // ---- back to generalized velocities: u = L^-T y ---------------------------------------------------
     for (int r = n - 1; r >= 0; --r) {
         const double xr = lane_value(u_d, r) * L.idg[r];
