@@ -96,20 +96,23 @@ static float norm3_f32(const float *x) {
 void qo_inv3_f32(const float *Af, float *Ainv) {
     double A[9];
     for (int i = 0; i < 9; ++i) A[i] = (double)Af[i];
-    const double c00 = A[4] * A[8] - A[5] * A[7];
-    const double c01 = A[5] * A[6] - A[3] * A[8];
-    const double c02 = A[3] * A[7] - A[4] * A[6];
-    const double det = (A[0] * c00 + A[1] * c01) + A[2] * c02;
+    /* a*b - c*d as fma(a, b, -(c*d)): one rounding less per cofactor and one instruction less; this is OUR
+     * way of reaching the correctly rounded float32 inverse, not an operation of the reference, so fusing
+     * is free as long as oracle and kernel do the same */
+    const double c00 = fma(A[4], A[8], -(A[5] * A[7]));
+    const double c01 = fma(A[5], A[6], -(A[3] * A[8]));
+    const double c02 = fma(A[3], A[7], -(A[4] * A[6]));
+    const double det = fma(A[2], c02, fma(A[1], c01, A[0] * c00));
     const double r = 1.0 / det;
     Ainv[0] = (float)(c00 * r);
     Ainv[3] = (float)(c01 * r);
     Ainv[6] = (float)(c02 * r);
-    Ainv[1] = (float)((A[2] * A[7] - A[1] * A[8]) * r);
-    Ainv[4] = (float)((A[0] * A[8] - A[2] * A[6]) * r);
-    Ainv[7] = (float)((A[1] * A[6] - A[0] * A[7]) * r);
-    Ainv[2] = (float)((A[1] * A[5] - A[2] * A[4]) * r);
-    Ainv[5] = (float)((A[2] * A[3] - A[0] * A[5]) * r);
-    Ainv[8] = (float)((A[0] * A[4] - A[1] * A[3]) * r);
+    Ainv[1] = (float)(fma(A[2], A[7], -(A[1] * A[8])) * r);
+    Ainv[4] = (float)(fma(A[0], A[8], -(A[2] * A[6])) * r);
+    Ainv[7] = (float)(fma(A[1], A[6], -(A[0] * A[7])) * r);
+    Ainv[2] = (float)(fma(A[1], A[5], -(A[2] * A[4])) * r);
+    Ainv[5] = (float)(fma(A[2], A[3], -(A[0] * A[5])) * r);
+    Ainv[8] = (float)(fma(A[0], A[4], -(A[1] * A[3])) * r);
 }
 
 /* ---- constants -------------------------------------------------------------------------- */
