@@ -24,6 +24,11 @@
 #include "mg_common.h"
 #include "mg_philox.h"
 
+// The library is built with -ffp-contract=off because the quadrotor and maze kernels must reproduce NumPy's
+// unfused arithmetic bit for bit. This engine has no such constraint (it is compared with its numpy oracle to
+// a tolerance, and the reference's physics is PyBullet): let the compiler fuse a*b+c here.
+#pragma clang fp contract(fast)
+
 namespace {
 
 constexpr int WK_BLOCK = 64;
