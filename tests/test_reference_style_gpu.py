@@ -72,3 +72,28 @@ def test_maze_envs_run_episodes_with_growing_mazes(name, kw, task_type):
             assert guard <= 61
         assert torch.isfinite(sum_reward).all()
         n += 2
+
+
+@pytest.mark.parametrize("env_id,prefix", [("meta-humanoid-v0", "humanoid"), ("meta-ant-v0", "ant")])
+def test_locomotion_envs_run_tasks_to_done(env_id, prefix):
+    """metalocomotion/test.py:4-28: for several tasks: set_task -> reset -> step(action_space.sample()) until done,
+    with max_steps=2. The body variants come from the parsed-model fixture (the MJCF files live in the reference)."""
+    import metagym_amd
+    from walker_fixtures import load_models
+    models = load_models()
+    variants = [k for k in sorted(models) if k.startswith(prefix)][:4]
+    n = 5
+    env = metagym_amd.make(env_id, num_envs=n, device="cuda:0", max_steps=2)
+    for name in variants:
+        env.set_task(models[name])
+        obs = env.reset()
+        assert tuple(obs.shape) == (n, env.obs_dim)
+        done = torch.zeros(n, dtype=torch.bool, device="cuda:0")
+        steps = 0
+        while not bool(done.all()):
+            obs, r, d, info = env.step(torch.as_tensor(np.asarray(env.action_space.sample(n))))
+            done |= d
+            steps += 1
+            assert steps <= 2
+        assert torch.isfinite(obs).all() and torch.isfinite(r).all()
+    env.close()
