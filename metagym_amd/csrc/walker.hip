@@ -631,6 +631,7 @@ struct WaveLds {   // pointers into the env's LDS slab
     double *cx;                              // per contact: ground (x, y, depth) or self (point xc, normal)
     double *sc;                              // sin / cos of every joint angle
     int *mask, *depth, *jstart, *jcount, *poff, *kind, *partner, *csphere, *misc, *bod;
+    short *ptab;                             // (body | dof << 8) of every Jacobian pair — topology only, built once per launch
 };
 
 // LDS layout. The solver works in Cholesky-whitened velocities y = L^T u (M = L L^T): with Jh = J L^-T
@@ -656,7 +657,10 @@ __host__ __device__ inline size_t wave_lds_doubles(int nb, int nj, int maxr, boo
            3 * (size_t)nj + 18 + (size_t)maxr * n + (wave_lds_alias2(nb, maxr) ? 1 : 3) * (size_t)maxr +
            6 * (size_t)W_MAXC + (2 * (size_t)nj <= 6 * (size_t)W_MAXC ? 0 : 2 * (size_t)nj);
 }
-__host__ __device__ inline size_t wave_lds_ints(int nb, int maxr) { return 5 * (size_t)nb + 2 * (size_t)maxr + 2 * W_MAXC + 8 + ND; }
+// + the (body, dof) pair table: one int16 per pair, at most maxr * ND / 6 pairs fit the assembly scratch
+__host__ __device__ inline size_t wave_lds_ints(int nb, int maxr) {
+    return 5 * (size_t)nb + 2 * (size_t)maxr + 2 * W_MAXC + 8 + ND + ((size_t)maxr * ND / 6 + 2) / 2;
+}
 
 __device__ __forceinline__ WaveLds carve(unsigned char *smem, int nb, int nj, int maxr, bool overlay) {
     const int n = 6 + nj;
@@ -680,7 +684,8 @@ __device__ __forceinline__ WaveLds carve(unsigned char *smem, int nb, int nj, in
     else { L.sc = d; d += 2 * nj; }
     int *i = reinterpret_cast<int *>(d);
     L.mask = i; i += nb; L.depth = i; i += nb; L.jstart = i; i += nb; L.jcount = i; i += nb; L.poff = i; i += nb;
-    L.kind = i; i += maxr; L.partner = i; i += maxr; L.csphere = i; i += 2 * W_MAXC; L.misc = i; i += 8; L.bod = i;
+    L.kind = i; i += maxr; L.partner = i; i += maxr; L.csphere = i; i += 2 * W_MAXC; L.misc = i; i += 8; L.bod = i; i += ND;
+    L.ptab = reinterpret_cast<short *>(i);
     return L;
 }
 
@@ -803,34 +808,14 @@ __device__ void wave_substep(const mg_walker_topology &tp, const ModelRef &m, co
     WSYNC();
     // ---- Jacobian columns of every (body, active dof) pair, lane-strided; parked in the J region, which
     //      the constraints only claim later in the sub-step -------------------------------------------
-    if (lane == 0) {
-        int off = 0;
-        for (int b = 0; b < nb; ++b) { L.poff[b] = off; off += 6 + __popc((unsigned)L.mask[b]); }
-        L.misc[1] = off;
-    }
-    if (lane < n) {   // bodies each dof moves, as a bitmask: M[d][e] only sums bodies in bod[d] & bod[e]
-        unsigned bm = 0;
-        for (int b = 0; b < nb; ++b)
-            if (lane < 6 || (((unsigned)L.mask[b] >> (lane - 6)) & 1u)) bm |= 1u << b;
-        L.bod[lane] = (int)bm;
-    }
-    WSYNC();
     double *pairs = L.J;          // [n_pairs][6] = (jv, jw)
     // flat over all (body, dof) pairs — 133 for the humanoid, three passes of the wave — instead of one pass
     // per body with a dozen active lanes
     const int n_pairs_tot = L.misc[1];
     for (int q = lane; q < n_pairs_tot; q += WV) {
-        int b = 0;
-        while (b + 1 < nb && L.poff[b + 1] <= q) ++b;
+        const int pe = L.ptab[q];
+        const int b = pe & 0xff, d = pe >> 8;
         const unsigned mk = (unsigned)L.mask[b];
-        const int l = q - L.poff[b];
-        // l-th active dof of body b: 0..5 = base, then the set bits of mk in ascending order
-        int d = l;
-        if (l >= 6) {
-            unsigned rem = mk;
-            for (int k = 6; k < l; ++k) rem &= rem - 1;          // drop the lowest set bits
-            d = 6 + __ffs(rem) - 1;
-        }
         const V3 jv = wjac_lin(L, mk, ldv(L.c, b), d), jw = wjac_ang(L, mk, d);
         double *pp = pairs + (size_t)q * 6;
         pp[0] = jv.x; pp[1] = jv.y; pp[2] = jv.z; pp[3] = jw.x; pp[4] = jw.y; pp[5] = jw.z;
@@ -1128,6 +1113,40 @@ __global__ __launch_bounds__(WV) void walker_step_wave_kernel(mg_walker_topology
             L.jcount[b] = j - L.jstart[b];
         }
         L.misc[0] = md;
+        // topology-only tables of the mass-matrix assembly, built once per launch: the joints on each body's
+        // chain (mask), where each body's (body, dof) Jacobian pairs start (poff), their total (misc[1])
+        int off = 0;
+        for (int b = 0; b < nb; ++b) {
+            const int pb = tp.body_parent[b];
+            unsigned mk = pb < 0 ? 0u : (unsigned)L.mask[pb];
+            for (int jj = L.jstart[b]; jj < L.jstart[b] + L.jcount[b]; ++jj) mk |= 1u << jj;
+            L.mask[b] = (int)mk;
+            L.poff[b] = off;
+            off += 6 + __popc(mk);
+        }
+        L.misc[1] = off;
+    }
+    WSYNC();
+    {
+        const int n = 6 + nj;
+        if (lane < n) {   // bodies each dof moves, as a bitmask: M[d][e] only sums bodies in bod[d] & bod[e]
+            unsigned bm = 0;
+            for (int b = 0; b < nb; ++b)
+                if (lane < 6 || (((unsigned)L.mask[b] >> (lane - 6)) & 1u)) bm |= 1u << b;
+            L.bod[lane] = (int)bm;
+        }
+        for (int q = lane; q < L.misc[1]; q += WV) {
+            int b = 0;
+            while (b + 1 < nb && L.poff[b + 1] <= q) ++b;
+            const int l = q - L.poff[b];
+            int d = l;       // l-th active dof of body b: 0..5 = base, then the set bits of its mask in ascending order
+            if (l >= 6) {
+                unsigned rem = (unsigned)L.mask[b];
+                for (int k = 6; k < l; ++k) rem &= rem - 1;
+                d = 6 + __ffs(rem) - 1;
+            }
+            L.ptab[q] = (short)(b | (d << 8));
+        }
     }
     if (lane < 3) {
         L.base[lane] = st.pos[(size_t)lane * n_envs + e];
