@@ -795,20 +795,40 @@ __device__ void wave_substep(const mg_walker_topology &tp, const ModelRef &m, co
         const V3 w = ldv(L.fw, b), al = ldv(L.fal, b), xr = ldv(L.fxr, b), ar = ldv(L.far_, b);
         const V3 r = ldv(L.c, b) - xr;
         const V3 a_c = ar + cross(al, r) + cross(w, cross(w, r));
-        double RI[9], Iw[9], Rt[9];
-        mulMM(L.R + 9 * b, m.body_inertia + 9 * b, RI);
-        for (int r0 = 0; r0 < 3; ++r0)
-            for (int c0 = 0; c0 < 3; ++c0) Rt[3 * r0 + c0] = L.R[9 * b + 3 * c0 + r0];
-        mulMM(RI, Rt, Iw);
-        for (int i = 0; i < 9; ++i) L.Iw[9 * b + i] = Iw[i];
-        const double mass = m.body_mass[b];
-        stv(L.F, b, mass * (a_c - v3(0, 0, -prm.gravity)));
-        stv(L.Nn, b, mulMv(Iw, al) + cross(w, mulMv(Iw, w)));
+        // World inertia in factored form: I_body = C C^T (3x3 Cholesky of a model constant), A = R C, so
+        // Iw = A A^T and the joint-space inertia becomes a plain sum of dot products of "whitened" Jacobian
+        // pairs (sqrt(m) jv, A^T jw) — no 3x3 inertia product per (matrix entry, body) later on. The bias
+        // wrench is stored whitened the same way: F / sqrt(m) and A^-1 N.
+        const double *Ib = m.body_inertia + 9 * b;
+        const double c00 = sqrt(Ib[0]), c10 = Ib[3] / c00, c20 = Ib[6] / c00;
+        const double c11 = sqrt(Ib[4] - c10 * c10), c21 = (Ib[7] - c20 * c10) / c11;
+        const double c22 = sqrt(Ib[8] - c20 * c20 - c21 * c21);
+        const double *R = L.R + 9 * b;
+        double A[9];
+        for (int i = 0; i < 3; ++i) {
+            A[3 * i] = R[3 * i] * c00 + R[3 * i + 1] * c10 + R[3 * i + 2] * c20;
+            A[3 * i + 1] = R[3 * i + 1] * c11 + R[3 * i + 2] * c21;
+            A[3 * i + 2] = R[3 * i + 2] * c22;
+        }
+        for (int i = 0; i < 9; ++i) L.Iw[9 * b + i] = A[i];
+        auto At = [&](V3 x) { return V3{A[0] * x.x + A[3] * x.y + A[6] * x.z, A[1] * x.x + A[4] * x.y + A[7] * x.z,
+                                        A[2] * x.x + A[5] * x.y + A[8] * x.z}; };
+        auto Iw_times = [&](V3 x) { return mulMv(A, At(x)); };
+        const double mass = m.body_mass[b], sm = sqrt(mass);
+        const V3 F = mass * (a_c - v3(0, 0, -prm.gravity));
+        const V3 N = Iw_times(al) + cross(w, Iw_times(w));
+        stv(L.F, b, (1.0 / sm) * F);
+        // A^-1 N = C^-1 (R^T N): forward substitution with the lower-triangular C
+        const V3 y{R[0] * N.x + R[3] * N.y + R[6] * N.z, R[1] * N.x + R[4] * N.y + R[7] * N.z,
+                   R[2] * N.x + R[5] * N.y + R[8] * N.z};
+        const double z0 = y.x / c00, z1 = (y.y - c10 * z0) / c11, z2 = (y.z - c20 * z0 - c21 * z1) / c22;
+        stv(L.Nn, b, V3{z0, z1, z2});
+        L.fal[3 * b] = sm;        // the acceleration frame of this body is dead from here on: park sqrt(m) in it
     }
     WSYNC();
     // ---- Jacobian columns of every (body, active dof) pair, lane-strided; parked in the J region, which
     //      the constraints only claim later in the sub-step -------------------------------------------
-    double *pairs = L.J;          // [n_pairs][6] = (jv, jw)
+    double *pairs = L.J;          // [n_pairs][6] = whitened (jv, jw), see the inertia factorisation above
     // flat over all (body, dof) pairs — 133 for the humanoid, three passes of the wave — instead of one pass
     // per body with a dozen active lanes
     const int n_pairs_tot = L.misc[1];
@@ -817,8 +837,13 @@ __device__ void wave_substep(const mg_walker_topology &tp, const ModelRef &m, co
         const int b = pe & 0xff, d = pe >> 8;
         const unsigned mk = (unsigned)L.mask[b];
         const V3 jv = wjac_lin(L, mk, ldv(L.c, b), d), jw = wjac_ang(L, mk, d);
-        double *pp = pairs + (size_t)q * 6;
-        pp[0] = jv.x; pp[1] = jv.y; pp[2] = jv.z; pp[3] = jw.x; pp[4] = jw.y; pp[5] = jw.z;
+        const double sm = L.fal[3 * b];
+        const double *A = L.Iw + 9 * b;
+        double *pp = pairs + (size_t)q * 6;          // whitened pair: (sqrt(m) jv, A^T jw)
+        pp[0] = sm * jv.x; pp[1] = sm * jv.y; pp[2] = sm * jv.z;
+        pp[3] = A[0] * jw.x + A[3] * jw.y + A[6] * jw.z;
+        pp[4] = A[1] * jw.x + A[4] * jw.y + A[7] * jw.z;
+        pp[5] = A[2] * jw.x + A[5] * jw.y + A[8] * jw.z;
     }
     WSYNC();
     auto pair_index = [&](int b, unsigned mk, int d) {
@@ -835,8 +860,7 @@ __device__ void wave_substep(const mg_walker_topology &tp, const ModelRef &m, co
             const int b = __ffs(bm) - 1;
             const unsigned mk = (unsigned)L.mask[b];
             const double *pd = pairs + (size_t)pair_index(b, mk, d) * 6, *pe = pairs + (size_t)pair_index(b, mk, e) * 6;
-            const V3 jv{pd[0], pd[1], pd[2]}, jw{pd[3], pd[4], pd[5]}, ev{pe[0], pe[1], pe[2]}, ew{pe[3], pe[4], pe[5]};
-            acc += dot(m.body_mass[b] * jv, ev) + dot(mulMv(L.Iw + 9 * b, jw), ew);
+            acc += (pd[0] * pe[0] + pd[1] * pe[1] + pd[2] * pe[2]) + (pd[3] * pe[3] + pd[4] * pe[4] + pd[5] * pe[5]);
         }
         if (d == e && d >= 6) acc += m.joint_arm[d - 6];
         L.M[t] = acc;                                       // t == TRI(d, e)
