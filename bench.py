@@ -146,6 +146,28 @@ def cpu_baseline_maze3d(seconds=4.0, res=256):
                       % (sum(counts), res, res, el)}
 
 
+def cpu_baseline_walker(seconds=3.0):
+    """Secondary CPU figure for C4: the numpy restatement of the walker engine (oracle/abd.py — the checker the
+    GPU kernels are tested against, NOT PyBullet, which the reference calls and which is not in its tree), one
+    env on one core."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from oracle import abd
+    from walker_fixtures import load_models
+    m = load_models()["humanoid"]
+    env = abd.WalkerEnv(m, prm=abd.Params(friction=0.8 * float(m.geom_friction), self_friction=float(m.geom_friction) ** 2))
+    rs = np.random.RandomState(0)
+    env.reset(rs.uniform(-0.1, 0.1, len(m.joint_lo)))
+    n, t0 = 0, time.perf_counter()
+    while time.perf_counter() - t0 < seconds:
+        _, _, done, _ = env.step(rs.uniform(-1, 1, len(m.joint_lo)))
+        if done:
+            env.reset(rs.uniform(-0.1, 0.1, len(m.joint_lo)))
+        n += 1
+    el = time.perf_counter() - t0
+    return {"value": n / el, "unit": "env-steps/s", "cores": 1, "kind": "port",
+            "sample": "%d env steps of one humanoid, %.1f s wall, numpy restatement of this engine (oracle/abd.py)" % (n, el)}
+
+
 def _time_steps(step_fn, steps, warmup):
     for i in range(warmup):
         step_fn(i)
@@ -418,6 +440,11 @@ def main():
                     out["secondary"]["C3_maze3d_discrete_9x9_256x256_16384envs"]["cpu_baseline"] = cpu_baseline_maze3d()
                 except Exception as e:
                     out["secondary"]["C3_maze3d_discrete_9x9_256x256_16384envs"]["cpu_baseline_error"] = repr(e)
+            if "secondary" in out and "C4_humanoid_8192envs" in out["secondary"]:
+                try:
+                    out["secondary"]["C4_humanoid_8192envs"]["cpu_baseline"] = cpu_baseline_walker()
+                except Exception as e:
+                    out["secondary"]["C4_humanoid_8192envs"]["cpu_baseline_error"] = repr(e)
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.destroy_process_group()
