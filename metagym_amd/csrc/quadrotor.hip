@@ -444,18 +444,24 @@ __device__ __forceinline__ void load_lane(const mg_quadrotor_state &st, int n, i
     s.power = 0.0f;
 }
 
+// Every output of a step is written once and next read by a later launch (or by the caller), never by
+// this one: streaming (nontemporal) stores let the bytes leave through the fabric as they are issued
+// instead of waiting in L2 for the end-of-kernel write-back (-2..3 % at 65 536 envs).
+template <typename T> __device__ __forceinline__ void st_stream(T *p, T v) { __builtin_nontemporal_store(v, p); }
+typedef float v4f __attribute__((ext_vector_type(4)));
+
 __device__ __forceinline__ void store_lane(const mg_quadrotor_state &st, int n, int e, const Lane &s, int ct) {
 #pragma unroll
-    for (int c = 0; c < 3; ++c) st.pos[(size_t)c * n + e] = s.p[c];
+    for (int c = 0; c < 3; ++c) st_stream(&st.pos[(size_t)c * n + e], s.p[c]);
 #pragma unroll
-    for (int c = 0; c < 3; ++c) st.vel[(size_t)c * n + e] = s.v[c];
+    for (int c = 0; c < 3; ++c) st_stream(&st.vel[(size_t)c * n + e], s.v[c]);
 #pragma unroll
-    for (int c = 0; c < 3; ++c) st.omega[(size_t)c * n + e] = s.w[c];
+    for (int c = 0; c < 3; ++c) st_stream(&st.omega[(size_t)c * n + e], s.w[c]);
 #pragma unroll
-    for (int c = 0; c < 4; ++c) st.propw[(size_t)c * n + e] = s.pw[c];
+    for (int c = 0; c < 4; ++c) st_stream(&st.propw[(size_t)c * n + e], s.pw[c]);
 #pragma unroll
-    for (int c = 0; c < 9; ++c) st.rot[(size_t)c * n + e] = s.R[c];
-    st.ct[e] = ct;
+    for (int c = 0; c < 9; ++c) st_stream(&st.rot[(size_t)c * n + e], s.R[c]);
+    st_stream(&st.ct[e], ct);
 }
 
 // Transpose the wave's 64 x 16 observation rows through LDS and store them as 4 coalesced
@@ -480,7 +486,7 @@ __device__ __forceinline__ void store_obs_wave(float *tile, const float *obs, fl
             const int q = j * mg::WAVE + lane;      // float4 index inside the wave's 4 KiB block
             const int row = q >> 2, col = (q & 3) * 4;
             const float *src = &tile[row * (OBS_DIM + 1) + col];
-            dst[q] = make_float4(src[0], src[1], src[2], src[3]);
+            st_stream(reinterpret_cast<v4f *>(dst + q), v4f{src[0], src[1], src[2], src[3]});
         }
         __builtin_amdgcn_wave_barrier();
     } else if (e < n) {
@@ -532,6 +538,16 @@ struct StepIO {
     uint8_t *done;         // [T][n]
     uint8_t *failed;       // [T][n] or null
 };
+
+// The step kernel's argument block as the kernarg segment lays it out, and a pointer to it that the
+// optimiser cannot relate to the kernel's own argument loads (see the epilogue of the step kernel).
+struct KArgs { QuadK k; mg_quadrotor_state st; StepIO io; int n; int n_steps; };
+typedef const __attribute__((address_space(4))) KArgs KArgsC;
+__device__ __forceinline__ KArgsC *kernargs_fresh() {
+    KArgsC *p = (KArgsC *)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(p));
+    return p;
+}
 
 template <bool SIMPLE>
 __global__ __launch_bounds__(BLOCK) void quadrotor_step_kernel(QuadK k, mg_quadrotor_state st, StepIO io,
@@ -585,33 +601,41 @@ __global__ __launch_bounds__(BLOCK) void quadrotor_step_kernel(QuadK k, mg_quadr
                 fail = failure_code(k, s);
             }
         }
-        const bool vel_task = k.task == MG_QUADROTOR_TASK_VELOCITY_CONTROL;
+        // The reward / observation constants and the output pointers are used only from here on. Held in
+        // SGPRs across the sub-step loop they overflow the scalar file and get spilled to VGPR lanes
+        // (125 spills, ~200 v_writelane/v_readlane on the hot path); re-reading them from the kernarg
+        // segment (scalar-cache hits, the prologue touched every line) through a pointer the compiler
+        // cannot connect to the prologue's loads keeps the loop's SGPR budget for the loop.
+        const KArgsC *kae = kernargs_fresh();
+        const QuadK &ke = *(const QuadK *)&kae->k;
+        const StepIO &ioe = *(const StepIO *)&kae->io;
+        const bool vel_task = ke.task == MG_QUADROTOR_TASK_VELOCITY_CONTROL;
         // _update_state env.py:262-273: the observation's target entries come from min(ct, nt-1) with ct
         // already incremented and not yet cleared by the episode end
-        const int tn_step = ct < k.nt - 1 ? ct : k.nt - 1;
+        const int tn_step = ct < ke.nt - 1 ? ct : ke.nt - 1;
         double reward = 0.0;
         int done = 1;
         if (fail == 0 && vel_task) {
             // env.py:150-157: body-frame target = Rinv(f32) @ target(f32); reward -0.001 * L1 difference
             float bt[3];
-            mv_f32(s.Ri, &k.vtargets[3 * (ct - 1)], bt);
+            mv_f32(s.Ri, &ke.vtargets[3 * (ct - 1)], bt);
             double b_v[3];
             mv_f32f64(s.Ri, s.v, b_v);
             const double diff = (fabs((double)bt[0] - b_v[0]) + fabs((double)bt[1] - b_v[1])) + fabs((double)bt[2] - b_v[2]);
-            const float energy = k.dt32 * s.power;
-            const double r = (k.healthy32 < energy) ? -k.healthy : -(double)energy;
+            const float energy = ke.dt32 * s.power;
+            const double r = (ke.healthy32 < energy) ? -ke.healthy : -(double)energy;
             reward = r + (-0.001 * diff);
             done = 0;
-            if (ct == k.nt) { done = 1; ct = 0; }
+            if (ct == ke.nt) { done = 1; ct = 0; }
         } else if (fail == 0) {
-            const double new_pos[3] = {(double)s.p[0] + k.xoff, (double)s.p[1] + k.yoff,
-                                       (double)(s.p[2] + k.zoff32)};
-            const bool hit = collision(k, old_pos, new_pos);                // env.py:145
+            const double new_pos[3] = {(double)s.p[0] + ke.xoff, (double)s.p[1] + ke.yoff,
+                                       (double)(s.p[2] + ke.zoff32)};
+            const bool hit = collision(ke, old_pos, new_pos);                // env.py:145
             // _get_reward env.py:211-246
-            const float energy = k.dt32 * s.power;
-            double r = (k.healthy32 < energy) ? -k.healthy : -(double)energy;   // -min(energy, healthy)
-            double task_reward = hit ? 0.0 : k.healthy;
-            if (k.task == MG_QUADROTOR_TASK_HOVERING_CONTROL) {
+            const float energy = ke.dt32 * s.power;
+            double r = (ke.healthy32 < energy) ? -ke.healthy : -(double)energy;   // -min(energy, healthy)
+            double task_reward = hit ? 0.0 : ke.healthy;
+            if (ke.task == MG_QUADROTOR_TASK_HOVERING_CONTROL) {
                 task_reward -= 1.0 * s.nv + 1.0 * s.nw;
                 const float z_move = fabsf(0.0f - s.p[2]);   // pos_0 is the reset position = 0 (env.py:123)
                 if (z_move < 0.5f) task_reward += 10;
@@ -620,13 +644,13 @@ __global__ __launch_bounds__(BLOCK) void quadrotor_step_kernel(QuadK k, mg_quadr
                     task_reward += (o > -20.0f) ? (double)o : -20.0;
                 }
             }
-            if (k.task == MG_QUADROTOR_TASK_HOVERING_CONTROL || k.healthy32 < energy)
+            if (ke.task == MG_QUADROTOR_TASK_HOVERING_CONTROL || ke.healthy32 < energy)
                 reward = r + task_reward;     // np.float64 task_reward, or python floats on both sides
             else                              // no_collision: np.float32 + weak python float -> f32 add (env.py:220-221)
                 reward = (double)((float)r + (float)task_reward);
             done = 0;
             if (hit) { done = 1; ct = 0; }                                  // env.py:147-149
-            if (ct == k.nt) { done = 1; ct = 0; }                           // env.py:159-161
+            if (ct == ke.nt) { done = 1; ct = 0; }                           // env.py:159-161
         } else {
             ct = 0;
         }
@@ -634,22 +658,25 @@ __global__ __launch_bounds__(BLOCK) void quadrotor_step_kernel(QuadK k, mg_quadr
         // optional in-place reset: stepped state for running envs, and — vector-env convention — the first
         // observation of the next episode for the envs that just finished.
         int tn = tn_step;
-        if (k.auto_reset && done) {
-            reset_lane_random(k, s, el, k.step_index + (uint64_t)t);
-            tn = ct < k.nt - 1 ? ct : k.nt - 1;
+        if (ke.auto_reset && done) {
+            reset_lane_random(ke, s, el, ke.step_index + (uint64_t)t);
+            tn = ct < ke.nt - 1 ? ct : ke.nt - 1;
         }
+        // The state is final here. Its stores (63 % of the bytes this launch writes) go out before the
+        // observation arithmetic so that they drain behind it instead of after it.
+        if (t == n_steps - 1 && live) store_lane(*(const mg_quadrotor_state *)&kae->st, n, e, s, ct);
+        __builtin_amdgcn_sched_barrier(0);   // pure arithmetic would otherwise be hoisted above the stores
         float obs[OBS_DIM + 3];
-        observe(k, s, obs);
-        if (vel_task) { obs[16] = k.vtargets[3 * tn]; obs[17] = k.vtargets[3 * tn + 1]; obs[18] = k.vtargets[3 * tn + 2]; }
-        store_obs_wave(tile, obs, io.obs + off * k.obs_dim, n, e, k.obs_dim);
+        observe(ke, s, obs);
+        if (vel_task) { obs[16] = ke.vtargets[3 * tn]; obs[17] = ke.vtargets[3 * tn + 1]; obs[18] = ke.vtargets[3 * tn + 2]; }
+        store_obs_wave(tile, obs, ioe.obs + off * ke.obs_dim, n, e, ke.obs_dim);
         if (live) {
-            if (io.reward) io.reward[off + e] = (float)reward;
-            if (io.reward64) io.reward64[off + e] = reward;
-            io.done[off + e] = (uint8_t)done;
-            if (io.failed) io.failed[off + e] = (uint8_t)fail;
+            if (ioe.reward) st_stream(&ioe.reward[off + e], (float)reward);
+            if (ioe.reward64) st_stream(&ioe.reward64[off + e], reward);
+            st_stream(&ioe.done[off + e], (uint8_t)done);
+            if (ioe.failed) st_stream(&ioe.failed[off + e], (uint8_t)fail);
         }
     }
-    if (live) store_lane(st, n, e, s, ct);
 }
 
 __global__ __launch_bounds__(BLOCK) void quadrotor_reset_kernel(QuadK k, mg_quadrotor_state st,
