@@ -62,6 +62,7 @@ struct Lane {       // one environment, in registers
     double w[3];
     float pw[4];
     float R[9];
+    double Rd[9];   // R widened to f64, exactly (double)R[i]: inv3 produces it, the next sub-step's R @ a reuses it
     float Ri[9];    // inv(R): _coordination_converter_to_body
     double nv, nw;  // ||v||, ||w|| of the current state (shared by drag and the failure test)
     float power;
@@ -123,8 +124,7 @@ __device__ __forceinline__ float sumsq3(const float *x) {
 // casts back, i.e. it returns the correctly rounded f32 inverse. Same here: adjugate / det in f64
 // (branch-free, ~60 f64 ops, one division), rounded to f32. R drifts away from orthonormal (the
 // reference never re-normalises it), so R^T is NOT a substitute.
-__device__ __forceinline__ void inv3(const float *Af, float *Ainv) {
-    double A[9];
+__device__ __forceinline__ void inv3(const float *Af, float *Ainv, double *A) {   // A: out, the widened input
 #pragma unroll
     for (int i = 0; i < 9; ++i) A[i] = (double)Af[i];
     // a*b - c*d as fma(a, b, -(c*d)): one rounding less per cofactor and one instruction less; this is OUR
@@ -245,7 +245,9 @@ __device__ __forceinline__ void substep(const QuadK &k, Lane &s, const float *ef
         t_all[c] = (double)(SIMPLE ? prop_torque[c] : prop_torque[c] + t_grav_neg[c]) + t_drag[c];
         body_acc[c] = k.quality_recip_exact ? f_all * k.inv_quality : f_all / k.quality;
     }
-    mv_f32f64(s.R, body_acc, acc);
+#pragma unroll
+    for (int r = 0; r < 3; ++r)   // mv_f32f64(s.R, body_acc, acc) on the already widened matrix
+        acc[r] = fma(s.Rd[3 * r + 2], body_acc[2], fma(s.Rd[3 * r], body_acc[0], s.Rd[3 * r + 1] * body_acc[1]));
     // :185-188
 #pragma unroll
     for (int c = 0; c < 3; ++c)
@@ -281,7 +283,7 @@ __device__ __forceinline__ void substep(const QuadK &k, Lane &s, const float *ef
     }
 #pragma unroll
     for (int c = 0; c < 3; ++c) s.w[c] = s.w[c] + k.prec * alpha[c];
-    inv3(s.R, s.Ri);                                             // :206-208
+    inv3(s.R, s.Ri, s.Rd);                                       // :206-208
     s.nv = norm3(s.v);
     s.nw = norm3(s.w);
 }
@@ -403,7 +405,8 @@ __device__ void substep_f32state(const QuadK &k, Lane32 &s, const float *eff32) 
     mm_f32(s.R, S, RS);
     for (int c = 0; c < 9; ++c) s.R[c] = s.R[c] + k.prec32 * RS[c];
     for (int c = 0; c < 3; ++c) s.w[c] = s.w[c] + k.prec32 * alpha[c];
-    inv3(s.R, s.Ri);
+    double Rd[9];
+    inv3(s.R, s.Ri, Rd);
 }
 
 __global__ void quadrotor_targets_kernel(QuadK k, int nt, const float *actions, float *targets) {
@@ -438,7 +441,7 @@ __device__ __forceinline__ void load_lane(const mg_quadrotor_state &st, int n, i
 #pragma unroll
     for (int c = 0; c < 9; ++c) s.R[c] = st.rot[(size_t)c * n + e];
     ct = st.ct[e];
-    inv3(s.R, s.Ri);
+    inv3(s.R, s.Ri, s.Rd);
     s.nv = norm3(s.v);
     s.nw = norm3(s.w);
     s.power = 0.0f;
@@ -522,6 +525,7 @@ __device__ __forceinline__ void reset_lane_random(const QuadK &k, Lane &s, int e
     for (int c = 0; c < 9; ++c) {
         s.R[c] = (c % 4 == 0) ? 1.0f : 0.0f;
         s.Ri[c] = s.R[c];
+        s.Rd[c] = (double)s.R[c];
     }
     s.nv = norm3(s.v);
     s.nw = norm3(s.w);
@@ -697,7 +701,7 @@ __global__ __launch_bounds__(BLOCK) void quadrotor_reset_kernel(QuadK k, mg_quad
     for (int c = 0; c < 4; ++c) s.pw[c] = 0.0f;
 #pragma unroll
     for (int c = 0; c < 9; ++c) s.R[c] = (c % 4 == 0) ? 1.0f : 0.0f;
-    inv3(s.R, s.Ri);
+    inv3(s.R, s.Ri, s.Rd);
     s.nv = norm3(s.v);
     s.nw = norm3(s.w);
     s.power = 0.0f;
