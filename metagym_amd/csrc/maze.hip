@@ -676,19 +676,6 @@ __device__ __forceinline__ void py_slice(long a, long b, long len, int &lo, int 
 
 struct int3s { int x, y, z; };   // 12-byte pixel, stored with one dwordx3
 
-// Workgroup b runs on XCD b % 8 (the hardware deals workgroups round-robin, whatever their cost). A frame's
-// cost follows its view, views follow the task and the pose, and callers lay tasks out periodically (env e
-// -> task e % T): with the identity mapping each XCD would render the same few tasks for the whole
-// launch and the launch would last as long as the unluckiest XCD (+35 % measured with agents near their
-// start cells). Inside every aligned group of 8 envs the env -> XCD assignment is therefore rotated by a
-// different amount per group, so any period in e spreads over all XCDs. Same 8 frames per group of 8
-// workgroups as before, so locality is unchanged; a ragged last group keeps the identity.
-__device__ __forceinline__ int env_of_block(int b, int n) {
-    const int q = b >> 3, x = b & 7;
-    if (((q + 1) << 3) > n) return b;
-    return (q << 3) | ((x + q + (q >> 3) + (q >> 6) + (q >> 9)) & 7);
-}
-
 __global__ __launch_bounds__(MZ_BLOCK) void maze3d_step_kernel(mg_maze_tasks T, mg_maze_state st, ViewK vk,
                                                                int task_type, int max_steps, int continuous,
                                                                int pre_moved, int auto_reset, int n_envs,
@@ -696,7 +683,7 @@ __global__ __launch_bounds__(MZ_BLOCK) void maze3d_step_kernel(mg_maze_tasks T, 
                                                                void *obs, float *reward, double *reward64,
                                                                uint8_t *done) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int e = env_of_block(blockIdx.x, n_envs);
+    const int e = mg::env_of_block(blockIdx.x, n_envs);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n_threads = blockDim.x, n_waves = n_threads >> 6;   // 1, 2 or 4 waves per env (host picks by frame size)
     const Task t = load_task(T, st.task_id[e]);

@@ -23,6 +23,19 @@ inline int check_launch(const char *kernel) { return check_hip(hipGetLastError()
 
 constexpr int WAVE = 64;  // gfx950 wavefront width
 
+// Workgroup b runs on XCD b % 8 (the hardware deals workgroups round-robin, whatever their cost). A frame's
+// cost follows its view, views follow the task and the pose, and callers lay tasks out periodically (env e
+// -> task e % T): with the identity mapping each XCD would render the same few tasks for the whole
+// launch and the launch would last as long as the unluckiest XCD (maze3d: +35 % measured with agents near
+// their start cells). Inside every aligned group of 8 envs the env -> XCD assignment is therefore rotated by a
+// different amount per group, so any period in e spreads over all XCDs. Same 8 frames per group of 8
+// workgroups as before, so locality is unchanged; a ragged last group keeps the identity.
+__device__ __forceinline__ int env_of_block(int b, int n) {
+    const int q = b >> 3, x = b & 7;
+    if (((q + 1) << 3) > n) return b;
+    return (q << 3) | ((x + q + (q >> 3) + (q >> 6) + (q >> 9)) & 7);
+}
+
 }  // namespace mg
 
 #define MG_REQUIRE_PTR(p)                                                         \
