@@ -1119,7 +1119,7 @@ __global__ __launch_bounds__(WV) void walker_step_wave_kernel(mg_walker_topology
                                                               int maxr_flags, const float *action, float *obs,
                                                               float *reward, float *rewards5, uint8_t *done) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int e = blockIdx.x, lane = threadIdx.x;
+    const int e = mg::env_of_block(blockIdx.x, n_envs), lane = threadIdx.x;
     const int nb = tp.n_bodies, nj = tp.n_joints, nf = tp.n_feet, obs_dim = 8 + 2 * nj + nf;
     const ModelRef m = model_ref(tp, ms, st.task_id[e]);
     const bool overlay = maxr_flags < 0;         // sign of the row-count argument: assembly scratch overlaid on Jh
