@@ -221,6 +221,34 @@ def test_maze3d_batch_matches_oracle(continuous):
         assert bad == 0 if not continuous else bad <= 1e-3 * total
 
 
+def test_maze3d_ragged_batch_every_env_every_frame():
+    """29 envs = three full groups of 8 (whose env -> workgroup assignment is rotated, mg::env_of_block) plus a
+    ragged group of 5 (identity): every env's reward, done and full frame against the oracle on every step."""
+    import metagym_amd
+    from metagym_amd.metamaze import MazeTaskSampler, MAZE_TASK_MANAGER
+    tex_u8 = MAZE_TASK_MANAGER.grounds.astype(np.uint8)
+    tt = mo.TASK_TYPES["SURVIVAL"]
+    tasks = [MazeTaskSampler(n=9, allow_loops=False, step_reward=-0.01, goal_reward=1.0, food_density=0.08,
+                             food_interval=4, seed=40 + s) for s in range(5)]
+    n, res = 29, (32, 24)
+    env = metagym_amd.make("meta-maze-discrete-3D-v0", num_envs=n, device="cuda:0", max_steps=50, resolution=res,
+                           task_type="SURVIVAL")
+    env.set_task(tasks)
+    ids = env.task_id.cpu().numpy()
+    otasks, states = _oracle_batch(tasks, ids, tt)
+    view = mo.View(tex_u8, MAZE_TASK_MANAGER.ceil, res[0], res[1])
+    env.reset()
+    rs = np.random.RandomState(3)
+    for t in range(6):
+        a = rs.choice(4, size=n, p=[0.2, 0.2, 0.1, 0.5])
+        obs, rew, done, info = env.step(torch.as_tensor(a))
+        r64, d, ob = env.reward64.cpu().numpy(), done.cpu().numpy(), obs.cpu().numpy()
+        for e in range(n):
+            r, dd = mo.step_disc3d(otasks[ids[e]], tt, 50, states[e], a[e])
+            assert r == r64[e] and dd == d[e], (t, e)
+            assert np.array_equal(ob[e], mo.observe_3d(otasks[ids[e]], tt, view, states[e], 0)), (t, e)
+
+
 def test_maze3d_full_size_properties():
     """Config C3 size (16 384 envs, 9x9) at 32x32 frames: determinism, env-permutation equivariance
     and auto-reset == explicit masked reset; plus one 256x256 batch checked against the oracle."""
