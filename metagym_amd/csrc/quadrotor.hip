@@ -580,6 +580,10 @@ __global__ __launch_bounds__(BLOCK) void quadrotor_step_kernel(QuadK k, mg_quadr
     Lane s;
     int ct;
     load_lane(st, n, el, s, ct);
+    // All prologue loads land here (vmcnt = 0), not at their first use inside the step loop: there the wait
+    // would be re-executed by every later step of a rollout and would also drain that step's freshly issued
+    // action prefetch and the previous step's stores (2.5 us per step at K > 1; free at K = 1).
+    __builtin_amdgcn_s_waitcnt(0x0F70);
 
     for (int t = 0; t < n_steps; ++t) {
         const size_t off = (size_t)t * n;
@@ -666,6 +670,10 @@ __global__ __launch_bounds__(BLOCK) void quadrotor_step_kernel(QuadK k, mg_quadr
             reset_lane_random(ke, s, el, ke.step_index + (uint64_t)t);
             tn = ct < ke.nt - 1 ? ct : ke.nt - 1;
         }
+        // The next step's action (requested at the top of this step) is taken out of flight here, before this
+        // step's stores are issued: vmcnt counts loads and stores in one queue, so a wait placed at the top of
+        // the next step would also wait for every store below.
+        if (t + 1 < n_steps) asm volatile("" : "+v"(a_next.x), "+v"(a_next.y), "+v"(a_next.z), "+v"(a_next.w));
         // The state is final here. Its stores (63 % of the bytes this launch writes) go out before the
         // observation arithmetic so that they drain behind it instead of after it.
         if (t == n_steps - 1 && live) store_lane(*(const mg_quadrotor_state *)&kae->st, n, e, s, ct);
