@@ -1,25 +1,36 @@
 #!/usr/bin/env python3
-"""bench.py — env-steps/sec of the batched Quadrotor hot path on N MI355X GPUs of one node.
+"""bench.py — env-steps/sec of the batched MetaGym hot path on N MI355X GPUs of one node.
 
     python bench.py --gpus 1 --steps 200 --warmup 20
     python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 \
-           --master-port 29500 bench.py --gpus 8 --steps 200 --warmup 20
+           --master-port 29500 bench.py --gpus 8 --steps 200 --warmup 20 [--workload mixed]
 
-Workload (BASELINE.json configs[1]): Quadrotor `hovering_control`, 65 536 parallel
-envs per GPU, default config.json physics, dt=0.01 (10 Euler sub-steps per env step), nt=1000, flat
-map; synthetic actions U(0.1, 15.0) f32 already resident in HBM; fused auto-reset so finished
-episodes restart inside the launch. A "step" = ONE call of env.step() = one launch of the HIP
-kernel over the whole batch. Envs shard across GPUs with no collective (weak scaling: 65 536
-envs per GPU); torch.distributed (RCCL) is used only for the timing barrier and the max-over-ranks.
+Headline workload (BASELINE.json configs[1]): Quadrotor `hovering_control`, 65 536
+parallel envs per GPU, default config.json physics, dt=0.01 (10 Euler sub-steps per env step), nt=1000,
+flat map; synthetic actions U(0.1, 15.0) f32 already resident in HBM; fused auto-reset so finished
+episodes restart inside the launch. A "step" = ONE env.step() over the whole batch = ONE launch of the HIP
+kernel. `--launch graph` (default) captures the K timed env.step() calls into one hipGraph and times
+its replay — the fused auto-reset draws its noise from per-env device counters, so no launch argument
+changes between steps; `--launch eager` issues the K calls from Python. Same kernel, same work per step.
+
+`--workload mixed` (BASELINE.json configs[4]): every rank steps 65 536 quadrotors AND
+65 536 MetaMazeDiscrete3D envs (9x9 mazes, 64x64 frames so 2^19 frames stay resident) on two HIP streams;
+at N = 8 that is 2^20 envs. A "step" = one step of both families.
+
+Envs shard across GPUs with no data-path collective (weak scaling). torch.distributed is initialised with
+the **gloo** backend and used only for the timing barrier and the max-over-ranks reduction of one float:
+there is no RCCL anywhere in the harness or the step path (north_star: "independent batches, no RCCL").
 
 Prints ONE JSON line on rank 0.
-  value        whole-job env-steps/s = n_gpus * 65536 * steps / max-over-ranks wall time
-  roofline     algorithmic bytes per launch (317 B/env-step, DESIGN.md §4) / average kernel-launch
+  value        whole-job env-steps/s = envs stepped by all ranks * steps / max-over-ranks wall time
+  roofline     algorithmic bytes per launch (317 B/env-step, DESIGN.md §3.1) / average kernel-launch
                duration measured with HIP events on the launching stream, vs the 8 TB/s HBM peak
-  cpu_baseline the CPU oracle (a C port of the reference algorithm) on the host cores, bounded sample
+  cpu_baseline the reference's own Quadrotor.step in a multiprocessing.Pool when the reference tree is
+               importable (build container); otherwise the C port of it (oracle/) on the host cores
 """
 import argparse
 import json
+import multiprocessing
 import os
 import sys
 import threading
@@ -35,7 +46,10 @@ if ROOT not in sys.path:
 ENVS_PER_GPU = 65536
 BYTES_PER_ENV_STEP = 317          # state R+W 2x116 + action 16 + obs 64 + reward 4 + done 1
 HBM_PEAK_GBS = 8000.0             # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+COPY_CEILING_GBS = 6290.0         # same guide: what a device copy achieves
+FP64_VALU_PEAK_TFLOPS = 78.6      # same guide: 256 CUs x 4 SIMD x 16 lanes x 2 flop x 2.4 GHz
 N_ACTION_BATCHES = 8
+METRIC = "env-steps/sec (whole node) at 2^16 parallel envs; 1/2/4/8-GPU scaling"
 
 
 def usable_cpus():
@@ -60,7 +74,8 @@ def usable_cpus():
     return n
 
 
-def cpu_baseline(seconds=12.0, n_envs_per_thread=256, max_threads=None):
+# ---------------------------------------------------------------------------------------- CPU baselines
+def cpu_port(seconds=12.0, n_envs_per_thread=256, max_threads=None):
     """Time the CPU oracle (oracle/quadrotor_oracle.c, a scalar C port of the reference algorithm) on
     the same workload. One thread per host core, each stepping its own block of envs; the timed loop
     runs inside C (ctypes releases the GIL), 100 env-steps per env per call."""
@@ -104,6 +119,66 @@ def cpu_baseline(seconds=12.0, n_envs_per_thread=256, max_threads=None):
             "sample": "%d env-steps of the same hovering_control workload (%d envs per thread, finished episodes "
                       "restart), %.1f s wall, C oracle gcc -O2 scalar, one thread per core"
                       % (total, n_envs_per_thread, el)}
+
+
+def reference_root():
+    return os.environ.get("METAGYM_REFERENCE", "/root/reference")
+
+
+def _reference_worker(args):
+    """One single-env reference worker (metagym/quadrotor/env.py:127 `Quadrotor.step`, unmodified, imported through
+    oracle/refstubs because gym is not installed): 20 warm-up steps, then steps until the deadline."""
+    idx, ref, seconds = args
+    sys.path.insert(0, os.path.join(ROOT, "oracle", "refstubs"))
+    sys.path.insert(0, ref)
+    np.int = int                      # quadrotorsim.py:243,250 use the removed alias
+    import gym  # noqa: F401  (the stub)
+    from metagym.quadrotor.env import Quadrotor
+    np.random.seed(1000 + idx)
+    env = Quadrotor(task="hovering_control", nt=1000)
+    env.reset()
+    rs = np.random.RandomState(2000 + idx)
+    acts = rs.uniform(0.1, 15.0, (256, 4)).astype(np.float32)
+    n = 0
+
+    def one(k):
+        try:
+            _, _, done, _ = env.step(acts[k % 256])
+        except Exception:             # _check_failure raises out of step() (quadrotorsim.py:212-221)
+            done = True
+        if done:
+            env.reset()
+    for k in range(20):
+        one(k)
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < seconds:
+        one(n)
+        n += 1
+    return n, time.perf_counter() - t0
+
+
+def cpu_reference(seconds=12.0):
+    """north_star: "the reference CPU path timed on the same box's host cores (core count stated) in the same
+    run" — a multiprocessing.Pool(P) of independent single-env `Quadrotor.step` workers (BASELINE.md §4,
+    SURVEY.md §8d C2). Only possible where the reference tree exists (the build container; the GPU box has no
+    /root/reference and bench.py may not read it there): returns (result, None) or (None, reason)."""
+    ref = reference_root()
+    if not os.path.isdir(os.path.join(ref, "metagym", "quadrotor")):
+        return None, ("no reference tree at %s on this machine (it is not shipped to the GPU box); the figure recorded "
+                      "in the build container is under from_profiles.reference_cpu" % ref)
+    cores = usable_cpus()
+    try:
+        ctx = multiprocessing.get_context("fork")
+        with ctx.Pool(cores) as pool:
+            res = pool.map(_reference_worker, [(i, ref, seconds) for i in range(cores)])
+    except Exception as e:
+        return None, "reference import / run failed: %r" % (e,)
+    steps = sum(r[0] for r in res)
+    wall = max(r[1] for r in res)
+    return {"value": steps / wall, "unit": "env-steps/s", "cores": cores, "kind": "reference",
+            "per_core": steps / wall / cores,
+            "sample": "%d env-steps, %d single-env workers of the unmodified metagym.quadrotor.env.Quadrotor "
+                      "(hovering_control, numpy %s, gym stubbed), %.1f s each" % (steps, cores, np.__version__, wall)}, None
 
 
 def cpu_baseline_maze3d(seconds=4.0, res=256):
@@ -150,10 +225,9 @@ def cpu_baseline_walker(seconds=3.0):
     """Secondary CPU figure for C4: the numpy restatement of the walker engine (oracle/abd.py — the checker the
     GPU kernels are tested against, NOT PyBullet, which the reference calls and which is not in its tree), one
     env on one core."""
-    sys.path.insert(0, os.path.join(ROOT, "tests"))
     from oracle import abd
-    from walker_fixtures import load_models
-    m = load_models()["humanoid"]
+    from metagym_amd.metalocomotion import variants
+    m = variants.model("humanoid", "TRAIN", 0)
     env = abd.WalkerEnv(m, prm=abd.Params(friction=0.8 * float(m.geom_friction), self_friction=float(m.geom_friction) ** 2))
     rs = np.random.RandomState(0)
     env.reset(rs.uniform(-0.1, 0.1, len(m.joint_lo)))
@@ -168,6 +242,7 @@ def cpu_baseline_walker(seconds=3.0):
             "sample": "%d env steps of one humanoid, %.1f s wall, numpy restatement of this engine (oracle/abd.py)" % (n, el)}
 
 
+# ---------------------------------------------------------------------------------------- GPU timing helpers
 def _time_steps(step_fn, steps, warmup):
     for i in range(warmup):
         step_fn(i)
@@ -181,30 +256,102 @@ def _time_steps(step_fn, steps, warmup):
     return e0.elapsed_time(e1) * 1e-3 / steps
 
 
+def capture_steps(dev, step_fn, steps):
+    """`steps` calls of step_fn(i) as one hipGraph (torch.cuda.graph). The C ABI only enqueues kernels on the
+    caller's stream, so it captures as it stands. Returns the graph; replaying it performs exactly those steps."""
+    side = torch.cuda.Stream(device=dev)
+    side.wait_stream(torch.cuda.current_stream(dev))
+    with torch.cuda.stream(side):          # lazy module load must not happen during capture
+        step_fn(0)
+    torch.cuda.current_stream(dev).wait_stream(side)
+    torch.cuda.synchronize(dev)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        for i in range(steps):
+            step_fn(i)
+    return graph
+
+
+def maze_tasks(n_tasks=64):
+    from metagym_amd.metamaze import MazeTaskSampler
+    return [MazeTaskSampler(n=9, allow_loops=False, step_reward=-0.01, goal_reward=1.0, food_density=0.06,
+                            food_interval=20, seed=s) for s in range(n_tasks)]
+
+
+def latest_profile_round():
+    try:
+        rounds = sorted(d for d in os.listdir(os.path.join(ROOT, "profiles")) if d.startswith("r") and d[1:].isdigit())
+        return rounds[-1] if rounds else None
+    except OSError:
+        return None
+
+
+def from_profiles(n, launch_s):
+    """Numbers that were NOT observed in this run: read from committed rocprofv3 / PMC summaries under profiles/
+    (file and round named next to each). Kept apart from `roofline`, which holds only what this run measured."""
+    out = {}
+    rnd = latest_profile_round()
+    if rnd is None:
+        return out
+    try:
+        q = json.load(open(os.path.join(ROOT, "profiles", rnd, "pmc_summary.json")))["quadrotor_step_kernel"]
+        src = "profiles/%s/pmc_summary.json" % rnd
+        if "hbm_bytes_per_launch" in q:
+            out["traffic"] = {"hbm_bytes_per_launch": q["hbm_bytes_per_launch"], "source": src, "round": rnd,
+                              "note": "2 x FETCH_SIZE + WRITE_SIZE of a separate --pmc pass at the same batch size"}
+        ipw = float(q["valu_insts_per_wave"])
+        waves = (n + 63) // 64
+        peak_issue = 1024 * 2.4e9 / 4.0           # one wave-instruction occupies a SIMD for >= 4 cycles
+        out["valu_issue"] = {"valu_insts_per_wave": ipw, "waves_per_launch": waves,
+                             "achieved_wave_insts_per_s": ipw * waves / launch_s,
+                             "peak_wave_insts_per_s": peak_issue, "frac": ipw * waves / launch_s / peak_issue,
+                             "source": src, "round": rnd,
+                             "note": "instruction count from the PMC pass, launch duration from this run"}
+    except Exception:
+        pass
+    try:
+        p = os.path.join(ROOT, "profiles", rnd, "reference_cpu_build_container.json")
+        if not os.path.exists(p):
+            p = None
+            for r in sorted(os.listdir(os.path.join(ROOT, "profiles")), reverse=True):
+                cand = os.path.join(ROOT, "profiles", r, "reference_cpu_build_container.json")
+                if os.path.exists(cand):
+                    p = cand
+                    break
+        if p:
+            out["reference_cpu"] = dict(json.load(open(p)), source=os.path.relpath(p, ROOT))
+    except Exception:
+        pass
+    return out
+
+
 def secondary_workloads(dev):
     """The other BASELINE configs on this GPU, each a few dozen launches (reported next to the headline,
     never folded into `value`): C3 MetaMazeDiscrete3D 9x9 at the registered 256x256 resolution with
-    16 384 envs, C1-scaled MetaMaze2D 15x15, C4 MetaLocomotion humanoid with 8 192 envs."""
+    16 384 envs, C1 MetaMaze2D 15x15, C4 MetaLocomotion humanoid with 8 192 envs over the 256 TRAIN variants."""
     import metagym_amd
     from metagym_amd.metamaze import MazeTaskSampler
     out = {}
     try:
         n, res = 16384, 256
-        tasks = [MazeTaskSampler(n=9, allow_loops=False, step_reward=-0.01, goal_reward=1.0, food_density=0.06,
-                                 food_interval=20, seed=s) for s in range(64)]
-        env = metagym_amd.make("meta-maze-discrete-3D-v0", num_envs=n, device=dev, max_steps=200,
-                               resolution=(res, res), task_type="SURVIVAL", auto_reset=True)
-        env.set_task(tasks)
-        env.reset()
-        acts = [torch.randint(0, 4, (n,), device=dev, dtype=torch.int32) for _ in range(4)]
-        s = _time_steps(lambda i: env.step(acts[i % 4]), 12, 3)
-        byt = (12 * res * res + 64) * n
-        out["C3_maze3d_discrete_9x9_256x256_16384envs"] = {
-            "env_steps_per_s": n / s, "ms_per_launch": s * 1e3,
-            "roofline": {"bound": "hbm", "achieved": byt / s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": byt / s / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes_per_env_step": 12 * res * res + 64}}
-        del env, acts
-        torch.cuda.empty_cache()
+        for cont, ident, key in ((False, "meta-maze-discrete-3D-v0", "C3_maze3d_discrete_9x9_256x256_16384envs"),
+                                 (True, "meta-maze-continuous-3D-v0", "C3_maze3d_continuous_9x9_256x256_16384envs")):
+            env = metagym_amd.make(ident, num_envs=n, device=dev, max_steps=200, resolution=(res, res),
+                                   task_type="SURVIVAL", auto_reset=True)
+            env.set_task(maze_tasks())
+            env.reset()
+            if cont:
+                acts = [torch.rand(n, 2, device=dev) * 2 - 1 for _ in range(4)]
+            else:
+                acts = [torch.randint(0, 4, (n,), device=dev, dtype=torch.int32) for _ in range(4)]
+            s = _time_steps(lambda i: env.step(acts[i % 4]), 12, 3)
+            byt = (12 * res * res + 64) * n
+            out[key] = {"env_steps_per_s": n / s, "ms_per_launch": s * 1e3,
+                        "roofline": {"bound": "hbm", "achieved": byt / s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                     "frac": byt / s / 1e9 / HBM_PEAK_GBS,
+                                     "algorithmic_bytes_per_env_step": 12 * res * res + 64}}
+            del env, acts
+            torch.cuda.empty_cache()
         n2 = 1 << 20
         tasks15 = [MazeTaskSampler(n=15, allow_loops=True, crowd_ratio=0.35, step_reward=-0.01, goal_reward=1.0,
                                    seed=s) for s in range(64)]
@@ -218,23 +365,14 @@ def secondary_workloads(dev):
         del env, acts
         torch.cuda.empty_cache()
         # C1 as BASELINE.json states it: ONE 15x15 env. Pure launch latency — eager, and 100 steps
-        # captured as one hipGraph (the C ABI only enqueues kernels, so torch.cuda.graph can capture it).
+        # captured as one hipGraph.
         env = metagym_amd.make("meta-maze-2D-v0", num_envs=1, device=dev, max_steps=10 ** 9, view_grid=1,
                                task_type="ESCAPE")
         env.set_task(tasks15[0])
         env.reset()
         a1 = torch.randint(0, 4, (100, 1), device=dev, dtype=torch.int32)
         s_eager = _time_steps(lambda i: env.step(a1[i % 100]), 200, 20)
-        side = torch.cuda.Stream(device=dev)
-        side.wait_stream(torch.cuda.current_stream(dev))
-        with torch.cuda.stream(side):
-            env.step(a1[0])
-        torch.cuda.current_stream(dev).wait_stream(side)
-        torch.cuda.synchronize()
-        graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
-            for k in range(100):
-                env.step(a1[k])
+        graph = capture_steps(dev, lambda i: env.step(a1[i]), 100)
         s_graph = _time_steps(lambda i: graph.replay(), 20, 3) / 100
         out["C1_maze2d_15x15_escape_1env"] = {"us_per_step_eager": s_eager * 1e6,
                                               "us_per_step_hipgraph_100": s_graph * 1e6,
@@ -244,31 +382,19 @@ def secondary_workloads(dev):
     except Exception as e:  # secondary numbers must never break the headline line
         out["maze_error"] = repr(e)
     try:
-        # C5 (mixed, 2^20 envs over 8 GPUs): one GPU's share = 65 536 quadrotors + 65 536 MetaMaze3D envs
-        # (64x64 frames so the batch stays resident). The two families are independent,
-        # so they are co-scheduled on two HIP streams: the VALU-bound quadrotor kernel and the
-        # store-heavy raycaster overlap instead of queueing behind each other.
-        nq = nm = 65536
-        tasks = [MazeTaskSampler(n=9, allow_loops=False, step_reward=-0.01, goal_reward=1.0, food_density=0.06,
-                                 food_interval=20, seed=s) for s in range(64)]
-        quad = metagym_amd.make("quadrotor-v0", num_envs=nq, device=dev, task="hovering_control", auto_reset=True)
-        maze = metagym_amd.make("meta-maze-discrete-3D-v0", num_envs=nm, device=dev, max_steps=200,
-                                resolution=(64, 64), task_type="SURVIVAL", auto_reset=True)
-        maze.set_task(tasks)
-        quad.reset(seed=0)
-        maze.reset()
-        qa = [torch.rand(nq, 4, device=dev) * 14.9 + 0.1 for _ in range(4)]
-        ma = [torch.randint(0, 4, (nm,), device=dev, dtype=torch.int32) for _ in range(4)]
-        s_q = _time_steps(lambda i: quad.step(qa[i % 4]), 40, 5)
-        s_m = _time_steps(lambda i: maze.step(ma[i % 4]), 40, 5)
+        # C5 (mixed, 2^20 envs over 8 GPUs): one GPU's share, same code path as `--workload mixed`
+        n = ENVS_PER_GPU
+        plan = shard_plan(0, 1, n, "mixed")
+        quad, maze = QuadrotorShard(dev, plan, n), MazeShard(dev, plan, n)
+        s_q = _time_steps(quad.step, 40, 5)
+        s_m = _time_steps(maze.step, 40, 5)
         st_q, st_m = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)
 
         def both(i):
             with torch.cuda.stream(st_q):
-                quad.step(qa[i % 4])
+                quad.step(i)
             with torch.cuda.stream(st_m):
-                maze.step(ma[i % 4])
-        torch.cuda.synchronize()
+                maze.step(i)
         for i in range(5):
             both(i)
         torch.cuda.synchronize()
@@ -278,37 +404,47 @@ def secondary_workloads(dev):
         torch.cuda.synchronize()
         s_b = (time.perf_counter() - t0) / 40
         out["C5_mixed_share_65536quad_plus_65536maze3d_64x64"] = {
-            "env_steps_per_s_two_streams": (nq + nm) / s_b, "ms_per_mixed_step_two_streams": s_b * 1e3,
-            "ms_quadrotor_alone": s_q * 1e3, "ms_maze3d_alone": s_m * 1e3,
-            "overlap_gain": (s_q + s_m) / s_b}
-        del quad, maze, qa, ma
+            "env_steps_per_s_two_streams": 2 * n / s_b, "ms_per_mixed_step_two_streams": s_b * 1e3,
+            "ms_quadrotor_alone": s_q * 1e3, "ms_maze3d_alone": s_m * 1e3, "overlap_gain": (s_q + s_m) / s_b,
+            "note": "one GPU's share of BASELINE configs[4]; the multi-GPU run is `bench.py --gpus N --workload mixed`"}
+        del quad, maze
         torch.cuda.empty_cache()
     except Exception as e:
         out["mixed_error"] = repr(e)
     try:
-        sys.path.insert(0, os.path.join(ROOT, "tests"))
-        from walker_fixtures import load_models
-        from metagym_amd.metalocomotion import MetaHumanoidEnv
-        M = load_models()
+        from metagym_amd.metalocomotion import MetaHumanoidEnv, variants
         n = 8192
         env = MetaHumanoidEnv(num_envs=n, device=dev)
-        env.set_task([M[k] for k in ("humanoid", "humanoid_tra_000", "humanoid_tra_137", "humanoid_ood_003")])
+        env.set_task(variants.models("humanoid", "TRAIN"))        # humanoid_var_tra_000..255, env e -> variant e % 256
         env.reset(seed=0)
         acts = [torch.rand(n, env.n_joints, device=dev) * 2 - 1 for _ in range(4)]
         s = _time_steps(lambda i: env.step(acts[i % 4]), 12, 3)
-        out["C4_humanoid_8192envs"] = {"env_steps_per_s": n / s, "ms_per_launch": s * 1e3,
-                                       "note": "physics parity unpinned (PyBullet is not in the reference tree)"}
+        byt, flop = 625, 1.0e5                                    # SURVEY.md §8(d) C4 per env-step figures
+        out["C4_humanoid_8192envs_256variants"] = {
+            "env_steps_per_s": n / s, "ms_per_launch": s * 1e3,
+            "roofline": {"bound": "valu", "achieved": flop * n / s / 1e12, "peak": FP64_VALU_PEAK_TFLOPS,
+                         "unit": "TFLOP/s", "frac": flop * n / s / 1e12 / FP64_VALU_PEAK_TFLOPS,
+                         "algorithmic_flop_per_env_step": flop,
+                         "achieved_hbm_gbs": byt * n / s / 1e9, "hbm_frac": byt * n / s / 1e9 / HBM_PEAK_GBS,
+                         "algorithmic_bytes_per_env_step": byt,
+                         "note": "f64 VALU peak; flop and byte figures are SURVEY.md §8(d)'s estimates for the "
+                                 "articulated-body step (4 sub-steps x [dynamics + contacts + 5 PGS sweeps])"},
+            "note": "physics parity unpinned (PyBullet is not in the reference tree)"}
+        del env, acts
+        torch.cuda.empty_cache()
     except Exception as e:
         out["walker_error"] = repr(e)
     return out
 
 
-def aggregate_throughput(dist, dev, wall, envs_per_rank, steps):
+# ---------------------------------------------------------------------------------------- multi-GPU plumbing
+def aggregate_throughput(dist, wall, envs_per_rank, steps):
     """Whole-job env-steps/s: every rank stepped `envs_per_rank` envs `steps` times; the job took as
-    long as its slowest rank. `dist` is torch.distributed (initialised) or None for one process."""
+    long as its slowest rank. `dist` is torch.distributed (initialised, any backend) or None for one process.
+    The reduction runs on a CPU tensor (gloo): nothing here touches RCCL."""
     wall_max, world = wall, 1
     if dist is not None:
-        t = torch.tensor([wall], dtype=torch.float64, device=dev)
+        t = torch.tensor([wall], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         wall_max = float(t.item())
         world = dist.get_world_size()
@@ -320,12 +456,64 @@ def shard_env_ids(rank, world, envs_per_rank):
     return np.arange(rank * envs_per_rank, (rank + 1) * envs_per_rank, dtype=np.int64)
 
 
+def shard_plan(rank, world, envs_per_rank, workload="quadrotor", job_seed=1000, n_maze_tasks=64):
+    """Everything rank `rank` needs to build its share of the job, as plain numbers (exercised on CPU by
+    tests/test_distributed_cpu.py): the global ids of its envs, the `env_id_base` handed to the fused auto-reset
+    (Philox streams are keyed by GLOBAL env id, so the union over ranks is the single-rank job), the seed of its
+    host-side initial reset and action streams, and for the mixed workload the maze task of every env
+    (global env id mod table size — the table itself is replicated)."""
+    ids = shard_env_ids(rank, world, envs_per_rank)
+    plan = {"rank": rank, "world": world, "env_ids": ids, "env_id_base": int(ids[0]), "job_seed": job_seed,
+            "reset_seed": job_seed + rank, "action_seed": 2 * job_seed + rank}
+    if workload == "mixed":
+        plan["maze_env_ids"] = ids
+        plan["maze_task_ids"] = (ids % n_maze_tasks).astype(np.int32)
+    return plan
+
+
+class QuadrotorShard:
+    """C2 on one GPU: this rank's quadrotors + resident action batches."""
+
+    def __init__(self, dev, plan, n):
+        import metagym_amd
+        self.n = n
+        self.env = metagym_amd.make("quadrotor-v0", num_envs=n, device=dev, task="hovering_control",
+                                    auto_reset=True, seed=plan["job_seed"], env_id_base=plan["env_id_base"])
+        self.env.reset(seed=plan["reset_seed"])
+        g = torch.Generator(device=dev)
+        g.manual_seed(plan["action_seed"])
+        self.actions = torch.rand(N_ACTION_BATCHES, n, 4, device=dev, generator=g) * 14.9 + 0.1
+
+    def step(self, i):
+        self.env.step(self.actions[i % N_ACTION_BATCHES])
+
+
+class MazeShard:
+    """C5's MetaMaze3D half on one GPU: 9x9 mazes, 64x64 int32 frames, SURVIVAL, fused auto-reset."""
+
+    def __init__(self, dev, plan, n, res=64):
+        import metagym_amd
+        self.n = n
+        self.env = metagym_amd.make("meta-maze-discrete-3D-v0", num_envs=n, device=dev, max_steps=200,
+                                    resolution=(res, res), task_type="SURVIVAL", auto_reset=True)
+        self.env.set_task(maze_tasks(), task_ids=torch.as_tensor(plan["maze_task_ids"]))
+        self.env.reset()
+        g = torch.Generator(device=dev)
+        g.manual_seed(plan["action_seed"] + 7)
+        self.actions = [torch.randint(0, 4, (n,), device=dev, dtype=torch.int32, generator=g) for _ in range(4)]
+
+    def step(self, i):
+        self.env.step(self.actions[i % 4])
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--envs-per-gpu", type=int, default=ENVS_PER_GPU)
+    ap.add_argument("--workload", choices=("quadrotor", "mixed"), default="quadrotor")
+    ap.add_argument("--launch", choices=("graph", "eager"), default="graph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the C1/C3/C4 side measurements")
     args = ap.parse_args()
@@ -338,73 +526,87 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
-    if world > 1 or os.environ.get("BENCH_FORCE_DIST") == "1":   # the env var lets a 1-GPU box test the RCCL path
+    if world > 1 or os.environ.get("BENCH_FORCE_DIST") == "1":   # the env var lets a 1-GPU box exercise this path
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
-
-    import metagym_amd
-    n = args.envs_per_gpu
-    env = metagym_amd.make("quadrotor-v0", num_envs=n, device=dev, task="hovering_control",
-                           auto_reset=True, seed=1000, env_id_base=int(shard_env_ids(rank, world, n)[0]))
-    env.reset(seed=1000 + rank)
-    g = torch.Generator(device=dev)
-    g.manual_seed(2000 + rank)
-    actions = torch.rand(N_ACTION_BATCHES, n, 4, device=dev, generator=g) * 14.9 + 0.1
+        os.environ.setdefault("MASTER_PORT", "29511")
+        dist.init_process_group("gloo", rank=rank, world_size=world)   # CPU barrier only: no RCCL in this harness
 
     def barrier():
         if dist is not None:
             dist.barrier()
 
+    n = args.envs_per_gpu
+    mixed = args.workload == "mixed"
+    plan = shard_plan(rank, world, n, args.workload)
+    quad = QuadrotorShard(dev, plan, n)
+    maze = MazeShard(dev, plan, n) if mixed else None
+    st_q = st_m = None
+    if mixed:
+        st_q, st_m = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)
+
+    def step(i):
+        if not mixed:
+            quad.step(i)
+            return
+        # the two families are independent: co-scheduled on two HIP streams, the VALU-bound quadrotor kernel
+        # and the store-heavy raycaster overlap instead of queueing behind each other
+        with torch.cuda.stream(st_q):
+            quad.step(i)
+        with torch.cuda.stream(st_m):
+            maze.step(i)
+
     for i in range(args.warmup):
-        env.step(actions[i % N_ACTION_BATCHES])
-    barrier()
+        step(i)
     torch.cuda.synchronize(dev)
-    ev0 = torch.cuda.Event(enable_timing=True)
-    ev1 = torch.cuda.Event(enable_timing=True)
-    t0 = time.perf_counter()
-    ev0.record()                      # torch's current stream == the stream the kernels are launched on
-    for i in range(args.steps):
-        env.step(actions[i % N_ACTION_BATCHES])
-    ev1.record()
-    torch.cuda.synchronize(dev)
-    t1 = time.perf_counter()
-    barrier()
-    wall = t1 - t0
-    dev_ms = ev0.elapsed_time(ev1)
+    launch_mode = args.launch if not mixed else "eager"
+    graph = None
+    if launch_mode == "graph":
+        try:
+            graph = capture_steps(dev, step, args.steps)
+            graph.replay()            # first replay uploads the executable graph: keep that out of the timed region
+            torch.cuda.synchronize(dev)
+        except Exception as e:        # report, fall back to the eager loop (same launches)
+            launch_mode = "eager (graph capture failed: %r)" % (e,)
+            graph = None
 
-    value, wall_max = aggregate_throughput(dist, dev, wall, n, args.steps)
+    def timed_region():
+        barrier()
+        torch.cuda.synchronize(dev)
+        ev0 = torch.cuda.Event(enable_timing=True)
+        ev1 = torch.cuda.Event(enable_timing=True)
+        t0 = time.perf_counter()
+        ev0.record()                  # torch's current stream == the stream the kernels / the graph are launched on
+        if graph is not None:
+            graph.replay()
+        else:
+            for i in range(args.steps):
+                step(i)
+        ev1.record()
+        torch.cuda.synchronize(dev)
+        t1 = time.perf_counter()
+        barrier()
+        return t1 - t0, ev0.elapsed_time(ev1)
 
-    done_frac = float(env._done.float().mean().item())
-    failed_any = int(env._failed.max().item())
+    wall, dev_ms = timed_region()
+    envs_per_rank = n * (2 if mixed else 1)
+    value, wall_max = aggregate_throughput(dist, wall, envs_per_rank, args.steps)
+
+    # the other launch mode, for the record (never `value`)
+    other = None
+    if not mixed and world == 1:
+        graph_keep, graph = graph, None
+        if graph_keep is not None:
+            w2, d2 = timed_region()               # eager
+            other = {"mode": "eager", "host_wall_ms_per_step": w2 / args.steps * 1e3, "hip_event_us_per_step": d2 / args.steps * 1e3}
+        graph = graph_keep
+
+    done_frac = float(quad.env._done.float().mean().item())
+    failed_any = int(quad.env._failed.max().item())
     if rank == 0:
         launch_s = dev_ms * 1e-3 / args.steps
-        achieved = BYTES_PER_ENV_STEP * n / launch_s / 1e9
-        traffic = None
-        pmc = os.path.join(ROOT, "profiles", "quadrotor_pmc.json")
-        if os.path.exists(pmc):
-            try:
-                traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
-        # The kernel is VALU-issue-bound, not HBM-bound: report how close the launch is to
-        # the SIMDs' issue limit too. VALU instructions per wave come from the committed PMC pass
-        # (profiles/<round>/pmc_summary.json, SQ_INSTS_VALU / SQ_WAVES); one wave-instruction occupies a
-        # SIMD for >= 4 cycles, 1024 SIMDs at 2.4 GHz.
-        valu = None
-        try:
-            rounds = sorted(d for d in os.listdir(os.path.join(ROOT, "profiles")) if d.startswith("r"))
-            q = json.load(open(os.path.join(ROOT, "profiles", rounds[-1], "pmc_summary.json")))["quadrotor_step_kernel"]
-            ipw = float(q["valu_insts_per_wave"])
-            waves = (n + 63) // 64
-            peak_issue = 1024 * 2.4e9 / 4.0
-            valu = {"valu_insts_per_wave": ipw, "waves_per_launch": waves,
-                    "achieved_wave_insts_per_s": ipw * waves / launch_s, "peak_wave_insts_per_s": peak_issue,
-                    "frac": ipw * waves / launch_s / peak_issue, "source": "profiles/%s/pmc_summary.json" % rounds[-1]}
-        except Exception:
-            valu = None
         out = {
-            "metric": "env-steps/sec (whole node) at 2^16 parallel envs; 1/2/4/8-GPU scaling",
+            "metric": METRIC,
             "value": value,
             "unit": "env-steps/s",
             "n_gpus": world,
@@ -416,35 +618,62 @@ def main():
             "vs_baseline": None,
             "dtype": "f32/f64 mixed (reference choreography)",
             "data": "synthetic",
-            "config": {"workload": "Quadrotor hovering_control, %d envs/GPU, dt=0.01 (10 Euler sub-steps), "
-                                   "nt=1000, flat map, actions U(0.1,15) f32, fused auto-reset" % n,
-                       "launch": "one mg_quadrotor_step_autoreset launch per env.step()",
-                       "envs_per_gpu": n, "sharding": "env-sharded, no collective"},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "frac_of_measured_copy_ceiling": achieved / 6290.0,
-                         "traffic": traffic,
-                         "kernel": "quadrotor_step_kernel", "avg_launch_us": launch_s * 1e6,
-                         "algorithmic_bytes_per_launch": BYTES_PER_ENV_STEP * n,
-                         "valu_issue": valu},
-            "sanity": {"done_frac_last_step": done_frac, "failed_max": failed_any,
-                       "host_wall_ms_per_step": wall / args.steps * 1e3},
         }
-        if world == 1 and not args.no_secondary:
-            del env
+        if not mixed:
+            achieved = BYTES_PER_ENV_STEP * n / launch_s / 1e9
+            out["config"] = {"workload": "Quadrotor hovering_control, %d envs/GPU, dt=0.01 (10 Euler sub-steps), "
+                                         "nt=1000, flat map, actions U(0.1,15) f32, fused auto-reset" % n,
+                             "launch": "one quadrotor_step_kernel launch per env.step(); %s" % (
+                                 "the %d timed env.step() calls replayed as one hipGraph" % args.steps
+                                 if graph is not None else launch_mode),
+                             "envs_per_gpu": n, "sharding": "env-sharded, no collective; gloo barrier for timing only"}
+            out["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                               "frac": achieved / HBM_PEAK_GBS, "frac_of_measured_copy_ceiling": achieved / COPY_CEILING_GBS,
+                               "traffic": None,
+                               "kernel": "quadrotor_step_kernel", "avg_launch_us": launch_s * 1e6,
+                               "algorithmic_bytes_per_launch": BYTES_PER_ENV_STEP * n,
+                               "note": "avg_launch_us = HIP events around the timed region / steps (includes "
+                                       "inter-launch gaps); traffic is not observed in this run, see from_profiles"}
+        else:
+            frame_b = 12 * 64 * 64 + 64
+            byt = (BYTES_PER_ENV_STEP + frame_b) * n
+            out["config"] = {"workload": "mixed (BASELINE configs[4]): %d Quadrotor hovering_control + %d "
+                                         "MetaMazeDiscrete3D 9x9 @64x64 envs per GPU, %d envs in the job"
+                                         % (n, n, 2 * n * world),
+                             "launch": "one quadrotor launch + one maze3d launch per step, two HIP streams, eager",
+                             "envs_per_gpu": 2 * n, "sharding": "env-sharded, no collective; gloo barrier for timing only"}
+            out["roofline"] = {"bound": "hbm", "achieved": byt / (wall / args.steps) / 1e9, "peak": HBM_PEAK_GBS,
+                               "unit": "GB/s", "frac": byt / (wall / args.steps) / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                               "kernel": "quadrotor_step_kernel + maze3d_step_kernel (concurrent)",
+                               "algorithmic_bytes_per_step": byt,
+                               "note": "rank 0's wall time per mixed step; per-kernel rooflines are in the "
+                                       "single-workload run"}
+        out["sanity"] = {"done_frac_last_step": done_frac, "failed_max": failed_any,
+                         "host_wall_ms_per_step": wall / args.steps * 1e3, "launch_mode": launch_mode,
+                         "other_launch_mode": other}
+        if not mixed:
+            out["from_profiles"] = from_profiles(n, launch_s)
+        if world == 1 and not args.no_secondary and not mixed:
+            del quad
             torch.cuda.empty_cache()
             out["secondary"] = secondary_workloads(dev)
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline()
-            if "secondary" in out and "C3_maze3d_discrete_9x9_256x256_16384envs" in out["secondary"]:
-                try:
-                    out["secondary"]["C3_maze3d_discrete_9x9_256x256_16384envs"]["cpu_baseline"] = cpu_baseline_maze3d()
-                except Exception as e:
-                    out["secondary"]["C3_maze3d_discrete_9x9_256x256_16384envs"]["cpu_baseline_error"] = repr(e)
-            if "secondary" in out and "C4_humanoid_8192envs" in out["secondary"]:
-                try:
-                    out["secondary"]["C4_humanoid_8192envs"]["cpu_baseline"] = cpu_baseline_walker()
-                except Exception as e:
-                    out["secondary"]["C4_humanoid_8192envs"]["cpu_baseline_error"] = repr(e)
+            port = cpu_port()
+            ref, why = cpu_reference()
+            if ref is not None:
+                out["cpu_baseline"] = ref
+                out["cpu_port"] = port
+            else:
+                out["cpu_baseline"] = port
+                out["reference_unavailable"] = why
+            sec = out.get("secondary", {})
+            for key, fn in (("C3_maze3d_discrete_9x9_256x256_16384envs", cpu_baseline_maze3d),
+                            ("C4_humanoid_8192envs_256variants", cpu_baseline_walker)):
+                if key in sec:
+                    try:
+                        sec[key]["cpu_baseline"] = fn()
+                    except Exception as e:
+                        sec[key]["cpu_baseline_error"] = repr(e)
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.destroy_process_group()

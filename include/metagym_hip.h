@@ -17,6 +17,9 @@
  *     lane e of a wavefront touches consecutive addresses (coalesced HBM access).
  *   - Calls are asynchronous: kernels are enqueued on `stream` and the call returns without
  *     synchronising. Re-entrant; no global mutable state except the thread-local error string.
+ *   - Multi-GPU processes: every launching entry point looks up the HIP device that owns the state memory it
+ *     is handed (hipPointerGetAttributes; cached inside a plan) and makes it current for the duration of the
+ *     call when it is not already, so `stream` must belong to that device.
  *   - Return value: MG_OK (0) or a negative error code. hipError_t values are returned negated;
  *     argument errors are in the -1000 range. Nothing throws or aborts across the ABI.
  *   - Per-environment simulation failures (the reference `raise`s out of step()) are DATA, not
@@ -32,7 +35,7 @@
 extern "C" {
 #endif
 
-#define MG_ABI_VERSION 1
+#define MG_ABI_VERSION 2
 
 #define MG_OK 0
 #define MG_ERR_NULL_POINTER (-1001)
@@ -46,6 +49,11 @@ int mg_abi_version(void);
 const char *mg_last_error(void);
 /* Name of the device architecture the kernels were compiled for ("gfx950"). */
 const char *mg_target_arch(void);
+
+/* Self-test hook: out_d[i][0..3] = Philox4x32-10(counter = ctr_key_d[i][0..3], key = ctr_key_d[i][4..5]) computed by
+ * the device function every fused auto-reset draws its noise from (DEVICE u32 [n][6] -> DEVICE u32 [n][4]).
+ * tests/ checks it against the published Random123 known-answer vectors. */
+int mg_selftest_philox(const uint32_t *ctr_key_d, uint32_t *out_d, int32_t n, void *stream);
 
 /* ========================================================================================
  * Quadrotor — replaces metagym/quadrotor/quadrotorsim.py + env.py for N envs
@@ -92,6 +100,9 @@ typedef struct mg_quadrotor_state {
     float *propw;    /* [4][n] propeller_angular_velocity */
     float *rot;      /* [9][n] rotation_matrix, row-major index */
     int32_t *ct;     /* [n]    Quadrotor.ct step counter */
+    uint32_t *episode;   /* [n] number of fused auto-resets env e has gone through = the Philox counter of its next
+                            one (see mg_quadrotor_autoreset). Not a reference quantity; only read / written by the
+                            auto-reset launches and may be NULL for every other call. */
 } mg_quadrotor_state;
 
 /* Fill `cfg` with the values of the reference's default config.json + default constructor args
@@ -148,16 +159,20 @@ int mg_quadrotor_rollout(const mg_quadrotor_config *cfg, int32_t n_envs, int32_t
  * like mg_quadrotor_rollout, but an env whose step ended with done=1 is reset inside the same
  * launch (QuadrotorSim.reset quadrotorsim.py:239-258: zero state + init noise) and the returned
  * observation row is the first observation of its next episode; reward/done/failed still describe
- * the step that ended. The noise is drawn on the device from Philox4x32-10 keyed by `seed` with
- * counter (env_id_base + env index, step_index + t), so results are independent of how envs are
- * sharded across GPUs. */
+ * the step that ended. The noise of the k-th auto-reset of global env g is a pure function of
+ * (seed, g, k): two Philox4x32-10 blocks with key = seed (lo, hi) and counter = (g lo, g hi, k, block),
+ *   velocity[c]  = init_velocity[c]         + noisy_v * (w[c]   / 2^32) * (bit c   of w[6] ? +1 : -1)
+ *   body rate[c] = init_angular_velocity[c] + noisy_w * (w[3+c] / 2^32) * (bit 3+c of w[6] ? +1 : -1)
+ * with w[0..7] the eight output words, g = env_id_base + env index and k = state->episode[e], which the
+ * launch increments. Nothing depends on a host-side step counter, so results are independent of how
+ * envs are sharded across GPUs and of how many steps go into one launch, and the launch is
+ * hipGraph-capturable as it stands (all arguments are replay-invariant). */
 typedef struct mg_quadrotor_autoreset {
     float init_velocity[3];            /* cfg['init_velocity'] x, y, z */
     float init_angular_velocity[3];    /* cfg['init_angular_velocity'] x, y, z */
     double init_velocity_noisy;        /* cfg['init_velocity']['noisy'] (2.0) */
     double init_angular_velocity_noisy;/* cfg['init_angular_velocity']['noisy'] (5.0) */
     uint64_t seed;
-    uint64_t step_index;               /* global index of the first step of this call */
     uint64_t env_id_base;              /* global id of env 0 of this shard (0 on a single GPU) */
 } mg_quadrotor_autoreset;
 
@@ -165,6 +180,22 @@ int mg_quadrotor_step_autoreset(const mg_quadrotor_config *cfg, int32_t n_envs, 
                                 const mg_quadrotor_state *state, const mg_quadrotor_autoreset *ar,
                                 const float *action, float *obs, float *reward, double *reward64,
                                 uint8_t *done, uint8_t *failed, void *stream);
+
+/* Prepared stepping. Every entry point above folds `cfg` into kernel constants on each call (a few hundred
+ * host instructions, two float32 sqrt searches). A plan does it once: mg_quadrotor_plan_init validates and
+ * folds cfg (+ the optional auto-reset block), records the state pointers, n_envs and the HIP device that
+ * owns the state memory into caller-owned HOST memory; mg_quadrotor_plan_step then only enqueues the launch
+ * (and selects that device for the duration of the call if it is not the calling thread's current one).
+ * Same kernels, same results as mg_quadrotor_step / _rollout / _step_autoreset with the same arguments.
+ * The plan holds no resources and needs no destructor; it must be re-initialised when cfg, the state
+ * tensors or n_envs change. */
+typedef struct mg_quadrotor_plan { uint64_t opaque[128]; } mg_quadrotor_plan;
+
+int mg_quadrotor_plan_init(mg_quadrotor_plan *plan, const mg_quadrotor_config *cfg,
+                           const mg_quadrotor_autoreset *ar /* NULL = no fused reset */, int32_t n_envs,
+                           const mg_quadrotor_state *state);
+int mg_quadrotor_plan_step(const mg_quadrotor_plan *plan, int32_t n_steps, const float *action, float *obs,
+                           float *reward, double *reward64, uint8_t *done, uint8_t *failed, void *stream);
 
 /* ========================================================================================
  * MetaMaze — replaces metagym/metamaze/envs/{maze_base,maze_2d,maze_discrete_3d,
@@ -233,7 +264,9 @@ typedef struct mg_maze_view {
     const uint32_t *ceil_texture;  /* DEVICE [tex][tex] */
     int32_t n_textures, tex_size;
     int32_t max_ray_records;       /* optional bound on translucent records per ray (0 = 2n+1). A ray crosses
-                                      at most 2*floor(max_vision / min cell_size) + 4 cells before it stops */
+                                      at most 2*floor(max_vision / min cell_size) + 4 cells before it stops.
+                                      Hard limit 127 (the count travels in 7 bits between the two render passes):
+                                      larger values, and 2n+1 > 127, are clamped to it */
     int32_t obs_format;            /* 0: int32 [N][res_h][res_v][3], the reference's dtype (values exceed 255);
                                       1: uint8 with saturation at 255 — a non-parity fast path (4x fewer HBM bytes) */
 } mg_maze_view;

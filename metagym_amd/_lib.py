@@ -8,7 +8,7 @@ import os
 
 from . import build as _build
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 MG_OK = 0
 
@@ -38,14 +38,19 @@ class QuadrotorConfig(C.Structure):
 class QuadrotorState(C.Structure):
     """mg_quadrotor_state (device pointers)"""
     _fields_ = [("pos", C.c_void_p), ("vel", C.c_void_p), ("omega", C.c_void_p),
-                ("propw", C.c_void_p), ("rot", C.c_void_p), ("ct", C.c_void_p)]
+                ("propw", C.c_void_p), ("rot", C.c_void_p), ("ct", C.c_void_p), ("episode", C.c_void_p)]
 
 
 class QuadrotorAutoReset(C.Structure):
     """mg_quadrotor_autoreset"""
     _fields_ = [("init_velocity", C.c_float * 3), ("init_angular_velocity", C.c_float * 3),
                 ("init_velocity_noisy", C.c_double), ("init_angular_velocity_noisy", C.c_double),
-                ("seed", C.c_uint64), ("step_index", C.c_uint64), ("env_id_base", C.c_uint64)]
+                ("seed", C.c_uint64), ("env_id_base", C.c_uint64)]
+
+
+class QuadrotorPlan(C.Structure):
+    """mg_quadrotor_plan (opaque, caller-owned host memory)"""
+    _fields_ = [("opaque", C.c_uint64 * 128)]
 
 
 class MazeTasks(C.Structure):
@@ -128,6 +133,7 @@ SIGNATURES = {
     "mg_abi_version": (C.c_int, []),
     "mg_last_error": (C.c_char_p, []),
     "mg_target_arch": (C.c_char_p, []),
+    "mg_selftest_philox": (C.c_int, [_P, _P, C.c_int32, _P]),
     "mg_quadrotor_default_config": (C.c_int, [C.POINTER(QuadrotorConfig)]),
     "mg_quadrotor_velocity_targets": (C.c_int, [C.POINTER(QuadrotorConfig), C.c_int32, _P, _P, _P]),
     "mg_quadrotor_reset": (C.c_int, [C.POINTER(QuadrotorConfig), C.c_int32, C.POINTER(QuadrotorState),
@@ -137,6 +143,9 @@ SIGNATURES = {
     "mg_quadrotor_step_autoreset": (C.c_int, [C.POINTER(QuadrotorConfig), C.c_int32, C.c_int32,
                                               C.POINTER(QuadrotorState), C.POINTER(QuadrotorAutoReset),
                                               _P, _P, _P, _P, _P, _P, _P]),
+    "mg_quadrotor_plan_init": (C.c_int, [C.POINTER(QuadrotorPlan), C.POINTER(QuadrotorConfig),
+                                         C.POINTER(QuadrotorAutoReset), C.c_int32, C.POINTER(QuadrotorState)]),
+    "mg_quadrotor_plan_step": (C.c_int, [C.POINTER(QuadrotorPlan), C.c_int32, _P, _P, _P, _P, _P, _P, _P]),
     "mg_quadrotor_rollout": (C.c_int, [C.POINTER(QuadrotorConfig), C.c_int32, C.c_int32,
                                        C.POINTER(QuadrotorState), _P, _P, _P, _P, _P, _P, _P]),
     "mg_maze_view_tables": (C.c_int, [C.c_int32, C.c_double, C.c_double, _P, _P]),

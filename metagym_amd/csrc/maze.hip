@@ -30,6 +30,8 @@
 #include <cstdlib>
 #include <cstring>
 
+#include <atomic>
+
 #include "mg_common.h"
 
 namespace {
@@ -932,6 +934,7 @@ extern "C" int mg_maze_reset(const mg_maze_tasks *T, int32_t task_type, int32_t 
     if (int rc = check_tasks(T, task_type)) return rc;
     if (int rc = check_mstate(st, task_type)) return rc;
     const long threads = (long)n * 64;
+    mg::DeviceGuard guard(mg::device_of(st->grid));
     hipLaunchKernelGGL(maze_reset_kernel, dim3((unsigned)((threads + MZ_BLOCK - 1) / MZ_BLOCK)), dim3(MZ_BLOCK), 0,
                        (hipStream_t)stream, *T, *st, task_type, n, mask);
     return mg::check_launch("maze_reset_kernel");
@@ -947,6 +950,7 @@ extern "C" int mg_maze2d_step(const mg_maze_tasks *T, int32_t task_type, int32_t
     if (n <= 0 || view_grid < 0) return mg::set_error(MG_ERR_BAD_SIZE, "n_envs=%d view_grid=%d", n, view_grid);
     if (int rc = check_tasks(T, task_type)) return rc;
     if (int rc = check_mstate(st, task_type)) return rc;
+    mg::DeviceGuard guard(mg::device_of(st->grid));
     hipLaunchKernelGGL(maze2d_step_kernel, dim3((n + MZ_BLOCK - 1) / MZ_BLOCK), dim3(MZ_BLOCK), 0, (hipStream_t)stream,
                        *T, *st, task_type, max_steps, view_grid, auto_reset, n, action, obs, reward, reward64, done);
     return mg::check_launch("maze2d_step_kernel");
@@ -1007,27 +1011,49 @@ extern "C" int mg_maze3d_step(const mg_maze_tasks *T, const mg_maze_view *view, 
     // at least one cell per step and stops at max_vision or at the maze border.
     vk.t_max = 2 * T->n + 1;
     if (view->max_ray_records > 0 && view->max_ray_records < vk.t_max) vk.t_max = view->max_ray_records;
+    // column_pass hands the record count to pixel_pass in 7 bits of the packed span word (span | n_tr << 24):
+    // more than 127 translucent cells on one ray needs n > 63 AND a vision range spanning them; capped, documented
+    // in metagym_hip.h (mg_maze_view.max_ray_records)
+    if (vk.t_max > 127) vk.t_max = 127;
     // Waves per env (measured on MI355X, 16 384 envs, profiles/r01/maze3d_waves_sweep.txt): 64x64 frames
     // run ~9 % faster with 2 waves per env (less per-env fixed work per pixel, more independent envs
     // resident per CU), 128x128 is a tie, 256x256 is fastest with 4. 32-column slabs beat 64 everywhere
     // (half the overlay-record LDS, more workgroups per CU).
     int n_waves = ((long)vk.H * vk.V < 128L * 128L) ? 2 : MZ_WAVES;
     vk.slab = SLAB;
-    if (const char *ev = getenv("MG_MAZE3D_WAVES")) {          // tuning override: "<waves>[,<slab>]"
-        int w = 0, sl = 0;
-        if (sscanf(ev, "%d,%d", &w, &sl) >= 1 && (w == 1 || w == 2 || w == 4)) {
-            n_waves = w;
-            vk.slab = (sl == 32 || sl == 64) ? sl : SLAB;
-        }
+    {
+        // tuning override MG_MAZE3D_WAVES="<waves>[,<slab>]", read ONCE per process (thread-safe static
+        // initialisation): a re-entrant ABI must not consult mutable process state on every step
+        struct Override { int waves = 0, slab = 0; };
+        static const Override ov = [] {
+            Override o;
+            if (const char *ev = getenv("MG_MAZE3D_WAVES")) {
+                int w = 0, sl = 0;
+                if (sscanf(ev, "%d,%d", &w, &sl) >= 1 && (w == 1 || w == 2 || w == 4)) {
+                    o.waves = w;
+                    o.slab = (sl == 32 || sl == 64) ? sl : SLAB;
+                }
+            }
+            return o;
+        }();
+        if (ov.waves) { n_waves = ov.waves; vk.slab = ov.slab; }
     }
     const size_t lds = ((sizeof(EnvShared) + 15) & ~size_t(15)) + sizeof(double) * T->n * T->n +
                        sizeof(uint2) * vk.slab * vk.t_max * n_waves +
                        2 * ((size_t)(T->n * T->n + 15) & ~size_t(15)) + (sizeof(double) * 3 + 1) * (size_t)vk.V + 16;
     if (lds > 160 * 1024) return mg::set_error(MG_ERR_BAD_SIZE, "maze n=%d needs %zu B of LDS (> 160 KiB)", T->n, lds);
+    const int device = mg::device_of(obs);
+    mg::DeviceGuard guard(device);
     if (lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(maze3d_step_kernel),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return mg::check_hip(e, "hipFuncSetAttribute(maze3d_step_kernel)");
+        // the opt-in is sticky per device: raise it when a larger request comes, not on every step
+        static std::atomic<size_t> granted[MG_MAX_DEVICES];
+        const int slot = (device >= 0 && device < MG_MAX_DEVICES) ? device : 0;
+        if (device < 0 || device >= MG_MAX_DEVICES || lds > granted[slot].load(std::memory_order_relaxed)) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(maze3d_step_kernel),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return mg::check_hip(e, "hipFuncSetAttribute(maze3d_step_kernel)");
+            granted[slot].store(lds, std::memory_order_relaxed);
+        }
     }
     int pre_moved = 0;
     if (continuous && action != nullptr) {

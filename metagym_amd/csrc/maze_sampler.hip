@@ -340,6 +340,7 @@ extern "C" int mg_maze_sample_tasks(const mg_maze_sample_params *p, int32_t n_ta
     k.crowd_ratio = p->crowd_ratio; k.has_goal_reward = p->has_goal_reward != 0; k.seed_base = seed_base;
     const int nn = p->n * p->n;
     const size_t lds = sizeof(double) * nn + sizeof(uint32_t) * 2 * MTN + sizeof(int16_t) * 3 * nn + 2 * (size_t)nn;
+    mg::DeviceGuard guard(mg::device_of(start));
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(maze_sample_tasks_kernel),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

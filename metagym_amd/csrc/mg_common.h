@@ -22,6 +22,36 @@ inline int check_hip(hipError_t e, const char *what) {
 inline int check_launch(const char *kernel) { return check_hip(hipGetLastError(), kernel); }
 
 constexpr int WAVE = 64;  // gfx950 wavefront width
+}  // namespace mg
+#define MG_MAX_DEVICES 64
+namespace mg {
+
+// HIP device that owns a device allocation (-1: not a device pointer / lookup failed; the launch then runs on
+// the current device as before and faults loudly if that is wrong).
+inline int device_of(const void *p) {
+    hipPointerAttribute_t a;
+    if (p == nullptr || hipPointerGetAttributes(&a, p) != hipSuccess) {
+        (void)hipGetLastError();
+        return -1;
+    }
+    return a.device;
+}
+
+// Kernels launch on the calling thread's CURRENT device; a caller holding tensors of cuda:1 while cuda:0 is
+// current would otherwise launch cuda:0 kernels on cuda:1 pointers. Switch for the duration of one ABI call.
+struct DeviceGuard {
+    int prev = -1;
+    bool switched = false;
+    explicit DeviceGuard(int dev) {
+        if (dev < 0) return;
+        if (hipGetDevice(&prev) == hipSuccess && prev != dev) switched = hipSetDevice(dev) == hipSuccess;
+    }
+    ~DeviceGuard() {
+        if (switched) (void)hipSetDevice(prev);
+    }
+    DeviceGuard(const DeviceGuard &) = delete;
+    DeviceGuard &operator=(const DeviceGuard &) = delete;
+};
 
 // Workgroup b runs on XCD b % 8 (the hardware deals workgroups round-robin, whatever their cost). A frame's
 // cost follows its view, views follow the task and the pose, and callers lay tasks out periodically (env e

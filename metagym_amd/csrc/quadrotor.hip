@@ -49,7 +49,7 @@ struct QuadK {
     int auto_reset;
     float init_v_base[3], init_w_base[3];   // cfg['init_velocity'] / ['init_angular_velocity'] x,y,z (f32 arrays)
     double init_v_noisy, init_w_noisy;      // ... ['noisy']
-    uint64_t seed, step_index, env_id_base;
+    uint64_t seed, env_id_base;
     const int32_t *map;
     int map_h, map_w;
     const float *vtargets;   // velocity_control target trajectory [nt][3]
@@ -501,15 +501,18 @@ __device__ __forceinline__ void store_obs_wave(float *tile, const float *obs, fl
 
 // QuadrotorSim.reset quadrotorsim.py:239-258 with the noise drawn on the device:
 // value = base + noisy * U[0,1) * (+1 if U' > 0.5 else -1), per component.
-__device__ __forceinline__ void reset_lane_random(const QuadK &k, Lane &s, int e, uint64_t step) {
-    // two Philox calls = 8 words: six 32-bit magnitudes and one word of sign bits (the reset sits on the
-    // critical path of every wave that holds a finished env, so a third call is worth avoiding)
+__device__ __forceinline__ void reset_lane_random(const QuadK &k, Lane &s, int e, uint32_t episode) {
+    // two Philox blocks = 8 words: six 32-bit magnitudes and one word of sign bits (the reset sits on the
+    // critical path of every wave that holds a finished env, so a third block is worth avoiding).
+    // counter = (global env id lo, hi, episode, block), key = seed: the k-th auto-reset of a given env draws
+    // the same noise whatever the sharding, the launch shape (steps per launch) or the host did in between,
+    // and no launch argument changes from step to step (hipGraph replay; oracle: qo_reset_random)
     uint32_t r[8];
-    const uint64_t gid = k.env_id_base + (uint64_t)e;   // global env id: shard-invariant streams
+    const uint64_t gid = k.env_id_base + (uint64_t)e;
 #pragma unroll
     for (int d = 0; d < 2; ++d)
-        philox4x32_10((uint32_t)gid, (uint32_t)step, (uint32_t)(step >> 32) ^ ((uint32_t)(gid >> 32) << 8),
-                      (uint32_t)d, (uint32_t)k.seed, (uint32_t)(k.seed >> 32), &r[4 * d]);
+        philox4x32_10((uint32_t)gid, (uint32_t)(gid >> 32), episode, (uint32_t)d, (uint32_t)k.seed,
+                      (uint32_t)(k.seed >> 32), &r[4 * d]);
     const double inv32 = 1.0 / 4294967296.0;
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
@@ -579,6 +582,9 @@ __global__ __launch_bounds__(BLOCK) void quadrotor_step_kernel(QuadK k, mg_quadr
 
     Lane s;
     int ct;
+    uint32_t episode = 0;
+    if (k.auto_reset) episode = st.episode[el];
+    const uint32_t episode_in = episode;
     load_lane(st, n, el, s, ct);
     // All prologue loads land here (vmcnt = 0), not at their first use inside the step loop: there the wait
     // would be re-executed by every later step of a rollout and would also drain that step's freshly issued
@@ -667,7 +673,8 @@ __global__ __launch_bounds__(BLOCK) void quadrotor_step_kernel(QuadK k, mg_quadr
         // observation of the next episode for the envs that just finished.
         int tn = tn_step;
         if (ke.auto_reset && done) {
-            reset_lane_random(ke, s, el, ke.step_index + (uint64_t)t);
+            reset_lane_random(ke, s, el, episode);
+            episode += 1;
             tn = ct < ke.nt - 1 ? ct : ke.nt - 1;
         }
         // The next step's action (requested at the top of this step) is taken out of flight here, before this
@@ -676,7 +683,11 @@ __global__ __launch_bounds__(BLOCK) void quadrotor_step_kernel(QuadK k, mg_quadr
         if (t + 1 < n_steps) asm volatile("" : "+v"(a_next.x), "+v"(a_next.y), "+v"(a_next.z), "+v"(a_next.w));
         // The state is final here. Its stores (63 % of the bytes this launch writes) go out before the
         // observation arithmetic so that they drain behind it instead of after it.
-        if (t == n_steps - 1 && live) store_lane(*(const mg_quadrotor_state *)&kae->st, n, e, s, ct);
+        if (t == n_steps - 1 && live) {
+            const mg_quadrotor_state &ste = *(const mg_quadrotor_state *)&kae->st;
+            store_lane(ste, n, e, s, ct);
+            if (episode != episode_in) st_stream(&ste.episode[e], episode);   // rare: only lanes that restarted
+        }
         __builtin_amdgcn_sched_barrier(0);   // pure arithmetic would otherwise be hoisted above the stores
         float obs[OBS_DIM + 3];
         observe(ke, s, obs);
@@ -812,7 +823,7 @@ int fold_config(const mg_quadrotor_config *c, QuadK *k, bool need_targets = true
     k->auto_reset = 0;
     for (int i = 0; i < 3; ++i) { k->init_v_base[i] = 0.0f; k->init_w_base[i] = 0.0f; }
     k->init_v_noisy = k->init_w_noisy = 0.0;
-    k->seed = k->step_index = k->env_id_base = 0;
+    k->seed = k->env_id_base = 0;
     return MG_OK;
 }
 
@@ -836,6 +847,61 @@ int check_state(const mg_quadrotor_state *s) {
     return MG_OK;
 }
 
+// What mg_quadrotor_plan holds (caller-owned host memory, see the header): everything a step launch needs
+// except the per-call I/O pointers.
+struct Plan {
+    uint32_t magic;
+    int32_t n, device, simple;
+    QuadK k;
+    mg_quadrotor_state st;
+};
+constexpr uint32_t PLAN_MAGIC = 0x4d475150u;   // "MGQP"
+static_assert(sizeof(Plan) <= sizeof(mg_quadrotor_plan), "mg_quadrotor_plan is too small for the folded constants");
+
+int make_plan(Plan *p, const mg_quadrotor_config *cfg, const mg_quadrotor_autoreset *ar, int32_t n,
+              const mg_quadrotor_state *state) {
+    MG_REQUIRE_PTR(cfg);
+    MG_REQUIRE_PTR(state);
+    if (n <= 0) return mg::set_error(MG_ERR_BAD_SIZE, "n_envs=%d", n);
+    if (int rc = check_state(state)) return rc;
+    if (int rc = fold_config(cfg, &p->k)) return rc;
+    if (ar != nullptr) {
+        if (state->episode == nullptr)
+            return mg::set_error(MG_ERR_NULL_POINTER, "fused auto-reset needs mg_quadrotor_state.episode");
+        QuadK &k = p->k;
+        k.auto_reset = 1;
+        for (int i = 0; i < 3; ++i) { k.init_v_base[i] = ar->init_velocity[i]; k.init_w_base[i] = ar->init_angular_velocity[i]; }
+        k.init_v_noisy = ar->init_velocity_noisy;
+        k.init_w_noisy = ar->init_angular_velocity_noisy;
+        k.seed = ar->seed;
+        k.env_id_base = ar->env_id_base;
+    }
+    p->magic = PLAN_MAGIC;
+    p->n = n;
+    p->device = mg::device_of(state->pos);
+    p->simple = (config_is_simple(cfg) && cfg->task != MG_QUADROTOR_TASK_VELOCITY_CONTROL) ? 1 : 0;
+    p->st = *state;
+    return MG_OK;
+}
+
+int launch_plan(const Plan *p, int32_t n_steps, const float *action, float *obs, float *reward, double *reward64,
+                uint8_t *done, uint8_t *failed, void *stream) {
+    MG_REQUIRE_PTR(action);
+    MG_REQUIRE_PTR(obs);
+    MG_REQUIRE_PTR(done);
+    if (n_steps <= 0) return mg::set_error(MG_ERR_BAD_SIZE, "n_steps=%d", n_steps);
+    mg::DeviceGuard guard(p->device);
+    StepIO io{action, obs, reward, reward64, done, failed};
+    const int n = p->n, grid = (n + BLOCK - 1) / BLOCK;
+    if (p->simple)
+        hipLaunchKernelGGL(quadrotor_step_kernel<true>, dim3(grid), dim3(BLOCK), 0, (hipStream_t)stream, p->k, p->st,
+                           io, n, n_steps);
+    else
+        hipLaunchKernelGGL(quadrotor_step_kernel<false>, dim3(grid), dim3(BLOCK), 0, (hipStream_t)stream, p->k, p->st,
+                           io, n, n_steps);
+    return mg::check_launch("quadrotor_step_kernel");
+}
+
 int launch_steps(const mg_quadrotor_config *cfg, int32_t n, int32_t n_steps, const mg_quadrotor_state *state,
                  const float *action, float *obs, float *reward, double *reward64, uint8_t *done,
                  uint8_t *failed, void *stream, const mg_quadrotor_autoreset *ar = nullptr) {
@@ -844,28 +910,9 @@ int launch_steps(const mg_quadrotor_config *cfg, int32_t n, int32_t n_steps, con
     MG_REQUIRE_PTR(action);
     MG_REQUIRE_PTR(obs);
     MG_REQUIRE_PTR(done);
-    if (n <= 0 || n_steps <= 0) return mg::set_error(MG_ERR_BAD_SIZE, "n_envs=%d n_steps=%d", n, n_steps);
-    if (int rc = check_state(state)) return rc;
-    QuadK k;
-    if (int rc = fold_config(cfg, &k)) return rc;
-    if (ar != nullptr) {
-        k.auto_reset = 1;
-        for (int i = 0; i < 3; ++i) { k.init_v_base[i] = ar->init_velocity[i]; k.init_w_base[i] = ar->init_angular_velocity[i]; }
-        k.init_v_noisy = ar->init_velocity_noisy;
-        k.init_w_noisy = ar->init_angular_velocity_noisy;
-        k.seed = ar->seed;
-        k.step_index = ar->step_index;
-        k.env_id_base = ar->env_id_base;
-    }
-    StepIO io{action, obs, reward, reward64, done, failed};
-    const int grid = (n + BLOCK - 1) / BLOCK;
-    if (config_is_simple(cfg) && cfg->task != MG_QUADROTOR_TASK_VELOCITY_CONTROL)
-        hipLaunchKernelGGL(quadrotor_step_kernel<true>, dim3(grid), dim3(BLOCK), 0, (hipStream_t)stream, k, *state,
-                           io, n, n_steps);
-    else
-        hipLaunchKernelGGL(quadrotor_step_kernel<false>, dim3(grid), dim3(BLOCK), 0, (hipStream_t)stream, k, *state,
-                           io, n, n_steps);
-    return mg::check_launch("quadrotor_step_kernel");
+    Plan p;
+    if (int rc = make_plan(&p, cfg, ar, n, state)) return rc;
+    return launch_plan(&p, n_steps, action, obs, reward, reward64, done, failed, stream);
 }
 
 }  // namespace
@@ -901,6 +948,7 @@ extern "C" int mg_quadrotor_velocity_targets(const mg_quadrotor_config *cfg, int
     if (nt <= 0) return mg::set_error(MG_ERR_BAD_SIZE, "nt=%d", nt);
     QuadK k;
     if (int rc = fold_config(cfg, &k, false)) return rc;
+    mg::DeviceGuard guard(mg::device_of(targets_d));
     hipLaunchKernelGGL(quadrotor_targets_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, k, nt, actions_d, targets_d);
     return mg::check_launch("quadrotor_targets_kernel");
 }
@@ -915,6 +963,7 @@ extern "C" int mg_quadrotor_reset(const mg_quadrotor_config *cfg, int32_t n, con
     QuadK k;
     if (int rc = fold_config(cfg, &k)) return rc;
     const int grid = (n + BLOCK - 1) / BLOCK;
+    mg::DeviceGuard guard(mg::device_of(state->pos));
     hipLaunchKernelGGL(quadrotor_reset_kernel, dim3(grid), dim3(BLOCK), 0, (hipStream_t)stream, k, *state, mask,
                        init_vel, init_omega, obs, n);
     return mg::check_launch("quadrotor_reset_kernel");
@@ -939,4 +988,21 @@ extern "C" int mg_quadrotor_rollout(const mg_quadrotor_config *cfg, int32_t n, i
                                     float *reward, double *reward64, uint8_t *done, uint8_t *failed,
                                     void *stream) {
     return launch_steps(cfg, n, n_steps, state, action, obs, reward, reward64, done, failed, stream);
+}
+
+extern "C" int mg_quadrotor_plan_init(mg_quadrotor_plan *plan, const mg_quadrotor_config *cfg,
+                                      const mg_quadrotor_autoreset *ar, int32_t n_envs,
+                                      const mg_quadrotor_state *state) {
+    MG_REQUIRE_PTR(plan);
+    Plan *p = reinterpret_cast<Plan *>(plan);
+    p->magic = 0;
+    return make_plan(p, cfg, ar, n_envs, state);
+}
+
+extern "C" int mg_quadrotor_plan_step(const mg_quadrotor_plan *plan, int32_t n_steps, const float *action, float *obs,
+                                      float *reward, double *reward64, uint8_t *done, uint8_t *failed, void *stream) {
+    MG_REQUIRE_PTR(plan);
+    const Plan *p = reinterpret_cast<const Plan *>(plan);
+    if (p->magic != PLAN_MAGIC) return mg::set_error(MG_ERR_BAD_CONFIG, "mg_quadrotor_plan is not initialised");
+    return launch_plan(p, n_steps, action, obs, reward, reward64, done, failed, stream);
 }

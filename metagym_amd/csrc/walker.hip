@@ -1336,6 +1336,7 @@ extern "C" int mg_walker_reset(const mg_walker_topology *tp, const mg_walker_mod
                                int32_t n, const mg_walker_state *st, const uint8_t *mask, const double *joint_noise,
                                float *obs, void *stream) {
     if (int rc = check_walker(tp, ms, prm, st, n)) return rc;
+    mg::DeviceGuard guard(mg::device_of(st->pos));
     hipLaunchKernelGGL(walker_reset_kernel, dim3((n + WK_BLOCK - 1) / WK_BLOCK), dim3(WK_BLOCK), 0, (hipStream_t)stream,
                        *tp, *ms, *prm, *st, n, mask, joint_noise, obs);
     return mg::check_launch("walker_reset_kernel");
@@ -1349,6 +1350,7 @@ extern "C" int mg_walker_step(const mg_walker_topology *tp, const mg_walker_mode
     MG_REQUIRE_PTR(obs);
     MG_REQUIRE_PTR(reward);
     MG_REQUIRE_PTR(done);
+    mg::DeviceGuard guard(mg::device_of(st->pos));
     if (prm->mapping == 0) {   // lane-per-env reference mapping (private-memory work set)
         hipLaunchKernelGGL(walker_step_kernel, dim3((n + WK_BLOCK - 1) / WK_BLOCK), dim3(WK_BLOCK), 0,
                            (hipStream_t)stream, *tp, *ms, *prm, *st, n, action, obs, reward, rewards5, done);

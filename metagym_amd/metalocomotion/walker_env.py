@@ -7,9 +7,12 @@ Same surface: `sample_task(task_type)` returns a variant file name, `set_task(ta
 reward, done and `info = {"rewards": [N,5], "steps": [N]}`. Batched extensions: `set_task` also takes
 a list of task files (or parsed `Model`s) plus `task_ids`, so env e can run its own body variant.
 
-The reference ships 386 MJCF variants per robot under metalocomotion/envs/assets/; this package does
-not copy them. Point `assets_dir` (or $METAGYM_LOCOMOTION_ASSETS) at that directory, or pass
-`Model` objects (metagym_amd.metalocomotion.load_mjcf).
+The reference ships 385 MJCF files per robot under metalocomotion/envs/assets/; this package does not copy
+them, it regenerates the same 384 body variants from their generator patterns (`variants.py`), so
+`sample_task('TRAIN' | 'TEST' | 'OOD')` returns the reference's file names and `set_task` accepts them on a
+machine without the reference tree. `assets_dir` (or $METAGYM_LOCOMOTION_ASSETS) may still point at a directory
+of MJCF files (the reference's, or your own robots of the same topology); `Model` objects
+(metagym_amd.metalocomotion.load_mjcf) are accepted too.
 
 Physics parity with the reference is UNPINNED (the reference calls PyBullet); see DESIGN.md §3.5.
 """
@@ -21,6 +24,7 @@ import torch
 
 from .. import _lib
 from ..spaces import Box
+from . import variants
 from .mjcf import Model, load_mjcf
 
 
@@ -68,6 +72,10 @@ class WalkerBatchEnv(object):
                     self.tst_tasks.append(f)
                 if f.find(self.variant_prefix + "_var_ood") == 0:
                     self.ood_tasks.append(f)
+        else:                                        # no asset directory: the same names, regenerated (variants.py)
+            self.tra_tasks = variants.task_names(self.variant_prefix, "TRAIN")
+            self.tst_tasks = variants.task_names(self.variant_prefix, "TEST")
+            self.ood_tasks = variants.task_names(self.variant_prefix, "OOD")
         self._robot_set = False
         self.np_random = np.random.RandomState()
         # fused auto-reset: finished envs restart inside the step launch with device-side (Philox) joint
@@ -93,6 +101,10 @@ class WalkerBatchEnv(object):
         if isinstance(t, Model):
             return t
         path = t if os.path.isabs(t) or self._robot_assets() is None else os.path.join(self._robot_assets(), t)
+        if not os.path.exists(path):
+            m = variants.model_from_task_name(t)     # one of the reference's file names: regenerate that variant
+            if m is not None:
+                return m
         return load_mjcf(path, foot_names=self.foot_list)
 
     def set_task(self, task_file, task_ids=None):

@@ -3,11 +3,9 @@
 `TaskConfig` has exactly the reference's fields (maze_task.py:15-17) so task objects are
 interchangeable: a TaskConfig sampled by the reference can be handed to these envs and vice versa.
 
-`MazeTaskSampler` is a from-scratch generator with the same knobs and the same statistical
-structure (odd-cell lattice, spanning-tree corridors, optional loop digging down to `crowd_ratio`,
-random wall textures, sparse food) driven by a private numpy RandomState; it does NOT reproduce the
-reference's python-`random` stream (task generation stays host-side and is not
-part of the parity contract — parity tests feed both sides the same TaskConfig).
+`MazeTaskSampler` is the reference's generator (maze_task.py:41-190) restated: for the same python-`random`
+and `numpy.random` streams it returns the reference's task, field for field (see `sample_task`); the same
+tasks can be drawn on the GPU with `sample_tasks_device` (`mg_maze_sample_tasks`).
 
 Textures: the reference ships seven 64x64 PNGs. `MazeTaskManager(texture_dir=...)` loads any
 directory with the same naming rule (file names containing 'ground' / 'wall' / 'ceil', sorted);
@@ -113,7 +111,6 @@ class MazeTaskManager(object):
             g, c = _procedural_textures()
         self.set_textures(g, c)
         self.verbose = verbose
-        self._rs = np.random.RandomState()
 
     def set_textures(self, grounds_u8, ceil_u8):
         """grounds [n_texts, S, S, 3] uint8 (index 0 = floor), ceil [S, S, 3] uint8."""
@@ -137,77 +134,115 @@ class MazeTaskManager(object):
                (c[..., 0] | (c[..., 1] << 8) | (c[..., 2] << 16)).astype(np.uint32)
 
     def seed(self, seed=None):
-        self._rs = np.random.RandomState(seed)
+        """Seed BOTH global streams the generator draws from, like a reference user would
+        (`random.seed(seed); numpy.random.seed(seed)`)."""
+        import random as _pyrandom
+        _pyrandom.seed(seed)
+        np.random.seed(seed)
 
     def sample_task(self, n=15, allow_loops=True, cell_size=2.0, wall_height=3.2, agent_height=1.6,
                     step_reward=-0.01, goal_reward=None, food_reward=0.50, initial_life=1.0, max_life=2.0,
                     food_density=0.010, food_interval=100, crowd_ratio=0.0, seed=None):
-        """Same signature as the reference sampler (maze_task.py:41-54) plus `seed`."""
+        """The reference's task generator (`MazeTaskManager.sample_task`, maze_task.py:41-190), same signature
+        plus `seed`, and the same task for the same random streams:
+
+          * `seed=None`: draws from python's global `random` and `numpy.random`, exactly like the reference —
+            `random.seed(s); numpy.random.seed(s); MazeTaskSampler(...)` returns the task the reference returns;
+          * `seed=s`: the same task from private generators (`random.Random(s)`, `numpy.random.RandomState(s)`),
+            leaving the global streams alone. `sample_tasks_device(..., seed=s)` row 0 is this task, drawn on
+            the GPU.
+
+        The algorithm is the reference's: texture ids for every cell (:61), corridors on the odd lattice (:64-66),
+        start and goal from python's generator (:68-83), then walls are dug one at a time — the wall list is
+        re-shuffled, walked until a wall qualifies (it joins two different components; or, with loops allowed, it
+        closes a cycle next to a component boundary, or a coin flip once everything is connected) and removed,
+        merging the components it touches — until one component is left and, with `allow_loops`, the interior wall
+        share is down to `crowd_ratio` (:103-154); passages get texture 0 (:157-160); food is drawn and thinned by
+        10 % sweeps until its sum fits `food_density` (:163-169). The draw order of both streams is part of the
+        contract; tests/test_maze_host_sampler.py checks 96 tasks recorded from the unmodified reference."""
+        import math
+        import random as _pyrandom
         assert n > 6, "Minimum required cells are 7"
         assert n % 2 != 0, "Cell Numbers can only be odd"
-        rs = self._rs if seed is None else np.random.RandomState(seed)
-        m = (n - 1) // 2                                   # corridor lattice is m x m odd cells
-        walls = np.ones((n, n), dtype=np.int32)
-        walls[1::2, 1::2] = 0
-        texts = rs.randint(1, self.n_texts, size=(n, n))
+        py = _pyrandom if seed is None else _pyrandom.Random(seed)
+        npr = np.random if seed is None else np.random.RandomState(seed)
 
-        # start / goal on odd cells, goal at least 0.45 n away when possible
-        sx, sy = (int(v) * 2 + 1 for v in rs.randint(0, m, size=2))
-        goal = (n - 2, n - 2)
-        for _ in range(m * m):
-            ex, ey = (int(v) * 2 + 1 for v in rs.randint(0, m, size=2))
-            if np.sqrt((ex - sx) ** 2 + (ey - sy) ** 2) > 0.45 * n:
-                goal = (ex, ey)
-                break
-
-        # spanning tree over the odd-cell lattice (randomised Kruskal with union-find)
-        parent = list(range(m * m))
-
-        def find(a):
-            while parent[a] != a:
-                parent[a] = parent[parent[a]]
-                a = parent[a]
-            return a
-
-        edges = [(i, j, 0) for i in range(m - 1) for j in range(m)] + [(i, j, 1) for i in range(m) for j in range(m - 1)]
-        order = rs.permutation(len(edges))
-        unused = []
-        for k in order:
-            i, j, d = edges[k]
-            a, b = i * m + j, (i + 1) * m + j if d == 0 else i * m + j + 1
-            ra, rb = find(a), find(b)
-            wall = (2 * i + 2, 2 * j + 1) if d == 0 else (2 * i + 1, 2 * j + 2)
-            if ra != rb:
-                parent[ra] = rb
-                walls[wall] = 0
-            else:
-                unused.append(wall)
-        if allow_loops:
-            # dig further walls (lattice edges first, then pillars) until the interior wall share
-            # drops to crowd_ratio; crowd_ratio=0 yields the reference's open room
-            interior = (n - 2) * (n - 2)
-            pillars = [(i, j) for i in range(2, n - 1, 2) for j in range(2, n - 1, 2)]
-            rs.shuffle(pillars)
-            for wall in unused + pillars:
-                if walls[1:-1, 1:-1].sum() <= interior * crowd_ratio:
+        walls = np.ones((n, n), dtype="int32")
+        texts = npr.randint(1, self.n_texts, size=(n, n))
+        walls[1:n:2, 1:n:2] = 0
+        half = (n - 1) // 2
+        start = (py.randint(0, half - 1) * 2 + 1, py.randint(0, half - 1) * 2 + 1)
+        goal, far_enough = (n - 2, n - 2), 0.45 * n
+        for _row in range(half):               # a hit only ends the inner sweep (the reference's `break`), so up
+            for _col in range(half):           # to `half` goals are drawn and the last one found is kept
+                cand = (py.randint(0, half - 1) * 2 + 1, py.randint(0, half - 1) * 2 + 1)
+                if math.sqrt((cand[0] - start[0]) ** 2 + (cand[1] - start[1]) ** 2) > far_enough:
+                    goal = cand
                     break
-                walls[wall] = 0
-        texts[1:-1, 1:-1][walls[1:-1, 1:-1] < 1] = 0        # corridors get the ground texture
+
+        # component label of every open interior cell (row-major numbering), and the diggable walls in the same order
+        label = {}
+        candidates = []
+        for i in range(1, n - 1):
+            for j in range(1, n - 1):
+                if walls[i, j] > 0:
+                    candidates.append((i, j))
+                else:
+                    label[i, j] = len(label)
+        n_components = len(label)
+        walls_left = len(candidates)
+        wall_budget = (n - 2) * (n - 2) * crowd_ratio
+        while n_components > 1 or (allow_loops and walls_left > wall_budget):
+            order = list(candidates)
+            py.shuffle(order)
+            pick, keep, absorbed = None, -1, []
+            for pick in order:
+                keep, absorbed, seen, twice = -1, [], {}, False
+                i, j = pick
+                for a, b in ((i - 1, j), (i + 1, j), (i, j - 1), (i, j + 1)):
+                    if 0 < a < n and 0 < b < n and walls[a, b] < 1:
+                        c = label[a, b]
+                        seen[c] = seen.get(c, 0) + 1
+                        twice = twice or seen[c] > 1
+                        if keep < 0 or c < keep:         # the smallest label survives a merge
+                            if keep >= 0 and keep not in absorbed:
+                                absorbed.append(keep)
+                            keep = c
+                        elif c != keep and c not in absorbed:
+                            absorbed.append(c)
+                if absorbed and (not twice or allow_loops):
+                    break
+                if allow_loops and n_components < 2 and py.random() < 0.2:
+                    break
+            if keep < 0:
+                continue
+            walls[pick] = 0
+            label[pick] = keep
+            candidates.remove(pick)
+            walls_left -= 1
+            for c in absorbed:
+                for cell, lab in label.items():
+                    if lab == c:
+                        label[cell] = keep
+                n_components -= 1
+
+        inner = texts[1:n - 1, 1:n - 1]
+        inner[walls[1:n - 1, 1:n - 1] < 1] = 0
 
         assert step_reward < 0, "step_reward must be < 0"
         def_goal_reward = -np.sqrt(n) * n * step_reward if goal_reward is None else goal_reward
         assert def_goal_reward > 0, "goal reward must be > 0"
 
-        food = np.clip(rs.rand(n, n) * food_reward, 0.10, food_reward) * (1.0 - walls)
-        exp_food = (n - 1) * (n - 1) * food_density
-        while food.sum() > exp_food:
-            food = food * (rs.rand(n, n) < 0.90).astype("float32")
+        food = np.clip(npr.rand(n, n) * food_reward, 0.10, food_reward)
+        food *= 1.0 - walls
+        expected = (n - 1) * (n - 1) * food_density
+        while np.sum(food) > expected:
+            food *= (npr.rand(n, n) < 0.90).astype("float32")
         interval = food_interval * (food > 1.0e-3).astype("int32")
-        return TaskConfig(start=(sx, sy), goal=goal, cell_walls=walls, cell_texts=texts, cell_size=cell_size,
+        return TaskConfig(start=start, goal=goal, cell_walls=walls, cell_texts=texts, cell_size=cell_size,
                           step_reward=step_reward, goal_reward=def_goal_reward, wall_height=wall_height,
                           agent_height=agent_height, initial_life=initial_life, max_life=max_life,
                           food_rewards=food, food_interval=interval)
-
 
     def sample_tasks_device(self, num_tasks, device="cuda", seed=0, seeds=None, n=15, allow_loops=True,
                             cell_size=2.0, wall_height=3.2, agent_height=1.6, step_reward=-0.01, goal_reward=None,

@@ -13,6 +13,7 @@ Differences forced by batching (documented in DESIGN.md):
     `np.random.seed(seed); env.reset()` of the reference exactly.
   * `info` values are float32 views of the observation (the reference hands back numpy scalars).
 """
+import ctypes as C
 import json
 import os
 from collections.abc import Mapping
@@ -114,7 +115,7 @@ class Quadrotor(object):
 
     def __init__(self, num_envs=1, device="cuda", dt=0.01, nt=1000, seed=0, task="no_collision",
                  map_file=None, simulator_conf=None, healthy_reward=1.0, auto_reset=False, env_id_base=0,
-                 **kwargs):
+                 exact_reward=True, **kwargs):
         assert task in TASKS, "Invalid task setting"
         self._lib = _lib.load()
         self.num_envs = int(num_envs)
@@ -139,13 +140,17 @@ class Quadrotor(object):
         self.rot = torch.zeros(9, N, dtype=torch.float32, device=dev)
         self.rot[0::4] = 1.0
         self.ct = torch.zeros(N, dtype=torch.int32, device=dev)
-        self._state = _lib.QuadrotorState(*[_lib.ptr(t) for t in
-                                            (self.pos, self.vel, self.omega, self.propw, self.rot, self.ct)])
+        # auto-resets each env has gone through = Philox counter of its next one (uint32 bit pattern; not a
+        # reference quantity, see mg_quadrotor_autoreset)
+        self.episode = torch.zeros(N, dtype=torch.int32, device=dev)
+        self._state = _lib.QuadrotorState(*[_lib.ptr(t) for t in (self.pos, self.vel, self.omega, self.propw,
+                                                                  self.rot, self.ct, self.episode)])
         # --- outputs ------------------------------------------------------------------------
         self.obs_dim = 19 if task == "velocity_control" else 16          # env.py:87-95
         self._obs = torch.zeros(N, self.obs_dim, dtype=torch.float32, device=dev)
         self._reward = torch.zeros(N, dtype=torch.float32, device=dev)
-        self._reward64 = torch.zeros(N, dtype=torch.float64, device=dev)
+        # the reference returns a python float (f64); the exact copy costs 8 B/env of stores per step
+        self._reward64 = torch.zeros(N, dtype=torch.float64, device=dev) if exact_reward else None
         self._done = torch.zeros(N, dtype=torch.bool, device=dev)    # kernel writes 0/1 bytes
         self._failed = torch.zeros(N, dtype=torch.uint8, device=dev)
         self._out_ptrs = [_lib.ptr(t) for t in (self._obs, self._reward, self._reward64, self._done, self._failed)]
@@ -197,7 +202,6 @@ class Quadrotor(object):
         self.seed_value = seed
         # fused auto-reset: done envs restart inside the step launch, noise from device-side Philox
         self.auto_reset = bool(auto_reset)
-        self.global_step = 0
         self._ar = _lib.QuadrotorAutoReset()
         cv = self.sim_config.get("init_velocity")
         cw = self.sim_config.get("init_angular_velocity") if cv is not None else None
@@ -208,6 +212,15 @@ class Quadrotor(object):
         self._ar.init_angular_velocity_noisy = float(cw["noisy"]) if cw else 0.0
         self._ar.seed = int(seed) & 0xFFFFFFFFFFFFFFFF
         self._ar.env_id_base = int(env_id_base)   # global id of env 0 when this batch is one shard of a larger job
+        # cfg is final: fold it once (mg_quadrotor_plan_init); step()/rollout() then only enqueue the launch
+        self._plan = _lib.QuadrotorPlan()
+        with torch.cuda.device(dev):
+            rc = self._lib.mg_quadrotor_plan_init(self._plan, self._cfg, self._ar if self.auto_reset else None, N,
+                                                  self._state)
+        _lib.check(rc, "mg_quadrotor_plan_init")
+        self._plan_ref = C.byref(self._plan)
+        self._plan_step = self._lib.mg_quadrotor_plan_step
+        self._action_shape = (N, 4)
 
     # ------------------------------------------------------------------ reference API
     def reset(self, mask=None, seed=None, init_velocity=None, init_angular_velocity=None):
@@ -252,19 +265,16 @@ class Quadrotor(object):
         if not (isinstance(a, torch.Tensor) and a.dtype == torch.float32 and a.device == self.device
                 and a.is_contiguous()):
             a = torch.as_tensor(action, dtype=torch.float32, device=self.device).contiguous()
-        assert a.shape == (self.num_envs, 4), "action must be [num_envs, 4]"
-        stream = _lib.current_stream(self.device)
+        if a.shape != self._action_shape:
+            raise ValueError("action must be [num_envs, 4], got %s" % (tuple(a.shape),))
+        # one ctypes call per step and nothing else on the host: the constants were folded at construction
+        # (mg_quadrotor_plan_init), the library selects the state's device itself, and no argument depends on
+        # a step counter — so this launch can also be captured into a hipGraph as it stands
         o = self._out_ptrs
-        if self.auto_reset:
-            self._ar.step_index = self.global_step
-            rc = self._lib.mg_quadrotor_step_autoreset(self._cfg, self.num_envs, 1, self._state, self._ar,
-                                                       a.data_ptr(), o[0], o[1], o[2], o[3], o[4], stream)
-        else:
-            rc = self._lib.mg_quadrotor_step(self._cfg, self.num_envs, self._state, a.data_ptr(),
-                                             o[0], o[1], o[2], o[3], o[4], stream)
+        rc = self._plan_step(self._plan_ref, 1, a.data_ptr(), o[0], o[1], o[2], o[3], o[4],
+                             torch.cuda.current_stream(self.device).cuda_stream)
         if rc != 0:
-            _lib.check(rc, "mg_quadrotor_step")
-        self.global_step += 1
+            _lib.check(rc, "mg_quadrotor_plan_step")
         return self._obs, self._reward, self._done, self._info_obj
 
     def rollout(self, actions):
@@ -279,17 +289,9 @@ class Quadrotor(object):
         rew64 = torch.empty(T, N, dtype=torch.float64, device=dev)
         done = torch.empty(T, N, dtype=torch.bool, device=dev)
         failed = torch.empty(T, N, dtype=torch.uint8, device=dev)
-        if self.auto_reset:
-            self._ar.step_index = self.global_step
-            rc = self._lib.mg_quadrotor_step_autoreset(self._cfg, N, T, self._state, self._ar, _lib.ptr(a),
-                                                       _lib.ptr(obs), _lib.ptr(rew), _lib.ptr(rew64), _lib.ptr(done),
-                                                       _lib.ptr(failed), _lib.current_stream(dev))
-        else:
-            rc = self._lib.mg_quadrotor_rollout(self._cfg, N, T, self._state, _lib.ptr(a), _lib.ptr(obs),
-                                                _lib.ptr(rew), _lib.ptr(rew64), _lib.ptr(done), _lib.ptr(failed),
-                                                _lib.current_stream(dev))
-        _lib.check(rc, "mg_quadrotor_rollout")
-        self.global_step += T
+        rc = self._plan_step(self._plan_ref, T, _lib.ptr(a), _lib.ptr(obs), _lib.ptr(rew), _lib.ptr(rew64),
+                             _lib.ptr(done), _lib.ptr(failed), _lib.current_stream(dev))
+        _lib.check(rc, "mg_quadrotor_plan_step")
         self._last_rollout_reward64 = rew64
         return obs, rew, done, failed
 
@@ -305,12 +307,26 @@ class Quadrotor(object):
         """float64 copy of the last step's reward (the reference returns a python float)."""
         return self._reward64
 
+    _STATE_KEYS = ("pos", "vel", "omega", "propw", "rot", "ct", "episode")
+
     def state_dict(self):
-        return {k: getattr(self, k).clone() for k in ("pos", "vel", "omega", "propw", "rot", "ct")}
+        """Everything a bit-identical continuation needs: the simulator arrays, the per-env auto-reset counters
+        (the Philox stream position of each env) and the host RandomState behind reset()."""
+        sd = {k: getattr(self, k).clone() for k in self._STATE_KEYS}
+        sd["np_random"] = self.np_random.get_state()
+        return sd
 
     def load_state_dict(self, sd):
-        for k in ("pos", "vel", "omega", "propw", "rot", "ct"):
-            getattr(self, k).copy_(torch.as_tensor(sd[k]).to(getattr(self, k).dtype))
+        for k in self._STATE_KEYS:
+            if k == "episode" and k not in sd:
+                continue                           # checkpoints of ABI 1 carried no counters
+            dst = getattr(self, k)
+            src = torch.as_tensor(sd[k])
+            if tuple(src.shape) != tuple(dst.shape):
+                raise ValueError("state_dict[%r] has shape %s, this env holds %s" % (k, tuple(src.shape), tuple(dst.shape)))
+            dst.copy_(src.to(dst.dtype))
+        if "np_random" in sd:
+            self.np_random.set_state(sd["np_random"])
 
     @staticmethod
     def load_map(map_file):

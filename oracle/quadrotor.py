@@ -48,6 +48,21 @@ class State(C.Structure):
     ]
 
 
+class AutoReset(C.Structure):
+    """qo_autoreset — same fields as the product's mg_quadrotor_autoreset"""
+    _fields_ = [("init_velocity", C.c_float * 3), ("init_angular_velocity", C.c_float * 3),
+                ("init_velocity_noisy", C.c_double), ("init_angular_velocity_noisy", C.c_double),
+                ("seed", C.c_uint64), ("env_id_base", C.c_uint64)]
+
+
+def default_autoreset(seed=0, env_id_base=0):
+    """config.json: init_velocity / init_angular_velocity = 0 +- noisy 2.0 / 5.0"""
+    ar = AutoReset()
+    ar.init_velocity_noisy, ar.init_angular_velocity_noisy = 2.0, 5.0
+    ar.seed, ar.env_id_base = seed, env_id_base
+    return ar
+
+
 _lib = None
 
 
@@ -145,6 +160,37 @@ def batch_env_step(consts, states, ct, actions):
                             actions.ctypes.data_as(C.c_void_p), obs.ctypes.data_as(C.c_void_p),
                             reward.ctypes.data_as(C.c_void_p), done.ctypes.data_as(C.c_void_p),
                             failed.ctypes.data_as(C.c_void_p))
+    return obs, reward, done, failed
+
+
+def philox4x32_10(ctr, key):
+    c = (C.c_uint32 * 4)(*[int(x) & 0xFFFFFFFF for x in ctr])
+    k = (C.c_uint32 * 2)(*[int(x) & 0xFFFFFFFF for x in key])
+    out = (C.c_uint32 * 4)()
+    lib().qo_philox4x32_10(c, k, out)
+    return [int(x) for x in out]
+
+
+def reset_noise(ar, gid, episode):
+    """(velocity[3], body rate[3]) of the `episode`-th auto-reset of global env `gid`."""
+    v, w = (C.c_double * 3)(), (C.c_double * 3)()
+    lib().qo_reset_noise(C.byref(ar), C.c_uint64(int(gid)), C.c_uint32(int(episode)), v, w)
+    return np.array(v[:]), np.array(w[:])
+
+
+def batch_env_step_autoreset(consts, ar, states, ct, episode, actions):
+    """batch_env_step with the fused reset. episode: uint32[n], updated in place."""
+    n = len(states)
+    actions = np.ascontiguousarray(actions, np.float32)
+    assert actions.shape == (n, 4) and ct.dtype == np.int32 and episode.dtype == np.uint32
+    obs = np.zeros((n, 16), np.float32)
+    reward = np.zeros(n, np.float64)
+    done = np.zeros(n, np.int32)
+    failed = np.zeros(n, np.int32)
+    lib().qo_batch_env_step_autoreset(C.byref(consts), C.byref(ar), C.c_int(n), states, ct.ctypes.data_as(C.c_void_p),
+                                      episode.ctypes.data_as(C.c_void_p), actions.ctypes.data_as(C.c_void_p),
+                                      obs.ctypes.data_as(C.c_void_p), reward.ctypes.data_as(C.c_void_p),
+                                      done.ctypes.data_as(C.c_void_p), failed.ctypes.data_as(C.c_void_p))
     return obs, reward, done, failed
 
 

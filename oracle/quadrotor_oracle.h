@@ -57,6 +57,20 @@ int qo_env_step_velocity(const qo_consts *c, qo_state *s, int *ct, const float a
                          double *reward, int *done);
 long qo_batch_run(const qo_consts *c, int n, qo_state *states, const qo_state *init, int *ct,
                   const float *actions, int n_batches, int iters);
+/* ---- fused auto-reset (not a reference operation: restates metagym_amd's device-side reset, whose
+ * zero-state / noise formula follows QuadrotorSim.reset quadrotorsim.py:239-258) ------------------------ */
+typedef struct {
+    float init_velocity[3], init_angular_velocity[3];
+    double init_velocity_noisy, init_angular_velocity_noisy;
+    uint64_t seed, env_id_base;
+} qo_autoreset;
+
+void qo_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);
+void qo_reset_noise(const qo_autoreset *ar, uint64_t gid, uint32_t episode, double vel[3], double omega[3]);
+void qo_reset_random(const qo_autoreset *ar, qo_state *s, uint64_t gid, uint32_t episode);
+void qo_batch_env_step_autoreset(const qo_consts *c, const qo_autoreset *ar, int n, qo_state *states, int *ct,
+                                 uint32_t *episode, const float *actions, float *obs, double *reward, int *done,
+                                 int *failed);
 size_t qo_sizeof_state(void);
 size_t qo_sizeof_consts(void);
 

@@ -55,6 +55,19 @@ def test_argument_errors_are_codes_not_crashes():
     rc = lib.mg_quadrotor_step(cfg, 0, st, None, None, None, None, None, None, None)
     assert rc == -1001 and b"NULL" in lib.mg_last_error()
     assert lib.mg_quadrotor_default_config(None) == -1001
+    # a plan is validated when it is made and when it is used
+    plan = _lib.QuadrotorPlan()
+    assert lib.mg_quadrotor_plan_step(plan, 1, None, None, None, None, None, None, None) == -1003   # not initialised
+    assert lib.mg_quadrotor_plan_init(plan, cfg, None, 4, st) == -1001                              # NULL state arrays
+    import ctypes as C
+    fake = C.create_string_buffer(64)
+    for name, _ in _lib.QuadrotorState._fields_:
+        setattr(st, name, C.addressof(fake) if name != "episode" else None)
+    assert lib.mg_quadrotor_plan_init(plan, cfg, None, 4, st) == 0            # host-only: folds cfg, launches nothing
+    ar = _lib.QuadrotorAutoReset()
+    assert lib.mg_quadrotor_plan_init(plan, cfg, ar, 4, st) == -1001 and b"episode" in lib.mg_last_error()
+    cfg.precision = 1.0                                                        # > dt (quadrotorsim.py:299-300)
+    assert lib.mg_quadrotor_plan_init(plan, cfg, None, 4, st) == -1003
 
 
 def test_no_cpu_fallback():
@@ -92,6 +105,8 @@ def test_integration_stub_structs_match_the_abi():
     for name, _ in ns["Cfg"]._fields_:
         assert getattr(ns["Cfg"], name).offset == getattr(_lib.QuadrotorConfig, name).offset, name
     assert C.sizeof(ns["State"]) == C.sizeof(_lib.QuadrotorState)
+    assert [f[0] for f in ns["State"]._fields_] == [f[0] for f in _lib.QuadrotorState._fields_]
+    assert "mg_abi_version() == %d" % _lib.ABI_VERSION in text
 
 
 def test_walker_wave_mapping_rejects_topologies_its_lds_scratch_cannot_hold():

@@ -1,6 +1,10 @@
-"""N>1 path of bench.py on CPU: two gloo ranks, each owning an env shard, agree on the whole-job
-number exactly the way bench.py computes it (max-over-ranks time, sum of shard sizes), and the
-shard-invariant reset noise keys give identical draws regardless of world size."""
+"""N>1 path of bench.py on CPU: two gloo ranks build their shards exactly the way bench.py does
+(`bench.shard_plan`: global env ids, the `env_id_base` of the fused auto-reset, reset / action seeds, the maze
+task of every env), STEP their shard, and agree on the whole-job number the way bench.py computes it
+(max-over-ranks time, sum of shard sizes — over gloo, the backend bench.py itself uses: the harness has no
+RCCL). The stepping runs on the CPU oracle's restatement of the fused-auto-reset launch (the HIP library needs
+a GPU), which consumes the same plan fields the GPU env does: the union of the two ranks' trajectories must be
+the single-rank job, bit for bit."""
 import os
 import socket
 import sys
@@ -12,6 +16,8 @@ import torch.multiprocessing as mp
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
+N_PER_RANK, NT, T_STEPS, JOB_SEED = 48, 5, 13, 1000
+
 
 def _free_port():
     s = socket.socket()
@@ -21,34 +27,86 @@ def _free_port():
     return p
 
 
+def _initial_noise(env_ids):
+    """Initial reset noise as a function of the GLOBAL env id (so that it does not depend on the sharding):
+    draw e of RandomState(JOB_SEED) in the reference's order (sign_v, mag_v, sign_w, mag_w), quadrotorsim.py:241-254."""
+    u = np.random.RandomState(JOB_SEED).random_sample((int(env_ids.max()) + 1, 4, 3))[env_ids]
+    vel = (2.0 * u[:, 1]) * ((u[:, 0] > 0.5) * 2 - 1.0)
+    om = (5.0 * u[:, 3]) * ((u[:, 2] > 0.5) * 2 - 1.0)
+    return vel, om
+
+
+def _actions(env_ids):
+    a = np.random.RandomState(JOB_SEED + 1).uniform(0.1, 15.0, (T_STEPS, 4 * N_PER_RANK, 4)).astype(np.float32)
+    return a[:, env_ids]
+
+
+def _run_shard(plan):
+    """Step one shard for T_STEPS with fused auto-reset; returns per-step obs / reward / done and the final counters."""
+    from oracle import quadrotor as qo
+    ids = plan["env_ids"]
+    n = len(ids)
+    vel, om = _initial_noise(ids)
+    st = qo.make_states(np.zeros((n, 3), np.float32), vel, om, np.zeros((n, 4), np.float32),
+                        np.tile(np.eye(3, dtype=np.float32).reshape(9), (n, 1)))
+    ct, ep = np.zeros(n, np.int32), np.zeros(n, np.uint32)
+    c = qo.default_consts(nt=NT)
+    ar = qo.default_autoreset(seed=plan["job_seed"], env_id_base=plan["env_id_base"])
+    acts = _actions(ids)
+    rec = []
+    for t in range(T_STEPS):
+        obs, rew, done, failed = qo.batch_env_step_autoreset(c, ar, st, ct, ep, acts[t])
+        rec.append((obs.copy(), rew.copy(), done.copy()))
+    s = qo.states_to_arrays(st)
+    return dict(obs=np.stack([r[0] for r in rec]), rew=np.stack([r[1] for r in rec]), done=np.stack([r[2] for r in rec]),
+                vel=s["vel"], omega=s["omega"], episode=ep)
+
+
 def _worker(rank, world, port, out):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     sys.path.insert(0, ROOT)
     import bench
     dist.init_process_group("gloo", rank=rank, world_size=world)
+    plan = bench.shard_plan(rank, world, N_PER_RANK, workload="mixed", job_seed=JOB_SEED)
+    res = _run_shard(plan)
     wall = 0.010 * (rank + 1)                       # rank 1 is the slow one
-    value, wall_max = bench.aggregate_throughput(dist, torch.device("cpu"), wall, envs_per_rank=1000, steps=7)
-    out[rank] = (value, wall_max)
+    value, wall_max = bench.aggregate_throughput(dist, wall, envs_per_rank=2 * N_PER_RANK, steps=T_STEPS)
+    out[rank] = dict(value=value, wall_max=wall_max, res=res, env_ids=plan["env_ids"], base=plan["env_id_base"],
+                     maze_task_ids=plan["maze_task_ids"], reset_seed=plan["reset_seed"], action_seed=plan["action_seed"])
     dist.barrier()
     dist.destroy_process_group()
 
 
-def test_two_rank_aggregation_gloo():
+def test_two_ranks_build_and_step_their_shards_gloo():
     world, port = 2, _free_port()
     mgr = mp.Manager()
     out = mgr.dict()
     mp.spawn(_worker, args=(world, port, out), nprocs=world, join=True)
     assert len(out) == 2
     for r in range(world):
-        value, wall_max = out[r]
-        assert abs(wall_max - 0.020) < 1e-12                       # max over ranks
-        assert abs(value - 2 * 1000 * 7 / 0.020) < 1e-6            # whole-job env-steps/s
+        assert abs(out[r]["wall_max"] - 0.020) < 1e-12                                    # max over ranks
+        assert abs(out[r]["value"] - 2 * (2 * N_PER_RANK) * T_STEPS / 0.020) < 1e-6       # whole-job env-steps/s
+    # the plans tile the job: contiguous global ids, bases, distinct host seeds, maze tasks by global id
+    ids = np.concatenate([out[r]["env_ids"] for r in range(world)])
+    assert np.array_equal(ids, np.arange(world * N_PER_RANK))
+    assert [out[r]["base"] for r in range(world)] == [0, N_PER_RANK]
+    assert len({out[r]["reset_seed"] for r in range(world)}) == world
+    assert len({out[r]["action_seed"] for r in range(world)}) == world
+    assert np.array_equal(np.concatenate([out[r]["maze_task_ids"] for r in range(world)]), ids % 64)
+    # the union of the two ranks' trajectories is the single-rank job (Philox keyed by global env id + episode)
+    sys.path.insert(0, ROOT)
+    import bench
+    single = _run_shard(bench.shard_plan(0, 1, world * N_PER_RANK, workload="mixed", job_seed=JOB_SEED))
+    for k, axis in (("obs", 1), ("rew", 1), ("done", 1), ("vel", 0), ("omega", 0), ("episode", 0)):
+        joined = np.concatenate([out[r]["res"][k] for r in range(world)], axis=axis)
+        assert np.array_equal(joined, single[k]), k
+    assert int(single["episode"].min()) == T_STEPS // NT                                   # episodes did restart
 
 
 def test_shard_invariant_env_ids():
     """bench.py gives rank r the global env ids [r*n, (r+1)*n): the union over ranks equals the
-    single-process id range, so the Philox reset keys (seed, global env id, step) are independent of
+    single-process id range, so the Philox reset keys (seed; global env id, episode) are independent of
     the number of shards."""
     sys.path.insert(0, ROOT)
     import bench
@@ -56,3 +114,6 @@ def test_shard_invariant_env_ids():
     one = bench.shard_env_ids(0, 1, 4 * n)
     four = np.concatenate([bench.shard_env_ids(r, 4, n) for r in range(4)])
     assert np.array_equal(one, four)
+    plans = [bench.shard_plan(r, 8, 65536, workload="mixed") for r in range(8)]
+    assert sum(len(p["env_ids"]) + len(p["maze_env_ids"]) for p in plans) == 1 << 20        # C5: 2^20 envs on 8 GPUs
+    assert [p["env_id_base"] for p in plans] == [r * 65536 for r in range(8)]

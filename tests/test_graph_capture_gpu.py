@@ -3,8 +3,10 @@
 The C ABI only enqueues kernels on the caller's stream — no allocation, no synchronisation, no host
 read-back — so a whole step (or several) can be captured into one hipGraph through torch's
 `torch.cuda.graph` and replayed with new actions written into the captured action buffer. Replays
-must be bit-identical to eager stepping. (With the fused auto-reset the Philox step counter is a
-kernel ARGUMENT and would be frozen by capture: capture is for auto_reset=False, or use rollout().)"""
+must be bit-identical to eager stepping. That includes the fused auto-reset: its noise is keyed by
+(seed, global env id, per-env episode counter held in device memory), so no launch argument changes
+from step to step and a captured launch replays correctly (ABI 1 passed a host step counter by value,
+which capture froze)."""
 import os
 
 import numpy as np
@@ -35,7 +37,7 @@ def test_quadrotor_step_graph_replay_is_bit_identical():
     eager, graphed = mk(), mk()
     eager.reset(seed=3)
     graphed.reset(seed=3)
-    sd0 = {k: v.clone() for k, v in graphed.state_dict().items()}
+    sd0 = graphed.state_dict()
     static_a = torch.zeros(K, n, 4, dtype=torch.float32, device="cuda:0")
     outs = []
 
@@ -57,7 +59,48 @@ def test_quadrotor_step_graph_replay_is_bit_identical():
             assert torch.equal(outs[k][0], obs) and torch.equal(outs[k][1], rew) and torch.equal(outs[k][2], done)
     se, sg = eager.state_dict(), graphed.state_dict()
     for k in se:
-        assert torch.equal(se[k], sg[k]), k
+        if torch.is_tensor(se[k]):
+            assert torch.equal(se[k], sg[k]), k
+
+
+def test_quadrotor_autoreset_graph_replay_is_bit_identical():
+    """The launch bench.py times, captured: K fused-auto-reset steps per graph, replayed T times with fresh
+    actions, episodes ending (ct == nt, nt = 7) inside and across replays."""
+    import metagym_amd
+    n, K, T, nt = 4096 + 5, 5, 6, 7
+    mk = lambda: metagym_amd.make("quadrotor-v0", num_envs=n, device="cuda:0", task="hovering_control", nt=nt,
+                                  auto_reset=True, seed=21)
+    eager, graphed = mk(), mk()
+    eager.reset(seed=3)
+    graphed.reset(seed=3)
+    sd0 = graphed.state_dict()
+    static_a = torch.zeros(K, n, 4, dtype=torch.float32, device="cuda:0")
+    outs = []
+
+    def k_steps():
+        outs.clear()
+        for k in range(K):
+            obs, rew, done, info = graphed.step(static_a[k])
+            outs.append((obs.clone(), rew.clone(), done.clone()))
+
+    g = _capture(k_steps)
+    graphed.load_state_dict(sd0)           # the warm-up and the capture pass advanced state and episode counters
+    rs = np.random.RandomState(0)
+    n_done = 0
+    for t in range(T):
+        a = torch.as_tensor(rs.uniform(0.1, 15.0, (K, n, 4)).astype(np.float32)).cuda()
+        static_a.copy_(a)
+        g.replay()
+        for k in range(K):
+            obs, rew, done, _ = eager.step(a[k])
+            assert torch.equal(outs[k][0], obs) and torch.equal(outs[k][1], rew) and torch.equal(outs[k][2], done)
+            n_done += int(done.sum())
+    assert n_done == n * (K * T // nt)
+    se, sg = eager.state_dict(), graphed.state_dict()
+    for k in se:
+        if torch.is_tensor(se[k]):
+            assert torch.equal(se[k], sg[k]), k
+    assert int(se["episode"].min()) == K * T // nt
 
 
 def test_maze2d_single_env_graph_replay_matches_eager_and_golden():

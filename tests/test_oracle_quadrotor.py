@@ -168,3 +168,96 @@ def test_oracle_velocity_control_matches_reference():
         assert np.array_equal(obs[nonang], g["obs"][t][nonang]), t
         assert r == g["reward"][t], t
     assert g["done"].sum() == 1
+
+
+# ---- fused auto-reset restatement (the checker of the launch bench.py times) -------------------------------
+
+RANDOM123_KAT = [   # Random123 kat_vectors, philox4x32 10: counter[4], key[2] -> output[4]
+    ([0x00000000] * 4, [0x00000000] * 2, [0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8]),
+    ([0xffffffff] * 4, [0xffffffff] * 2, [0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd]),
+    ([0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344], [0xa4093822, 0x299f31d0],
+     [0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1]),
+]
+
+
+def _philox_python(ctr, key):
+    """Philox4x32-10 from the paper's definition (Salmon et al., SC'11, section 3.3 / Random123 philox.h), written
+    independently of the C restatement: S-box = mulhilo by two constants, key bumped by Weyl constants per round."""
+    M0, M1, W0, W1, MASK = 0xD2511F53, 0xCD9E8D57, 0x9E3779B9, 0xBB67AE85, 0xFFFFFFFF
+    c, k = [int(x) for x in ctr], [int(x) for x in key]
+    for r in range(10):
+        hi0, lo0 = divmod(M0 * c[0], 1 << 32)
+        hi1, lo1 = divmod(M1 * c[2], 1 << 32)
+        c = [hi1 ^ c[1] ^ k[0], lo1, hi0 ^ c[3] ^ k[1], lo0]
+        k = [(k[0] + W0) & MASK, (k[1] + W1) & MASK]
+    return c
+
+
+def test_philox_known_answers():
+    for ctr, key, want in RANDOM123_KAT:
+        assert qo.philox4x32_10(ctr, key) == want
+        assert _philox_python(ctr, key) == want
+    rs = np.random.RandomState(0)
+    for _ in range(200):
+        v = [int(x) for x in rs.randint(0, 2 ** 32, 6, dtype=np.uint64)]
+        assert qo.philox4x32_10(v[:4], v[4:]) == _philox_python(v[:4], v[4:])
+
+
+def test_reset_noise_formula_and_stream_separation():
+    """base + noisy * U[0,1) * (+-1) per component (quadrotorsim.py:242-254) from the two Philox blocks keyed by
+    (seed; global env id, episode); distinct envs / episodes / seeds get distinct draws; statistics are uniform."""
+    seed = (0xABCD << 32) | 17
+    ar = qo.default_autoreset(seed=seed)
+    ar.init_velocity[:] = [0.5, -0.25, 0.125]
+    ar.init_angular_velocity[:] = [1.0, 2.0, -3.0]
+    for gid, ep in ((0, 0), (5, 3), ((1 << 40) + 9, 70000)):
+        w = []
+        for d in range(2):
+            w += _philox_python([gid & 0xFFFFFFFF, gid >> 32, ep, d], [seed & 0xFFFFFFFF, seed >> 32])
+        v, om = qo.reset_noise(ar, gid, ep)
+        for k in range(3):
+            sv = 1.0 if (w[6] >> k) & 1 else -1.0
+            sw = 1.0 if (w[6] >> (3 + k)) & 1 else -1.0
+            assert v[k] == float(np.float32(ar.init_velocity[k])) + (2.0 * (w[k] / 4294967296.0)) * sv
+            assert om[k] == float(np.float32(ar.init_angular_velocity[k])) + (5.0 * (w[3 + k] / 4294967296.0)) * sw
+    ar = qo.default_autoreset(seed=3)
+    draws = np.array([np.concatenate(qo.reset_noise(ar, g, e)) for g in range(200) for e in range(10)])
+    assert len({tuple(r) for r in draws}) == len(draws)
+    assert np.all(np.abs(draws[:, :3]) < 2.0) and np.all(np.abs(draws[:, 3:]) < 5.0)
+    assert abs(np.mean(draws > 0) - 0.5) < 0.02
+    assert abs(np.mean(np.abs(draws[:, :3])) - 1.0) < 0.05 and abs(np.mean(np.abs(draws[:, 3:])) - 2.5) < 0.1
+    other = np.concatenate(qo.reset_noise(qo.default_autoreset(seed=4), 0, 0))
+    assert not np.array_equal(other, draws[0])
+
+
+def test_autoreset_step_is_step_plus_reset():
+    """qo_batch_env_step_autoreset == qo_batch_env_step, then for the finished envs zero state + the drawn noise
+    (QuadrotorSim.reset quadrotorsim.py:239-258) and the observation of that state; ct stays as the done rule left it."""
+    n, nt = 64, 4
+    c = qo.default_consts(nt=nt)
+    ar = qo.default_autoreset(seed=11, env_id_base=1000)
+    rs = np.random.RandomState(0)
+    mk = lambda: qo.make_states(np.zeros((n, 3), np.float32), rs2.uniform(-1, 1, (n, 3)), rs2.uniform(-2, 2, (n, 3)),
+                                np.zeros((n, 4), np.float32), np.tile(np.eye(3, dtype=np.float32).reshape(9), (n, 1)))
+    rs2 = np.random.RandomState(1)
+    a_st = mk()
+    rs2 = np.random.RandomState(1)
+    b_st = mk()
+    a_ct, b_ct, ep = np.zeros(n, np.int32), np.zeros(n, np.int32), np.zeros(n, np.uint32)
+    for t in range(9):
+        act = rs.uniform(0.1, 15, (n, 4)).astype(np.float32)
+        obs_a, rew_a, done_a, fail_a = qo.batch_env_step_autoreset(c, ar, a_st, a_ct, ep, act)
+        ep_before = ep - done_a.astype(np.uint32)
+        obs_b, rew_b, done_b, fail_b = qo.batch_env_step(c, b_st, b_ct, act)
+        assert np.array_equal(rew_a, rew_b) and np.array_equal(done_a, done_b) and np.array_equal(a_ct, b_ct)
+        for e in np.nonzero(done_b)[0]:
+            v, w = qo.reset_noise(ar, 1000 + e, ep_before[e])
+            one = qo.make_states(np.zeros((1, 3), np.float32), v[None], w[None], np.zeros((1, 4), np.float32),
+                                 np.eye(3, dtype=np.float32).reshape(1, 9))
+            b_st[e] = one[0]
+            obs_b[e] = qo.observe(c, one)[0]
+        assert np.array_equal(obs_a, obs_b)
+        sa, sb = qo.states_to_arrays(a_st), qo.states_to_arrays(b_st)
+        for k in sa:
+            assert np.array_equal(sa[k], sb[k]), k
+    assert np.array_equal(ep, np.full(n, 2, np.uint32))

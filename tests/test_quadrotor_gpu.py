@@ -256,7 +256,7 @@ def test_full_size_properties_65536():
     perm = torch.randperm(n, device="cuda:0")
     c = _make_env(n)
     sd = a.state_dict()
-    c.load_state_dict({k: (v[..., perm] if v.dim() > 1 else v[perm]) for k, v in sd.items()})
+    c.load_state_dict({k: (v[..., perm] if v.dim() > 1 else v[perm]) for k, v in sd.items() if torch.is_tensor(v)})
     for t in range(T):
         oa, ra, da, _ = a.step(acts[t])
         ob, rb, db, _ = b.step(acts[t])
@@ -266,7 +266,7 @@ def test_full_size_properties_65536():
     assert torch.isfinite(oa).all()
     # spot-check 256 random envs of the big batch against the oracle, bit-exact state
     idx = np.random.RandomState(0).choice(n, 256, replace=False)
-    s0 = {k: v.cpu().numpy() for k, v in sd.items()}
+    s0 = {k: v.cpu().numpy() for k, v in sd.items() if torch.is_tensor(v)}
     st = qo.make_states(s0["pos"].T[idx], s0["vel"].T[idx], s0["omega"].T[idx], s0["propw"].T[idx], s0["rot"].T[idx])
     ct = np.zeros(256, np.int32)
     cc = qo.default_consts()
@@ -386,3 +386,194 @@ def test_velocity_control_matches_oracle_and_reference():
         _, _, d, _ = env2.step(torch.full((64, 4), 2.2))
         dones += int(d.sum())
     assert dones == 2 * 64                                         # ct == nt twice per env
+
+
+# ---- fused auto-reset: the launch bench.py times (mg_quadrotor_plan_step with an auto-reset block) ---------
+
+RANDOM123_KAT = [   # Random123 kat_vectors, philox4x32 10: counter[4], key[2] -> output[4]
+    ([0x00000000] * 4, [0x00000000] * 2, [0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8]),
+    ([0xffffffff] * 4, [0xffffffff] * 2, [0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd]),
+    ([0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344], [0xa4093822, 0x299f31d0],
+     [0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1]),
+]
+
+
+def test_device_philox_known_answers():
+    """The device generator behind every fused auto-reset against the published Random123 vectors, and against
+    the oracle's restatement on 4096 random (counter, key) pairs."""
+    from metagym_amd import _lib
+    lib = _lib.load()
+    rs = np.random.RandomState(0)
+    rnd = rs.randint(0, 2 ** 32, (4096, 6), dtype=np.uint64).astype(np.uint32)
+    inp = np.concatenate([np.array([c + k for c, k, _ in RANDOM123_KAT], np.uint32), rnd])
+    d_in = torch.as_tensor(inp.view(np.int32)).cuda()
+    d_out = torch.zeros(len(inp), 4, dtype=torch.int32, device="cuda:0")
+    rc = lib.mg_selftest_philox(_lib.ptr(d_in), _lib.ptr(d_out), len(inp), _lib.current_stream(d_out.device))
+    _lib.check(rc, "mg_selftest_philox")
+    out = d_out.cpu().numpy().view(np.uint32)
+    for i, (_, _, want) in enumerate(RANDOM123_KAT):
+        assert [int(x) for x in out[i]] == want, i
+    for i in range(3, len(inp), 97):
+        assert [int(x) for x in out[i]] == qo.philox4x32_10(inp[i, :4], inp[i, 4:]), i
+
+
+def _autoreset_env(n, nt, seed, env_id_base=0, task="hovering_control"):
+    import metagym_amd
+    return metagym_amd.make("quadrotor-v0", num_envs=n, device="cuda:0", task=task, nt=nt, auto_reset=True,
+                            seed=seed, env_id_base=env_id_base)
+
+
+def _hard_actions(rs, T, n):
+    """Mostly full-range voltages, with stretches of idle motors so that some envs drop through the floor
+    (collision episode ends) besides the ct == nt ones."""
+    a = rs.uniform(0.1, 15.0, (T, n, 4)).astype(np.float32)
+    idle = rs.random_sample((T, n)) < 0.25
+    a[idle] = 0.1
+    return a
+
+
+def test_autoreset_matches_oracle_bit_exact():
+    """(i) The benched launch against the oracle's restatement of it: 4 133 envs, >= 2 episode ends per env
+    (ct == nt twice, plus floor collisions), every step's obs / reward / done / failed, the final state and the
+    per-env episode counters; 64-bit seed and a non-zero env_id_base."""
+    n, nt, T = 4096 + 37, 23, 52
+    seed, base = (0xC0FFEE << 32) | 0x1234567, (1 << 33) + 12345
+    env = _autoreset_env(n, nt, seed, env_id_base=base)
+    env.reset(seed=3)
+    env.pos[2, ::3] = -4.97          # a third of the envs start 3 cm above the floor: collision episode ends
+    sd = {k: v.cpu().numpy() for k, v in env.state_dict().items() if torch.is_tensor(v)}
+    st = qo.make_states(sd["pos"].T, sd["vel"].T, sd["omega"].T, sd["propw"].T, sd["rot"].T)
+    ct = np.zeros(n, np.int32)
+    ep = np.zeros(n, np.uint32)
+    c = qo.default_consts(nt=nt)
+    ar = qo.default_autoreset(seed=seed, env_id_base=base)
+    acts = _hard_actions(np.random.RandomState(4), T, n)
+    ends = np.zeros(n, int)
+    collided = 0
+    for t in range(T):
+        obs, rew, done, info = env.step(torch.as_tensor(acts[t]))
+        ct_before = ct.copy()
+        out = qo.batch_env_step_autoreset(c, ar, st, ct, ep, acts[t])
+        gpu_out = (obs.cpu().numpy(), env.reward64.cpu().numpy(), done.cpu().numpy(), info["failed"].cpu().numpy())
+        _assert_matches_oracle(_get_state(env), gpu_out, st, ct, out)
+        ends += out[2]
+        collided += int(np.sum((out[2] != 0) & (ct_before + 1 != nt)))
+    assert ends.min() >= 2 and collided > 0
+    assert np.array_equal(env.episode.cpu().numpy().view(np.uint32), ep) and np.array_equal(ep, ends.astype(np.uint32))
+
+
+def test_autoreset_equals_explicit_masked_reset_with_the_drawn_noise():
+    """(ii) auto_reset=True  ==  a twin env stepped without it whose finished envs are reset by hand with
+    reset(mask=done, init_velocity=<the Philox draws of that env's k-th restart>): same observations (the reset
+    row is the first observation of the next episode), same state, same counters."""
+    import metagym_amd
+    n, nt, T, seed = 777, 9, 31, 99
+    auto = _autoreset_env(n, nt, seed)
+    twin = metagym_amd.make("quadrotor-v0", num_envs=n, device="cuda:0", task="hovering_control", nt=nt, seed=seed)
+    auto.reset(seed=1)
+    twin.reset(seed=1)
+    ar = qo.default_autoreset(seed=seed)
+    acts = _hard_actions(np.random.RandomState(2), T, n)
+    episodes = np.zeros(n, int)
+    for t in range(T):
+        a = torch.as_tensor(acts[t]).cuda()
+        oa, ra, da, ia = auto.step(a)
+        ot, rt, dt_, it = twin.step(a)
+        ot = ot.clone()
+        assert torch.equal(ra, rt) and torch.equal(da, dt_) and torch.equal(ia["failed"], it["failed"])
+        d = dt_.cpu().numpy()
+        if d.any():
+            iv, iw = np.zeros((n, 3)), np.zeros((n, 3))
+            for e in np.nonzero(d)[0]:
+                iv[e], iw[e] = qo.reset_noise(ar, e, episodes[e])
+                episodes[e] += 1
+            ot_reset = twin.reset(mask=dt_, init_velocity=iv, init_angular_velocity=iw)
+            ot[dt_] = ot_reset[dt_]
+        assert torch.equal(oa, ot), t
+        sa, stw = auto.state_dict(), twin.state_dict()
+        for k in ("pos", "vel", "omega", "propw", "rot", "ct"):
+            assert torch.equal(sa[k], stw[k]), (k, t)
+    assert episodes.min() >= 2
+    assert np.array_equal(auto.episode.cpu().numpy(), episodes)
+    assert int(twin.episode.abs().sum()) == 0            # the explicit path never touches the counters
+
+
+def test_autoreset_is_shard_invariant():
+    """(iii) Two half-shards with env_id_base 0 / n/2 == one full batch: the noise of an env depends on its global
+    id and its own episode count only (multi-GPU sharding cannot change a trajectory)."""
+    n, nt, T, seed = 1024, 7, 30, 5
+    full = _autoreset_env(n, nt, seed)
+    lo = _autoreset_env(n // 2, nt, seed, env_id_base=0)
+    hi = _autoreset_env(n // 2, nt, seed, env_id_base=n // 2)
+    full.reset(seed=8)
+    sd = full.state_dict()
+    for env, sl in ((lo, slice(0, n // 2)), (hi, slice(n // 2, n))):
+        env.load_state_dict({k: (v[..., sl] if v.dim() > 1 else v[sl]) for k, v in sd.items() if torch.is_tensor(v)})
+    acts = torch.as_tensor(_hard_actions(np.random.RandomState(6), T, n)).cuda()
+    for t in range(T):
+        of, rf, df, _ = full.step(acts[t])
+        ol, rl, dl, _ = lo.step(acts[t, : n // 2].contiguous())
+        oh, rh, dh, _ = hi.step(acts[t, n // 2:].contiguous())
+        assert torch.equal(of, torch.cat([ol, oh])) and torch.equal(rf, torch.cat([rl, rh]))
+        assert torch.equal(df, torch.cat([dl, dh]))
+    assert int(full.episode.min()) >= 2
+    sf, sl_, sh = full.state_dict(), lo.state_dict(), hi.state_dict()
+    for k in ("pos", "vel", "omega", "propw", "rot", "ct", "episode"):
+        assert torch.equal(sf[k], torch.cat([sl_[k], sh[k]], dim=-1)), k
+
+
+def test_autoreset_rollout_equals_single_steps():
+    """(iv) n_steps > 1 with resets INSIDE the launch == the same steps one launch at a time (the noise no longer
+    depends on a step counter, so the two launch shapes must agree bit for bit)."""
+    n, nt, T, seed = 1500, 6, 20, 77
+    a, b = _autoreset_env(n, nt, seed), _autoreset_env(n, nt, seed)
+    a.reset(seed=4)
+    b.reset(seed=4)
+    acts = torch.as_tensor(_hard_actions(np.random.RandomState(9), T, n)).cuda()
+    obs_r, rew_r, done_r, failed_r = a.rollout(acts)
+    for t in range(T):
+        obs, rew, done, info = b.step(acts[t])
+        assert torch.equal(obs, obs_r[t]) and torch.equal(rew, rew_r[t]) and torch.equal(done, done_r[t]), t
+        assert torch.equal(info["failed"], failed_r[t])
+    assert int(done_r.sum(0).min()) >= 3
+    sa, sb = a.state_dict(), b.state_dict()
+    for k in ("pos", "vel", "omega", "propw", "rot", "ct", "episode"):
+        assert torch.equal(sa[k], sb[k]), k
+
+
+def test_autoreset_full_size_sampled_against_oracle():
+    """The C2 batch itself (65 536 envs, the size bench.py times): 256 sampled envs of the fused-auto-reset run
+    against the oracle, bit-exact state and counters, plus the noise range / sign statistics of every restart."""
+    n, nt, T, seed = 65536, 11, 25, 1000
+    env = _autoreset_env(n, nt, seed)
+    env.reset(seed=1000)
+    sd = {k: v.cpu().numpy() for k, v in env.state_dict().items() if torch.is_tensor(v)}
+    idx = np.sort(np.random.RandomState(0).choice(n, 256, replace=False))
+    acts = torch.rand(T, n, 4, device="cuda:0") * 14.9 + 0.1
+    acts_h = acts.cpu().numpy()
+    first_obs = []
+    for t in range(T):
+        obs, rew, done, info = env.step(acts[t])
+        if t == nt - 1:
+            assert bool(done.all())                                  # every env just restarted (ct == nt) ...
+            first_obs.append(obs.cpu().numpy().copy())               # ... so this is 65 536 reset observations
+    c = qo.default_consts(nt=nt)
+    fin = _get_state(env)
+    ep = env.episode.cpu().numpy().view(np.uint32)
+    for j, e in enumerate(idx):
+        st = qo.make_states(sd["pos"].T[[e]], sd["vel"].T[[e]], sd["omega"].T[[e]], sd["propw"].T[[e]], sd["rot"].T[[e]])
+        ct, epo = np.zeros(1, np.int32), np.zeros(1, np.uint32)
+        ar = qo.default_autoreset(seed=seed, env_id_base=int(e))
+        for t in range(T):
+            qo.batch_env_step_autoreset(c, ar, st, ct, epo, acts_h[t][[e]])
+        o = qo.states_to_arrays(st)
+        for k in ("pos", "vel", "omega", "propw", "R"):
+            assert np.array_equal(fin[k][e], o[k][0]), (k, e)
+        assert fin["ct"][e] == ct[0] and ep[e] == epo[0]
+    # reset observations: b_v = velocity (R = I), gyro = body rate; |v| < 2, |w| < 5 per component, signs balanced
+    o = first_obs[0]
+    assert np.all(np.abs(o[:, 0:3]) <= 2.0) and np.all(np.abs(o[:, 9:12]) <= 5.0)
+    assert np.all(o[:, 3:6] == 0) and np.all(o[:, 15] == 5.0)
+    for cols, scale in ((slice(0, 3), 2.0), (slice(9, 12), 5.0)):
+        x = o[:, cols] / scale
+        assert abs(np.mean(x > 0) - 0.5) < 0.01 and abs(np.mean(np.abs(x)) - 0.5) < 0.01
