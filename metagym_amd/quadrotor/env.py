@@ -198,7 +198,8 @@ class Quadrotor(object):
         self.action_space = Box(low=np.array([lo] * 4, dtype="float32"),
                                 high=np.array([hi] * 4, dtype="float32"), shape=[4])
         self.observation_space = Space(shape=[self.obs_dim], dtype="float32")
-        self.np_random = np.random.RandomState(seed)
+        # numpy's legacy seeding takes 32 bits; the fused auto-reset below uses all 64 of a larger seed
+        self.np_random = np.random.RandomState(None if seed is None else int(seed) & 0xFFFFFFFF)
         self.seed_value = seed
         # fused auto-reset: done envs restart inside the step launch, noise from device-side Philox
         self.auto_reset = bool(auto_reset)
@@ -210,7 +211,7 @@ class Quadrotor(object):
             self._ar.init_angular_velocity[i] = float(cw[ax]) if cw else 0.0
         self._ar.init_velocity_noisy = float(cv["noisy"]) if cv else 0.0
         self._ar.init_angular_velocity_noisy = float(cw["noisy"]) if cw else 0.0
-        self._ar.seed = int(seed) & 0xFFFFFFFFFFFFFFFF
+        self._ar.seed = int(seed or 0) & 0xFFFFFFFFFFFFFFFF
         self._ar.env_id_base = int(env_id_base)   # global id of env 0 when this batch is one shard of a larger job
         # cfg is final: fold it once (mg_quadrotor_plan_init); step()/rollout() then only enqueue the launch
         self._plan = _lib.QuadrotorPlan()

@@ -39,6 +39,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--skip2d", action="store_true")
     ap.add_argument("--no-u8", action="store_true", help="skip the uint8 fast-path runs (profiling passes)")
+    ap.add_argument("--only", choices=("discrete", "continuous"), default=None,
+                    help="run one action space only (separate kernel-trace rows for the two maze3d variants)")
     args = ap.parse_args()
     dev = "cuda:0"
     tasks9 = [MazeTaskSampler(n=9, allow_loops=False, step_reward=-0.01, goal_reward=1.0, food_density=0.06,
@@ -46,6 +48,8 @@ def main():
     n = args.envs
     for res in args.res:
         for name, cont in (("meta-maze-discrete-3D-v0", False), ("meta-maze-continuous-3D-v0", True)):
+            if args.only is not None and (args.only == "continuous") != cont:
+                continue
             for tt in ("SURVIVAL",):
                 if res >= 256 and n * res * res * 12 > 40e9:
                     continue

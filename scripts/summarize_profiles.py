@@ -2,7 +2,8 @@
 
     python scripts/summarize_profiles.py r01
 
-Writes profiles/<round>/pmc_summary.json (per-kernel averages of every collected counter, plus the
+The two maze3d variants are traced in separate runs (`bench_maze.py --only discrete|continuous`) so each has
+its own kernel-stats row. Writes profiles/<round>/pmc_summary.json (per-kernel averages of every collected counter, plus the
 derived HBM traffic per launch: 2*FETCH_SIZE + WRITE_SIZE in KB — FETCH_SIZE on gfx950 reports half of
 a coalesced stream's bytes, /opt/skills/guides/MI355X_MICROARCH.md §HBM) and copies the kernel-stats
 CSVs and bench JSON lines. Also refreshes profiles/quadrotor_pmc.json, which bench.py reads for its
@@ -14,7 +15,7 @@ import os
 import shutil
 import sys
 
-rnd = sys.argv[1] if len(sys.argv) > 1 else "r01"
+rnd = sys.argv[1] if len(sys.argv) > 1 else "r02"
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 R = os.path.join(ROOT, "gpurun_out", rnd)
 P = os.path.join(ROOT, "profiles", rnd)
@@ -58,7 +59,12 @@ for kernel, prefix, stem in (("quadrotor_step_kernel", "quad", "q"), ("maze3d_st
 json.dump(summary, open(os.path.join(P, "pmc_summary.json"), "w"), indent=1)
 print(json.dumps(summary, indent=1))
 for src, dst in (("quad_trace/q_kernel_stats.csv", "quadrotor_bench_kernel_stats.csv"),
+                 ("quad_graph_trace/q_kernel_stats.csv", "quadrotor_bench_graph_kernel_stats.csv"),
                  ("maze_trace/m_kernel_stats.csv", "maze_bench_kernel_stats.csv"),
+                 ("maze_discrete_trace/m_kernel_stats.csv", "maze3d_discrete_kernel_stats.csv"),
+                 ("maze_continuous_trace/m_kernel_stats.csv", "maze3d_continuous_kernel_stats.csv"),
+                 ("bench_eager.json", "bench_eager.json"), ("bench_force_dist.json", "bench_force_dist.json"),
+                 ("bench_mixed_force_dist.json", "bench_mixed_force_dist.json"),
                  ("walker_trace/w_kernel_stats.csv", "walker_bench_kernel_stats.csv"),
                  ("bench.json", "bench.json"), ("bench_maze.jsonl", "bench_maze.jsonl"),
                  ("bench_walker.jsonl", "bench_walker.jsonl")):
