@@ -383,7 +383,11 @@ typedef struct mg_walker_params {
     double joints_at_limit_cost;   /* -0.1 walker_base_env.py:22 */
     double walk_target_x, walk_target_y;       /* 1e3, 0 */
     int32_t max_steps;
-    int32_t floor_in_parts;    /* 1: the floor link counts in the mean part position (walker_base_env.py:30-31) */
+    int32_t floor_in_parts;    /* 1: the floor link counts in the mean part position (walker_base_env.py:30-31): true
+                                  from the first step on and for every later reset of the same robot object; 0 for
+                                  the FIRST reset after a set_task (the floor joins robot.parts after robot.reset()).
+                                  The mean runs over all of robot.parts: the base once, every other body once per hinge
+                                  joint it carries (min. 1) */
     int32_t mapping;           /* 1 (default): wave per env, LDS-resident; 0: lane per env (cross-check) */
     int32_t self_collision;    /* 1: capsule-capsule contacts between the topology's geom pairs */
     double self_friction;      /* geom friction squared (Bullet multiplies the two coefficients) */
@@ -395,6 +399,12 @@ typedef struct mg_walker_params {
      * depend on how envs are sharded. The caller advances step_index by one per launch. */
     int32_t auto_reset;
     uint64_t seed, step_index, env_id_base;
+    /* The reference's own float choreography (tests/golden/walker_rules.npz, recorded from the unmodified Python):
+     * torque_f32 1 = Humanoid.apply_action humanoids.py:50-54 (python floats times a float32 action: float32 product),
+     *            0 = WalkerBase.apply_action walker_base.py:26-29 (float() first: float64 product) — the ant;
+     * height_f32 1 = the alive test adds the python float initial_z to the float32 obs[0] in float32 (humanoid),
+     *            0 = initial_z is a float64 taken from the first calc_state (ant). */
+    int32_t torque_f32, height_f32;
 } mg_walker_params;
 
 /* Per-env state, SoA doubles: component c of env e at base[c*N + e]. */

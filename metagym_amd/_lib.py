@@ -117,7 +117,7 @@ class WalkerParams(C.Structure):
                 ("max_steps", C.c_int32), ("floor_in_parts", C.c_int32), ("mapping", C.c_int32),
                 ("self_collision", C.c_int32), ("self_friction", C.c_double),
                 ("auto_reset", C.c_int32), ("seed", C.c_uint64), ("step_index", C.c_uint64),
-                ("env_id_base", C.c_uint64)]
+                ("env_id_base", C.c_uint64), ("torque_f32", C.c_int32), ("height_f32", C.c_int32)]
 
 
 class WalkerState(C.Structure):

@@ -405,6 +405,29 @@ __device__ void substep(const mg_walker_topology &tp, const ModelRef &m, const m
     }
 }
 
+// ---- the reference's Python-side arithmetic (pinned by tests/golden/walker_rules.npz) -------------------
+// Entries of `robot.parts` that report body b's frame: the base once, every other body once per hinge joint it
+// carries (a body with k joints is k links in Bullet's MJCF import, the intermediates massless) or once if it has
+// none (fixed joint). walker_base.py:39-41 averages x and y over ALL parts.
+__device__ __forceinline__ int part_weight(const mg_walker_topology &tp, int b) {
+    if (b == 0) return 1;
+    int c = 0;
+    for (int j = 0; j < tp.n_joints; ++j) c += tp.joint_body[j] == b;
+    return c > 0 ? c : 1;
+}
+// Humanoid.apply_action humanoids.py:50-54: `1 * power * 0.41 * np.clip(a[i], -1, +1)` with a float32 action is a
+// float32 product under NumPy-2 promotion (python floats are weak); WalkerBase.apply_action walker_base.py:26-29
+// (the ant) calls float() on the clipped action first and multiplies in float64.
+__device__ __forceinline__ double motor_torque(const mg_walker_params &prm, double gain, float a) {
+    a = a < -1.0f ? -1.0f : (a > 1.0f ? 1.0f : a);
+    return prm.torque_f32 ? (double)((float)gain * a) : gain * (double)a;
+}
+// walker_base_env.py:47 `alive_bonus(state[0] + initial_z, ...)`: state[0] is float32; the humanoid's initial_z is
+// the python float 0.8 (humanoids.py:48) -> float32 sum; the ant's came out of calc_state as a float64 -> float64 sum.
+__device__ __forceinline__ double alive_height(const mg_walker_params &prm, float obs0) {
+    return prm.height_f32 ? (double)(obs0 + (float)prm.initial_z) : (double)obs0 + prm.initial_z;
+}
+
 // ---- state I/O ---------------------------------------------------------------------------------------
 
 __device__ void load_env(const mg_walker_state &st, int n_envs, int nj, int e, Env &s) {
@@ -429,8 +452,13 @@ __device__ void observe(const mg_walker_topology &tp, const ModelRef &m, const m
     Kin k;
     kinematics(tp, m, s, k);
     double sx = 0.0, sy = 0.0;
-    for (int b = 0; b < nb; ++b) { sx += k.o[b].x; sy += k.o[b].y; }
-    const double cnt = (double)(nb + (prm.floor_in_parts ? 1 : 0));   // the floor link sits at the origin
+    int parts = prm.floor_in_parts ? 1 : 0;                           // the floor link sits at the origin
+    for (int b = 0; b < nb; ++b) {
+        const int w = part_weight(tp, b);
+        sx += w * k.o[b].x; sy += w * k.o[b].y;
+        parts += w;
+    }
+    const double cnt = (double)parts;
     const double bx = sx / cnt, by = sy / cnt, z = k.o[0].z;
     const double *R = k.R[0];
     const double roll = atan2(R[7], R[8]);
@@ -477,9 +505,7 @@ __global__ __launch_bounds__(WK_BLOCK) void walker_step_kernel(mg_walker_topolog
     load_env(st, n_envs, nj, e, s);
     double tau[NJ];
     for (int j = 0; j < nj; ++j) {
-        float a = action[(size_t)e * nj + j];
-        a = a < -1.0f ? -1.0f : (a > 1.0f ? 1.0f : a);                 // humanoids.py:50-54
-        tau[j] = m.motor[j] * (double)a;
+        tau[j] = motor_torque(prm, m.motor[j], action[(size_t)e * nj + j]);
     }
     unsigned long long touch = 0ull;
     for (int it = 0; it < prm.frame_skip; ++it) substep(tp, m, prm, s, tau, touch);   // scene_bases.py:45-50
@@ -496,7 +522,7 @@ __global__ __launch_bounds__(WK_BLOCK) void walker_step_kernel(mg_walker_topolog
             if (((touch >> g) & 1ull) && tp.sphere_body[g] == tp.foot_body[f]) c = 1.0f;
         st.feet_contact[(size_t)f * n_envs + e] = c;
     }
-    const double alive = ((double)ob[0] + prm.initial_z > prm.alive_z) ? prm.alive_bonus : prm.dead_bonus;   // :47
+    const double alive = (alive_height(prm, ob[0]) > prm.alive_z) ? prm.alive_bonus : prm.dead_bonus;   // :47
     bool finite = true;
     for (int i = 0; i < obs_dim; ++i) finite = finite && isfinite(ob[i]);
     const double pot_old = st.potential[e];
@@ -1181,9 +1207,7 @@ __global__ __launch_bounds__(WV) void walker_step_wave_kernel(mg_walker_topology
     if (lane < nj) {
         L.q[lane] = st.q[(size_t)lane * n_envs + e];
         L.qd[lane] = st.qd[(size_t)lane * n_envs + e];
-        float a = action[(size_t)e * nj + lane];
-        a = a < -1.0f ? -1.0f : (a > 1.0f ? 1.0f : a);                 // humanoids.py:50-54
-        L.tau[lane] = m.motor[lane] * (double)a;
+        L.tau[lane] = motor_torque(prm, m.motor[lane], action[(size_t)e * nj + lane]);
     }
     WSYNC();
     const int max_depth = L.misc[0];
@@ -1198,7 +1222,9 @@ __global__ __launch_bounds__(WV) void walker_step_wave_kernel(mg_walker_topology
     float head[8];
     auto calc_state = [&](bool after_reset, double &dist, int &at_limit, bool &all_finite) {
         wave_kinematics(tp, m, L, lane, max_depth, false);
-        const double sxm = wave_sum(lane < nb ? L.o[3 * lane] : 0.0), sym = wave_sum(lane < nb ? L.o[3 * lane + 1] : 0.0);
+        const int pw = lane < nb ? part_weight(tp, lane) : 0;
+        const double sxm = wave_sum(pw * (lane < nb ? L.o[3 * lane] : 0.0)), sym = wave_sum(pw * (lane < nb ? L.o[3 * lane + 1] : 0.0));
+        const int parts = (int)wave_sum((double)pw) + (prm.floor_in_parts ? 1 : 0);
         float jp = 0.0f, jv = 0.0f;
         bool lim = false;
         if (lane < nj) {
@@ -1225,7 +1251,7 @@ __global__ __launch_bounds__(WV) void walker_step_wave_kernel(mg_walker_topology
         }
         dist = 0.0;
         if (lane == 0) {
-            const double cnt = (double)(nb + (prm.floor_in_parts ? 1 : 0));
+            const double cnt = (double)parts;
             const double bx = sxm / cnt, by = sym / cnt, z = L.o[2];
             const double *R = L.R;
             const double roll = atan2(R[7], R[8]);
@@ -1261,7 +1287,7 @@ __global__ __launch_bounds__(WV) void walker_step_wave_kernel(mg_walker_topology
         }
         int ended = 0;
         if (lane == 0) {
-            const double alive = ((double)head[0] + prm.initial_z > prm.alive_z) ? prm.alive_bonus : prm.dead_bonus;
+            const double alive = (alive_height(prm, head[0]) > prm.alive_z) ? prm.alive_bonus : prm.dead_bonus;
             const double pot_old = st.potential[e];
             const double pot = -dist / (prm.time_step * prm.frame_skip);
             const double progress = pot - pot_old;

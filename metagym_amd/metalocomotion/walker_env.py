@@ -46,6 +46,7 @@ class WalkerBatchEnv(object):
     motor_power = None            # per joint, or None -> 100 (robot_bases.py:93 power_coef)
     alive_z, alive_bonus = 0.0, 1.0
     initial_z = None              # None -> height of the base at reset (walker_base.py:44-45)
+    torque_f32 = False            # apply_action multiplies in float64 (walker_base.py:26-29) / float32 (humanoids.py:50-54)
 
     def __init__(self, num_envs=1, device="cuda", frame_skip=4, time_step=0.005, enable_render=False,
                  max_steps=2000, assets_dir=None, solver_iterations=5, mapping="wave", self_collision=True,
@@ -166,6 +167,9 @@ class WalkerBatchEnv(object):
         p.self_friction = float(m0.geom_friction) ** 2            # Bullet multiplies the two geoms' friction
         p.auto_reset = int(self.auto_reset)
         p.seed, p.env_id_base = self.seed_value & 0xFFFFFFFFFFFFFFFF, self.env_id_base
+        p.torque_f32 = int(self.torque_f32)
+        p.height_f32 = int(self.initial_z is not None)     # python-float initial_z: float32 alive sum (walker_base_env.py:47)
+        self._first_reset = True                           # the floor link is not in robot.parts yet (walker_base_env.py:30-31)
         self._params_c = p
         self._obs = torch.zeros(N, self.obs_dim, dtype=torch.float32, device=dev)
         self._reward = torch.zeros(N, dtype=torch.float32, device=dev)
@@ -200,8 +204,13 @@ class WalkerBatchEnv(object):
         m = None
         if mask is not None:
             m = torch.as_tensor(mask, device=dev).to(torch.uint8).contiguous()
+        # WalkerBaseEnv.reset adds the floor to robot.parts AFTER robot.reset() computed the reset observation and
+        # potential (walker_base_env.py:24-31): the first reset after set_task averages over the robot's parts only
+        self._params_c.floor_in_parts = 0 if self._first_reset else 1
         rc = self._lib.mg_walker_reset(self._topo, self._models_c, self._params_c, N, self._state_c, _lib.ptr(m),
                                        _lib.ptr(jn), _lib.ptr(self._obs), _lib.current_stream(dev))
+        self._params_c.floor_in_parts = 1
+        self._first_reset = False
         _lib.check(rc, "mg_walker_reset")
         return self._obs
 
@@ -232,6 +241,7 @@ class MetaHumanoidEnv(WalkerBatchEnv):
     motor_power = [100, 100, 100, 100, 100, 300, 200, 100, 100, 300, 200, 75, 75, 75, 75, 75, 75]   # humanoids.py:19-28
     alive_z, alive_bonus = 0.50, 2.0      # humanoids.py:56
     initial_z = 0.8                       # humanoids.py:48
+    torque_f32 = True                     # humanoids.py:50-54: python floats x np.float32 action -> float32 product
 
 
 class MetaAntEnv(WalkerBatchEnv):

@@ -331,17 +331,39 @@ def rot_to_rpy(R):
     return roll, pitch, yaw
 
 
+def part_weights(m):
+    """How many entries of `robot.parts` report body b's frame (walker_base.py:39-41 averages over ALL parts):
+    the base once, every other body once per hinge joint it carries (a body with k joints is k links, the k-1
+    massless intermediates reporting the same frame) and once if it has none (it hangs on a fixed joint) — the
+    enumeration oracle/refstubs/pybullet attributes to Bullet's MJCF importer."""
+    w = np.ones(len(m.body_parent))
+    for b in range(1, len(m.body_parent)):
+        w[b] = max(1, int(np.count_nonzero(np.asarray(m.joint_body) == b)))
+    return w
+
+
 class WalkerEnv(object):
-    """calc_state / step bookkeeping of WalkerBase + WalkerBaseEnv around `substep`."""
+    """calc_state / step bookkeeping of WalkerBase + WalkerBaseEnv around `substep`.
+
+    torque_f32: Humanoid.apply_action (humanoids.py:50-54) multiplies python floats into np.clip(a[i], -1, +1),
+    which for the float32 actions a gym Box hands over is a float32 scalar: under NumPy-2 promotion the whole
+    product `1 * power * 0.41 * clip` is evaluated in float32. WalkerBase.apply_action (walker_base.py:26-29, the
+    ant) converts with float() first and multiplies in float64.
+    initial_z: 0.8 for the humanoid (a python float, humanoids.py:48: the alive test `state[0] + initial_z` is
+    then a float32 sum); None for the ant — taken from the first calc_state (walker_base.py:44-45), a float64."""
 
     def __init__(self, model, prm=None, motor_power=HUMANOID_MOTOR_POWER, alive_z=0.50, alive_bonus=2.0,
-                 max_steps=2000, initial_z=0.8, floor_in_parts=True):
+                 max_steps=2000, initial_z=0.8, floor_in_parts=True, torque_f32=True):
         self.m, self.prm = model, prm or Params()
         self.motor_power, self.alive_z, self.alive_bonus = motor_power, alive_z, alive_bonus
-        self.max_steps, self.initial_z = max_steps, initial_z
-        # WalkerBaseEnv.reset re-runs addToScene on the ground bodies, so the floor link (at the
-        # origin) joins robot.parts (walker_base_env.py:30-31) and dilutes the mean part position
+        self.max_steps, self.initial_z_cfg = max_steps, initial_z
+        # WalkerBaseEnv.reset re-runs addToScene on the ground bodies AFTER robot.reset(), so the floor link (at
+        # the origin) joins robot.parts (walker_base_env.py:30-31) from the first step on — and stays there for
+        # every later reset() of the same robot object, i.e. until the next set_task()
         self.floor_in_parts = floor_in_parts
+        self.floor_known = False
+        self.torque_f32 = torque_f32
+        self.weights = part_weights(model)
         self.walk_target = np.array([1e3, 0.0])
 
     def reset(self, joint_noise):
@@ -350,8 +372,10 @@ class WalkerEnv(object):
         self.s = s
         self.steps = 0
         self.feet_contact = np.zeros(len(self.m.foot_body))
+        self.initial_z = self.initial_z_cfg               # humanoids.py:48 / walker_base.py:24
         obs = self.calc_state()
-        self.potential = self.calc_potential()
+        self.potential = self.calc_potential()            # env_bases.py:80, before the floor joins the parts
+        self.floor_known = self.floor_in_parts            # walker_base_env.py:30-31
         return obs
 
     def calc_state(self):
@@ -362,14 +386,14 @@ class WalkerEnv(object):
         vel = 0.1 * s.qd                                                    # :327-328 (revolute)
         j = np.stack([pos, vel], 1).astype(np.float32).flatten()
         self.joints_at_limit = int(np.count_nonzero(np.abs(j[0::2]) > 0.99))
-        parts = list(kin["o"])
-        if self.floor_in_parts:
-            parts = parts + [np.zeros(3)]
-        parts = np.array(parts)
-        self.body_xyz = (parts[:, 0].mean(), parts[:, 1].mean(), kin["o"][0][2])
+        cnt = self.weights.sum() + (1.0 if self.floor_known else 0.0)      # the floor link sits at the origin
+        self.body_xyz = (float(self.weights @ kin["o"][:, 0]) / cnt, float(self.weights @ kin["o"][:, 1]) / cnt,
+                         kin["o"][0][2])
         roll, pitch, yaw = rot_to_rpy(kin["R"][0])
         self.body_rpy = (roll, pitch, yaw)
         z = self.body_xyz[2]
+        if self.initial_z is None:
+            self.initial_z = z                                              # walker_base.py:44-45
         theta = np.arctan2(self.walk_target[1] - self.body_xyz[1], self.walk_target[0] - self.body_xyz[0])
         self.walk_target_dist = np.linalg.norm([self.walk_target[1] - self.body_xyz[1],
                                                 self.walk_target[0] - self.body_xyz[0]])
@@ -384,10 +408,16 @@ class WalkerEnv(object):
     def calc_potential(self):
         return -self.walk_target_dist / (self.prm.dt * self.prm.substeps)   # walker_base.py:66-82
 
+    def torques(self, action):
+        a32 = np.clip(np.asarray(action, np.float32), np.float32(-1), np.float32(1))
+        if self.torque_f32:                                                  # humanoids.py:50-54, float32 product
+            gain = (np.asarray(self.motor_power, float) * self.prm.power).astype(np.float32)
+            return (gain * a32).astype(np.float64)
+        return (self.prm.power * np.asarray(self.motor_power, float)) * a32.astype(np.float64)   # walker_base.py:26-29
+
     def step(self, action):
         m, prm = self.m, self.prm
-        a = np.clip(np.asarray(action, float), -1, 1)
-        tau = self.motor_power * prm.power * a                               # humanoids.py:50-54
+        tau = self.torques(action)
         touching = set()
         for _ in range(prm.substeps):
             touching = substep(m, self.s, tau, prm)
@@ -396,7 +426,13 @@ class WalkerEnv(object):
         state = self.calc_state()
         for i, fb in enumerate(m.foot_body):                                 # walker_base_env.py:57-63
             self.feet_contact[i] = 1.0 if any(m.sph_body[g] == fb for g in touching) else 0.0
-        alive = float(self.alive_bonus if state[0] + self.initial_z > self.alive_z else -1)
+        # walker_base_env.py:47: alive_bonus(state[0] + initial_z, ...) — float32 + python float stays float32
+        # (humanoid), float32 + numpy float64 is float64 (ant: initial_z came out of calc_state)
+        if self.initial_z_cfg is not None:
+            height = float(np.float32(state[0]) + np.float32(self.initial_z))
+        else:
+            height = float(state[0]) + float(self.initial_z)
+        alive = float(self.alive_bonus if height > self.alive_z else -1)
         done = alive < 0 or not np.isfinite(state).all()
         old = self.potential
         self.potential = self.calc_potential()
