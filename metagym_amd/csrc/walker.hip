@@ -608,6 +608,38 @@ constexpr int WV = 64;
 #define TRI(r, c) ((r) * ((r) + 1) / 2 + (c))
 constexpr int W_MAXC = 12;   // ground contacts kept per env (first W_MAXC penetrating spheres)
 
+// Robot shape as template constants (all zero = read the topology at run time). Every MetaLocomotion variant of a
+// robot shares one shape (humanoid: 13 bodies, 17 hinges, 29 collision spheres, 17 capsules; ant: 13 / 8 / 25 / 13),
+// and with the shape known at compile time every LDS address and every model-table offset below is a literal in the
+// instruction. Computed at run time they were ~40 LDS pointers and 18 table pointers held in SGPRs for the whole
+// sub-step: 413 SGPR spills to VGPR lanes in the humanoid kernel (v_writelane / v_readlane on the hot path).
+template <int B, int J, int S, int G, int OVL>
+struct Shape { static constexpr int nb = B, nj = J, ns = S, ng = G, overlay = OVL; };
+using ShapeAny = Shape<0, 0, 0, 0, -1>;
+
+struct ModelW {   // one task's table row (layout: mg_walker_models in metagym_hip.h); offsets fold when the shape is constant
+    const double *p;
+    int nb, nj, ns, ng;
+    __device__ __forceinline__ const double *body_pos() const { return p; }
+    __device__ __forceinline__ const double *body_rot() const { return p + 3 * nb; }
+    __device__ __forceinline__ const double *body_mass() const { return p + 12 * nb; }
+    __device__ __forceinline__ const double *body_com() const { return p + 13 * nb; }
+    __device__ __forceinline__ const double *body_inertia() const { return p + 16 * nb; }
+    __device__ __forceinline__ const double *joint_anchor() const { return p + 25 * nb; }
+    __device__ __forceinline__ const double *joint_axis() const { return p + 25 * nb + 3 * nj; }
+    __device__ __forceinline__ const double *joint_lo() const { return p + 25 * nb + 6 * nj; }
+    __device__ __forceinline__ const double *joint_hi() const { return p + 25 * nb + 7 * nj; }
+    __device__ __forceinline__ const double *joint_arm() const { return p + 25 * nb + 8 * nj; }
+    __device__ __forceinline__ const double *joint_damp() const { return p + 25 * nb + 9 * nj; }
+    __device__ __forceinline__ const double *joint_stiff() const { return p + 25 * nb + 10 * nj; }
+    __device__ __forceinline__ const double *motor() const { return p + 25 * nb + 11 * nj; }
+    __device__ __forceinline__ const double *sph_pos() const { return p + 25 * nb + 12 * nj; }
+    __device__ __forceinline__ const double *sph_r() const { return p + 25 * nb + 12 * nj + 3 * ns; }
+    __device__ __forceinline__ const double *geom_p0() const { return p + 25 * nb + 12 * nj + 4 * ns; }
+    __device__ __forceinline__ const double *geom_p1() const { return p + 25 * nb + 12 * nj + 4 * ns + 3 * ng; }
+    __device__ __forceinline__ const double *geom_r() const { return p + 25 * nb + 12 * nj + 4 * ns + 6 * ng; }
+};
+
 // Sum over the 64 lanes without LDS: four DPP steps fold each 16-lane row (quad_perm xor-1, xor-2,
 // row_half_mirror, row_mirror), then the four row totals are fetched with v_readlane.
 template <int CTRL>
@@ -657,6 +689,7 @@ struct WaveLds {   // pointers into the env's LDS slab
     double *cx;                              // per contact: ground (x, y, depth) or self (point xc, normal)
     double *sc;                              // sin / cos of every joint angle
     int *mask, *depth, *jstart, *jcount, *poff, *kind, *partner, *csphere, *misc, *bod;
+    int *parent, *sbody;                     // topology tables copied out of the kernarg segment: body_parent, sphere_body
     short *ptab;                             // (body | dof << 8) of every Jacobian pair — topology only, built once per launch
 };
 
@@ -684,11 +717,11 @@ __host__ __device__ inline size_t wave_lds_doubles(int nb, int nj, int maxr, boo
            6 * (size_t)W_MAXC + (2 * (size_t)nj <= 6 * (size_t)W_MAXC ? 0 : 2 * (size_t)nj);
 }
 // + the (body, dof) pair table: one int16 per pair, at most maxr * ND / 6 pairs fit the assembly scratch
-__host__ __device__ inline size_t wave_lds_ints(int nb, int maxr) {
-    return 5 * (size_t)nb + 2 * (size_t)maxr + 2 * W_MAXC + 8 + ND + ((size_t)maxr * ND / 6 + 2) / 2;
+__host__ __device__ inline size_t wave_lds_ints(int nb, int ns, int maxr) {
+    return 6 * (size_t)nb + (size_t)ns + 2 * (size_t)maxr + 2 * W_MAXC + 8 + ND + ((size_t)maxr * ND / 6 + 2) / 2;
 }
 
-__device__ __forceinline__ WaveLds carve(unsigned char *smem, int nb, int nj, int maxr, bool overlay) {
+__device__ __forceinline__ WaveLds carve(unsigned char *smem, int nb, int nj, int ns, int maxr, bool overlay) {
     const int n = 6 + nj;
     WaveLds L;
     double *d = reinterpret_cast<double *>(smem);
@@ -711,6 +744,7 @@ __device__ __forceinline__ WaveLds carve(unsigned char *smem, int nb, int nj, in
     int *i = reinterpret_cast<int *>(d);
     L.mask = i; i += nb; L.depth = i; i += nb; L.jstart = i; i += nb; L.jcount = i; i += nb; L.poff = i; i += nb;
     L.kind = i; i += maxr; L.partner = i; i += maxr; L.csphere = i; i += 2 * W_MAXC; L.misc = i; i += 8; L.bod = i; i += ND;
+    L.parent = i; i += nb; L.sbody = i; i += ns;
     L.ptab = reinterpret_cast<short *>(i);
     return L;
 }
@@ -747,9 +781,8 @@ __device__ __forceinline__ void rodrigues_sc(V3 k, double s, double c, double *R
 
 // forceinline: with three call sites the compiler would otherwise emit a real call, which pushes the
 // kernels into scratch (ant: 1.04 -> 1.92 ms)
-__device__ __forceinline__ void wave_kinematics(const mg_walker_topology &tp, const ModelRef &m, const WaveLds &L, int lane,
-                                int max_depth, bool with_frames) {
-    const int nb = tp.n_bodies, nj = tp.n_joints;
+__device__ __forceinline__ void wave_kinematics(const ModelW &m, const WaveLds &L, int lane, int max_depth, bool with_frames) {
+    const int nb = m.nb, nj = m.nj;
     // the f64 sin/cos of all joint angles at once (lane = joint): the level loop below is serial in the
     // tree depth and must not carry ~300 instructions of range reduction per joint
     if (lane < nj) {
@@ -760,7 +793,7 @@ __device__ __forceinline__ void wave_kinematics(const mg_walker_topology &tp, co
     WSYNC();
     for (int level = 0; level <= max_depth; ++level) {
         if (lane < nb && L.depth[lane] == level) {
-            const int b = lane, pb = tp.body_parent[b];
+            const int b = lane, pb = L.parent[b];
             double Rc[9];
             V3 oc, w, al, xr, ar;
             unsigned mk = 0;
@@ -770,14 +803,14 @@ __device__ __forceinline__ void wave_kinematics(const mg_walker_topology &tp, co
                 w = V3{L.base[15], L.base[16], L.base[17]};
                 al = v3(0, 0, 0); xr = oc; ar = v3(0, 0, 0);
             } else {
-                mulMM(L.R + 9 * pb, m.body_rot + 9 * b, Rc);
-                oc = ldv(L.o, pb) + mulMv(L.R + 9 * pb, ld3(m.body_pos + 3 * b));
+                mulMM(L.R + 9 * pb, m.body_rot() + 9 * b, Rc);
+                oc = ldv(L.o, pb) + mulMv(L.R + 9 * pb, ld3(m.body_pos() + 3 * b));
                 mk = (unsigned)L.mask[pb];
                 w = ldv(L.fw, pb); al = ldv(L.fal, pb); xr = ldv(L.fxr, pb); ar = ldv(L.far_, pb);
             }
             const int j0 = L.jstart[b], j1 = j0 + L.jcount[b];
             for (int j = j0; j < j1; ++j) {
-                const V3 anchor = ld3(m.joint_anchor + 3 * j), axis = ld3(m.joint_axis + 3 * j);
+                const V3 anchor = ld3(m.joint_anchor() + 3 * j), axis = ld3(m.joint_axis() + 3 * j);
                 const V3 pj = oc + mulMv(Rc, anchor), aj = mulMv(Rc, axis);
                 stv(L.p, j, pj);
                 stv(L.a, j, aj);
@@ -798,7 +831,7 @@ __device__ __forceinline__ void wave_kinematics(const mg_walker_topology &tp, co
             }
             for (int i = 0; i < 9; ++i) L.R[9 * b + i] = Rc[i];
             stv(L.o, b, oc);
-            const V3 cb = oc + mulMv(Rc, ld3(m.body_com + 3 * b));
+            const V3 cb = oc + mulMv(Rc, ld3(m.body_com() + 3 * b));
             stv(L.c, b, cb);
             L.mask[b] = (int)mk;
             if (with_frames) {
@@ -810,11 +843,16 @@ __device__ __forceinline__ void wave_kinematics(const mg_walker_topology &tp, co
 }
 
 template <int NMAX>
-__device__ void wave_substep(const mg_walker_topology &tp, const ModelRef &m, const mg_walker_params &prm,
-                             const WaveLds &L, int lane, int max_depth, int maxr, unsigned long long &touch_mask) {
-    const int nb = tp.n_bodies, nj = tp.n_joints, ns = tp.n_spheres, n = 6 + nj;
+__device__ __forceinline__ void wave_substep(const mg_walker_topology &tp, const ModelW &m, const mg_walker_params &prm,
+                                             const WaveLds &L, int lane, int max_depth, int maxr,
+                                             unsigned long long &touch_mask) {
+    const int nb = m.nb, nj = m.nj, ns = m.ns, n = 6 + nj;
     const double dt = prm.time_step;
-    wave_kinematics(tp, m, L, lane, max_depth, true);
+    // A fresh copy of the lane id per sub-step: the ~140 lane predicates of the unrolled Cholesky / substitution
+    // code (lane == c, k <= lane, ...) are invariant across the sub-step loop, so they were hoisted out of it as
+    // 64-bit masks and spilled to VGPR lanes; one v_cmp where it is needed is cheaper than the reload.
+    asm volatile("" : "+v"(lane));
+    wave_kinematics(m, L, lane, max_depth, true);
     // ---- per-body world inertia and bias wrench (lane = body) ---------------------------------------
     if (lane < nb) {
         const int b = lane;
@@ -825,7 +863,7 @@ __device__ void wave_substep(const mg_walker_topology &tp, const ModelRef &m, co
         // Iw = A A^T and the joint-space inertia becomes a plain sum of dot products of "whitened" Jacobian
         // pairs (sqrt(m) jv, A^T jw) — no 3x3 inertia product per (matrix entry, body) later on. The bias
         // wrench is stored whitened the same way: F / sqrt(m) and A^-1 N.
-        const double *Ib = m.body_inertia + 9 * b;
+        const double *Ib = m.body_inertia() + 9 * b;
         const double c00 = sqrt(Ib[0]), c10 = Ib[3] / c00, c20 = Ib[6] / c00;
         const double c11 = sqrt(Ib[4] - c10 * c10), c21 = (Ib[7] - c20 * c10) / c11;
         const double c22 = sqrt(Ib[8] - c20 * c20 - c21 * c21);
@@ -840,7 +878,7 @@ __device__ void wave_substep(const mg_walker_topology &tp, const ModelRef &m, co
         auto At = [&](V3 x) { return V3{A[0] * x.x + A[3] * x.y + A[6] * x.z, A[1] * x.x + A[4] * x.y + A[7] * x.z,
                                         A[2] * x.x + A[5] * x.y + A[8] * x.z}; };
         auto Iw_times = [&](V3 x) { return mulMv(A, At(x)); };
-        const double mass = m.body_mass[b], sm = sqrt(mass);
+        const double mass = m.body_mass()[b], sm = sqrt(mass);
         const V3 F = mass * (a_c - v3(0, 0, -prm.gravity));
         const V3 N = Iw_times(al) + cross(w, Iw_times(w));
         stv(L.F, b, (1.0 / sm) * F);
@@ -888,7 +926,7 @@ __device__ void wave_substep(const mg_walker_topology &tp, const ModelRef &m, co
             const double *pd = pairs + (size_t)pair_index(b, mk, d) * 6, *pe = pairs + (size_t)pair_index(b, mk, e) * 6;
             acc += (pd[0] * pe[0] + pd[1] * pe[1] + pd[2] * pe[2]) + (pd[3] * pe[3] + pd[4] * pe[4] + pd[5] * pe[5]);
         }
-        if (d == e && d >= 6) acc += m.joint_arm[d - 6];
+        if (d == e && d >= 6) acc += m.joint_arm()[d - 6];
         L.M[t] = acc;                                       // t == TRI(d, e)
     }
     if (lane < n) {
@@ -938,7 +976,7 @@ __device__ void wave_substep(const mg_walker_topology &tp, const ModelRef &m, co
         x_d = -L.h[d];
         if (d >= 6) {
             const int j = d - 6;
-            x_d += L.tau[j] - m.joint_damp[j] * L.qd[j] - m.joint_stiff[j] * L.q[j];
+            x_d += L.tau[j] - m.joint_damp()[j] * L.qd[j] - m.joint_stiff()[j] * L.q[j];
             u_d = L.qd[j];
         } else {
             u_d = L.base[d < 3 ? 12 + d : 15 + (d - 3)];
@@ -957,9 +995,9 @@ __device__ void wave_substep(const mg_walker_topology &tp, const ModelRef &m, co
     bool hit = false;
     double sx = 0, sy = 0, depth = 0;
     if (lane < ns) {
-        const int b = tp.sphere_body[lane];
-        const V3 xw = ldv(L.o, b) + mulMv(L.R + 9 * b, ld3(m.sph_pos + 3 * lane));
-        depth = m.sph_r[lane] - xw.z;
+        const int b = L.sbody[lane];
+        const V3 xw = ldv(L.o, b) + mulMv(L.R + 9 * b, ld3(m.sph_pos() + 3 * lane));
+        depth = m.sph_r()[lane] - xw.z;
         hit = depth > 0.0;
         sx = xw.x; sy = xw.y;
     }
@@ -989,17 +1027,17 @@ __device__ void wave_substep(const mg_walker_topology &tp, const ModelRef &m, co
                 ba = tp.geom_body[ga];
                 bb = tp.geom_body[gb];
                 V3 ca, cb;
-                segment_closest(ldv(L.o, ba) + mulMv(L.R + 9 * ba, ld3(m.geom_p0 + 3 * ga)),
-                                ldv(L.o, ba) + mulMv(L.R + 9 * ba, ld3(m.geom_p1 + 3 * ga)),
-                                ldv(L.o, bb) + mulMv(L.R + 9 * bb, ld3(m.geom_p0 + 3 * gb)),
-                                ldv(L.o, bb) + mulMv(L.R + 9 * bb, ld3(m.geom_p1 + 3 * gb)), ca, cb);
+                segment_closest(ldv(L.o, ba) + mulMv(L.R + 9 * ba, ld3(m.geom_p0() + 3 * ga)),
+                                ldv(L.o, ba) + mulMv(L.R + 9 * ba, ld3(m.geom_p1() + 3 * ga)),
+                                ldv(L.o, bb) + mulMv(L.R + 9 * bb, ld3(m.geom_p0() + 3 * gb)),
+                                ldv(L.o, bb) + mulMv(L.R + 9 * bb, ld3(m.geom_p1() + 3 * gb)), ca, cb);
                 const V3 dv = ca - cb;
                 const double dist = sqrt(dot(dv, dv));
-                sdepth = m.geom_r[ga] + m.geom_r[gb] - dist;
+                sdepth = m.geom_r()[ga] + m.geom_r()[gb] - dist;
                 sh = sdepth > 0.0 && dist > 1e-9;
                 if (sh) {
                     nrm = (1.0 / dist) * dv;
-                    xc = 0.5 * ((ca - m.geom_r[ga] * nrm) + (cb + m.geom_r[gb] * nrm));
+                    xc = 0.5 * ((ca - m.geom_r()[ga] * nrm) + (cb + m.geom_r()[gb] * nrm));
                 }
             }
             const unsigned long long sh_mask = __ballot(sh);
@@ -1017,8 +1055,8 @@ __device__ void wave_substep(const mg_walker_topology &tp, const ModelRef &m, co
     double lsgn = 0.0, viol = 0.0;
     if (lane < nj) {
         const double qj = L.q[lane];
-        if (qj < m.joint_lo[lane]) { lsgn = 1.0; viol = m.joint_lo[lane] - qj; }
-        else if (qj > m.joint_hi[lane]) { lsgn = -1.0; viol = qj - m.joint_hi[lane]; }
+        if (qj < m.joint_lo()[lane]) { lsgn = 1.0; viol = m.joint_lo()[lane] - qj; }
+        else if (qj > m.joint_hi()[lane]) { lsgn = -1.0; viol = qj - m.joint_hi()[lane]; }
     }
     const unsigned long long lims = __ballot(lsgn != 0.0);
     const int nr = 3 * ncont + __popcll(lims);
@@ -1033,7 +1071,7 @@ __device__ void wave_substep(const mg_walker_topology &tp, const ModelRef &m, co
         const int c = t / n, d = t % n;
         const double *cc = L.cx + 6 * c;
         if (L.csphere[2 * c + 1] < 0) {          // ground: point on the plane under the sphere
-            const unsigned mk = (unsigned)L.mask[tp.sphere_body[L.csphere[2 * c]]];
+            const unsigned mk = (unsigned)L.mask[L.sbody[L.csphere[2 * c]]];
             const V3 jc = wjac_lin(L, mk, V3{cc[0], cc[1], 0.0}, d);
             L.J[(size_t)(3 * c) * n + d] = jc.z;
             L.J[(size_t)(3 * c + 1) * n + d] = jc.x;
@@ -1053,7 +1091,9 @@ __device__ void wave_substep(const mg_walker_topology &tp, const ModelRef &m, co
     // ---- Jh = J L^-T, lane = row, in place. The right-hand side lives in registers (a fully unrolled
     //      NMAX-slot array): through LDS every step of the substitution would wait on its own previous store.
     //      A joint-limit row starts as +-e_(6+j) and is never materialised before this point -------------------
-    for (int r = lane; r < nr; r += WV) {
+    static_assert(3 * W_MAXC + NJ <= WV, "one lane per constraint row");
+    if (lane < nr) {        // (not a lane-strided loop: its invariant L.M reads would be hoisted into ~500 VGPRs)
+        const int r = lane;
         double w[NMAX];
         const int rkind = L.kind[r];
         const bool is_limit = rkind >= 4;
@@ -1139,23 +1179,34 @@ __device__ void wave_substep(const mg_walker_topology &tp, const ModelRef &m, co
     WSYNC();
 }
 
-template <int NMAX>
+template <int NMAX, class SH>
 __global__ __launch_bounds__(WV) void walker_step_wave_kernel(mg_walker_topology tp, mg_walker_models ms,
                                                               mg_walker_params prm, mg_walker_state st, int n_envs,
                                                               int maxr_flags, const float *action, float *obs,
                                                               float *reward, float *rewards5, uint8_t *done) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int e = mg::env_of_block(blockIdx.x, n_envs), lane = threadIdx.x;
-    const int nb = tp.n_bodies, nj = tp.n_joints, nf = tp.n_feet, obs_dim = 8 + 2 * nj + nf;
-    const ModelRef m = model_ref(tp, ms, st.task_id[e]);
-    const bool overlay = maxr_flags < 0;         // sign of the row-count argument: assembly scratch overlaid on Jh
-    const int maxr = maxr_flags < 0 ? -maxr_flags : maxr_flags;
-    const WaveLds L = carve(smem, nb, nj, maxr, overlay);
+    const int nb = SH::nb ? SH::nb : tp.n_bodies, nj = SH::nb ? SH::nj : tp.n_joints, ns = SH::nb ? SH::ns : tp.n_spheres;
+    const int nf = tp.n_feet, obs_dim = 8 + 2 * nj + nf;
+    const ModelW m{ms.table + (size_t)st.task_id[e] * ms.model_stride, nb, nj, ns, SH::nb ? SH::ng : tp.n_geoms};
+    // sign of the row-count argument: assembly scratch overlaid on Jh
+    const bool overlay = SH::overlay >= 0 ? SH::overlay != 0 : maxr_flags < 0;
+    const int maxr = SH::nb ? 3 * W_MAXC + SH::nj : (maxr_flags < 0 ? -maxr_flags : maxr_flags);
+    // The slab's base goes through a VGPR the optimiser cannot see into: every LDS access below is then
+    // `ds_* v_base offset:<literal>`. Left as the symbol `smem`, each distinct constant address (hundreds in the
+    // unrolled Cholesky / whitening loops) was materialised in its own SGPR, hoisted, and spilled to VGPR lanes.
+    unsigned slab_off = 0;
+    asm volatile("" : "+v"(slab_off));
+    unsigned char *slab = smem + slab_off;
+    const WaveLds L = carve(slab, nb, nj, ns, maxr, overlay);
+    if (lane < nb) L.parent[lane] = tp.body_parent[lane];
+    if (lane < ns) L.sbody[lane] = tp.sphere_body[lane];
+    WSYNC();
     // tree bookkeeping (lane 0) + state load (lanes)
     if (lane == 0) {
         int md = 0, j = 0;
         for (int b = 0; b < nb; ++b) {
-            const int pb = tp.body_parent[b];
+            const int pb = L.parent[b];
             L.depth[b] = pb < 0 ? 0 : L.depth[pb] + 1;
             md = max(md, L.depth[b]);
             L.jstart[b] = j;
@@ -1167,7 +1218,7 @@ __global__ __launch_bounds__(WV) void walker_step_wave_kernel(mg_walker_topology
         // chain (mask), where each body's (body, dof) Jacobian pairs start (poff), their total (misc[1])
         int off = 0;
         for (int b = 0; b < nb; ++b) {
-            const int pb = tp.body_parent[b];
+            const int pb = L.parent[b];
             unsigned mk = pb < 0 ? 0u : (unsigned)L.mask[pb];
             for (int jj = L.jstart[b]; jj < L.jstart[b] + L.jcount[b]; ++jj) mk |= 1u << jj;
             L.mask[b] = (int)mk;
@@ -1207,7 +1258,7 @@ __global__ __launch_bounds__(WV) void walker_step_wave_kernel(mg_walker_topology
     if (lane < nj) {
         L.q[lane] = st.q[(size_t)lane * n_envs + e];
         L.qd[lane] = st.qd[(size_t)lane * n_envs + e];
-        L.tau[lane] = motor_torque(prm, m.motor[lane], action[(size_t)e * nj + lane]);
+        L.tau[lane] = motor_torque(prm, m.motor()[lane], action[(size_t)e * nj + lane]);
     }
     WSYNC();
     const int max_depth = L.misc[0];
@@ -1221,14 +1272,14 @@ __global__ __launch_bounds__(WV) void walker_step_wave_kernel(mg_walker_topology
     float *ob = obs + (size_t)e * obs_dim;
     float head[8];
     auto calc_state = [&](bool after_reset, double &dist, int &at_limit, bool &all_finite) {
-        wave_kinematics(tp, m, L, lane, max_depth, false);
+        wave_kinematics(m, L, lane, max_depth, false);
         const int pw = lane < nb ? part_weight(tp, lane) : 0;
         const double sxm = wave_sum(pw * (lane < nb ? L.o[3 * lane] : 0.0)), sym = wave_sum(pw * (lane < nb ? L.o[3 * lane + 1] : 0.0));
         const int parts = (int)wave_sum((double)pw) + (prm.floor_in_parts ? 1 : 0);
         float jp = 0.0f, jv = 0.0f;
         bool lim = false;
         if (lane < nj) {
-            const double lo = m.joint_lo[lane], hi = m.joint_hi[lane];
+            const double lo = m.joint_lo()[lane], hi = m.joint_hi()[lane];
             jp = (float)(2 * (L.q[lane] - 0.5 * (lo + hi)) / (hi - lo));
             jv = (float)(0.1 * L.qd[lane]);
             lim = fabsf(jp) > 0.99f;
@@ -1244,8 +1295,8 @@ __global__ __launch_bounds__(WV) void walker_step_wave_kernel(mg_walker_topology
                 const float prev = st.feet_contact[(size_t)lane * n_envs + e];
                 ob[8 + 2 * nj + lane] = clip5(prev);
                 float cnow = 0.0f;
-                for (int g = 0; g < tp.n_spheres; ++g)
-                    if (((touch >> g) & 1ull) && tp.sphere_body[g] == tp.foot_body[lane]) cnow = 1.0f;
+                for (int g = 0; g < ns; ++g)
+                    if (((touch >> g) & 1ull) && L.sbody[g] == tp.foot_body[lane]) cnow = 1.0f;
                 st.feet_contact[(size_t)lane * n_envs + e] = cnow;
             }
         }
@@ -1309,11 +1360,11 @@ __global__ __launch_bounds__(WV) void walker_step_wave_kernel(mg_walker_topology
         // returned obs row is the first observation of the next episode (vector-env convention)
         WSYNC();
         if (lane < 3) {
-            L.base[lane] = m.body_pos[lane];
+            L.base[lane] = m.body_pos()[lane];
             L.base[12 + lane] = 0.0;
             L.base[15 + lane] = 0.0;
         }
-        if (lane < 9) L.base[3 + lane] = m.body_rot[lane];
+        if (lane < 9) L.base[3 + lane] = m.body_rot()[lane];
         if (lane < nj) {
             L.q[lane] = reset_joint_noise(prm, e, lane);
             L.qd[lane] = 0.0;
@@ -1405,21 +1456,28 @@ extern "C" int mg_walker_step(const mg_walker_topology *tp, const mg_walker_mode
         overlay = 6 * pairs + 27 * (size_t)tp->n_bodies <= block;
     }
     const size_t lds = wave_lds_doubles(tp->n_bodies, tp->n_joints, maxr, overlay) * sizeof(double) +
-                       wave_lds_ints(tp->n_bodies, maxr) * sizeof(int);
+                       wave_lds_ints(tp->n_bodies, tp->n_spheres, maxr) * sizeof(int);
     const int maxr_flags = overlay ? -maxr : maxr;
     if (lds > 160 * 1024) return mg::set_error(MG_ERR_BAD_SIZE, "walker needs %zu B of LDS", lds);
     if (lds > 64 * 1024) return mg::set_error(MG_ERR_BAD_SIZE, "walker needs %zu B of LDS (> 64 KiB)", lds);
     const int ndof = 6 + tp->n_joints;
     // the substitution keeps its vector in registers, so the dof count is a template parameter:
     // 14 = ant, 23 = humanoid, 30 = the ABI maximum
-    if (ndof <= 14)
-        hipLaunchKernelGGL(walker_step_wave_kernel<14>, dim3(n), dim3(WV), lds, (hipStream_t)stream, *tp, *ms, *prm, *st,
-                           n, maxr_flags, action, obs, reward, rewards5, done);
-    else if (ndof <= 23)
-        hipLaunchKernelGGL(walker_step_wave_kernel<23>, dim3(n), dim3(WV), lds, (hipStream_t)stream, *tp, *ms, *prm, *st,
-                           n, maxr_flags, action, obs, reward, rewards5, done);
-    else
-        hipLaunchKernelGGL(walker_step_wave_kernel<ND>, dim3(n), dim3(WV), lds, (hipStream_t)stream, *tp, *ms, *prm, *st,
-                           n, maxr_flags, action, obs, reward, rewards5, done);
+    // ... and so is the whole robot shape for the two robots MetaLocomotion ships (LDS addresses and model-table
+    // offsets become literals); any other topology runs the shape-generic instantiations
+    using Humanoid = Shape<13, 17, 29, 17, 1>;
+    using Ant = Shape<13, 8, 25, 13, 1>;
+    auto is_shape = [&](int b, int j, int s, int g) {
+        return overlay && tp->n_bodies == b && tp->n_joints == j && tp->n_spheres == s && tp->n_geoms == g;
+    };
+#define MG_WALKER_LAUNCH(NMAX_, SHAPE_)                                                                                  \
+    hipLaunchKernelGGL((walker_step_wave_kernel<NMAX_, SHAPE_>), dim3(n), dim3(WV), lds, (hipStream_t)stream, *tp, *ms, \
+                       *prm, *st, n, maxr_flags, action, obs, reward, rewards5, done)
+    if (is_shape(Humanoid::nb, Humanoid::nj, Humanoid::ns, Humanoid::ng)) MG_WALKER_LAUNCH(23, Humanoid);
+    else if (is_shape(Ant::nb, Ant::nj, Ant::ns, Ant::ng)) MG_WALKER_LAUNCH(14, Ant);
+    else if (ndof <= 14) MG_WALKER_LAUNCH(14, ShapeAny);
+    else if (ndof <= 23) MG_WALKER_LAUNCH(23, ShapeAny);
+    else MG_WALKER_LAUNCH(ND, ShapeAny);
+#undef MG_WALKER_LAUNCH
     return mg::check_launch("walker_step_wave_kernel");
 }
