@@ -680,7 +680,6 @@ __device__ __forceinline__ double wave_sum32(double v) {
 struct WaveLds {   // pointers into the env's LDS slab
     double *R, *o, *c, *p, *a;               // kinematics
     double *fw, *fal, *fxr, *far_;           // frames after each body's joints
-    double *F, *Nn, *Iw;                     // per-body bias wrench and world inertia
     double *M, *h, *idg;                     // joint-space inertia (then its packed Cholesky factor), bias, 1/diag(L)
                                              // vector, reciprocal Cholesky diagonal
     double *q, *qd, *tau;
@@ -688,19 +687,18 @@ struct WaveLds {   // pointers into the env's LDS slab
     double *J, *bias, *diag, *lam;            // J: constraint rows, whitened in place (Jh = J L^-T)
     double *cx;                              // per contact: ground (x, y, depth) or self (point xc, normal)
     double *sc;                              // sin / cos of every joint angle
-    int *mask, *depth, *jstart, *jcount, *poff, *kind, *partner, *csphere, *misc, *bod;
+    int *mask, *depth, *jstart, *jcount, *kids, *kind, *partner, *csphere, *misc, *dbody;
     int *parent, *sbody;                     // topology tables copied out of the kernarg segment: body_parent, sphere_body
-    short *ptab;                             // (body | dof << 8) of every Jacobian pair — topology only, built once per launch
 };
 
 // LDS layout. The solver works in Cholesky-whitened velocities y = L^T u (M = L L^T): with Jh = J L^-T
 //     J M^-1 J^T = Jh Jh^T,   J u = Jh y,   u += M^-1 J^T dl  <=>  y += Jh^T dl,
 // so ONE constraint matrix Jh (maxr rows of n doubles) replaces both J and W = M^-1 J^T, and a row costs one
 // forward substitution instead of a forward and a backward one. Blocks with disjoint lifetimes share storage:
-//  * the Jh block is scratch while M and h are assembled: the (body, dof) Jacobian pairs grow from its start,
-//    the Newton-Euler temporaries (velocity-product frames fw/fal/fxr/far, body wrenches F/Nn, world
-//    inertias Iw: 27 doubles per body) sit at its end — both dead before the first constraint row is written
-//    (`overlay` says whether they fit; mg_walker_step computes it from the topology);
+//  * the Jh block is scratch while M and h are assembled: the composite-rigid-body tables (16 doubles per body,
+//    12 per generalized coordinate) at its start, the velocity-product frames of the Newton-Euler pass
+//    (fw/fal/fxr/far: 12 doubles per body) at its end — all dead before the first constraint row is written
+//    (`overlay` says whether the frames fit too; mg_walker_step computes it from the topology);
 //  * the solver's reciprocal diagonals and multipliers (diag, lam: 2 maxr doubles) are first written after the
 //    constraint rows are complete, when the body frames R / o / c (15 doubles per body) are dead until the
 //    next kinematics pass;
@@ -712,14 +710,15 @@ struct WaveLds {   // pointers into the env's LDS slab
 __host__ __device__ inline bool wave_lds_alias2(int nb, int maxr) { return 2 * (size_t)maxr <= 15 * (size_t)nb; }
 __host__ __device__ inline size_t wave_lds_doubles(int nb, int nj, int maxr, bool overlay) {
     const int n = 6 + nj;
-    return (size_t)nb * 15 + (size_t)nj * 6 + (overlay ? 0 : 27 * (size_t)nb) + (size_t)n * (n + 1) / 2 + 2 * (size_t)n +
+    return (size_t)nb * 15 + (size_t)nj * 6 + (overlay ? 0 : 12 * (size_t)nb) + (size_t)n * (n + 1) / 2 + 2 * (size_t)n +
            3 * (size_t)nj + 18 + (size_t)maxr * n + (wave_lds_alias2(nb, maxr) ? 1 : 3) * (size_t)maxr +
            6 * (size_t)W_MAXC + (2 * (size_t)nj <= 6 * (size_t)W_MAXC ? 0 : 2 * (size_t)nj);
 }
-// + the (body, dof) pair table: one int16 per pair, at most maxr * ND / 6 pairs fit the assembly scratch
 __host__ __device__ inline size_t wave_lds_ints(int nb, int ns, int maxr) {
-    return 6 * (size_t)nb + (size_t)ns + 2 * (size_t)maxr + 2 * W_MAXC + 8 + ND + ((size_t)maxr * ND / 6 + 2) / 2;
+    return 6 * (size_t)nb + (size_t)ns + 2 * (size_t)maxr + 2 * W_MAXC + 8 + ND;
 }
+// doubles of the Jh block the M / h assembly uses as scratch (composite tables; + the frames when overlaid)
+__host__ __device__ inline size_t wave_assembly_doubles(int nb, int nj) { return 16 * (size_t)nb + 12 * (size_t)(6 + nj); }
 
 __device__ __forceinline__ WaveLds carve(unsigned char *smem, int nb, int nj, int ns, int maxr, bool overlay) {
     const int n = 6 + nj;
@@ -727,14 +726,13 @@ __device__ __forceinline__ WaveLds carve(unsigned char *smem, int nb, int nj, in
     double *d = reinterpret_cast<double *>(smem);
     L.R = d; d += 9 * nb; L.o = d; d += 3 * nb; L.c = d; d += 3 * nb; L.p = d; d += 3 * nj; L.a = d; d += 3 * nj;
     double *ne = d;                       // Newton-Euler temporaries: own block, or the tail of the Jh block
-    if (!overlay) d += 27 * nb;
+    if (!overlay) d += 12 * nb;
     L.M = d; d += n * (n + 1) / 2; L.h = d; d += n; L.idg = d; d += n;
     L.q = d; d += nj; L.qd = d; d += nj; L.tau = d; d += nj;
     L.base = d; d += 18;
     L.J = d; d += (size_t)maxr * n;       // constraint rows, whitened in place (Jh)
-    if (overlay) ne = d - 27 * nb;
-    L.fw = ne; ne += 3 * nb; L.fal = ne; ne += 3 * nb; L.fxr = ne; ne += 3 * nb; L.far_ = ne; ne += 3 * nb;
-    L.F = ne; ne += 3 * nb; L.Nn = ne; ne += 3 * nb; L.Iw = ne;
+    if (overlay) ne = d - 12 * nb;
+    L.fw = ne; ne += 3 * nb; L.fal = ne; ne += 3 * nb; L.fxr = ne; ne += 3 * nb; L.far_ = ne;
     L.bias = d; d += maxr;
     if (wave_lds_alias2(nb, maxr)) { L.diag = L.R; L.lam = L.R + maxr; }
     else { L.diag = d; d += maxr; L.lam = d; d += maxr; }
@@ -742,10 +740,9 @@ __device__ __forceinline__ WaveLds carve(unsigned char *smem, int nb, int nj, in
     if (2 * nj <= 6 * W_MAXC) L.sc = L.cx;
     else { L.sc = d; d += 2 * nj; }
     int *i = reinterpret_cast<int *>(d);
-    L.mask = i; i += nb; L.depth = i; i += nb; L.jstart = i; i += nb; L.jcount = i; i += nb; L.poff = i; i += nb;
-    L.kind = i; i += maxr; L.partner = i; i += maxr; L.csphere = i; i += 2 * W_MAXC; L.misc = i; i += 8; L.bod = i; i += ND;
+    L.mask = i; i += nb; L.depth = i; i += nb; L.jstart = i; i += nb; L.jcount = i; i += nb; L.kids = i; i += nb;
+    L.kind = i; i += maxr; L.partner = i; i += maxr; L.csphere = i; i += 2 * W_MAXC; L.misc = i; i += 8; L.dbody = i; i += ND;
     L.parent = i; i += nb; L.sbody = i; i += ns;
-    L.ptab = reinterpret_cast<short *>(i);
     return L;
 }
 
@@ -853,92 +850,101 @@ __device__ __forceinline__ void wave_substep(const mg_walker_topology &tp, const
     // 64-bit masks and spilled to VGPR lanes; one v_cmp where it is needed is cheaper than the reload.
     asm volatile("" : "+v"(lane));
     wave_kinematics(m, L, lane, max_depth, true);
-    // ---- per-body world inertia and bias wrench (lane = body) ---------------------------------------
+    // ---- M and h by the composite-rigid-body algorithm (Featherstone RBDA ch. 6) in world coordinates, all spatial
+    //      quantities taken about the base origin O so that subtree sums are plain sums:
+    //        body b:  mass m, first moment m r, inertia about O  I_O = I_c + m (|r|^2 1 - r r^T),  r = c_b - O,
+    //                 bias wrench (F, N_O = N + r x F) of the velocity-product accelerations;
+    //        subtree(b) = own + children, pulled level by level from the leaves;
+    //        dof d on body b_d:  S_d = (v_O, w) = velocity of the point at O and angular velocity per unit u_d,
+    //                 F_d = I^c_subtree(b_d) S_d = (m v + w x mr,  mr x v + I_O w),   h_d = S_d . (F, N_O)^c;
+    //        M[d][e] = S_e . F_d  when dof e lies on the chain from the base to b_d (e <= d), else 0.
+    //      Algebraically the same M = sum_b m Jv^T Jv + Jw^T I_c Jw as the lane kernel / oracle/abd.py assemble from
+    //      per-body Jacobians; it replaces 133 (body, dof) Jacobian pairs and a sum over common bodies per matrix
+    //      entry (26 % of the sub-step) by 13 + 23 small lane-parallel items and one 6-term dot product per entry.
+    double *comp = L.J;                 // [nb][16]: m, m r (3), I_O (xx xy xz yy yz zz), F (3), N_O (3)
+    double *Sd = comp + 16 * nb;        // [n][6]
+    double *Fd = Sd + 6 * n;            // [n][6]
+    const V3 O = ldv(L.o, 0);
     if (lane < nb) {
         const int b = lane;
         const V3 w = ldv(L.fw, b), al = ldv(L.fal, b), xr = ldv(L.fxr, b), ar = ldv(L.far_, b);
-        const V3 r = ldv(L.c, b) - xr;
-        const V3 a_c = ar + cross(al, r) + cross(w, cross(w, r));
-        // World inertia in factored form: I_body = C C^T (3x3 Cholesky of a model constant), A = R C, so
-        // Iw = A A^T and the joint-space inertia becomes a plain sum of dot products of "whitened" Jacobian
-        // pairs (sqrt(m) jv, A^T jw) — no 3x3 inertia product per (matrix entry, body) later on. The bias
-        // wrench is stored whitened the same way: F / sqrt(m) and A^-1 N.
+        const V3 cb = ldv(L.c, b);
+        const V3 rx = cb - xr;
+        const V3 a_c = ar + cross(al, rx) + cross(w, cross(w, rx));
         const double *Ib = m.body_inertia() + 9 * b;
-        const double c00 = sqrt(Ib[0]), c10 = Ib[3] / c00, c20 = Ib[6] / c00;
-        const double c11 = sqrt(Ib[4] - c10 * c10), c21 = (Ib[7] - c20 * c10) / c11;
-        const double c22 = sqrt(Ib[8] - c20 * c20 - c21 * c21);
         const double *R = L.R + 9 * b;
-        double A[9];
-        for (int i = 0; i < 3; ++i) {
-            A[3 * i] = R[3 * i] * c00 + R[3 * i + 1] * c10 + R[3 * i + 2] * c20;
-            A[3 * i + 1] = R[3 * i + 1] * c11 + R[3 * i + 2] * c21;
-            A[3 * i + 2] = R[3 * i + 2] * c22;
-        }
-        for (int i = 0; i < 9; ++i) L.Iw[9 * b + i] = A[i];
-        auto At = [&](V3 x) { return V3{A[0] * x.x + A[3] * x.y + A[6] * x.z, A[1] * x.x + A[4] * x.y + A[7] * x.z,
-                                        A[2] * x.x + A[5] * x.y + A[8] * x.z}; };
-        auto Iw_times = [&](V3 x) { return mulMv(A, At(x)); };
-        const double mass = m.body_mass()[b], sm = sqrt(mass);
+        double RI[9];
+        mulMM(R, Ib, RI);                // I_c = R I_body R^T, symmetric
+        const double ixx = RI[0] * R[0] + RI[1] * R[1] + RI[2] * R[2], ixy = RI[0] * R[3] + RI[1] * R[4] + RI[2] * R[5],
+                     ixz = RI[0] * R[6] + RI[1] * R[7] + RI[2] * R[8], iyy = RI[3] * R[3] + RI[4] * R[4] + RI[5] * R[5],
+                     iyz = RI[3] * R[6] + RI[4] * R[7] + RI[5] * R[8], izz = RI[6] * R[6] + RI[7] * R[7] + RI[8] * R[8];
+        auto Ic = [&](V3 x) { return V3{ixx * x.x + ixy * x.y + ixz * x.z, ixy * x.x + iyy * x.y + iyz * x.z,
+                                        ixz * x.x + iyz * x.y + izz * x.z}; };
+        const double mass = m.body_mass()[b];
         const V3 F = mass * (a_c - v3(0, 0, -prm.gravity));
-        const V3 N = Iw_times(al) + cross(w, Iw_times(w));
-        stv(L.F, b, (1.0 / sm) * F);
-        // A^-1 N = C^-1 (R^T N): forward substitution with the lower-triangular C
-        const V3 y{R[0] * N.x + R[3] * N.y + R[6] * N.z, R[1] * N.x + R[4] * N.y + R[7] * N.z,
-                   R[2] * N.x + R[5] * N.y + R[8] * N.z};
-        const double z0 = y.x / c00, z1 = (y.y - c10 * z0) / c11, z2 = (y.z - c20 * z0 - c21 * z1) / c22;
-        stv(L.Nn, b, V3{z0, z1, z2});
-        L.fal[3 * b] = sm;        // the acceleration frame of this body is dead from here on: park sqrt(m) in it
+        const V3 N = Ic(al) + cross(w, Ic(w));
+        const V3 r = cb - O;
+        const V3 NO = N + cross(r, F);
+        const double rr = dot(r, r);
+        double *cp = comp + 16 * b;
+        cp[0] = mass; cp[1] = mass * r.x; cp[2] = mass * r.y; cp[3] = mass * r.z;
+        cp[4] = ixx + mass * (rr - r.x * r.x); cp[5] = ixy - mass * r.x * r.y; cp[6] = ixz - mass * r.x * r.z;
+        cp[7] = iyy + mass * (rr - r.y * r.y); cp[8] = iyz - mass * r.y * r.z; cp[9] = izz + mass * (rr - r.z * r.z);
+        cp[10] = F.x; cp[11] = F.y; cp[12] = F.z; cp[13] = NO.x; cp[14] = NO.y; cp[15] = NO.z;
     }
     WSYNC();
-    // ---- Jacobian columns of every (body, active dof) pair, lane-strided; parked in the J region, which
-    //      the constraints only claim later in the sub-step -------------------------------------------
-    double *pairs = L.J;          // [n_pairs][6] = whitened (jv, jw), see the inertia factorisation above
-    // flat over all (body, dof) pairs — 133 for the humanoid, three passes of the wave — instead of one pass
-    // per body with a dozen active lanes
-    const int n_pairs_tot = L.misc[1];
-    for (int q = lane; q < n_pairs_tot; q += WV) {
-        const int pe = L.ptab[q];
-        const int b = pe & 0xff, d = pe >> 8;
-        const unsigned mk = (unsigned)L.mask[b];
-        const V3 jv = wjac_lin(L, mk, ldv(L.c, b), d), jw = wjac_ang(L, mk, d);
-        const double sm = L.fal[3 * b];
-        const double *A = L.Iw + 9 * b;
-        double *pp = pairs + (size_t)q * 6;          // whitened pair: (sqrt(m) jv, A^T jw)
-        pp[0] = sm * jv.x; pp[1] = sm * jv.y; pp[2] = sm * jv.z;
-        pp[3] = A[0] * jw.x + A[3] * jw.y + A[6] * jw.z;
-        pp[4] = A[1] * jw.x + A[4] * jw.y + A[7] * jw.z;
-        pp[5] = A[2] * jw.x + A[5] * jw.y + A[8] * jw.z;
+    for (int level = max_depth - 1; level >= 0; --level) {      // subtree sums: a body pulls its finished children
+        if (lane < nb && L.depth[lane] == level) {
+            unsigned kids = (unsigned)L.kids[lane];
+            if (kids) {
+                double acc[16];
+                double *cp = comp + 16 * lane;
+                for (int i = 0; i < 16; ++i) acc[i] = cp[i];
+                for (; kids != 0; kids &= kids - 1) {
+                    const double *ck = comp + 16 * (__ffs(kids) - 1);
+                    for (int i = 0; i < 16; ++i) acc[i] += ck[i];
+                }
+                for (int i = 0; i < 16; ++i) cp[i] = acc[i];
+            }
+        }
+        WSYNC();
+    }
+    if (lane < n) {
+        const int d = lane;
+        V3 v{0, 0, 0}, w{0, 0, 0};
+        int b = 0;
+        if (d < 3) v = V3{d == 0 ? 1.0 : 0.0, d == 1 ? 1.0 : 0.0, d == 2 ? 1.0 : 0.0};
+        else if (d < 6) w = V3{d == 3 ? 1.0 : 0.0, d == 4 ? 1.0 : 0.0, d == 5 ? 1.0 : 0.0};
+        else {
+            w = ldv(L.a, d - 6);
+            v = cross(w, O - ldv(L.p, d - 6));
+            b = L.dbody[d];
+        }
+        const double *cp = comp + 16 * b;
+        const double mass = cp[0];
+        const V3 hc{cp[1], cp[2], cp[3]};
+        const V3 pl = mass * v + cross(w, hc);
+        const V3 Iw{cp[4] * w.x + cp[5] * w.y + cp[6] * w.z, cp[5] * w.x + cp[7] * w.y + cp[8] * w.z,
+                    cp[6] * w.x + cp[8] * w.y + cp[9] * w.z};
+        const V3 Lo = cross(hc, v) + Iw;
+        double *sp = Sd + 6 * d, *fp = Fd + 6 * d;
+        sp[0] = v.x; sp[1] = v.y; sp[2] = v.z; sp[3] = w.x; sp[4] = w.y; sp[5] = w.z;
+        fp[0] = pl.x; fp[1] = pl.y; fp[2] = pl.z; fp[3] = Lo.x; fp[4] = Lo.y; fp[5] = Lo.z;
+        L.h[d] = dot(v, V3{cp[10], cp[11], cp[12]}) + dot(w, V3{cp[13], cp[14], cp[15]});
     }
     WSYNC();
-    auto pair_index = [&](int b, unsigned mk, int d) {
-        return L.poff[b] + (d < 6 ? d : 6 + __popc(mk & ((1u << (d - 6)) - 1u)));
-    };
-    // ---- M (lower triangle) and h: lane-strided over entries ----------------------------------------
     for (int t = lane; t < n * (n + 1) / 2; t += WV) {      // packed lower triangle: every lane has an entry
         int d = (int)((sqrtf(8.0f * (float)t + 1.0f) - 1.0f) * 0.5f);
         while ((d + 1) * (d + 2) / 2 <= t) ++d;
         while (d * (d + 1) / 2 > t) --d;
         const int e = t - d * (d + 1) / 2;
         double acc = 0.0;
-        for (unsigned bm = (unsigned)L.bod[d] & (unsigned)L.bod[e]; bm != 0; bm &= bm - 1) {
-            const int b = __ffs(bm) - 1;
-            const unsigned mk = (unsigned)L.mask[b];
-            const double *pd = pairs + (size_t)pair_index(b, mk, d) * 6, *pe = pairs + (size_t)pair_index(b, mk, e) * 6;
-            acc += (pd[0] * pe[0] + pd[1] * pe[1] + pd[2] * pe[2]) + (pd[3] * pe[3] + pd[4] * pe[4] + pd[5] * pe[5]);
+        if (e < 6 || (((unsigned)L.mask[L.dbody[d]] >> (e - 6)) & 1u)) {
+            const double *se = Sd + 6 * e, *fd = Fd + 6 * d;
+            acc = (se[0] * fd[0] + se[1] * fd[1] + se[2] * fd[2]) + (se[3] * fd[3] + se[4] * fd[4] + se[5] * fd[5]);
         }
         if (d == e && d >= 6) acc += m.joint_arm()[d - 6];
         L.M[t] = acc;                                       // t == TRI(d, e)
-    }
-    if (lane < n) {
-        const int d = lane;
-        double acc = 0.0;
-        for (unsigned bm = (unsigned)L.bod[d]; bm != 0; bm &= bm - 1) {
-            const int b = __ffs(bm) - 1;
-            const unsigned mk = (unsigned)L.mask[b];
-            const double *pd = pairs + (size_t)pair_index(b, mk, d) * 6;
-            acc += dot(V3{pd[0], pd[1], pd[2]}, ldv(L.F, b)) + dot(V3{pd[3], pd[4], pd[5]}, ldv(L.Nn, b));
-        }
-        L.h[d] = acc;
     }
     WSYNC();
     // ---- Cholesky in registers: lane i keeps row i of the lower triangle in a fully unrolled NMAX-slot
@@ -1215,40 +1221,18 @@ __global__ __launch_bounds__(WV) void walker_step_wave_kernel(mg_walker_topology
         }
         L.misc[0] = md;
         // topology-only tables of the mass-matrix assembly, built once per launch: the joints on each body's
-        // chain (mask), where each body's (body, dof) Jacobian pairs start (poff), their total (misc[1])
-        int off = 0;
+        // chain (mask), its children (kids), the body every generalized coordinate sits on (dbody)
         for (int b = 0; b < nb; ++b) {
             const int pb = L.parent[b];
             unsigned mk = pb < 0 ? 0u : (unsigned)L.mask[pb];
-            for (int jj = L.jstart[b]; jj < L.jstart[b] + L.jcount[b]; ++jj) mk |= 1u << jj;
+            for (int jj = L.jstart[b]; jj < L.jstart[b] + L.jcount[b]; ++jj) { mk |= 1u << jj; L.dbody[6 + jj] = b; }
             L.mask[b] = (int)mk;
-            L.poff[b] = off;
-            off += 6 + __popc(mk);
+            L.kids[b] = 0;
+            if (pb >= 0) L.kids[pb] |= 1 << b;
         }
-        L.misc[1] = off;
+        for (int d = 0; d < 6; ++d) L.dbody[d] = 0;
     }
     WSYNC();
-    {
-        const int n = 6 + nj;
-        if (lane < n) {   // bodies each dof moves, as a bitmask: M[d][e] only sums bodies in bod[d] & bod[e]
-            unsigned bm = 0;
-            for (int b = 0; b < nb; ++b)
-                if (lane < 6 || (((unsigned)L.mask[b] >> (lane - 6)) & 1u)) bm |= 1u << b;
-            L.bod[lane] = (int)bm;
-        }
-        for (int q = lane; q < L.misc[1]; q += WV) {
-            int b = 0;
-            while (b + 1 < nb && L.poff[b + 1] <= q) ++b;
-            const int l = q - L.poff[b];
-            int d = l;       // l-th active dof of body b: 0..5 = base, then the set bits of its mask in ascending order
-            if (l >= 6) {
-                unsigned rem = (unsigned)L.mask[b];
-                for (int k = 6; k < l; ++k) rem &= rem - 1;
-                d = 6 + __ffs(rem) - 1;
-            }
-            L.ptab[q] = (short)(b | (d << 8));
-        }
-    }
     if (lane < 3) {
         L.base[lane] = st.pos[(size_t)lane * n_envs + e];
         L.base[12 + lane] = st.vel[(size_t)lane * n_envs + e];
@@ -1436,24 +1420,15 @@ extern "C" int mg_walker_step(const mg_walker_topology *tp, const mg_walker_mode
     if (tp->n_spheres > 64 || 6 + tp->n_joints > 64)
         return mg::set_error(MG_ERR_BAD_SIZE, "wave mapping needs <= 64 spheres and <= 58 joints");
     const int maxr = 3 * W_MAXC + tp->n_joints;
-    // scratch use of the Jh block during the M / h assembly: 6 doubles per (body, dof-on-its-chain) pair from the
-    // front and, when they also fit, 27 doubles per body of Newton-Euler temporaries from the back
+    // scratch use of the Jh block during the M / h assembly: the composite-rigid-body tables from the front and, when
+    // they also fit, the 12 doubles per body of velocity-product frames from the back
     bool overlay = false;
     {
-        int chain[MG_WALKER_MAX_BODIES];
-        size_t pairs = 0;
-        for (int b = 0; b < tp->n_bodies; ++b) {
-            int own = 0;
-            for (int j = 0; j < tp->n_joints; ++j) own += tp->joint_body[j] == b;
-            const int pb = tp->body_parent[b];
-            chain[b] = own + (pb >= 0 && pb < b ? chain[pb] : 0);
-            pairs += 6 + chain[b];
-        }
-        const size_t block = (size_t)maxr * ndof_of(tp);
-        if (6 * pairs > block)
+        const size_t block = (size_t)maxr * ndof_of(tp), need = wave_assembly_doubles(tp->n_bodies, tp->n_joints);
+        if (need > block)
             return mg::set_error(MG_ERR_UNSUPPORTED, "walker topology needs %zu scratch doubles for the mass-matrix "
-                                 "assembly, the wave mapping has %zu: use mapping = lane", 6 * pairs, block);
-        overlay = 6 * pairs + 27 * (size_t)tp->n_bodies <= block;
+                                 "assembly, the wave mapping has %zu: use mapping = lane", need, block);
+        overlay = need + 12 * (size_t)tp->n_bodies <= block;
     }
     const size_t lds = wave_lds_doubles(tp->n_bodies, tp->n_joints, maxr, overlay) * sizeof(double) +
                        wave_lds_ints(tp->n_bodies, tp->n_spheres, maxr) * sizeof(int);
