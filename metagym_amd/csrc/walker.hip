@@ -677,6 +677,22 @@ __device__ __forceinline__ double wave_sum32(double v) {
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");  \
     } while (0)
 
+// Optional phase profile (-DMG_WALKER_PROFILE, timing builds only: scripts/walker_phases.py): shader-clock deltas
+// between the phase boundaries of the wave kernel, summed over all waves of a launch.
+#ifdef MG_WALKER_PROFILE
+__device__ unsigned long long mg_walker_phase_cycles[16];
+#define PHASE_BEGIN() unsigned long long ph_t0 = __builtin_readcyclecounter()
+#define PHASE(i)                                                                          \
+    do {                                                                                  \
+        const unsigned long long ph_t1 = __builtin_readcyclecounter();                    \
+        if (lane == 0) atomicAdd(&mg_walker_phase_cycles[i], ph_t1 - ph_t0);               \
+        ph_t0 = ph_t1;                                                                    \
+    } while (0)
+#else
+#define PHASE_BEGIN() do { } while (0)
+#define PHASE(i) do { } while (0)
+#endif
+
 struct WaveLds {   // pointers into the env's LDS slab
     double *R, *o, *c, *p, *a;               // kinematics
     double *fw, *fal, *fxr, *far_;           // frames after each body's joints
@@ -849,7 +865,9 @@ __device__ __forceinline__ void wave_substep(const mg_walker_topology &tp, const
     // code (lane == c, k <= lane, ...) are invariant across the sub-step loop, so they were hoisted out of it as
     // 64-bit masks and spilled to VGPR lanes; one v_cmp where it is needed is cheaper than the reload.
     asm volatile("" : "+v"(lane));
+    PHASE_BEGIN();
     wave_kinematics(m, L, lane, max_depth, true);
+    PHASE(0);
     // ---- M and h by the composite-rigid-body algorithm (Featherstone RBDA ch. 6) in world coordinates, all spatial
     //      quantities taken about the base origin O so that subtree sums are plain sums:
     //        body b:  mass m, first moment m r, inertia about O  I_O = I_c + m (|r|^2 1 - r r^T),  r = c_b - O,
@@ -909,6 +927,7 @@ __device__ __forceinline__ void wave_substep(const mg_walker_topology &tp, const
         }
         WSYNC();
     }
+    PHASE(1);
     if (lane < n) {
         const int d = lane;
         V3 v{0, 0, 0}, w{0, 0, 0};
@@ -947,36 +966,19 @@ __device__ __forceinline__ void wave_substep(const mg_walker_topology &tp, const
         L.M[t] = acc;                                       // t == TRI(d, e)
     }
     WSYNC();
-    // ---- Cholesky in registers: lane i keeps row i of the lower triangle in a fully unrolled NMAX-slot
-    //      array, so column c needs no LDS at all — L[i][k] is the lane's own slot k and L[c][k] is lane c's
-    //      slot k, read with v_readlane (a scalar operand of the FMA). Through LDS every step of the dot
-    //      products waited on two dependent reads (22 % of the sub-step). Slots above the diagonal hold
-    //      garbage that never reaches a valid entry. ---------------------------------------------------------
-    {
-        double row[NMAX];
-#pragma unroll
-        for (int k = 0; k < NMAX; ++k) row[k] = (lane < n && k <= lane) ? L.M[TRI(lane, k)] : 0.0;
-#pragma unroll
-        for (int c = 0; c < NMAX; ++c) {
-            if (c < n) {
-                double v = row[c];
-#pragma unroll
-                for (int k = 0; k < c; ++k) v -= row[k] * lane_value(row[k], c);
-                const double piv = sqrt(lane_value(v, c));
-                const double ipiv = 1.0 / piv;
-                row[c] = lane == c ? piv : v * ipiv;
-                if (lane == c) L.idg[c] = ipiv;
-            }
-        }
-#pragma unroll
-        for (int k = 0; k < NMAX; ++k)
-            if (lane < n && k <= lane) L.M[TRI(lane, k)] = row[k];
-    }
-    WSYNC();
-    // ---- free motion in whitened coordinates: y* = L^T u + dt L^-1 (tau - h) (one forward solve; the
-    //      backward solve happens once, after the constraint solver) ------------------------------------
+    PHASE(2);
+    // ---- Cholesky in registers, fused with the forward solve of the free motion: lane i keeps row i of the
+    //      lower triangle in a fully unrolled NMAX-slot array, so column c needs no LDS at all — L[i][k] is the
+    //      lane's own slot k and L[c][k] is lane c's slot k, read with v_readlane (a scalar operand of the FMA).
+    //      Slots above the diagonal hold garbage that never reaches a valid entry. The pivot's reciprocal square
+    //      root comes from v_rsq_f64 + two Newton steps (the IEEE sqrt followed by an IEEE division was ~550
+    //      dependent cycles per column, 16 % of a lone wave's sub-step). As soon as column c is final, L z = b
+    //      advances one step with it (z_c = b_c / L_cc; b_i -= L_ic z_c below the diagonal) — no LDS either.
+    //      Free motion in whitened coordinates: y* = L^T u + dt L^-1 (tau - h); the backward solve happens once,
+    //      after the constraint solver. -----------------------------------------------------------------------
     double u_d = 0.0;   // lane d < n: generalized velocity on entry, whitened velocity y_d from here on
     double x_d = 0.0;
+    double idg_d = 0.0; // lane d < n: 1 / L[d][d]
     if (lane < n) {
         const int d = lane;
         x_d = -L.h[d];
@@ -988,15 +990,59 @@ __device__ __forceinline__ void wave_substep(const mg_walker_topology &tp, const
             u_d = L.base[d < 3 ? 12 + d : 15 + (d - 3)];
         }
     }
-    double y_d = 0.0;
-    for (int r = 0; r < n; ++r) {
-        const double xr = lane_value(x_d, r) * L.idg[r];           // L z = b
-        if (lane == r) x_d = xr;
-        else if (lane > r && lane < n) x_d -= L.M[TRI(lane, r)] * xr;
-        const double ur = lane_value(u_d, r);                       // y = L^T u: y_d = sum_{r >= d} L[r][d] u_r
-        if (lane <= r) y_d += L.M[TRI(r, lane)] * ur;
+    const int lrow = lane < n ? lane : n - 1;
+    {
+        double row[NMAX];
+#pragma unroll
+        // unconditional reads at clamped (always valid) indices: a predicate per slot costs an exec-mask branch each
+        // and the 23 masks stay live (spilled) until the write-back below; slots above the diagonal may hold anything
+        for (int k = 0; k < NMAX; ++k) row[k] = L.M[TRI(lrow, k < lrow ? k : lrow)];
+        // right-looking: once column c is final every later column takes its rank-1 update at once — the n - c - 1
+        // FMAs of a step are independent of each other (the left-looking form chained c dependent FMAs per column)
+#pragma unroll
+        for (int c = 0; c < NMAX; ++c) {
+            if (c < n) {
+                const double vc = lane_value(row[c], c), hv = 0.5 * vc;
+                double ipiv = __builtin_amdgcn_rsq(vc);
+                ipiv = ipiv * fma(-hv * ipiv, ipiv, 1.5);
+                ipiv = ipiv * fma(-hv * ipiv, ipiv, 1.5);
+                const double lc = lane == c ? vc * ipiv : row[c] * ipiv;       // L[lane][c]
+                row[c] = lc;
+#pragma unroll
+                for (int k = c + 1; k < NMAX; ++k) {
+                    if (k < n) row[k] -= lc * lane_value(lc, k);               // M[lane][k] -= L[lane][c] L[k][c]
+                    // the broadcasts land in SGPRs: fence the scheduler every few columns, or it hoists all of a
+                    // step's v_readlane ahead of the FMAs and spills the SGPRs it ran out of
+                    if ((k - c) % 6 == 0) __builtin_amdgcn_sched_barrier(0);
+                }
+                idg_d = lane == c ? ipiv : idg_d;     // (no branch inside the column loop: the broadcasts above are
+                                                      // convergent and stay put, the FMAs would sink below it)
+                const double xr = lane_value(x_d, c) * ipiv;                   // L z = b, one column behind the factor
+                x_d = lane == c ? xr : (lane > c ? x_d - lc * xr : x_d);
+            }
+        }
+        if (lane < n) {     // descending: slots above the diagonal alias the diagonal's address and are overwritten by it
+            L.idg[lane] = idg_d;
+#pragma unroll
+            for (int k = NMAX - 1; k >= 0; --k) L.M[TRI(lane, k < lane ? k : lane)] = row[k];
+        }
     }
-    u_d = lane < n ? y_d + dt * x_d : 0.0;
+    WSYNC();
+    PHASE(3);
+    {   // y = L^T u: y_d = sum_{r >= d} L[r][d] u_r; the lane's column of L is fetched in one batch of LDS reads
+        double col[NMAX];
+#pragma unroll
+        for (int r = 0; r < NMAX; ++r) {
+            const double v = L.M[TRI(r > lrow ? (r < n ? r : n - 1) : lrow, lrow)];
+            col[r] = (r < n && r >= lane) ? v : 0.0;
+        }
+        double y_d = 0.0;
+#pragma unroll
+        for (int r = 0; r < NMAX; ++r)
+            if (r < n) y_d += col[r] * lane_value(u_d, r);
+        u_d = lane < n ? y_d + dt * x_d : 0.0;
+    }
+    PHASE(4);
     // ---- constraint detection ------------------------------------------------------------------------
     bool hit = false;
     double sx = 0, sy = 0, depth = 0;
@@ -1072,6 +1118,7 @@ __device__ __forceinline__ void wave_substep(const mg_walker_topology &tp, const
         L.bias[r] = prm.limit_erp * viol / dt; L.kind[r] = lsgn > 0.0 ? 4 : 5; L.partner[r] = lane;
     }
     WSYNC();
+    PHASE(5);
     // contact Jacobian rows, lane-strided over (contact, column)
     for (int t = lane; t < ncont * n; t += WV) {
         const int c = t / n, d = t % n;
@@ -1094,6 +1141,7 @@ __device__ __forceinline__ void wave_substep(const mg_walker_topology &tp, const
         }
     }
     WSYNC();
+    PHASE(6);
     // ---- Jh = J L^-T, lane = row, in place. The right-hand side lives in registers (a fully unrolled
     //      NMAX-slot array): through LDS every step of the substitution would wait on its own previous store.
     //      A joint-limit row starts as +-e_(6+j) and is never materialised before this point -------------------
@@ -1124,6 +1172,7 @@ __device__ __forceinline__ void wave_substep(const mg_walker_topology &tp, const
         L.lam[r] = 0.0;
     }
     WSYNC();
+    PHASE(7);
     // ---- projected Gauss-Seidel on the whitened velocity y (wave-uniform row loop) --------------------
     //      The row's Jacobian element and scalars are fetched one row AHEAD, so their LDS latency hides behind
     //      the previous row's reduction; the reduction itself only spans the lanes that hold coordinates.
@@ -1154,11 +1203,23 @@ __device__ __forceinline__ void wave_substep(const mg_walker_topology &tp, const
             if (lane == 0) L.lam[rr] = x;
         }
     }
-    // ---- back to generalized velocities: u = L^-T y ---------------------------------------------------
-    for (int r = n - 1; r >= 0; --r) {
-        const double xr = lane_value(u_d, r) * L.idg[r];
-        if (lane == r) u_d = xr;
-        else if (lane < r) u_d -= L.M[TRI(r, lane)] * xr;
+    PHASE(8);
+    // ---- back to generalized velocities: u = L^-T y (column of L in registers, reciprocal diagonal from the
+    //      owning lane: no LDS inside the dependent chain) ------------------------------------------------------
+    {
+        double col[NMAX];
+#pragma unroll
+        for (int r = 0; r < NMAX; ++r) {
+            const double v = L.M[TRI(r > lrow ? (r < n ? r : n - 1) : lrow, lrow)];
+            col[r] = (r < n && r > lane) ? v : 0.0;
+        }
+#pragma unroll
+        for (int r = NMAX - 1; r >= 0; --r) {
+            if (r < n) {
+                const double xr = lane_value(u_d * idg_d, r);
+                u_d = lane == r ? xr : u_d - col[r] * xr;
+            }
+        }
     }
     // ---- integrate -------------------------------------------------------------------------------------
     if (lane < n) {
@@ -1183,10 +1244,11 @@ __device__ __forceinline__ void wave_substep(const mg_walker_topology &tp, const
         }
     }
     WSYNC();
+    PHASE(9);
 }
 
 template <int NMAX, class SH>
-__global__ __launch_bounds__(WV) void walker_step_wave_kernel(mg_walker_topology tp, mg_walker_models ms,
+__global__ __launch_bounds__(WV) __attribute__((amdgpu_waves_per_eu(2))) void walker_step_wave_kernel(mg_walker_topology tp, mg_walker_models ms,
                                                               mg_walker_params prm, mg_walker_state st, int n_envs,
                                                               int maxr_flags, const float *action, float *obs,
                                                               float *reward, float *rewards5, uint8_t *done) {
@@ -1247,6 +1309,9 @@ __global__ __launch_bounds__(WV) void walker_step_wave_kernel(mg_walker_topology
     WSYNC();
     const int max_depth = L.misc[0];
     unsigned long long touch = 0ull;
+#ifdef MG_WALKER_PROFILE
+    unsigned long long ph_k0 = __builtin_readcyclecounter();
+#endif
     for (int it = 0; it < prm.frame_skip; ++it) wave_substep<NMAX>(tp, m, prm, L, lane, max_depth, maxr, touch);
     // ---- calc_state (walker_base.py:31-64) on the current configuration ------------------------------
     // after_reset = false: post-step state; the obs carries the PREVIOUS step's feet flags and the flags
@@ -1355,6 +1420,9 @@ __global__ __launch_bounds__(WV) void walker_step_wave_kernel(mg_walker_topology
         }
         WSYNC();
     }
+#ifdef MG_WALKER_PROFILE
+    if (lane == 0) atomicAdd(&mg_walker_phase_cycles[15], __builtin_readcyclecounter() - ph_k0);   // sub-steps + calc_state
+#endif
     // ---- state store ----------------------------------------------------------------------------------
     if (lane < 3) {
         st.pos[(size_t)lane * n_envs + e] = L.base[lane];
@@ -1392,6 +1460,17 @@ int check_walker(const mg_walker_topology *tp, const mg_walker_models *ms, const
 }
 
 }  // namespace
+
+#ifdef MG_WALKER_PROFILE
+extern "C" int mg_walker_profile_read(unsigned long long *out16, int clear) {
+    if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(mg_walker_phase_cycles), 16 * sizeof(unsigned long long)) != hipSuccess) return -1;
+    if (clear) {
+        unsigned long long z[16] = {0};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(mg_walker_phase_cycles), z, sizeof(z)) != hipSuccess) return -1;
+    }
+    return 0;
+}
+#endif
 
 extern "C" int mg_walker_reset(const mg_walker_topology *tp, const mg_walker_models *ms, const mg_walker_params *prm,
                                int32_t n, const mg_walker_state *st, const uint8_t *mask, const double *joint_noise,

@@ -1,0 +1,40 @@
+"""Phase profile of the walker wave kernel. Needs a -DMG_WALKER_PROFILE build:
+    scripts/build_variant.sh prof WORK -DMG_WALKER_PROFILE
+    METAGYM_HIP_LIB=$PWD/metagym_amd/lib/variants/prof.so python scripts/walker_phases.py [humanoid|ant] [n_envs]
+Prints the share of the shader-clock cycles each phase of the sub-step takes (summed over all waves)."""
+import ctypes
+import json
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+
+from metagym_amd import _lib
+from metagym_amd.metalocomotion import MetaAntEnv, MetaHumanoidEnv, variants
+
+NAMES = ["kinematics", "body inertia + subtree sums", "S_d, F_d, h and M entries", "Cholesky", "free motion",
+         "detection", "contact rows", "whitening", "PGS", "back-solve + integrate"]
+robot = sys.argv[1] if len(sys.argv) > 1 else "humanoid"
+n = int(sys.argv[2]) if len(sys.argv) > 2 else 8192
+cls = MetaHumanoidEnv if robot == "humanoid" else MetaAntEnv
+env = cls(num_envs=n, device="cuda:0")
+env.set_task(variants.models(robot, "TRAIN"))
+env.reset(seed=0)
+lib = _lib.load()
+buf = (ctypes.c_ulonglong * 16)()
+acts = [torch.rand(n, env.n_joints, device="cuda:0") * 2 - 1 for _ in range(8)]
+for i in range(10):
+    env.step(acts[i % 8])
+torch.cuda.synchronize()
+lib.mg_walker_profile_read(buf, 1)
+steps = 20
+for i in range(steps):
+    env.step(acts[i % 8])
+torch.cuda.synchronize()
+lib.mg_walker_profile_read(buf, 0)
+tot = sum(buf[i] for i in range(10))
+out = {NAMES[i]: round(100.0 * buf[i] / tot, 1) for i in range(10)}
+out["cycles_per_substep_per_wave"] = round(tot / (steps * n * 4))
+out["substeps_share_of_kernel_body"] = round(tot / buf[15], 3)
+print(json.dumps({"robot": robot, "envs": n, "phase_percent": out}))
