@@ -428,9 +428,11 @@ __device__ __forceinline__ ColRec bcast(const ColRec &r, int lane) {
 
 // Pass A, lane = screen column: ray_caster_utils.py:84-90 (direction tables), :11-62 (DDA_2D) and the
 // per-column parts of :155-205.
+template <int REC>
 __device__ ColRec column_pass(const ViewK &vk, const Task &t, const EnvShared &es, const int8_t *walls,
                               const uint8_t *texts, const double *transp, int col, int lane,
-                              uint2 *entries /* [t_max][SLAB] */, double cs, double inv_cs, int cs_pow2) {
+                              uint32_t *entries /* [t_max][SLAB] records of REC words */, double cs, double inv_cs,
+                              int cs_pow2) {
     const int n = t.n;
     const double chp = vk.col_cos[col], shp = vk.col_sin[col];
     const float sin_abs = (float)(shp * es.c_ori + chp * es.s_ori);
@@ -461,7 +463,13 @@ __device__ ColRec column_pass(const ViewK &vk, const Task &t, const EnvShared &e
         int e2 = to_int_clamped((vk.half_v + bv) / vk.pixel_size, -1, vk.V - 1);
         if (s2 < 0) s2 = 0;
         if (e2 > vk.V) e2 = vk.V;
-        entries[n_tr * vk.slab + lane] = make_uint2((unsigned)s2 | ((unsigned)e2 << 16), (unsigned)cell);
+        // compact record (one word: 12-bit span bounds, 8-bit cell) when the frame has < 4096 rows and the maze
+        // <= 256 cells — half the LDS of the overlay records, which is what bounds the resident envs per CU
+        if (REC == 1) entries[n_tr * vk.slab + lane] = (unsigned)s2 | ((unsigned)e2 << 12) | ((unsigned)cell << 24);
+        else {
+            entries[(n_tr * vk.slab + lane) * 2] = (unsigned)s2 | ((unsigned)e2 << 16);
+            entries[(n_tr * vk.slab + lane) * 2 + 1] = (unsigned)cell;
+        }
         ++n_tr;
     };
 
@@ -549,9 +557,10 @@ __device__ __forceinline__ RowK row_constants(const ViewK &vk, const Task &t, in
 // Pass B, lane = screen row d_v, for screen column `col` (slot `k` of the wave's 64): the floor /
 // ceiling cast (:102-126 / :135-153), then the wall column (:181-192), then the translucent
 // overlays in ray order (:194-205), then the life bar (maze_discrete_3d.py:118-126).
+template <int REC>
 __device__ __forceinline__ void pixel_pass(const ViewK &vk, const Task &t, double pos_x, double pos_y, const RowK &rk,
                                            const uint8_t *texts, const double *transp, const ColRec &wc,
-                                           const uint2 *entries, int k, int d_v, double cs, double inv_cs,
+                                           const uint32_t *entries, int k, int d_v, double cs, double inv_cs,
                                            int cs_pow2, double text_to_cell, double inv_ttc, int ttc_pow2,
                                            int fast_tex, double tex_scale, int cell_shift, int &R, int &G, int &B) {
     const int n = t.n, TS = vk.TS;
@@ -659,9 +668,16 @@ __device__ __forceinline__ void pixel_pass(const ViewK &vk, const Task &t, doubl
         B = (int)(light * (oma * tex_b(tx)));
     }
     for (int q = 0; q < n_tr; ++q) {                                          // :194-205
-        const uint2 en = entries[q * vk.slab + k];
-        if (!tflag && d_v >= (int)(en.x & 0xffffu) && d_v < (int)(en.x >> 16)) {
-            const double tf = transp[en.y] * 0.50 + 0.10, om = 1.0 - tf;
+        int lo, hi, cell;
+        if (REC == 1) {
+            const uint32_t en = entries[q * vk.slab + k];
+            lo = (int)(en & 0xfffu); hi = (int)((en >> 12) & 0xfffu); cell = (int)(en >> 24);
+        } else {
+            const uint32_t e0 = entries[(q * vk.slab + k) * 2], e1 = entries[(q * vk.slab + k) * 2 + 1];
+            lo = (int)(e0 & 0xffffu); hi = (int)(e0 >> 16); cell = (int)e1;
+        }
+        if (!tflag && d_v >= lo && d_v < hi) {
+            const double tf = transp[cell] * 0.50 + 0.10, om = 1.0 - tf;
             R = (int)(om * (double)R);
             G = (int)(om * (double)G + tf * 255.0);
             B = (int)(om * (double)B);
@@ -678,6 +694,7 @@ __device__ __forceinline__ void py_slice(long a, long b, long len, int &lo, int 
 
 struct int3s { int x, y, z; };   // 12-byte pixel, stored with one dwordx3
 
+template <int REC>     // words per translucent-cell record: 1 (compact) or 2
 __global__ __launch_bounds__(MZ_BLOCK) void maze3d_step_kernel(mg_maze_tasks T, mg_maze_state st, ViewK vk,
                                                                int task_type, int max_steps, int continuous,
                                                                int pre_moved, int auto_reset, int n_envs,
@@ -696,8 +713,8 @@ __global__ __launch_bounds__(MZ_BLOCK) void maze3d_step_kernel(mg_maze_tasks T, 
     size_t off = (sizeof(EnvShared) + 15) & ~size_t(15);
     double *transp = reinterpret_cast<double *>(smem + off);
     off += sizeof(double) * nn;
-    uint2 *entries_all = reinterpret_cast<uint2 *>(smem + off);
-    off += sizeof(uint2) * vk.slab * vk.t_max * n_waves;
+    uint32_t *entries_all = reinterpret_cast<uint32_t *>(smem + off);
+    off += sizeof(uint32_t) * REC * vk.slab * vk.t_max * n_waves;
     int8_t *walls = reinterpret_cast<int8_t *>(smem + off);
     off += (nn + 15) & ~15;
     uint8_t *texts = reinterpret_cast<uint8_t *>(smem + off);
@@ -792,7 +809,7 @@ __global__ __launch_bounds__(MZ_BLOCK) void maze3d_step_kernel(mg_maze_tasks T, 
         py_slice((long)sy, (long)(sy + 0.05 * vk.H), vk.V, lb_y0, lb_y1);
     }
 
-    uint2 *entries = entries_all + (size_t)wave * vk.slab * vk.t_max;
+    uint32_t *entries = entries_all + (size_t)wave * vk.slab * vk.t_max * REC;
     const double pos_x = es->pos[0], pos_y = es->pos[1];   // registers: the pixel loop must not re-read LDS for them
     int32_t *img = static_cast<int32_t *>(obs) + (size_t)e * vk.H * vk.V * 3;
     uint8_t *img8 = static_cast<uint8_t *>(obs) + (size_t)e * vk.H * vk.V * 3;
@@ -802,7 +819,7 @@ __global__ __launch_bounds__(MZ_BLOCK) void maze3d_step_kernel(mg_maze_tasks T, 
         const int ncols = min(slab, vk.H - cbase);
         ColRec mine{};
         if (lane < ncols)
-            mine = column_pass(vk, t, *es, walls, texts, transp, cbase + lane, lane, entries, cs, inv_cs, cs_pow2);
+            mine = column_pass<REC>(vk, t, *es, walls, texts, transp, cbase + lane, lane, entries, cs, inv_cs, cs_pow2);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -825,10 +842,12 @@ __global__ __launch_bounds__(MZ_BLOCK) void maze3d_step_kernel(mg_maze_tasks T, 
                 rk.light = row_tab[rt + 1];
                 rk.ys = row_tab[rt + 2];
                 int R, G, B;
-                pixel_pass(vk, t, pos_x, pos_y, rk, texts, transp, wc, entries, k, d_v, cs, inv_cs, cs_pow2, text_to_cell,
+                pixel_pass<REC>(vk, t, pos_x, pos_y, rk, texts, transp, wc, entries, k, d_v, cs, inv_cs, cs_pow2, text_to_cell,
                            inv_ttc, ttc_pow2, fast_tex, tex_scale, cell_shift, R, G, B);
-                if (in_lb_x && d_v >= lb_y0 && d_v < lb_y1) { R = 255; G = 0; B = 0; }
-                const uint32_t off = col_off + (uint32_t)d_v * px_bytes;
+                if (in_lb_x) {          // wave-uniform: most columns are outside the life bar, ESCAPE tasks have none
+                    if (d_v >= lb_y0 && d_v < lb_y1) { R = 255; G = 0; B = 0; }
+                }
+                const uint32_t off = col_off + __umul24((uint32_t)d_v, px_bytes);   // (a 32-bit multiply is quarter rate)
                 if (row_ok) {
                     if (vk.obs_u8) {      // non-parity fast path: saturate to a byte
                         uint8_t *q = img8 + off;
@@ -1038,8 +1057,9 @@ extern "C" int mg_maze3d_step(const mg_maze_tasks *T, const mg_maze_view *view, 
         }();
         if (ov.waves) { n_waves = ov.waves; vk.slab = ov.slab; }
     }
+    const int rec = (vk.V < 4096 && T->n * T->n <= 256) ? 1 : 2;
     const size_t lds = ((sizeof(EnvShared) + 15) & ~size_t(15)) + sizeof(double) * T->n * T->n +
-                       sizeof(uint2) * vk.slab * vk.t_max * n_waves +
+                       sizeof(uint32_t) * rec * vk.slab * vk.t_max * n_waves +
                        2 * ((size_t)(T->n * T->n + 15) & ~size_t(15)) + (sizeof(double) * 3 + 1) * (size_t)vk.V + 16;
     if (lds > 160 * 1024) return mg::set_error(MG_ERR_BAD_SIZE, "maze n=%d needs %zu B of LDS (> 160 KiB)", T->n, lds);
     const int device = mg::device_of(obs);
@@ -1049,9 +1069,11 @@ extern "C" int mg_maze3d_step(const mg_maze_tasks *T, const mg_maze_view *view, 
         static std::atomic<size_t> granted[MG_MAX_DEVICES];
         const int slot = (device >= 0 && device < MG_MAX_DEVICES) ? device : 0;
         if (device < 0 || device >= MG_MAX_DEVICES || lds > granted[slot].load(std::memory_order_relaxed)) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(maze3d_step_kernel),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            if (e != hipSuccess) return mg::check_hip(e, "hipFuncSetAttribute(maze3d_step_kernel)");
+            for (const void *fn : {reinterpret_cast<const void *>(maze3d_step_kernel<1>),
+                                   reinterpret_cast<const void *>(maze3d_step_kernel<2>)}) {
+                hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                if (e != hipSuccess) return mg::check_hip(e, "hipFuncSetAttribute(maze3d_step_kernel)");
+            }
             granted[slot].store(lds, std::memory_order_relaxed);
         }
     }
@@ -1062,7 +1084,11 @@ extern "C" int mg_maze3d_step(const mg_maze_tasks *T, const mg_maze_view *view, 
         if (int rc = mg::check_launch("maze_cont_move_kernel")) return rc;
         pre_moved = 1;
     }
-    hipLaunchKernelGGL(maze3d_step_kernel, dim3(n), dim3(n_waves * mg::WAVE), lds, (hipStream_t)stream, *T, *st, vk, task_type,
-                       max_steps, continuous, pre_moved, auto_reset, n, action, obs, reward, reward64, done);
+    if (rec == 1)
+        hipLaunchKernelGGL(maze3d_step_kernel<1>, dim3(n), dim3(n_waves * mg::WAVE), lds, (hipStream_t)stream, *T, *st, vk,
+                           task_type, max_steps, continuous, pre_moved, auto_reset, n, action, obs, reward, reward64, done);
+    else
+        hipLaunchKernelGGL(maze3d_step_kernel<2>, dim3(n), dim3(n_waves * mg::WAVE), lds, (hipStream_t)stream, *T, *st, vk,
+                           task_type, max_steps, continuous, pre_moved, auto_reset, n, action, obs, reward, reward64, done);
     return mg::check_launch("maze3d_step_kernel");
 }
