@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define MG_ABI_VERSION 2
+#define MG_ABI_VERSION 3
 
 #define MG_OK 0
 #define MG_ERR_NULL_POINTER (-1001)
@@ -433,6 +433,73 @@ int mg_walker_reset(const mg_walker_topology *topo, const mg_walker_models *mode
 int mg_walker_step(const mg_walker_topology *topo, const mg_walker_models *models, const mg_walker_params *prm,
                    int32_t n_envs, const mg_walker_state *state, const float *action, float *obs, float *reward,
                    float *rewards5, uint8_t *done, void *stream);
+
+/* ========================================================================================
+ * Quadrupedal (Unitree A1) — the ACTUATION path of metagym/quadrupedal/robots/minitaur.py + a1.py +
+ * laikago_motor.py for N robots: everything `Minitaur._StepInternal` (minitaur.py:232-238) does on either side of
+ * `pybullet.stepSimulation()`. The A1 body itself is NOT here: a1/a1.urdf ships with pybullet_data and the physics is
+ * PyBullet — neither is in the reference tree. Pinned bit for bit to the unmodified
+ * reference by tests/golden/a1_actuation.npz (oracle/gen_golden_a1.py).
+ *
+ * One sub-step of the reference is   ApplyAction -> stepSimulation -> ReceiveObservation:
+ *   mg_a1_apply_action          A1.ApplyAction a1.py:451-483 (optional command clip), Minitaur.ApplyAction
+ *                               minitaur.py:906-955, ProcessAction :1419-1436 (action interpolation),
+ *                               _GetPDObservation / _GetDelayedObservation :1205-1232 (pd latency),
+ *                               LaikagoMotorModel.convert_to_torque laikago_motor.py:92-169
+ *   (the caller advances its physics with the returned torques)
+ *   mg_a1_receive_observation   ReceiveObservation minitaur.py:1184-1203: GetTrueObservation :1175-1182 pushed on the
+ *                               history deque (maxlen 100, :139), control observation = history delayed by the
+ *                               control latency
+ *   mg_a1_sensors               GetMotorAngles / Velocities / Torques :755-810, GetBaseRollPitchYawRate :874-885,
+ *                               GetEnergyConsumptionPerControlStep :812-820 (sensor noise is zero, :48)
+ * All values are float64 like the reference's numpy arrays. Arrays are SoA: component c of robot e at base[c*N + e].
+ * ======================================================================================== */
+
+#define MG_A1_NUM_MOTORS 12
+#define MG_A1_OBS_DIM 43          /* motor angles 12, velocities 12, torques 12, base quaternion 4, rpy rate 3 */
+enum { MG_A1_MODE_POSITION = 1, MG_A1_MODE_TORQUE = 2, MG_A1_MODE_HYBRID = 3 };   /* robot_config.py:13-27 */
+
+typedef struct mg_a1_actuator_config {
+    double time_step;              /* 0.002  locomotion_gym_config.py:18 */
+    int32_t action_repeat;         /* 13     env_builder.py:45 */
+    int32_t history_len;           /* 100    minitaur.py:139 (deque maxlen); any value > latency / time_step + 1 gives
+                                      the same results once that many observations exist */
+    int32_t mode;                  /* MG_A1_MODE_* */
+    int32_t clip_commands;         /* A1._ClipMotorCommands a1.py:465-483 (POSITION commands only) */
+    double max_angle_change;       /* 0.2    a1.py:52 */
+    double control_latency, pd_latency;               /* seconds; used when the per-robot arrays below are NULL */
+    const double *control_latency_env, *pd_latency_env;   /* DEVICE [N] or NULL (locomotion_gym_env.py:349,374-375) */
+    double kp[MG_A1_NUM_MOTORS], kd[MG_A1_NUM_MOTORS];    /* a1.py:63-68 */
+    const double *kp_env, *kd_env;                        /* DEVICE [12][N] or NULL (SetMotorGains, :388-392) */
+    double strength[MG_A1_NUM_MOTORS];                    /* laikago_motor.py:58 */
+    double torque_limit[MG_A1_NUM_MOTORS];                /* 33.5 minitaur.py:88 */
+    int32_t has_torque_limit;
+} mg_a1_actuator_config;
+
+typedef struct mg_a1_actuator_state {
+    double *history;          /* DEVICE [history_len][43][N] ring of true observations */
+    int32_t *count;           /* DEVICE [N] observations held (<= history_len) */
+    int32_t *head;            /* DEVICE [N] ring slot of the newest observation */
+    double *observed_torque;  /* DEVICE [12][N] torques of the last ApplyAction (enter the next observation) */
+    double *control_obs;      /* DEVICE [43][N] observation delayed by the control latency */
+} mg_a1_actuator_state;
+
+/* command: DEVICE f64 [12][N] (POSITION / TORQUE) or [60][N] (HYBRID, laikago_motor.py:143-153). last_command may be
+ * NULL; otherwise the command used is last + lerp * (command - last) (ProcessAction, lerp = (substep + 1) / repeat).
+ * torque: DEVICE f64 [12][N] out (what _SetMotorTorqueByIds hands to the physics). */
+int mg_a1_apply_action(const mg_a1_actuator_config *cfg, int32_t n_envs, const mg_a1_actuator_state *state,
+                       const double *command, const double *last_command, double lerp, double *torque, void *stream);
+/* q, qd: DEVICE f64 [12][N] true motor angles / rates; base_quat [4][N] (x y z w, relative to the initial
+ * orientation); rpy_rate [3][N] angular velocity in the body frame. clear_mask: DEVICE u8 [N] or NULL — robots whose
+ * history is emptied first (Minitaur.Reset, minitaur.py:437). */
+int mg_a1_receive_observation(const mg_a1_actuator_config *cfg, int32_t n_envs, const mg_a1_actuator_state *state,
+                              const double *q, const double *qd, const double *base_quat, const double *rpy_rate,
+                              const uint8_t *clear_mask, void *stream);
+/* Any output may be NULL. motor_angles / motor_velocities / motor_torques: f64 [12][N]; rpy_rate f64 [3][N];
+ * energy f64 [N]. */
+int mg_a1_sensors(const mg_a1_actuator_config *cfg, int32_t n_envs, const mg_a1_actuator_state *state,
+                  double *motor_angles, double *motor_velocities, double *motor_torques, double *rpy_rate,
+                  double *energy, void *stream);
 
 #ifdef __cplusplus
 }

@@ -8,7 +8,7 @@ import os
 
 from . import build as _build
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 MG_OK = 0
 
@@ -127,6 +127,28 @@ class WalkerState(C.Structure):
                 ("feet_contact", C.c_void_p), ("steps", C.c_void_p)]
 
 
+A1_NUM_MOTORS, A1_OBS_DIM = 12, 43
+A1_MODE_POSITION, A1_MODE_TORQUE, A1_MODE_HYBRID = 1, 2, 3
+
+
+class A1ActuatorConfig(C.Structure):
+    """mg_a1_actuator_config"""
+    _fields_ = [("time_step", C.c_double), ("action_repeat", C.c_int32), ("history_len", C.c_int32),
+                ("mode", C.c_int32), ("clip_commands", C.c_int32), ("max_angle_change", C.c_double),
+                ("control_latency", C.c_double), ("pd_latency", C.c_double),
+                ("control_latency_env", C.c_void_p), ("pd_latency_env", C.c_void_p),
+                ("kp", C.c_double * A1_NUM_MOTORS), ("kd", C.c_double * A1_NUM_MOTORS),
+                ("kp_env", C.c_void_p), ("kd_env", C.c_void_p),
+                ("strength", C.c_double * A1_NUM_MOTORS), ("torque_limit", C.c_double * A1_NUM_MOTORS),
+                ("has_torque_limit", C.c_int32)]
+
+
+class A1ActuatorState(C.Structure):
+    """mg_a1_actuator_state (device pointers)"""
+    _fields_ = [("history", C.c_void_p), ("count", C.c_void_p), ("head", C.c_void_p),
+                ("observed_torque", C.c_void_p), ("control_obs", C.c_void_p)]
+
+
 # symbol -> (restype, argtypes); tests/test_abi.py checks this list against include/metagym_hip.h
 _P = C.c_void_p
 SIGNATURES = {
@@ -160,6 +182,12 @@ SIGNATURES = {
                                   C.c_int32, C.POINTER(WalkerState), _P, _P, _P, _P]),
     "mg_walker_step": (C.c_int, [C.POINTER(WalkerTopology), C.POINTER(WalkerModels), C.POINTER(WalkerParams),
                                  C.c_int32, C.POINTER(WalkerState), _P, _P, _P, _P, _P, _P]),
+    "mg_a1_apply_action": (C.c_int, [C.POINTER(A1ActuatorConfig), C.c_int32, C.POINTER(A1ActuatorState), _P, _P,
+                                     C.c_double, _P, _P]),
+    "mg_a1_receive_observation": (C.c_int, [C.POINTER(A1ActuatorConfig), C.c_int32, C.POINTER(A1ActuatorState),
+                                            _P, _P, _P, _P, _P, _P]),
+    "mg_a1_sensors": (C.c_int, [C.POINTER(A1ActuatorConfig), C.c_int32, C.POINTER(A1ActuatorState),
+                                _P, _P, _P, _P, _P, _P]),
 }
 
 _lib = None

@@ -1,0 +1,239 @@
+"""`A1Actuators` — N robots' worth of what `a1.A1` / `minitaur.Minitaur` / `LaikagoMotorModel` do around the physics
+step (metagym/quadrupedal/robots/a1.py, minitaur.py, laikago_motor.py), with the reference's method names.
+
+    act = A1Actuators(num_envs=4096, device="cuda:0")               # POSITION mode, kp/kd of a1.py:63-68
+    act.Reset()                                                     # Minitaur.Reset: history cleared
+    act.ReceiveObservation(q, qd, base_quat, rpy_rate)              # first observation (minitaur.py:226)
+    torques = act.Step(action, physics)                             # 13 x (ApplyAction -> physics -> ReceiveObservation)
+
+`physics(torques) -> (q, qd, base_quat, rpy_rate)` is the caller's simulator: the A1 body is not part of this package
+(a1.urdf and PyBullet are absent from the reference tree). All tensors are float64 `[num_envs, k]` on the device; the
+kernels behind the C ABI (metagym_amd/csrc/a1.hip) keep them as `[k][num_envs]`. No CPU fallback."""
+import ctypes as C
+import enum
+
+import numpy as np
+import torch
+
+from .. import _lib
+
+NUM_MOTORS = _lib.A1_NUM_MOTORS
+MOTOR_NAMES = ["%s_%s_joint" % (leg, part) for leg in ("FR", "FL", "RR", "RL") for part in ("hip", "upper", "lower")]   # a1.py:27-40
+INIT_MOTOR_ANGLES = np.array([0, 0.9, -1.8] * 4, dtype=np.float64)          # a1.py:71
+# a1.py:63-68: abduction / hip / knee gains
+DEFAULT_KP = [80.0, 80.0, 80.0] * 4
+DEFAULT_KD = [1.0, 2.0, 2.0] * 4
+
+
+class MotorControlMode(enum.Enum):
+    """robots/robot_config.py:13-27 (PWM is Minitaur-only and rejected like laikago_motor.py:119-121)."""
+    POSITION = 1
+    TORQUE = 2
+    HYBRID = 3
+
+
+class A1Actuators(object):
+    def __init__(self, num_envs, device="cuda:0", time_step=0.002, action_repeat=13, control_latency=0.002,
+                 pd_latency=0.0, motor_control_mode=MotorControlMode.POSITION, motor_kp=DEFAULT_KP, motor_kd=DEFAULT_KD,
+                 motor_torque_limits=33.5, enable_action_interpolation=False, enable_clip_motor_commands=False,
+                 history_len=100):
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise _lib.MetaGymHipError("metagym_amd has no CPU path: device must be a ROCm GPU, got %r" % (device,))
+        self._lib = _lib.load()
+        self.num_envs = N = int(num_envs)
+        self.num_motors = NUM_MOTORS
+        self.time_step = float(time_step)
+        self._action_repeat = int(action_repeat)
+        self._enable_action_interpolation = bool(enable_action_interpolation)
+        self._last_action = None
+        self._step_counter = 0
+        f64 = dict(dtype=torch.float64, device=self.device)
+        self._history = torch.zeros(int(history_len), _lib.A1_OBS_DIM, N, **f64)
+        self._count = torch.zeros(N, dtype=torch.int32, device=self.device)
+        self._head = torch.zeros(N, dtype=torch.int32, device=self.device)
+        self._observed_torque = torch.zeros(NUM_MOTORS, N, **f64)
+        self._control_obs = torch.zeros(_lib.A1_OBS_DIM, N, **f64)
+        self._torque = torch.zeros(NUM_MOTORS, N, **f64)
+        self._keep = {}
+        c = self._cfg = _lib.A1ActuatorConfig()
+        c.time_step, c.action_repeat, c.history_len = self.time_step, self._action_repeat, int(history_len)
+        c.clip_commands, c.max_angle_change = int(bool(enable_clip_motor_commands)), 0.2
+        self._set_mode(motor_control_mode)
+        self.SetControlLatency(control_latency)
+        self.SetPDLatency(pd_latency)
+        self.SetMotorGains(motor_kp, motor_kd)
+        self.SetMotorStrengthRatios(np.full(NUM_MOTORS, 1.0))
+        if motor_torque_limits is None:
+            c.has_torque_limit = 0
+        else:
+            c.has_torque_limit = 1
+            c.torque_limit[:] = list(np.broadcast_to(np.asarray(motor_torque_limits, dtype=np.float64), (NUM_MOTORS,)))
+        s = self._st = _lib.A1ActuatorState()
+        s.history, s.count, s.head = self._history.data_ptr(), self._count.data_ptr(), self._head.data_ptr()
+        s.observed_torque, s.control_obs = self._observed_torque.data_ptr(), self._control_obs.data_ptr()
+
+    # ---- configuration (minitaur.py:1246-1328) ------------------------------------------------------
+    def _set_mode(self, mode):
+        if not isinstance(mode, MotorControlMode):
+            mode = MotorControlMode(getattr(mode, "value", mode))
+        self._motor_control_mode = mode
+        self._cfg.mode = mode.value
+
+    def _per_env(self, key, value, shape):
+        """scalar / per-motor values go into the config struct, [N]-shaped tensors stay on the device."""
+        if torch.is_tensor(value) and value.dim() >= 1 and value.shape[0] == self.num_envs and value.dim() == len(shape) + 1:
+            t = value.to(self.device, torch.float64)
+            t = t.t().contiguous() if t.dim() == 2 else t.contiguous()
+            self._keep[key] = t
+            return t
+        self._keep.pop(key, None)
+        return None
+
+    def SetControlLatency(self, latency):
+        t = self._per_env("control_latency", latency, ())
+        self._cfg.control_latency_env = t.data_ptr() if t is not None else None
+        if t is None:
+            self._cfg.control_latency = float(latency)
+
+    def SetPDLatency(self, latency):
+        t = self._per_env("pd_latency", latency, ())
+        self._cfg.pd_latency_env = t.data_ptr() if t is not None else None
+        if t is None:
+            self._cfg.pd_latency = float(latency)
+
+    def SetMotorGains(self, kp, kd):
+        """kp, kd: scalar, 12 values, or `[num_envs, 12]` tensors (locomotion_gym_env.py:388-392 draws them per robot)."""
+        for name, v in (("kp", kp), ("kd", kd)):
+            t = self._per_env(name, v, (NUM_MOTORS,))
+            setattr(self._cfg, name + "_env", t.data_ptr() if t is not None else None)
+            if t is None:
+                getattr(self._cfg, name)[:] = list(np.broadcast_to(np.asarray(v, dtype=np.float64), (NUM_MOTORS,)))
+
+    def SetMotorStrengthRatios(self, ratios):
+        self._cfg.strength[:] = list(np.broadcast_to(np.asarray(ratios, dtype=np.float64), (NUM_MOTORS,)))
+
+    def SetMotorStrengthRatio(self, ratio):
+        self.SetMotorStrengthRatios(np.full(NUM_MOTORS, ratio))
+
+    # ---- the sub-step (minitaur.py:232-255) ------------------------------------------------------------
+    def _soa(self, x, k):
+        x = torch.as_tensor(x, dtype=torch.float64, device=self.device)
+        assert x.shape == (self.num_envs, k), "expected [num_envs, %d], got %s" % (k, tuple(x.shape))
+        return x.t().contiguous()
+
+    def Reset(self, mask=None):
+        """Minitaur.Reset (minitaur.py:434-441): history cleared, counters zeroed; the next ReceiveObservation starts it."""
+        if mask is None:
+            self._count.zero_()
+            self._observed_torque.zero_()
+        else:
+            m = torch.as_tensor(mask, device=self.device).bool()
+            self._count[m] = 0
+            self._observed_torque[:, m] = 0.0
+        self._step_counter = 0
+        self._last_action = None
+
+    def ProcessAction(self, action, substep_count):
+        """minitaur.py:1419-1436 — returns (command, last_command or None, lerp) for the kernel to combine."""
+        if self._enable_action_interpolation and self._last_action is not None:
+            return action, self._last_action, float(substep_count + 1) / self._action_repeat
+        return action, None, 0.0
+
+    def ApplyAction(self, motor_commands, motor_control_mode=None):
+        """-> torques `[num_envs, 12]` (what _SetMotorTorqueByIds hands to the physics)."""
+        if motor_control_mode is not None:
+            self._set_mode(motor_control_mode)
+        k = 5 * NUM_MOTORS if self._motor_control_mode is MotorControlMode.HYBRID else NUM_MOTORS
+        return self._apply(self._soa(motor_commands, k), None, 0.0)
+
+    def _apply(self, cmd, last, lerp):
+        with torch.cuda.device(self.device):
+            rc = self._lib.mg_a1_apply_action(C.byref(self._cfg), self.num_envs, C.byref(self._st), _lib.ptr(cmd),
+                                              _lib.ptr(last), float(lerp), _lib.ptr(self._torque),
+                                              _lib.current_stream(self.device))
+        _lib.check(rc, "mg_a1_apply_action")
+        return self._torque.t()
+
+    def ReceiveObservation(self, motor_angles, motor_velocities, base_orientation, base_rpy_rate, clear_mask=None):
+        """The four arguments are what the reference reads from Bullet at this point (getJointStates, base orientation
+        relative to the initial one, angular velocity in the body frame; minitaur.py:1190-1200, :840-872)."""
+        q, qd = self._soa(motor_angles, NUM_MOTORS), self._soa(motor_velocities, NUM_MOTORS)
+        quat, rate = self._soa(base_orientation, 4), self._soa(base_rpy_rate, 3)
+        cm = None if clear_mask is None else torch.as_tensor(clear_mask, device=self.device).to(torch.uint8).contiguous()
+        with torch.cuda.device(self.device):
+            rc = self._lib.mg_a1_receive_observation(C.byref(self._cfg), self.num_envs, C.byref(self._st), _lib.ptr(q),
+                                                     _lib.ptr(qd), _lib.ptr(quat), _lib.ptr(rate), _lib.ptr(cm),
+                                                     _lib.current_stream(self.device))
+        _lib.check(rc, "mg_a1_receive_observation")
+
+    def Step(self, action, physics, control_mode=None):
+        """Minitaur.Step: `action_repeat` x (ProcessAction, ApplyAction, physics(torques), ReceiveObservation).
+        Returns the applied torques `[action_repeat, num_envs, 12]`."""
+        if control_mode is not None:
+            self._set_mode(control_mode)
+        k = 5 * NUM_MOTORS if self._motor_control_mode is MotorControlMode.HYBRID else NUM_MOTORS
+        act = self._soa(action, k)
+        torques = []
+        for i in range(self._action_repeat):
+            cmd, last, lerp = self.ProcessAction(act, i)
+            t = self._apply(cmd, last, lerp)
+            torques.append(t.clone())
+            self.ReceiveObservation(*physics(t))
+            self._step_counter += 1
+        self._last_action = act
+        return torch.stack(torques)
+
+    def GetTimeSinceReset(self):
+        return self._step_counter * self.time_step
+
+    # ---- sensor getters (minitaur.py:755-885; the noise standard deviations are zero, :48) -----------------------
+    def _sensors(self, **want):
+        outs = {}
+        f64 = dict(dtype=torch.float64, device=self.device)
+        shapes = dict(angles=(NUM_MOTORS, self.num_envs), vels=(NUM_MOTORS, self.num_envs),
+                      torques=(NUM_MOTORS, self.num_envs), rate=(3, self.num_envs), energy=(self.num_envs,))
+        for k in shapes:
+            outs[k] = torch.empty(*shapes[k], **f64) if want.get(k) else None
+        with torch.cuda.device(self.device):
+            rc = self._lib.mg_a1_sensors(C.byref(self._cfg), self.num_envs, C.byref(self._st), _lib.ptr(outs["angles"]),
+                                         _lib.ptr(outs["vels"]), _lib.ptr(outs["torques"]), _lib.ptr(outs["rate"]),
+                                         _lib.ptr(outs["energy"]), _lib.current_stream(self.device))
+        _lib.check(rc, "mg_a1_sensors")
+        return outs
+
+    def GetMotorAngles(self):
+        return self._sensors(angles=True)["angles"].t()
+
+    def GetMotorVelocities(self):
+        return self._sensors(vels=True)["vels"].t()
+
+    def GetMotorTorques(self):
+        return self._sensors(torques=True)["torques"].t()
+
+    def GetBaseRollPitchYawRate(self):
+        return self._sensors(rate=True)["rate"].t()
+
+    def GetEnergyConsumptionPerControlStep(self):
+        return self._sensors(energy=True)["energy"]
+
+    def GetControlObservation(self):
+        """`_control_observation` (minitaur.py:1234-1237): `[num_envs, 43]`."""
+        return self._control_obs.t()
+
+    def GetTrueMotorTorques(self):
+        return self._observed_torque.t()
+
+    def state_dict(self):
+        return dict(history=self._history.clone(), count=self._count.clone(), head=self._head.clone(),
+                    observed_torque=self._observed_torque.clone(), control_obs=self._control_obs.clone(),
+                    step_counter=self._step_counter,
+                    last_action=None if self._last_action is None else self._last_action.clone())
+
+    def load_state_dict(self, sd):
+        for k, t in (("history", self._history), ("count", self._count), ("head", self._head),
+                     ("observed_torque", self._observed_torque), ("control_obs", self._control_obs)):
+            assert sd[k].shape == t.shape, "state_dict[%s] has shape %s, expected %s" % (k, tuple(sd[k].shape), tuple(t.shape))
+            t.copy_(sd[k])
+        self._step_counter = int(sd["step_counter"])
+        self._last_action = None if sd["last_action"] is None else sd["last_action"].to(self.device).clone()

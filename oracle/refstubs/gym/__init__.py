@@ -22,3 +22,26 @@ class Env(object):
 
 def make(id, **kwargs):
     return envs.registration.make(id, **kwargs)
+
+
+class Wrapper(Env):
+    """gym.Wrapper (gym 0.18 core.py): forwards everything to `env` (quadrupedal/envs/env_wrappers/MonitorEnv.py)."""
+
+    def __init__(self, env):
+        self.env = env
+        self.action_space = getattr(env, "action_space", None)
+        self.observation_space = getattr(env, "observation_space", None)
+
+    def __getattr__(self, name):
+        if name.startswith("_"):
+            raise AttributeError("attempted to get missing private attribute '%s'" % name)
+        return getattr(self.env, name)
+
+    def step(self, action):
+        return self.env.step(action)
+
+    def reset(self, **kwargs):
+        return self.env.reset(**kwargs)
+
+    def close(self):
+        return self.env.close()

@@ -110,21 +110,20 @@ def test_integration_stub_structs_match_the_abi():
 
 
 def test_walker_wave_mapping_rejects_topologies_its_lds_scratch_cannot_hold():
-    """Argument validation happens before any launch, so it can be exercised without a GPU: a 16-body chain
-    with one joint per body needs more mass-matrix assembly scratch than the wave mapping's constraint block
-    offers -> MG_ERR_UNSUPPORTED with a message, not a silent LDS overrun."""
+    """Argument validation happens before any launch, so it can be exercised without a GPU: 16 bodies welded
+    together (no joints: 6 generalized coordinates) need more mass-matrix assembly scratch (16 doubles per body + 12
+    per coordinate) than the wave mapping's 36 x 6 constraint block offers -> MG_ERR_UNSUPPORTED with a message,
+    not a silent LDS overrun."""
     import ctypes as C
     from metagym_amd import _lib
     lib = _lib.load()
     tp = _lib.WalkerTopology()
-    tp.n_bodies, tp.n_joints, tp.n_spheres, tp.n_feet = 16, 15, 0, 0
+    tp.n_bodies, tp.n_joints, tp.n_spheres, tp.n_feet = 16, 0, 0, 0
     for b in range(16):
         tp.body_parent[b] = b - 1
-    for j in range(15):
-        tp.joint_body[j] = j + 1
     ms = _lib.WalkerModels()
     fake = C.create_string_buffer(8)
-    ms.table, ms.n_tasks, ms.model_stride = C.addressof(fake), 1, 25 * 16 + 12 * 15
+    ms.table, ms.n_tasks, ms.model_stride = C.addressof(fake), 1, 25 * 16
     prm = _lib.WalkerParams()
     prm.time_step, prm.frame_skip, prm.solver_iterations, prm.mapping = 0.005, 4, 5, 1
     st = _lib.WalkerState()
