@@ -501,6 +501,70 @@ int mg_a1_sensors(const mg_a1_actuator_config *cfg, int32_t n_envs, const mg_a1_
                   double *motor_angles, double *motor_velocities, double *motor_torques, double *rpy_rate,
                   double *energy, void *stream);
 
+/* ---- Control-side wrappers of A1GymEnv.step (envs/env_wrappers/MonitorEnv.py), pinned by tests/golden/a1_control.npz ----
+ * Transcendentals (sin, exp, arccos, arcsin, arctan2, tanh) come from the device math library: results agree with the
+ * reference's libm to a few ulp (tests use 1e-12), everything else is the reference's float64 arithmetic in its order. */
+
+#define MG_A1_ETG_MAX_H 32
+
+/* ETGWrapper (MonitorEnv.py:222-273): ETG_layer.update2 + ETG_model.forward + act_clip
+ * (envs/utilities/ETG_model.py:38-55,98-130; leg IK robots/a1.py:88-102,493-524), then
+ * TrajectoryGeneratorWrapperEnv.step -> LaikagoPoseOffsetGenerator.get_action (simple_openloop.py:144-165). */
+typedef struct mg_a1_etg_config {
+    int32_t enabled;               /* ETG != 0; 0: command = generator(action) only */
+    int32_t H;                     /* 20   number of radial basis functions (<= MG_A1_ETG_MAX_H) */
+    double T, T2_ratio;            /* 0.5, 0.5 */
+    double sigma_sq, amp;          /* 0.04, 0.2  MonitorEnv.py:238 */
+    double phase[2];               /* (-pi/2, 0) MonitorEnv.py:236 */
+    double omega;                  /* 2 pi / T   ETG_model.py:20 (host value, so it is numpy's) */
+    double u[MG_A1_ETG_MAX_H][2];  /* RBF centres, ETG_model.py:22-25 (host: numpy's sin) */
+    double w[3][MG_A1_ETG_MAX_H], b[3];   /* ETG_w, ETG_b (the evolved parameters, MonitorEnv.py:240-245) */
+    int32_t act_mode_pose;         /* 1: act_mode "pose" (tanh scaling); 0: "traj" (foot trajectory + IK) */
+    int32_t gallop;                /* task_mode == "gallop" leg assignment, ETG_model.py:106-115 */
+    double etg_weight;             /* 1    MonitorEnv.py:239 */
+    int32_t action_space;          /* LaikagoPoseOffsetGenerator action_mode 0..3 */
+    double pose[MG_A1_NUM_MOTORS]; /* (0, 0.9, -1.8) x 4  laikago_pose_utils.py:17-19 */
+} mg_a1_etg_config;
+
+/* last_etg_act: DEVICE f64 [12][N] state (ETGWrapper.last_ETG_act). t: DEVICE f64 [N], time since reset BEFORE this
+ * env step (locomotion_gym_env get_time_since_reset). action: DEVICE f64 [12][N], or NULL = ETGWrapper.reset (only the
+ * ETG state is refreshed, no command). command: DEVICE f64 [12][N] out — what reaches LocomotionGymEnv.step, i.e. the
+ * input of mg_a1_apply_action. etg_obs: DEVICE f64 [H][N] out or NULL (info["ETG_obs"]). */
+int mg_a1_etg_action(const mg_a1_etg_config *cfg, int32_t n_envs, double *last_etg_act, const double *action,
+                     const double *t, double *command, double *etg_obs, void *stream);
+
+#define MG_A1_MAX_SEGMENTS 8
+
+/* RewardShaping (MonitorEnv.py:275-519), vel_mode "max". */
+typedef struct mg_a1_reward_config {
+    double w_torso, w_up, w_feet, w_tau, w_badfoot, w_footcontact;   /* Param_Dict MonitorEnv.py:12 */
+    double reward_p, vel_d;        /* 1.0, 0.6 */
+    double cw_half, cw_04;         /* arctanh(sqrt(0.95)) / 0.5 and / 0.4: c_prec's w (:421-425), host (numpy) values */
+    int32_t n_segments;            /* info["env_info"] rows (locomotion_gym_env.py:76): x0, x1, upslope, downslope, angle */
+    double seg[MG_A1_MAX_SEGMENTS][5];
+} mg_a1_reward_config;
+
+typedef struct mg_a1_reward_state {
+    double *last_base;     /* DEVICE [3][N]  last_basepose */
+    double *last_base10;   /* DEVICE [30][N] last_base10 (10 x 3, newest first) */
+    double *last_foot;     /* DEVICE [12][N] last_footposition (world frame, 4 x 3) */
+    double *vd2;           /* DEVICE [2][N]  third component of the mutable default `vd` of re_torso / re_feet (:475,:430):
+                              written on slopes only and never cleared, so it outlives the step (and reset()) */
+    int32_t *steps;        /* DEVICE [N] */
+} mg_a1_reward_state;
+
+/* RewardShaping.reset (:305-318): base [3][N], rot_mat [9][N], footposition (base frame) [12][N] of the RESET info;
+ * mask u8 [N] or NULL = all. */
+int mg_a1_reward_reset(const mg_a1_reward_config *cfg, int32_t n_envs, const mg_a1_reward_state *state, const double *base,
+                       const double *rot_mat, const double *footposition, const uint8_t *mask, void *stream);
+/* RewardShaping.step (:320-366) on this step's info: base [3][N], pose (roll, pitch, yaw) [3][N], rot_mat [9][N],
+ * footposition [12][N], real_contact f64 [4][N] (0/1), energy [N], bad_contacts i32 [N], d_yaw [N] or NULL (= 0).
+ * Out: terms f64 [6][N] (torso, up, feet, tau, badfoot, footcontact; may be NULL), reward f64 [N], done u8 [N]. */
+int mg_a1_reward_step(const mg_a1_reward_config *cfg, int32_t n_envs, const mg_a1_reward_state *state, const double *base,
+                      const double *pose, const double *rot_mat, const double *footposition, const double *real_contact,
+                      const double *energy, const int32_t *bad_contacts, const double *d_yaw, double *terms,
+                      double *reward, uint8_t *done, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -149,6 +149,32 @@ class A1ActuatorState(C.Structure):
                 ("observed_torque", C.c_void_p), ("control_obs", C.c_void_p)]
 
 
+A1_ETG_MAX_H, A1_MAX_SEGMENTS = 32, 8
+
+
+class A1EtgConfig(C.Structure):
+    """mg_a1_etg_config"""
+    _fields_ = [("enabled", C.c_int32), ("H", C.c_int32), ("T", C.c_double), ("T2_ratio", C.c_double),
+                ("sigma_sq", C.c_double), ("amp", C.c_double), ("phase", C.c_double * 2), ("omega", C.c_double),
+                ("u", (C.c_double * 2) * A1_ETG_MAX_H), ("w", (C.c_double * A1_ETG_MAX_H) * 3), ("b", C.c_double * 3),
+                ("act_mode_pose", C.c_int32), ("gallop", C.c_int32), ("etg_weight", C.c_double),
+                ("action_space", C.c_int32), ("pose", C.c_double * A1_NUM_MOTORS)]
+
+
+class A1RewardConfig(C.Structure):
+    """mg_a1_reward_config"""
+    _fields_ = [("w_torso", C.c_double), ("w_up", C.c_double), ("w_feet", C.c_double), ("w_tau", C.c_double),
+                ("w_badfoot", C.c_double), ("w_footcontact", C.c_double), ("reward_p", C.c_double), ("vel_d", C.c_double),
+                ("cw_half", C.c_double), ("cw_04", C.c_double), ("n_segments", C.c_int32),
+                ("seg", (C.c_double * 5) * A1_MAX_SEGMENTS)]
+
+
+class A1RewardState(C.Structure):
+    """mg_a1_reward_state (device pointers)"""
+    _fields_ = [("last_base", C.c_void_p), ("last_base10", C.c_void_p), ("last_foot", C.c_void_p), ("vd2", C.c_void_p),
+                ("steps", C.c_void_p)]
+
+
 # symbol -> (restype, argtypes); tests/test_abi.py checks this list against include/metagym_hip.h
 _P = C.c_void_p
 SIGNATURES = {
@@ -188,6 +214,10 @@ SIGNATURES = {
                                             _P, _P, _P, _P, _P, _P]),
     "mg_a1_sensors": (C.c_int, [C.POINTER(A1ActuatorConfig), C.c_int32, C.POINTER(A1ActuatorState),
                                 _P, _P, _P, _P, _P, _P]),
+    "mg_a1_etg_action": (C.c_int, [C.POINTER(A1EtgConfig), C.c_int32, _P, _P, _P, _P, _P, _P]),
+    "mg_a1_reward_reset": (C.c_int, [C.POINTER(A1RewardConfig), C.c_int32, C.POINTER(A1RewardState), _P, _P, _P, _P, _P]),
+    "mg_a1_reward_step": (C.c_int, [C.POINTER(A1RewardConfig), C.c_int32, C.POINTER(A1RewardState), _P, _P, _P, _P, _P,
+                                    _P, _P, _P, _P, _P, _P, _P]),
 }
 
 _lib = None

@@ -173,6 +173,239 @@ __global__ __launch_bounds__(A1_BLOCK) void a1_sensors_kernel(A1K k, mg_a1_actua
     if (energy) energy[e] = fabs(dot) * c.time_step * (double)c.action_repeat;
 }
 
+// ---- ETGWrapper + trajectory generator (MonitorEnv.py:222-273) -----------------------------------------------------
+
+struct EtgK { mg_a1_etg_config c; };
+
+// foot_position_in_hip_frame_to_joint_angle robots/a1.py:88-102
+__device__ __forceinline__ void leg_ik(double x, double y, double z, double l_hip_sign, double out[3]) {
+    const double l_up = 0.2, l_low = 0.2, l_hip = 0.08505 * l_hip_sign;
+    const double theta_knee = -acos((x * x + y * y + z * z - l_hip * l_hip - l_low * l_low - l_up * l_up) / (2 * l_low * l_up));
+    const double l = sqrt(l_up * l_up + l_low * l_low + 2 * l_up * l_low * cos(theta_knee));
+    const double theta_hip = asin(-x / l) - theta_knee / 2;
+    const double ch = cos(theta_hip + theta_knee / 2);
+    const double c1 = l_hip * y - l * ch * z;
+    const double s1 = l * ch * y + l_hip * z;
+    out[0] = atan2(s1, c1);
+    out[1] = theta_hip;
+    out[2] = theta_knee;
+}
+
+__global__ __launch_bounds__(A1_BLOCK) void a1_etg_kernel(EtgK k, int n, double *last_act, const double *action,
+                                                          const double *t_in, double *command, double *etg_obs) {
+    const int e = blockIdx.x * A1_BLOCK + threadIdx.x;
+    if (e >= n) return;
+    const mg_a1_etg_config &c = k.c;
+    double total[NM];
+#pragma unroll
+    for (int i = 0; i < NM; ++i) total[i] = action ? action[(size_t)i * n + e] : 0.0;
+    if (c.enabled) {
+        if (action)                                                              // MonitorEnv.py:263
+#pragma unroll
+            for (int i = 0; i < NM; ++i) total[i] = total[i] + last_act[(size_t)i * n + e];
+        const double t = t_in ? t_in[e] : 0.0;
+        // ETG_layer.update2 ETG_model.py:38-55: x = forward(t), x2 = forward(t + T2_ratio * T)
+        const double t2 = t + c.T2_ratio * c.T;
+        const double x0 = c.amp * sin(c.phase[0] + t * c.omega), x1 = c.amp * sin(c.phase[1] + t * c.omega);
+        const double y0 = c.amp * sin(c.phase[0] + t2 * c.omega), y1 = c.amp * sin(c.phase[1] + t2 * c.omega);
+        double act1[3] = {0, 0, 0}, act2[3] = {0, 0, 0};
+        for (int h = 0; h < c.H; ++h) {
+            const double d0 = x0 - c.u[h][0], d1 = x1 - c.u[h][1], g0 = y0 - c.u[h][0], g1 = y1 - c.u[h][1];
+            const double r = exp(-((d0 * d0 + d1 * d1) / c.sigma_sq)), r2 = exp(-((g0 * g0 + g1 * g1) / c.sigma_sq));
+            if (etg_obs) etg_obs[(size_t)h * n + e] = r;
+#pragma unroll
+            for (int a = 0; a < 3; ++a) { act1[a] += c.w[a][h] * r; act2[a] += c.w[a][h] * r2; }      // ETG_model.forward :99-103
+        }
+#pragma unroll
+        for (int a = 0; a < 3; ++a) { act1[a] += c.b[a]; act2[a] += c.b[a]; }
+        double ref[NM];
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {                                            // :104-115
+            ref[a] = act1[a];
+            ref[3 + a] = c.gallop ? act1[a] : act2[a];
+            ref[6 + a] = act2[a];
+            ref[9 + a] = c.gallop ? act2[a] : act1[a];
+        }
+        const double base_foot[NM] = {0.18, -0.15, -0.23, 0.18, 0.148, -0.23, -0.18, -0.14, -0.23, -0.18, 0.135, -0.23};   // :5-6
+        const double com[3] = {-0.012731, -0.002186, -0.000515};                 // a1.py:60
+        const double hipx[4] = {0.183, 0.183, -0.183, -0.183}, hipy[4] = {-0.047, 0.047, -0.047, 0.047};               // a1.py:61-63
+        const double pose_ori[3] = {0.0, 0.9, -1.8};                             // ETG_model.py:83
+        for (int leg = 0; leg < 4; ++leg) {
+            double ang[3];
+            if (c.act_mode_pose) {                                               // act_clip :118-120
+                const double sc[3] = {0.1, 0.7, 0.7};
+                for (int a = 0; a < 3; ++a) ang[a] = tanh(ref[3 * leg + a]) * sc[a];
+            } else {                                                             // :121-130
+                double d[3] = {ref[3 * leg], ref[3 * leg + 1], ref[3 * leg + 2]};
+                const double sgn = (leg & 1) ? 1.0 : -1.0;                       // (-1) ** (leg + 1)
+                for (int it = 0; it < 4096; ++it) {                              // `while(1)`: |delta| shrinks 5 % per retry
+                    leg_ik((d[0] + base_foot[3 * leg]) - (hipx[leg] + com[0]), (d[1] + base_foot[3 * leg + 1]) - (hipy[leg] + com[1]),
+                           (d[2] + base_foot[3 * leg + 2]) - (0.0 + com[2]), sgn, ang);
+                    if (!(isnan(ang[0]) || isnan(ang[1]) || isnan(ang[2]))) break;
+                    d[0] *= 0.95; d[1] *= 0.95; d[2] *= 0.95;
+                }
+                for (int a = 0; a < 3; ++a) ang[a] = ang[a] - pose_ori[a];
+            }
+            for (int a = 0; a < 3; ++a) last_act[(size_t)(3 * leg + a) * n + e] = ang[a] * c.etg_weight;   // MonitorEnv.py:269
+        }
+    }
+    if (action == nullptr) return;                                               // ETGWrapper.reset: no command
+    // LaikagoPoseOffsetGenerator.get_action simple_openloop.py:144-165
+#pragma unroll
+    for (int i = 0; i < NM; ++i) {
+        double a = total[i];
+        if (c.action_space >= 2) {
+            double extra = 0.0;                                                  // new_action = zeros; [6:9] = a[3:6]; [9:12] = a[:3]
+            if (i >= 6 && i < 9) extra = total[i - 3];
+            else if (i >= 9) extra = total[i - 9];
+            a = extra + a;                                                       // new_action += input_action
+        }
+        command[(size_t)i * n + e] = c.pose[i] + a;
+    }
+}
+
+// ---- RewardShaping (MonitorEnv.py:275-519) -------------------------------------------------------------------------
+
+struct RewK { mg_a1_reward_config c; };
+
+__device__ __forceinline__ void env_vec(const mg_a1_reward_config &c, double posex, int &up, int &down, double &ang) {
+    up = 0; down = 0; ang = 0.0;
+    for (int s = 0; s < c.n_segments; ++s)
+        if (posex + 0.2 >= c.seg[s][0] && posex + 0.2 <= c.seg[s][1]) {          // :328-333
+            up = c.seg[s][2] != 0.0; down = c.seg[s][3] != 0.0; ang = c.seg[s][4];
+            return;
+        }
+}
+__device__ __forceinline__ double c_prec(double v, double t, double w) {          // :421-425
+    const double x = (v - t) * w;
+    return tanh(x * x);
+}
+__device__ __forceinline__ double re_rot(const mg_a1_reward_config &c, double yaw, double d_yaw, double r) {   // :411-419
+    const double two_pi = 2 * 3.141592653589793;
+    const double k1 = 1 - c_prec(yaw, d_yaw, c.cw_half), k2 = 1 - c_prec(yaw, d_yaw + two_pi, c.cw_half),
+                 k3 = 1 - c_prec(yaw, d_yaw - two_pi, c.cw_half);
+    const double k = fmax(fmax(k1, k2), k3);
+    return fmin(k * r, r);
+}
+// the direction block shared by re_torso (:481-497) and re_feet (:431-446); vd2 persists (mutable default argument)
+__device__ __forceinline__ void direction(const mg_a1_reward_config &c, double d_yaw, double posex, double &vd0, double &vd1,
+                                          double &vd2) {
+    vd0 = cos(d_yaw); vd1 = sin(d_yaw);
+    int up, down; double ang;
+    env_vec(c, posex, up, down, ang);
+    if (up) { vd0 *= fabs(cos(ang)); vd1 *= fabs(cos(ang)); vd2 = fabs(sin(ang)); }
+    else if (down) { vd0 *= fabs(cos(ang)); vd1 *= fabs(cos(ang)); vd2 = -fabs(sin(ang)); }
+}
+// get_foot_world :458-473: rot_mat (3 x 3) . foot^T + base
+__device__ __forceinline__ void foot_world(const double *rot, const double *base, const double *foot, int n, int e, double fw[12]) {
+    double R[9], b[3];
+    for (int i = 0; i < 9; ++i) R[i] = rot[(size_t)i * n + e];
+    for (int i = 0; i < 3; ++i) b[i] = base[(size_t)i * n + e];
+    for (int f = 0; f < 4; ++f) {
+        const double x = foot[(size_t)(3 * f) * n + e], y = foot[(size_t)(3 * f + 1) * n + e], z = foot[(size_t)(3 * f + 2) * n + e];
+        for (int r = 0; r < 3; ++r) fw[3 * f + r] = ((R[3 * r] * x + R[3 * r + 1] * y) + R[3 * r + 2] * z) + b[r];
+    }
+}
+
+__global__ __launch_bounds__(A1_BLOCK) void a1_reward_reset_kernel(mg_a1_reward_state st, int n, const double *base,
+                                                                   const double *rot, const double *foot, const uint8_t *mask) {
+    const int e = blockIdx.x * A1_BLOCK + threadIdx.x;
+    if (e >= n || (mask && !mask[e])) return;
+    double fw[12];
+    foot_world(rot, base, foot, n, e, fw);
+    for (int i = 0; i < 12; ++i) st.last_foot[(size_t)i * n + e] = fw[i];
+    for (int i = 0; i < 3; ++i) {
+        const double b = base[(size_t)i * n + e];
+        st.last_base[(size_t)i * n + e] = b;
+        for (int r = 0; r < 10; ++r) st.last_base10[(size_t)(3 * r + i) * n + e] = b;     // np.tile(base, (10, 1))
+    }
+    st.steps[e] = 0;
+}
+
+__global__ __launch_bounds__(A1_BLOCK) void a1_reward_step_kernel(RewK k, mg_a1_reward_state st, int n, const double *base,
+                                                                  const double *pose, const double *rot, const double *foot,
+                                                                  const double *contact, const double *energy, const int32_t *bad,
+                                                                  const double *d_yaw_in, double *terms, double *reward,
+                                                                  uint8_t *done) {
+    const int e = blockIdx.x * A1_BLOCK + threadIdx.x;
+    if (e >= n) return;
+    const mg_a1_reward_config &c = k.c;
+    const int steps = st.steps[e] + 1;                                           // :321
+    const double d_yaw = d_yaw_in ? d_yaw_in[e] : 0.0;
+    double b[3], v[3];
+    for (int i = 0; i < 3; ++i) {
+        b[i] = base[(size_t)i * n + e];
+        v[i] = (b[i] - st.last_base[(size_t)i * n + e]) / 0.026;                 // :339
+    }
+    const double roll = pose[e], pitch0 = pose[(size_t)n + e], yaw = pose[2 * (size_t)n + e];
+    // torso :475-506
+    double vd0, vd1, vd2 = st.vd2[e];
+    direction(c, d_yaw, b[0], vd0, vd1, vd2);
+    st.vd2[e] = vd2;
+    double v_ = (v[0] * vd0 + v[1] * vd1) + v[2] * vd2;
+    const double torso = c.w_torso * re_rot(c, yaw, d_yaw, fmin(c.vel_d, v_));
+    const double kk = 1 - c_prec(fmin(v[0], c.vel_d), c.vel_d, c.cw_half);       // :377
+    // up :394-409
+    int up_f, down_f; double ang;
+    env_vec(c, b[0], up_f, down_f, ang);
+    double pitch = pitch0;
+    if (up_f) pitch += fabs(ang);
+    else if (down_f) pitch -= fabs(ang);
+    const double up = (c.w_up * (1 - c_prec(sqrt(roll * roll + pitch * pitch), 0.0, c.cw_04))) * kk;
+    // feet :430-456
+    double wd0, wd1, wd2 = st.vd2[(size_t)n + e];
+    direction(c, d_yaw, b[0], wd0, wd1, wd2);
+    st.vd2[(size_t)n + e] = wd2;
+    double fw[12];
+    foot_world(rot, base, foot, n, e, fw);
+    double v_sum = 0.0;
+    for (int f = 0; f < 4; ++f) {
+        double df[3];
+        for (int r = 0; r < 3; ++r) df[r] = (fw[3 * f + r] - st.last_foot[(size_t)(3 * f + r) * n + e]) / 0.026;
+        const double vf = (df[0] * wd0 + df[1] * wd1) + df[2] * wd2;
+        const double rr = fmin(vf, c.vel_d) / 4.0;
+        v_sum += fmin(rr, 1.0 * rr);
+    }
+    const double feet = c.w_feet * re_rot(c, yaw, d_yaw, v_sum);
+    const double tau = (-c.w_tau * energy[e]) * kk;                              // :380
+    const double badfoot = -c.w_badfoot * (double)bad[e];                        // :381
+    double lose = 0.0;
+    for (int f = 0; f < 4; ++f) lose += 1.0 - contact[(size_t)f * n + e];        // :382
+    const double footcontact = -c.w_footcontact * fmax(lose - 2, 0.0);
+    // terminate :373-381, on last_base10 BEFORE this step's base enters it
+    double fz[4], fzsum = 0.0, fzmax = -1e300;
+    for (int f = 0; f < 4; ++f) { fz[f] = foot[(size_t)(3 * f + 2) * n + e]; fzsum += fz[f]; fzmax = fmax(fzmax, fz[f]); }
+    double base_std = 0.0;
+    for (int i = 0; i < 3; ++i) {                                                // np.sum(np.std(last_base10, axis=0))
+        double m = 0.0;
+        for (int r = 0; r < 10; ++r) m += st.last_base10[(size_t)(3 * r + i) * n + e];
+        m /= 10.0;
+        double s2 = 0.0;
+        for (int r = 0; r < 10; ++r) { const double d = st.last_base10[(size_t)(3 * r + i) * n + e] - m; s2 += d * d; }
+        base_std += sqrt(s2 / 10.0);
+    }
+    const bool is_done = rot[(size_t)8 * n + e] < 0.5 || fzsum / 4.0 > -0.1 || fzmax > 0.0 || (base_std <= 2e-4 && steps >= 10) ||
+                         fabs(yaw) > 0.6;
+    // rewards: the Param_Dict keys present in info, in dict order (:12,:350-353): torso up feet tau done badfoot footcontact
+    double rewards = 0.0;
+    rewards += torso; rewards += up; rewards += feet; rewards += tau; rewards += is_done ? -1.0 : 0.0;
+    rewards += badfoot; rewards += footcontact;
+    reward[e] = c.reward_p * rewards;
+    done[e] = (uint8_t)is_done;
+    if (terms) {
+        terms[e] = torso; terms[(size_t)n + e] = up; terms[2 * (size_t)n + e] = feet; terms[3 * (size_t)n + e] = tau;
+        terms[4 * (size_t)n + e] = badfoot; terms[5 * (size_t)n + e] = footcontact;
+    }
+    // :355-358
+    for (int i = 0; i < 3; ++i) {
+        st.last_base[(size_t)i * n + e] = b[i];
+        for (int r = 9; r >= 1; --r) st.last_base10[(size_t)(3 * r + i) * n + e] = st.last_base10[(size_t)(3 * (r - 1) + i) * n + e];
+        st.last_base10[(size_t)i * n + e] = b[i];
+    }
+    for (int i = 0; i < 12; ++i) st.last_foot[(size_t)i * n + e] = fw[i];
+    st.steps[e] = steps;
+}
+
 int check_a1(const mg_a1_actuator_config *cfg, const mg_a1_actuator_state *st, int n) {
     if (!cfg || !st) return mg::set_error(MG_ERR_NULL_POINTER, "a1: NULL descriptor");
     if (n <= 0) return mg::set_error(MG_ERR_BAD_SIZE, "n_envs=%d", n);
@@ -226,4 +459,66 @@ extern "C" int mg_a1_sensors(const mg_a1_actuator_config *cfg, int32_t n, const 
     hipLaunchKernelGGL(a1_sensors_kernel, dim3((n + A1_BLOCK - 1) / A1_BLOCK), dim3(A1_BLOCK), 0, (hipStream_t)stream, k,
                        *st, n, motor_angles, motor_velocities, motor_torques, rpy_rate, energy);
     return mg::check_launch("a1_sensors_kernel");
+}
+
+extern "C" int mg_a1_etg_action(const mg_a1_etg_config *cfg, int32_t n, double *last_etg_act, const double *action,
+                                const double *t, double *command, double *etg_obs, void *stream) {
+    if (!cfg) return mg::set_error(MG_ERR_NULL_POINTER, "mg_a1_etg_action: cfg is NULL");
+    if (n <= 0) return mg::set_error(MG_ERR_BAD_SIZE, "n_envs=%d", n);
+    if (cfg->enabled && (cfg->H < 1 || cfg->H > MG_A1_ETG_MAX_H || !(cfg->sigma_sq > 0)))
+        return mg::set_error(MG_ERR_BAD_CONFIG, "ETG: H %d (max %d) sigma_sq %g", cfg->H, MG_A1_ETG_MAX_H, cfg->sigma_sq);
+    if (cfg->action_space < 0 || cfg->action_space > 3)
+        return mg::set_error(MG_ERR_BAD_CONFIG, "LaikagoPoseOffsetGenerator action_space %d", cfg->action_space);
+    if (cfg->enabled) MG_REQUIRE_PTR(last_etg_act);
+    if (action != nullptr) MG_REQUIRE_PTR(command);
+    mg::DeviceGuard guard(mg::device_of(action ? (const void *)command : (const void *)last_etg_act));
+    EtgK k{*cfg};
+    hipLaunchKernelGGL(a1_etg_kernel, dim3((n + A1_BLOCK - 1) / A1_BLOCK), dim3(A1_BLOCK), 0, (hipStream_t)stream, k, n,
+                       last_etg_act, action, t, command, etg_obs);
+    return mg::check_launch("a1_etg_kernel");
+}
+
+namespace {
+int check_reward(const mg_a1_reward_config *cfg, const mg_a1_reward_state *st, int n) {
+    if (!cfg || !st) return mg::set_error(MG_ERR_NULL_POINTER, "a1 reward: NULL descriptor");
+    if (n <= 0) return mg::set_error(MG_ERR_BAD_SIZE, "n_envs=%d", n);
+    if (cfg->n_segments < 0 || cfg->n_segments > MG_A1_MAX_SEGMENTS)
+        return mg::set_error(MG_ERR_BAD_SIZE, "a1 reward: %d terrain segments (max %d)", cfg->n_segments, MG_A1_MAX_SEGMENTS);
+    if (!st->last_base || !st->last_base10 || !st->last_foot || !st->vd2 || !st->steps)
+        return mg::set_error(MG_ERR_NULL_POINTER, "mg_a1_reward_state has a NULL array");
+    return MG_OK;
+}
+}  // namespace
+
+extern "C" int mg_a1_reward_reset(const mg_a1_reward_config *cfg, int32_t n, const mg_a1_reward_state *st, const double *base,
+                                  const double *rot_mat, const double *footposition, const uint8_t *mask, void *stream) {
+    if (int rc = check_reward(cfg, st, n)) return rc;
+    MG_REQUIRE_PTR(base);
+    MG_REQUIRE_PTR(rot_mat);
+    MG_REQUIRE_PTR(footposition);
+    mg::DeviceGuard guard(mg::device_of(st->last_base));
+    hipLaunchKernelGGL(a1_reward_reset_kernel, dim3((n + A1_BLOCK - 1) / A1_BLOCK), dim3(A1_BLOCK), 0, (hipStream_t)stream,
+                       *st, n, base, rot_mat, footposition, mask);
+    return mg::check_launch("a1_reward_reset_kernel");
+}
+
+extern "C" int mg_a1_reward_step(const mg_a1_reward_config *cfg, int32_t n, const mg_a1_reward_state *st, const double *base,
+                                 const double *pose, const double *rot_mat, const double *footposition,
+                                 const double *real_contact, const double *energy, const int32_t *bad_contacts,
+                                 const double *d_yaw, double *terms, double *reward, uint8_t *done, void *stream) {
+    if (int rc = check_reward(cfg, st, n)) return rc;
+    MG_REQUIRE_PTR(base);
+    MG_REQUIRE_PTR(pose);
+    MG_REQUIRE_PTR(rot_mat);
+    MG_REQUIRE_PTR(footposition);
+    MG_REQUIRE_PTR(real_contact);
+    MG_REQUIRE_PTR(energy);
+    MG_REQUIRE_PTR(bad_contacts);
+    MG_REQUIRE_PTR(reward);
+    MG_REQUIRE_PTR(done);
+    mg::DeviceGuard guard(mg::device_of(st->last_base));
+    RewK k{*cfg};
+    hipLaunchKernelGGL(a1_reward_step_kernel, dim3((n + A1_BLOCK - 1) / A1_BLOCK), dim3(A1_BLOCK), 0, (hipStream_t)stream, k,
+                       *st, n, base, pose, rot_mat, footposition, real_contact, energy, bad_contacts, d_yaw, terms, reward, done);
+    return mg::check_launch("a1_reward_step_kernel");
 }

@@ -1,0 +1,145 @@
+"""The control-side wrappers of `A1GymEnv.step` (metagym/quadrupedal/envs/env_wrappers/MonitorEnv.py), batched:
+
+    EtgActionPath   ETGWrapper (:222-273) + TrajectoryGeneratorWrapperEnv + LaikagoPoseOffsetGenerator:
+                    policy action [N,12] -> motor command [N,12] (what LocomotionGymEnv.step / robot.Step receive)
+    RewardShaping   RewardShaping (:275-519): the step's `info` -> reward terms, reward, done
+
+Both run as one HIP kernel per call behind mg_a1_etg_action / mg_a1_reward_* (metagym_amd/csrc/a1.hip). float64
+tensors `[num_envs, k]` on the device. The physics between them is the caller's (see a1_actuators.py)."""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from .. import _lib
+
+Param_Dict = {'torso': 1.0, 'up': 0.3, 'feet': 0.2, 'tau': 0.1, 'done': 1, 'velx': 0, 'badfoot': 0.1, 'footcontact': 0.1}   # MonitorEnv.py:12
+FLAT_GROUND = [[-100, 100, np.array([1, 0, 0, 0, 0, 0, 0])]]          # locomotion_gym_env.py:76 (env_info)
+
+
+def _soa(x, n, k, device, dtype=torch.float64):
+    x = torch.as_tensor(x, dtype=dtype, device=device)
+    assert x.shape == (n, k), "expected [num_envs, %d], got %s" % (k, tuple(x.shape))
+    return x.t().contiguous()
+
+
+class EtgActionPath(object):
+    def __init__(self, num_envs, device="cuda:0", ETG=1, ETG_T=0.5, ETG_T2=0.5, ETG_H=20, ETG_w=None, ETG_b=None, act_mode="traj",
+                 task_mode="normal", action_space=0):
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise _lib.MetaGymHipError("metagym_amd has no CPU path: device must be a ROCm GPU, got %r" % (device,))
+        assert act_mode in ("traj", "pose") and 1 <= ETG_H <= _lib.A1_ETG_MAX_H
+        self._lib = _lib.load()
+        self.num_envs, self.H = int(num_envs), int(ETG_H)
+        c = self._cfg = _lib.A1EtgConfig()
+        c.enabled, c.H, c.T, c.T2_ratio, c.sigma_sq, c.amp = int(bool(ETG)), self.H, ETG_T, ETG_T2, 0.04, 0.2      # MonitorEnv.py:238
+        phase = np.array([-np.pi / 2, 0])                                                                      # :236
+        c.phase[:] = list(phase)
+        c.omega = 2.0 * np.pi / ETG_T                                                                          # ETG_model.py:20
+        for h in range(self.H):                                                                                # :22-25
+            t_now = h * ETG_T / (self.H - 0.9)
+            c.u[h][:] = [float(c.amp * np.sin(phase[i] + t_now * c.omega)) for i in range(2)]
+        self.set_etg_parameters(np.zeros((3, self.H)) if ETG_w is None else ETG_w, np.zeros(3) if ETG_b is None else ETG_b)
+        c.act_mode_pose, c.gallop, c.etg_weight, c.action_space = int(act_mode == "pose"), int(task_mode == "gallop"), 1.0, int(action_space)
+        c.pose[:] = [0.0, 0.9, -1.8] * 4                                                                       # laikago_pose_utils.py:17-19
+        self.last_ETG_act = torch.zeros(12, self.num_envs, dtype=torch.float64, device=self.device)
+
+    def set_etg_parameters(self, w, b):
+        """ETG_w [3, H], ETG_b [3] (MonitorEnv.py:240-245, or reset(ETG_w=, ETG_b=) :250-253)."""
+        w, b = np.asarray(w, dtype=np.float64), np.asarray(b, dtype=np.float64)
+        assert w.shape == (3, self.H) and b.shape == (3,)
+        for a in range(3):
+            self._cfg.w[a][:self.H] = list(w[a])
+        self._cfg.b[:] = list(b)
+
+    def _launch(self, action, t, command, etg_obs):
+        tt = torch.as_tensor(t, dtype=torch.float64, device=self.device)
+        if tt.dim() == 0:
+            tt = tt.expand(self.num_envs)
+        tt = tt.contiguous()
+        with torch.cuda.device(self.device):
+            rc = self._lib.mg_a1_etg_action(C.byref(self._cfg), self.num_envs, _lib.ptr(self.last_ETG_act), _lib.ptr(action),
+                                            _lib.ptr(tt), _lib.ptr(command), _lib.ptr(etg_obs), _lib.current_stream(self.device))
+        _lib.check(rc, "mg_a1_etg_action")
+
+    def reset(self, t=0.0):
+        """ETGWrapper.reset (:246-259): returns info["ETG_obs"] `[num_envs, H]` (None when the ETG is off)."""
+        if not self._cfg.enabled:
+            return None
+        obs = torch.empty(self.H, self.num_envs, dtype=torch.float64, device=self.device)
+        self._launch(None, t, None, obs)
+        return obs.t()
+
+    def step(self, action, t):
+        """action `[num_envs, 12]`, t = time since reset before this env step (scalar or `[num_envs]`).
+        Returns (motor command `[num_envs, 12]`, info["ETG_obs"] or None); info["ETG_act"] is `last_ETG_act.t()`."""
+        a = _soa(action, self.num_envs, 12, self.device)
+        cmd = torch.empty(12, self.num_envs, dtype=torch.float64, device=self.device)
+        obs = torch.empty(self.H, self.num_envs, dtype=torch.float64, device=self.device) if self._cfg.enabled else None
+        self._launch(a, t, cmd, obs)
+        return cmd.t(), (None if obs is None else obs.t())
+
+
+class RewardShaping(object):
+    def __init__(self, num_envs, device="cuda:0", param=Param_Dict, reward_p=1, vel_d=0.6, vel_mode="max", env_info=FLAT_GROUND):
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise _lib.MetaGymHipError("metagym_amd has no CPU path: device must be a ROCm GPU, got %r" % (device,))
+        if vel_mode != "max":
+            raise NotImplementedError("vel_mode %r: only the reference default 'max' is built" % (vel_mode,))
+        self._lib = _lib.load()
+        self.num_envs = N = int(num_envs)
+        c = self._cfg = _lib.A1RewardConfig()
+        c.w_torso, c.w_up, c.w_feet, c.w_tau = param['torso'], param['up'], param['feet'], param['tau']
+        c.w_badfoot, c.w_footcontact, c.reward_p, c.vel_d = param['badfoot'], param['footcontact'], reward_p, vel_d
+        c.cw_half = float(np.arctanh(np.sqrt(0.95)) / 0.5)          # c_prec's w (:421-425) for m = 0.5 and m = 0.4
+        c.cw_04 = float(np.arctanh(np.sqrt(0.95)) / 0.4)
+        assert len(env_info) <= _lib.A1_MAX_SEGMENTS
+        c.n_segments = len(env_info)
+        for i, (x0, x1, vec) in enumerate(env_info):
+            c.seg[i][:] = [float(x0), float(x1), float(vec[0]), float(vec[1]), float(vec[4])]
+        f64 = dict(dtype=torch.float64, device=self.device)
+        self._t = dict(last_base=torch.zeros(3, N, **f64), last_base10=torch.zeros(30, N, **f64), last_foot=torch.zeros(12, N, **f64),
+                       vd2=torch.zeros(2, N, **f64), steps=torch.zeros(N, dtype=torch.int32, device=self.device))
+        s = self._st = _lib.A1RewardState()
+        for k, t in self._t.items():
+            setattr(s, k, t.data_ptr())
+
+    def reset(self, base, rot_mat, footposition, mask=None):
+        """RewardShaping.reset (:305-318) with the RESET info's base [N,3], rot_mat [N,9], footposition [N,12] (base frame)."""
+        N, d = self.num_envs, self.device
+        m = None if mask is None else torch.as_tensor(mask, device=d).to(torch.uint8).contiguous()
+        # (named locals: the SoA copies must outlive the launch call, _lib.ptr() only keeps their addresses)
+        b, r, f = _soa(base, N, 3, d), _soa(rot_mat, N, 9, d), _soa(footposition, N, 12, d)
+        with torch.cuda.device(d):
+            rc = self._lib.mg_a1_reward_reset(C.byref(self._cfg), N, C.byref(self._st), _lib.ptr(b), _lib.ptr(r), _lib.ptr(f),
+                                              _lib.ptr(m), _lib.current_stream(d))
+        _lib.check(rc, "mg_a1_reward_reset")
+
+    def step(self, base, pose, rot_mat, footposition, real_contact, energy, bad_foot_contacts, d_yaw=None):
+        """-> (reward [N], done [N] bool, terms dict of [N]) from this step's info (locomotion_gym_env.py:534-545)."""
+        N, d = self.num_envs, self.device
+        f64 = dict(dtype=torch.float64, device=d)
+        terms, reward = torch.empty(6, N, **f64), torch.empty(N, **f64)
+        done = torch.empty(N, dtype=torch.uint8, device=d)
+        en = torch.as_tensor(energy, **f64).contiguous()
+        bad = torch.as_tensor(bad_foot_contacts, device=d).to(torch.int32).contiguous()
+        dy = None if d_yaw is None else torch.as_tensor(d_yaw, **f64).expand(N).contiguous()
+        b, p, r = _soa(base, N, 3, d), _soa(pose, N, 3, d), _soa(rot_mat, N, 9, d)
+        f, ct = _soa(footposition, N, 12, d), _soa(real_contact, N, 4, d)
+        with torch.cuda.device(d):
+            rc = self._lib.mg_a1_reward_step(C.byref(self._cfg), N, C.byref(self._st), _lib.ptr(b), _lib.ptr(p), _lib.ptr(r),
+                                             _lib.ptr(f), _lib.ptr(ct), _lib.ptr(en), _lib.ptr(bad), _lib.ptr(dy),
+                                             _lib.ptr(terms), _lib.ptr(reward), _lib.ptr(done), _lib.current_stream(d))
+        _lib.check(rc, "mg_a1_reward_step")
+        names = ("torso", "up", "feet", "tau", "badfoot", "footcontact")
+        return reward, done.bool(), {k: terms[i] for i, k in enumerate(names)}
+
+    def state_dict(self):
+        return {k: t.clone() for k, t in self._t.items()}
+
+    def load_state_dict(self, sd):
+        for k, t in self._t.items():
+            assert sd[k].shape == t.shape, k
+            t.copy_(sd[k])

@@ -121,3 +121,197 @@ def from_golden(g, name, n=1):
     dt, repeat, clat, plat, interp, clip, mode, _ = g[name + "/config"]
     return A1Actuation(n, dt, int(repeat), clat, plat, int(mode), g[name + "/kp"], g[name + "/kd"], g[name + "/strength"],
                        g[name + "/torque_limit"], bool(interp), bool(clip))
+
+
+# =====================================================================================================================
+# Control-side wrappers of A1GymEnv.step: the ETG action path and the reward shaping (pinned by
+# tests/golden/a1_control.npz, oracle/gen_golden_a1_control.py)
+# =====================================================================================================================
+
+BASE_FOOT = np.array([0.18, -0.15, -0.23, 0.18, 0.148, -0.23, -0.18, -0.14, -0.23, -0.18, 0.135, -0.23])   # ETG_model.py:5-6
+COM_OFFSET = -np.array([0.012731, 0.002186, 0.000515])                                                     # a1.py:60
+HIP_OFFSETS = np.array([[0.183, -0.047, 0.], [0.183, 0.047, 0.], [-0.183, -0.047, 0.], [-0.183, 0.047, 0.]]) + COM_OFFSET
+POSE_ORI = np.array([0, 0.9, -1.8] * 4)                                                                    # ETG_model.py:83
+
+
+def foot_position_in_hip_frame_to_joint_angle(foot_position, l_hip_sign=1):
+    """robots/a1.py:88-102, verbatim arithmetic."""
+    l_up, l_low = 0.2, 0.2
+    l_hip = 0.08505 * l_hip_sign
+    x, y, z = foot_position[0], foot_position[1], foot_position[2]
+    with np.errstate(invalid="ignore"):
+        theta_knee = -np.arccos((x**2 + y**2 + z**2 - l_hip**2 - l_low**2 - l_up**2) / (2 * l_low * l_up))
+        l = np.sqrt(l_up**2 + l_low**2 + 2 * l_up * l_low * np.cos(theta_knee))
+        theta_hip = np.arcsin(-x / l) - theta_knee / 2
+    c1 = l_hip * y - l * np.cos(theta_hip + theta_knee / 2) * z
+    s1 = l * np.cos(theta_hip + theta_knee / 2) * y + l_hip * z
+    theta_ab = np.arctan2(s1, c1)
+    return np.array([theta_ab, theta_hip, theta_knee])
+
+
+class EtgActionPath(object):
+    """One robot's ETGWrapper (MonitorEnv.py:222-273) over TrajectoryGeneratorWrapperEnv + LaikagoPoseOffsetGenerator."""
+
+    def __init__(self, w, b, enabled=True, T=0.5, T2_ratio=0.5, H=20, sigma_sq=0.04, amp=0.2, pose_mode=False, gallop=False,
+                 action_space=0, etg_weight=1):
+        self.enabled, self.T, self.T2, self.H, self.sigma_sq, self.amp = enabled, T, T2_ratio, H, sigma_sq, amp
+        self.phase = np.array([-np.pi / 2, 0])                        # MonitorEnv.py:236
+        self.omega = 2.0 * np.pi / T                                   # ETG_model.py:20
+        self.u = np.asarray([self.forward(h * T / (H - 0.9)) for h in range(H)]).reshape(-1, 2)      # :22-25
+        self.w, self.b, self.pose_mode, self.gallop = np.asarray(w), np.asarray(b), pose_mode, gallop
+        self.action_space, self.weight = action_space, etg_weight
+        self.pose = np.array([0, 0.9, -1.8] * 4, dtype=np.float64)     # laikago_pose_utils.py:17-19
+        self.last_etg_act = np.zeros(12)
+        self.retries = 0
+
+    def forward(self, t):                                             # ETG_layer.forward :28-32
+        return np.asarray([self.amp * np.sin(self.phase[i] + t * self.omega) for i in range(2)]).reshape(-1)
+
+    def rbf(self, x):                                                 # ETG_layer.update2 :48-51
+        return np.asarray([np.exp(-(np.sum(np.power(x - self.u[i], 2)) / self.sigma_sq)) for i in range(self.H)]).reshape(-1)
+
+    def etg(self, t):
+        """update2 + ETG_model.forward + act_clip: returns (state[0], clipped reference action * weight)."""
+        r, r2 = self.rbf(self.forward(t)), self.rbf(self.forward(t + self.T2 * self.T))
+        act1 = self.w.dot(r.reshape(-1, 1)).reshape(-1) + self.b       # ETG_model.py:99-103
+        act2 = self.w.dot(r2.reshape(-1, 1)).reshape(-1) + self.b
+        new_act = np.zeros(12)
+        if self.gallop:
+            new_act[:3], new_act[3:6], new_act[6:9], new_act[9:] = act1, act1, act2, act2
+        else:
+            new_act[:3], new_act[3:6], new_act[6:9], new_act[9:] = act1, act2, act2, act1
+        if self.pose_mode:                                            # act_clip :118-120
+            act = np.tanh(new_act) * np.array([0.1, 0.7, 0.7] * 4)
+        else:                                                         # :121-130
+            act = np.zeros(12)
+            for i in range(4):
+                delta = new_act[i * 3:(i + 1) * 3].copy()
+                while True:
+                    angle = foot_position_in_hip_frame_to_joint_angle(delta + BASE_FOOT[i * 3:(i + 1) * 3] - HIP_OFFSETS[i],
+                                                                      l_hip_sign=(-1) ** (i + 1))      # a1.py:509-511
+                    angle = np.multiply(angle - np.zeros(3), np.ones(3))                               # :514-517
+                    if np.sum(np.isnan(angle)) == 0:
+                        break
+                    delta *= 0.95
+                    self.retries += 1
+                act[i * 3:(i + 1) * 3] = angle
+            act -= POSE_ORI
+        return r, act * self.weight
+
+    def reset(self, t=0.0):
+        """ETGWrapper.reset :246-259."""
+        if not self.enabled:
+            return None
+        obs, self.last_etg_act = self.etg(t)
+        return obs
+
+    def generator(self, a):
+        """LaikagoPoseOffsetGenerator.get_action simple_openloop.py:144-165."""
+        if self.action_space <= 1:
+            return self.pose + a
+        new_action = np.zeros(12)
+        new_action[6:9] = a[3:6]
+        new_action[9:12] = a[:3]
+        new_action += a
+        return self.pose + new_action
+
+    def step(self, action, t):
+        """ETGWrapper.step :261-273 -> TrajectoryGeneratorWrapperEnv.step: returns (motor command, ETG_obs or None)."""
+        if not self.enabled:
+            return self.generator(np.asarray(action)), None
+        total = np.asarray(action).reshape(-1) + self.last_etg_act
+        obs, self.last_etg_act = self.etg(t)
+        return self.generator(total), obs
+
+
+class RewardShaping(object):
+    """One robot's RewardShaping wrapper, MonitorEnv.py:275-519 (vel_mode "max")."""
+
+    def __init__(self, param, reward_p=1.0, vel_d=0.6, segments=((-100, 100, 1, 0, 0.0),)):
+        self.p = dict(zip(("torso", "up", "feet", "tau", "badfoot", "footcontact"), param))
+        self.reward_p, self.vel_d, self.segments = reward_p, vel_d, [tuple(s) for s in segments]
+        self.vd_torso, self.vd_feet = [1, 0, 0], [1, 0, 0]              # the mutable default arguments of :475 and :430
+        self.steps = 0
+
+    def env_vec(self, posex):                                          # :328-333 (and four more copies)
+        for x0, x1, up, down, ang in self.segments:
+            if posex + 0.2 >= x0 and posex + 0.2 <= x1:
+                return up, down, ang
+        return 0, 0, 0.0
+
+    @staticmethod
+    def c_prec(v, t, m):                                               # :421-425
+        w = np.arctanh(np.sqrt(0.95)) / m
+        return np.tanh(np.power((v - t) * w, 2))
+
+    @staticmethod
+    def foot_world(base, rot_mat, foot):                               # get_foot_world :458-473
+        f = np.array(foot).transpose()
+        return (np.array(rot_mat).reshape(-1, 3).dot(f) + np.array(base).reshape(-1, 1)).transpose()
+
+    def reset(self, base, rot_mat, foot):                              # :305-318
+        self.steps = 0
+        self.last_basepose = np.array(base)
+        self.last_foot = self.foot_world(base, rot_mat, foot)
+        self.last_base10 = np.tile(base, (10, 1))
+
+    def direction(self, vd, d_yaw, base):                              # the block shared by re_torso :481-497 and re_feet :431-446
+        vd[0], vd[1] = np.cos(d_yaw), np.sin(d_yaw)
+        up, down, ang = self.env_vec(base[0])
+        if up:
+            vd[0] *= abs(np.cos(ang)); vd[1] *= abs(np.cos(ang)); vd[2] = abs(np.sin(ang))
+        elif down:
+            vd[0] *= abs(np.cos(ang)); vd[1] *= abs(np.cos(ang)); vd[2] = -abs(np.sin(ang))
+        return vd
+
+    def re_rot(self, yaw, d_yaw, r):                                   # :411-419
+        k = max(1 - self.c_prec(yaw, d_yaw, 0.5), 1 - self.c_prec(yaw, d_yaw + 2 * np.pi, 0.5),
+                1 - self.c_prec(yaw, d_yaw - 2 * np.pi, 0.5))
+        return min(k * r, r)
+
+    def step(self, base, pose, rot_mat, foot, contact, energy, bad, d_yaw=0):
+        """RewardShaping.step :320-366. Returns (terms[6], reward, done)."""
+        self.steps += 1
+        base, pose = np.array(base), np.array(pose)
+        v = (base - self.last_basepose) / 0.026
+        # torso :475-506
+        vd = self.direction(self.vd_torso, d_yaw, base)
+        v_ = v[0] * vd[0] + v[1] * vd[1] + v[2] * vd[2]
+        torso = self.p["torso"] * self.re_rot(pose[-1], d_yaw, min(self.vel_d, v_))
+        k = 1 - self.c_prec(min(v[0], self.vel_d), self.vel_d, 0.5)
+        # up :394-409
+        up_flag, down_flag, ang = self.env_vec(base[0])
+        roll, pitch = pose[0], pose[1]
+        if up_flag:
+            pitch += abs(ang)
+        elif down_flag:
+            pitch -= abs(ang)
+        up = self.p["up"] * (1 - self.c_prec(np.sqrt(roll ** 2 + pitch ** 2), 0, 0.4)) * k
+        # feet :430-456
+        vd = self.direction(self.vd_feet, d_yaw, base)
+        fw = self.foot_world(base, rot_mat, foot)
+        d_foot = (fw - self.last_foot) / 0.026
+        v_sum = 0
+        for i in range(4):
+            vf = d_foot[i]
+            v_ = vf[0] * vd[0] + vf[1] * vd[1] + vf[2] * vd[2]
+            r = min(v_, self.vel_d) / 4.0
+            v_sum += min(r, 1.0 * r)
+        feet = self.p["feet"] * self.re_rot(pose[-1], d_yaw, v_sum)
+        tau = -self.p["tau"] * energy * k
+        badfoot = -self.p["badfoot"] * bad
+        lose = np.sum(1.0 - np.array(contact))
+        footcontact = -self.p["footcontact"] * max(lose - 2, 0)
+        # terminate :373-381 (last_base10 not yet updated)
+        footz = np.array(foot)[:, -1]
+        base_std = np.sum(np.std(self.last_base10, axis=0))
+        done = bool(rot_mat[-1] < 0.5 or np.mean(footz) > -0.1 or np.max(footz) > 0 or
+                    (base_std <= 2e-4 and self.steps >= 10) or abs(pose[-1]) > 0.6)
+        rewards = 0
+        for term in (torso, up, feet, tau, -1 if done else 0, badfoot, footcontact):       # Param_Dict key order :12
+            rewards += term
+        self.last_basepose = base.copy()
+        self.last_base10[1:, :] = self.last_base10[:9, :]
+        self.last_base10[0, :] = base
+        self.last_foot = fw
+        return np.array([torso, up, feet, tau, badfoot, footcontact]), self.reward_p * rewards, done

@@ -1,0 +1,69 @@
+"""CPU: the oracle's restatement of the A1 control-side wrappers (ETG action path, reward shaping; oracle/a1.py)
+against vectors recorded from the unmodified reference (tests/golden/a1_control.npz, oracle/gen_golden_a1_control.py)."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import a1 as oa
+
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden", "a1_control.npz")
+
+
+@pytest.fixture(scope="module")
+def g():
+    return np.load(GOLDEN)
+
+
+def etg_path(g, name):
+    etg, T, T2, H, sig, amp, pose_mode, gallop, space, _dt = g[name + "/config"]
+    return oa.EtgActionPath(g[name + "/w"], g[name + "/b"], bool(etg), T, T2, int(H), sig, amp, bool(pose_mode), bool(gallop), int(space))
+
+
+@pytest.mark.parametrize("idx", range(5))
+def test_action_path_matches_reference(g, idx):
+    name = str(g["b_cases"][idx])
+    p = etg_path(g, name)
+    obs = p.reset(0.0)
+    if p.enabled:
+        assert np.array_equal(obs, g[name + "/reset_etg_obs"][0])
+        assert np.array_equal(p.last_etg_act, g[name + "/reset_etg_act"][0])
+    for k in range(len(g[name + "/action"])):
+        cmd, obs = p.step(g[name + "/action"][k], g[name + "/t"][k])
+        assert np.array_equal(cmd, g[name + "/command"][k]), "%s command, step %d" % (name, k)
+        if p.enabled:
+            assert np.array_equal(obs, g[name + "/etg_obs"][k])
+            assert np.array_equal(p.last_etg_act, g[name + "/etg_act"][k])
+    if name == "etg_traj_unreachable":
+        assert p.retries > 0, "the fixture must exercise the IK retry loop (ETG_model.py:126-129)"
+
+
+def reward_case(g, name):
+    reward_p, vel_d, d_yaw = g[name + "/config"]
+    r = oa.RewardShaping(g[name + "/param"], reward_p, vel_d, g[name + "/segments"])
+    return r, d_yaw
+
+
+@pytest.mark.parametrize("idx", range(6))
+def test_reward_shaping_matches_reference(g, idx):
+    name = str(g["c_cases"][idx])
+    r, d_yaw = reward_case(g, name)
+    # reset(): last_* come from the RESET info; get_foot_world of it is recorded
+    r.steps = 0
+    r.last_basepose = g[name + "/reset_base"].copy()
+    r.last_foot = g[name + "/reset_foot_world"].copy()
+    r.last_base10 = np.tile(g[name + "/reset_base"], (10, 1))
+    for k in range(len(g[name + "/reward"])):
+        terms, reward, done = r.step(g[name + "/base"][k], g[name + "/pose"][k], g[name + "/rot_mat"][k],
+                                     g[name + "/footposition"][k], g[name + "/real_contact"][k], g[name + "/energy"][k],
+                                     g[name + "/bad"][k], d_yaw)
+        assert np.array_equal(terms, g[name + "/terms"][k]), "%s terms, step %d" % (name, k)
+        assert reward == g[name + "/reward"][k]
+        assert done == bool(g[name + "/done"][k])
+        assert np.array_equal(r.last_foot, g[name + "/foot_world"][k])
+
+
+def test_reward_goldens_cover_every_termination_rule(g):
+    done = {n: g[n + "/done"] for n in map(str, g["c_cases"])}
+    assert done["reward_tumble"].any() and done["reward_feet_up"].any() and done["reward_still"].any()
+    assert not done["reward_walk"][:5].any()
