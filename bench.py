@@ -29,6 +29,7 @@ Prints ONE JSON line on rank 0.
                importable (build container); otherwise the C port of it (oracle/) on the host cores
 """
 import argparse
+import ctypes
 import json
 import multiprocessing
 import os
@@ -434,6 +435,39 @@ def secondary_workloads(dev):
         torch.cuda.empty_cache()
     except Exception as e:
         out["walker_error"] = repr(e)
+    try:
+        # Quadrupedal: the A1 actuation sub-step around the (absent) physics — ApplyAction + ReceiveObservation
+        from metagym_amd.quadrupedal import A1Actuators
+        n = ENVS_PER_GPU
+        act = A1Actuators(n, dev)                                 # POSITION mode, control latency 0.002 s, pd latency 0
+        f64 = dict(dtype=torch.float64, device=dev)
+        q, qd = torch.rand(n, 12, **f64), torch.rand(n, 12, **f64)
+        quat, rate, cmd = torch.rand(n, 4, **f64), torch.rand(n, 3, **f64), torch.rand(n, 12, **f64)
+        qs, qds, quats, rates, cmds = [x.t().contiguous() for x in (q, qd, quat, rate, cmd)]
+        act.Reset()
+        act.ReceiveObservation(q, qd, quat, rate)
+
+        def substep(i):       # the C ABI pair of one sub-step on SoA inputs (the [N, k] -> [k][N] copy is the caller's layout choice)
+            act._apply(cmds, None, 0.0)
+            rc = act._lib.mg_a1_receive_observation(ctypes.byref(act._cfg), n, ctypes.byref(act._st), qs.data_ptr(), qds.data_ptr(),
+                                                    quats.data_ptr(), rates.data_ptr(), None,
+                                                    torch.cuda.current_stream(dev).cuda_stream)
+            assert rc == 0
+        s = _time_steps(substep, 60, 10)
+        # algorithmic bytes per robot sub-step (f64): apply: q, qd of the newest observation 192 + command 96 in, torque and
+        # observed torque 192 out; receive: q, qd, quaternion, rate 248 + observed torque 96 in, one history entry 344 out,
+        # control observation = blend of two entries 688 in, 344 out  ->  2 200 B
+        byt = 192 + 96 + 192 + 248 + 96 + 344 + 688 + 344
+        out["A1_actuation_substep_%denvs" % n] = {
+            "robot_substeps_per_s": n / s, "us_per_substep_pair": s * 1e6,
+            "roofline": {"bound": "hbm", "achieved": byt * n / s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": byt * n / s / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes_per_robot_substep": byt},
+            "note": "mg_a1_apply_action + mg_a1_receive_observation (two launches); bit-exact against the unmodified reference; "
+                    "the A1 body / physics is not built (a1.urdf and PyBullet are absent from the reference tree)"}
+        del act
+        torch.cuda.empty_cache()
+    except Exception as e:
+        out["a1_error"] = repr(e)
     return out
 
 

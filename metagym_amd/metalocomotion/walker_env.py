@@ -184,11 +184,24 @@ class WalkerBatchEnv(object):
     _STATE_KEYS = ("pos", "rot", "vel", "omega", "q", "qd", "potential", "feet_contact", "steps")
 
     def state_dict(self):
-        return {k: getattr(self, k).clone() for k in self._STATE_KEYS}
+        """Simulator arrays + what a bit-identical continuation also needs: which model every env runs (task_id), the
+        auto-reset stream position (global_step is the Philox step index) and the host RandomState behind reset()."""
+        sd = {k: getattr(self, k).clone() for k in self._STATE_KEYS}
+        sd["task_id"] = self.task_id.clone()
+        sd["global_step"] = int(self.global_step)
+        sd["np_random"] = self.np_random.get_state()
+        return sd
 
     def load_state_dict(self, sd):
-        for k in self._STATE_KEYS:
-            getattr(self, k).copy_(torch.as_tensor(sd[k]).to(getattr(self, k).dtype))
+        for k in self._STATE_KEYS + (("task_id",) if "task_id" in sd else ()):
+            dst, src = getattr(self, k), torch.as_tensor(sd[k])
+            if tuple(src.shape) != tuple(dst.shape):
+                raise ValueError("state_dict[%r] has shape %s, this env holds %s" % (k, tuple(src.shape), tuple(dst.shape)))
+            dst.copy_(src.to(dst.dtype))
+        if "global_step" in sd:
+            self.global_step = int(sd["global_step"])
+        if "np_random" in sd:
+            self.np_random.set_state(sd["np_random"])
 
     # ------------------------------------------------------------------ episode control
     def reset(self, mask=None, seed=None, joint_noise=None):

@@ -142,12 +142,20 @@ class _MazeBatch(object):
     _STATE_KEYS = ("grid", "steps", "ori_idx", "ori", "loc", "life", "cur_food", "wait_refresh", "revival")
 
     def state_dict(self):
-        return {k: getattr(self, k).clone() for k in self._STATE_KEYS if hasattr(self, k)}
+        """Per-env arrays + task_id: the SURVIVAL food arrays only make sense next to the task they were drawn for."""
+        sd = {k: getattr(self, k).clone() for k in self._STATE_KEYS if hasattr(self, k)}
+        if hasattr(self, "task_id"):
+            sd["task_id"] = self.task_id.clone()
+        return sd
 
     def load_state_dict(self, sd):
-        for k in self._STATE_KEYS:
+        for k in self._STATE_KEYS + ("task_id",):
             if hasattr(self, k) and k in sd:
-                getattr(self, k).copy_(torch.as_tensor(sd[k]).to(getattr(self, k).dtype))
+                dst, src = getattr(self, k), torch.as_tensor(sd[k])
+                if tuple(src.shape) != tuple(dst.shape):
+                    raise ValueError("state_dict[%r] has shape %s, this env holds %s (same num_envs and maze size n needed)"
+                                     % (k, tuple(src.shape), tuple(dst.shape)))
+                dst.copy_(src.to(dst.dtype))
 
     # ------------------------------------------------------------------ episode control
     def reset(self, mask=None):

@@ -23,10 +23,10 @@ if has quad; then
 fi
 if has maze; then
   for V in discrete continuous; do
-    M="python scripts/bench_maze.py --skip2d --no-u8 --res 256 --steps 10 --warmup 2 --only $V"
+    M="python scripts/bench_maze.py --skip2d --no-u8 --res 256 --steps 30 --warmup 5 --only $V"
     timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/maze_${V}_trace -o m -- $M > $OUT/maze_${V}_trace.log 2>&1
   done
-  M="python scripts/bench_maze.py --skip2d --no-u8 --res 256 --steps 10 --warmup 2 --only discrete"
+  M="python scripts/bench_maze.py --skip2d --no-u8 --res 256 --steps 30 --warmup 5 --only discrete"
   timeout 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/maze_pmc_fetch -o m -- $M > $OUT/maze_pmc_fetch.log 2>&1
   timeout 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/maze_pmc_write -o m -- $M > $OUT/maze_pmc_write.log 2>&1
   timeout 300 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT \

@@ -279,13 +279,15 @@ def test_auto_reset_equals_explicit_masked_reset(mapping):
         assert torch.equal(oa[~d], ob[~d])
         sa, sb = auto.state_dict(), twin.state_dict()
         for k in sa:
+            if not torch.is_tensor(sa[k]):
+                continue                           # global_step / np_random: host-side stream positions
             # the fused reset runs the wave kernel's observation code, the explicit one the lane-per-env reset
             # kernel's; with FMA contraction on in this engine they may differ in the last bit of a double
             if sa[k].dtype == torch.float64:
                 assert torch.allclose(sa[k], sb[k], rtol=1e-12, atol=1e-12), (t, k)
             else:
                 assert torch.equal(sa[k], sb[k]), (t, k)
-        twin.load_state_dict(sa)          # keep the twins on identical bits so the comparison stays sharp
+        twin.load_state_dict({k: v for k, v in sa.items() if torch.is_tensor(v)})          # keep the twins on identical bits so the comparison stays sharp
     assert ended_total >= n                                    # max_steps=5: everyone restarted at least once
     # shard invariance: envs 12..23 run as their own shard draw the same noise
     full = _make("MetaHumanoidEnv", models, n, max_steps=2, mapping=mapping, auto_reset=True, seed=5)
