@@ -565,6 +565,31 @@ int mg_a1_reward_step(const mg_a1_reward_config *cfg, int32_t n_envs, const mg_a
                       const double *energy, const int32_t *bad_contacts, const double *d_yaw, double *terms,
                       double *reward, uint8_t *done, void *stream);
 
+/* The sensor stack behind A1GymEnv's observation (envs/env_builder.py:62-80, SENSOR_MODE dis / imu / motor / contact = 1):
+ * BaseDisplacementSensor(convert_to_local_frame) robot_sensors.py:217-312, IMUSensor(R P Y dR dP dY) :314-437,
+ * MotorAngleAccSensor :85-162, FootContactSensor :552-578, ordered by sensor name (locomotion_gym_env.py:621-632) and
+ * flattened (env_utils.py:11-42): obs[0:3] base displacement, [3:7] foot contacts, [7:13] IMU, [13:37] motor angles and
+ * their finite-difference rates. Pinned by tests/golden/a1_sensors.npz. */
+#define MG_A1_SENSOR_OBS_DIM 37
+typedef struct mg_a1_sensor_config {
+    int32_t normal;            /* 1: (x - mean) / std of each sensor (robot_sensors.py:117-118,261-262,347-348) */
+    double disp_dt;            /* 0.026  BaseDisplacementSensor's own default (:225) */
+    double motor_dt;           /* num_action_repeat * sim_time_step (env_builder.py:49,73) */
+} mg_a1_sensor_config;
+typedef struct mg_a1_sensor_state {
+    double *base_last, *base_cur;   /* DEVICE [3][N] */
+    double *yaw;                    /* DEVICE [2][N] last, current */
+    double *first_rpy;              /* DEVICE [3][N] */
+    double *last_angle;             /* DEVICE [12][N] */
+    int32_t *first;                 /* DEVICE [N] bit 0: IMU first_time, bit 1: MotorAngleAcc first_time */
+} mg_a1_sensor_state;
+/* One observation per robot. reset_mask (u8 [N] or NULL = none): robots that were just reset — sensor.reset() + on_reset
+ * (locomotion_gym_env.py:231-232,426-427) instead of on_step (:521-522). base [3][N] (GetBasePosition), rpy [3][N]
+ * (GetBaseRollPitchYaw), drpy [3][N], motor_angles [12][N] (mg_a1_sensors), contact [4][N] (0 / 1). obs: f64 [N][37]. */
+int mg_a1_observation(const mg_a1_sensor_config *cfg, int32_t n_envs, const mg_a1_sensor_state *state, const double *base,
+                      const double *rpy, const double *drpy, const double *motor_angles, const double *contact,
+                      const uint8_t *reset_mask, double *obs, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -175,6 +175,20 @@ class A1RewardState(C.Structure):
                 ("steps", C.c_void_p)]
 
 
+A1_SENSOR_OBS_DIM = 37
+
+
+class A1SensorConfig(C.Structure):
+    """mg_a1_sensor_config"""
+    _fields_ = [("normal", C.c_int32), ("disp_dt", C.c_double), ("motor_dt", C.c_double)]
+
+
+class A1SensorState(C.Structure):
+    """mg_a1_sensor_state (device pointers)"""
+    _fields_ = [("base_last", C.c_void_p), ("base_cur", C.c_void_p), ("yaw", C.c_void_p), ("first_rpy", C.c_void_p),
+                ("last_angle", C.c_void_p), ("first", C.c_void_p)]
+
+
 # symbol -> (restype, argtypes); tests/test_abi.py checks this list against include/metagym_hip.h
 _P = C.c_void_p
 SIGNATURES = {
@@ -216,6 +230,8 @@ SIGNATURES = {
                                 _P, _P, _P, _P, _P, _P]),
     "mg_a1_etg_action": (C.c_int, [C.POINTER(A1EtgConfig), C.c_int32, _P, _P, _P, _P, _P, _P]),
     "mg_a1_reward_reset": (C.c_int, [C.POINTER(A1RewardConfig), C.c_int32, C.POINTER(A1RewardState), _P, _P, _P, _P, _P]),
+    "mg_a1_observation": (C.c_int, [C.POINTER(A1SensorConfig), C.c_int32, C.POINTER(A1SensorState), _P, _P, _P, _P, _P, _P,
+                                    _P, _P]),
     "mg_a1_reward_step": (C.c_int, [C.POINTER(A1RewardConfig), C.c_int32, C.POINTER(A1RewardState), _P, _P, _P, _P, _P,
                                     _P, _P, _P, _P, _P, _P, _P]),
 }

@@ -406,6 +406,59 @@ __global__ __launch_bounds__(A1_BLOCK) void a1_reward_step_kernel(RewK k, mg_a1_
     st.steps[e] = steps;
 }
 
+// ---- sensor stack -> observation (robot_sensors.py, locomotion_gym_env.py:621-632) -------------------------------------
+
+__global__ __launch_bounds__(A1_BLOCK) void a1_observation_kernel(mg_a1_sensor_config c, mg_a1_sensor_state st, int n,
+                                                                  const double *base, const double *rpy, const double *drpy,
+                                                                  const double *angles, const double *contact,
+                                                                  const uint8_t *reset_mask, double *obs) {
+    const int e = blockIdx.x * A1_BLOCK + threadIdx.x;
+    if (e >= n) return;
+    double *o = obs + (size_t)e * MG_A1_SENSOR_OBS_DIM;
+    const bool was_reset = reset_mask != nullptr && reset_mask[e];
+    int first = was_reset ? 3 : st.first[e];                                      // IMUSensor.reset / MotorAngleAccSensor.reset
+    double cur[3], last[3], yaw_last, yaw_cur;
+    for (int i = 0; i < 3; ++i) cur[i] = base[(size_t)i * n + e];
+    yaw_cur = rpy[2 * (size_t)n + e];
+    if (was_reset) {                                                             // BaseDisplacementSensor.on_reset :298-303
+        for (int i = 0; i < 3; ++i) last[i] = cur[i];
+        yaw_last = yaw_cur;
+    } else {                                                                     // on_step :305-310
+        for (int i = 0; i < 3; ++i) last[i] = st.base_cur[(size_t)i * n + e];
+        yaw_last = st.yaw[(size_t)n + e];
+    }
+    for (int i = 0; i < 3; ++i) { st.base_last[(size_t)i * n + e] = last[i]; st.base_cur[(size_t)i * n + e] = cur[i]; }
+    st.yaw[e] = yaw_last; st.yaw[(size_t)n + e] = yaw_cur;
+    // BaseDisplacementSensor._get_observation :278-296
+    const double dx = (cur[0] - last[0]) / c.disp_dt, dy = (cur[1] - last[1]) / c.disp_dt, dz = (cur[2] - last[2]) / c.disp_dt;
+    const double cy = cos(yaw_last), sy = sin(yaw_last);
+    double d0 = cy * dx + sy * dy, d1 = -sy * dx + cy * dy, d2 = dz;
+    if (c.normal) { d0 = (d0 - 0.0) / 0.1; d1 = (d1 - 0.0) / 0.1; d2 = (d2 - 0.0) / 0.1; }
+    o[0] = d0; o[1] = d1; o[2] = d2;
+    // FootContactSensor :575-576
+    for (int f = 0; f < 4; ++f) o[3 + f] = contact[(size_t)f * n + e];
+    // IMUSensor._get_observation :387-434
+    for (int i = 0; i < 3; ++i) {
+        const double r = rpy[(size_t)i * n + e];
+        double fr = st.first_rpy[(size_t)i * n + e];
+        if (first & 1) { fr = r; st.first_rpy[(size_t)i * n + e] = r; }
+        double v = r - fr, w = drpy[(size_t)i * n + e];
+        if (c.normal) { v = (v - 0.0) / 0.1; w = (w - 0.0) / 0.5; }
+        o[7 + i] = v; o[10 + i] = w;
+    }
+    // MotorAngleAccSensor._get_observation :136-158
+    const double mean[3] = {0.0, 0.9, -1.8};
+    for (int i = 0; i < NM; ++i) {
+        const double a = angles[(size_t)i * n + e];
+        double acc = (first & 2) ? 0.0 : (a - st.last_angle[(size_t)i * n + e]) / c.motor_dt;
+        st.last_angle[(size_t)i * n + e] = a;
+        double av = a;
+        if (c.normal) { av = (a - mean[i % 3]) / 0.1; acc = (acc - 0.0) / 1.0; }
+        o[13 + i] = av; o[25 + i] = acc;
+    }
+    st.first[e] = 0;
+}
+
 int check_a1(const mg_a1_actuator_config *cfg, const mg_a1_actuator_state *st, int n) {
     if (!cfg || !st) return mg::set_error(MG_ERR_NULL_POINTER, "a1: NULL descriptor");
     if (n <= 0) return mg::set_error(MG_ERR_BAD_SIZE, "n_envs=%d", n);
@@ -521,4 +574,24 @@ extern "C" int mg_a1_reward_step(const mg_a1_reward_config *cfg, int32_t n, cons
     hipLaunchKernelGGL(a1_reward_step_kernel, dim3((n + A1_BLOCK - 1) / A1_BLOCK), dim3(A1_BLOCK), 0, (hipStream_t)stream, k,
                        *st, n, base, pose, rot_mat, footposition, real_contact, energy, bad_contacts, d_yaw, terms, reward, done);
     return mg::check_launch("a1_reward_step_kernel");
+}
+
+extern "C" int mg_a1_observation(const mg_a1_sensor_config *cfg, int32_t n, const mg_a1_sensor_state *st, const double *base,
+                                 const double *rpy, const double *drpy, const double *motor_angles, const double *contact,
+                                 const uint8_t *reset_mask, double *obs, void *stream) {
+    if (!cfg || !st) return mg::set_error(MG_ERR_NULL_POINTER, "mg_a1_observation: NULL descriptor");
+    if (n <= 0) return mg::set_error(MG_ERR_BAD_SIZE, "n_envs=%d", n);
+    if (!(cfg->disp_dt > 0) || !(cfg->motor_dt > 0)) return mg::set_error(MG_ERR_BAD_CONFIG, "a1 sensors: dt");
+    if (!st->base_last || !st->base_cur || !st->yaw || !st->first_rpy || !st->last_angle || !st->first)
+        return mg::set_error(MG_ERR_NULL_POINTER, "mg_a1_sensor_state has a NULL array");
+    MG_REQUIRE_PTR(base);
+    MG_REQUIRE_PTR(rpy);
+    MG_REQUIRE_PTR(drpy);
+    MG_REQUIRE_PTR(motor_angles);
+    MG_REQUIRE_PTR(contact);
+    MG_REQUIRE_PTR(obs);
+    mg::DeviceGuard guard(mg::device_of(st->base_cur));
+    hipLaunchKernelGGL(a1_observation_kernel, dim3((n + A1_BLOCK - 1) / A1_BLOCK), dim3(A1_BLOCK), 0, (hipStream_t)stream, *cfg,
+                       *st, n, base, rpy, drpy, motor_angles, contact, reset_mask, obs);
+    return mg::check_launch("a1_observation_kernel");
 }

@@ -3,7 +3,9 @@ step (metagym/quadrupedal/robots/a1.py, minitaur.py, laikago_motor.py), with the
 
     act = A1Actuators(num_envs=4096, device="cuda:0")               # POSITION mode, kp/kd of a1.py:63-68
     act.Reset()                                                     # Minitaur.Reset: history cleared
-    act.ReceiveObservation(q, qd, base_quat, rpy_rate)              # first observation (minitaur.py:226)
+    act.ReceiveObservation(q, qd, base_quat, rpy_rate)              # first observation (Reset -> _SettleDownForReset,
+                                                                    # minitaur.py:460-462). A bare `a1.A1(...)` observes a second
+                                                                    # time in __init__ (:226): call it twice to mirror that
     torques = act.Step(action, physics)                             # 13 x (ApplyAction -> physics -> ReceiveObservation)
 
 `physics(torques) -> (q, qd, base_quat, rpy_rate)` is the caller's simulator: the A1 body is not part of this package

@@ -143,3 +143,37 @@ class RewardShaping(object):
         for k, t in self._t.items():
             assert sd[k].shape == t.shape, k
             t.copy_(sd[k])
+
+
+class SensorStack(object):
+    """The observation of `A1GymEnv` (37 float64): BaseDisplacementSensor (local frame), FootContactSensor, IMUSensor
+    (R P Y dR dP dY), MotorAngleAccSensor in sensor-name order (envs/sensors/robot_sensors.py, locomotion_gym_env.py:621-632)."""
+
+    def __init__(self, num_envs, device="cuda:0", normal=0, num_action_repeat=13, sim_time_step=0.002):
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise _lib.MetaGymHipError("metagym_amd has no CPU path: device must be a ROCm GPU, got %r" % (device,))
+        self._lib = _lib.load()
+        self.num_envs = N = int(num_envs)
+        c = self._cfg = _lib.A1SensorConfig()
+        c.normal, c.disp_dt, c.motor_dt = int(normal), 0.026, num_action_repeat * sim_time_step        # env_builder.py:49
+        f64 = dict(dtype=torch.float64, device=self.device)
+        self._t = dict(base_last=torch.zeros(3, N, **f64), base_cur=torch.zeros(3, N, **f64), yaw=torch.zeros(2, N, **f64),
+                       first_rpy=torch.zeros(3, N, **f64), last_angle=torch.zeros(12, N, **f64),
+                       first=torch.full((N,), 3, dtype=torch.int32, device=self.device))
+        s = self._st = _lib.A1SensorState()
+        for k, t in self._t.items():
+            setattr(s, k, t.data_ptr())
+
+    def observe(self, base_position, base_rpy, base_rpy_rate, motor_angles, foot_contacts, reset_mask=None):
+        """-> obs `[num_envs, 37]`. `reset_mask`: robots that were just reset (sensor.reset() + on_reset instead of on_step)."""
+        N, d = self.num_envs, self.device
+        b, r, dr = _soa(base_position, N, 3, d), _soa(base_rpy, N, 3, d), _soa(base_rpy_rate, N, 3, d)
+        a, ct = _soa(motor_angles, N, 12, d), _soa(foot_contacts, N, 4, d)
+        m = None if reset_mask is None else torch.as_tensor(reset_mask, device=d).to(torch.uint8).contiguous()
+        obs = torch.empty(N, _lib.A1_SENSOR_OBS_DIM, dtype=torch.float64, device=d)
+        with torch.cuda.device(d):
+            rc = self._lib.mg_a1_observation(C.byref(self._cfg), N, C.byref(self._st), _lib.ptr(b), _lib.ptr(r), _lib.ptr(dr),
+                                             _lib.ptr(a), _lib.ptr(ct), _lib.ptr(m), _lib.ptr(obs), _lib.current_stream(d))
+        _lib.check(rc, "mg_a1_observation")
+        return obs

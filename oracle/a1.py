@@ -315,3 +315,41 @@ class RewardShaping(object):
         self.last_base10[0, :] = base
         self.last_foot = fw
         return np.array([torso, up, feet, tau, badfoot, footcontact]), self.reward_p * rewards, done
+
+
+class SensorStack(object):
+    """One robot's observation: the four default sensors of env_builder.py:62-80 in sensor-name order
+    (robot_sensors.py:85-162,217-312,314-437,552-578; locomotion_gym_env.py:621-632; env_utils.py:11-42)."""
+
+    def __init__(self, normal=0, motor_dt=13 * 0.002, disp_dt=0.026):
+        self.normal, self.motor_dt, self.disp_dt = normal, motor_dt, disp_dt
+        self.imu_first = self.motor_first = True
+        self.last_angle = np.zeros(12)
+
+    def observe(self, base, rpy, drpy, angles, contact, was_reset):
+        base, rpy, angles = np.array(base, np.float64), np.array(rpy, np.float64), np.array(angles, np.float64)
+        if was_reset:
+            self.imu_first = self.motor_first = True                       # IMUSensor.reset :435-436, MotorAngleAccSensor.reset :159-162
+            self.last_angle = np.zeros(12)
+            self.cur, self.last, self.yaw_cur, self.yaw_last = base, base, rpy[2], rpy[2]       # on_reset :298-303
+        else:
+            self.last, self.cur, self.yaw_last, self.yaw_cur = self.cur, base, self.yaw_cur, rpy[2]   # on_step :305-310
+        dx, dy, dz = (self.cur - self.last) / self.disp_dt                 # :280
+        disp = np.array([np.cos(self.yaw_last) * dx + np.sin(self.yaw_last) * dy,
+                         -np.sin(self.yaw_last) * dx + np.cos(self.yaw_last) * dy, dz])
+        if self.normal:
+            disp = (disp - np.array([0] * 3)) / np.array([0.1] * 3)
+        if self.imu_first:                                                 # :388-390
+            self.first_rpy, self.imu_first = rpy.copy(), False
+        imu = np.concatenate([rpy - self.first_rpy, drpy])
+        if self.normal:
+            imu = (imu - np.array([0] * 6)) / np.array([0.1] * 3 + [0.5] * 3)
+        if self.motor_first:                                               # :141-145
+            acc, self.motor_first = np.zeros(12), False
+        else:
+            acc = (angles - self.last_angle) / self.motor_dt
+        self.last_angle = angles
+        motor = np.concatenate((angles, acc))
+        if self.normal:
+            motor = (motor - np.array([0, 0.9, -1.8] * 4 + [0] * 12)) / np.array([0.1] * 12 + [1] * 12)
+        return np.concatenate([disp, np.asarray(contact, np.float64), imu, motor])   # BaseDisplacement < FootContactSensor < IMU < MotorAngleAcc

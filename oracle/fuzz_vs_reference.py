@@ -311,6 +311,51 @@ def fuzz_sampler(gym, n_cfg, seed):
     return bad
 
 
+def fuzz_a1(n_cfg, seed):
+    """Quadrupedal actuation: random motor modes, gains, latencies (PD and control, up to longer than the history), action
+    repeat, interpolation, clip, strength ratios and torque limits through the unmodified a1.A1 on the scripted Bullet
+    client of gen_golden_a1.py, and through oracle/a1.py fed the recorded world states: every torque and control
+    observation must be bit-identical."""
+    import gen_golden_a1 as ga
+    from oracle import a1 as oa
+    a1, robot_config = ga.import_reference()
+    M = robot_config.MotorControlMode
+    rs = np.random.RandomState(seed + 4242)
+    bad = subs = 0
+    for i in range(n_cfg):
+        mode = [M.POSITION, M.HYBRID, M.TORQUE][rs.randint(3)]
+        c = dict(name="f", seed=int(rs.randint(1 << 30)), mode=mode, n_steps=int(rs.randint(3, 12)),
+                 action_repeat=int(rs.randint(1, 20)), control_latency=float(rs.choice([0.0, rs.uniform(0, 0.05)])),
+                 pd_latency=float(rs.choice([0.0, rs.uniform(0, 0.01)])), interpolate=bool(rs.randint(2)),
+                 clip=bool(rs.randint(2)) and mode is M.POSITION, big=bool(rs.randint(2)),
+                 strength=rs.uniform(0.3, 1.0, 12), torque_limit=float(rs.uniform(5, 40)))
+        if mode is M.POSITION and rs.randint(2):
+            c.update(kp=rs.uniform(20, 300, 12), kd=rs.uniform(0.1, 6, 12))
+        g = ga.run_case(a1, robot_config, **c)
+        act = oa.from_golden(g, "f")
+        repeat = int(g["f/config"][1])
+        first = g["f/first_obs"][0]
+        act.reset()
+        for _ in range(int(g["f/n_history_at_start"][0])):      # the constructor observes twice (minitaur.py:226 after Reset)
+            act.receive_observation(first[None, 0:12], first[None, 12:24], first[None, 36:40], first[None, 40:43])
+        k, ok = 0, True
+        for s_ in range(int(g["f/config"][7])):
+            action = g["f/action"][s_][None]
+            for j in range(repeat):
+                t = act.apply_action(act.process_action(action, j))
+                true = g["f/true_obs"][k]
+                act.receive_observation(true[None, 0:12], true[None, 12:24], true[None, 36:40], true[None, 40:43])
+                ok = ok and np.array_equal(t[0], g["f/torque"][k]) and np.array_equal(act.control_obs[0], g["f/control_obs"][k])
+                k += 1
+            act.last_action = action
+            ang, vel, tor, rate, energy = act.sensors()
+            ok = ok and np.array_equal(ang[0], g["f/motor_angles"][s_]) and np.array_equal(rate[0], g["f/rpy_rate"][s_])
+        subs += k
+        bad += not ok
+    print(json.dumps({"a1_actuation_configs": n_cfg, "sub_steps": subs, "configs_with_any_difference": bad}))
+    return bad
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--quad", type=int, default=60)
@@ -318,12 +363,13 @@ def main():
     ap.add_argument("--tasks", type=int, default=40)
     ap.add_argument("--maze2", type=int, default=40)
     ap.add_argument("--sampler", type=int, default=40)
+    ap.add_argument("--a1", type=int, default=40)
     ap.add_argument("--seed", type=int, default=0)
     args = ap.parse_args()
     gym = gen_golden._import_reference()
     bad = (fuzz_quadrotor(gym, args.quad, args.seed) + fuzz_quadrotor_tasks(gym, args.tasks, args.seed) +
            fuzz_maze(gym, args.maze, args.seed) + fuzz_maze_2d_and_continuous(gym, args.maze2, args.seed) +
-           fuzz_sampler(gym, args.sampler, args.seed))
+           fuzz_sampler(gym, args.sampler, args.seed) + fuzz_a1(args.a1, args.seed))
     sys.exit(1 if bad else 0)
 
 

@@ -72,3 +72,17 @@ def test_reward_shaping_matches_reference(g, idx):
         assert np.allclose(reward.cpu().numpy(), g[name + "/reward"][k], **TOL)
         assert bool(done.cpu().numpy()[2]) == bool(g[name + "/done"][k]), "%s done, step %d" % (name, k)
         assert np.allclose(r._t["last_foot"].t().cpu().numpy()[0], g[name + "/foot_world"][k].reshape(-1), **TOL)
+
+
+@pytest.mark.parametrize("name", ["sensors_raw", "sensors_normalised"])
+def test_sensor_stack_matches_reference(name):
+    from metagym_amd.quadrupedal import SensorStack
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "a1_sensors.npz"))
+    normal, _dt = g[name + "/config"]
+    n = 3
+    st = SensorStack(n, DEV, normal=int(normal))
+    for k in range(len(g[name + "/obs"])):
+        mask = torch.full((n,), bool(g[name + "/kind"][k] == 0), device=DEV)
+        obs = st.observe(T(g[name + "/in_base"][k], n), T(g[name + "/in_rpy"][k], n), T(g[name + "/in_drpy"][k], n),
+                         T(g[name + "/in_angles"][k], n), T(g[name + "/in_contact"][k], n), reset_mask=mask)
+        assert np.allclose(obs.cpu().numpy(), np.broadcast_to(g[name + "/obs"][k], (n, 37)), **TOL), "%s observation %d" % (name, k)

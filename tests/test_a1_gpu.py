@@ -41,7 +41,8 @@ def test_kernels_reproduce_reference_actuation(g, idx):
     act = make_actuators(g, name, n)
     first = g[name + "/first_obs"][0]
     act.Reset()
-    act.ReceiveObservation(T(first[0:12], n), T(first[12:24], n), T(first[36:40], n), T(first[40:43], n))
+    for _ in range(int(g[name + "/n_history_at_start"][0])):      # a1.A1.__init__ observes twice before the first Step
+        act.ReceiveObservation(T(first[0:12], n), T(first[12:24], n), T(first[36:40], n), T(first[40:43], n))
     k = [0]
 
     def physics(torque):

@@ -22,7 +22,10 @@ def replay(g, name, act):
     repeat, n_steps = int(repeat), int(n_steps)
     first = g[name + "/first_obs"][0]
     act.reset()
-    act.receive_observation(first[None, 0:12], first[None, 12:24], first[None, 36:40], first[None, 40:43])
+    # a1.A1.__init__ observes twice before the first Step (Reset -> _SettleDownForReset, then minitaur.py:226): the
+    # history starts with two identical entries, and a blend of two equal values is not always that value bit for bit
+    for _ in range(int(g[name + "/n_history_at_start"][0])):
+        act.receive_observation(first[None, 0:12], first[None, 12:24], first[None, 36:40], first[None, 40:43])
     k = 0
     for s in range(n_steps):
         action = g[name + "/action"][s][None]

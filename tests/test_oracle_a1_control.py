@@ -67,3 +67,14 @@ def test_reward_goldens_cover_every_termination_rule(g):
     done = {n: g[n + "/done"] for n in map(str, g["c_cases"])}
     assert done["reward_tumble"].any() and done["reward_feet_up"].any() and done["reward_still"].any()
     assert not done["reward_walk"][:5].any()
+
+
+@pytest.mark.parametrize("name", ["sensors_raw", "sensors_normalised"])
+def test_sensor_stack_matches_reference(name):
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "a1_sensors.npz"))
+    normal, dt = g[name + "/config"]
+    st = oa.SensorStack(int(normal), dt)
+    for k in range(len(g[name + "/obs"])):
+        obs = st.observe(g[name + "/in_base"][k], g[name + "/in_rpy"][k], g[name + "/in_drpy"][k], g[name + "/in_angles"][k],
+                         g[name + "/in_contact"][k], g[name + "/kind"][k] == 0)
+        assert np.array_equal(obs, g[name + "/obs"][k]), "%s observation %d" % (name, k)
