@@ -804,6 +804,7 @@ __device__ __forceinline__ void wave_kinematics(const ModelW &m, const WaveLds &
         L.sc[2 * lane + 1] = cos(qj);
     }
     WSYNC();
+    PHASE_BEGIN();
     for (int level = 0; level <= max_depth; ++level) {
         if (lane < nb && L.depth[lane] == level) {
             const int b = lane, pb = L.parent[b];
@@ -853,6 +854,7 @@ __device__ __forceinline__ void wave_kinematics(const ModelW &m, const WaveLds &
         }
         WSYNC();
     }
+    PHASE(11);      // (profile builds) the level loop alone; phase 0 minus this = sin / cos
 }
 
 template <int NMAX>

@@ -35,6 +35,7 @@ torch.cuda.synchronize()
 lib.mg_walker_profile_read(buf, 0)
 tot = sum(buf[i] for i in range(10))
 out = {NAMES[i]: round(100.0 * buf[i] / tot, 1) for i in range(10)}
+out["kinematics level loop (of kinematics, incl. the calc_state pass)"] = round(100.0 * buf[11] / tot, 1)
 out["cycles_per_substep_per_wave"] = round(tot / (steps * n * 4))
 out["substeps_share_of_kernel_body"] = round(tot / buf[15], 3)
 print(json.dumps({"robot": robot, "envs": n, "phase_percent": out}))
