@@ -590,6 +590,22 @@ int mg_a1_observation(const mg_a1_sensor_config *cfg, int32_t n_envs, const mg_a
                       const double *rpy, const double *drpy, const double *motor_angles, const double *contact,
                       const uint8_t *reset_mask, double *obs, void *stream);
 
+/* ActionFilter.filter / init_history / reset (quadrupedal/robots/action_filter.py:70-99), as Minitaur._FilterAction uses it
+ * on the policy's motor commands (minitaur.py:1438-1457): per joint
+ *   y = x b0 + sum_k xhist[k] b[k+1] - sum_k yhist[k] a[k+1],   history depth = order (low-pass) or 2 order (band-pass).
+ * Coefficients come from the host (scipy.signal.butter like action_filter.py:160-185). Pinned by tests/golden/a1_filter.npz. */
+#define MG_A1_FILTER_MAX_HIST 4
+typedef struct mg_a1_filter_config {
+    int32_t hist_len;                                             /* 1..4 */
+    double a[MG_A1_NUM_MOTORS][MG_A1_FILTER_MAX_HIST + 1];        /* normalised: a[j][0] == 1 */
+    double b[MG_A1_NUM_MOTORS][MG_A1_FILTER_MAX_HIST + 1];
+} mg_a1_filter_config;
+/* xhist, yhist: DEVICE f64 [hist_len][12][N] state (newest first). x: DEVICE f64 [12][N]. y: DEVICE f64 [12][N] out (may alias
+ * x). init_mask: u8 [N] or NULL — robots whose history is first set to x (init_history; the filtered value follows from it);
+ * mode 0 = filter, 1 = reset (histories zeroed for robots in init_mask, or all if NULL; x / y unused). */
+int mg_a1_action_filter(const mg_a1_filter_config *cfg, int32_t n_envs, double *xhist, double *yhist, const double *x,
+                        double *y, const uint8_t *init_mask, int32_t mode, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -189,6 +189,15 @@ class A1SensorState(C.Structure):
                 ("last_angle", C.c_void_p), ("first", C.c_void_p)]
 
 
+A1_FILTER_MAX_HIST = 4
+
+
+class A1FilterConfig(C.Structure):
+    """mg_a1_filter_config"""
+    _fields_ = [("hist_len", C.c_int32), ("a", (C.c_double * (A1_FILTER_MAX_HIST + 1)) * A1_NUM_MOTORS),
+                ("b", (C.c_double * (A1_FILTER_MAX_HIST + 1)) * A1_NUM_MOTORS)]
+
+
 # symbol -> (restype, argtypes); tests/test_abi.py checks this list against include/metagym_hip.h
 _P = C.c_void_p
 SIGNATURES = {
@@ -232,6 +241,7 @@ SIGNATURES = {
     "mg_a1_reward_reset": (C.c_int, [C.POINTER(A1RewardConfig), C.c_int32, C.POINTER(A1RewardState), _P, _P, _P, _P, _P]),
     "mg_a1_observation": (C.c_int, [C.POINTER(A1SensorConfig), C.c_int32, C.POINTER(A1SensorState), _P, _P, _P, _P, _P, _P,
                                     _P, _P]),
+    "mg_a1_action_filter": (C.c_int, [C.POINTER(A1FilterConfig), C.c_int32, _P, _P, _P, _P, _P, C.c_int32, _P]),
     "mg_a1_reward_step": (C.c_int, [C.POINTER(A1RewardConfig), C.c_int32, C.POINTER(A1RewardState), _P, _P, _P, _P, _P,
                                     _P, _P, _P, _P, _P, _P, _P]),
 }

@@ -459,6 +459,41 @@ __global__ __launch_bounds__(A1_BLOCK) void a1_observation_kernel(mg_a1_sensor_c
     st.first[e] = 0;
 }
 
+// ---- ActionFilter (robots/action_filter.py:70-99) ---------------------------------------------------------------------
+
+__global__ __launch_bounds__(A1_BLOCK) void a1_filter_kernel(mg_a1_filter_config c, int n, double *xh, double *yh,
+                                                             const double *x, double *y, const uint8_t *init_mask, int mode) {
+    const int e = blockIdx.x * A1_BLOCK + threadIdx.x;
+    if (e >= n) return;
+    const int H = c.hist_len;
+    const bool flagged = init_mask == nullptr ? mode == 1 : init_mask[e] != 0;
+    if (mode == 1) {                                                             // reset :70-76
+        if (flagged)
+            for (int k = 0; k < H; ++k)
+                for (int j = 0; j < NM; ++j) { xh[((size_t)k * NM + j) * n + e] = 0.0; yh[((size_t)k * NM + j) * n + e] = 0.0; }
+        return;
+    }
+    for (int j = 0; j < NM; ++j) {
+        const double xv = x[(size_t)j * n + e];
+        double hx[MG_A1_FILTER_MAX_HIST], hy[MG_A1_FILTER_MAX_HIST];
+        for (int k = 0; k < H; ++k) {
+            hx[k] = flagged ? xv : xh[((size_t)k * NM + j) * n + e];            // init_history :95-99
+            hy[k] = flagged ? xv : yh[((size_t)k * NM + j) * n + e];
+        }
+        // np.sum(..., axis=-1) over H <= 4 contiguous elements is a plain left-to-right sum (numpy pairs only from 8 up)
+        double sx = hx[0] * c.b[j][1], sy = hy[0] * c.a[j][1];
+        for (int k = 1; k < H; ++k) { sx += hx[k] * c.b[j][k + 1]; sy += hy[k] * c.a[j][k + 1]; }
+        const double yv = (xv * c.b[j][0] + sx) - sy;                            // :80-84
+        for (int k = H - 1; k >= 1; --k) {                                       // appendleft :85-86
+            xh[((size_t)k * NM + j) * n + e] = hx[k - 1];
+            yh[((size_t)k * NM + j) * n + e] = hy[k - 1];
+        }
+        xh[(size_t)j * n + e] = xv;
+        yh[(size_t)j * n + e] = yv;
+        y[(size_t)j * n + e] = yv;
+    }
+}
+
 int check_a1(const mg_a1_actuator_config *cfg, const mg_a1_actuator_state *st, int n) {
     if (!cfg || !st) return mg::set_error(MG_ERR_NULL_POINTER, "a1: NULL descriptor");
     if (n <= 0) return mg::set_error(MG_ERR_BAD_SIZE, "n_envs=%d", n);
@@ -594,4 +629,19 @@ extern "C" int mg_a1_observation(const mg_a1_sensor_config *cfg, int32_t n, cons
     hipLaunchKernelGGL(a1_observation_kernel, dim3((n + A1_BLOCK - 1) / A1_BLOCK), dim3(A1_BLOCK), 0, (hipStream_t)stream, *cfg,
                        *st, n, base, rpy, drpy, motor_angles, contact, reset_mask, obs);
     return mg::check_launch("a1_observation_kernel");
+}
+
+extern "C" int mg_a1_action_filter(const mg_a1_filter_config *cfg, int32_t n, double *xhist, double *yhist, const double *x,
+                                   double *y, const uint8_t *init_mask, int32_t mode, void *stream) {
+    if (!cfg) return mg::set_error(MG_ERR_NULL_POINTER, "mg_a1_action_filter: cfg is NULL");
+    if (n <= 0) return mg::set_error(MG_ERR_BAD_SIZE, "n_envs=%d", n);
+    if (cfg->hist_len < 1 || cfg->hist_len > MG_A1_FILTER_MAX_HIST)
+        return mg::set_error(MG_ERR_BAD_CONFIG, "action filter history %d (1..%d)", cfg->hist_len, MG_A1_FILTER_MAX_HIST);
+    MG_REQUIRE_PTR(xhist);
+    MG_REQUIRE_PTR(yhist);
+    if (mode == 0) { MG_REQUIRE_PTR(x); MG_REQUIRE_PTR(y); }
+    mg::DeviceGuard guard(mg::device_of(xhist));
+    hipLaunchKernelGGL(a1_filter_kernel, dim3((n + A1_BLOCK - 1) / A1_BLOCK), dim3(A1_BLOCK), 0, (hipStream_t)stream, *cfg, n,
+                       xhist, yhist, x, y, init_mask, mode);
+    return mg::check_launch("a1_filter_kernel");
 }

@@ -38,7 +38,7 @@ class A1Actuators(object):
     def __init__(self, num_envs, device="cuda:0", time_step=0.002, action_repeat=13, control_latency=0.002,
                  pd_latency=0.0, motor_control_mode=MotorControlMode.POSITION, motor_kp=DEFAULT_KP, motor_kd=DEFAULT_KD,
                  motor_torque_limits=33.5, enable_action_interpolation=False, enable_clip_motor_commands=False,
-                 history_len=100):
+                 enable_action_filter=False, history_len=100):
         self.device = torch.device(device)
         if self.device.type != "cuda":
             raise _lib.MetaGymHipError("metagym_amd has no CPU path: device must be a ROCm GPU, got %r" % (device,))
@@ -48,6 +48,10 @@ class A1Actuators(object):
         self.time_step = float(time_step)
         self._action_repeat = int(action_repeat)
         self._enable_action_interpolation = bool(enable_action_interpolation)
+        self._action_filter = None
+        if enable_action_filter:                            # Minitaur._BuildActionFilter minitaur.py:1438-1443
+            from .a1_wrappers import ActionFilter
+            self._action_filter = ActionFilter.butter(num_envs, 1 / (float(time_step) * int(action_repeat)), device)
         self._last_action = None
         self._step_counter = 0
         f64 = dict(dtype=torch.float64, device=self.device)
@@ -135,6 +139,8 @@ class A1Actuators(object):
             self._observed_torque[:, m] = 0.0
         self._step_counter = 0
         self._last_action = None
+        if self._action_filter is not None:                 # _ResetActionFilter minitaur.py:1445-1446
+            self._action_filter.reset(mask)
 
     def ProcessAction(self, action, substep_count):
         """minitaur.py:1419-1436 — returns (command, last_command or None, lerp) for the kernel to combine."""
@@ -175,6 +181,10 @@ class A1Actuators(object):
         if control_mode is not None:
             self._set_mode(control_mode)
         k = 5 * NUM_MOTORS if self._motor_control_mode is MotorControlMode.HYBRID else NUM_MOTORS
+        if self._action_filter is not None:                 # _FilterAction minitaur.py:1448-1457
+            if self._step_counter == 0:
+                self._action_filter.init_history(self.GetMotorAngles())
+            action = self._action_filter.filter(action)
         act = self._soa(action, k)
         torques = []
         for i in range(self._action_repeat):

@@ -177,3 +177,65 @@ class SensorStack(object):
                                              _lib.ptr(a), _lib.ptr(ct), _lib.ptr(m), _lib.ptr(obs), _lib.current_stream(d))
         _lib.check(rc, "mg_a1_observation")
         return obs
+
+
+class ActionFilter(object):
+    """`ActionFilter` / `ActionFilterButter` / `ActionFilterExp` of quadrupedal/robots/action_filter.py for N robots.
+    Give normalised coefficient arrays `a`, `b` `[12, hist_len + 1]`, or use `butter()` for the reference's default
+    (`Minitaur._BuildActionFilter`, minitaur.py:1438-1443: 2nd-order Butterworth low-pass at 4 Hz)."""
+
+    def __init__(self, num_envs, a, b, device="cuda:0"):
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise _lib.MetaGymHipError("metagym_amd has no CPU path: device must be a ROCm GPU, got %r" % (device,))
+        self._lib = _lib.load()
+        self.num_envs = N = int(num_envs)
+        a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+        assert a.shape == b.shape and a.shape[0] == 12 and 2 <= a.shape[1] <= _lib.A1_FILTER_MAX_HIST + 1
+        c = self._cfg = _lib.A1FilterConfig()
+        c.hist_len = H = a.shape[1] - 1
+        for j in range(12):
+            c.a[j][:H + 1] = list(a[j] / a[j][0])          # action_filter.py:55-57
+            c.b[j][:H + 1] = list(b[j] / a[j][0])
+        self.xhist = torch.zeros(H, 12, N, dtype=torch.float64, device=self.device)
+        self.yhist = torch.zeros(H, 12, N, dtype=torch.float64, device=self.device)
+
+    @classmethod
+    def butter(cls, num_envs, sampling_rate, device="cuda:0", lowcut=(0.0,), highcut=(4.0,), order=2):
+        """ActionFilterButter (action_filter.py:102-185); the coefficients are scipy.signal.butter's, like the reference's."""
+        from scipy.signal import butter
+        lowcut, highcut = [float(x) for x in lowcut], [float(x) for x in highcut]
+        a, b = [], []
+        for l, h in zip(lowcut, highcut):
+            nyq = 0.5 * sampling_rate
+            bb, aa = butter(order, [l / nyq, h / nyq], btype="band") if l else butter(order, [h / nyq], btype="low")
+            a.append(aa); b.append(bb)
+        if len(a) == 1:
+            a, b = a * 12, b * 12
+        return cls(num_envs, np.stack(a), np.stack(b), device)
+
+    def _call(self, x, y, mask, mode):
+        m = None if mask is None else torch.as_tensor(mask, device=self.device).to(torch.uint8).contiguous()
+        with torch.cuda.device(self.device):
+            rc = self._lib.mg_a1_action_filter(C.byref(self._cfg), self.num_envs, _lib.ptr(self.xhist), _lib.ptr(self.yhist),
+                                               _lib.ptr(x), _lib.ptr(y), _lib.ptr(m), mode, _lib.current_stream(self.device))
+        _lib.check(rc, "mg_a1_action_filter")
+
+    def reset(self, mask=None):
+        self._call(None, None, mask, 1)
+
+    def filter(self, x, init_mask=None):
+        """x `[num_envs, 12]` -> filtered `[num_envs, 12]`. Robots in `init_mask` first get `init_history(x)` (the reference
+        does that with the current motor angles on the first step of an episode, minitaur.py:1452-1454 — pass those as x
+        through `init_history` instead when they differ from the command)."""
+        xs = _soa(x, self.num_envs, 12, self.device)
+        y = torch.empty_like(xs)
+        self._call(xs, y, init_mask, 0)
+        return y.t()
+
+    def init_history(self, x, mask=None):
+        """ActionFilter.init_history (action_filter.py:95-99) for the robots in `mask` (None = all)."""
+        xs = _soa(x, self.num_envs, 12, self.device)
+        sel = slice(None) if mask is None else torch.as_tensor(mask, device=self.device).bool()
+        self.xhist[:, :, sel] = xs[:, sel]
+        self.yhist[:, :, sel] = xs[:, sel]

@@ -353,3 +353,27 @@ class SensorStack(object):
         if self.normal:
             motor = (motor - np.array([0, 0.9, -1.8] * 4 + [0] * 12)) / np.array([0.1] * 12 + [1] * 12)
         return np.concatenate([disp, np.asarray(contact, np.float64), imu, motor])   # BaseDisplacement < FootContactSensor < IMU < MotorAngleAcc
+
+
+class ActionFilter(object):
+    """robots/action_filter.py:31-99 for one robot: normalised coefficients a, b [12, H + 1], histories newest first."""
+
+    def __init__(self, a, b):
+        self.a, self.b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+        self.H = self.a.shape[1] - 1
+        self.reset()
+
+    def reset(self):                                       # :70-76
+        self.xhist = [np.zeros(12) for _ in range(self.H)]
+        self.yhist = [np.zeros(12) for _ in range(self.H)]
+
+    def init_history(self, x):                             # :95-99
+        self.xhist = [np.array(x, np.float64) for _ in range(self.H)]
+        self.yhist = [np.array(x, np.float64) for _ in range(self.H)]
+
+    def filter(self, x):                                   # :78-93
+        xs, ys = np.stack(self.xhist, axis=-1), np.stack(self.yhist, axis=-1)
+        y = np.multiply(x, self.b[:, 0]) + np.sum(np.multiply(xs, self.b[:, 1:]), axis=-1) - np.sum(np.multiply(ys, self.a[:, 1:]), axis=-1)
+        self.xhist = [np.array(x, np.float64)] + self.xhist[:-1]
+        self.yhist = [y.copy()] + self.yhist[:-1]
+        return y

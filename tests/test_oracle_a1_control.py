@@ -78,3 +78,26 @@ def test_sensor_stack_matches_reference(name):
         obs = st.observe(g[name + "/in_base"][k], g[name + "/in_rpy"][k], g[name + "/in_drpy"][k], g[name + "/in_angles"][k],
                          g[name + "/in_contact"][k], g[name + "/kind"][k] == 0)
         assert np.array_equal(obs, g[name + "/obs"][k]), "%s observation %d" % (name, k)
+
+
+@pytest.mark.parametrize("name", ["butter_default", "butter_bandpass", "exp"])
+def test_action_filter_matches_reference(name):
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "a1_filter.npz"))
+    f = oa.ActionFilter(g[name + "/a"], g[name + "/b"])
+    for k in range(len(g[name + "/x"])):
+        kind, x = g[name + "/kind"][k], g[name + "/x"][k]
+        if kind == 1:
+            f.reset()
+        elif kind == 2:
+            f.reset(); f.init_history(x)
+        else:
+            assert np.array_equal(f.filter(x), g[name + "/y"][k]), "%s sample %d" % (name, k)
+
+
+def test_butter_coefficients_are_scipys():
+    """The product's ActionFilter.butter must hand the kernel the coefficients the reference's ActionFilterButter computes."""
+    pytest.importorskip("scipy")
+    from scipy.signal import butter
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "a1_filter.npz"))
+    b, a = butter(2, [4.0 / (0.5 * (1 / (0.002 * 13)))], btype="low")
+    assert np.array_equal(a / a[0], g["butter_default/a"][0]) and np.array_equal(b / a[0], g["butter_default/b"][0])
