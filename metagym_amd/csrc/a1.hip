@@ -133,23 +133,36 @@ __global__ __launch_bounds__(A1_BLOCK) void a1_receive_kernel(A1K k, mg_a1_actua
     head = count == 0 ? 0 : (head + 1 == c.history_len ? 0 : head + 1);             // appendleft
     if (count < c.history_len) ++count;
     double *slot = st.history + (size_t)head * stride + e;
+    double in[OD];                                                                  // (all 43 loads in flight, then the stores)
 #pragma unroll
     for (int i = 0; i < NM; ++i) {
         // GetTrueMotorAngles (:743-753): (angle - offset) * direction with offset 0, direction 1 (a1.py:43-49)
-        slot[(size_t)i * n] = (q[(size_t)i * n + e] - 0.0) * 1.0;
-        slot[(size_t)(NM + i) * n] = qd[(size_t)i * n + e] * 1.0;
-        slot[(size_t)(2 * NM + i) * n] = st.observed_torque[(size_t)i * n + e];
+        in[i] = (q[(size_t)i * n + e] - 0.0) * 1.0;
+        in[NM + i] = qd[(size_t)i * n + e] * 1.0;
+        in[2 * NM + i] = st.observed_torque[(size_t)i * n + e];
     }
 #pragma unroll
-    for (int i = 0; i < 4; ++i) slot[(size_t)(3 * NM + i) * n] = quat[(size_t)i * n + e];
+    for (int i = 0; i < 4; ++i) in[3 * NM + i] = quat[(size_t)i * n + e];
 #pragma unroll
-    for (int i = 0; i < 3; ++i) slot[(size_t)(3 * NM + 4 + i) * n] = rate[(size_t)i * n + e];
+    for (int i = 0; i < 3; ++i) in[3 * NM + 4 + i] = rate[(size_t)i * n + e];
+#pragma unroll
+    for (int i = 0; i < OD; ++i) slot[(size_t)i * n] = in[i];
     st.count[e] = count;
     st.head[e] = head;
     // a lane reads back only what it wrote itself (its own column of the ring): no fence needed
     const double lat = c.control_latency_env ? c.control_latency_env[e] : c.control_latency;
     const Delay d = delayed(lat, c.time_step, count, head, c.history_len);
-    for (int comp = 0; comp < OD; ++comp) st.control_obs[(size_t)comp * n + e] = blend(d, st.history, stride, comp, n, e);
+    // all loads of a chunk first, then its stores: written as load -> store per component the compiler must assume the
+    // control-observation store may alias the history and serialises 43 dependent round trips
+    constexpr int CH = 11;
+    for (int c0 = 0; c0 < OD; c0 += CH) {
+        double v[CH];
+#pragma unroll
+        for (int i = 0; i < CH; ++i) v[i] = c0 + i < OD ? blend(d, st.history, stride, c0 + i, n, e) : 0.0;
+#pragma unroll
+        for (int i = 0; i < CH; ++i)
+            if (c0 + i < OD) st.control_obs[(size_t)(c0 + i) * n + e] = v[i];
+    }
 }
 
 __global__ __launch_bounds__(A1_BLOCK) void a1_sensors_kernel(A1K k, mg_a1_actuator_state st, int n, double *angles,

@@ -134,19 +134,21 @@ HIP_OFFSETS = np.array([[0.183, -0.047, 0.], [0.183, 0.047, 0.], [-0.183, -0.047
 POSE_ORI = np.array([0, 0.9, -1.8] * 4)                                                                    # ETG_model.py:83
 
 
-def foot_position_in_hip_frame_to_joint_angle(foot_position, l_hip_sign=1):
-    """robots/a1.py:88-102, verbatim arithmetic."""
-    l_up, l_low = 0.2, 0.2
-    l_hip = 0.08505 * l_hip_sign
-    x, y, z = foot_position[0], foot_position[1], foot_position[2]
+def leg_ik(foot, side):
+    """Leg inverse kinematics of robots/a1.py:88-102 (foot position in the hip frame -> abduction, hip, knee angles), same
+    operations in the same order: squares as `**2`, knee from the law of cosines, the virtual leg length from the knee angle,
+    hip from the fore-aft offset, abduction from atan2 of the lateral / vertical pair. `side` = +1 left, -1 right."""
+    upper = lower = 0.2
+    hip = 0.08505 * side
+    fx, fy, fz = foot[0], foot[1], foot[2]
     with np.errstate(invalid="ignore"):
-        theta_knee = -np.arccos((x**2 + y**2 + z**2 - l_hip**2 - l_low**2 - l_up**2) / (2 * l_low * l_up))
-        l = np.sqrt(l_up**2 + l_low**2 + 2 * l_up * l_low * np.cos(theta_knee))
-        theta_hip = np.arcsin(-x / l) - theta_knee / 2
-    c1 = l_hip * y - l * np.cos(theta_hip + theta_knee / 2) * z
-    s1 = l * np.cos(theta_hip + theta_knee / 2) * y + l_hip * z
-    theta_ab = np.arctan2(s1, c1)
-    return np.array([theta_ab, theta_hip, theta_knee])
+        knee = -np.arccos((fx**2 + fy**2 + fz**2 - hip**2 - lower**2 - upper**2) / (2 * lower * upper))
+        leg = np.sqrt(upper**2 + lower**2 + 2 * upper * lower * np.cos(knee))
+        hip_angle = np.arcsin(-fx / leg) - knee / 2
+    swing = np.cos(hip_angle + knee / 2)
+    cos_term = hip * fy - leg * swing * fz
+    sin_term = leg * swing * fy + hip * fz
+    return np.array([np.arctan2(sin_term, cos_term), hip_angle, knee])
 
 
 class EtgActionPath(object):
@@ -187,8 +189,7 @@ class EtgActionPath(object):
             for i in range(4):
                 delta = new_act[i * 3:(i + 1) * 3].copy()
                 while True:
-                    angle = foot_position_in_hip_frame_to_joint_angle(delta + BASE_FOOT[i * 3:(i + 1) * 3] - HIP_OFFSETS[i],
-                                                                      l_hip_sign=(-1) ** (i + 1))      # a1.py:509-511
+                    angle = leg_ik(delta + BASE_FOOT[i * 3:(i + 1) * 3] - HIP_OFFSETS[i], (-1) ** (i + 1))   # a1.py:509-511
                     angle = np.multiply(angle - np.zeros(3), np.ones(3))                               # :514-517
                     if np.sum(np.isnan(angle)) == 0:
                         break
