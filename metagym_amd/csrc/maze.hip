@@ -627,9 +627,13 @@ __device__ __forceinline__ void pixel_pass(const ViewK &vk, const Task &t, doubl
                 const double alpha = a * rk.light;
                 const uint32_t tx = vk.tex[__umul24(__umul24((uint32_t)texts[cell], TS) + (uint32_t)ti, TS) + (uint32_t)tj];
                 const double oma = 1.0 - alpha;
+#ifdef MG_MAZE3D_KNOCKOUT_COLOR      /* timing experiment only: no colour arithmetic */
+                R = (int)(tx & 255u) + (int)oma; G = (int)((tx >> 8) & 255u); B = (int)(tx >> 16);
+#else
                 R = (int)(rk.light * (oma * tex_r(tx)));
                 G = (int)(rk.light * (oma * tex_g(tx)));
                 B = (int)(rk.light * (oma * tex_b(tx)));
+#endif
                 const double tr = transp[cell];
                 if (tr > 0.01) {
                     const double tf = tr * 0.50 + 0.10, om = 1.0 - tf;
