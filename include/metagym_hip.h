@@ -606,6 +606,17 @@ typedef struct mg_a1_filter_config {
 int mg_a1_action_filter(const mg_a1_filter_config *cfg, int32_t n_envs, double *xhist, double *yhist, const double *x,
                         double *y, const uint8_t *init_mask, int32_t mode, void *stream);
 
+/* The Python-computed entries of LocomotionGymEnv's `info` (locomotion_gym_env.py:534-545) from the control observation:
+ *   pose          GetBaseRollPitchYaw minitaur.py:622-636 — roll, pitch, yaw of the DELAYED base quaternion. The reference
+ *                 asks Bullet (getEulerFromQuaternion); here the standard ZYX formulas (roll = atan2(2(wx+yz), 1-2(x^2+y^2)),
+ *                 pitch = asin(2(wy-zx)), yaw = atan2(2(wz+xy), 1-2(y^2+z^2))) — Bullet's own code is not in the reference tree
+ *   rot_mat       getMatrixFromQuaternion(GetBaseOrientation()) :830-838: matrix of the quaternion rebuilt from `pose`
+ *   footposition  GetFootPositionsInBaseFrame a1.py:141-147,527-530: leg forward kinematics of the motor angles (a1.py:105-123)
+ *   joint_angle, drpy, energy as mg_a1_sensors.
+ * Every output may be NULL. pose [3][N], rot_mat [9][N], footposition [12][N], joint_angle [12][N], drpy [3][N], energy [N]. */
+int mg_a1_info(const mg_a1_actuator_config *cfg, int32_t n_envs, const mg_a1_actuator_state *state, double *pose,
+               double *rot_mat, double *footposition, double *joint_angle, double *drpy, double *energy, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

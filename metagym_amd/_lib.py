@@ -237,6 +237,7 @@ SIGNATURES = {
                                             _P, _P, _P, _P, _P, _P]),
     "mg_a1_sensors": (C.c_int, [C.POINTER(A1ActuatorConfig), C.c_int32, C.POINTER(A1ActuatorState),
                                 _P, _P, _P, _P, _P, _P]),
+    "mg_a1_info": (C.c_int, [C.POINTER(A1ActuatorConfig), C.c_int32, C.POINTER(A1ActuatorState), _P, _P, _P, _P, _P, _P, _P]),
     "mg_a1_etg_action": (C.c_int, [C.POINTER(A1EtgConfig), C.c_int32, _P, _P, _P, _P, _P, _P]),
     "mg_a1_reward_reset": (C.c_int, [C.POINTER(A1RewardConfig), C.c_int32, C.POINTER(A1RewardState), _P, _P, _P, _P, _P]),
     "mg_a1_observation": (C.c_int, [C.POINTER(A1SensorConfig), C.c_int32, C.POINTER(A1SensorState), _P, _P, _P, _P, _P, _P,

@@ -507,6 +507,58 @@ __global__ __launch_bounds__(A1_BLOCK) void a1_filter_kernel(mg_a1_filter_config
     }
 }
 
+// ---- info entries computed from the control observation (locomotion_gym_env.py:534-545) ------------------------------
+
+__global__ __launch_bounds__(A1_BLOCK) void a1_info_kernel(A1K k, mg_a1_actuator_state st, int n, double *pose, double *rot,
+                                                           double *foot, double *angles, double *drpy, double *energy) {
+    const int e = blockIdx.x * A1_BLOCK + threadIdx.x;
+    if (e >= n) return;
+    const mg_a1_actuator_config &c = k.c;
+    const double *co = st.control_obs;
+    double ang[NM], dot = 0.0;
+#pragma unroll
+    for (int i = 0; i < NM; ++i) {
+        ang[i] = map_to_pi(co[(size_t)i * n + e]);
+        dot += co[(size_t)(2 * NM + i) * n + e] * co[(size_t)(NM + i) * n + e];
+        if (angles) angles[(size_t)i * n + e] = ang[i];
+    }
+    if (energy) energy[e] = fabs(dot) * c.time_step * (double)c.action_repeat;
+    if (drpy)
+        for (int i = 0; i < 3; ++i) drpy[(size_t)i * n + e] = co[(size_t)(3 * NM + 4 + i) * n + e];
+    if (pose || rot) {
+        const double x = co[(size_t)(3 * NM) * n + e], y = co[(size_t)(3 * NM + 1) * n + e], z = co[(size_t)(3 * NM + 2) * n + e],
+                     w = co[(size_t)(3 * NM + 3) * n + e];
+        const double roll = atan2(2 * (w * x + y * z), 1 - 2 * (x * x + y * y));
+        const double sp = 2 * (w * y - z * x);
+        const double pitch = asin(fmax(-1.0, fmin(1.0, sp)));
+        const double yaw = atan2(2 * (w * z + x * y), 1 - 2 * (y * y + z * z));
+        if (pose) { pose[e] = roll; pose[(size_t)n + e] = pitch; pose[2 * (size_t)n + e] = yaw; }
+        if (rot) {      // GetBaseOrientation: getQuaternionFromEuler(rpy), then its matrix
+            const double cr = cos(roll / 2), sr = sin(roll / 2), cp = cos(pitch / 2), sq = sin(pitch / 2), cy = cos(yaw / 2), sy = sin(yaw / 2);
+            const double qx = sr * cp * cy - cr * sq * sy, qy = cr * sq * cy + sr * cp * sy, qz = cr * cp * sy - sr * sq * cy,
+                         qw = cr * cp * cy + sr * sq * sy;
+            const double m[9] = {1 - 2 * (qy * qy + qz * qz), 2 * (qx * qy - qw * qz), 2 * (qx * qz + qw * qy),
+                                 2 * (qx * qy + qw * qz), 1 - 2 * (qx * qx + qz * qz), 2 * (qy * qz - qw * qx),
+                                 2 * (qx * qz - qw * qy), 2 * (qy * qz + qw * qx), 1 - 2 * (qx * qx + qy * qy)};
+            for (int i = 0; i < 9; ++i) rot[(size_t)i * n + e] = m[i];
+        }
+    }
+    if (foot) {                                                                  // a1.py:105-123 + HIP_OFFSETS :61-63
+        const double com[3] = {-0.012731, -0.002186, -0.000515};
+        const double hipx[4] = {0.183, 0.183, -0.183, -0.183}, hipy[4] = {-0.047, 0.047, -0.047, 0.047};
+        for (int leg = 0; leg < 4; ++leg) {
+            const double ab = ang[3 * leg], hip = ang[3 * leg + 1], knee = ang[3 * leg + 2];
+            const double l_up = 0.2, l_low = 0.2, l_hip = 0.08505 * ((leg & 1) ? 1.0 : -1.0);
+            const double dist = sqrt(l_up * l_up + l_low * l_low + 2 * l_up * l_low * cos(knee));
+            const double swing = hip + knee / 2;
+            const double ox = -dist * sin(swing), oz = -dist * cos(swing), oy = l_hip;
+            foot[(size_t)(3 * leg) * n + e] = ox + (hipx[leg] + com[0]);
+            foot[(size_t)(3 * leg + 1) * n + e] = (cos(ab) * oy - sin(ab) * oz) + (hipy[leg] + com[1]);
+            foot[(size_t)(3 * leg + 2) * n + e] = (sin(ab) * oy + cos(ab) * oz) + (0.0 + com[2]);
+        }
+    }
+}
+
 int check_a1(const mg_a1_actuator_config *cfg, const mg_a1_actuator_state *st, int n) {
     if (!cfg || !st) return mg::set_error(MG_ERR_NULL_POINTER, "a1: NULL descriptor");
     if (n <= 0) return mg::set_error(MG_ERR_BAD_SIZE, "n_envs=%d", n);
@@ -657,4 +709,15 @@ extern "C" int mg_a1_action_filter(const mg_a1_filter_config *cfg, int32_t n, do
     hipLaunchKernelGGL(a1_filter_kernel, dim3((n + A1_BLOCK - 1) / A1_BLOCK), dim3(A1_BLOCK), 0, (hipStream_t)stream, *cfg, n,
                        xhist, yhist, x, y, init_mask, mode);
     return mg::check_launch("a1_filter_kernel");
+}
+
+extern "C" int mg_a1_info(const mg_a1_actuator_config *cfg, int32_t n, const mg_a1_actuator_state *st, double *pose,
+                          double *rot_mat, double *footposition, double *joint_angle, double *drpy, double *energy,
+                          void *stream) {
+    if (int rc = check_a1(cfg, st, n)) return rc;
+    mg::DeviceGuard guard(mg::device_of(st->history));
+    A1K k{*cfg};
+    hipLaunchKernelGGL(a1_info_kernel, dim3((n + A1_BLOCK - 1) / A1_BLOCK), dim3(A1_BLOCK), 0, (hipStream_t)stream, k, *st, n,
+                       pose, rot_mat, footposition, joint_angle, drpy, energy);
+    return mg::check_launch("a1_info_kernel");
 }

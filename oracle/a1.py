@@ -378,3 +378,77 @@ class ActionFilter(object):
         self.xhist = [np.array(x, np.float64)] + self.xhist[:-1]
         self.yhist = [y.copy()] + self.yhist[:-1]
         return y
+
+
+def foot_positions_in_base_frame(angles):
+    """robots/a1.py:105-123,141-147: forward kinematics of the four legs from the 12 motor angles, + HIP_OFFSETS."""
+    out = np.zeros((4, 3))
+    for i in range(4):
+        ab, hip, knee = angles[3 * i], angles[3 * i + 1], angles[3 * i + 2]
+        upper = lower = 0.2
+        side = 0.08505 * (-1) ** (i + 1)
+        leg = np.sqrt(upper**2 + lower**2 + 2 * upper * lower * np.cos(knee))
+        swing = hip + knee / 2
+        x_hip, z_hip, y_hip = -leg * np.sin(swing), -leg * np.cos(swing), side
+        out[i] = np.array([x_hip, np.cos(ab) * y_hip - np.sin(ab) * z_hip, np.sin(ab) * y_hip + np.cos(ab) * z_hip])
+    return out + HIP_OFFSETS
+
+
+class A1Env(object):
+    """The composition `A1GymEnv.reset / step` performs (envs/gym_envs/a1_gym_env.py, env_builder.py, MonitorEnv.py:14-25)
+    around a physics the caller supplies as recorded world states. One robot. Pinned by tests/golden/a1_env.npz."""
+
+    def __init__(self, w, b, etg=True, normal=0, control_latency=0.002):
+        self.path = EtgActionPath(w, b, enabled=etg)
+        self.act = A1Actuation(1, control_latency=control_latency)                # POSITION, kp/kd of a1.py:63-68
+        self.sensors = SensorStack(normal)
+        self.shaping = RewardShaping([1.0, 0.3, 0.2, 0.1, 0.1, 0.1])               # Param_Dict MonitorEnv.py:12
+        self.substeps = 0
+
+    def time_since_reset(self):
+        return self.substeps * 0.002                                               # GetTimeSinceReset minitaur.py:228-230
+
+    def robot_step(self, command, true_obs):
+        """Minitaur.Step with the world's 13 recorded sub-step states; returns the 13 x 12 torques."""
+        torques = []
+        for i in range(13):
+            torques.append(self.act.apply_action(self.act.process_action(command[None], i))[0])
+            t = true_obs[i]
+            self.act.receive_observation(t[None, 0:12], t[None, 12:24], t[None, 36:40], t[None, 40:43])
+            self.substeps += 1
+        self.act.last_action = command[None]
+        return np.array(torques)
+
+    def info(self, world):
+        """What LocomotionGymEnv.step / reset put in `info` (locomotion_gym_env.py:440-455,534-545) that is computed in
+        Python: foot positions (FK of the delayed motor angles), energy, drpy; base / pose / rot_mat / contacts are the world's."""
+        ang, vel, tor, rate, energy = self.act.sensors()
+        return dict(footposition=foot_positions_in_base_frame(ang[0]), joint_angle=ang[0], drpy=rate[0], energy=energy[0])
+
+    def reset(self, reset_true_obs, reset_world, hidden_true_obs, hidden_world):
+        """A1GymEnv.reset(): LocomotionGymEnv.reset (robot.Reset: history cleared, one observation; sensors reset),
+        ETGWrapper.reset, then RewardShaping.reset's hidden zero-action step (MonitorEnv.py:305-318).
+        Returns (the hidden step's command, torques, the observation reset() returns)."""
+        self.act.reset(); self.substeps = 0
+        t = reset_true_obs
+        self.act.receive_observation(t[None, 0:12], t[None, 12:24], t[None, 36:40], t[None, 40:43])
+        inf = self.info(reset_world)
+        self.sensors.observe(reset_world["base"], reset_world["pose"], inf["drpy"], inf["joint_angle"], reset_world["contact"], True)
+        self.path.reset(self.time_since_reset())
+        cmd, torques, obs, _ = self._step(np.zeros(12), hidden_true_obs, hidden_world, shaped=False)
+        self.shaping.reset(reset_world["base"], reset_world["rot_mat"], inf["footposition"])
+        return cmd, torques, obs
+
+    def _step(self, action, true_obs, world, shaped=True):
+        cmd, _ = self.path.step(action, self.time_since_reset())
+        torques = self.robot_step(cmd, true_obs)
+        inf = self.info(world)
+        obs = self.sensors.observe(world["base"], world["pose"], inf["drpy"], inf["joint_angle"], world["contact"], False)
+        out = None
+        if shaped:
+            out = self.shaping.step(world["base"], world["pose"], world["rot_mat"], inf["footposition"], world["contact"],
+                                    inf["energy"], world["bad"])
+        return cmd, torques, obs, (out, inf)
+
+    def step(self, action, true_obs, world):
+        return self._step(action, true_obs, world)

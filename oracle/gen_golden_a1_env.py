@@ -1,0 +1,192 @@
+#!/usr/bin/env python3
+"""Golden vectors for the WHOLE `A1GymEnv.reset / step` composition, recorded from the UNMODIFIED reference.
+
+TEST INFRASTRUCTURE; runs only in the build container (needs /root/reference):
+
+    python oracle/gen_golden_a1_env.py
+
+`metagym.quadrupedal.A1GymEnv` (envs/gym_envs/a1_gym_env.py) is constructed exactly as `gym.make('quadrupedal-v0', ...)`
+would (env_builder.build_regular_env -> LocomotionGymEnv -> a1.A1 with the four default sensors -> obs-to-array ->
+trajectory generator -> ETGWrapper -> ActionFilterWrapper -> RandomWrapper -> ObservationWrapper -> RewardShaping,
+MonitorEnv.py:14-25) — with one substitution: its `BulletClient` is the scripted 12-joint world of gen_golden_a1.py,
+extended by the world-level calls the env makes (plane, gravity, contacts, debug items). PyBullet and a1.urdf are not in
+the reference tree; the scripted world decides nothing the checkers are graded on: per sub-step and per env step every
+value it hands out (joint states, base pose / rates, contact points) is recorded as an INPUT.
+
+What this pins beyond the per-piece goldens (a1_actuation / a1_control / a1_sensors / a1_filter): the ORDER in which
+`A1GymEnv.step` composes them — which time the ETG sees, that the policy action is added to the PREVIOUS ETG output,
+13 x (ApplyAction, stepSimulation, ReceiveObservation), sensors' on_step before the observation, the reward computed from
+this step's info against last step's base / feet, reset()'s hidden first step with a zero action (MonitorEnv.py:310).
+Recorded per step: policy action, motor command reaching robot.Step, the 13 x 12 torques, observation (37), reward,
+done, the reward terms, and the world inputs."""
+import collections
+import collections.abc
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, HERE)
+import gen_golden_a1 as ga  # noqa: E402
+
+OUT = os.path.join(ROOT, "tests", "golden", "a1_env.npz")
+
+
+class ScriptedWorld(ga.ScriptedBullet):
+    """gen_golden_a1.ScriptedBullet + the world-level API of LocomotionGymEnv / MonitorEnv, with a1.urdf's joint list
+    (imu, then hip / hip_fixed / upper / lower / toe per leg: toe links 5, 10, 15, 20 as GetBadFootContacts assumes,
+    robots/a1.py:330)."""
+    JOINTS = ["imu_joint"]
+    for leg in ("FR", "FL", "RR", "RL"):
+        JOINTS += ["%s_hip_joint" % leg, "%s_hip_fixed" % leg, "%s_upper_joint" % leg, "%s_lower_joint" % leg, "%s_toe_fixed" % leg]
+    COV_ENABLE_RENDERING, COV_ENABLE_GUI, COV_ENABLE_SINGLE_STEP_RENDERING, DIRECT, GUI = 7, 1, 13, 2, 1
+    LINK_FRAME = 1
+
+    def __init__(self, seed, dt=0.002):
+        super(ScriptedWorld, self).__init__(seed, dt)
+        self.records = collections.defaultdict(list)
+        self.v_base = np.array([0.4, 0.02, 0.0])
+        self.contacts = []
+
+    def setAdditionalSearchPath(self, p): pass
+    def resetSimulation(self): pass
+    def setPhysicsEngineParameter(self, **k): pass
+    def setTimeStep(self, t): self.dt = t
+    def setGravity(self, *g): pass
+    def configureDebugVisualizer(self, *a, **k): pass
+    def resetDebugVisualizerCamera(self, *a, **k): pass
+    def addUserDebugLine(self, **k): return 0
+    def removeUserDebugItem(self, i): pass
+    def removeAllUserDebugItems(self): pass
+    def loadURDF(self, path, *a, **k): return 0 if "plane" in str(path) else 1
+    def resetBasePositionAndOrientation(self, body, pos, orn): self.base_pos = list(pos)
+    def getMatrixFromQuaternion(self, q):
+        x, y, z, w = q
+        return (1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y), 2 * (x * y + w * z), 1 - 2 * (x * x + z * z),
+                2 * (y * z - w * x), 2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y))
+    def getContactPoints(self, bodyA=None):
+        return list(self.contacts)
+    def stepSimulation(self):
+        super(ScriptedWorld, self).stepSimulation()
+        self.base_pos = list(np.asarray(self.base_pos) + self.dt * (self.v_base + 0.2 * np.sin(3 * self.t + np.arange(3))))
+    def new_contacts(self):
+        """A fresh scripted contact set for this env step: some feet down, now and then a knee or the trunk."""
+        pts = []
+        for link in (5, 10, 15, 20):
+            if self.rs.rand() < 0.75:
+                pts.append((0, 1, 0, link, -1, (0, 0, 0), (0, 0, 0), (0.0, 0.0, 1.0), 0.0, float(self.rs.uniform(5, 60)), 0, (1, 0, 0), 0, (0, 1, 0)))
+        if self.rs.rand() < 0.2:
+            pts.append((0, 1, 0, int(self.rs.choice([4, 9, -1, 14])), -1, (0, 0, 0), (0, 0, 0), (0.0, 0.0, 1.0), 0.0, 10.0, 0, (1, 0, 0), 0, (0, 1, 0)))
+        if self.rs.rand() < 0.1:
+            pts.append((0, 1, 1, 5, 3, (0, 0, 0), (0, 0, 0), (0.0, 0.0, 1.0), 0.0, 1.0, 0, (1, 0, 0), 0, (0, 1, 0)))   # a self contact: ignored
+        self.contacts = pts
+
+
+def main():
+    a1, robot_config = ga.import_reference()
+    import pybullet_utils.bullet_client as bullet_client
+    from metagym.quadrupedal.envs.gym_envs import a1_gym_env
+    from metagym.quadrupedal.robots import minitaur
+    out = {"numpy_version": np.array(np.__version__)}
+    cases = [dict(name="env_etg_traj", seed=1, ETG=1, wscale=0.04, n_steps=25, normal=0),
+             dict(name="env_plain", seed=2, ETG=0, wscale=0.0, n_steps=20, normal=1),
+             dict(name="env_latency", seed=3, ETG=1, wscale=0.05, n_steps=20, normal=0, dynamic_param={"control_latency": 13.7})]
+    for c in cases:
+        world = ScriptedWorld(c["seed"])
+        bullet_client.BulletClient = lambda connection_mode=None, w=world: w
+        rs = np.random.RandomState(100 + c["seed"])
+        H = 20
+        w, b = rs.uniform(-1, 1, (3, H)) * c["wscale"], rs.uniform(-1, 1, 3) * c["wscale"] * 0.2
+        path = "/tmp/_etg_env_%s.npz" % c["name"]
+        np.savez(path, w=w, b=b)
+        rec = collections.defaultdict(list)
+        # record what robot.Step receives and what each sub-step sees / produces, through the robot class's own methods
+        orig_step, orig_apply, orig_recv = minitaur.Minitaur.Step, minitaur.Minitaur.ApplyAction, minitaur.Minitaur.ReceiveObservation
+        cur = {"torques": [], "true": []}
+
+        def step_rec(self, action, control_mode=None):
+            cur["torques"], cur["true"] = [], []
+            world.new_contacts()
+            rec["command"].append(np.array(action, dtype=np.float64))
+            r = orig_step(self, action, control_mode)
+            rec["torques"].append(np.array(cur["torques"]))
+            rec["true_obs"].append(np.array(cur["true"]))
+            return r
+
+        def apply_rec(self, cmd, mode):
+            t = orig_apply(self, cmd, mode)
+            cur["torques"].append(np.array(t, dtype=np.float64))
+            return t
+
+        def recv_rec(self):
+            orig_recv(self)
+            cur["true"].append(np.array(self._observation_history[0], dtype=np.float64))
+            rec["all_true_obs"].append(np.array(self._observation_history[0], dtype=np.float64))
+        minitaur.Minitaur.Step, minitaur.Minitaur.ApplyAction, minitaur.Minitaur.ReceiveObservation = step_rec, apply_rec, recv_rec
+        # every info dictionary LocomotionGymEnv hands up after construction, in call order: reset, the hidden zero-action
+        # step of RewardShaping.reset (MonitorEnv.py:310), then one per env.step
+        from metagym.quadrupedal.envs import locomotion_gym_env
+        orig_lreset, orig_lstep = locomotion_gym_env.LocomotionGymEnv.reset, locomotion_gym_env.LocomotionGymEnv.step
+        live = {"on": False}
+
+        def note(info, kind, robot):
+            if not live["on"]:
+                return
+            rec["loco_kind"].append(kind)
+            for key in ("base", "pose", "rot_mat", "footposition", "real_contact", "energy", "drpy", "joint_angle"):
+                rec["loco_" + key].append(np.array(info[key], dtype=np.float64))
+            rec["loco_bad"].append(robot.GetBadFootContacts())
+            rec["loco_contact_force"].append(np.array(robot.GetFootContactsForce(mode="simple"), dtype=np.float64))
+
+        def lreset(self, **kw):
+            r = orig_lreset(self, **kw)
+            note(r[1], 0, self._robot)
+            return r
+
+        def lstep(self, action):
+            r = orig_lstep(self, action)
+            note(r[3], 1, self._robot)
+            return r
+        locomotion_gym_env.LocomotionGymEnv.reset, locomotion_gym_env.LocomotionGymEnv.step = lreset, lstep
+        try:
+            env = a1_gym_env.A1GymEnv(ETG=c["ETG"], ETG_path=path, normal=c["normal"], dynamic_param=c.get("dynamic_param", {}),
+                                      sensor_mode={"dis": 1, "motor": 1, "imu": 1, "contact": 1, "footpose": 0, "ETG": 0})
+            n_before_reset = len(rec["all_true_obs"])
+            live["on"] = True
+            obs, info = env.reset()
+            rec["reset_obs"].append(np.array(obs, dtype=np.float64))
+            rec["n_true_obs_before_reset"].append(n_before_reset)
+            rec["n_true_obs_after_reset"].append(len(rec["all_true_obs"]))
+            rec["n_commands_after_reset"].append(len(rec["command"]))
+            for k in range(c["n_steps"]):
+                action = rs.uniform(-0.3, 0.3, 12)
+                rec["action"].append(action)
+                rec["t"].append(env.get_time_since_reset())
+                obs, reward, done, info = env.step(action)
+                rec["obs"].append(np.array(obs, dtype=np.float64))
+                rec["reward"].append(float(reward))
+                rec["done"].append(bool(done))
+                rec["terms"].append(np.array([info[t] for t in ("torso", "up", "feet", "tau", "badfoot", "footcontact")]))
+                for key in ("base", "pose", "rot_mat", "footposition", "real_contact", "energy", "drpy", "joint_angle"):
+                    rec["info_" + key].append(np.array(info[key], dtype=np.float64))
+                rec["bad"].append(env.robot.GetBadFootContacts())
+        finally:
+            locomotion_gym_env.LocomotionGymEnv.reset, locomotion_gym_env.LocomotionGymEnv.step = orig_lreset, orig_lstep
+            minitaur.Minitaur.Step, minitaur.Minitaur.ApplyAction, minitaur.Minitaur.ReceiveObservation = orig_step, orig_apply, orig_recv
+        rec["reset_true_obs"] = [rec["all_true_obs"][rec["n_true_obs_before_reset"][0]]]      # robot.Reset's one observation
+        del rec["all_true_obs"]                                                               # (500 settle sub-steps of __init__)
+        for k2, v in rec.items():
+            out[c["name"] + "/" + k2] = np.array(v)
+        out[c["name"] + "/w"], out[c["name"] + "/b"] = w, b
+        out[c["name"] + "/config"] = np.array([c["ETG"], c["normal"], c.get("dynamic_param", {}).get("control_latency", -1.0)], dtype=np.float64)
+        print(c["name"], "steps", len(rec["obs"]), "obs dim", np.array(rec["obs"]).shape, "dones", int(np.sum(rec["done"])),
+              "reward range", np.min(rec["reward"]), np.max(rec["reward"]))
+    out["cases"] = np.array([c["name"] for c in cases])
+    np.savez_compressed(OUT, **out)
+    print("wrote", OUT, os.path.getsize(OUT), "bytes")
+
+
+if __name__ == "__main__":
+    main()

@@ -32,3 +32,14 @@ class Discrete(Space):
 
     def sample(self):
         return int(self._rng.randint(self.n))
+
+
+class Dict(Space):
+    """gym.spaces.Dict: an ordered mapping of named sub-spaces (quadrupedal/envs/sensors/space_utils.py:115)."""
+    def __init__(self, spaces=None):
+        super().__init__(None, None)
+        import collections
+        self.spaces = collections.OrderedDict(spaces or {})
+
+    def sample(self):
+        return {k: s.sample() for k, s in self.spaces.items()}

@@ -1,0 +1,46 @@
+"""CPU: the oracle's composition of the A1 pieces (oracle/a1.py: A1Env) against the WHOLE unmodified `A1GymEnv`
+running on a scripted Bullet client (tests/golden/a1_env.npz, oracle/gen_golden_a1_env.py): motor commands reaching
+robot.Step, all 13 x 12 torques per step, the 37-entry observation, the six reward terms, reward and done — for reset()
+(with its hidden zero-action step) and every step()."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import a1 as oa
+
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden", "a1_env.npz")
+
+
+def world(g, name, k):
+    return dict(base=g[name + "/loco_base"][k], pose=g[name + "/loco_pose"][k], rot_mat=g[name + "/loco_rot_mat"][k],
+                contact=g[name + "/loco_real_contact"][k], bad=g[name + "/loco_bad"][k])
+
+
+def make_env(g, name):
+    etg, normal, lat_ms = g[name + "/config"]
+    return oa.A1Env(g[name + "/w"], g[name + "/b"], bool(etg), int(normal), 0.002 if lat_ms < 0 else 0.001 * lat_ms)
+
+
+@pytest.mark.parametrize("idx", range(3))
+def test_composed_env_matches_reference(idx):
+    g = np.load(GOLDEN)
+    name = str(g["cases"][idx])
+    env = make_env(g, name)
+    assert list(g[name + "/loco_kind"][:2]) == [0, 1]               # reset info, then the hidden step's
+    cmd, torques, obs = env.reset(g[name + "/reset_true_obs"][0], world(g, name, 0), g[name + "/true_obs"][0], world(g, name, 1))
+    assert np.array_equal(cmd, g[name + "/command"][0])
+    assert np.array_equal(torques, g[name + "/torques"][0])
+    assert np.array_equal(obs, g[name + "/reset_obs"][0])
+    for k in range(len(g[name + "/action"])):
+        assert env.time_since_reset() == g[name + "/t"][k]
+        cmd, torques, obs, (shaped, inf) = env.step(g[name + "/action"][k], g[name + "/true_obs"][k + 1], world(g, name, k + 2))
+        assert np.array_equal(cmd, g[name + "/command"][k + 1]), "%s command, step %d" % (name, k)
+        assert np.array_equal(torques, g[name + "/torques"][k + 1]), "%s torques, step %d" % (name, k)
+        assert np.array_equal(inf["footposition"], g[name + "/info_footposition"][k])
+        assert inf["energy"] == pytest.approx(g[name + "/info_energy"][k], rel=1e-14, abs=1e-300)
+        assert np.array_equal(obs, g[name + "/obs"][k]), "%s observation, step %d" % (name, k)
+        terms, reward, done = shaped
+        assert np.allclose(terms, g[name + "/terms"][k], rtol=1e-13, atol=1e-15), "%s reward terms, step %d" % (name, k)
+        assert reward == pytest.approx(g[name + "/reward"][k], rel=1e-13, abs=1e-15)
+        assert done == bool(g[name + "/done"][k])
