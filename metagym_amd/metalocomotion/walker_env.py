@@ -28,6 +28,12 @@ from . import variants
 from .mjcf import Model, load_mjcf
 
 
+# The Bullet world parameters the reference sets (tests/test_walker_rules.py checks them against what its own scene code
+# hands to the PyBullet stand-in): scene_bases.py:52-56 (gravity from env_bases.py:48, contact ERP, 4 sub-steps of 5 ms,
+# 5 solver iterations), stadium.py:19-25 (ground lateral friction; Bullet multiplies it with the geom's).
+CONTACT_ERP, GRAVITY, GROUND_FRICTION = 0.9, 9.8, 0.8
+
+
 def pack_model(m, motor_torque):
     """One row of the mg_walker_models table (layout documented in include/metagym_hip.h)."""
     parts = [m.body_pos, m.body_rot, m.body_mass, m.body_com, m.body_inertia, m.joint_anchor, m.joint_axis,
@@ -156,7 +162,7 @@ class WalkerBatchEnv(object):
         p.time_step, p.frame_skip, p.solver_iterations = self.time_step, self.frame_skip, self.solver_iterations
         # Bullet multiplies the two bodies' lateral friction: ground 0.8 (stadium.py:23) x geom friction (MJCF)
         p.limit_erp = 0.2                                          # Bullet's default constraint ERP
-        p.erp, p.gravity, p.friction = 0.9, 9.8, 0.8 * float(m0.geom_friction)   # scene_bases.py:55, env_bases.py:48
+        p.erp, p.gravity, p.friction = CONTACT_ERP, GRAVITY, GROUND_FRICTION * float(m0.geom_friction)
         p.alive_z, p.alive_bonus, p.dead_bonus = self.alive_z, self.alive_bonus, -1.0
         p.initial_z = float(self.initial_z if self.initial_z is not None else m0.body_pos[0][2])
         p.joints_at_limit_cost = -0.1                              # walker_base_env.py:22

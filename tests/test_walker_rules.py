@@ -112,3 +112,32 @@ def test_parser_joint_order_is_what_addToScene_enumerates():
             named = [L["link"] for L in links if not L["link"].startswith("link1_")]
             assert named == m.body_names[1:], f                     # one named link per non-base body, same order
             assert all(foot in named for foot in variants.FEET[robot])
+
+
+@pytest.mark.skipif(not os.path.isdir(ASSETS), reason="reference tree not present (build container only)")
+def test_world_parameters_are_what_the_reference_sets():
+    """L1: the unmodified Scene / StadiumScene / env code (scene_bases.py:52-56, stadium.py:19-25, env_bases.py:47-48) runs
+    on the PyBullet stand-in, which records what it is told; those values are the product's."""
+    import inspect
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for p in (root, os.path.join(root, "oracle", "refstubs"), os.environ.get("METAGYM_REFERENCE", "/root/reference")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    np.int = int
+    import gym
+    import metagym.metalocomotion  # noqa: F401
+    from metagym_amd import registration
+    from metagym_amd.metalocomotion import walker_env
+    for env_id, task in (("meta-humanoid-v0", "humanoid.xml"), ("meta-ant-v0", "ant.xml")):
+        env = gym.make(env_id, enable_render=False)
+        env.set_task(task)
+        env.reset()
+        w = env._p._world
+        kw = registration.registry[env_id][1]
+        defaults = inspect.signature(walker_env.WalkerBatchEnv.__init__).parameters
+        assert w.gravity == walker_env.GRAVITY and w.contact_erp == walker_env.CONTACT_ERP
+        assert w.sub_steps == kw["frame_skip"] and w.fixed_time_step == kw["time_step"] * kw["frame_skip"]
+        assert w.solver_iterations == defaults["solver_iterations"].default
+        floors = [b for b in w.bodies if type(b).__name__ == "_Floor"]
+        assert floors and all(f.friction == walker_env.GROUND_FRICTION for f in floors)
