@@ -466,6 +466,31 @@ def secondary_workloads(dev):
                     "the A1 body / physics is not built (a1.urdf and PyBullet are absent from the reference tree)"}
         del act
         torch.cuda.empty_cache()
+        # the whole A1GymEnv.step composition (ETG + IK, 13 x (motor model, history), info, sensors, reward) around a NULL
+        # physics that hands back constant joint states: the cost of everything the reference computes in Python per env step
+        from metagym_amd.quadrupedal import A1GymEnv
+
+        class NullPhysics(object):
+            def __init__(self, n):
+                self.s = (q[:n].contiguous(), qd[:n].contiguous(), quat[:n].contiguous(), rate[:n].contiguous())
+                self.w = dict(base=torch.zeros(n, 3, **f64), contact=torch.ones(n, 4, **f64),
+                              bad=torch.zeros(n, dtype=torch.int32, device=dev))
+            def reset(self, mask): return self.s
+            def substep(self, torques): return self.s
+            def world(self): return self.w
+        n2 = 16384
+        env = A1GymEnv(n2, NullPhysics(n2), dev, ETG=1, ETG_w=np.full((3, 20), 0.01), ETG_b=np.zeros(3))
+        env.reset()
+        a12 = torch.zeros(n2, 12, **f64)
+        s2 = _time_steps(lambda i: env.step(a12), 20, 3)
+        out["A1GymEnv_python_side_%denvs_null_physics" % n2] = {
+            "env_steps_per_s": n2 / s2, "ms_per_env_step": s2 * 1e3, "launches_per_env_step": 1 + 13 * 2 + 3,
+            "note": "ETG action path, 13 sub-steps of motor model + observation history, info, sensor stack, reward shaping — "
+                    "what the reference's A1GymEnv.step computes in Python (3.3 ms per env step on one core of the build container, measured "
+                    "with the same scripted world standing in for PyBullet, so ~3e2 env-steps/s/core), all on the GPU; "
+                    "no physics in this figure"}
+        del env
+        torch.cuda.empty_cache()
     except Exception as e:
         out["a1_error"] = repr(e)
     return out
