@@ -447,11 +447,10 @@ def secondary_workloads(dev):
         act.Reset()
         act.ReceiveObservation(q, qd, quat, rate)
 
-        def substep(i):       # the C ABI pair of one sub-step on SoA inputs (the [N, k] -> [k][N] copy is the caller's layout choice)
-            act._apply(cmds, None, 0.0)
-            rc = act._lib.mg_a1_receive_observation(ctypes.byref(act._cfg), n, ctypes.byref(act._st), qs.data_ptr(), qds.data_ptr(),
-                                                    quats.data_ptr(), rates.data_ptr(), None,
-                                                    torch.cuda.current_stream(dev).cuda_stream)
+        def substep(i):       # one sub-step on SoA inputs: ReceiveObservation + the next ApplyAction, fused (one launch)
+            rc = act._lib.mg_a1_receive_and_apply(ctypes.byref(act._cfg), n, ctypes.byref(act._st), qs.data_ptr(), qds.data_ptr(),
+                                                  quats.data_ptr(), rates.data_ptr(), cmds.data_ptr(), None, 0.0,
+                                                  act._torque.data_ptr(), torch.cuda.current_stream(dev).cuda_stream)
             assert rc == 0
         s = _time_steps(substep, 60, 10)
         # algorithmic bytes per robot sub-step (f64): apply: q, qd of the newest observation 192 + command 96 in, torque and
@@ -462,7 +461,7 @@ def secondary_workloads(dev):
             "robot_substeps_per_s": n / s, "us_per_substep_pair": s * 1e6,
             "roofline": {"bound": "hbm", "achieved": byt * n / s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": byt * n / s / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes_per_robot_substep": byt},
-            "note": "mg_a1_apply_action + mg_a1_receive_observation (two launches); bit-exact against the unmodified reference; "
+            "note": "mg_a1_receive_and_apply (ReceiveObservation + the next sub-step's ApplyAction in one launch); bit-exact against the unmodified reference; "
                     "the A1 body / physics is not built (a1.urdf and PyBullet are absent from the reference tree)"}
         del act
         torch.cuda.empty_cache()
@@ -484,7 +483,7 @@ def secondary_workloads(dev):
         a12 = torch.zeros(n2, 12, **f64)
         s2 = _time_steps(lambda i: env.step(a12), 20, 3)
         out["A1GymEnv_python_side_%denvs_null_physics" % n2] = {
-            "env_steps_per_s": n2 / s2, "ms_per_env_step": s2 * 1e3, "launches_per_env_step": 1 + 13 * 2 + 3,
+            "env_steps_per_s": n2 / s2, "ms_per_env_step": s2 * 1e3, "launches_per_env_step": 1 + 1 + 12 + 1 + 3,
             "note": "ETG action path, 13 sub-steps of motor model + observation history, info, sensor stack, reward shaping — "
                     "what the reference's A1GymEnv.step computes in Python (3.3 ms per env step on one core of the build container, measured "
                     "with the same scripted world standing in for PyBullet, so ~3e2 env-steps/s/core), all on the GPU; "

@@ -495,6 +495,13 @@ int mg_a1_apply_action(const mg_a1_actuator_config *cfg, int32_t n_envs, const m
 int mg_a1_receive_observation(const mg_a1_actuator_config *cfg, int32_t n_envs, const mg_a1_actuator_state *state,
                               const double *q, const double *qd, const double *base_quat, const double *rpy_rate,
                               const uint8_t *clear_mask, void *stream);
+/* mg_a1_receive_observation immediately followed by mg_a1_apply_action of the NEXT sub-step (they are adjacent in
+ * Minitaur.Step's loop: ... stepSimulation, ReceiveObservation | ApplyAction, stepSimulation ...) as ONE launch: the
+ * observation just pushed is the one the PD term reads (pd latency 0), so it never travels back from HBM. Same arguments as
+ * the two calls; results are bit-identical to calling them one after the other. */
+int mg_a1_receive_and_apply(const mg_a1_actuator_config *cfg, int32_t n_envs, const mg_a1_actuator_state *state,
+                            const double *q, const double *qd, const double *base_quat, const double *rpy_rate,
+                            const double *command, const double *last_command, double lerp, double *torque, void *stream);
 /* Any output may be NULL. motor_angles / motor_velocities / motor_torques: f64 [12][N]; rpy_rate f64 [3][N];
  * energy f64 [N]. */
 int mg_a1_sensors(const mg_a1_actuator_config *cfg, int32_t n_envs, const mg_a1_actuator_state *state,

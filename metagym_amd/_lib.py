@@ -235,6 +235,8 @@ SIGNATURES = {
                                      C.c_double, _P, _P]),
     "mg_a1_receive_observation": (C.c_int, [C.POINTER(A1ActuatorConfig), C.c_int32, C.POINTER(A1ActuatorState),
                                             _P, _P, _P, _P, _P, _P]),
+    "mg_a1_receive_and_apply": (C.c_int, [C.POINTER(A1ActuatorConfig), C.c_int32, C.POINTER(A1ActuatorState), _P, _P, _P, _P,
+                                          _P, _P, C.c_double, _P, _P]),
     "mg_a1_sensors": (C.c_int, [C.POINTER(A1ActuatorConfig), C.c_int32, C.POINTER(A1ActuatorState),
                                 _P, _P, _P, _P, _P, _P]),
     "mg_a1_info": (C.c_int, [C.POINTER(A1ActuatorConfig), C.c_int32, C.POINTER(A1ActuatorState), _P, _P, _P, _P, _P, _P, _P]),

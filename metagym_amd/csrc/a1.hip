@@ -64,12 +64,8 @@ __device__ __forceinline__ double map_to_pi(double x) {
     return m;
 }
 
-__global__ __launch_bounds__(A1_BLOCK) void a1_apply_action_kernel(A1K k, mg_a1_actuator_state st, int n,
-                                                                   const double *command, const double *last_command,
-                                                                   double lerp, double *torque) {
-    const int e = blockIdx.x * A1_BLOCK + threadIdx.x;
-    if (e >= n) return;
-    const mg_a1_actuator_config &c = k.c;
+__device__ __forceinline__ void a1_apply(const mg_a1_actuator_config &c, const mg_a1_actuator_state &st, int n, int e,
+                                         const double *command, const double *last_command, double lerp, double *torque) {
     const size_t stride = (size_t)OD * n;
     const double pd_lat = c.pd_latency_env ? c.pd_latency_env[e] : c.pd_latency;
     const Delay d = delayed(pd_lat, c.time_step, st.count[e], st.head[e], c.history_len);
@@ -121,12 +117,9 @@ __global__ __launch_bounds__(A1_BLOCK) void a1_apply_action_kernel(A1K k, mg_a1_
     }
 }
 
-__global__ __launch_bounds__(A1_BLOCK) void a1_receive_kernel(A1K k, mg_a1_actuator_state st, int n, const double *q,
-                                                              const double *qd, const double *quat, const double *rate,
-                                                              const uint8_t *clear_mask) {
-    const int e = blockIdx.x * A1_BLOCK + threadIdx.x;
-    if (e >= n) return;
-    const mg_a1_actuator_config &c = k.c;
+__device__ __forceinline__ void a1_receive(const mg_a1_actuator_config &c, const mg_a1_actuator_state &st, int n, int e,
+                                           const double *q, const double *qd, const double *quat, const double *rate,
+                                           const uint8_t *clear_mask) {
     const size_t stride = (size_t)OD * n;
     int count = st.count[e], head = st.head[e];
     if (clear_mask != nullptr && clear_mask[e]) count = 0;                          // _observation_history.clear()
@@ -163,6 +156,32 @@ __global__ __launch_bounds__(A1_BLOCK) void a1_receive_kernel(A1K k, mg_a1_actua
         for (int i = 0; i < CH; ++i)
             if (c0 + i < OD) st.control_obs[(size_t)(c0 + i) * n + e] = v[i];
     }
+}
+
+__global__ __launch_bounds__(A1_BLOCK) void a1_apply_action_kernel(A1K k, mg_a1_actuator_state st, int n,
+                                                                   const double *command, const double *last_command,
+                                                                   double lerp, double *torque) {
+    const int e = blockIdx.x * A1_BLOCK + threadIdx.x;
+    if (e < n) a1_apply(k.c, st, n, e, command, last_command, lerp, torque);
+}
+
+__global__ __launch_bounds__(A1_BLOCK) void a1_receive_kernel(A1K k, mg_a1_actuator_state st, int n, const double *q,
+                                                              const double *qd, const double *quat, const double *rate,
+                                                              const uint8_t *clear_mask) {
+    const int e = blockIdx.x * A1_BLOCK + threadIdx.x;
+    if (e < n) a1_receive(k.c, st, n, e, q, qd, quat, rate, clear_mask);
+}
+
+// ReceiveObservation of sub-step k and ApplyAction of sub-step k + 1 in one launch. A lane only ever reads ring entries it
+// wrote itself, in program order, so no fence is needed between the two halves.
+__global__ __launch_bounds__(A1_BLOCK) void a1_receive_apply_kernel(A1K k, mg_a1_actuator_state st, int n, const double *q,
+                                                                    const double *qd, const double *quat, const double *rate,
+                                                                    const double *command, const double *last_command,
+                                                                    double lerp, double *torque) {
+    const int e = blockIdx.x * A1_BLOCK + threadIdx.x;
+    if (e >= n) return;
+    a1_receive(k.c, st, n, e, q, qd, quat, rate, nullptr);
+    a1_apply(k.c, st, n, e, command, last_command, lerp, torque);
 }
 
 __global__ __launch_bounds__(A1_BLOCK) void a1_sensors_kernel(A1K k, mg_a1_actuator_state st, int n, double *angles,
@@ -720,4 +739,22 @@ extern "C" int mg_a1_info(const mg_a1_actuator_config *cfg, int32_t n, const mg_
     hipLaunchKernelGGL(a1_info_kernel, dim3((n + A1_BLOCK - 1) / A1_BLOCK), dim3(A1_BLOCK), 0, (hipStream_t)stream, k, *st, n,
                        pose, rot_mat, footposition, joint_angle, drpy, energy);
     return mg::check_launch("a1_info_kernel");
+}
+
+extern "C" int mg_a1_receive_and_apply(const mg_a1_actuator_config *cfg, int32_t n, const mg_a1_actuator_state *st,
+                                       const double *q, const double *qd, const double *base_quat, const double *rpy_rate,
+                                       const double *command, const double *last_command, double lerp, double *torque,
+                                       void *stream) {
+    if (int rc = check_a1(cfg, st, n)) return rc;
+    MG_REQUIRE_PTR(q);
+    MG_REQUIRE_PTR(qd);
+    MG_REQUIRE_PTR(base_quat);
+    MG_REQUIRE_PTR(rpy_rate);
+    MG_REQUIRE_PTR(command);
+    MG_REQUIRE_PTR(torque);
+    mg::DeviceGuard guard(mg::device_of(st->history));
+    A1K k{*cfg};
+    hipLaunchKernelGGL(a1_receive_apply_kernel, dim3((n + A1_BLOCK - 1) / A1_BLOCK), dim3(A1_BLOCK), 0, (hipStream_t)stream, k,
+                       *st, n, q, qd, base_quat, rpy_rate, command, last_command, lerp, torque);
+    return mg::check_launch("a1_receive_apply_kernel");
 }

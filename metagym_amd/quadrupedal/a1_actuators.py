@@ -163,6 +163,16 @@ class A1Actuators(object):
         _lib.check(rc, "mg_a1_apply_action")
         return self._torque.t()
 
+    def _receive_and_apply(self, motor_angles, motor_velocities, base_orientation, base_rpy_rate, cmd, last, lerp):
+        q, qd = self._soa(motor_angles, NUM_MOTORS), self._soa(motor_velocities, NUM_MOTORS)
+        quat, rate = self._soa(base_orientation, 4), self._soa(base_rpy_rate, 3)
+        with torch.cuda.device(self.device):
+            rc = self._lib.mg_a1_receive_and_apply(C.byref(self._cfg), self.num_envs, C.byref(self._st), _lib.ptr(q), _lib.ptr(qd),
+                                                   _lib.ptr(quat), _lib.ptr(rate), _lib.ptr(cmd), _lib.ptr(last), float(lerp),
+                                                   _lib.ptr(self._torque), _lib.current_stream(self.device))
+        _lib.check(rc, "mg_a1_receive_and_apply")
+        return self._torque.t()
+
     def ReceiveObservation(self, motor_angles, motor_velocities, base_orientation, base_rpy_rate, clear_mask=None):
         """The four arguments are what the reference reads from Bullet at this point (getJointStates, base orientation
         relative to the initial one, angular velocity in the body frame; minitaur.py:1190-1200, :840-872)."""
@@ -187,11 +197,16 @@ class A1Actuators(object):
             action = self._action_filter.filter(action)
         act = self._soa(action, k)
         torques = []
+        cmd, last, lerp = self.ProcessAction(act, 0)
+        t = self._apply(cmd, last, lerp)
         for i in range(self._action_repeat):
-            cmd, last, lerp = self.ProcessAction(act, i)
-            t = self._apply(cmd, last, lerp)
             torques.append(t.clone())
-            self.ReceiveObservation(*physics(t))
+            q, qd, quat, rate = physics(t)
+            if i + 1 < self._action_repeat:      # ReceiveObservation of sub-step i and ApplyAction of i + 1 in one launch
+                cmd, last, lerp = self.ProcessAction(act, i + 1)
+                t = self._receive_and_apply(q, qd, quat, rate, cmd, last, lerp)
+            else:
+                self.ReceiveObservation(q, qd, quat, rate)
             self._step_counter += 1
         self._last_action = act
         return torch.stack(torques)
