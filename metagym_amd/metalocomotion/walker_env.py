@@ -71,7 +71,9 @@ class WalkerBatchEnv(object):
         self.assets_dir = assets_dir or os.environ.get("METAGYM_LOCOMOTION_ASSETS")
         self.tra_tasks, self.tst_tasks, self.ood_tasks = [], [], []
         d = self._robot_assets()
-        if d and os.path.isdir(d):
+        if self.variant_prefix is None:              # a robot without MetaLocomotion variant files (set_task takes Models)
+            pass
+        elif d and os.path.isdir(d):
             for f in sorted(os.listdir(d)):          # meta_humanoids_env.py:18-27
                 if f.find(self.variant_prefix + "_var_tra") == 0:
                     self.tra_tasks.append(f)

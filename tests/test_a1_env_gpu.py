@@ -82,3 +82,24 @@ def test_a1_gym_env_matches_the_unmodified_reference_env(idx):
 def test_quadrupedal_without_physics_explains_itself():
     with pytest.raises(Exception, match="a1.urdf"):
         metagym_amd.make("quadrupedal-v0", num_envs=4, device=DEV)
+
+
+def test_closed_loop_on_the_example_standin_body_holds_the_default_pose():
+    """examples/a1_standin: the env's physics protocol driven by this repo's articulated-body engine with a STAND-IN body
+    (not the reference's robot). Zero actions -> the PD loop holds (0, 0.9, -1.8) x 4: the base settles near the leg length
+    and nothing terminates. A plumbing test of the closed loop, not a parity statement."""
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "examples", "a1_standin"))
+    from physics import StandinPhysics
+    n = 256
+    env = metagym_amd.make("quadrupedal-v0", num_envs=n, physics=StandinPhysics(n, DEV), device=DEV)
+    obs, info = env.reset()
+    a = torch.zeros(n, 12, dtype=torch.float64, device=DEV)
+    for _ in range(20):
+        obs, reward, done, info = env.step(a)
+        assert torch.isfinite(obs).all() and not bool(done.any())
+    z = info["base"][:, 2]
+    assert 0.22 < float(z.min()) and float(z.max()) < 0.30
+    assert float((env.robot.GetMotorAngles() - torch.as_tensor([0, 0.9, -1.8] * 4, device=DEV)).abs().max()) < 0.15
+    assert float(info["real_contact"].sum(dim=1).min()) >= 2.0      # it stands on its feet (flags flicker with the penetration depth)
