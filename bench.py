@@ -471,7 +471,7 @@ def secondary_workloads(dev):
 
         class NullPhysics(object):
             def __init__(self, n):
-                self.s = (q[:n].contiguous(), qd[:n].contiguous(), quat[:n].contiguous(), rate[:n].contiguous())
+                self.s = tuple(x[:n].t().contiguous() for x in (q, qd, quat, rate))      # SoA [k][N]: taken without a copy
                 self.w = dict(base=torch.zeros(n, 3, **f64), contact=torch.ones(n, 4, **f64),
                               bad=torch.zeros(n, dtype=torch.int32, device=dev))
             def reset(self, mask): return self.s

@@ -124,7 +124,11 @@ class A1Actuators(object):
 
     # ---- the sub-step (minitaur.py:232-255) ------------------------------------------------------------
     def _soa(self, x, k):
+        """`[num_envs, k]` -> the kernels' `[k][num_envs]` layout. A contiguous float64 `[k, num_envs]` device tensor is taken as
+        already being in that layout (no copy) when num_envs != k — what a batched simulator naturally produces."""
         x = torch.as_tensor(x, dtype=torch.float64, device=self.device)
+        if x.shape == (k, self.num_envs) and self.num_envs != k and x.is_contiguous():
+            return x
         assert x.shape == (self.num_envs, k), "expected [num_envs, %d], got %s" % (k, tuple(x.shape))
         return x.t().contiguous()
 
