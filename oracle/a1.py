@@ -398,7 +398,8 @@ class A1Env(object):
     """The composition `A1GymEnv.reset / step` performs (envs/gym_envs/a1_gym_env.py, env_builder.py, MonitorEnv.py:14-25)
     around a physics the caller supplies as recorded world states. One robot. Pinned by tests/golden/a1_env.npz."""
 
-    def __init__(self, w, b, etg=True, normal=0, control_latency=0.002):
+    def __init__(self, w, b, etg=True, normal=0, control_latency=0.002, action_filter=None):
+        self.filter = action_filter                                                # Minitaur._BuildActionFilter minitaur.py:1438-1443
         self.path = EtgActionPath(w, b, enabled=etg)
         self.act = A1Actuation(1, control_latency=control_latency)                # POSITION, kp/kd of a1.py:63-68
         self.sensors = SensorStack(normal)
@@ -411,6 +412,10 @@ class A1Env(object):
     def robot_step(self, command, true_obs):
         """Minitaur.Step with the world's 13 recorded sub-step states; returns the 13 x 12 torques."""
         torques = []
+        if self.filter is not None:                                                # _FilterAction minitaur.py:1448-1457
+            if self.substeps == 0:
+                self.filter.init_history(self.act.sensors()[0][0])
+            command = self.filter.filter(command)
         for i in range(13):
             torques.append(self.act.apply_action(self.act.process_action(command[None], i))[0])
             t = true_obs[i]
@@ -430,6 +435,8 @@ class A1Env(object):
         ETGWrapper.reset, then RewardShaping.reset's hidden zero-action step (MonitorEnv.py:305-318).
         Returns (the hidden step's command, torques, the observation reset() returns)."""
         self.act.reset(); self.substeps = 0
+        if self.filter is not None:
+            self.filter.reset()                                                    # _ResetActionFilter (Minitaur.Reset :443-444)
         t = reset_true_obs
         self.act.receive_observation(t[None, 0:12], t[None, 12:24], t[None, 36:40], t[None, 40:43])
         inf = self.info(reset_world)

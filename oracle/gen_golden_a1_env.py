@@ -92,7 +92,8 @@ def main():
     out = {"numpy_version": np.array(np.__version__)}
     cases = [dict(name="env_etg_traj", seed=1, ETG=1, wscale=0.04, n_steps=25, normal=0),
              dict(name="env_plain", seed=2, ETG=0, wscale=0.0, n_steps=20, normal=1),
-             dict(name="env_latency", seed=3, ETG=1, wscale=0.05, n_steps=20, normal=0, dynamic_param={"control_latency": 13.7})]
+             dict(name="env_latency", seed=3, ETG=1, wscale=0.05, n_steps=20, normal=0, dynamic_param={"control_latency": 13.7}),
+             dict(name="env_action_filter", seed=4, ETG=1, wscale=0.04, n_steps=20, normal=0, filter_=1)]
     for c in cases:
         world = ScriptedWorld(c["seed"])
         bullet_client.BulletClient = lambda connection_mode=None, w=world: w
@@ -152,6 +153,7 @@ def main():
         locomotion_gym_env.LocomotionGymEnv.reset, locomotion_gym_env.LocomotionGymEnv.step = lreset, lstep
         try:
             env = a1_gym_env.A1GymEnv(ETG=c["ETG"], ETG_path=path, normal=c["normal"], dynamic_param=c.get("dynamic_param", {}),
+                                      filter_=c.get("filter_", 0),
                                       sensor_mode={"dis": 1, "motor": 1, "imu": 1, "contact": 1, "footpose": 0, "ETG": 0})
             n_before_reset = len(rec["all_true_obs"])
             live["on"] = True
@@ -180,7 +182,8 @@ def main():
         for k2, v in rec.items():
             out[c["name"] + "/" + k2] = np.array(v)
         out[c["name"] + "/w"], out[c["name"] + "/b"] = w, b
-        out[c["name"] + "/config"] = np.array([c["ETG"], c["normal"], c.get("dynamic_param", {}).get("control_latency", -1.0)], dtype=np.float64)
+        out[c["name"] + "/config"] = np.array([c["ETG"], c["normal"], c.get("dynamic_param", {}).get("control_latency", -1.0),
+                                               c.get("filter_", 0)], dtype=np.float64)
         print(c["name"], "steps", len(rec["obs"]), "obs dim", np.array(rec["obs"]).shape, "dones", int(np.sum(rec["done"])),
               "reward range", np.min(rec["reward"]), np.max(rec["reward"]))
     out["cases"] = np.array([c["name"] for c in cases])

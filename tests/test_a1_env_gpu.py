@@ -50,14 +50,14 @@ class ReplayPhysics(object):
                     bad=torch.full((self.n,), int(g[name + "/loco_bad"][k]), dtype=torch.int32, device=DEV))
 
 
-@pytest.mark.parametrize("idx", range(3))
+@pytest.mark.parametrize("idx", range(4))
 def test_a1_gym_env_matches_the_unmodified_reference_env(idx):
     g = np.load(GOLDEN)
     name, n = str(g["cases"][idx]), 3
-    etg, normal, lat_ms = g[name + "/config"]
+    etg, normal, lat_ms, filt = g[name + "/config"]
     phys = ReplayPhysics(g, name, n)
     env = metagym_amd.make("quadrupedal-v0", num_envs=n, physics=phys, device=DEV, ETG=int(etg), ETG_w=g[name + "/w"], ETG_b=g[name + "/b"],
-                           normal=int(normal), control_latency=0.002 if lat_ms < 0 else 0.001 * lat_ms)
+                           normal=int(normal), control_latency=0.002 if lat_ms < 0 else 0.001 * lat_ms, filter_=int(filt))
     assert isinstance(env, A1GymEnv)
     obs, info = env.reset()
     assert np.allclose(obs.cpu().numpy(), np.broadcast_to(g[name + "/reset_obs"][0], (n, 37)), **TOL)

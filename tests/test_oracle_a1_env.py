@@ -18,24 +18,30 @@ def world(g, name, k):
 
 
 def make_env(g, name):
-    etg, normal, lat_ms = g[name + "/config"]
-    return oa.A1Env(g[name + "/w"], g[name + "/b"], bool(etg), int(normal), 0.002 if lat_ms < 0 else 0.001 * lat_ms)
+    etg, normal, lat_ms, filt = g[name + "/config"]
+    flt = None
+    if filt:
+        from scipy.signal import butter                      # the reference's own source of coefficients (action_filter.py:182-185)
+        bb, aa = butter(2, [4.0 / (0.5 * (1 / (0.002 * 13)))], btype="low")
+        flt = oa.ActionFilter(np.tile(aa / aa[0], (12, 1)), np.tile(bb / aa[0], (12, 1)))
+    return oa.A1Env(g[name + "/w"], g[name + "/b"], bool(etg), int(normal), 0.002 if lat_ms < 0 else 0.001 * lat_ms, flt)
 
 
-@pytest.mark.parametrize("idx", range(3))
+@pytest.mark.parametrize("idx", range(4))
 def test_composed_env_matches_reference(idx):
     g = np.load(GOLDEN)
     name = str(g["cases"][idx])
     env = make_env(g, name)
     assert list(g[name + "/loco_kind"][:2]) == [0, 1]               # reset info, then the hidden step's
     cmd, torques, obs = env.reset(g[name + "/reset_true_obs"][0], world(g, name, 0), g[name + "/true_obs"][0], world(g, name, 1))
-    assert np.array_equal(cmd, g[name + "/command"][0])
+    assert np.array_equal(cmd, g[name + "/command"][0])      # (the command handed to robot.Step, before its own filter)
     assert np.array_equal(torques, g[name + "/torques"][0])
     assert np.array_equal(obs, g[name + "/reset_obs"][0])
     for k in range(len(g[name + "/action"])):
         assert env.time_since_reset() == g[name + "/t"][k]
         cmd, torques, obs, (shaped, inf) = env.step(g[name + "/action"][k], g[name + "/true_obs"][k + 1], world(g, name, k + 2))
-        assert np.array_equal(cmd, g[name + "/command"][k + 1]), "%s command, step %d" % (name, k)
+        if env.filter is None:      # (with the robot-level filter, robot.Step records the UNFILTERED command; the torques below see it)
+            assert np.array_equal(cmd, g[name + "/command"][k + 1]), "%s command, step %d" % (name, k)
         assert np.array_equal(torques, g[name + "/torques"][k + 1]), "%s torques, step %d" % (name, k)
         assert np.array_equal(inf["footposition"], g[name + "/info_footposition"][k])
         assert inf["energy"] == pytest.approx(g[name + "/info_energy"][k], rel=1e-14, abs=1e-300)
