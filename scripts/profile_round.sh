@@ -5,7 +5,7 @@
 export TMPDIR=/tmp
 cd "${GRAFT_REPO_ROOT:-.}"
 R=${1:-r02}; shift
-PARTS=${@:-quad maze walker bench}
+PARTS=${@:-quad maze walker a1 bench}
 OUT=gpurun_out/$R
 mkdir -p $OUT
 has() { [[ " $PARTS " == *" $1 "* ]]; }
@@ -38,6 +38,11 @@ if has walker; then
   timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/walker_trace -o w -- python scripts/bench_walker.py > $OUT/walker_trace.log 2>&1
   timeout 300 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_INSTS_LDS SQ_INSTS_SALU \
             --output-format csv -d $OUT/walker_pmc_sq -o w -- python scripts/bench_walker.py humanoid > $OUT/walker_pmc_sq.log 2>&1
+fi
+if has a1; then
+  # every secondary workload of bench.py under the tracer: the a1_* kernels (Quadrupedal actuation / wrappers) among them
+  timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/a1_trace -o a -- \
+          python bench.py --no-cpu-baseline --steps 50 --warmup 5 > $OUT/a1_trace.log 2>&1
 fi
 if has bench; then
   python bench.py > $OUT/bench.json 2> $OUT/bench.err

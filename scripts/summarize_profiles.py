@@ -66,6 +66,7 @@ for src, dst in (("quad_trace/q_kernel_stats.csv", "quadrotor_bench_kernel_stats
                  ("bench_eager.json", "bench_eager.json"), ("bench_force_dist.json", "bench_force_dist.json"),
                  ("bench_mixed_force_dist.json", "bench_mixed_force_dist.json"),
                  ("walker_trace/w_kernel_stats.csv", "walker_bench_kernel_stats.csv"),
+                 ("a1_trace/a_kernel_stats.csv", "bench_all_secondary_kernel_stats.csv"),
                  ("bench.json", "bench.json"), ("bench_maze.jsonl", "bench_maze.jsonl"),
                  ("bench_walker.jsonl", "bench_walker.jsonl")):
     if os.path.exists(os.path.join(R, src)):
