@@ -3,8 +3,10 @@ STAND-IN body (a1_standin.xml: only the leg geometry the reference's Python stat
 placeholders). It shows how the `physics` protocol plugs in and lets `quadrupedal-v0` run closed-loop on the GPU; it says
 nothing about the reference's dynamics (PyBullet + pybullet_data/a1/a1.urdf, neither in the reference tree).
 
-One 2 ms sub-step = one `mg_walker_step` launch with frame_skip 1; the motor torques of `A1Actuators` go in as the engine's
-action (torque = 33.5 * clip(a, -1, 1) with a = torque / 33.5 — the motor model has already clipped them to +-33.5)."""
+Two ways to run an env step: `substep` — one 2 ms `mg_walker_step` launch per sub-step with the torques `A1Actuators` computed
+(13 x 2 launches per env step), or `fused_step` — all 13 sub-steps in ONE launch with the reference's PD motor model evaluated
+inside the engine before every sub-step (mg_walker_params.actuation) and the 13 observations logged for mg_a1_receive_log.
+Both give bit-identical results (tests/test_a1_env_gpu.py)."""
 import os
 
 import numpy as np
@@ -27,13 +29,15 @@ class _StandinWalker(WalkerBatchEnv):
 
 
 class StandinPhysics(object):
-    def __init__(self, num_envs, device="cuda:0", solver_iterations=23):
+    def __init__(self, num_envs, device="cuda:0", solver_iterations=23, fused=True):
         # locomotion_gym_env.py:113-114: 300 / 13 = 23 solver iterations; 2 ms steps (locomotion_gym_config.py:18)
         self.env = _StandinWalker(num_envs=num_envs, device=device, frame_skip=1, time_step=0.002, max_steps=2 ** 30,
                                   solver_iterations=solver_iterations, self_collision=False)
         self.env.set_task([load_mjcf(XML, foot_names=FEET)])
         self.n, self.device = int(num_envs), torch.device(device)
         self._init = np.tile(INIT_MOTOR_ANGLES, (self.n, 1))
+        if fused:                                  # A1GymEnv takes the one-launch path when the physics offers it
+            self.fused_step = self._fused_step
 
     def _state(self):
         e = self.env
@@ -49,8 +53,23 @@ class StandinPhysics(object):
         return self._state()
 
     def substep(self, torques):
-        self.env.step((torques / TORQUE_LIMIT).to(torch.float32).contiguous())
-        return self._state()
+        """One sub-step with the motor torques A1Actuators computed (raw float64 torques, in-launch actuation mode 2); the
+        returned observation is the engine's own sub-step log, so the fused path below sees bit-identical numbers."""
+        t = torch.as_tensor(torques, dtype=torch.float64, device=self.device)
+        t = t if t.shape == (12, self.n) and t.is_contiguous() else t.t().contiguous()
+        if not hasattr(self, "_log1"):
+            self._log1 = torch.empty(1, 43, self.n, dtype=torch.float64, device=self.device)
+        self.env.step_actuated(t, raw_torque=True, n_substeps=1, log=self._log1)
+        g = self._log1[0]
+        return g[0:12], g[12:24], g[36:40], g[40:43]                            # SoA views: taken without a copy
+
+    def _fused_step(self, command, actuators):
+        """13 sub-steps in one engine launch, the PD motor model evaluated inside it before every sub-step."""
+        kp, kd, strength, limit = actuators.motor_model_parameters()
+        if not hasattr(self, "_log"):
+            self._log = torch.empty(13, 43, self.n, dtype=torch.float64, device=self.device)
+        self.env.step_actuated(command, kp, kd, strength, limit, n_substeps=13, log=self._log)
+        return self._log
 
     def world(self):
         e = self.env

@@ -1,6 +1,6 @@
 """`quadrupedal-v0` closed-loop on the GPU with the stand-in body of this directory (see physics.py for what that means):
 
-    python examples/a1_standin/run.py [num_envs] [steps]
+    python examples/a1_standin/run.py [num_envs] [steps] [--unfused]
 
 Zero policy actions: the motor model holds the default pose (0, 0.9, -1.8) x 4 through its PD loop, 13 sub-steps per env
 step; then the same with the ETG's open-loop trot. Prints base height / reward / done fraction and env-steps/s."""
@@ -16,12 +16,13 @@ import torch
 import metagym_amd
 from physics import StandinPhysics
 
-n = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
-steps = int(sys.argv[2]) if len(sys.argv) > 2 else 40
+args = [a for a in sys.argv[1:] if not a.startswith("--")]
+n = int(args[0]) if len(args) > 0 else 4096
+steps = int(args[1]) if len(args) > 1 else 40
 for label, kw in (("hold the default pose", dict(ETG=0)),
                   ("ETG open-loop gait (hand-set weights)", dict(ETG=1, ETG_w=np.tile([[0.03], [0.0], [0.02]], (1, 20)) * np.sin(np.linspace(0, 2 * np.pi, 20)),
                                                                  ETG_b=np.zeros(3)))):
-    phys = StandinPhysics(n)
+    phys = StandinPhysics(n, fused="--unfused" not in sys.argv)
     env = metagym_amd.make("quadrupedal-v0", num_envs=n, physics=phys, **kw)
     obs, info = env.reset()
     a = torch.zeros(n, 12, dtype=torch.float64, device="cuda:0")

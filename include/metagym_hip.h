@@ -405,6 +405,19 @@ typedef struct mg_walker_params {
      * height_f32 1 = the alive test adds the python float initial_z to the float32 obs[0] in float32 (humanoid),
      *            0 = initial_z is a float64 taken from the first calc_state (ant). */
     int32_t torque_f32, height_f32;
+    /* Actuators evaluated INSIDE the launch, once per physics sub-step (wave mapping only; 0 keeps the action path above):
+     *   1  position control: torque_j = LaikagoMotorModel.convert_to_torque (quadrupedal/robots/laikago_motor.py:136-168,
+     *      the same expression as mg_a1_apply_action) of the CURRENT joint state (pd latency 0, the A1 default) and the
+     *      desired angles in pd_command — what Minitaur.Step does 13 times per env step around stepSimulation;
+     *   2  raw torques from pd_command (the caller ran the motor model itself).
+     * pd_command: DEVICE f64 [nj][N]. substep_log: DEVICE f64 [frame_skip][3 nj + 7][N] or NULL — after every sub-step the
+     * joint angles, rates, applied torques, the base quaternion (x y z w) and the body-frame angular velocity, i.e. one
+     * Minitaur.GetTrueObservation (minitaur.py:1175-1182) per sub-step, ready for mg_a1_receive_log. */
+    int32_t actuation;
+    const double *pd_command;
+    double pd_kp[MG_WALKER_MAX_JOINTS], pd_kd[MG_WALKER_MAX_JOINTS], pd_strength[MG_WALKER_MAX_JOINTS],
+        pd_limit[MG_WALKER_MAX_JOINTS];
+    double *substep_log;
 } mg_walker_params;
 
 /* Per-env state, SoA doubles: component c of env e at base[c*N + e]. */
@@ -502,6 +515,12 @@ int mg_a1_receive_observation(const mg_a1_actuator_config *cfg, int32_t n_envs, 
 int mg_a1_receive_and_apply(const mg_a1_actuator_config *cfg, int32_t n_envs, const mg_a1_actuator_state *state,
                             const double *q, const double *qd, const double *base_quat, const double *rpy_rate,
                             const double *command, const double *last_command, double lerp, double *torque, void *stream);
+/* K ReceiveObservation calls at once from a sub-step log (mg_walker_params.substep_log, [K][43][N]: q 12, qd 12, torque 12,
+ * quaternion 4, body rate 3 per sub-step): the K observations are pushed on the history in order and the control observation
+ * is refreshed once at the end (only the last one is ever read between env steps). The logged torques become the observed
+ * torques. Identical to K mg_a1_receive_observation calls each preceded by the ApplyAction that produced that torque. */
+int mg_a1_receive_log(const mg_a1_actuator_config *cfg, int32_t n_envs, const mg_a1_actuator_state *state, const double *log,
+                      int32_t n_substeps, void *stream);
 /* Any output may be NULL. motor_angles / motor_velocities / motor_torques: f64 [12][N]; rpy_rate f64 [3][N];
  * energy f64 [N]. */
 int mg_a1_sensors(const mg_a1_actuator_config *cfg, int32_t n_envs, const mg_a1_actuator_state *state,

@@ -117,7 +117,11 @@ class WalkerParams(C.Structure):
                 ("max_steps", C.c_int32), ("floor_in_parts", C.c_int32), ("mapping", C.c_int32),
                 ("self_collision", C.c_int32), ("self_friction", C.c_double),
                 ("auto_reset", C.c_int32), ("seed", C.c_uint64), ("step_index", C.c_uint64),
-                ("env_id_base", C.c_uint64), ("torque_f32", C.c_int32), ("height_f32", C.c_int32)]
+                ("env_id_base", C.c_uint64), ("torque_f32", C.c_int32), ("height_f32", C.c_int32),
+                ("actuation", C.c_int32), ("pd_command", C.c_void_p),
+                ("pd_kp", C.c_double * WALKER_MAX_JOINTS), ("pd_kd", C.c_double * WALKER_MAX_JOINTS),
+                ("pd_strength", C.c_double * WALKER_MAX_JOINTS), ("pd_limit", C.c_double * WALKER_MAX_JOINTS),
+                ("substep_log", C.c_void_p)]
 
 
 class WalkerState(C.Structure):
@@ -237,6 +241,7 @@ SIGNATURES = {
                                             _P, _P, _P, _P, _P, _P]),
     "mg_a1_receive_and_apply": (C.c_int, [C.POINTER(A1ActuatorConfig), C.c_int32, C.POINTER(A1ActuatorState), _P, _P, _P, _P,
                                           _P, _P, C.c_double, _P, _P]),
+    "mg_a1_receive_log": (C.c_int, [C.POINTER(A1ActuatorConfig), C.c_int32, C.POINTER(A1ActuatorState), _P, C.c_int32, _P]),
     "mg_a1_sensors": (C.c_int, [C.POINTER(A1ActuatorConfig), C.c_int32, C.POINTER(A1ActuatorState),
                                 _P, _P, _P, _P, _P, _P]),
     "mg_a1_info": (C.c_int, [C.POINTER(A1ActuatorConfig), C.c_int32, C.POINTER(A1ActuatorState), _P, _P, _P, _P, _P, _P, _P]),

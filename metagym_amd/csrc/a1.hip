@@ -578,6 +578,42 @@ __global__ __launch_bounds__(A1_BLOCK) void a1_info_kernel(A1K k, mg_a1_actuator
     }
 }
 
+// K logged sub-step observations (mg_walker_params.substep_log) pushed at once; control observation refreshed at the end.
+__global__ __launch_bounds__(A1_BLOCK) void a1_receive_log_kernel(A1K k, mg_a1_actuator_state st, int n, const double *log, int K) {
+    const int e = blockIdx.x * A1_BLOCK + threadIdx.x;
+    if (e >= n) return;
+    const mg_a1_actuator_config &c = k.c;
+    const size_t stride = (size_t)OD * n;
+    int count = st.count[e], head = st.head[e];
+    for (int s = 0; s < K; ++s) {
+        head = count == 0 ? 0 : (head + 1 == c.history_len ? 0 : head + 1);
+        if (count < c.history_len) ++count;
+        const double *src = log + (size_t)s * stride + e;
+        double *slot = st.history + (size_t)head * stride + e;
+        double in[OD];
+#pragma unroll
+        for (int i = 0; i < OD; ++i) in[i] = src[(size_t)i * n];
+#pragma unroll
+        for (int i = 0; i < OD; ++i) slot[(size_t)i * n] = in[i];
+        if (s == K - 1)
+#pragma unroll
+            for (int i = 0; i < NM; ++i) st.observed_torque[(size_t)i * n + e] = in[2 * NM + i];
+    }
+    st.count[e] = count;
+    st.head[e] = head;
+    const double lat = c.control_latency_env ? c.control_latency_env[e] : c.control_latency;
+    const Delay d = delayed(lat, c.time_step, count, head, c.history_len);
+    constexpr int CH = 11;
+    for (int c0 = 0; c0 < OD; c0 += CH) {
+        double v[CH];
+#pragma unroll
+        for (int i = 0; i < CH; ++i) v[i] = c0 + i < OD ? blend(d, st.history, stride, c0 + i, n, e) : 0.0;
+#pragma unroll
+        for (int i = 0; i < CH; ++i)
+            if (c0 + i < OD) st.control_obs[(size_t)(c0 + i) * n + e] = v[i];
+    }
+}
+
 int check_a1(const mg_a1_actuator_config *cfg, const mg_a1_actuator_state *st, int n) {
     if (!cfg || !st) return mg::set_error(MG_ERR_NULL_POINTER, "a1: NULL descriptor");
     if (n <= 0) return mg::set_error(MG_ERR_BAD_SIZE, "n_envs=%d", n);
@@ -757,4 +793,16 @@ extern "C" int mg_a1_receive_and_apply(const mg_a1_actuator_config *cfg, int32_t
     hipLaunchKernelGGL(a1_receive_apply_kernel, dim3((n + A1_BLOCK - 1) / A1_BLOCK), dim3(A1_BLOCK), 0, (hipStream_t)stream, k,
                        *st, n, q, qd, base_quat, rpy_rate, command, last_command, lerp, torque);
     return mg::check_launch("a1_receive_apply_kernel");
+}
+
+extern "C" int mg_a1_receive_log(const mg_a1_actuator_config *cfg, int32_t n, const mg_a1_actuator_state *st, const double *log,
+                                 int32_t n_substeps, void *stream) {
+    if (int rc = check_a1(cfg, st, n)) return rc;
+    MG_REQUIRE_PTR(log);
+    if (n_substeps < 1) return mg::set_error(MG_ERR_BAD_SIZE, "n_substeps=%d", n_substeps);
+    mg::DeviceGuard guard(mg::device_of(st->history));
+    A1K k{*cfg};
+    hipLaunchKernelGGL(a1_receive_log_kernel, dim3((n + A1_BLOCK - 1) / A1_BLOCK), dim3(A1_BLOCK), 0, (hipStream_t)stream, k, *st,
+                       n, log, n_substeps);
+    return mg::check_launch("a1_receive_log_kernel");
 }

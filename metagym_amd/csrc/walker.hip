@@ -422,6 +422,17 @@ __device__ __forceinline__ double motor_torque(const mg_walker_params &prm, doub
     a = a < -1.0f ? -1.0f : (a > 1.0f ? 1.0f : a);
     return prm.torque_f32 ? (double)((float)gain * a) : gain * (double)a;
 }
+// In-launch actuators (mg_walker_params.actuation): the reference's PD motor model, laikago_motor.py:157-168, in the exact
+// expression order of mg_a1_apply_action (a1.hip) — contraction off here, so the two files produce the same bits.
+#pragma clang fp contract(off)
+__device__ __forceinline__ double actuator_torque(const mg_walker_params &prm, int j, double q, double qd, double cmd) {
+    if (prm.actuation == 2) return cmd;
+    double t = (-1.0 * (prm.pd_kp[j] * (q - cmd)) - prm.pd_kd[j] * (qd - 0.0)) + 0.0;
+    t = prm.pd_strength[j] * t;
+    return fmin(fmax(t, -1.0 * prm.pd_limit[j]), prm.pd_limit[j]);
+}
+#pragma clang fp contract(fast)
+
 // walker_base_env.py:47 `alive_bonus(state[0] + initial_z, ...)`: state[0] is float32; the humanoid's initial_z is
 // the python float 0.8 (humanoids.py:48) -> float32 sum; the ant's came out of calc_state as a float64 -> float64 sum.
 __device__ __forceinline__ double alive_height(const mg_walker_params &prm, float obs0) {
@@ -860,7 +871,7 @@ __device__ __forceinline__ void wave_kinematics(const ModelW &m, const WaveLds &
 template <int NMAX>
 __device__ __forceinline__ void wave_substep(const mg_walker_topology &tp, const ModelW &m, const mg_walker_params &prm,
                                              const WaveLds &L, int lane, int max_depth, int maxr,
-                                             unsigned long long &touch_mask) {
+                                             unsigned long long &touch_mask, double pd_cmd, double *log_row, int n_envs) {
     const int nb = m.nb, nj = m.nj, ns = m.ns, n = 6 + nj;
     const double dt = prm.time_step;
     // A fresh copy of the lane id per sub-step: the ~140 lane predicates of the unrolled Cholesky / substitution
@@ -868,6 +879,8 @@ __device__ __forceinline__ void wave_substep(const mg_walker_topology &tp, const
     // 64-bit masks and spilled to VGPR lanes; one v_cmp where it is needed is cheaper than the reload.
     asm volatile("" : "+v"(lane));
     PHASE_BEGIN();
+    if (prm.actuation != 0 && lane < nj)      // read by lane 6 + j after the kinematics' barriers
+        L.tau[lane] = actuator_torque(prm, lane, L.q[lane], L.qd[lane], pd_cmd);
     wave_kinematics(m, L, lane, max_depth, true);
     PHASE(0);
     // ---- M and h by the composite-rigid-body algorithm (Featherstone RBDA ch. 6) in world coordinates, all spatial
@@ -1247,6 +1260,38 @@ __device__ __forceinline__ void wave_substep(const mg_walker_topology &tp, const
     }
     WSYNC();
     PHASE(9);
+    if (log_row != nullptr) {     // one Minitaur.GetTrueObservation: q, qd, torque | quaternion (x y z w) | body-frame rate
+        if (lane < nj) {
+            log_row[(size_t)lane * n_envs] = L.q[lane];
+            log_row[(size_t)(nj + lane) * n_envs] = L.qd[lane];
+            log_row[(size_t)(2 * nj + lane) * n_envs] = L.tau[lane];
+        }
+        if (lane == 0) {
+            const double *R = L.base + 3;
+            const V3 om{L.base[15], L.base[16], L.base[17]};
+            double qx, qy, qz, qw;
+            const double tr = R[0] + R[4] + R[8];
+            if (tr > 0.0) {
+                const double s4 = 2.0 * sqrt(tr + 1.0);
+                qw = 0.25 * s4; qx = (R[7] - R[5]) / s4; qy = (R[2] - R[6]) / s4; qz = (R[3] - R[1]) / s4;
+            } else if (R[0] > R[4] && R[0] > R[8]) {
+                const double s4 = 2.0 * sqrt(1.0 + R[0] - R[4] - R[8]);
+                qw = (R[7] - R[5]) / s4; qx = 0.25 * s4; qy = (R[1] + R[3]) / s4; qz = (R[2] + R[6]) / s4;
+            } else if (R[4] > R[8]) {
+                const double s4 = 2.0 * sqrt(1.0 + R[4] - R[0] - R[8]);
+                qw = (R[2] - R[6]) / s4; qx = (R[1] + R[3]) / s4; qy = 0.25 * s4; qz = (R[5] + R[7]) / s4;
+            } else {
+                const double s4 = 2.0 * sqrt(1.0 + R[8] - R[0] - R[4]);
+                qw = (R[3] - R[1]) / s4; qx = (R[2] + R[6]) / s4; qy = (R[5] + R[7]) / s4; qz = 0.25 * s4;
+            }
+            double *r = log_row + (size_t)(3 * nj) * n_envs;
+            r[0] = qx; r[(size_t)n_envs] = qy; r[2 * (size_t)n_envs] = qz; r[3 * (size_t)n_envs] = qw;
+            // R^T omega
+            r[4 * (size_t)n_envs] = R[0] * om.x + R[3] * om.y + R[6] * om.z;
+            r[5 * (size_t)n_envs] = R[1] * om.x + R[4] * om.y + R[7] * om.z;
+            r[6 * (size_t)n_envs] = R[2] * om.x + R[5] * om.y + R[8] * om.z;
+        }
+    }
 }
 
 template <int NMAX, class SH>
@@ -1306,7 +1351,7 @@ __global__ __launch_bounds__(WV) __attribute__((amdgpu_waves_per_eu(2))) void wa
     if (lane < nj) {
         L.q[lane] = st.q[(size_t)lane * n_envs + e];
         L.qd[lane] = st.qd[(size_t)lane * n_envs + e];
-        L.tau[lane] = motor_torque(prm, m.motor()[lane], action[(size_t)e * nj + lane]);
+        L.tau[lane] = prm.actuation != 0 ? 0.0 : motor_torque(prm, m.motor()[lane], action[(size_t)e * nj + lane]);
     }
     WSYNC();
     const int max_depth = L.misc[0];
@@ -1314,7 +1359,11 @@ __global__ __launch_bounds__(WV) __attribute__((amdgpu_waves_per_eu(2))) void wa
 #ifdef MG_WALKER_PROFILE
     unsigned long long ph_k0 = __builtin_readcyclecounter();
 #endif
-    for (int it = 0; it < prm.frame_skip; ++it) wave_substep<NMAX>(tp, m, prm, L, lane, max_depth, maxr, touch);
+    const double pd_cmd = (prm.actuation != 0 && lane < nj) ? prm.pd_command[(size_t)lane * n_envs + e] : 0.0;
+    for (int it = 0; it < prm.frame_skip; ++it) {
+        double *log_row = prm.substep_log ? prm.substep_log + ((size_t)it * (3 * nj + 7)) * n_envs + e : nullptr;
+        wave_substep<NMAX>(tp, m, prm, L, lane, max_depth, maxr, touch, pd_cmd, log_row, n_envs);
+    }
     // ---- calc_state (walker_base.py:31-64) on the current configuration ------------------------------
     // after_reset = false: post-step state; the obs carries the PREVIOUS step's feet flags and the flags
     // are then refreshed from this step's contacts (walker_base_env.py:46 vs :57-63).
@@ -1488,7 +1537,12 @@ extern "C" int mg_walker_step(const mg_walker_topology *tp, const mg_walker_mode
                               int32_t n, const mg_walker_state *st, const float *action, float *obs, float *reward,
                               float *rewards5, uint8_t *done, void *stream) {
     if (int rc = check_walker(tp, ms, prm, st, n)) return rc;
-    MG_REQUIRE_PTR(action);
+    if (prm->actuation == 0) MG_REQUIRE_PTR(action);
+    else {
+        if (prm->actuation != 1 && prm->actuation != 2) return mg::set_error(MG_ERR_BAD_CONFIG, "walker actuation %d", prm->actuation);
+        if (prm->mapping == 0) return mg::set_error(MG_ERR_UNSUPPORTED, "in-launch actuators need the wave mapping");
+        MG_REQUIRE_PTR(prm->pd_command);
+    }
     MG_REQUIRE_PTR(obs);
     MG_REQUIRE_PTR(reward);
     MG_REQUIRE_PTR(done);

@@ -247,6 +247,37 @@ class WalkerBatchEnv(object):
         _lib.check(rc, "mg_walker_step")
         return self._obs, self._reward, self._done, {"rewards": self._rewards5, "steps": self.steps}
 
+    def step_actuated(self, command, kp=None, kd=None, strength=None, limit=None, raw_torque=False, n_substeps=None, log=None):
+        """The engine's in-launch actuators (mg_walker_params.actuation): `n_substeps` physics sub-steps in ONE launch, the
+        joint torques re-evaluated before each of them — position control with the reference's PD motor model
+        (quadrupedal/robots/laikago_motor.py:136-168) on the current joint state and the desired angles `command`
+        (float64 `[n_joints, num_envs]`, SoA), or `raw_torque=True`: `command` are the torques themselves. `log` (float64
+        `[n_substeps, 3 n_joints + 7, num_envs]`) receives one true observation per sub-step (joint angles, rates, torques,
+        base quaternion x y z w, body-frame angular velocity). The MetaLocomotion outputs (obs / reward / done) of the launch
+        are those of the walker rules and are returned for completeness."""
+        nj, p = self.n_joints, self._params_c
+        cmd = torch.as_tensor(command, dtype=torch.float64, device=self.device)
+        assert cmd.shape == (nj, self.num_envs) and cmd.is_contiguous(), "command must be a contiguous [n_joints, num_envs] float64 tensor"
+        k = self.frame_skip if n_substeps is None else int(n_substeps)
+        if log is not None:
+            assert log.shape == (k, 3 * nj + 7, self.num_envs) and log.is_contiguous() and log.dtype == torch.float64
+        saved = (p.frame_skip, p.actuation)
+        p.frame_skip, p.actuation, p.pd_command = k, 2 if raw_torque else 1, cmd.data_ptr()
+        p.substep_log = None if log is None else log.data_ptr()
+        if not raw_torque:
+            for name, v, dflt in (("pd_kp", kp, 0.0), ("pd_kd", kd, 0.0), ("pd_strength", strength, 1.0), ("pd_limit", limit, 1e30)):
+                getattr(p, name)[:nj] = list(np.broadcast_to(np.asarray(dflt if v is None else v, dtype=np.float64), (nj,)))
+        p.step_index = self.global_step
+        self.global_step += 1
+        try:
+            rc = self._lib.mg_walker_step(self._topo, self._models_c, p, self.num_envs, self._state_c, None, _lib.ptr(self._obs),
+                                          _lib.ptr(self._reward), _lib.ptr(self._rewards5), _lib.ptr(self._done),
+                                          _lib.current_stream(self.device))
+        finally:
+            p.frame_skip, p.actuation, p.pd_command, p.substep_log = saved[0], saved[1], None, None
+        _lib.check(rc, "mg_walker_step (actuated)")
+        return self._obs, self._reward, self._done, {"rewards": self._rewards5, "steps": self.steps}
+
     def render(self, mode="human", close=False):
         raise NotImplementedError("rendering is out of scope for the batched engine")
 

@@ -215,6 +215,37 @@ class A1Actuators(object):
         self._last_action = act
         return torch.stack(torques)
 
+    def StepFused(self, action, fused_physics):
+        """Minitaur.Step when the physics can run the whole action-repeat loop in one launch with the PD motor model evaluated
+        inside it (`fused_physics(command_soa, actuators) -> log`, float64 `[action_repeat, 43, num_envs]`: one true
+        observation per sub-step, torques included — e.g. WalkerBatchEnv.step_actuated). POSITION mode, pd latency 0, no
+        command clip, no interpolation (the reference's A1 configuration, env_builder.py:44-52); any control latency. The log
+        is pushed on the history in one launch (mg_a1_receive_log). Returns the applied torques `[action_repeat, num_envs, 12]`."""
+        c = self._cfg
+        if (self._motor_control_mode is not MotorControlMode.POSITION or c.pd_latency != 0.0 or c.pd_latency_env or c.clip_commands
+                or self._enable_action_interpolation or c.kp_env or c.kd_env):
+            raise _lib.MetaGymHipError("StepFused covers POSITION mode with pd latency 0, shared gains, no clip / interpolation; use Step")
+        if self._action_filter is not None:
+            if self._step_counter == 0:
+                self._action_filter.init_history(self.GetMotorAngles())
+            action = self._action_filter.filter(action)
+        act = self._soa(action, NUM_MOTORS)
+        log = fused_physics(act, self)
+        assert log.shape == (self._action_repeat, _lib.A1_OBS_DIM, self.num_envs) and log.is_contiguous()
+        with torch.cuda.device(self.device):
+            rc = self._lib.mg_a1_receive_log(C.byref(c), self.num_envs, C.byref(self._st), _lib.ptr(log), self._action_repeat,
+                                             _lib.current_stream(self.device))
+        _lib.check(rc, "mg_a1_receive_log")
+        self._step_counter += self._action_repeat
+        self._last_action = act
+        return log[:, 2 * NUM_MOTORS:3 * NUM_MOTORS, :].permute(0, 2, 1)
+
+    def motor_model_parameters(self):
+        """(kp, kd, strength, torque limit) per motor, for a physics that evaluates the PD model itself."""
+        c = self._cfg
+        lim = list(c.torque_limit) if c.has_torque_limit else [1e30] * NUM_MOTORS
+        return list(c.kp), list(c.kd), list(c.strength), lim
+
     def GetTimeSinceReset(self):
         return self._step_counter * self.time_step
 

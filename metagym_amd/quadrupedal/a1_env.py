@@ -13,6 +13,8 @@ in the reference tree. `physics` is the caller's batched simulator:
     physics.substep(torques) -> the same four after one 2 ms pybullet.stepSimulation() with those motor torques
     physics.world()          -> dict(base=[N,3] GetBasePosition, contact=[N,4] foot-ground flags, bad=[N] number of non-foot
                                 contact points) at the end of the env step
+    physics.fused_step(command[12][N], actuators) -> log[13][43][N]   (optional) the whole 13-sub-step loop in one launch with
+                                the PD motor model evaluated inside it (A1Actuators.StepFused)
 
 The composition (which time the ETG sees, the hidden zero-action step inside reset(), sensors before the observation,
 the reward against last step's base and feet) is pinned end to end against the unmodified `A1GymEnv` running on a scripted
@@ -47,6 +49,7 @@ class A1GymEnv(object):
         self.shaping = RewardShaping(num_envs, device, param=reward_param, reward_p=reward_p, vel_d=vel_d, env_info=env_info)
         self._lib = _lib.load()
         self.last_torques = None
+        self._fusable = motor_control_mode is MotorControlMode.POSITION and motor_kp is None
 
     def get_time_since_reset(self):
         return self.robot.GetTimeSinceReset()
@@ -66,7 +69,10 @@ class A1GymEnv(object):
     def _env_step(self, action, reset_mask=None):
         """LocomotionGymEnv.step below the wrappers (locomotion_gym_env.py:461-546)."""
         cmd, etg_obs = self.path.step(action, self.get_time_since_reset())
-        self.last_torques = self.robot.Step(cmd, self.physics.substep)
+        if hasattr(self.physics, "fused_step") and self._fusable:      # 13 sub-steps + PD model inside one physics launch
+            self.last_torques = self.robot.StepFused(cmd, self.physics.fused_step)
+        else:
+            self.last_torques = self.robot.Step(cmd, self.physics.substep)
         world, info = self.physics.world(), self._info()
         info.update(base=world["base"], real_contact=world["contact"], bad=world["bad"], real_action=cmd, ETG_obs=etg_obs,
                     ETG_act=self.path.last_ETG_act.t())

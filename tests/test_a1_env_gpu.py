@@ -103,3 +103,35 @@ def test_closed_loop_on_the_example_standin_body_holds_the_default_pose():
     assert 0.22 < float(z.min()) and float(z.max()) < 0.30
     assert float((env.robot.GetMotorAngles() - torch.as_tensor([0, 0.9, -1.8] * 4, device=DEV)).abs().max()) < 0.15
     assert float(info["real_contact"].sum(dim=1).min()) >= 2.0      # it stands on its feet (flags flicker with the penetration depth)
+
+
+def test_fused_engine_step_equals_thirteen_separate_substeps_bit_for_bit():
+    """The engine's in-launch actuators (13 sub-steps, PD motor model inside the launch, sub-step log -> mg_a1_receive_log)
+    against the same closed loop run sub-step by sub-step through mg_a1_apply_action / mg_a1_receive_and_apply (whose motor
+    model is pinned to the reference): observations, rewards, torques and the engine state must be bit-identical."""
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "examples", "a1_standin"))
+    from physics import StandinPhysics
+    n = 192
+    w = np.tile([[0.02], [0.0], [0.015]], (1, 20)) * np.sin(np.linspace(0, 2 * np.pi, 20))
+    envs = []
+    for fused in (True, False):
+        phys = StandinPhysics(n, DEV, fused=fused)
+        envs.append(metagym_amd.make("quadrupedal-v0", num_envs=n, physics=phys, device=DEV, ETG=1, ETG_w=w, ETG_b=np.zeros(3),
+                                     control_latency=0.0057))
+    assert hasattr(envs[0].physics, "fused_step") and not hasattr(envs[1].physics, "fused_step")
+    o0, _ = envs[0].reset()
+    o1, _ = envs[1].reset()
+    assert torch.equal(o0, o1)
+    rs = np.random.RandomState(3)
+    for k in range(8):
+        a = torch.as_tensor(rs.uniform(-0.2, 0.2, (n, 12)), device=DEV)
+        r0, r1 = envs[0].step(a), envs[1].step(a)
+        assert torch.equal(r0[0], r1[0]), "observation, step %d" % k
+        assert torch.equal(r0[1], r1[1]) and torch.equal(r0[2], r1[2])
+        assert torch.equal(envs[0].last_torques, envs[1].last_torques), "torques, step %d" % k
+        for key in ("pos", "rot", "vel", "omega", "q", "qd"):
+            assert torch.equal(getattr(envs[0].physics.env, key), getattr(envs[1].physics.env, key)), key
+        assert torch.equal(envs[0].robot.GetControlObservation(), envs[1].robot.GetControlObservation())
+    assert torch.isfinite(r0[0]).all()
