@@ -301,3 +301,29 @@ def test_auto_reset_equals_explicit_masked_reset(mapping):
         oh, _, dh, _ = half.step(a[n // 2:])
         assert torch.equal(of[n // 2:], oh) and torch.equal(df[n // 2:], dh)
     assert torch.equal(full.q[:, n // 2:], half.q)
+
+
+def test_in_launch_raw_torque_actuation_equals_the_action_path():
+    """mg_walker_params.actuation = 2 (raw float64 torques, re-applied before every sub-step inside the launch) fed
+    gain * clip(a) is the action path itself: same states bit for bit over 6 env steps of the ant (whose apply_action
+    multiplies in float64, walker_base.py:26-29) — which ties the in-launch actuators to the oracle-checked engine path.
+    And the sub-step log of those launches ends on the state arrays."""
+    models = [MODELS["ant"]]
+    n = 96
+    a_env, b_env = _make("MetaAntEnv", models, n), _make("MetaAntEnv", models, n)
+    rs = np.random.RandomState(5)
+    noise = rs.uniform(-0.1, 0.1, (n, 8))
+    a_env.reset(joint_noise=noise); b_env.reset(joint_noise=noise)
+    gain = 100.0 * a_env.power                                             # motor_power None -> 100 (robot_bases.py:93)
+    log = torch.empty(a_env.frame_skip, 3 * 8 + 7, n, dtype=torch.float64, device="cuda:0")
+    for k in range(6):
+        act = torch.as_tensor(rs.uniform(-1.3, 1.3, (n, 8)).astype(np.float32))
+        a_env.step(act)
+        torque = (gain * act.clamp(-1.0, 1.0).double()).t().contiguous().cuda()
+        b_env.step_actuated(torque, raw_torque=True, log=log)
+        for key in ("pos", "rot", "vel", "omega", "q", "qd"):
+            assert torch.equal(getattr(a_env, key), getattr(b_env, key)), (k, key)
+        assert torch.equal(a_env._obs, b_env._obs) and torch.equal(a_env._reward, b_env._reward)
+        assert torch.equal(log[-1, 0:8], b_env.q) and torch.equal(log[-1, 8:16], b_env.qd) and torch.equal(log[-1, 16:24], torque)
+        quat = log[-1, 24:28]
+        assert torch.allclose((quat * quat).sum(0), torch.ones(n, dtype=torch.float64, device="cuda:0"), atol=1e-12)
