@@ -440,7 +440,8 @@ int mg_walker_reset(const mg_walker_topology *topo, const mg_walker_models *mode
                     int32_t n_envs, const mg_walker_state *state, const uint8_t *mask, const double *joint_noise,
                     float *obs, void *stream);
 
-/* WalkerBaseEnv.step for all envs: torques from action (f32 [N][nj]), frame_skip physics sub-steps,
+/* WalkerBaseEnv.step for all envs: torques from action (f32 [N][nj]; NULL when prm->actuation != 0: the in-launch actuators
+ * read prm->pd_command instead), frame_skip physics sub-steps,
  * calc_state -> obs f32 [N][8 + 2 nj + nf], reward f32 [N], rewards5 f32 [N][5] (alive, progress,
  * electricity, joints_at_limit, feet_collision; may be NULL), done u8 [N]. */
 int mg_walker_step(const mg_walker_topology *topo, const mg_walker_models *models, const mg_walker_params *prm,
