@@ -141,3 +141,34 @@ def test_state_dict_round_trip_and_rejects_cpu():
     assert torch.equal(b.ApplyAction(q + 0.1), t1)
     with pytest.raises(Exception):
         A1Actuators(4, "cpu")
+
+
+def test_full_size_batch_is_lane_independent():
+    """65 536 robots (the bench size): results do not depend on where a robot sits in the batch (permutation equivariance)
+    and repeat exactly (determinism) — size-independent properties at the size the oracle is too slow for."""
+    n = 65536
+    g = torch.Generator(device="cpu").manual_seed(0)
+    perm = torch.randperm(n, generator=g)
+    lat = torch.rand(n, generator=g, dtype=torch.float64) * 0.02
+
+    def run(order):
+        a = A1Actuators(n, DEV, action_repeat=3, enable_action_interpolation=True)
+        a.SetControlLatency(lat[order].to(DEV))
+        gg = torch.Generator(device="cpu").manual_seed(1)
+        outs = []
+        w = [torch.rand(n, k, generator=gg, dtype=torch.float64) for k in (12, 12, 4, 3)]
+        a.Reset(); a.ReceiveObservation(*[x[order].to(DEV) for x in w])
+        for s in range(3):
+            act = torch.rand(n, 12, generator=gg, dtype=torch.float64)[order].to(DEV)
+            ws = [[torch.rand(n, k, generator=gg, dtype=torch.float64)[order].to(DEV) for k in (12, 12, 4, 3)] for _ in range(3)]
+            it = iter(ws)
+            t = a.Step(act, lambda torque: next(it))
+            outs.append(t.clone()); outs.append(a.GetControlObservation().clone())
+        outs.append(a.GetEnergyConsumptionPerControlStep().clone())
+        return outs
+    ident = torch.arange(n)
+    base, again, shuffled = run(ident), run(ident), run(perm)
+    for x, y, z in zip(base, again, shuffled):
+        assert torch.equal(x, y)
+        px = x[:, perm.to(DEV)] if x.dim() == 3 else x[perm.to(DEV)]
+        assert torch.equal(px, z)
