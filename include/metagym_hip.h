@@ -560,7 +560,7 @@ typedef struct mg_a1_etg_config {
 int mg_a1_etg_action(const mg_a1_etg_config *cfg, int32_t n_envs, double *last_etg_act, const double *action,
                      const double *t, double *command, double *etg_obs, void *stream);
 
-#define MG_A1_MAX_SEGMENTS 8
+#define MG_A1_MAX_SEGMENTS 32   /* the reference task terrains report up to 26 stretches (stairslope, slopeslope) */
 
 /* RewardShaping (MonitorEnv.py:275-519), vel_mode "max". */
 typedef struct mg_a1_reward_config {

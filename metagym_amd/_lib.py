@@ -153,7 +153,7 @@ class A1ActuatorState(C.Structure):
                 ("observed_torque", C.c_void_p), ("control_obs", C.c_void_p)]
 
 
-A1_ETG_MAX_H, A1_MAX_SEGMENTS = 32, 8
+A1_ETG_MAX_H, A1_MAX_SEGMENTS = 32, 32
 
 
 class A1EtgConfig(C.Structure):

@@ -15,23 +15,32 @@ in the reference tree. `physics` is the caller's batched simulator:
                                 contact points) at the end of the env step
     physics.fused_step(command[12][N], actuators) -> log[13][43][N]   (optional) the whole 13-sub-step loop in one launch with
                                 the PD motor model evaluated inside it (A1Actuators.StepFused)
+    physics.set_terrain(boxes, default_pose)   (optional) called once with the static boxes of `task`'s terrain
+                                (terrain.task_terrain — what the reference creates in its Bullet world) and the reset pose
+                                [0, 0, 0.28 + add_height] (locomotion_gym_env.py:337)
+
+`task` selects the terrain exactly as in the reference (locomotion_gym_env.py:309-325): its `env_info` stretches drive the
+slope / stair handling of the reward; the boxes and the reset height are handed to the physics.
 
 The composition (which time the ETG sees, the hidden zero-action step inside reset(), sensors before the observation,
 the reward against last step's base and feet) is pinned end to end against the unmodified `A1GymEnv` running on a scripted
 Bullet client: tests/golden/a1_env.npz, tests/test_a1_env_gpu.py."""
 import ctypes as C
+import os
 
+import numpy as np
 import torch
 
 from .. import _lib
 from .a1_actuators import A1Actuators, MotorControlMode
-from .a1_wrappers import EtgActionPath, Param_Dict, RewardShaping, SensorStack, FLAT_GROUND
+from .a1_wrappers import EtgActionPath, Param_Dict, RewardShaping, SensorStack
+from .terrain import task_terrain
 
 
 class A1GymEnv(object):
-    def __init__(self, num_envs, physics, device="cuda:0", ETG=0, ETG_T=0.5, ETG_H=20, ETG_w=None, ETG_b=None, act_mode="traj",
-                 task="plane", normal=0, action_space=0, reward_param=Param_Dict, reward_p=1.0, vel_d=0.6, filter_=0,
-                 control_latency=0.002, motor_kp=None, motor_kd=None, env_info=FLAT_GROUND,
+    def __init__(self, num_envs, physics, device="cuda:0", ETG=0, ETG_T=0.5, ETG_H=20, ETG_path="", ETG_w=None, ETG_b=None,
+                 act_mode="traj", task="plane", normal=0, action_space=0, reward_param=Param_Dict, reward_p=1.0, vel_d=0.6,
+                 filter_=0, control_latency=0.002, motor_kp=None, motor_kd=None, env_info=None,
                  motor_control_mode=MotorControlMode.POSITION):
         if physics is None:
             raise _lib.MetaGymHipError(
@@ -39,6 +48,15 @@ class A1GymEnv(object):
                 "package — a1/a1.urdf ships with pybullet_data and the dynamics are PyBullet's, neither is in the reference tree. "
                 "Everything around the physics (motor model, latency, ETG, sensors, reward) runs on the GPU.")
         self.num_envs, self.device, self.physics = int(num_envs), torch.device(device), physics
+        self.task = task
+        self.add_height, task_env_info, self.terrain_boxes = task_terrain(task)
+        self.env_info = task_env_info if env_info is None else env_info
+        self.default_pose = [0.0, 0.0, 0.28 + self.add_height]                      # locomotion_gym_env.py:337
+        if hasattr(physics, "set_terrain"):
+            physics.set_terrain(self.terrain_boxes, self.default_pose)
+        if ETG and ETG_w is None and len(ETG_path) > 1 and os.path.exists(ETG_path):   # MonitorEnv.py:241-244
+            saved = np.load(ETG_path)
+            ETG_w, ETG_b = saved["w"], saved["b"]
         kw = {} if motor_kp is None else dict(motor_kp=motor_kp, motor_kd=motor_kd)
         # env_builder.py:44-52: 13 sub-steps of 2 ms, no action interpolation, no command clip
         self.robot = A1Actuators(num_envs, device, time_step=0.002, action_repeat=13, control_latency=control_latency,
@@ -46,7 +64,7 @@ class A1GymEnv(object):
         self.path = EtgActionPath(num_envs, device, ETG=ETG, ETG_T=ETG_T, ETG_H=ETG_H, ETG_w=ETG_w, ETG_b=ETG_b, act_mode=act_mode,
                                   task_mode="gallop" if task == "gallop" else "normal", action_space=action_space)
         self.sensors = SensorStack(num_envs, device, normal=normal)
-        self.shaping = RewardShaping(num_envs, device, param=reward_param, reward_p=reward_p, vel_d=vel_d, env_info=env_info)
+        self.shaping = RewardShaping(num_envs, device, param=reward_param, reward_p=reward_p, vel_d=vel_d, env_info=self.env_info)
         self._lib = _lib.load()
         self.last_torques = None
         self._fusable = motor_control_mode is MotorControlMode.POSITION and motor_kp is None

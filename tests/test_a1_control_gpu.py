@@ -112,3 +112,48 @@ def test_action_filter_matches_reference(name):
         y_mask = h.filter(x0, init_mask=torch.ones(n, dtype=torch.bool)).cpu().numpy()
         f.reset(); f.init_history(x0); y_ref = f.filter(x0).cpu().numpy()
         assert np.array_equal(y_mask, y_ref)
+
+
+@pytest.mark.parametrize("task", ["stairslope", "slopeslope", "slopestair"])
+def test_reward_shaping_on_the_task_terrains(task):
+    """The reference's own `task=` terrains (metagym_amd/quadrupedal/terrain.py, up to 26 env_info stretches): robots spread
+    along the whole course, each against its own CPU checker — the stretch lookup (first match on base x + 0.2), the slope
+    handling of torso / up / feet and the never-cleared third component of the walking direction."""
+    from oracle import a1 as oa
+    from metagym_amd.quadrupedal.terrain import task_terrain
+
+    _, env_info, _ = task_terrain(task)
+    segs = [(r[0], r[1], r[2][0], r[2][1], r[2][4]) for r in env_info]
+    n, rs = 384, np.random.RandomState(5)
+    pm = dict(torso=1.0, up=0.3, feet=0.2, tau=0.1, badfoot=0.1, footcontact=0.1)
+    gpu = RewardShaping(n, DEV, param=pm, env_info=env_info)
+    cpu = [oa.RewardShaping([pm[k] for k in ("torso", "up", "feet", "tau", "badfoot", "footcontact")], segments=segs) for _ in range(n)]
+    x_end = env_info[-1][1]
+
+    def world(k):
+        base = np.stack([rs.uniform(-1.4, x_end + 0.5, n), rs.uniform(-0.2, 0.2, n), rs.uniform(0.2, 0.4, n)], 1)
+        if k:          # a plausible stride from the previous base so the velocity terms are in their active range
+            base = prev_base + np.stack([rs.uniform(-0.005, 0.03, n), rs.uniform(-0.004, 0.004, n), rs.uniform(-0.01, 0.01, n)], 1)
+        pose = rs.uniform(-0.3, 0.3, (n, 3))
+        rot = np.tile(np.eye(3).reshape(-1), (n, 1)) + rs.uniform(-0.05, 0.05, (n, 9))
+        foot = np.tile([0.18, -0.13, -0.27, 0.18, 0.13, -0.27, -0.18, -0.13, -0.27, -0.18, 0.13, -0.27], (n, 1)) + rs.uniform(-0.03, 0.03, (n, 12))
+        return base, pose, rot, foot, (rs.rand(n, 4) < 0.7).astype(np.float64), rs.uniform(0, 3, n), rs.randint(0, 3, n)
+
+    base, pose, rot, foot, *_ = world(0)
+    prev_base = base
+    gpu.reset(torch.as_tensor(base, device=DEV), torch.as_tensor(rot, device=DEV), torch.as_tensor(foot, device=DEV))
+    for i in range(n):
+        cpu[i].reset(base[i], rot[i], foot[i].reshape(4, 3))
+    slopes_seen = 0
+    for k in range(1, 6):
+        base, pose, rot, foot, contact, energy, bad = world(k)
+        prev_base = base
+        reward, done, terms = gpu.step(*(torch.as_tensor(a, device=DEV) for a in (base, pose, rot, foot, contact, energy)),
+                                       torch.as_tensor(bad, dtype=torch.int32, device=DEV))
+        got = np.stack([terms[t].cpu().numpy() for t in ("torso", "up", "feet", "tau", "badfoot", "footcontact")], 1)
+        for i in range(n):
+            w_terms, w_reward, w_done = cpu[i].step(base[i], pose[i], rot[i], foot[i].reshape(4, 3), contact[i], energy[i], int(bad[i]))
+            assert np.allclose(got[i], w_terms, **TOL), "%s robot %d step %d at x=%.3f" % (task, i, k, base[i, 0])
+            assert np.allclose(reward[i].item(), w_reward, **TOL) and bool(done[i].item()) == w_done
+            slopes_seen += int(any(cpu[i].env_vec(base[i, 0])[:2]))
+    assert slopes_seen > n // 4 or task == "stairstair"

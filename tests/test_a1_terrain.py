@@ -1,0 +1,60 @@
+"""metagym_amd/quadrupedal/terrain.py against the unmodified reference terrain builder run on a recording PyBullet
+(tests/golden/a1_terrain.npz, oracle/gen_golden_a1_terrain.py): every box the reference would create (half extents,
+position, orientation, final lateral friction), add_height and env_info, bit for bit — the eight `task=` terrains, the
+hardset modes, and the random modes under the reference's np.random draws."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from metagym_amd.quadrupedal import terrain
+
+GOLD = np.load(os.path.join(os.path.dirname(__file__), "golden", "a1_terrain.npz"))
+CASES = json.loads(str(GOLD["cases"]))
+
+
+def _same_bits(a, b):
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    return a.shape == b.shape and np.array_equal(a.view(np.uint64), b.view(np.uint64))
+
+
+def _flatten(add_height, env_info, boxes):
+    rows = np.array([[r[0], r[1]] + [float(x) for x in r[2]] for r in env_info], dtype=np.float64).reshape(len(env_info), 9)
+    bodies = np.array([list(b.half_extents) + list(b.position) + list(b.quaternion) + [b.friction] for b in boxes],
+                      dtype=np.float64).reshape(len(boxes), 11)
+    return float(add_height), rows, bodies
+
+
+@pytest.mark.parametrize("case", CASES, ids=[c["name"] for c in CASES])
+def test_terrain_matches_reference(case):
+    name, kw = case["name"], dict(case["kwargs"])
+    if name.startswith("task:"):
+        out = terrain.task_terrain(name[5:])
+    else:
+        rng = np.random.RandomState(case["seed"]) if case["seed"] is not None else np.random
+        out = terrain.upstair_terrain(rng=rng, **kw)
+    add_height, rows, bodies = _flatten(*out)
+    want = GOLD[name + "/bodies"].copy()
+    untouched = np.isnan(want[:, 10])                 # the reference never set a friction on these: Bullet's default
+    want[untouched, 10] = terrain.DEFAULT_FRICTION
+    assert _same_bits(add_height, GOLD[name + "/add_height"])
+    assert _same_bits(rows, GOLD[name + "/env_info"])
+    assert _same_bits(bodies, want)
+    if name == "task:balancebeam":
+        assert untouched.tolist() == [False, True, False]          # the slip at terrain.py:254-258 is kept
+
+
+def test_every_task_fits_the_reward_kernel_and_plane_is_the_constructor_default():
+    from metagym_amd import _lib
+    for task in terrain.TASKS:
+        add_height, env_info, boxes = terrain.task_terrain(task)
+        assert len(env_info) <= _lib.A1_MAX_SEGMENTS
+    add_height, env_info, boxes = terrain.task_terrain("plane")
+    assert add_height == 0 and boxes == [] and env_info[0][:2] == [-100, 100] and list(env_info[0][2]) == [1, 0, 0, 0, 0, 0, 0]
+
+
+def test_random_modes_follow_the_reference_draw_order_on_the_global_stream():
+    np.random.seed(100)
+    a = _flatten(*terrain.upstair_terrain(mode="random"))
+    assert _same_bits(a[2], GOLD["random:random:0/bodies"])
