@@ -617,6 +617,18 @@ int mg_a1_observation(const mg_a1_sensor_config *cfg, int32_t n_envs, const mg_a
                       const double *rpy, const double *drpy, const double *motor_angles, const double *contact,
                       const uint8_t *reset_mask, double *obs, void *stream);
 
+/* ObservationWrapper (envs/env_wrappers/MonitorEnv.py:77-221): the entries it appends to the sensor observation, in its
+ * order. flags: MG_A1_EXTRA_ETG = info["ETG_act"] (12; (x - ETG_mean) / ETG_std of :89-94 when `normal`),
+ * MG_A1_EXTRA_ETG_OBS = info["ETG_obs"] (etg_h), MG_A1_EXTRA_YAW = cos / sin(d_yaw - yaw) (:204-211; d_yaw [N] or NULL = 0).
+ * etg_act: DEVICE f64 [12][N] (ETGWrapper.last_ETG_act), etg_obs: [etg_h][N], pose: [3][N] (roll, pitch, yaw).
+ * out: DEVICE f64 [N][width], width = 12 * ETG + etg_h * ETG_OBS + 2 * YAW. (force_vec / dynamic_vec come from the
+ * caller's physics and the RNN stacking is a copy: neither needs a kernel.) */
+#define MG_A1_EXTRA_ETG 1
+#define MG_A1_EXTRA_ETG_OBS 2
+#define MG_A1_EXTRA_YAW 4
+int mg_a1_observation_extras(int32_t n_envs, int32_t flags, int32_t normal, int32_t etg_h, const double *etg_act,
+                             const double *etg_obs, const double *pose, const double *d_yaw, double *out, void *stream);
+
 /* ActionFilter.filter / init_history / reset (quadrupedal/robots/action_filter.py:70-99), as Minitaur._FilterAction uses it
  * on the policy's motor commands (minitaur.py:1438-1457): per joint
  *   y = x b0 + sum_k xhist[k] b[k+1] - sum_k yhist[k] a[k+1],   history depth = order (low-pass) or 2 order (band-pass).

@@ -154,6 +154,7 @@ class A1ActuatorState(C.Structure):
 
 
 A1_ETG_MAX_H, A1_MAX_SEGMENTS = 32, 32
+A1_EXTRA_ETG, A1_EXTRA_ETG_OBS, A1_EXTRA_YAW = 1, 2, 4
 
 
 class A1EtgConfig(C.Structure):
@@ -249,6 +250,7 @@ SIGNATURES = {
     "mg_a1_reward_reset": (C.c_int, [C.POINTER(A1RewardConfig), C.c_int32, C.POINTER(A1RewardState), _P, _P, _P, _P, _P]),
     "mg_a1_observation": (C.c_int, [C.POINTER(A1SensorConfig), C.c_int32, C.POINTER(A1SensorState), _P, _P, _P, _P, _P, _P,
                                     _P, _P]),
+    "mg_a1_observation_extras": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P, _P, _P, _P]),
     "mg_a1_action_filter": (C.c_int, [C.POINTER(A1FilterConfig), C.c_int32, _P, _P, _P, _P, _P, C.c_int32, _P]),
     "mg_a1_reward_step": (C.c_int, [C.POINTER(A1RewardConfig), C.c_int32, C.POINTER(A1RewardState), _P, _P, _P, _P, _P,
                                     _P, _P, _P, _P, _P, _P, _P]),

@@ -628,6 +628,38 @@ int check_a1(const mg_a1_actuator_config *cfg, const mg_a1_actuator_state *st, i
     return MG_OK;
 }
 
+
+// ---- ObservationWrapper (MonitorEnv.py:77-221): the entries it appends to the sensor observation ---------------------
+__global__ __launch_bounds__(A1_BLOCK) void a1_obs_extras_kernel(int n, int flags, int normal, int H, const double *etg_act,
+                                                                 const double *etg_obs, const double *pose, const double *d_yaw,
+                                                                 double *out, int width) {
+    const int i = blockIdx.x * A1_BLOCK + threadIdx.x;
+    if (i >= n) return;
+    // :89-94
+    const double mean[NM] = {2.1505982e-02, 3.6674485e-02, -6.0444288e-02, 2.4625482e-02, 1.5869144e-02, -3.2513142e-02,
+                             2.1506395e-02, 3.1869926e-02, -6.0140789e-02, 2.4625063e-02, 1.1628972e-02, -3.2163858e-02};
+    const double sd[NM] = {4.5967497e-02, 2.0340437e-01, 3.7410179e-01, 4.6187632e-02, 1.9441207e-01, 3.9488649e-01,
+                           4.5966785e-02, 2.0323379e-01, 3.7382501e-01, 4.6188373e-02, 1.9457331e-01, 3.9302582e-01};
+    double *o = out + (size_t)i * width;
+    if (flags & MG_A1_EXTRA_ETG) {                                                   // :186-190
+#pragma unroll
+        for (int j = 0; j < NM; ++j) {
+            const double a = etg_act[(size_t)j * n + i];
+            o[j] = normal ? (a - mean[j]) / sd[j] : a;
+        }
+        o += NM;
+    }
+    if (flags & MG_A1_EXTRA_ETG_OBS) {                                               // :192-194
+        for (int h = 0; h < H; ++h) o[h] = etg_obs[(size_t)h * n + i];
+        o += H;
+    }
+    if (flags & MG_A1_EXTRA_YAW) {                                                   // :204-211
+        const double d = (d_yaw ? d_yaw[i] : 0.0) - pose[(size_t)2 * n + i];
+        o[0] = cos(d);
+        o[1] = sin(d);
+    }
+}
+
 }  // namespace
 
 extern "C" int mg_a1_apply_action(const mg_a1_actuator_config *cfg, int32_t n, const mg_a1_actuator_state *st,
@@ -749,6 +781,25 @@ extern "C" int mg_a1_observation(const mg_a1_sensor_config *cfg, int32_t n, cons
     hipLaunchKernelGGL(a1_observation_kernel, dim3((n + A1_BLOCK - 1) / A1_BLOCK), dim3(A1_BLOCK), 0, (hipStream_t)stream, *cfg,
                        *st, n, base, rpy, drpy, motor_angles, contact, reset_mask, obs);
     return mg::check_launch("a1_observation_kernel");
+}
+
+extern "C" int mg_a1_observation_extras(int32_t n, int32_t flags, int32_t normal, int32_t etg_h, const double *etg_act,
+                                        const double *etg_obs, const double *pose, const double *d_yaw, double *out,
+                                        void *stream) {
+    if (n <= 0) return mg::set_error(MG_ERR_BAD_SIZE, "n_envs=%d", n);
+    if (flags <= 0 || (flags & ~(MG_A1_EXTRA_ETG | MG_A1_EXTRA_ETG_OBS | MG_A1_EXTRA_YAW)))
+        return mg::set_error(MG_ERR_BAD_CONFIG, "mg_a1_observation_extras: flags=0x%x", flags);
+    if ((flags & MG_A1_EXTRA_ETG_OBS) && (etg_h < 1 || etg_h > MG_A1_ETG_MAX_H))
+        return mg::set_error(MG_ERR_BAD_SIZE, "mg_a1_observation_extras: etg_h=%d (1..%d)", etg_h, MG_A1_ETG_MAX_H);
+    if ((flags & MG_A1_EXTRA_ETG) && !etg_act) return mg::set_error(MG_ERR_NULL_POINTER, "mg_a1_observation_extras: etg_act is NULL");
+    if ((flags & MG_A1_EXTRA_ETG_OBS) && !etg_obs) return mg::set_error(MG_ERR_NULL_POINTER, "mg_a1_observation_extras: etg_obs is NULL");
+    if ((flags & MG_A1_EXTRA_YAW) && !pose) return mg::set_error(MG_ERR_NULL_POINTER, "mg_a1_observation_extras: pose is NULL");
+    MG_REQUIRE_PTR(out);
+    const int width = ((flags & MG_A1_EXTRA_ETG) ? 12 : 0) + ((flags & MG_A1_EXTRA_ETG_OBS) ? etg_h : 0) + ((flags & MG_A1_EXTRA_YAW) ? 2 : 0);
+    mg::DeviceGuard guard(mg::device_of(out));
+    hipLaunchKernelGGL(a1_obs_extras_kernel, dim3((n + A1_BLOCK - 1) / A1_BLOCK), dim3(A1_BLOCK), 0, (hipStream_t)stream, n, flags,
+                       normal, etg_h, etg_act, etg_obs, pose, d_yaw, out, width);
+    return mg::check_launch("a1_obs_extras_kernel");
 }
 
 extern "C" int mg_a1_action_filter(const mg_a1_filter_config *cfg, int32_t n, double *xhist, double *yhist, const double *x,

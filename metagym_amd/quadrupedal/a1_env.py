@@ -37,11 +37,14 @@ from .a1_wrappers import EtgActionPath, Param_Dict, RewardShaping, SensorStack
 from .terrain import task_terrain
 
 
+SENSOR_MODE = {"dis": 1, "motor": 1, "imu": 1, "contact": 1, "footpose": 0, "ETG": 0}      # a1_gym_env.py:13
+
+
 class A1GymEnv(object):
     def __init__(self, num_envs, physics, device="cuda:0", ETG=0, ETG_T=0.5, ETG_H=20, ETG_path="", ETG_w=None, ETG_b=None,
                  act_mode="traj", task="plane", normal=0, action_space=0, reward_param=Param_Dict, reward_p=1.0, vel_d=0.6,
                  filter_=0, control_latency=0.002, motor_kp=None, motor_kd=None, env_info=None,
-                 motor_control_mode=MotorControlMode.POSITION):
+                 motor_control_mode=MotorControlMode.POSITION, sensor_mode=SENSOR_MODE):
         if physics is None:
             raise _lib.MetaGymHipError(
                 "quadrupedal-v0 needs a `physics` object (see metagym_amd/quadrupedal/a1_env.py): the A1 body is not part of this "
@@ -68,6 +71,58 @@ class A1GymEnv(object):
         self._lib = _lib.load()
         self.last_torques = None
         self._fusable = motor_control_mode is MotorControlMode.POSITION and motor_kp is None
+        self._configure_observation(dict(sensor_mode), bool(ETG), int(ETG_H), int(normal))
+
+    def _configure_observation(self, mode, etg, etg_h, normal):
+        """env_builder.py:62-80 picks the sensors from `sensor_mode`, ObservationWrapper (MonitorEnv.py:77-221) appends to
+        their observation. The sensor stack here is the default one; the wrapper's own entries are all there except the two
+        that come out of PyBullet-side randomisation (force_vec, dynamic_vec)."""
+        if not (mode.get("dis") == 1 and mode.get("imu") == 1 and mode.get("motor") == 1 and mode.get("contact") == 1) \
+                or mode.get("footpose") or mode.get("noise"):
+            raise _lib.MetaGymHipError("sensor_mode %r: only the default sensor stack (dis / imu / motor / contact = 1, no footpose, "
+                                       "no noise) is built on the device" % (mode,))
+        for key in ("force_vec", "dynamic_vec"):
+            if mode.get(key):
+                raise _lib.MetaGymHipError("sensor_mode[%r] reads the reference's PyBullet-side randomisation (RandomWrapper / "
+                                           "LocomotionGymEnv dynamics); append your physics' own vector to the observation" % key)
+        self._extras = ((_lib.A1_EXTRA_ETG if etg and mode.get("ETG") else 0) | (_lib.A1_EXTRA_ETG_OBS if etg and mode.get("ETG_obs") else 0)
+                        | (_lib.A1_EXTRA_YAW if mode.get("yaw") else 0))
+        self._etg_h, self._normal = etg_h, normal
+        width = _lib.A1_SENSOR_OBS_DIM + (12 if self._extras & _lib.A1_EXTRA_ETG else 0) \
+            + (etg_h if self._extras & _lib.A1_EXTRA_ETG_OBS else 0) + (2 if self._extras & _lib.A1_EXTRA_YAW else 0)
+        rnn = mode.get("RNN")
+        self._rnn = None
+        if rnn and rnn["time_steps"] > 0:                                              # MonitorEnv.py:126-134
+            assert rnn["mode"] in ("stack", "GRU")
+            self._rnn = (int(rnn["time_steps"]), int(rnn["time_interval"]), rnn["mode"])
+            self._obs_history = torch.zeros(self._rnn[0] * self._rnn[1], self.num_envs, width, dtype=torch.float64, device=self.device)
+        self.observation_width = width
+
+    def _wrap_observation(self, obs, pose, etg_obs, d_yaw, on_reset):
+        """ObservationWrapper.reset (MonitorEnv.py:136-179) / step (:181-221) on the sensor observation `[N, 37]`."""
+        N, d = self.num_envs, self.device
+        if self._extras:
+            extra = torch.empty(N, self.observation_width - _lib.A1_SENSOR_OBS_DIM, dtype=torch.float64, device=d)
+            p = pose.t().contiguous()
+            eo = None if etg_obs is None else etg_obs.t().contiguous()
+            dy = None if d_yaw is None else torch.as_tensor(d_yaw, dtype=torch.float64, device=d).expand(N).contiguous()
+            with torch.cuda.device(d):
+                rc = self._lib.mg_a1_observation_extras(N, self._extras, self._normal, self._etg_h, _lib.ptr(self.path.last_ETG_act),
+                                                        _lib.ptr(eo), _lib.ptr(p), _lib.ptr(dy), _lib.ptr(extra), _lib.current_stream(d))
+            _lib.check(rc, "mg_a1_observation_extras")
+            obs = torch.cat([obs, extra], dim=1)
+        if self._rnn is not None:
+            steps, interval, mode = self._rnn
+            if on_reset:
+                self._obs_history.zero_()
+            frames = [self._obs_history[t * interval].clone() for t in range(steps)] + [obs]
+            if not on_reset:
+                self._obs_history[:-1] = self._obs_history[1:].clone()
+            self._obs_history[-1] = obs
+            obs = torch.stack(frames, dim=1)                                           # [N, steps + 1, width] ("GRU")
+            if mode == "stack":
+                obs = obs.reshape(N, -1)
+        return obs
 
     def get_time_since_reset(self):
         return self.robot.GetTimeSinceReset()
@@ -84,7 +139,7 @@ class A1GymEnv(object):
         _lib.check(rc, "mg_a1_info")
         return {k: (v if v.dim() == 1 else v.t()) for k, v in o.items()}
 
-    def _env_step(self, action, reset_mask=None):
+    def _env_step(self, action, reset_mask=None, d_yaw=None):
         """LocomotionGymEnv.step below the wrappers (locomotion_gym_env.py:461-546)."""
         cmd, etg_obs = self.path.step(action, self.get_time_since_reset())
         if hasattr(self.physics, "fused_step") and self._fusable:      # 13 sub-steps + PD model inside one physics launch
@@ -95,25 +150,27 @@ class A1GymEnv(object):
         info.update(base=world["base"], real_contact=world["contact"], bad=world["bad"], real_action=cmd, ETG_obs=etg_obs,
                     ETG_act=self.path.last_ETG_act.t())
         obs = self.sensors.observe(world["base"], info["pose"], info["drpy"], info["joint_angle"], world["contact"], reset_mask)
-        return obs, info
+        return self._wrap_observation(obs, info["pose"], etg_obs, d_yaw, False), info
 
-    def reset(self):
+    def reset(self, d_yaw=None):
         """A1GymEnv.reset(): robot.Reset and one observation, sensors reset, ETGWrapper.reset, then the hidden zero-action step
-        of RewardShaping.reset (MonitorEnv.py:305-318) whose observation is the one returned."""
+        of RewardShaping.reset (MonitorEnv.py:305-318) whose observation is the one returned. `d_yaw` only reaches
+        ObservationWrapper.reset (the first frame of an RNN history): the hidden step runs without it."""
         N, d = self.num_envs, self.device
         self.robot.Reset()
         self.robot.ReceiveObservation(*self.physics.reset(None))
         world, info = self.physics.world(), self._info()
         every = torch.ones(N, dtype=torch.bool, device=d)
-        self.sensors.observe(world["base"], info["pose"], info["drpy"], info["joint_angle"], world["contact"], every)
-        self.path.reset(self.get_time_since_reset())
+        obs0 = self.sensors.observe(world["base"], info["pose"], info["drpy"], info["joint_angle"], world["contact"], every)
+        etg_obs0 = self.path.reset(self.get_time_since_reset())
+        self._wrap_observation(obs0, info["pose"], etg_obs0, d_yaw, True)
         obs, _ = self._env_step(torch.zeros(N, 12, dtype=torch.float64, device=d))
         self.shaping.reset(world["base"], info["rot_mat"], info["footposition"])
         info.update(base=world["base"], real_contact=world["contact"])
         return obs, info
 
     def step(self, action, d_yaw=None):
-        obs, info = self._env_step(action)
+        obs, info = self._env_step(action, d_yaw=d_yaw)
         reward, done, terms = self.shaping.step(info["base"], info["pose"], info["rot_mat"], info["footposition"],
                                                 info["real_contact"], info["energy"], info["bad"], d_yaw)
         info.update(terms)

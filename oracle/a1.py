@@ -398,13 +398,44 @@ class A1Env(object):
     """The composition `A1GymEnv.reset / step` performs (envs/gym_envs/a1_gym_env.py, env_builder.py, MonitorEnv.py:14-25)
     around a physics the caller supplies as recorded world states. One robot. Pinned by tests/golden/a1_env.npz."""
 
-    def __init__(self, w, b, etg=True, normal=0, control_latency=0.002, action_filter=None):
+    ETG_MEAN = np.array([2.1505982e-02, 3.6674485e-02, -6.0444288e-02, 2.4625482e-02, 1.5869144e-02, -3.2513142e-02,     # MonitorEnv.py:89-94
+                         2.1506395e-02, 3.1869926e-02, -6.0140789e-02, 2.4625063e-02, 1.1628972e-02, -3.2163858e-02])
+    ETG_STD = np.array([4.5967497e-02, 2.0340437e-01, 3.7410179e-01, 4.6187632e-02, 1.9441207e-01, 3.9488649e-01,
+                        4.5966785e-02, 2.0323379e-01, 3.7382501e-01, 4.6188373e-02, 1.9457331e-01, 3.9302582e-01])
+
+    def __init__(self, w, b, etg=True, normal=0, control_latency=0.002, action_filter=None, segments=None, sensor_mode=None):
         self.filter = action_filter                                                # Minitaur._BuildActionFilter minitaur.py:1438-1443
         self.path = EtgActionPath(w, b, enabled=etg)
         self.act = A1Actuation(1, control_latency=control_latency)                # POSITION, kp/kd of a1.py:63-68
         self.sensors = SensorStack(normal)
-        self.shaping = RewardShaping([1.0, 0.3, 0.2, 0.1, 0.1, 0.1])               # Param_Dict MonitorEnv.py:12
+        kw = {} if segments is None else dict(segments=segments)                  # info["env_info"] of the task's terrain
+        self.shaping = RewardShaping([1.0, 0.3, 0.2, 0.1, 0.1, 0.1], **kw)        # Param_Dict MonitorEnv.py:12
         self.substeps = 0
+        self.etg, self.normal, self.mode = etg, normal, dict(sensor_mode or {})
+        rnn = self.mode.get("RNN")
+        self.rnn = (rnn["time_steps"], rnn["time_interval"], rnn["mode"]) if rnn and rnn["time_steps"] > 0 else None
+
+    def wrap_observation(self, obs, yaw, etg_obs, d_yaw, on_reset):
+        """ObservationWrapper.reset :136-179 / step :181-221."""
+        if self.etg and self.mode.get("ETG"):
+            out = self.path.last_etg_act
+            if self.normal:
+                out = (out - self.ETG_MEAN) / self.ETG_STD
+            obs = np.concatenate((obs, out), axis=0)
+        if self.etg and self.mode.get("ETG_obs"):
+            obs = np.concatenate((obs, etg_obs), axis=0)
+        if self.mode.get("yaw"):
+            obs = np.concatenate((obs, np.array([np.cos(d_yaw - yaw), np.sin(d_yaw - yaw)])), axis=0)
+        if self.rnn:
+            steps, interval, mode = self.rnn
+            if on_reset:
+                self.obs_history = np.zeros((steps * interval, obs.shape[0]))
+            frames = [self.obs_history[t * interval].copy() for t in range(steps)] + [obs.copy()]
+            if not on_reset:
+                self.obs_history[:-1] = self.obs_history[1:].copy()
+            self.obs_history[-1] = obs
+            obs = np.stack(frames, axis=0) if mode == "GRU" else np.array(frames).reshape(-1)
+        return obs
 
     def time_since_reset(self):
         return self.substeps * 0.002                                               # GetTimeSinceReset minitaur.py:228-230
@@ -430,7 +461,7 @@ class A1Env(object):
         ang, vel, tor, rate, energy = self.act.sensors()
         return dict(footposition=foot_positions_in_base_frame(ang[0]), joint_angle=ang[0], drpy=rate[0], energy=energy[0])
 
-    def reset(self, reset_true_obs, reset_world, hidden_true_obs, hidden_world):
+    def reset(self, reset_true_obs, reset_world, hidden_true_obs, hidden_world, d_yaw=0):
         """A1GymEnv.reset(): LocomotionGymEnv.reset (robot.Reset: history cleared, one observation; sensors reset),
         ETGWrapper.reset, then RewardShaping.reset's hidden zero-action step (MonitorEnv.py:305-318).
         Returns (the hidden step's command, torques, the observation reset() returns)."""
@@ -440,22 +471,24 @@ class A1Env(object):
         t = reset_true_obs
         self.act.receive_observation(t[None, 0:12], t[None, 12:24], t[None, 36:40], t[None, 40:43])
         inf = self.info(reset_world)
-        self.sensors.observe(reset_world["base"], reset_world["pose"], inf["drpy"], inf["joint_angle"], reset_world["contact"], True)
-        self.path.reset(self.time_since_reset())
+        obs0 = self.sensors.observe(reset_world["base"], reset_world["pose"], inf["drpy"], inf["joint_angle"], reset_world["contact"], True)
+        etg_obs0 = self.path.reset(self.time_since_reset())
+        self.wrap_observation(obs0, reset_world["pose"][-1], etg_obs0, d_yaw, True)
         cmd, torques, obs, _ = self._step(np.zeros(12), hidden_true_obs, hidden_world, shaped=False)
         self.shaping.reset(reset_world["base"], reset_world["rot_mat"], inf["footposition"])
         return cmd, torques, obs
 
-    def _step(self, action, true_obs, world, shaped=True):
-        cmd, _ = self.path.step(action, self.time_since_reset())
+    def _step(self, action, true_obs, world, shaped=True, d_yaw=0):
+        cmd, etg_obs = self.path.step(action, self.time_since_reset())
         torques = self.robot_step(cmd, true_obs)
         inf = self.info(world)
         obs = self.sensors.observe(world["base"], world["pose"], inf["drpy"], inf["joint_angle"], world["contact"], False)
+        obs = self.wrap_observation(obs, world["pose"][-1], etg_obs, d_yaw, False)
         out = None
         if shaped:
             out = self.shaping.step(world["base"], world["pose"], world["rot_mat"], inf["footposition"], world["contact"],
-                                    inf["energy"], world["bad"])
+                                    inf["energy"], world["bad"], d_yaw)
         return cmd, torques, obs, (out, inf)
 
-    def step(self, action, true_obs, world):
-        return self._step(action, true_obs, world)
+    def step(self, action, true_obs, world, d_yaw=0):
+        return self._step(action, true_obs, world, d_yaw=d_yaw)

@@ -21,6 +21,7 @@ Recorded per step: policy action, motor command reaching robot.Step, the 13 x 12
 done, the reward terms, and the world inputs."""
 import collections
 import collections.abc
+import json
 import os
 import sys
 
@@ -61,7 +62,9 @@ class ScriptedWorld(ga.ScriptedBullet):
     def removeUserDebugItem(self, i): pass
     def removeAllUserDebugItems(self): pass
     def loadURDF(self, path, *a, **k): return 0 if "plane" in str(path) else 1
-    def resetBasePositionAndOrientation(self, body, pos, orn): self.base_pos = list(pos)
+    def resetBasePositionAndOrientation(self, body, pos, orn):
+        self.base_pos = list(pos)
+        self.base_pos_at_reset = list(pos)
     def getMatrixFromQuaternion(self, q):
         x, y, z, w = q
         return (1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y), 2 * (x * y + w * z), 1 - 2 * (x * x + z * z),
@@ -93,9 +96,23 @@ def main():
     cases = [dict(name="env_etg_traj", seed=1, ETG=1, wscale=0.04, n_steps=25, normal=0),
              dict(name="env_plain", seed=2, ETG=0, wscale=0.0, n_steps=20, normal=1),
              dict(name="env_latency", seed=3, ETG=1, wscale=0.05, n_steps=20, normal=0, dynamic_param={"control_latency": 13.7}),
-             dict(name="env_action_filter", seed=4, ETG=1, wscale=0.04, n_steps=20, normal=0, filter_=1)]
+             dict(name="env_action_filter", seed=4, ETG=1, wscale=0.04, n_steps=20, normal=0, filter_=1),
+             # task terrains: env_info comes from the reference's own terrain builder (its pybullet calls go to a recorder)
+             # and the scripted base runs fast enough to cross flat / up-slope / flat / down-slope stretches
+             dict(name="env_slopeslope", seed=5, ETG=1, wscale=0.04, n_steps=40, normal=0, task="slopeslope", v_base=[2.6, 0.02, 0.0]),
+             dict(name="env_slopestair", seed=6, ETG=0, wscale=0.0, n_steps=40, normal=0, task="slopestair", v_base=[3.4, -0.01, 0.0]),
+             # ObservationWrapper's own entries (MonitorEnv.py:136-221): ETG output (normalised), ETG_obs, yaw target, RNN frames
+             dict(name="env_obs_extras_stack", seed=7, ETG=1, wscale=0.04, n_steps=16, normal=1, d_yaw=0.3,
+                  sensor_mode={"ETG": 1, "ETG_obs": 1, "yaw": 1, "RNN": {"time_steps": 2, "time_interval": 3, "mode": "stack"}}),
+             dict(name="env_obs_extras_gru", seed=8, ETG=1, wscale=0.04, n_steps=10, normal=0, d_yaw=-0.2,
+                  sensor_mode={"ETG": 1, "yaw": 1, "RNN": {"time_steps": 3, "time_interval": 1, "mode": "GRU"}})]
+    from metagym.quadrupedal.envs.utilities import terrain
+    from gen_golden_a1_terrain import Recorder
     for c in cases:
         world = ScriptedWorld(c["seed"])
+        if "v_base" in c:
+            world.v_base = np.array(c["v_base"], dtype=np.float64)
+        terrain.p = Recorder()
         bullet_client.BulletClient = lambda connection_mode=None, w=world: w
         rs = np.random.RandomState(100 + c["seed"])
         H = 20
@@ -153,11 +170,14 @@ def main():
         locomotion_gym_env.LocomotionGymEnv.reset, locomotion_gym_env.LocomotionGymEnv.step = lreset, lstep
         try:
             env = a1_gym_env.A1GymEnv(ETG=c["ETG"], ETG_path=path, normal=c["normal"], dynamic_param=c.get("dynamic_param", {}),
-                                      filter_=c.get("filter_", 0),
-                                      sensor_mode={"dis": 1, "motor": 1, "imu": 1, "contact": 1, "footpose": 0, "ETG": 0})
+                                      filter_=c.get("filter_", 0), task=c.get("task", "plane"),
+                                      sensor_mode=dict({"dis": 1, "motor": 1, "imu": 1, "contact": 1, "footpose": 0, "ETG": 0},
+                                                       **c.get("sensor_mode", {})))
             n_before_reset = len(rec["all_true_obs"])
             live["on"] = True
-            obs, info = env.reset()
+            step_kw = {"d_yaw": c["d_yaw"]} if "d_yaw" in c else {}
+            obs, info = env.reset(**step_kw)
+            rec["reset_pose_z"].append(world.base_pos_at_reset[2])
             rec["reset_obs"].append(np.array(obs, dtype=np.float64))
             rec["n_true_obs_before_reset"].append(n_before_reset)
             rec["n_true_obs_after_reset"].append(len(rec["all_true_obs"]))
@@ -166,7 +186,7 @@ def main():
                 action = rs.uniform(-0.3, 0.3, 12)
                 rec["action"].append(action)
                 rec["t"].append(env.get_time_since_reset())
-                obs, reward, done, info = env.step(action)
+                obs, reward, done, info = env.step(action, **step_kw)
                 rec["obs"].append(np.array(obs, dtype=np.float64))
                 rec["reward"].append(float(reward))
                 rec["done"].append(bool(done))
@@ -182,6 +202,7 @@ def main():
         for k2, v in rec.items():
             out[c["name"] + "/" + k2] = np.array(v)
         out[c["name"] + "/w"], out[c["name"] + "/b"] = w, b
+        out[c["name"] + "/spec"] = np.array(json.dumps({k: c[k] for k in ("task", "sensor_mode", "d_yaw") if k in c}))
         out[c["name"] + "/config"] = np.array([c["ETG"], c["normal"], c.get("dynamic_param", {}).get("control_latency", -1.0),
                                                c.get("filter_", 0)], dtype=np.float64)
         print(c["name"], "steps", len(rec["obs"]), "obs dim", np.array(rec["obs"]).shape, "dones", int(np.sum(rec["done"])),

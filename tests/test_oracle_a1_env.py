@@ -2,6 +2,7 @@
 running on a scripted Bullet client (tests/golden/a1_env.npz, oracle/gen_golden_a1_env.py): motor commands reaching
 robot.Step, all 13 x 12 torques per step, the 37-entry observation, the six reward terms, reward and done — for reset()
 (with its hidden zero-action step) and every step()."""
+import json
 import os
 
 import numpy as np
@@ -24,22 +25,31 @@ def make_env(g, name):
         from scipy.signal import butter                      # the reference's own source of coefficients (action_filter.py:182-185)
         bb, aa = butter(2, [4.0 / (0.5 * (1 / (0.002 * 13)))], btype="low")
         flt = oa.ActionFilter(np.tile(aa / aa[0], (12, 1)), np.tile(bb / aa[0], (12, 1)))
-    return oa.A1Env(g[name + "/w"], g[name + "/b"], bool(etg), int(normal), 0.002 if lat_ms < 0 else 0.001 * lat_ms, flt)
+    spec = json.loads(str(g[name + "/spec"]))
+    segments = None
+    if "task" in spec:      # the task's terrain stretches (the product's restatement of terrain.py, itself pinned by a1_terrain.npz)
+        from metagym_amd.quadrupedal.terrain import task_terrain
+        add_height, env_info, _ = task_terrain(spec["task"])
+        assert 0.28 + add_height == g[name + "/reset_pose_z"][0]                 # locomotion_gym_env.py:337
+        segments = [(r[0], r[1], r[2][0], r[2][1], r[2][4]) for r in env_info]
+    env = oa.A1Env(g[name + "/w"], g[name + "/b"], bool(etg), int(normal), 0.002 if lat_ms < 0 else 0.001 * lat_ms, flt,
+                   segments=segments, sensor_mode=spec.get("sensor_mode"))
+    return env, spec.get("d_yaw", 0)
 
 
-@pytest.mark.parametrize("idx", range(4))
+@pytest.mark.parametrize("idx", range(8))
 def test_composed_env_matches_reference(idx):
     g = np.load(GOLDEN)
     name = str(g["cases"][idx])
-    env = make_env(g, name)
+    env, d_yaw = make_env(g, name)
     assert list(g[name + "/loco_kind"][:2]) == [0, 1]               # reset info, then the hidden step's
-    cmd, torques, obs = env.reset(g[name + "/reset_true_obs"][0], world(g, name, 0), g[name + "/true_obs"][0], world(g, name, 1))
+    cmd, torques, obs = env.reset(g[name + "/reset_true_obs"][0], world(g, name, 0), g[name + "/true_obs"][0], world(g, name, 1), d_yaw)
     assert np.array_equal(cmd, g[name + "/command"][0])      # (the command handed to robot.Step, before its own filter)
     assert np.array_equal(torques, g[name + "/torques"][0])
     assert np.array_equal(obs, g[name + "/reset_obs"][0])
     for k in range(len(g[name + "/action"])):
         assert env.time_since_reset() == g[name + "/t"][k]
-        cmd, torques, obs, (shaped, inf) = env.step(g[name + "/action"][k], g[name + "/true_obs"][k + 1], world(g, name, k + 2))
+        cmd, torques, obs, (shaped, inf) = env.step(g[name + "/action"][k], g[name + "/true_obs"][k + 1], world(g, name, k + 2), d_yaw)
         if env.filter is None:      # (with the robot-level filter, robot.Step records the UNFILTERED command; the torques below see it)
             assert np.array_equal(cmd, g[name + "/command"][k + 1]), "%s command, step %d" % (name, k)
         assert np.array_equal(torques, g[name + "/torques"][k + 1]), "%s torques, step %d" % (name, k)
