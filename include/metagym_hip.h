@@ -370,6 +370,8 @@ typedef struct mg_walker_models {
     int32_t n_tasks, model_stride;
 } mg_walker_models;
 
+#define MG_WALKER_BOX_DOUBLES 16
+
 typedef struct mg_walker_params {
     double time_step;          /* 0.005  walker_base_env.py:7 */
     int32_t frame_skip;        /* 4      sub-steps per env step */
@@ -418,6 +420,14 @@ typedef struct mg_walker_params {
     double pd_kp[MG_WALKER_MAX_JOINTS], pd_kd[MG_WALKER_MAX_JOINTS], pd_strength[MG_WALKER_MAX_JOINTS],
         pd_limit[MG_WALKER_MAX_JOINTS];
     double *substep_log;
+    /* Static terrain on top of the ground plane (wave mapping only): n_terrain_boxes oriented boxes shared by every env —
+     * what the quadrupedal tasks build in their Bullet world (quadrupedal/envs/utilities/terrain.py; the box lists come from
+     * metagym_amd/quadrupedal/terrain.py). terrain: DEVICE f64 [n_terrain_boxes][MG_WALKER_BOX_DOUBLES]: position[3],
+     * R[9] (row-major, box -> world), half extents[3], mu (the contact's friction coefficient: Bullet multiplies the two
+     * bodies' lateral frictions). Per collision sphere the deepest penetrated box (first on ties) gives one contact: normal
+     * from the closest surface point to the sphere centre, or — centre inside the box — the face of least penetration. */
+    int32_t n_terrain_boxes;
+    const double *terrain;
 } mg_walker_params;
 
 /* Per-env state, SoA doubles: component c of env e at base[c*N + e]. */

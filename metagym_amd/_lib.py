@@ -121,7 +121,7 @@ class WalkerParams(C.Structure):
                 ("actuation", C.c_int32), ("pd_command", C.c_void_p),
                 ("pd_kp", C.c_double * WALKER_MAX_JOINTS), ("pd_kd", C.c_double * WALKER_MAX_JOINTS),
                 ("pd_strength", C.c_double * WALKER_MAX_JOINTS), ("pd_limit", C.c_double * WALKER_MAX_JOINTS),
-                ("substep_log", C.c_void_p)]
+                ("substep_log", C.c_void_p), ("n_terrain_boxes", C.c_int32), ("terrain", C.c_void_p)]
 
 
 class WalkerState(C.Structure):
@@ -155,6 +155,7 @@ class A1ActuatorState(C.Structure):
 
 A1_ETG_MAX_H, A1_MAX_SEGMENTS = 32, 32
 A1_EXTRA_ETG, A1_EXTRA_ETG_OBS, A1_EXTRA_YAW = 1, 2, 4
+WALKER_BOX_DOUBLES = 16
 
 
 class A1EtgConfig(C.Structure):

@@ -868,7 +868,7 @@ __device__ __forceinline__ void wave_kinematics(const ModelW &m, const WaveLds &
     PHASE(11);      // (profile builds) the level loop alone; phase 0 minus this = sin / cos
 }
 
-template <int NMAX>
+template <int NMAX, bool TERRAIN>
 __device__ __forceinline__ void wave_substep(const mg_walker_topology &tp, const ModelW &m, const mg_walker_params &prm,
                                              const WaveLds &L, int lane, int max_depth, int maxr,
                                              unsigned long long &touch_mask, double pd_cmd, double *log_row, int n_envs) {
@@ -1081,7 +1081,70 @@ __device__ __forceinline__ void wave_substep(const mg_walker_topology &tp, const
     touch_mask = 0ull;
     for (int g = 0; g < ns; ++g)
         if (((hits >> g) & 1ull) && __popcll(hits & ((1ull << g) - 1ull)) < W_MAXC) touch_mask |= 1ull << g;
-    // self-collision: lane = geom pair (in pair order, 64 at a time); slots after the ground contacts
+    // terrain: lane = collision sphere against the static boxes (the same for every env; wave-uniform loop, boxes whose
+    // x range misses the robot are skipped by the whole wave); per sphere the deepest box, first on ties. Slots after the
+    // ground contacts; the friction rows carry the box's own coefficient in their (otherwise zero) bias slot, kind -1.
+    if (TERRAIN && prm.n_terrain_boxes > 0 && ncont < W_MAXC) {
+        const double rad = lane < ns ? m.sph_r()[lane] : 0.0;
+        const double sz = rad - depth;
+        double lo = lane < ns ? sx - rad : 1e300, hi = lane < ns ? sx + rad : -1e300;
+        for (int off = 32; off > 0; off >>= 1) {
+            lo = fmin(lo, __shfl_xor(lo, off));
+            hi = fmax(hi, __shfl_xor(hi, off));
+        }
+        double bdepth = 0.0, bmu = 0.0;
+        V3 bn{0, 0, 1}, bx{0, 0, 0};
+        for (int bi = 0; bi < prm.n_terrain_boxes; ++bi) {
+            const double *B = prm.terrain + (size_t)MG_WALKER_BOX_DOUBLES * bi;
+            const V3 bp{B[0], B[1], B[2]}, bh{B[12], B[13], B[14]};
+            const double ex = fabs(B[3]) * bh.x + fabs(B[4]) * bh.y + fabs(B[5]) * bh.z;      // world x half extent
+            if (bp.x + ex < lo || bp.x - ex > hi) continue;
+            if (lane < ns) {
+                const V3 rel = V3{sx, sy, sz} - bp;
+                const V3 l{B[3] * rel.x + B[6] * rel.y + B[9] * rel.z, B[4] * rel.x + B[7] * rel.y + B[10] * rel.z,
+                           B[5] * rel.x + B[8] * rel.y + B[11] * rel.z};                       // R^T (x - p)
+                V3 c{fmin(fmax(l.x, -bh.x), bh.x), fmin(fmax(l.y, -bh.y), bh.y), fmin(fmax(l.z, -bh.z), bh.z)};
+                const V3 dv = l - c;
+                const double dist2 = dot(dv, dv);
+                double dpt;
+                V3 nl;
+                if (dist2 > 0.0) {
+                    const double dist = sqrt(dist2);
+                    dpt = rad - dist;
+                    nl = (1.0 / dist) * dv;
+                } else {            // centre inside the box: out through the face of least penetration (x, y, z order on ties)
+                    const double px = bh.x - fabs(l.x), py = bh.y - fabs(l.y), pz = bh.z - fabs(l.z);
+                    const int k = (px <= py && px <= pz) ? 0 : (py <= pz ? 1 : 2);
+                    const double lk = k == 0 ? l.x : (k == 1 ? l.y : l.z), sg = lk >= 0.0 ? 1.0 : -1.0;
+                    nl = V3{k == 0 ? sg : 0.0, k == 1 ? sg : 0.0, k == 2 ? sg : 0.0};
+                    if (k == 0) c.x = sg * bh.x; else if (k == 1) c.y = sg * bh.y; else c.z = sg * bh.z;
+                    dpt = rad + (k == 0 ? px : (k == 1 ? py : pz));
+                }
+                if (dpt > bdepth) {
+                    bdepth = dpt; bmu = B[15];
+                    bn = V3{B[3] * nl.x + B[4] * nl.y + B[5] * nl.z, B[6] * nl.x + B[7] * nl.y + B[8] * nl.z,
+                            B[9] * nl.x + B[10] * nl.y + B[11] * nl.z};                        // R n
+                    bx = bp + V3{B[3] * c.x + B[4] * c.y + B[5] * c.z, B[6] * c.x + B[7] * c.y + B[8] * c.z,
+                                 B[9] * c.x + B[10] * c.y + B[11] * c.z};
+                }
+            }
+        }
+        const bool th = bdepth > 0.0;
+        const unsigned long long th_mask = __ballot(th);
+        const int slot = ncont + __popcll(th_mask & ((1ull << lane) - 1ull));
+        const bool kept = th && slot < W_MAXC;
+        if (kept) {
+            double *cc = L.cx + 6 * slot;
+            cc[0] = bx.x; cc[1] = bx.y; cc[2] = bx.z; cc[3] = bn.x; cc[4] = bn.y; cc[5] = bn.z;
+            L.csphere[2 * slot] = L.sbody[lane]; L.csphere[2 * slot + 1] = -2;       // one body against the world
+            L.bias[3 * slot] = prm.erp * bdepth / dt; L.kind[3 * slot] = 0; L.partner[3 * slot] = -1;
+            L.bias[3 * slot + 1] = bmu; L.kind[3 * slot + 1] = -1; L.partner[3 * slot + 1] = 3 * slot;
+            L.bias[3 * slot + 2] = bmu; L.kind[3 * slot + 2] = -1; L.partner[3 * slot + 2] = 3 * slot;
+        }
+        touch_mask |= __ballot(kept);
+        ncont = min(ncont + __popcll(th_mask), W_MAXC);
+    }
+    // self-collision: lane = geom pair (in pair order, 64 at a time); slots after the ground and terrain contacts
     if (prm.self_collision)
         for (int base = 0; base < tp.n_pairs && ncont < W_MAXC; base += WV) {
             const int pr = base + lane;
@@ -1138,16 +1201,17 @@ __device__ __forceinline__ void wave_substep(const mg_walker_topology &tp, const
     for (int t = lane; t < ncont * n; t += WV) {
         const int c = t / n, d = t % n;
         const double *cc = L.cx + 6 * c;
-        if (L.csphere[2 * c + 1] < 0) {          // ground: point on the plane under the sphere
+        const int other = L.csphere[2 * c + 1];
+        if (TERRAIN ? other == -1 : other < 0) { // ground: point on the plane under the sphere
             const unsigned mk = (unsigned)L.mask[L.sbody[L.csphere[2 * c]]];
             const V3 jc = wjac_lin(L, mk, V3{cc[0], cc[1], 0.0}, d);
             L.J[(size_t)(3 * c) * n + d] = jc.z;
             L.J[(size_t)(3 * c + 1) * n + d] = jc.x;
             L.J[(size_t)(3 * c + 2) * n + d] = jc.y;
-        } else {                                 // self contact: relative velocity of the two bodies at xc
+        } else {                                 // self contact: relative velocity of the two bodies at xc; terrain (-2): one body
             const V3 xc{cc[0], cc[1], cc[2]}, nrm{cc[3], cc[4], cc[5]};
-            const V3 jd = wjac_lin(L, (unsigned)L.mask[L.csphere[2 * c]], xc, d) -
-                          wjac_lin(L, (unsigned)L.mask[L.csphere[2 * c + 1]], xc, d);
+            V3 jd = wjac_lin(L, (unsigned)L.mask[L.csphere[2 * c]], xc, d);
+            if (!TERRAIN || other >= 0) jd = jd - wjac_lin(L, (unsigned)L.mask[other], xc, d);
             V3 t1, t2;
             tangent_basis(nrm, t1, t2);
             L.J[(size_t)(3 * c) * n + d] = dot(nrm, jd);
@@ -1205,10 +1269,11 @@ __device__ __forceinline__ void wave_substep(const mg_walker_topology &tp, const
             if (!(idg > 0.0)) continue;
             const double jv = NMAX <= 32 ? wave_sum32(jh * u_d) : wave_sum(jh * u_d);   // J_r u = Jh_r . y
             const double lr = L.lam[rr];
-            double x = lr - (jv - bias) * idg;
+            const bool tfric = TERRAIN && rkind < 0;                     // a terrain friction row keeps its mu in `bias`
+            double x = lr - (jv - (tfric ? 0.0 : bias)) * idg;
             if (rkind == 0 || rkind >= 4) x = x > 0.0 ? x : 0.0;
             else {
-                const double lim = (rkind == 3 ? prm.self_friction : prm.friction) * L.lam[partner];
+                const double lim = (tfric ? bias : (rkind == 3 ? prm.self_friction : prm.friction)) * L.lam[partner];
                 x = x < -lim ? -lim : (x > lim ? lim : x);
             }
             const double dl = x - lr;
@@ -1362,7 +1427,7 @@ __global__ __launch_bounds__(WV) __attribute__((amdgpu_waves_per_eu(2))) void wa
     const double pd_cmd = (prm.actuation != 0 && lane < nj) ? prm.pd_command[(size_t)lane * n_envs + e] : 0.0;
     for (int it = 0; it < prm.frame_skip; ++it) {
         double *log_row = prm.substep_log ? prm.substep_log + ((size_t)it * (3 * nj + 7)) * n_envs + e : nullptr;
-        wave_substep<NMAX>(tp, m, prm, L, lane, max_depth, maxr, touch, pd_cmd, log_row, n_envs);
+        wave_substep<NMAX, SH::nb == 0>(tp, m, prm, L, lane, max_depth, maxr, touch, pd_cmd, log_row, n_envs);
     }
     // ---- calc_state (walker_base.py:31-64) on the current configuration ------------------------------
     // after_reset = false: post-step state; the obs carries the PREVIOUS step's feet flags and the flags
@@ -1543,6 +1608,11 @@ extern "C" int mg_walker_step(const mg_walker_topology *tp, const mg_walker_mode
         if (prm->mapping == 0) return mg::set_error(MG_ERR_UNSUPPORTED, "in-launch actuators need the wave mapping");
         MG_REQUIRE_PTR(prm->pd_command);
     }
+    if (prm->n_terrain_boxes < 0) return mg::set_error(MG_ERR_BAD_SIZE, "walker terrain: %d boxes", prm->n_terrain_boxes);
+    if (prm->n_terrain_boxes > 0) {
+        if (prm->mapping == 0) return mg::set_error(MG_ERR_UNSUPPORTED, "terrain boxes need the wave mapping");
+        MG_REQUIRE_PTR(prm->terrain);
+    }
     MG_REQUIRE_PTR(obs);
     MG_REQUIRE_PTR(reward);
     MG_REQUIRE_PTR(done);
@@ -1577,8 +1647,9 @@ extern "C" int mg_walker_step(const mg_walker_topology *tp, const mg_walker_mode
     // offsets become literals); any other topology runs the shape-generic instantiations
     using Humanoid = Shape<13, 17, 29, 17, 1>;
     using Ant = Shape<13, 8, 25, 13, 1>;
+    // (terrain boxes are compiled into the shape-generic instantiations only: the two tuned kernels keep their registers)
     auto is_shape = [&](int b, int j, int s, int g) {
-        return overlay && tp->n_bodies == b && tp->n_joints == j && tp->n_spheres == s && tp->n_geoms == g;
+        return overlay && prm->n_terrain_boxes == 0 && tp->n_bodies == b && tp->n_joints == j && tp->n_spheres == s && tp->n_geoms == g;
     };
 #define MG_WALKER_LAUNCH(NMAX_, SHAPE_)                                                                                  \
     hipLaunchKernelGGL((walker_step_wave_kernel<NMAX_, SHAPE_>), dim3(n), dim3(WV), lds, (hipStream_t)stream, *tp, *ms, \

@@ -165,6 +165,7 @@ class WalkerBatchEnv(object):
         # Bullet multiplies the two bodies' lateral friction: ground 0.8 (stadium.py:23) x geom friction (MJCF)
         p.limit_erp = 0.2                                          # Bullet's default constraint ERP
         p.erp, p.gravity, p.friction = CONTACT_ERP, GRAVITY, GROUND_FRICTION * float(m0.geom_friction)
+        self._geom_friction = float(m0.geom_friction)
         p.alive_z, p.alive_bonus, p.dead_bonus = self.alive_z, self.alive_bonus, -1.0
         p.initial_z = float(self.initial_z if self.initial_z is not None else m0.body_pos[0][2])
         p.joints_at_limit_cost = -0.1                              # walker_base_env.py:22
@@ -179,6 +180,7 @@ class WalkerBatchEnv(object):
         p.height_f32 = int(self.initial_z is not None)     # python-float initial_z: float32 alive sum (walker_base_env.py:47)
         self._first_reset = True                           # the floor link is not in robot.parts yet (walker_base_env.py:30-31)
         self._params_c = p
+        self._apply_terrain()
         self._obs = torch.zeros(N, self.obs_dim, dtype=torch.float32, device=dev)
         self._reward = torch.zeros(N, dtype=torch.float32, device=dev)
         self._rewards5 = torch.zeros(N, 5, dtype=torch.float32, device=dev)
@@ -246,6 +248,32 @@ class WalkerBatchEnv(object):
                                       _lib.current_stream(self.device))
         _lib.check(rc, "mg_walker_step")
         return self._obs, self._reward, self._done, {"rewards": self._rewards5, "steps": self.steps}
+
+    def set_terrain(self, boxes):
+        """Static boxes on top of the ground plane, shared by every env (mg_walker_params.terrain; wave mapping only) — e.g. the
+        list `metagym_amd.quadrupedal.terrain.task_terrain(task)` returns. Each box: (half_extents[3], position[3],
+        quaternion (x, y, z, w), friction); the contact's coefficient is friction x the robot's geom friction (Bullet
+        multiplies the two bodies' lateral frictions). `None` / [] removes the terrain."""
+        self._terrain_spec = list(boxes) if boxes else None
+        if getattr(self, "_robot_set", False):
+            self._apply_terrain()
+
+    def _apply_terrain(self):
+        spec, p = getattr(self, "_terrain_spec", None), self._params_c
+        if not spec:
+            self._terrain_t, p.n_terrain_boxes, p.terrain = None, 0, None
+            return
+        rows = np.zeros((len(spec), _lib.WALKER_BOX_DOUBLES))
+        for i, (half, pos, quat, friction) in enumerate(spec):
+            x, y, z, w = [float(v) for v in quat]
+            nq = np.sqrt(x * x + y * y + z * z + w * w)
+            x, y, z, w = x / nq, y / nq, z / nq, w / nq
+            R = [1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y), 2 * (x * y + w * z), 1 - 2 * (x * x + z * z),
+                 2 * (y * z - w * x), 2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)]
+            rows[i, 0:3], rows[i, 3:12], rows[i, 12:15] = pos, R, half
+            rows[i, 15] = float(friction) * float(self._geom_friction)
+        self._terrain_t = torch.as_tensor(rows, dtype=torch.float64, device=self.device).contiguous()
+        p.n_terrain_boxes, p.terrain = len(spec), self._terrain_t.data_ptr()
 
     def step_actuated(self, command, kp=None, kd=None, strength=None, limit=None, raw_torque=False, n_substeps=None, log=None):
         """The engine's in-launch actuators (mg_walker_params.actuation): `n_substeps` physics sub-steps in ONE launch, the

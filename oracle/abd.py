@@ -158,7 +158,8 @@ def integrate_positions(s, dt):
 
 class Params(object):
     def __init__(self, dt=0.005, substeps=4, iterations=5, erp=0.9, friction=0.8 * 0.8, power=0.41, max_contacts=12,
-                 limit_erp=0.2, self_collision=True, self_friction=0.8 * 0.8):
+                 limit_erp=0.2, self_collision=True, self_friction=0.8 * 0.8, terrain=()):
+        self.terrain = list(terrain)          # static boxes on top of the ground plane: (position[3], R[3,3] box->world, half_extents[3], mu)
         self.dt, self.substeps, self.iterations, self.erp, self.friction, self.power = dt, substeps, iterations, erp, friction, power
         self.limit_erp = limit_erp            # Bullet's default constraint ERP (btContactSolverInfo::m_erp2 = 0.2);
         #                                       setDefaultContactERP(0.9) only changes the contact ERP
@@ -192,6 +193,27 @@ def segment_closest(p1, q1, p2, q2):
     return p1 + sc * d1, p2 + tc * d2
 
 
+def sphere_box(x, radius, box):
+    """Deepest-point contact of a sphere (centre x) with a static oriented box (position, R, half extents, mu):
+    returns (depth, normal, point on the box surface) — depth <= 0: no contact. Outside the box the normal points from the
+    closest surface point to the centre; with the centre inside, along the face of least penetration (first of x, y, z on ties)."""
+    p, R, h, _ = box
+    l = R.T @ (x - p)
+    c = np.minimum(np.maximum(l, -h), h)
+    d = l - c
+    dist2 = d @ d
+    if dist2 > 0.0:
+        dist = np.sqrt(dist2)
+        return radius - dist, R @ (d / dist), p + R @ c
+    k = int(np.argmin(h - np.abs(l)))
+    sgn = 1.0 if l[k] >= 0.0 else -1.0
+    n_l = np.zeros(3)
+    n_l[k] = sgn
+    c = l.copy()
+    c[k] = sgn * h[k]
+    return radius + (h[k] - abs(l[k])), R @ n_l, p + R @ c
+
+
 def tangent_basis(nrm):
     """Two unit tangents orthogonal to nrm (deterministic choice shared with the kernels)."""
     ref = np.array([1.0, 0.0, 0.0]) if abs(nrm[0]) < 0.9 else np.array([0.0, 1.0, 0.0])
@@ -216,6 +238,26 @@ def constraint_rows(m, s, kin, prm):
             rows.append((Jc[2], prm.erp * depth / prm.dt, 0, -1, g))
             rows.append((Jc[0], 0.0, 1, k, g))
             rows.append((Jc[1], 0.0, 2, k, g))
+    # terrain: per collision sphere the deepest static box (first on ties); friction rows carry the box's own coefficient
+    if prm.terrain:
+        for g in range(len(m.sph_body)):
+            if len(rows) >= 3 * prm.max_contacts:
+                break
+            b = m.sph_body[g]
+            x = kin["o"][b] + kin["R"][b] @ m.sph_pos[g]
+            best = None
+            for box in prm.terrain:
+                depth, nrm, xc = sphere_box(x, m.sph_radius[g], box)
+                if depth > 0.0 and (best is None or depth > best[0]):
+                    best = (depth, nrm, xc, box[3])
+            if best is not None:
+                depth, nrm, xc, mu = best
+                Jc = point_jacobian(m, kin, b, xc)
+                t1, t2 = tangent_basis(nrm)
+                k = len(rows)
+                rows.append((nrm @ Jc, prm.erp * depth / prm.dt, 0, -1, g))
+                rows.append((t1 @ Jc, 0.0, -1, k, g, mu))
+                rows.append((t2 @ Jc, 0.0, -1, k, g, mu))
     # self-collision between the capsule geoms of bodies that are neither ancestor-related nor welded
     # (PyBullet flags at robot_bases.py:119); friction = geom friction squared (Bullet multiplies)
     if prm.self_collision and hasattr(m, "pair_a"):
@@ -259,14 +301,15 @@ def pgs(A, rhs, rows, friction, iterations):
     self-contact rows (kind 3)), natural row order, zero warm start."""
     lam = np.zeros(len(rows))
     for _ in range(iterations):
-        for r, (_, _, kind, partner, _) in enumerate(rows):
+        for r, row in enumerate(rows):
+            kind, partner = row[2], row[3]
             if A[r, r] <= 0:
                 continue
             x = lam[r] - (A[r] @ lam + rhs[r]) / A[r, r]
             if kind == 0:
                 lam[r] = max(0.0, x)
             else:
-                lim = (friction[1] if kind == 3 else friction[0]) * lam[partner]
+                lim = (row[5] if kind < 0 else friction[1] if kind == 3 else friction[0]) * lam[partner]
                 lam[r] = min(lim, max(-lim, x))
     return lam
 

@@ -201,3 +201,71 @@ def test_self_collision_is_an_internal_force():
         assert np.abs(P1 - P0).max() < 0.05 and np.abs(L1 - L0).max() < 0.05
     finally:
         abd.GRAVITY[:] = g
+
+
+def _box(pos, half, mu=1.0, pitch=0.0):
+    c, s = np.cos(pitch), np.sin(pitch)
+    R = np.array([[c, 0, s], [0, 1, 0], [-s, 0, c]])        # rotation about y by `pitch`
+    return (np.array(pos, float), R, np.array(half, float), mu)
+
+
+def test_sphere_box_contact_cases():
+    box = _box([1.0, 0.0, 0.5], [0.5, 2.0, 0.1])
+    depth, n, xc = abd.sphere_box(np.array([1.2, 0.3, 0.65]), 0.1, box)            # above the top face
+    assert np.isclose(depth, 0.05) and np.allclose(n, [0, 0, 1]) and np.allclose(xc, [1.2, 0.3, 0.6])
+    depth, n, xc = abd.sphere_box(np.array([1.56, 0.0, 0.66]), 0.1, box)           # over the +x edge: normal along the diagonal
+    assert np.allclose(n, np.array([0.06, 0, 0.06]) / np.hypot(0.06, 0.06)) and np.isclose(depth, 0.1 - np.hypot(0.06, 0.06))
+    depth, n, xc = abd.sphere_box(np.array([1.0, 0.0, 0.58]), 0.05, box)           # centre inside: out through the nearest face
+    assert np.isclose(depth, 0.05 + 0.02) and np.allclose(n, [0, 0, 1]) and np.allclose(xc, [1.0, 0.0, 0.6])
+    assert abd.sphere_box(np.array([3.0, 0.0, 0.5]), 0.1, box)[0] < 0                # far away
+    tilted = _box([0, 0, 0], [5, 5, 0.01], pitch=-0.3)                              # a ramp rising towards +x
+    depth, n, xc = abd.sphere_box(np.array([1.0, 0.0, 1.0 * np.tan(0.3) + 0.05]), 0.1, tilted)
+    assert np.allclose(n, [-np.sin(0.3), 0, np.cos(0.3)]) and depth > 0
+
+
+@pytest.mark.parametrize("name", ["ant"])
+def test_drop_on_a_box_rests_on_its_top_face(name):
+    """A platform 0.4 m above the ground plane: the robot dropped over it comes to rest on the platform (no sphere deeper than
+    2 cm in the top face, none anywhere near the ground plane), and the contact impulses carry its weight."""
+    m = MODELS[name]
+    top = 0.4
+    prm = abd.Params(terrain=[_box([0.0, 0.0, top - 0.05], [2.0, 2.0, 0.05], mu=0.8)])
+    env = abd.WalkerEnv(m, prm=prm, motor_power=np.full(len(m.joint_lo), 100.0), alive_z=-1.0)
+    env.reset(np.zeros(len(m.joint_lo)))
+    env.s.pos[2] += top
+    lowest = np.inf
+    for t in range(150):
+        env.step(np.zeros(len(m.joint_lo)))
+        kin = abd.kinematics(m, env.s)
+        lowest = min(lowest, min((kin["o"][b] + kin["R"][b] @ m.sph_pos[g])[2] - m.sph_radius[g] for g, b in enumerate(m.sph_body)))
+    assert top - 0.02 < lowest
+    P, _ = abd.momentum(m, env.s)
+    assert abs(P[2]) < 0.05 * 9.8 * m.body_mass.sum()
+
+
+@pytest.mark.parametrize("mu,slides", [(1.0, False), (0.1, True)])
+def test_friction_cone_on_a_ramp(mu, slides):
+    """A 0.3 rad ramp (tan = 0.31) with the box's own friction coefficient: at mu = 1.0 the dropped robot comes to rest and
+    stays; at mu = 0.1 it slides downhill with the acceleration of a block on an incline, g (sin - mu cos)."""
+    m = MODELS["ant"]
+    ang = 0.3
+    ramp = _box([0.0, 0.0, 0.0], [30.0, 5.0, 0.02], mu=mu, pitch=-ang)             # rises towards +x through the origin
+    env = abd.WalkerEnv(m, prm=abd.Params(terrain=[ramp]), motor_power=np.full(len(m.joint_lo), 100.0), alive_z=-1.0)
+    env.reset(np.zeros(len(m.joint_lo)))
+    env.s.pos[:] = [5.0, 0.0, 5.0 * np.tan(ang) + env.s.pos[2] + 0.45]             # feet 5 cm above the ramp
+    zero = np.zeros(len(m.joint_lo))
+    if not slides:
+        for t in range(110):
+            env.step(zero)
+        x0 = env.s.pos[0]
+        for t in range(25):
+            env.step(zero)
+        assert abs(env.s.pos[0] - x0) < 0.03 and np.abs(env.s.u()).max() < 0.3
+    else:
+        for t in range(30):
+            env.step(zero)
+        v0 = env.s.v.copy()
+        for t in range(50):      # 1 s on the ramp
+            env.step(zero)
+        along = (env.s.v - v0) @ np.array([np.cos(ang), 0.0, np.sin(ang)])
+        assert along == pytest.approx(-9.8 * (np.sin(ang) - mu * np.cos(ang)), rel=0.25)

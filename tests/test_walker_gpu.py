@@ -327,3 +327,87 @@ def test_in_launch_raw_torque_actuation_equals_the_action_path():
         assert torch.equal(log[-1, 0:8], b_env.q) and torch.equal(log[-1, 8:16], b_env.qd) and torch.equal(log[-1, 16:24], torque)
         quat = log[-1, 24:28]
         assert torch.allclose((quat * quat).sum(0), torch.ones(n, dtype=torch.float64, device="cuda:0"), atol=1e-12)
+
+
+def _terrain_for_tests():
+    """A little course around the origin: a platform, a two-step stair, an up-ramp and a steep low-friction down-ramp —
+    (half_extents, position, quaternion, friction) like metagym_amd.quadrupedal.terrain's boxes."""
+    def yq(a):
+        return [0.0, np.sin(a / 2), 0.0, np.cos(a / 2)]
+    return [([0.6, 2.5, 0.05], [0.0, 0.0, 0.05], yq(0.0), 1.0),            # platform, top at z = 0.1
+            ([0.15, 2.5, 0.05], [0.75, 0.0, 0.15], yq(0.0), 5.0),          # step 1, top 0.2
+            ([0.15, 2.5, 0.05], [1.05, 0.0, 0.25], yq(0.0), 5.0),          # step 2, top 0.3
+            ([0.8, 2.5, 0.01], [-1.3, 0.0, 0.25], yq(0.25), 0.9),          # ramp rising towards -x
+            ([0.5, 2.5, 0.01], [0.0, 3.2, 0.3], yq(-0.5), 0.2)]            # off to the side, slippery
+
+
+def _oracle_boxes(spec, geom_friction):
+    out = []
+    for half, pos, (x, y, z, w), mu in spec:
+        R = np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y)],
+                      [2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x)],
+                      [2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)]])
+        out.append((np.array(pos, float), R, np.array(half, float), mu * geom_friction))
+    return out
+
+
+@pytest.mark.parametrize("robot", ["humanoid", "ant"])
+def test_terrain_boxes_match_oracle_trajectory(robot):
+    """Static terrain boxes (mg_walker_params.terrain): robots dropped at different places of a small course — platform,
+    stair edges, ramps, next to it on the plain ground — follow the oracle's trajectories (same deepest-box contact rule,
+    per-box friction), and the terrain actually carries them."""
+    ant = robot == "ant"
+    names = ["ant", "ant_tra_005"] if ant else ["humanoid", "humanoid_tra_137"]
+    models = [MODELS[k] for k in names]
+    n = 5 * len(models)
+    spec = _terrain_for_tests()
+    env = _make("MetaAntEnv" if ant else "MetaHumanoidEnv", models, n, max_steps=1000)
+    env.set_terrain(spec)
+    ids = env.task_id.cpu().numpy()
+    nj = env.n_joints
+    rs = np.random.RandomState(3)
+    noise = rs.uniform(-0.1, 0.1, (n, nj))
+    env.reset(joint_noise=noise)
+    starts = np.array([[0.0, 0.0, 0.12], [0.8, 0.1, 0.32], [-1.3, -0.2, 0.35], [0.45, 0.0, 0.2], [3.0, 0.0, 0.0]])   # last: off the course
+    offs = starts[np.arange(n) % len(starts)]
+    env.pos += torch.as_tensor(offs.T, device=env.pos.device)
+    oenvs = []
+    for e in range(n):
+        m = models[ids[e]]
+        kw = dict(friction=0.8 * float(m.geom_friction), self_friction=float(m.geom_friction) ** 2,
+                  terrain=_oracle_boxes(spec, float(m.geom_friction)))
+        if ant:
+            o = abd.WalkerEnv(m, prm=abd.Params(power=2.5, **kw), motor_power=np.full(nj, 100.0), alive_z=0.26, alive_bonus=1.0,
+                              initial_z=None, torque_f32=False, max_steps=1000)
+        else:
+            o = abd.WalkerEnv(m, prm=abd.Params(**kw), max_steps=1000)
+        o.reset(noise[e])
+        o.s.pos += offs[e]
+        oenvs.append(o)
+    worst, on_terrain = 0.0, 0
+    for t in range(30):
+        a = rs.uniform(-0.6, 0.6, (n, nj)).astype(np.float32)
+        env.step(torch.as_tensor(a))
+        q, pos, fc = env.q.cpu().numpy().T, env.pos.cpu().numpy().T, env.feet_contact.cpu().numpy().T
+        for e in range(n):
+            oenvs[e].step(a[e])
+            s = oenvs[e].s
+            worst = max(worst, np.abs(q[e] - s.q).max(), np.abs(pos[e] - s.pos).max())
+            assert np.allclose(q[e], s.q, rtol=0, atol=2e-7), (t, e, np.abs(q[e] - s.q).max())
+            assert np.allclose(pos[e], s.pos, rtol=0, atol=2e-7), (t, e)
+            assert np.array_equal(fc[e], oenvs[e].feet_contact), (t, e)
+    for e in range(n):      # whoever started over the course is still above the plain ground level it would have fallen to
+        kin = abd.kinematics(models[ids[e]], oenvs[e].s)
+        lowest = min((kin["o"][b] + kin["R"][b] @ models[ids[e]].sph_pos[g])[2] - models[ids[e]].sph_radius[g]
+                     for g, b in enumerate(models[ids[e]].sph_body))
+        on_terrain += int(lowest > 0.05)
+    assert on_terrain >= n // 2
+    print(robot, "terrain: max |state diff| GPU vs oracle over 30 steps: %.2e, %d / %d robots resting on boxes" % (worst, on_terrain, n))
+
+
+def test_terrain_needs_the_wave_mapping():
+    env = _make("MetaAntEnv", [MODELS["ant"]], 4, mapping="lane")
+    env.set_terrain(_terrain_for_tests())
+    env.reset()
+    with pytest.raises(Exception, match="wave mapping"):
+        env.step(torch.zeros(4, env.n_joints))
