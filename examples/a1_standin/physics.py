@@ -48,8 +48,19 @@ class StandinPhysics(object):
         rate = torch.einsum("nij,ni->nj", R, e.omega.t())                      # body-frame angular velocity R^T omega
         return e.q.t().contiguous(), e.qd.t().contiguous(), quat.contiguous(), rate.contiguous()
 
+    def set_terrain(self, boxes, default_pose):
+        """A1GymEnv hands over the task's terrain (metagym_amd.quadrupedal.terrain) and the reset pose [x, y, 0.28 + add_height]
+        (locomotion_gym_env.py:337): the boxes go to the engine (mg_walker_params.terrain), the robot is reset that much higher."""
+        self.env.set_terrain(boxes)
+        self._pose_offset = torch.tensor([default_pose[0], default_pose[1], default_pose[2] - 0.28], dtype=torch.float64,
+                                         device=self.device).reshape(3, 1)
+
     def reset(self, mask):
         self.env.reset(mask=mask, joint_noise=self._init)                      # joints at (0, 0.9, -1.8) x 4 (a1.py:71)
+        off = getattr(self, "_pose_offset", None)
+        if off is not None:
+            m = torch.ones(self.n, dtype=torch.bool, device=self.device) if mask is None else torch.as_tensor(mask, device=self.device).bool()
+            self.env.pos += off * m.to(torch.float64)
         return self._state()
 
     def substep(self, torques):

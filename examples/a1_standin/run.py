@@ -20,6 +20,7 @@ args = [a for a in sys.argv[1:] if not a.startswith("--")]
 n = int(args[0]) if len(args) > 0 else 4096
 steps = int(args[1]) if len(args) > 1 else 40
 for label, kw in (("hold the default pose", dict(ETG=0)),
+                  ("hold the pose on the slopestair start platform", dict(ETG=0, task="slopestair")),
                   ("ETG open-loop gait (hand-set weights)", dict(ETG=1, ETG_w=np.tile([[0.03], [0.0], [0.02]], (1, 20)) * np.sin(np.linspace(0, 2 * np.pi, 20)),
                                                                  ETG_b=np.zeros(3)))):
     phys = StandinPhysics(n, fused="--unfused" not in sys.argv)

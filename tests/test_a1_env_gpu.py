@@ -150,3 +150,29 @@ def test_fused_engine_step_equals_thirteen_separate_substeps_bit_for_bit():
             assert torch.equal(getattr(envs[0].physics.env, key), getattr(envs[1].physics.env, key)), key
         assert torch.equal(envs[0].robot.GetControlObservation(), envs[1].robot.GetControlObservation())
     assert torch.isfinite(r0[0]).all()
+
+
+def test_standin_robot_stands_on_the_task_terrain():
+    """`task=` hands the reference's terrain boxes to the physics (StandinPhysics.set_terrain -> mg_walker_params.terrain) and
+    resets the robot 0.28 + add_height up: on `slopestair` (start platform 0.278 m above the ground plane) the stand-in holds
+    its pose ON the platform; with the boxes withheld it would drop to the plane."""
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "examples", "a1_standin"))
+    from physics import StandinPhysics
+    n = 128
+    heights = {}
+    for with_boxes in (True, False):
+        phys = StandinPhysics(n, DEV)
+        env = metagym_amd.make("quadrupedal-v0", num_envs=n, physics=phys, device=DEV, task="slopestair")
+        assert len(env.terrain_boxes) == 44 and abs(env.add_height - 0.27757873) < 1e-6 and len(env.env_info) == 20
+        if not with_boxes:
+            phys.env.set_terrain(None)
+        obs, info = env.reset()
+        a = torch.zeros(n, 12, dtype=torch.float64, device=DEV)
+        for _ in range(25):
+            obs, reward, done, info = env.step(a)
+        assert torch.isfinite(obs).all()
+        heights[with_boxes] = float(info["base"][:, 2].mean())
+    assert 0.22 + 0.2776 < heights[True] < 0.30 + 0.2776, heights
+    assert heights[False] < heights[True] - 0.2, heights
