@@ -16,14 +16,13 @@ Batched extensions
     returned observation is the first one of the next episode).
   * rendering (`enable_render`, pygame god-view) is out of scope; the argument is accepted and ignored.
 """
-import ctypes as C
 
 import numpy as np
 import torch
 
 from .. import _lib
 from ..spaces import Box, Discrete
-from .maze_task import MAZE_TASK_MANAGER, DeviceTaskTable, TaskConfig
+from .maze_task import MAZE_TASK_MANAGER, DeviceTaskTable, TaskConfig  # noqa: F401  (TaskConfig re-exported like the reference's maze_env)
 
 PI = 3.1415926                      # dynamics.py:6
 DISCRETE_ACTIONS = [(-1, 0), (1, 0), (0, -1), (0, 1)]   # maze_env.py:14
