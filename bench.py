@@ -461,7 +461,7 @@ def secondary_workloads(dev):
             "robot_substeps_per_s": n / s, "us_per_substep_pair": s * 1e6,
             "roofline": {"bound": "hbm", "achieved": byt * n / s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": byt * n / s / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes_per_robot_substep": byt},
-            "note": "mg_a1_receive_and_apply (ReceiveObservation + the next sub-step's ApplyAction in one launch); bit-exact against the unmodified reference; "
+            "note": "mg_a1_receive_and_apply (ReceiveObservation + the next sub-step's ApplyAction in one launch, four lanes per robot); bit-exact against the unmodified reference; "
                     "the A1 body / physics is not built (a1.urdf and PyBullet are absent from the reference tree)"}
         del act
         torch.cuda.empty_cache()
@@ -482,8 +482,12 @@ def secondary_workloads(dev):
         env.reset()
         a12 = torch.zeros(n2, 12, **f64)
         s2 = _time_steps(lambda i: env.step(a12), 20, 3)
+        replay = env.capture_step()                  # the same step as one hipGraph
+        env.reset()
+        s2g = _time_steps(lambda i: replay(a12), 20, 3)
         out["A1GymEnv_python_side_%denvs_null_physics" % n2] = {
             "env_steps_per_s": n2 / s2, "ms_per_env_step": s2 * 1e3, "launches_per_env_step": 1 + 1 + 12 + 1 + 3,
+            "ms_per_env_step_hipgraph": s2g * 1e3, "env_steps_per_s_hipgraph": n2 / s2g,
             "note": "ETG action path, 13 sub-steps of motor model + observation history, info, sensor stack, reward shaping — "
                     "what the reference's A1GymEnv.step computes in Python (3.3 ms per env step on one core of the build container, measured "
                     "with the same scripted world standing in for PyBullet, so ~3e2 env-steps/s/core), all on the GPU; "

@@ -1,6 +1,6 @@
 """`quadrupedal-v0` closed-loop on the GPU with the stand-in body of this directory (see physics.py for what that means):
 
-    python examples/a1_standin/run.py [num_envs] [steps] [--unfused]
+    python examples/a1_standin/run.py [num_envs] [steps] [--unfused] [--graph]
 
 Zero policy actions: the motor model holds the default pose (0, 0.9, -1.8) x 4 through its PD loop, 13 sub-steps per env
 step; then the same with the ETG's open-loop trot. Prints base height / reward / done fraction and env-steps/s."""
@@ -26,12 +26,16 @@ for label, kw in (("hold the default pose", dict(ETG=0)),
     phys = StandinPhysics(n, fused="--unfused" not in sys.argv)
     env = metagym_amd.make("quadrupedal-v0", num_envs=n, physics=phys, **kw)
     obs, info = env.reset()
+    step = env.step
+    if "--graph" in sys.argv:          # the whole env step replayed as one hipGraph
+        step = env.capture_step()
+        obs, info = env.reset()
     a = torch.zeros(n, 12, dtype=torch.float64, device="cuda:0")
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     dones = 0.0
     for k in range(steps):
-        obs, reward, done, info = env.step(a)
+        obs, reward, done, info = step(a)
         dones = max(dones, float(done.double().mean()))
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / steps

@@ -12,14 +12,15 @@
 // element-wise arithmetic in the order NumPy evaluates it, so the results are bit-identical to the reference
 // (tests/golden/a1_actuation.npz); the library is built with -ffp-contract=off.
 //
-// Mapping: one lane per robot, SoA arrays ([component][N]) so a wave's loads and stores are contiguous. The path is
-// HBM-bound: per sub-step a robot writes one 43-double observation into its history ring and reads two ring entries
-// for the control observation (+ two 24-double halves when the PD latency is not zero) — about 1.4 KB.
+// Mapping: SoA arrays ([component][N]) so a wave's loads and stores are contiguous; four lanes per robot in the per-sub-step
+// kernels (see act_lane), one lane per robot elsewhere. The path is HBM-bound: per sub-step a robot writes one 43-double
+// observation into its history ring and reads two ring entries for the control observation (+ two 24-double halves when
+// the PD latency is not zero).
 #include "mg_common.h"
 
 namespace {
 
-constexpr int A1_BLOCK = 256;
+constexpr int A1_BLOCK = 64;   // one wave per workgroup: 16 384 robots still reach every CU
 constexpr int NM = MG_A1_NUM_MOTORS;
 constexpr int OD = MG_A1_OBS_DIM;
 
@@ -64,21 +65,38 @@ __device__ __forceinline__ double map_to_pi(double x) {
     return m;
 }
 
-__device__ __forceinline__ void a1_apply(const mg_a1_actuator_config &c, const mg_a1_actuator_state &st, int n, int e,
-                                         const double *command, const double *last_command, double lerp, double *torque) {
+// Lane mapping of the actuation kernels: FOUR lanes per robot, lane `sub` owning motors 3 sub .. 3 sub + 2 (their angle,
+// velocity and torque components) and its share of the 7 base components — 16 robots per wave, a component's 16 values
+// still contiguous. One lane per robot left 16 384 robots on 256 waves (a quarter of the chip's SIMDs, one dependent chain
+// of ~180 memory operations each); per-motor arithmetic is independent, so the results are bit-identical.
+constexpr int ACT_SUBS = 4, ACT_MOTORS = NM / ACT_SUBS, ACT_ROBOTS_PER_WAVE = 64 / ACT_SUBS;
+__device__ __forceinline__ bool act_lane(int n, int &e, int &sub) {
+    const int gid = blockIdx.x * A1_BLOCK + threadIdx.x, lane = gid & 63;
+    e = (gid >> 6) * ACT_ROBOTS_PER_WAVE + (lane & (ACT_ROBOTS_PER_WAVE - 1));
+    sub = lane / ACT_ROBOTS_PER_WAVE;
+    return e < n;
+}
+__host__ inline unsigned act_blocks(int n) {
+    const long waves = ((long)n + ACT_ROBOTS_PER_WAVE - 1) / ACT_ROBOTS_PER_WAVE;
+    return (unsigned)((waves * 64 + A1_BLOCK - 1) / A1_BLOCK);
+}
+struct Ring { int count, head; };
+
+__device__ __forceinline__ void a1_apply(const mg_a1_actuator_config &c, const mg_a1_actuator_state &st, int n, int e, int sub,
+                                         Ring ring, const double *command, const double *last_command, double lerp,
+                                         double *torque) {
     const size_t stride = (size_t)OD * n;
     const double pd_lat = c.pd_latency_env ? c.pd_latency_env[e] : c.pd_latency;
-    const Delay d = delayed(pd_lat, c.time_step, st.count[e], st.head[e], c.history_len);
-    const int cdim = c.mode == MG_A1_MODE_HYBRID ? 5 * NM : NM;
+    const Delay d = delayed(pd_lat, c.time_step, ring.count, ring.head, c.history_len);
     auto cmd = [&](int i) {      // ProcessAction: last + lerp * (action - last)
         const double a = command[(size_t)i * n + e];
         if (last_command == nullptr) return a;
         const double l = last_command[(size_t)i * n + e];
         return l + lerp * (a - l);
     };
-    (void)cdim;
 #pragma unroll
-    for (int i = 0; i < NM; ++i) {
+    for (int m = 0; m < ACT_MOTORS; ++m) {
+        const int i = ACT_MOTORS * sub + m;
         double t;
         if (c.mode == MG_A1_MODE_TORQUE) {
             t = c.strength[i] * cmd(i);                                             // laikago_motor.py:125-128
@@ -117,7 +135,15 @@ __device__ __forceinline__ void a1_apply(const mg_a1_actuator_config &c, const m
     }
 }
 
-__device__ __forceinline__ void a1_receive(const mg_a1_actuator_config &c, const mg_a1_actuator_state &st, int n, int e,
+// The history components lane `sub` owns: 3 x (angle, velocity, torque) + base component sub (and sub + 4 when < 7).
+constexpr int ACT_COMPS = 3 * ACT_MOTORS + 2;
+__device__ __forceinline__ int act_comp(int sub, int k) {      // k-th owned component, or -1
+    if (k < 3 * ACT_MOTORS) return (k / ACT_MOTORS) * NM + ACT_MOTORS * sub + k % ACT_MOTORS;
+    const int x = sub + ACT_SUBS * (k - 3 * ACT_MOTORS);
+    return x < OD - 3 * NM ? 3 * NM + x : -1;
+}
+
+__device__ __forceinline__ Ring a1_receive(const mg_a1_actuator_config &c, const mg_a1_actuator_state &st, int n, int e, int sub,
                                            const double *q, const double *qd, const double *quat, const double *rate,
                                            const uint8_t *clear_mask) {
     const size_t stride = (size_t)OD * n;
@@ -126,62 +152,74 @@ __device__ __forceinline__ void a1_receive(const mg_a1_actuator_config &c, const
     head = count == 0 ? 0 : (head + 1 == c.history_len ? 0 : head + 1);             // appendleft
     if (count < c.history_len) ++count;
     double *slot = st.history + (size_t)head * stride + e;
-    double in[OD];                                                                  // (all 43 loads in flight, then the stores)
+    double in[ACT_COMPS];                                                           // (all loads in flight, then the stores)
 #pragma unroll
-    for (int i = 0; i < NM; ++i) {
-        // GetTrueMotorAngles (:743-753): (angle - offset) * direction with offset 0, direction 1 (a1.py:43-49)
-        in[i] = (q[(size_t)i * n + e] - 0.0) * 1.0;
-        in[NM + i] = qd[(size_t)i * n + e] * 1.0;
-        in[2 * NM + i] = st.observed_torque[(size_t)i * n + e];
+    for (int k = 0; k < ACT_COMPS; ++k) {
+        double v = 0.0;
+        if (k < 3 * ACT_MOTORS) {      // (k is a literal after unrolling: the group is decided at compile time)
+            const int i = ACT_MOTORS * sub + k % ACT_MOTORS;
+            // GetTrueMotorAngles (:743-753): (angle - offset) * direction with offset 0, direction 1 (a1.py:43-49)
+            if (k / ACT_MOTORS == 0) v = (q[(size_t)i * n + e] - 0.0) * 1.0;
+            else if (k / ACT_MOTORS == 1) v = qd[(size_t)i * n + e] * 1.0;
+            else v = st.observed_torque[(size_t)i * n + e];
+        } else {
+            const int x = sub + ACT_SUBS * (k - 3 * ACT_MOTORS);      // base quaternion (4) then body rates (3)
+            if (x < 4) v = quat[(size_t)x * n + e];
+            else if (x < 7) v = rate[(size_t)(x - 4) * n + e];
+        }
+        in[k] = v;
     }
 #pragma unroll
-    for (int i = 0; i < 4; ++i) in[3 * NM + i] = quat[(size_t)i * n + e];
-#pragma unroll
-    for (int i = 0; i < 3; ++i) in[3 * NM + 4 + i] = rate[(size_t)i * n + e];
-#pragma unroll
-    for (int i = 0; i < OD; ++i) slot[(size_t)i * n] = in[i];
-    st.count[e] = count;
-    st.head[e] = head;
-    // a lane reads back only what it wrote itself (its own column of the ring): no fence needed
+    for (int k = 0; k < ACT_COMPS; ++k) {
+        const int comp = act_comp(sub, k);
+        if (comp >= 0) slot[(size_t)comp * n] = in[k];
+    }
+    // the four lanes of a robot sit in one wave and all of them loaded count / head in the instruction above: one writes
+    if (sub == 0) { st.count[e] = count; st.head[e] = head; }
+    // a lane reads back only what it wrote itself (its own components of the ring): no fence needed
     const double lat = c.control_latency_env ? c.control_latency_env[e] : c.control_latency;
     const Delay d = delayed(lat, c.time_step, count, head, c.history_len);
-    // all loads of a chunk first, then its stores: written as load -> store per component the compiler must assume the
-    // control-observation store may alias the history and serialises 43 dependent round trips
-    constexpr int CH = 11;
-    for (int c0 = 0; c0 < OD; c0 += CH) {
-        double v[CH];
+    // all loads first, then the stores: written as load -> store per component the compiler must assume the
+    // control-observation store may alias the history and serialises the round trips
+    double v[ACT_COMPS];
 #pragma unroll
-        for (int i = 0; i < CH; ++i) v[i] = c0 + i < OD ? blend(d, st.history, stride, c0 + i, n, e) : 0.0;
-#pragma unroll
-        for (int i = 0; i < CH; ++i)
-            if (c0 + i < OD) st.control_obs[(size_t)(c0 + i) * n + e] = v[i];
+    for (int k = 0; k < ACT_COMPS; ++k) {
+        const int comp = act_comp(sub, k);
+        v[k] = comp >= 0 ? blend(d, st.history, stride, comp, n, e) : 0.0;
     }
+#pragma unroll
+    for (int k = 0; k < ACT_COMPS; ++k) {
+        const int comp = act_comp(sub, k);
+        if (comp >= 0) st.control_obs[(size_t)comp * n + e] = v[k];
+    }
+    return Ring{count, head};
 }
 
 __global__ __launch_bounds__(A1_BLOCK) void a1_apply_action_kernel(A1K k, mg_a1_actuator_state st, int n,
                                                                    const double *command, const double *last_command,
                                                                    double lerp, double *torque) {
-    const int e = blockIdx.x * A1_BLOCK + threadIdx.x;
-    if (e < n) a1_apply(k.c, st, n, e, command, last_command, lerp, torque);
+    int e, sub;
+    if (act_lane(n, e, sub)) a1_apply(k.c, st, n, e, sub, Ring{st.count[e], st.head[e]}, command, last_command, lerp, torque);
 }
 
 __global__ __launch_bounds__(A1_BLOCK) void a1_receive_kernel(A1K k, mg_a1_actuator_state st, int n, const double *q,
                                                               const double *qd, const double *quat, const double *rate,
                                                               const uint8_t *clear_mask) {
-    const int e = blockIdx.x * A1_BLOCK + threadIdx.x;
-    if (e < n) a1_receive(k.c, st, n, e, q, qd, quat, rate, clear_mask);
+    int e, sub;
+    if (act_lane(n, e, sub)) a1_receive(k.c, st, n, e, sub, q, qd, quat, rate, clear_mask);
 }
 
 // ReceiveObservation of sub-step k and ApplyAction of sub-step k + 1 in one launch. A lane only ever reads ring entries it
-// wrote itself, in program order, so no fence is needed between the two halves.
+// wrote itself, in program order (the PD observation of a motor is made of that motor's own components), so no fence is
+// needed between the two halves; the ring position travels in registers.
 __global__ __launch_bounds__(A1_BLOCK) void a1_receive_apply_kernel(A1K k, mg_a1_actuator_state st, int n, const double *q,
                                                                     const double *qd, const double *quat, const double *rate,
                                                                     const double *command, const double *last_command,
                                                                     double lerp, double *torque) {
-    const int e = blockIdx.x * A1_BLOCK + threadIdx.x;
-    if (e >= n) return;
-    a1_receive(k.c, st, n, e, q, qd, quat, rate, nullptr);
-    a1_apply(k.c, st, n, e, command, last_command, lerp, torque);
+    int e, sub;
+    if (!act_lane(n, e, sub)) return;
+    const Ring ring = a1_receive(k.c, st, n, e, sub, q, qd, quat, rate, nullptr);
+    a1_apply(k.c, st, n, e, sub, ring, command, last_command, lerp, torque);
 }
 
 __global__ __launch_bounds__(A1_BLOCK) void a1_sensors_kernel(A1K k, mg_a1_actuator_state st, int n, double *angles,
@@ -670,7 +708,7 @@ extern "C" int mg_a1_apply_action(const mg_a1_actuator_config *cfg, int32_t n, c
     MG_REQUIRE_PTR(torque);
     mg::DeviceGuard guard(mg::device_of(st->history));
     A1K k{*cfg};
-    hipLaunchKernelGGL(a1_apply_action_kernel, dim3((n + A1_BLOCK - 1) / A1_BLOCK), dim3(A1_BLOCK), 0, (hipStream_t)stream,
+    hipLaunchKernelGGL(a1_apply_action_kernel, dim3(act_blocks(n)), dim3(A1_BLOCK), 0, (hipStream_t)stream,
                        k, *st, n, command, last_command, lerp, torque);
     return mg::check_launch("a1_apply_action_kernel");
 }
@@ -685,7 +723,7 @@ extern "C" int mg_a1_receive_observation(const mg_a1_actuator_config *cfg, int32
     MG_REQUIRE_PTR(rpy_rate);
     mg::DeviceGuard guard(mg::device_of(st->history));
     A1K k{*cfg};
-    hipLaunchKernelGGL(a1_receive_kernel, dim3((n + A1_BLOCK - 1) / A1_BLOCK), dim3(A1_BLOCK), 0, (hipStream_t)stream, k,
+    hipLaunchKernelGGL(a1_receive_kernel, dim3(act_blocks(n)), dim3(A1_BLOCK), 0, (hipStream_t)stream, k,
                        *st, n, q, qd, base_quat, rpy_rate, clear_mask);
     return mg::check_launch("a1_receive_kernel");
 }
@@ -841,7 +879,7 @@ extern "C" int mg_a1_receive_and_apply(const mg_a1_actuator_config *cfg, int32_t
     MG_REQUIRE_PTR(torque);
     mg::DeviceGuard guard(mg::device_of(st->history));
     A1K k{*cfg};
-    hipLaunchKernelGGL(a1_receive_apply_kernel, dim3((n + A1_BLOCK - 1) / A1_BLOCK), dim3(A1_BLOCK), 0, (hipStream_t)stream, k,
+    hipLaunchKernelGGL(a1_receive_apply_kernel, dim3(act_blocks(n)), dim3(A1_BLOCK), 0, (hipStream_t)stream, k,
                        *st, n, q, qd, base_quat, rpy_rate, command, last_command, lerp, torque);
     return mg::check_launch("a1_receive_apply_kernel");
 }

@@ -71,6 +71,9 @@ class A1GymEnv(object):
         self._lib = _lib.load()
         self.last_torques = None
         self._fusable = motor_control_mode is MotorControlMode.POSITION and motor_kp is None
+        # sub-steps since reset, on the device (exact in float64): the ETG's clock without a host value inside step(), so a
+        # step can be captured into a hipGraph (capture_step)
+        self._substeps_dev = torch.zeros(self.num_envs, dtype=torch.float64, device=self.device)
         self._configure_observation(dict(sensor_mode), bool(ETG), int(ETG_H), int(normal))
 
     def _configure_observation(self, mode, etg, etg_h, normal):
@@ -141,7 +144,8 @@ class A1GymEnv(object):
 
     def _env_step(self, action, reset_mask=None, d_yaw=None):
         """LocomotionGymEnv.step below the wrappers (locomotion_gym_env.py:461-546)."""
-        cmd, etg_obs = self.path.step(action, self.get_time_since_reset())
+        cmd, etg_obs = self.path.step(action, self._substeps_dev * self.robot.time_step)   # == get_time_since_reset()
+        self._substeps_dev += 13.0
         if hasattr(self.physics, "fused_step") and self._fusable:      # 13 sub-steps + PD model inside one physics launch
             self.last_torques = self.robot.StepFused(cmd, self.physics.fused_step)
         else:
@@ -158,6 +162,7 @@ class A1GymEnv(object):
         ObservationWrapper.reset (the first frame of an RNN history): the hidden step runs without it."""
         N, d = self.num_envs, self.device
         self.robot.Reset()
+        self._substeps_dev.zero_()
         self.robot.ReceiveObservation(*self.physics.reset(None))
         world, info = self.physics.world(), self._info()
         every = torch.ones(N, dtype=torch.bool, device=d)
@@ -168,6 +173,34 @@ class A1GymEnv(object):
         self.shaping.reset(world["base"], info["rot_mat"], info["footposition"])
         info.update(base=world["base"], real_contact=world["contact"])
         return obs, info
+
+    def capture_step(self, warmup=2):
+        """One `step(action)` as a hipGraph: the ~20 kernels of an env step (6 with a fused physics) are launch-bound at
+        moderate batch sizes. Every launch of step() goes to torch's current stream through the C ABI and nothing in it reads a
+        host value, so it captures as it stands. Returns `replay(action) -> (obs, reward, done, info)`; the outputs are the
+        graph's static tensors (overwritten by the next replay). Capturing runs `warmup + 1` real steps: call reset()
+        afterwards. Not for an env whose robot-level action filter still has to be initialised (first step after reset),
+        nor with a yaw target."""
+        d = self.device
+        static_action = torch.zeros(self.num_envs, 12, dtype=torch.float64, device=d)
+        side = torch.cuda.Stream(device=d)
+        side.wait_stream(torch.cuda.current_stream(d))
+        with torch.cuda.stream(side):
+            for _ in range(warmup):
+                self.step(static_action)
+        torch.cuda.current_stream(d).wait_stream(side)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            out = self.step(static_action)
+        robot, repeat = self.robot, 13
+
+        def replay(action):
+            static_action.copy_(action)
+            graph.replay()
+            robot._step_counter += repeat          # the host-side mirror of the device clock
+            return out
+        replay.graph = graph
+        return replay
 
     def step(self, action, d_yaw=None):
         obs, info = self._env_step(action, d_yaw=d_yaw)

@@ -176,3 +176,36 @@ def test_standin_robot_stands_on_the_task_terrain():
         heights[with_boxes] = float(info["base"][:, 2].mean())
     assert 0.22 + 0.2776 < heights[True] < 0.30 + 0.2776, heights
     assert heights[False] < heights[True] - 0.2, heights
+
+
+@pytest.mark.parametrize("fused", [True, False])
+def test_graph_replay_of_a_step_equals_eager_steps_bit_for_bit(fused):
+    """A1GymEnv.capture_step: one env step (ETG, 13 sub-steps on the engine, info, sensors, reward) replayed as a hipGraph
+    against the same env stepped eagerly — identical bits in observations, rewards, dones and the engine state, and the
+    device-side clock the ETG reads equals the host's get_time_since_reset()."""
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "examples", "a1_standin"))
+    from physics import StandinPhysics
+    n = 160
+    w = np.tile([[0.02], [0.0], [0.015]], (1, 20)) * np.sin(np.linspace(0, 2 * np.pi, 20))
+    rs = np.random.RandomState(4)
+    actions = [torch.as_tensor(rs.uniform(-0.1, 0.1, (n, 12)), device=DEV) for _ in range(8)]
+    runs = []
+    for graphed in (True, False):
+        phys = StandinPhysics(n, DEV, fused=fused)
+        env = metagym_amd.make("quadrupedal-v0", num_envs=n, physics=phys, device=DEV, ETG=1, ETG_w=w, ETG_b=np.zeros(3))
+        env.reset()
+        step = env.step
+        if graphed:
+            step = env.capture_step()
+            env.reset()
+        rec = []
+        for a in actions:
+            obs, reward, done, info = step(a)
+            assert float(env._substeps_dev[0]) * 0.002 == env.get_time_since_reset()
+            rec.append((obs.clone(), reward.clone(), done.clone(), phys.env.q.clone(), phys.env.pos.clone()))
+        runs.append(rec)
+    for k, (g, e) in enumerate(zip(*runs)):
+        for x, y in zip(g, e):
+            assert torch.equal(x, y), "step %d" % k
