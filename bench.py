@@ -592,7 +592,18 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
-        dist.init_process_group("gloo", rank=rank, world_size=world)   # CPU barrier only: no RCCL in this harness
+        # gloo's C++ side reports its peer count on STDOUT ("[Gloo] Rank 0 is connected to ..."): keep the one JSON line
+        # this script owes its caller alone there by pointing fd 1 at stderr while the context comes up
+        sys.stdout.flush()
+        saved_stdout = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            dist.init_process_group("gloo", rank=rank, world_size=world)   # CPU barrier only: no RCCL in this harness
+            dist.barrier()
+        finally:
+            sys.stdout.flush()
+            os.dup2(saved_stdout, 1)
+            os.close(saved_stdout)
 
     def barrier():
         if dist is not None:
