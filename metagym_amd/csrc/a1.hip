@@ -618,8 +618,8 @@ __global__ __launch_bounds__(A1_BLOCK) void a1_info_kernel(A1K k, mg_a1_actuator
 
 // K logged sub-step observations (mg_walker_params.substep_log) pushed at once; control observation refreshed at the end.
 __global__ __launch_bounds__(A1_BLOCK) void a1_receive_log_kernel(A1K k, mg_a1_actuator_state st, int n, const double *log, int K) {
-    const int e = blockIdx.x * A1_BLOCK + threadIdx.x;
-    if (e >= n) return;
+    int e, sub;
+    if (!act_lane(n, e, sub)) return;             // four lanes per robot, each pushing the components it owns
     const mg_a1_actuator_config &c = k.c;
     const size_t stride = (size_t)OD * n;
     int count = st.count[e], head = st.head[e];
@@ -628,27 +628,35 @@ __global__ __launch_bounds__(A1_BLOCK) void a1_receive_log_kernel(A1K k, mg_a1_a
         if (count < c.history_len) ++count;
         const double *src = log + (size_t)s * stride + e;
         double *slot = st.history + (size_t)head * stride + e;
-        double in[OD];
+        double in[ACT_COMPS];
 #pragma unroll
-        for (int i = 0; i < OD; ++i) in[i] = src[(size_t)i * n];
+        for (int q = 0; q < ACT_COMPS; ++q) {
+            const int comp = act_comp(sub, q);
+            in[q] = comp >= 0 ? src[(size_t)comp * n] : 0.0;
+        }
 #pragma unroll
-        for (int i = 0; i < OD; ++i) slot[(size_t)i * n] = in[i];
+        for (int q = 0; q < ACT_COMPS; ++q) {
+            const int comp = act_comp(sub, q);
+            if (comp >= 0) slot[(size_t)comp * n] = in[q];
+        }
         if (s == K - 1)
 #pragma unroll
-            for (int i = 0; i < NM; ++i) st.observed_torque[(size_t)i * n + e] = in[2 * NM + i];
+            for (int m = 0; m < ACT_MOTORS; ++m)      // act_comp(sub, 2 * ACT_MOTORS + m) = the torque of motor 3 sub + m
+                st.observed_torque[(size_t)(ACT_MOTORS * sub + m) * n + e] = in[2 * ACT_MOTORS + m];
     }
-    st.count[e] = count;
-    st.head[e] = head;
+    if (sub == 0) { st.count[e] = count; st.head[e] = head; }
     const double lat = c.control_latency_env ? c.control_latency_env[e] : c.control_latency;
     const Delay d = delayed(lat, c.time_step, count, head, c.history_len);
-    constexpr int CH = 11;
-    for (int c0 = 0; c0 < OD; c0 += CH) {
-        double v[CH];
+    double v[ACT_COMPS];
 #pragma unroll
-        for (int i = 0; i < CH; ++i) v[i] = c0 + i < OD ? blend(d, st.history, stride, c0 + i, n, e) : 0.0;
+    for (int q = 0; q < ACT_COMPS; ++q) {
+        const int comp = act_comp(sub, q);
+        v[q] = comp >= 0 ? blend(d, st.history, stride, comp, n, e) : 0.0;
+    }
 #pragma unroll
-        for (int i = 0; i < CH; ++i)
-            if (c0 + i < OD) st.control_obs[(size_t)(c0 + i) * n + e] = v[i];
+    for (int q = 0; q < ACT_COMPS; ++q) {
+        const int comp = act_comp(sub, q);
+        if (comp >= 0) st.control_obs[(size_t)comp * n + e] = v[q];
     }
 }
 
@@ -891,7 +899,7 @@ extern "C" int mg_a1_receive_log(const mg_a1_actuator_config *cfg, int32_t n, co
     if (n_substeps < 1) return mg::set_error(MG_ERR_BAD_SIZE, "n_substeps=%d", n_substeps);
     mg::DeviceGuard guard(mg::device_of(st->history));
     A1K k{*cfg};
-    hipLaunchKernelGGL(a1_receive_log_kernel, dim3((n + A1_BLOCK - 1) / A1_BLOCK), dim3(A1_BLOCK), 0, (hipStream_t)stream, k, *st,
+    hipLaunchKernelGGL(a1_receive_log_kernel, dim3(act_blocks(n)), dim3(A1_BLOCK), 0, (hipStream_t)stream, k, *st,
                        n, log, n_substeps);
     return mg::check_launch("a1_receive_log_kernel");
 }
