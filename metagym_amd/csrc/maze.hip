@@ -830,6 +830,10 @@ __global__ __launch_bounds__(MZ_BLOCK) void maze3d_step_kernel(mg_maze_tasks T, 
         // column-major walk: column k's record is broadcast ONCE (11 v_readlane + 4 converts) and then
         // reused by all V/64 row chunks; the per-row constants come from the LDS row table
         const uint32_t px_bytes = vk.obs_u8 ? 3u : 12u;
+#ifdef MG_MAZE3D_KNOCKOUT_PIXELS      /* timing experiment only: everything but the pixel loop */
+        if (mine.w_span == 0x7fffffff) ((int *)obs)[e] = 1;
+        continue;
+#endif
         for (int k = 0; k < ncols; ++k) {
             const ColRec wc = bcast(mine, k);
             const int col = cbase + k;
