@@ -35,7 +35,7 @@ class StandinPhysics(object):
                                   solver_iterations=solver_iterations, self_collision=False)
         self.env.set_task([load_mjcf(XML, foot_names=FEET)])
         self.n, self.device = int(num_envs), torch.device(device)
-        self._init = np.tile(INIT_MOTOR_ANGLES, (self.n, 1))
+        self._init = torch.as_tensor(np.tile(INIT_MOTOR_ANGLES, (self.n, 1)), dtype=torch.float64, device=self.device)
         if fused:                                  # A1GymEnv takes the one-launch path when the physics offers it
             self.fused_step = self._fused_step
 

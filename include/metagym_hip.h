@@ -514,8 +514,9 @@ typedef struct mg_a1_actuator_state {
 int mg_a1_apply_action(const mg_a1_actuator_config *cfg, int32_t n_envs, const mg_a1_actuator_state *state,
                        const double *command, const double *last_command, double lerp, double *torque, void *stream);
 /* q, qd: DEVICE f64 [12][N] true motor angles / rates; base_quat [4][N] (x y z w, relative to the initial
- * orientation); rpy_rate [3][N] angular velocity in the body frame. clear_mask: DEVICE u8 [N] or NULL — robots whose
- * history is emptied first (Minitaur.Reset, minitaur.py:437). */
+ * orientation); rpy_rate [3][N] angular velocity in the body frame. clear_mask: DEVICE u8 [N] or NULL — per robot 0 = push,
+ * 1 = empty the history first (Minitaur.Reset, minitaur.py:437), 2 = leave this robot untouched (the first observation
+ * after a reset of PART of the batch: the others are between two sub-steps and must not see a second push). */
 int mg_a1_receive_observation(const mg_a1_actuator_config *cfg, int32_t n_envs, const mg_a1_actuator_state *state,
                               const double *q, const double *qd, const double *base_quat, const double *rpy_rate,
                               const uint8_t *clear_mask, void *stream);
@@ -620,7 +621,7 @@ typedef struct mg_a1_sensor_state {
     double *last_angle;             /* DEVICE [12][N] */
     int32_t *first;                 /* DEVICE [N] bit 0: IMU first_time, bit 1: MotorAngleAcc first_time */
 } mg_a1_sensor_state;
-/* One observation per robot. reset_mask (u8 [N] or NULL = none): robots that were just reset — sensor.reset() + on_reset
+/* One observation per robot. reset_mask (u8 [N] or NULL = none; 2 = skip this robot, its sensor state and obs row stay): robots that were just reset — sensor.reset() + on_reset
  * (locomotion_gym_env.py:231-232,426-427) instead of on_step (:521-522). base [3][N] (GetBasePosition), rpy [3][N]
  * (GetBaseRollPitchYaw), drpy [3][N], motor_angles [12][N] (mg_a1_sensors), contact [4][N] (0 / 1). obs: f64 [N][37]. */
 int mg_a1_observation(const mg_a1_sensor_config *cfg, int32_t n_envs, const mg_a1_sensor_state *state, const double *base,

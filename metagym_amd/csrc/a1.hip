@@ -148,7 +148,9 @@ __device__ __forceinline__ Ring a1_receive(const mg_a1_actuator_config &c, const
                                            const uint8_t *clear_mask) {
     const size_t stride = (size_t)OD * n;
     int count = st.count[e], head = st.head[e];
-    if (clear_mask != nullptr && clear_mask[e]) count = 0;                          // _observation_history.clear()
+    const int cm = clear_mask != nullptr ? clear_mask[e] : 0;
+    if (cm == 2) return Ring{count, head};                                          // not this robot's call (partial reset)
+    if (cm == 1) count = 0;                                                         // _observation_history.clear()
     head = count == 0 ? 0 : (head + 1 == c.history_len ? 0 : head + 1);             // appendleft
     if (count < c.history_len) ++count;
     double *slot = st.history + (size_t)head * stride + e;
@@ -485,7 +487,9 @@ __global__ __launch_bounds__(A1_BLOCK) void a1_observation_kernel(mg_a1_sensor_c
     const int e = blockIdx.x * A1_BLOCK + threadIdx.x;
     if (e >= n) return;
     double *o = obs + (size_t)e * MG_A1_SENSOR_OBS_DIM;
-    const bool was_reset = reset_mask != nullptr && reset_mask[e];
+    const int rm = reset_mask != nullptr ? reset_mask[e] : 0;
+    if (rm == 2) return;                                                          // not this robot's call (partial reset): state and row untouched
+    const bool was_reset = rm == 1;
     int first = was_reset ? 3 : st.first[e];                                      // IMUSensor.reset / MotorAngleAccSensor.reset
     double cur[3], last[3], yaw_last, yaw_cur;
     for (int i = 0; i < 3; ++i) cur[i] = base[(size_t)i * n + e];

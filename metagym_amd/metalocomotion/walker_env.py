@@ -222,7 +222,10 @@ class WalkerBatchEnv(object):
             self.np_random = np.random.RandomState(seed)
         if joint_noise is None:                                    # walker_base.py:15, per env in joint order
             joint_noise = self.np_random.uniform(low=-0.1, high=0.1, size=(N, self.n_joints))
-        jn = torch.as_tensor(np.ascontiguousarray(np.asarray(joint_noise, np.float64).T), device=dev)
+        if isinstance(joint_noise, torch.Tensor):                  # a device tensor stays on the device (no host trip: capturable)
+            jn = joint_noise.to(device=dev, dtype=torch.float64).t().contiguous()
+        else:
+            jn = torch.as_tensor(np.ascontiguousarray(np.asarray(joint_noise, np.float64).T), device=dev)
         assert jn.shape == (self.n_joints, N)
         m = None
         if mask is not None:

@@ -139,10 +139,11 @@ class A1Actuators(object):
             self._observed_torque.zero_()
         else:
             m = torch.as_tensor(mask, device=self.device).bool()
-            self._count[m] = 0
-            self._observed_torque[:, m] = 0.0
-        self._step_counter = 0
-        self._last_action = None
+            self._count.mul_((~m).to(self._count.dtype))                   # (no boolean indexing: nothing here syncs with the host)
+            self._observed_torque.mul_((~m).to(torch.float64))
+        if mask is None:                # the host-side scalars describe the batch as a whole: a partial reset leaves them
+            self._step_counter = 0
+            self._last_action = None
         if self._action_filter is not None:                 # _ResetActionFilter minitaur.py:1445-1446
             self._action_filter.reset(mask)
 
@@ -177,19 +178,23 @@ class A1Actuators(object):
         _lib.check(rc, "mg_a1_receive_and_apply")
         return self._torque.t()
 
-    def ReceiveObservation(self, motor_angles, motor_velocities, base_orientation, base_rpy_rate, clear_mask=None):
+    def ReceiveObservation(self, motor_angles, motor_velocities, base_orientation, base_rpy_rate, clear_mask=None, only_mask=None):
         """The four arguments are what the reference reads from Bullet at this point (getJointStates, base orientation
-        relative to the initial one, angular velocity in the body frame; minitaur.py:1190-1200, :840-872)."""
+        relative to the initial one, angular velocity in the body frame; minitaur.py:1190-1200, :840-872). `only_mask`: the
+        first observation after Reset(mask) of PART of the batch — every other robot is left exactly as it is."""
         q, qd = self._soa(motor_angles, NUM_MOTORS), self._soa(motor_velocities, NUM_MOTORS)
         quat, rate = self._soa(base_orientation, 4), self._soa(base_rpy_rate, 3)
         cm = None if clear_mask is None else torch.as_tensor(clear_mask, device=self.device).to(torch.uint8).contiguous()
+        if only_mask is not None:       # kernel mask values: 0 push, 1 clear + push, 2 untouched
+            om = torch.as_tensor(only_mask, device=self.device).bool()
+            cm = torch.where(om, torch.ones_like(om, dtype=torch.uint8), torch.full_like(om, 2, dtype=torch.uint8)).contiguous()
         with torch.cuda.device(self.device):
             rc = self._lib.mg_a1_receive_observation(C.byref(self._cfg), self.num_envs, C.byref(self._st), _lib.ptr(q),
                                                      _lib.ptr(qd), _lib.ptr(quat), _lib.ptr(rate), _lib.ptr(cm),
                                                      _lib.current_stream(self.device))
         _lib.check(rc, "mg_a1_receive_observation")
 
-    def Step(self, action, physics, control_mode=None):
+    def Step(self, action, physics, control_mode=None, filter_init_mask=None):
         """Minitaur.Step: `action_repeat` x (ProcessAction, ApplyAction, physics(torques), ReceiveObservation).
         Returns the applied torques `[action_repeat, num_envs, 12]`."""
         if control_mode is not None:
@@ -198,6 +203,8 @@ class A1Actuators(object):
         if self._action_filter is not None:                 # _FilterAction minitaur.py:1448-1457
             if self._step_counter == 0:
                 self._action_filter.init_history(self.GetMotorAngles())
+            elif filter_init_mask is not None:              # first step of the robots that were just reset
+                self._action_filter.init_history(self.GetMotorAngles(), filter_init_mask)
             action = self._action_filter.filter(action)
         act = self._soa(action, k)
         torques = []
@@ -215,7 +222,7 @@ class A1Actuators(object):
         self._last_action = act
         return torch.stack(torques)
 
-    def StepFused(self, action, fused_physics):
+    def StepFused(self, action, fused_physics, filter_init_mask=None):
         """Minitaur.Step when the physics can run the whole action-repeat loop in one launch with the PD motor model evaluated
         inside it (`fused_physics(command_soa, actuators) -> log`, float64 `[action_repeat, 43, num_envs]`: one true
         observation per sub-step, torques included — e.g. WalkerBatchEnv.step_actuated). POSITION mode, pd latency 0, no
@@ -228,6 +235,8 @@ class A1Actuators(object):
         if self._action_filter is not None:
             if self._step_counter == 0:
                 self._action_filter.init_history(self.GetMotorAngles())
+            elif filter_init_mask is not None:
+                self._action_filter.init_history(self.GetMotorAngles(), filter_init_mask)
             action = self._action_filter.filter(action)
         act = self._soa(action, NUM_MOTORS)
         log = fused_physics(act, self)

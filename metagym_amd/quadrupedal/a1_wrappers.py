@@ -63,12 +63,16 @@ class EtgActionPath(object):
                                             _lib.ptr(tt), _lib.ptr(command), _lib.ptr(etg_obs), _lib.current_stream(self.device))
         _lib.check(rc, "mg_a1_etg_action")
 
-    def reset(self, t=0.0):
-        """ETGWrapper.reset (:246-259): returns info["ETG_obs"] `[num_envs, H]` (None when the ETG is off)."""
+    def reset(self, t=0.0, mask=None):
+        """ETGWrapper.reset (:246-259): returns info["ETG_obs"] `[num_envs, H]` (None when the ETG is off). `mask`: only these
+        robots' ETG state is refreshed."""
         if not self._cfg.enabled:
             return None
         obs = torch.empty(self.H, self.num_envs, dtype=torch.float64, device=self.device)
+        keep = None if mask is None else self.last_ETG_act.clone()
         self._launch(None, t, None, obs)
+        if keep is not None:
+            self.last_ETG_act.copy_(torch.where(torch.as_tensor(mask, device=self.device).bool(), self.last_ETG_act, keep))
         return obs.t()
 
     def step(self, action, t):
@@ -236,6 +240,10 @@ class ActionFilter(object):
     def init_history(self, x, mask=None):
         """ActionFilter.init_history (action_filter.py:95-99) for the robots in `mask` (None = all)."""
         xs = _soa(x, self.num_envs, 12, self.device)
-        sel = slice(None) if mask is None else torch.as_tensor(mask, device=self.device).bool()
-        self.xhist[:, :, sel] = xs[:, sel]
-        self.yhist[:, :, sel] = xs[:, sel]
+        if mask is None:
+            self.xhist[:] = xs
+            self.yhist[:] = xs
+        else:                           # torch.where, not boolean indexing: no host sync
+            m = torch.as_tensor(mask, device=self.device).bool()
+            self.xhist.copy_(torch.where(m, xs, self.xhist))
+            self.yhist.copy_(torch.where(m, xs, self.yhist))

@@ -190,11 +190,11 @@ def test_graph_replay_of_a_step_equals_eager_steps_bit_for_bit(fused):
     n = 160
     w = np.tile([[0.02], [0.0], [0.015]], (1, 20)) * np.sin(np.linspace(0, 2 * np.pi, 20))
     rs = np.random.RandomState(4)
-    actions = [torch.as_tensor(rs.uniform(-0.1, 0.1, (n, 12)), device=DEV) for _ in range(8)]
-    runs = []
+    actions = [torch.as_tensor(rs.uniform(-0.1, 0.1, (n, 12)) * (1 + 20 * (np.arange(n) % 4 == 0))[:, None], device=DEV) for _ in range(14)]
+    runs = []          # (every fourth robot gets offsets that make it fall: the fused auto-reset runs inside the captured step)
     for graphed in (True, False):
         phys = StandinPhysics(n, DEV, fused=fused)
-        env = metagym_amd.make("quadrupedal-v0", num_envs=n, physics=phys, device=DEV, ETG=1, ETG_w=w, ETG_b=np.zeros(3))
+        env = metagym_amd.make("quadrupedal-v0", num_envs=n, physics=phys, device=DEV, ETG=1, ETG_w=w, ETG_b=np.zeros(3), auto_reset=True)
         env.reset()
         step = env.step
         if graphed:
@@ -203,9 +203,73 @@ def test_graph_replay_of_a_step_equals_eager_steps_bit_for_bit(fused):
         rec = []
         for a in actions:
             obs, reward, done, info = step(a)
-            assert float(env._substeps_dev[0]) * 0.002 == env.get_time_since_reset()
+            assert float(env._substeps_dev[1]) * 0.002 == env.get_time_since_reset()      # (robot 1 is never reset)
             rec.append((obs.clone(), reward.clone(), done.clone(), phys.env.q.clone(), phys.env.pos.clone()))
         runs.append(rec)
+    assert any(bool(r[2].any()) for r in runs[0]), "no episode ended: the auto-reset path was not exercised"
     for k, (g, e) in enumerate(zip(*runs)):
         for x, y in zip(g, e):
             assert torch.equal(x, y), "step %d" % k
+
+
+@pytest.mark.parametrize("fused", [True, False])
+def test_partial_reset_inside_a_step_equals_a_fresh_reset_for_those_robots(fused):
+    """step(reset_mask=m): the robots in m run A1GymEnv.reset() inside the step (its hidden zero-action env step IS this step),
+    the others must not notice. Against two witnesses on the same deterministic physics: an env that is never reset (the
+    untouched robots, bit for bit) and a fresh env that does a full reset() at that moment (the reset robots: the observation
+    reset() returns, then every later observation / reward / done, bit for bit)."""
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "examples", "a1_standin"))
+    from physics import StandinPhysics
+    n, k_reset, k_end = 96, 5, 10
+    w = np.tile([[0.02], [0.0], [0.015]], (1, 20)) * np.sin(np.linspace(0, 2 * np.pi, 20))
+    rs = np.random.RandomState(9)
+    actions = [torch.as_tensor(rs.uniform(-0.1, 0.1, (n, 12)), device=DEV) for _ in range(k_end)]
+    m = torch.zeros(n, dtype=torch.bool, device=DEV)
+    m[::3] = True
+
+    def make():
+        env = metagym_amd.make("quadrupedal-v0", num_envs=n, physics=StandinPhysics(n, DEV, fused=fused), device=DEV, ETG=1, ETG_w=w,
+                               ETG_b=np.zeros(3), sensor_mode={"dis": 1, "motor": 1, "imu": 1, "contact": 1, "footpose": 0, "ETG": 1,
+                                                               "RNN": {"time_steps": 2, "time_interval": 2, "mode": "stack"}})
+        return env
+
+    a_env, never, fresh = make(), make(), make()
+    a_env.reset(); never.reset()
+    for k in range(k_end):
+        if k == k_reset:
+            out = a_env.step(actions[k], reset_mask=m)
+            obs_f, _ = fresh.reset()
+            assert torch.equal(out[0][m], obs_f[m]), "the observation reset() returns"
+            assert float(out[1][m].abs().max()) == 0.0 and not bool(out[2][m].any()) and bool(out[3]["reset"][m].all())
+        else:
+            out = a_env.step(actions[k])
+            if k > k_reset:
+                of, rf, df, _ = fresh.step(actions[k])
+                assert torch.equal(out[0][m], of[m]) and torch.equal(out[1][m], rf[m]) and torch.equal(out[2][m], df[m]), "reset robots, step %d" % k
+        on, rn, dn, _ = never.step(actions[k])
+        assert torch.equal(out[0][~m], on[~m]) and torch.equal(out[1][~m], rn[~m]) and torch.equal(out[2][~m], dn[~m]), "untouched robots, step %d" % k
+
+
+def test_auto_reset_restarts_finished_robots_without_a_host_round_trip():
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "examples", "a1_standin"))
+    from physics import StandinPhysics
+    n = 64
+    env = metagym_amd.make("quadrupedal-v0", num_envs=n, physics=StandinPhysics(n, DEV), device=DEV, auto_reset=True)
+    env.reset()
+    rs = np.random.RandomState(2)
+    wild = torch.as_tensor(rs.uniform(-2.5, 2.5, (n, 12)), device=DEV)        # large offsets: robots fall over and terminate
+    calm = torch.zeros(n, 12, dtype=torch.float64, device=DEV)
+    ended = torch.zeros(n, dtype=torch.bool, device=DEV)
+    prev_done = torch.zeros(n, dtype=torch.bool, device=DEV)
+    for k in range(60):
+        a = torch.where((torch.arange(n, device=DEV) % 2 == 0).reshape(-1, 1), wild, calm)
+        obs, reward, done, info = env.step(a)
+        assert torch.isfinite(obs).all()
+        assert torch.equal(info["reset"], prev_done)                           # exactly the robots that ended one step earlier
+        ended |= done
+        prev_done = done.clone()
+    assert bool(ended[0::2].any()) and not bool(ended[1::2].any())
