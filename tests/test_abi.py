@@ -151,3 +151,36 @@ def test_public_header_is_plain_c99(tmp_path):
     out = subprocess.run([gcc, "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", os.path.join(root, "include"),
                           "-c", str(src), "-o", str(tmp_path / "use_header.o")], capture_output=True, text=True)
     assert out.returncode == 0, out.stderr
+
+
+def test_new_round2_entry_points_validate_before_they_launch():
+    """mg_a1_observation_extras and the walker's terrain parameters: wrong arguments are error codes with a message, decided
+    on the host before any device call (so this runs without a GPU)."""
+    import ctypes as C
+    from metagym_amd import _lib
+    lib = _lib.load()
+    fake = C.create_string_buffer(64)
+    p = C.c_void_p(C.addressof(fake))
+    assert lib.mg_a1_observation_extras(0, 1, 0, 20, p, p, p, None, p, None) == -1002                  # n_envs
+    assert lib.mg_a1_observation_extras(4, 0, 0, 20, p, p, p, None, p, None) == -1003 and b"flags" in lib.mg_last_error()
+    assert lib.mg_a1_observation_extras(4, 8, 0, 20, p, p, p, None, p, None) == -1003                  # unknown flag bit
+    assert lib.mg_a1_observation_extras(4, _lib.A1_EXTRA_ETG_OBS, 0, 99, p, p, p, None, p, None) == -1002 and b"etg_h" in lib.mg_last_error()
+    assert lib.mg_a1_observation_extras(4, _lib.A1_EXTRA_ETG, 0, 20, None, p, p, None, p, None) == -1001 and b"etg_act" in lib.mg_last_error()
+    assert lib.mg_a1_observation_extras(4, _lib.A1_EXTRA_YAW, 0, 20, None, None, None, None, p, None) == -1001 and b"pose" in lib.mg_last_error()
+    # terrain boxes: a negative count, a NULL table, the lane mapping
+    tp = _lib.WalkerTopology()
+    tp.n_bodies, tp.n_joints, tp.n_spheres, tp.n_feet = 2, 1, 1, 0
+    tp.body_parent[0], tp.body_parent[1] = -1, 0
+    ms = _lib.WalkerModels()
+    ms.table, ms.n_tasks, ms.model_stride = C.addressof(fake), 1, 25 * 2 + 12 + 4
+    prm = _lib.WalkerParams()
+    prm.time_step, prm.frame_skip, prm.solver_iterations, prm.mapping = 0.005, 4, 5, 1
+    st = _lib.WalkerState()
+    for name, _ in _lib.WalkerState._fields_:
+        setattr(st, name, C.addressof(fake))
+    prm.n_terrain_boxes = -1
+    assert lib.mg_walker_step(tp, ms, prm, 4, st, p, p, p, None, p, None) == -1002 and b"terrain" in lib.mg_last_error()
+    prm.n_terrain_boxes, prm.terrain = 3, None
+    assert lib.mg_walker_step(tp, ms, prm, 4, st, p, p, p, None, p, None) == -1001
+    prm.terrain, prm.mapping = C.addressof(fake), 0
+    assert lib.mg_walker_step(tp, ms, prm, 4, st, p, p, p, None, p, None) == -1004 and b"wave mapping" in lib.mg_last_error()
