@@ -356,6 +356,49 @@ def fuzz_a1(n_cfg, seed):
     return bad
 
 
+def fuzz_terrain(n_cfg, seed):
+    """metagym_amd/quadrupedal/terrain.py (the product's restatement — a host-side data builder, checked here against the
+    LIVE reference terrain module on a recording pybullet): random modes, parameters, env vectors and np.random seeds."""
+    import gen_golden_a1 as ga
+    from gen_golden_a1_terrain import Recorder
+    ga.import_reference()
+    from metagym.quadrupedal.envs.utilities import terrain as ref
+    from metagym_amd.quadrupedal import terrain as ours
+    rs = np.random.RandomState(seed + 77)
+    bad = boxes = 0
+    modes = ["stair-fix", "stair-var", "downstair", "slope", "special", "random", "upstair-random", "downstair-random", "upslope-random",
+             "downslope-random", "balance_beam", "gallop", "hurdle", "cave"]
+    for c in range(n_cfg):
+        mode = modes[rs.randint(len(modes))]
+        kw = dict(mode=mode, stepwidth=float(rs.uniform(0.05, 0.6)), stepheight=float(rs.uniform(0.02, 0.3)),
+                  slope=float(rs.uniform(-0.5, 0.5)), stepnum=int(rs.randint(1, 45)))
+        if mode == "special":
+            vecs = []
+            for _ in range(rs.randint(1, 14)):
+                v = np.zeros(7)
+                h = rs.randint(5)
+                if h < 4:
+                    v[h] = 1
+                v[4], v[5], v[6] = rs.uniform(0.05, 0.5), rs.uniform(0.03, 0.12), rs.uniform(0.2, 0.4)
+                vecs.append(v)
+            kw["env_vecs"] = vecs
+        s_ = int(rs.randint(1 << 30))
+        ref.p = rec = Recorder()
+        np.random.seed(s_)
+        h_ref, info_ref = ref.upstair_terrain(**{k: ([v.copy() for v in val] if k == "env_vecs" else val) for k, val in kw.items()})
+        h_our, info_our, b_our = ours.upstair_terrain(rng=np.random.RandomState(s_), **kw)
+        want = np.array(rec.bodies, dtype=np.float64).reshape(-1, 11)
+        want[np.isnan(want[:, 10]), 10] = ours.DEFAULT_FRICTION
+        got = np.array([list(b.half_extents) + list(b.position) + list(b.quaternion) + [b.friction] for b in b_our], dtype=np.float64).reshape(-1, 11)
+        flat = lambda info: np.array([[r[0], r[1]] + [float(x) for x in r[2]] for r in info], dtype=np.float64).reshape(-1, 9)
+        ok = (got.shape == want.shape and np.array_equal(got.view(np.uint64), want.view(np.uint64)) and float(h_ref) == float(h_our)
+              and np.array_equal(flat(info_ref).view(np.uint64), flat(info_our).view(np.uint64)))
+        bad += not ok
+        boxes += len(want)
+    print(json.dumps({"a1_terrain_configs": n_cfg, "boxes": boxes, "configs_with_any_difference": bad}))
+    return bad
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--quad", type=int, default=60)
@@ -364,12 +407,13 @@ def main():
     ap.add_argument("--maze2", type=int, default=40)
     ap.add_argument("--sampler", type=int, default=40)
     ap.add_argument("--a1", type=int, default=40)
+    ap.add_argument("--terrain", type=int, default=60)
     ap.add_argument("--seed", type=int, default=0)
     args = ap.parse_args()
     gym = gen_golden._import_reference()
     bad = (fuzz_quadrotor(gym, args.quad, args.seed) + fuzz_quadrotor_tasks(gym, args.tasks, args.seed) +
            fuzz_maze(gym, args.maze, args.seed) + fuzz_maze_2d_and_continuous(gym, args.maze2, args.seed) +
-           fuzz_sampler(gym, args.sampler, args.seed) + fuzz_a1(args.a1, args.seed))
+           fuzz_sampler(gym, args.sampler, args.seed) + fuzz_a1(args.a1, args.seed) + fuzz_terrain(args.terrain, args.seed))
     sys.exit(1 if bad else 0)
 
 
