@@ -326,6 +326,45 @@ def from_profiles(n, launch_s):
     return out
 
 
+def north_star_quadrotor(dev, sizes=(131072, 1048576), steps=60, warmup=10):
+    """north_star's own configuration — Quadrotor hovering_control at 2^20 parallel envs on 8 GPUs, i.e. 2^17 per GPU —
+    and the whole 2^20 batch on ONE GPU, through the same QuadrotorShard (staggered clocks, steady-state pre-roll, fused
+    auto-reset) as the headline. Both roofline fractions: HBM on the 317 B/env-step of SURVEY.md §8(d), and VALU issue
+    from the per-wave instruction count of the committed PMC pass (a wave-instruction holds a SIMD for >= 4 cycles)."""
+    out = {}
+    ipw, src = None, None
+    rnd = latest_profile_round()
+    for r in ([rnd] if rnd else []) + ["r02"]:
+        try:
+            ipw = float(json.load(open(os.path.join(ROOT, "profiles", r, "pmc_summary.json")))["quadrotor_step_kernel"]["valu_insts_per_wave"])
+            src = "profiles/%s/pmc_summary.json" % r
+            break
+        except Exception:
+            continue
+    for n in sizes:
+        plan = shard_plan(0, 1, n, "quadrotor")
+        q = QuadrotorShard(dev, plan, n)
+        ep0 = q.episodes()
+        s = _time_steps(q.step, steps, warmup)
+        ep1 = q.episodes()
+        gbs = BYTES_PER_ENV_STEP * n / s / 1e9
+        e = {"env_steps_per_s": n / s, "us_per_launch": s * 1e6,
+             "done_frac_per_step": (ep1 - ep0) / float(n * (steps + warmup)),
+             "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+                          "algorithmic_bytes_per_launch": BYTES_PER_ENV_STEP * n}}
+        if ipw:
+            waves = (n + 63) // 64
+            peak_issue = 1024 * 2.4e9 / 4.0
+            e["valu_issue"] = {"valu_insts_per_wave": ipw, "waves_per_launch": waves, "waves_per_simd": waves / 1024.0,
+                               "achieved_wave_insts_per_s": ipw * waves / s, "peak_wave_insts_per_s": peak_issue,
+                               "frac": ipw * waves / s / peak_issue, "source": src,
+                               "note": "instruction count from the committed PMC pass, launch duration from this run"}
+        out["north_star_quadrotor_hovering_%denvs_1gpu" % n] = e
+        del q
+        torch.cuda.empty_cache()
+    return out
+
+
 def secondary_workloads(dev):
     """The other BASELINE configs on this GPU, each a few dozen launches (reported next to the headline,
     never folded into `value`): C3 MetaMazeDiscrete3D 9x9 at the registered 256x256 resolution with
@@ -333,6 +372,10 @@ def secondary_workloads(dev):
     import metagym_amd
     from metagym_amd.metamaze import MazeTaskSampler
     out = {}
+    try:
+        out.update(north_star_quadrotor(dev))
+    except Exception as e:
+        out["north_star_error"] = repr(e)
     try:
         n, res = 16384, 256
         for cont, ident, key in ((False, "meta-maze-discrete-3D-v0", "C3_maze3d_discrete_9x9_256x256_16384envs"),
@@ -389,13 +432,7 @@ def secondary_workloads(dev):
         quad, maze = QuadrotorShard(dev, plan, n), MazeShard(dev, plan, n)
         s_q = _time_steps(quad.step, 40, 5)
         s_m = _time_steps(maze.step, 40, 5)
-        st_q, st_m = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)
-
-        def both(i):
-            with torch.cuda.stream(st_q):
-                quad.step(i)
-            with torch.cuda.stream(st_m):
-                maze.step(i)
+        both = MixedStep(dev, quad, maze)
         for i in range(5):
             both(i)
         torch.cuda.synchronize()
@@ -471,7 +508,8 @@ def secondary_workloads(dev):
 
         class NullPhysics(object):
             def __init__(self, n):
-                self.s = tuple(x[:n].t().contiguous() for x in (q, qd, quat, rate))      # SoA [k][N]: taken without a copy
+                from metagym_amd.quadrupedal import SoA
+                self.s = tuple(SoA(x[:n].t().contiguous()) for x in (q, qd, quat, rate))  # [k][N], declared: taken without a copy
                 self.w = dict(base=torch.zeros(n, 3, **f64), contact=torch.ones(n, 4, **f64),
                               bad=torch.zeros(n, dtype=torch.int32, device=dev))
             def reset(self, mask): return self.s
@@ -500,6 +538,15 @@ def secondary_workloads(dev):
 
 
 # ---------------------------------------------------------------------------------------- multi-GPU plumbing
+def gather_walls(dist, wall):
+    """Every rank's wall time of the timed region (CPU tensors over gloo), for the record."""
+    if dist is None:
+        return [wall]
+    ws = [torch.zeros(1, dtype=torch.float64) for _ in range(dist.get_world_size())]
+    dist.all_gather(ws, torch.tensor([wall], dtype=torch.float64))
+    return [float(w.item()) for w in ws]
+
+
 def aggregate_throughput(dist, wall, envs_per_rank, steps):
     """Whole-job env-steps/s: every rank stepped `envs_per_rank` envs `steps` times; the job took as
     long as its slowest rank. `dist` is torch.distributed (initialised, any backend) or None for one process.
@@ -536,27 +583,44 @@ def shard_plan(rank, world, envs_per_rank, workload="quadrotor", job_seed=1000, 
 class QuadrotorShard:
     """C2 on one GPU: this rank's quadrotors + resident action batches."""
 
-    def __init__(self, dev, plan, n):
+    def __init__(self, dev, plan, n, preroll=None, nt=1000):
         import metagym_amd
         self.n = n
-        self.env = metagym_amd.make("quadrotor-v0", num_envs=n, device=dev, task="hovering_control",
+        self.env = metagym_amd.make("quadrotor-v0", num_envs=n, device=dev, task="hovering_control", nt=nt,
                                     auto_reset=True, seed=plan["job_seed"], env_id_base=plan["env_id_base"])
         self.env.reset(seed=plan["reset_seed"])
         g = torch.Generator(device=dev)
         g.manual_seed(plan["action_seed"])
         self.actions = torch.rand(N_ACTION_BATCHES, n, 4, device=dev, generator=g) * 14.9 + 0.1
+        # Steady state before anything is timed: a fresh batch has every env at ct = 0, so a short timed region
+        # would contain no episode end at all (and none of the fused in-launch reset work). Episode clocks start
+        # staggered over [0, nt) by GLOBAL env id (shard-invariant) and the batch is rolled `preroll` untimed
+        # steps (default nt: every env has ended at least once, by the clock or on the floor).
+        nt = int(self.env.nt)
+        ids = torch.arange(n, device=dev, dtype=torch.int64) + int(plan["env_id_base"])
+        sd = self.env.state_dict()
+        sd["ct"] = ((ids * 977) % nt).to(torch.int32)
+        self.env.load_state_dict(sd)
+        self.preroll_steps = nt if preroll is None else int(preroll)
+        for i in range(self.preroll_steps):
+            self.step(i)
+        torch.cuda.synchronize(dev)
 
     def step(self, i):
         self.env.step(self.actions[i % N_ACTION_BATCHES])
+
+    def episodes(self):
+        """Total number of in-launch restarts so far (sum of the per-env episode counters)."""
+        return int(self.env.episode.to(torch.int64).sum().item())
 
 
 class MazeShard:
     """C5's MetaMaze3D half on one GPU: 9x9 mazes, 64x64 int32 frames, SURVIVAL, fused auto-reset."""
 
-    def __init__(self, dev, plan, n, res=64):
+    def __init__(self, dev, plan, n, res=64, max_steps=200):
         import metagym_amd
         self.n = n
-        self.env = metagym_amd.make("meta-maze-discrete-3D-v0", num_envs=n, device=dev, max_steps=200,
+        self.env = metagym_amd.make("meta-maze-discrete-3D-v0", num_envs=n, device=dev, max_steps=max_steps,
                                     resolution=(res, res), task_type="SURVIVAL", auto_reset=True)
         self.env.set_task(maze_tasks(), task_ids=torch.as_tensor(plan["maze_task_ids"]))
         self.env.reset()
@@ -568,7 +632,45 @@ class MazeShard:
         self.env.step(self.actions[i % 4])
 
 
-def main():
+def _free_port():
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def _spawned_rank(local_rank, argv, world, port):
+    """One rank of a bare `python bench.py --gpus N` (no torch.distributed.run around it): the environment
+    torch.distributed.run would have provided, then the ordinary main()."""
+    os.environ.update({"RANK": str(local_rank), "LOCAL_RANK": str(local_rank), "WORLD_SIZE": str(world),
+                       "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "BENCH_SPAWNED": "1"})
+    main(argv)
+
+
+def self_spawn(argv, world):
+    """`python bench.py --gpus N` without a launcher: fork-free spawn of N ranks on this node (one process per GPU,
+    same code path as under torch.distributed.run); rank 0 prints the one JSON line."""
+    import torch.multiprocessing as mp
+    mp.spawn(_spawned_rank, args=(list(argv), world, _free_port()), nprocs=world, join=True)
+
+
+class MixedStep:
+    """C5's step on one GPU: the two families are independent, so the quadrotor launch and the maze3d launch go to two
+    HIP streams and may run concurrently (tests/test_mixed_gpu.py: identical, bit for bit, to each family stepped alone)."""
+
+    def __init__(self, dev, quad, maze):
+        self.quad, self.maze = quad, maze
+        self.st_q, self.st_m = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)
+
+    def __call__(self, i):
+        with torch.cuda.stream(self.st_q):
+            self.quad.step(i)
+        with torch.cuda.stream(self.st_m):
+            self.maze.step(i)
+
+
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else list(argv)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
@@ -578,14 +680,23 @@ def main():
     ap.add_argument("--launch", choices=("graph", "eager"), default="graph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the C1/C3/C4 side measurements")
-    args = ap.parse_args()
+    ap.add_argument("--preroll", type=int, default=None,
+                    help="untimed steps that bring the batch to its steady episode-age mix (default: nt = 1000)")
+    ap.add_argument("--single-gpu-value", type=float, default=None,
+                    help="a prior N=1 `value`; with it the line carries efficiency = value(N) / (N * value(1))")
+    ap.add_argument("--plan-only", action="store_true",
+                    help="rendezvous + shard plans only, on CPU (what tests/test_distributed_cpu.py drives); no GPU work")
+    args = ap.parse_args(argv)
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return self_spawn(argv, args.gpus)     # bare `python bench.py --gpus N`: spawn the N ranks ourselves
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.gpus > 1 and world != args.gpus:
-        raise SystemExit("--gpus %d needs torch.distributed.run with --nproc-per-node %d" % (args.gpus, args.gpus))
-    torch.cuda.set_device(local_rank)
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if not args.plan_only:
+        torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
     if world > 1 or os.environ.get("BENCH_FORCE_DIST") == "1":   # the env var lets a 1-GPU box exercise this path
@@ -612,22 +723,25 @@ def main():
     n = args.envs_per_gpu
     mixed = args.workload == "mixed"
     plan = shard_plan(rank, world, n, args.workload)
-    quad = QuadrotorShard(dev, plan, n)
+    if args.plan_only:
+        # every rank reports its shard; rank 0 checks that the union is the single-process job and prints it
+        lo_hi = torch.tensor([int(plan["env_ids"][0]), int(plan["env_ids"][-1]) + 1, plan["env_id_base"]], dtype=torch.int64)
+        gathered = [torch.zeros(3, dtype=torch.int64) for _ in range(world)]
+        if dist is not None:
+            dist.all_gather(gathered, lo_hi)
+        else:
+            gathered = [lo_hi]
+        if rank == 0:
+            shards = [[int(x) for x in g] for g in gathered]
+            ok = all(shards[r][0] == r * n and shards[r][1] == (r + 1) * n and shards[r][2] == r * n for r in range(world))
+            print(json.dumps({"plan_only": True, "n_gpus": world, "envs_per_gpu": n, "shards": shards,
+                              "union_is_single_job": bool(ok), "spawned": os.environ.get("BENCH_SPAWNED") == "1"}), flush=True)
+        if dist is not None:
+            dist.destroy_process_group()
+        return
+    quad = QuadrotorShard(dev, plan, n, preroll=args.preroll)
     maze = MazeShard(dev, plan, n) if mixed else None
-    st_q = st_m = None
-    if mixed:
-        st_q, st_m = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)
-
-    def step(i):
-        if not mixed:
-            quad.step(i)
-            return
-        # the two families are independent: co-scheduled on two HIP streams, the VALU-bound quadrotor kernel
-        # and the store-heavy raycaster overlap instead of queueing behind each other
-        with torch.cuda.stream(st_q):
-            quad.step(i)
-        with torch.cuda.stream(st_m):
-            maze.step(i)
+    step = MixedStep(dev, quad, maze) if mixed else quad.step
 
     for i in range(args.warmup):
         step(i)
@@ -661,9 +775,12 @@ def main():
         barrier()
         return t1 - t0, ev0.elapsed_time(ev1)
 
+    ep0 = quad.episodes()
     wall, dev_ms = timed_region()
+    ep1 = quad.episodes()
     envs_per_rank = n * (2 if mixed else 1)
     value, wall_max = aggregate_throughput(dist, wall, envs_per_rank, args.steps)
+    rank_walls = gather_walls(dist, wall)
 
     # the other launch mode, for the record (never `value`)
     other = None
@@ -691,7 +808,11 @@ def main():
             "vs_baseline": None,
             "dtype": "f32/f64 mixed (reference choreography)",
             "data": "synthetic",
+            "rank_wall_ms": [w * 1e3 for w in rank_walls],
         }
+        if args.single_gpu_value:
+            out["efficiency"] = value / (world * args.single_gpu_value)
+            out["single_gpu_value"] = args.single_gpu_value
         if not mixed:
             achieved = BYTES_PER_ENV_STEP * n / launch_s / 1e9
             out["config"] = {"workload": "Quadrotor hovering_control, %d envs/GPU, dt=0.01 (10 Euler sub-steps), "
@@ -722,6 +843,9 @@ def main():
                                "note": "rank 0's wall time per mixed step; per-kernel rooflines are in the "
                                        "single-workload run"}
         out["sanity"] = {"done_frac_last_step": done_frac, "failed_max": failed_any,
+                         "episode_ends_in_timed_region": ep1 - ep0,
+                         "done_frac_timed_region": (ep1 - ep0) / float(n * args.steps),
+                         "preroll_steps": quad.preroll_steps,
                          "host_wall_ms_per_step": wall / args.steps * 1e3, "launch_mode": launch_mode,
                          "other_launch_mode": other}
         if not mixed:
@@ -737,6 +861,12 @@ def main():
                 out["cpu_baseline"] = ref
                 out["cpu_port"] = port
             else:
+                # say it in the baseline itself: this is the C port, and the reference's own path was not timed on this box
+                port["reference_timed_here"] = False
+                port["reference_unavailable"] = why
+                ref_fig = out.get("from_profiles", {}).get("reference_cpu")
+                if ref_fig:
+                    port["reference_figure_other_machine"] = ref_fig
                 out["cpu_baseline"] = port
                 out["reference_unavailable"] = why
             sec = out.get("secondary", {})

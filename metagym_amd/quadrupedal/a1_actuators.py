@@ -34,6 +34,15 @@ class MotorControlMode(enum.Enum):
     HYBRID = 3
 
 
+class SoA(object):
+    """Explicit layout marker: `SoA(t)` declares that the float64 device tensor `t` is already `[k][num_envs]` (component-major,
+    the kernels' layout) — what a batched simulator naturally holds. Anything not wrapped is `[num_envs, k]`."""
+    __slots__ = ("t",)
+
+    def __init__(self, t):
+        self.t = t.t if isinstance(t, SoA) else t
+
+
 class A1Actuators(object):
     def __init__(self, num_envs, device="cuda:0", time_step=0.002, action_repeat=13, control_latency=0.002,
                  pd_latency=0.0, motor_control_mode=MotorControlMode.POSITION, motor_kp=DEFAULT_KP, motor_kd=DEFAULT_KD,
@@ -124,12 +133,19 @@ class A1Actuators(object):
 
     # ---- the sub-step (minitaur.py:232-255) ------------------------------------------------------------
     def _soa(self, x, k):
-        """`[num_envs, k]` -> the kernels' `[k][num_envs]` layout. A contiguous float64 `[k, num_envs]` device tensor is taken as
-        already being in that layout (no copy) when num_envs != k — what a batched simulator naturally produces."""
+        """`[num_envs, k]` -> the kernels' `[k][num_envs]` layout (one transpose-copy). The layout is never guessed from the
+        shape (a `[k, num_envs]` tensor is indistinguishable from `[num_envs, k]` when num_envs == k): a simulator that already
+        holds its state as `[k][num_envs]` says so by wrapping the tensor in `SoA(...)`, which is then taken without a copy."""
+        if isinstance(x, SoA):
+            t = x.t
+            if not (t.dtype == torch.float64 and t.device == self.device and tuple(t.shape) == (k, self.num_envs) and t.is_contiguous()):
+                raise ValueError("SoA tensor must be contiguous float64 [%d, num_envs=%d] on %s, got %s %s on %s"
+                                 % (k, self.num_envs, self.device, t.dtype, tuple(t.shape), t.device))
+            return t
         x = torch.as_tensor(x, dtype=torch.float64, device=self.device)
-        if x.shape == (k, self.num_envs) and self.num_envs != k and x.is_contiguous():
-            return x
-        assert x.shape == (self.num_envs, k), "expected [num_envs, %d], got %s" % (k, tuple(x.shape))
+        if tuple(x.shape) != (self.num_envs, k):
+            raise ValueError("expected [num_envs=%d, %d], got %s (wrap a [k, num_envs] tensor in metagym_amd.quadrupedal.SoA)"
+                             % (self.num_envs, k, tuple(x.shape)))
         return x.t().contiguous()
 
     def Reset(self, mask=None):

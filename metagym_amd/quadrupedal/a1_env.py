@@ -11,6 +11,8 @@ in the reference tree. `physics` is the caller's batched simulator:
     physics.reset(mask)      -> q[N,12], qd[N,12], base_quat[N,4] (relative to the initial orientation), rpy_rate[N,3] (body
                                 frame) after Minitaur.Reset (minitaur.py:398-444)
     physics.substep(torques) -> the same four after one 2 ms pybullet.stepSimulation() with those motor torques
+                                (tensors are `[N, k]`; a simulator that keeps its state component-major hands back
+                                `SoA(tensor[k, N])` instead and no copy is made — the layout is declared, never inferred)
     physics.world()          -> dict(base=[N,3] GetBasePosition, contact=[N,4] foot-ground flags, bad=[N] number of non-foot
                                 contact points) at the end of the env step
     physics.fused_step(command[12][N], actuators) -> log[13][43][N]   (optional) the whole 13-sub-step loop in one launch with

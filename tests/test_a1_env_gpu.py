@@ -120,15 +120,17 @@ def test_closed_loop_on_the_example_standin_body_holds_the_default_pose():
     assert float(info["real_contact"].sum(dim=1).min()) >= 2.0      # it stands on its feet (flags flicker with the penetration depth)
 
 
-def test_fused_engine_step_equals_thirteen_separate_substeps_bit_for_bit():
-    """The engine's in-launch actuators (13 sub-steps, PD motor model inside the launch, sub-step log -> mg_a1_receive_log)
+@pytest.mark.parametrize("n", [192, 4, 12, 3])
+def test_fused_engine_step_equals_thirteen_separate_substeps_bit_for_bit(n):
+    """(num_envs = 4, 12, 3 are the sizes at which a `[k, num_envs]` tensor has the shape of a `[num_envs, k]` one — quaternion,
+    motor angles, body rate: the layout is declared with `SoA(...)`, never guessed from the shape.)
+    The engine's in-launch actuators (13 sub-steps, PD motor model inside the launch, sub-step log -> mg_a1_receive_log)
     against the same closed loop run sub-step by sub-step through mg_a1_apply_action / mg_a1_receive_and_apply (whose motor
     model is pinned to the reference): observations, rewards, torques and the engine state must be bit-identical."""
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     sys.path.insert(0, os.path.join(root, "examples", "a1_standin"))
     from physics import StandinPhysics
-    n = 192
     w = np.tile([[0.02], [0.0], [0.015]], (1, 20)) * np.sin(np.linspace(0, 2 * np.pi, 20))
     envs = []
     for fused in (True, False):

@@ -117,3 +117,24 @@ def test_shard_invariant_env_ids():
     plans = [bench.shard_plan(r, 8, 65536, workload="mixed") for r in range(8)]
     assert sum(len(p["env_ids"]) + len(p["maze_env_ids"]) for p in plans) == 1 << 20        # C5: 2^20 envs on 8 GPUs
     assert [p["env_id_base"] for p in plans] == [r * 65536 for r in range(8)]
+
+
+def test_bare_gpus_flag_self_spawns_ranks_and_reaches_the_plan_stage(capfd):
+    """`python bench.py --gpus 2` WITHOUT torch.distributed.run around it (the form the driver uses for N = 1): bench.main
+    spawns the two ranks itself (LOCAL_RANK / RANK / WORLD_SIZE, a free port), they rendezvous over gloo, build their
+    shard plans and rank 0 prints one JSON line. `--plan-only` stops before any GPU work, so this runs here."""
+    import json
+    sys.path.insert(0, ROOT)
+    import bench
+    saved = {k: os.environ.pop(k, None) for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    try:
+        bench.main(["--gpus", "2", "--plan-only", "--envs-per-gpu", "4096"])
+    finally:
+        for k, v in saved.items():
+            if v is not None:
+                os.environ[k] = v
+    lines = [l for l in capfd.readouterr().out.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["spawned"] and rec["union_is_single_job"]
+    assert rec["shards"] == [[0, 4096, 0], [4096, 8192, 4096]]
