@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define MG_ABI_VERSION 3
+#define MG_ABI_VERSION 4
 
 #define MG_OK 0
 #define MG_ERR_NULL_POINTER (-1001)
@@ -339,7 +339,7 @@ int mg_maze3d_step(const mg_maze_tasks *tasks, const mg_maze_view *view, int32_t
 
 #define MG_WALKER_MAX_BODIES 16
 #define MG_WALKER_MAX_JOINTS 24
-#define MG_WALKER_MAX_SPHERES 40
+#define MG_WALKER_MAX_SPHERES 128
 #define MG_WALKER_MAX_FEET 6
 #define MG_WALKER_MAX_GEOMS 24
 #define MG_WALKER_MAX_PAIRS 128
@@ -356,6 +356,12 @@ typedef struct mg_walker_topology {
     int32_t n_geoms, n_pairs;
     int32_t geom_body[MG_WALKER_MAX_GEOMS];
     uint8_t pair_a[MG_WALKER_MAX_PAIRS], pair_b[MG_WALKER_MAX_PAIRS];
+    /* Which feet_contact flag a collision proxy reports to: f in [0, n_feet) or -1 (not a foot). A MetaLocomotion foot is a
+     * whole body (walker_base_env.py:57-63: sphere_foot[g] = f iff sphere_body[g] == foot_body[f]); a URDF robot whose fixed
+     * links were merged into their parents keeps the LINK a proxy came from this way (the A1's toe spheres on the calf body:
+     * quadrupedal/robots/a1.py:299-312 GetFootContacts looks at the toe links only). Proxies with -1 that touch the ground or
+     * the terrain are counted in mg_walker_state.bad_contacts (a1.py:314-323 GetBadFootContacts). */
+    int8_t sphere_foot[MG_WALKER_MAX_SPHERES];
 } mg_walker_topology;
 
 /* Per-task geometry / inertia table, doubles, one row of `model_stride` values per task:
@@ -428,6 +434,16 @@ typedef struct mg_walker_params {
      * from the closest surface point to the sphere centre, or — centre inside the box — the face of least penetration. */
     int32_t n_terrain_boxes;
     const double *terrain;
+    /* Per-proxy lateral friction (shape-generic wave kernels only; NULL = one coefficient for the whole robot, above):
+     * DEVICE f64 [n_spheres], the coefficient of the LINK each collision proxy belongs to. Bullet multiplies the two bodies'
+     * coefficients, so with this set `friction` is the ground plane's OWN coefficient and terrain[.][15] each box's own
+     * (quadrupedal: plane 5, locomotion_gym_env.py:258; boxes 5, terrain.py:14; feet SetFootFriction(1), :408). */
+    const double *sphere_friction;
+    /* Velocity damping of every body, btMultiBody's m_linearDamping / m_angularDamping (default 0.04 each, what
+     * pybullet.changeDynamics documents): force -m v (k + k |v|) at the centre of mass, torque -I w (k + k |w|). 0 = off.
+     * Shape-generic wave kernels only. The quadrupedal reference switches it off (minitaur.py:346-353 at :419); MetaLocomotion
+     * never touches it, so PyBullet's default applies there — an option of metalocomotion.mjcf / WalkerBatchEnv. */
+    double body_linear_damping, body_angular_damping;
 } mg_walker_params;
 
 /* Per-env state, SoA doubles: component c of env e at base[c*N + e]. */
@@ -441,6 +457,7 @@ typedef struct mg_walker_state {
     double *potential;    /* [N] */
     float *feet_contact;  /* [nf][N] */
     int32_t *steps;       /* [N] */
+    int32_t *bad_contacts; /* [N] or NULL: ground / terrain contact points of the last sub-step on proxies that are no foot */
 } mg_walker_state;
 
 /* WalkerBaseEnv.reset: base to its model pose, joints to joint_noise (f64 [nj][N], the caller draws

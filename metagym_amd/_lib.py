@@ -8,7 +8,7 @@ import os
 
 from . import build as _build
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 MG_OK = 0
 
@@ -89,7 +89,7 @@ class MazeView(C.Structure):
                 ("obs_format", C.c_int32)]
 
 
-WALKER_MAX_BODIES, WALKER_MAX_JOINTS, WALKER_MAX_SPHERES, WALKER_MAX_FEET = 16, 24, 40, 6
+WALKER_MAX_BODIES, WALKER_MAX_JOINTS, WALKER_MAX_SPHERES, WALKER_MAX_FEET = 16, 24, 128, 6
 WALKER_MAX_GEOMS, WALKER_MAX_PAIRS = 24, 128
 
 
@@ -99,7 +99,8 @@ class WalkerTopology(C.Structure):
                 ("body_parent", C.c_int32 * WALKER_MAX_BODIES), ("joint_body", C.c_int32 * WALKER_MAX_JOINTS),
                 ("sphere_body", C.c_int32 * WALKER_MAX_SPHERES), ("foot_body", C.c_int32 * WALKER_MAX_FEET),
                 ("n_geoms", C.c_int32), ("n_pairs", C.c_int32), ("geom_body", C.c_int32 * WALKER_MAX_GEOMS),
-                ("pair_a", C.c_uint8 * WALKER_MAX_PAIRS), ("pair_b", C.c_uint8 * WALKER_MAX_PAIRS)]
+                ("pair_a", C.c_uint8 * WALKER_MAX_PAIRS), ("pair_b", C.c_uint8 * WALKER_MAX_PAIRS),
+                ("sphere_foot", C.c_int8 * WALKER_MAX_SPHERES)]
 
 
 class WalkerModels(C.Structure):
@@ -121,14 +122,15 @@ class WalkerParams(C.Structure):
                 ("actuation", C.c_int32), ("pd_command", C.c_void_p),
                 ("pd_kp", C.c_double * WALKER_MAX_JOINTS), ("pd_kd", C.c_double * WALKER_MAX_JOINTS),
                 ("pd_strength", C.c_double * WALKER_MAX_JOINTS), ("pd_limit", C.c_double * WALKER_MAX_JOINTS),
-                ("substep_log", C.c_void_p), ("n_terrain_boxes", C.c_int32), ("terrain", C.c_void_p)]
+                ("substep_log", C.c_void_p), ("n_terrain_boxes", C.c_int32), ("terrain", C.c_void_p),
+                ("sphere_friction", C.c_void_p), ("body_linear_damping", C.c_double), ("body_angular_damping", C.c_double)]
 
 
 class WalkerState(C.Structure):
     """mg_walker_state (device pointers)"""
     _fields_ = [("task_id", C.c_void_p), ("pos", C.c_void_p), ("rot", C.c_void_p), ("vel", C.c_void_p),
                 ("omega", C.c_void_p), ("q", C.c_void_p), ("qd", C.c_void_p), ("potential", C.c_void_p),
-                ("feet_contact", C.c_void_p), ("steps", C.c_void_p)]
+                ("feet_contact", C.c_void_p), ("steps", C.c_void_p), ("bad_contacts", C.c_void_p)]
 
 
 A1_NUM_MOTORS, A1_OBS_DIM = 12, 43

@@ -707,6 +707,7 @@ __device__ unsigned long long mg_walker_phase_cycles[16];
 struct WaveLds {   // pointers into the env's LDS slab
     double *R, *o, *c, *p, *a;               // kinematics
     double *fw, *fal, *fxr, *far_;           // frames after each body's joints
+    double *fvr;                             // (shape-generic kernels) velocity of the frame's reference point, for body damping
     double *M, *h, *idg;                     // joint-space inertia (then its packed Cholesky factor), bias, 1/diag(L)
                                              // vector, reciprocal Cholesky diagonal
     double *q, *qd, *tau;
@@ -715,7 +716,7 @@ struct WaveLds {   // pointers into the env's LDS slab
     double *cx;                              // per contact: ground (x, y, depth) or self (point xc, normal)
     double *sc;                              // sin / cos of every joint angle
     int *mask, *depth, *jstart, *jcount, *kids, *kind, *partner, *csphere, *misc, *dbody;
-    int *parent, *sbody;                     // topology tables copied out of the kernarg segment: body_parent, sphere_body
+    int *parent, *sbody, *sfoot;             // topology tables copied out of the kernarg segment: body_parent, sphere_body, sphere_foot
 };
 
 // LDS layout. The solver works in Cholesky-whitened velocities y = L^T u (M = L L^T): with Jh = J L^-T
@@ -735,31 +736,33 @@ struct WaveLds {   // pointers into the env's LDS slab
 // Humanoid: 33.2 KB in the first layout (4 envs per CU) -> 17.4 KB; the register file (2 waves per SIMD)
 // then caps the kernel at 8 envs per CU.
 __host__ __device__ inline bool wave_lds_alias2(int nb, int maxr) { return 2 * (size_t)maxr <= 15 * (size_t)nb; }
-__host__ __device__ inline size_t wave_lds_doubles(int nb, int nj, int maxr, bool overlay) {
+// fd: doubles per body of velocity-product frames — 12 (w, alpha, x_ref, a_ref), 15 in the shape-generic kernels (+ v_ref)
+__host__ __device__ inline size_t wave_lds_doubles(int nb, int nj, int maxr, bool overlay, int fd = 12) {
     const int n = 6 + nj;
-    return (size_t)nb * 15 + (size_t)nj * 6 + (overlay ? 0 : 12 * (size_t)nb) + (size_t)n * (n + 1) / 2 + 2 * (size_t)n +
+    return (size_t)nb * 15 + (size_t)nj * 6 + (overlay ? 0 : fd * (size_t)nb) + (size_t)n * (n + 1) / 2 + 2 * (size_t)n +
            3 * (size_t)nj + 18 + (size_t)maxr * n + (wave_lds_alias2(nb, maxr) ? 1 : 3) * (size_t)maxr +
            6 * (size_t)W_MAXC + (2 * (size_t)nj <= 6 * (size_t)W_MAXC ? 0 : 2 * (size_t)nj);
 }
 __host__ __device__ inline size_t wave_lds_ints(int nb, int ns, int maxr) {
-    return 6 * (size_t)nb + (size_t)ns + 2 * (size_t)maxr + 2 * W_MAXC + 8 + ND;
+    return 6 * (size_t)nb + 2 * (size_t)ns + 2 * (size_t)maxr + 2 * W_MAXC + 8 + ND;
 }
 // doubles of the Jh block the M / h assembly uses as scratch (composite tables; + the frames when overlaid)
 __host__ __device__ inline size_t wave_assembly_doubles(int nb, int nj) { return 16 * (size_t)nb + 12 * (size_t)(6 + nj); }
 
-__device__ __forceinline__ WaveLds carve(unsigned char *smem, int nb, int nj, int ns, int maxr, bool overlay) {
+__device__ __forceinline__ WaveLds carve(unsigned char *smem, int nb, int nj, int ns, int maxr, bool overlay, int fd) {
     const int n = 6 + nj;
     WaveLds L;
     double *d = reinterpret_cast<double *>(smem);
     L.R = d; d += 9 * nb; L.o = d; d += 3 * nb; L.c = d; d += 3 * nb; L.p = d; d += 3 * nj; L.a = d; d += 3 * nj;
     double *ne = d;                       // Newton-Euler temporaries: own block, or the tail of the Jh block
-    if (!overlay) d += 12 * nb;
+    if (!overlay) d += fd * nb;
     L.M = d; d += n * (n + 1) / 2; L.h = d; d += n; L.idg = d; d += n;
     L.q = d; d += nj; L.qd = d; d += nj; L.tau = d; d += nj;
     L.base = d; d += 18;
     L.J = d; d += (size_t)maxr * n;       // constraint rows, whitened in place (Jh)
-    if (overlay) ne = d - 12 * nb;
-    L.fw = ne; ne += 3 * nb; L.fal = ne; ne += 3 * nb; L.fxr = ne; ne += 3 * nb; L.far_ = ne;
+    if (overlay) ne = d - fd * nb;
+    L.fw = ne; ne += 3 * nb; L.fal = ne; ne += 3 * nb; L.fxr = ne; ne += 3 * nb; L.far_ = ne; ne += 3 * nb;
+    L.fvr = ne;                           // only touched when fd == 15
     L.bias = d; d += maxr;
     if (wave_lds_alias2(nb, maxr)) { L.diag = L.R; L.lam = L.R + maxr; }
     else { L.diag = d; d += maxr; L.lam = d; d += maxr; }
@@ -769,7 +772,7 @@ __device__ __forceinline__ WaveLds carve(unsigned char *smem, int nb, int nj, in
     int *i = reinterpret_cast<int *>(d);
     L.mask = i; i += nb; L.depth = i; i += nb; L.jstart = i; i += nb; L.jcount = i; i += nb; L.kids = i; i += nb;
     L.kind = i; i += maxr; L.partner = i; i += maxr; L.csphere = i; i += 2 * W_MAXC; L.misc = i; i += 8; L.dbody = i; i += ND;
-    L.parent = i; i += nb; L.sbody = i; i += ns;
+    L.parent = i; i += nb; L.sbody = i; i += ns; L.sfoot = i; i += ns;
     return L;
 }
 
@@ -805,6 +808,7 @@ __device__ __forceinline__ void rodrigues_sc(V3 k, double s, double c, double *R
 
 // forceinline: with three call sites the compiler would otherwise emit a real call, which pushes the
 // kernels into scratch (ant: 1.04 -> 1.92 ms)
+template <bool VEL>
 __device__ __forceinline__ void wave_kinematics(const ModelW &m, const WaveLds &L, int lane, int max_depth, bool with_frames) {
     const int nb = m.nb, nj = m.nj;
     // the f64 sin/cos of all joint angles at once (lane = joint): the level loop below is serial in the
@@ -820,18 +824,20 @@ __device__ __forceinline__ void wave_kinematics(const ModelW &m, const WaveLds &
         if (lane < nb && L.depth[lane] == level) {
             const int b = lane, pb = L.parent[b];
             double Rc[9];
-            V3 oc, w, al, xr, ar;
+            V3 oc, w, al, xr, ar, vr{0, 0, 0};
             unsigned mk = 0;
             if (pb < 0) {
                 for (int i = 0; i < 9; ++i) Rc[i] = L.base[3 + i];
                 oc = ldv(L.base, 0);
                 w = V3{L.base[15], L.base[16], L.base[17]};
                 al = v3(0, 0, 0); xr = oc; ar = v3(0, 0, 0);
+                if (VEL) vr = V3{L.base[12], L.base[13], L.base[14]};
             } else {
                 mulMM(L.R + 9 * pb, m.body_rot() + 9 * b, Rc);
                 oc = ldv(L.o, pb) + mulMv(L.R + 9 * pb, ld3(m.body_pos() + 3 * b));
                 mk = (unsigned)L.mask[pb];
                 w = ldv(L.fw, pb); al = ldv(L.fal, pb); xr = ldv(L.fxr, pb); ar = ldv(L.far_, pb);
+                if (VEL && with_frames) vr = ldv(L.fvr, pb);
             }
             const int j0 = L.jstart[b], j1 = j0 + L.jcount[b];
             for (int j = j0; j < j1; ++j) {
@@ -848,6 +854,7 @@ __device__ __forceinline__ void wave_kinematics(const ModelW &m, const WaveLds &
                 if (with_frames) {
                     const V3 r = pj - xr;
                     ar = ar + cross(al, r) + cross(w, cross(w, r));
+                    if (VEL) vr = vr + cross(w, r);      // velocity of the new reference point (the joint anchor)
                     xr = pj;
                     const V3 wj = L.qd[j] * aj;
                     al = al + cross(w, wj);
@@ -861,6 +868,7 @@ __device__ __forceinline__ void wave_kinematics(const ModelW &m, const WaveLds &
             L.mask[b] = (int)mk;
             if (with_frames) {
                 stv(L.fw, b, w); stv(L.fal, b, al); stv(L.fxr, b, xr); stv(L.far_, b, ar);
+                if (VEL) stv(L.fvr, b, vr);
             }
         }
         WSYNC();
@@ -868,10 +876,10 @@ __device__ __forceinline__ void wave_kinematics(const ModelW &m, const WaveLds &
     PHASE(11);      // (profile builds) the level loop alone; phase 0 minus this = sin / cos
 }
 
-template <int NMAX, bool TERRAIN>
+template <int NMAX, bool GENERIC>
 __device__ __forceinline__ void wave_substep(const mg_walker_topology &tp, const ModelW &m, const mg_walker_params &prm,
                                              const WaveLds &L, int lane, int max_depth, int maxr,
-                                             unsigned long long &touch_mask, double pd_cmd, double *log_row, int n_envs) {
+                                             unsigned long long (&touch)[2], double pd_cmd, double *log_row, int n_envs) {
     const int nb = m.nb, nj = m.nj, ns = m.ns, n = 6 + nj;
     const double dt = prm.time_step;
     // A fresh copy of the lane id per sub-step: the ~140 lane predicates of the unrolled Cholesky / substitution
@@ -881,7 +889,7 @@ __device__ __forceinline__ void wave_substep(const mg_walker_topology &tp, const
     PHASE_BEGIN();
     if (prm.actuation != 0 && lane < nj)      // read by lane 6 + j after the kinematics' barriers
         L.tau[lane] = actuator_torque(prm, lane, L.q[lane], L.qd[lane], pd_cmd);
-    wave_kinematics(m, L, lane, max_depth, true);
+    wave_kinematics<GENERIC>(m, L, lane, max_depth, true);
     PHASE(0);
     // ---- M and h by the composite-rigid-body algorithm (Featherstone RBDA ch. 6) in world coordinates, all spatial
     //      quantities taken about the base origin O so that subtree sums are plain sums:
@@ -914,8 +922,16 @@ __device__ __forceinline__ void wave_substep(const mg_walker_topology &tp, const
         auto Ic = [&](V3 x) { return V3{ixx * x.x + ixy * x.y + ixz * x.z, ixy * x.x + iyy * x.y + iyz * x.z,
                                         ixz * x.x + iyz * x.y + izz * x.z}; };
         const double mass = m.body_mass()[b];
-        const V3 F = mass * (a_c - v3(0, 0, -prm.gravity));
-        const V3 N = Ic(al) + cross(w, Ic(w));
+        V3 F = mass * (a_c - v3(0, 0, -prm.gravity));
+        V3 N = Ic(al) + cross(w, Ic(w));
+        if (GENERIC && (prm.body_linear_damping != 0.0 || prm.body_angular_damping != 0.0)) {
+            // btMultiBody's velocity damping (mg_walker_params.body_*_damping): an external force -m v (k + k |v|) at the
+            // centre of mass and torque -I w (k + k |w|), i.e. their negatives join the bias wrench
+            const V3 vc = ldv(L.fvr, b) + cross(w, rx);
+            const double kl = prm.body_linear_damping, ka = prm.body_angular_damping;
+            F = F + (mass * (kl + kl * sqrt(dot(vc, vc)))) * vc;
+            N = N + (ka + ka * sqrt(dot(w, w))) * Ic(w);
+        }
         const V3 r = cb - O;
         const V3 NO = N + cross(r, F);
         const double rr = dot(r, r);
@@ -1059,91 +1075,111 @@ __device__ __forceinline__ void wave_substep(const mg_walker_topology &tp, const
     }
     PHASE(4);
     // ---- constraint detection ------------------------------------------------------------------------
-    bool hit = false;
-    double sx = 0, sy = 0, depth = 0;
-    if (lane < ns) {
-        const int b = L.sbody[lane];
-        const V3 xw = ldv(L.o, b) + mulMv(L.R + 9 * b, ld3(m.sph_pos() + 3 * lane));
-        depth = m.sph_r()[lane] - xw.z;
-        hit = depth > 0.0;
-        sx = xw.x; sy = xw.y;
-    }
-    const unsigned long long hits = __ballot(hit);
-    const int rank = __popcll(hits & ((1ull << lane) - 1ull));
-    int ncont = min(__popcll(hits), W_MAXC);
-    if (hit && rank < W_MAXC) {
-        L.cx[6 * rank] = sx; L.cx[6 * rank + 1] = sy; L.cx[6 * rank + 2] = depth;
-        L.csphere[2 * rank] = lane; L.csphere[2 * rank + 1] = -1;       // ground contact of sphere `lane`
-        L.bias[3 * rank] = prm.erp * depth / dt; L.kind[3 * rank] = 0; L.partner[3 * rank] = -1;
-        L.bias[3 * rank + 1] = 0.0; L.kind[3 * rank + 1] = 1; L.partner[3 * rank + 1] = 3 * rank;
-        L.bias[3 * rank + 2] = 0.0; L.kind[3 * rank + 2] = 2; L.partner[3 * rank + 2] = 3 * rank;
-    }
-    touch_mask = 0ull;
-    for (int g = 0; g < ns; ++g)
-        if (((hits >> g) & 1ull) && __popcll(hits & ((1ull << g) - 1ull)) < W_MAXC) touch_mask |= 1ull << g;
-    // terrain: lane = collision sphere against the static boxes (the same for every env; wave-uniform loop, boxes whose
-    // x range misses the robot are skipped by the whole wave); per sphere the deepest box, first on ties. Slots after the
-    // ground contacts; the friction rows carry the box's own coefficient in their (otherwise zero) bias slot, kind -1.
-    if (TERRAIN && prm.n_terrain_boxes > 0 && ncont < W_MAXC) {
-        const double rad = lane < ns ? m.sph_r()[lane] : 0.0;
-        const double sz = rad - depth;
-        double lo = lane < ns ? sx - rad : 1e300, hi = lane < ns ? sx + rad : -1e300;
-        for (int off = 32; off > 0; off >>= 1) {
-            lo = fmin(lo, __shfl_xor(lo, off));
-            hi = fmax(hi, __shfl_xor(hi, off));
+    //      lane = collision proxy, 64 at a time (the two tuned shapes have at most 64: one pass). Slots in proxy order,
+    //      the first W_MAXC penetrating ones are kept. With per-proxy friction (mg_walker_params.sphere_friction) a ground
+    //      friction row carries its own coefficient in the (otherwise zero) bias slot, kind -1, like a terrain row.
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+    const int nchunk = GENERIC ? (ns + WV - 1) / WV : 1;
+    const bool own_mu = GENERIC && prm.sphere_friction != nullptr;
+    int ncont = 0;
+    touch[0] = 0ull;
+    touch[1] = 0ull;
+    for (int ch = 0; ch < nchunk; ++ch) {
+        const int g = ch * WV + lane;
+        bool hit = false;
+        double sx = 0, sy = 0, depth = 0;
+        if (g < ns) {
+            const int b = L.sbody[g];
+            const V3 xw = ldv(L.o, b) + mulMv(L.R + 9 * b, ld3(m.sph_pos() + 3 * g));
+            depth = m.sph_r()[g] - xw.z;
+            hit = depth > 0.0;
+            sx = xw.x; sy = xw.y;
         }
-        double bdepth = 0.0, bmu = 0.0;
-        V3 bn{0, 0, 1}, bx{0, 0, 0};
-        for (int bi = 0; bi < prm.n_terrain_boxes; ++bi) {
-            const double *B = prm.terrain + (size_t)MG_WALKER_BOX_DOUBLES * bi;
-            const V3 bp{B[0], B[1], B[2]}, bh{B[12], B[13], B[14]};
-            const double ex = fabs(B[3]) * bh.x + fabs(B[4]) * bh.y + fabs(B[5]) * bh.z;      // world x half extent
-            if (bp.x + ex < lo || bp.x - ex > hi) continue;
-            if (lane < ns) {
-                const V3 rel = V3{sx, sy, sz} - bp;
-                const V3 l{B[3] * rel.x + B[6] * rel.y + B[9] * rel.z, B[4] * rel.x + B[7] * rel.y + B[10] * rel.z,
-                           B[5] * rel.x + B[8] * rel.y + B[11] * rel.z};                       // R^T (x - p)
-                V3 c{fmin(fmax(l.x, -bh.x), bh.x), fmin(fmax(l.y, -bh.y), bh.y), fmin(fmax(l.z, -bh.z), bh.z)};
-                const V3 dv = l - c;
-                const double dist2 = dot(dv, dv);
-                double dpt;
-                V3 nl;
-                if (dist2 > 0.0) {
-                    const double dist = sqrt(dist2);
-                    dpt = rad - dist;
-                    nl = (1.0 / dist) * dv;
-                } else {            // centre inside the box: out through the face of least penetration (x, y, z order on ties)
-                    const double px = bh.x - fabs(l.x), py = bh.y - fabs(l.y), pz = bh.z - fabs(l.z);
-                    const int k = (px <= py && px <= pz) ? 0 : (py <= pz ? 1 : 2);
-                    const double lk = k == 0 ? l.x : (k == 1 ? l.y : l.z), sg = lk >= 0.0 ? 1.0 : -1.0;
-                    nl = V3{k == 0 ? sg : 0.0, k == 1 ? sg : 0.0, k == 2 ? sg : 0.0};
-                    if (k == 0) c.x = sg * bh.x; else if (k == 1) c.y = sg * bh.y; else c.z = sg * bh.z;
-                    dpt = rad + (k == 0 ? px : (k == 1 ? py : pz));
-                }
-                if (dpt > bdepth) {
-                    bdepth = dpt; bmu = B[15];
-                    bn = V3{B[3] * nl.x + B[4] * nl.y + B[5] * nl.z, B[6] * nl.x + B[7] * nl.y + B[8] * nl.z,
-                            B[9] * nl.x + B[10] * nl.y + B[11] * nl.z};                        // R n
-                    bx = bp + V3{B[3] * c.x + B[4] * c.y + B[5] * c.z, B[6] * c.x + B[7] * c.y + B[8] * c.z,
-                                 B[9] * c.x + B[10] * c.y + B[11] * c.z};
+        const unsigned long long hits = __ballot(hit);
+        const int slot = ncont + __popcll(hits & lt_mask);
+        const bool kept = hit && slot < W_MAXC;
+        if (kept) {
+            L.cx[6 * slot] = sx; L.cx[6 * slot + 1] = sy; L.cx[6 * slot + 2] = depth;
+            L.csphere[2 * slot] = g; L.csphere[2 * slot + 1] = -1;       // ground contact of proxy g
+            const double mu = own_mu ? prm.friction * prm.sphere_friction[g] : 0.0;
+            L.bias[3 * slot] = prm.erp * depth / dt; L.kind[3 * slot] = 0; L.partner[3 * slot] = -1;
+            L.bias[3 * slot + 1] = mu; L.kind[3 * slot + 1] = own_mu ? -1 : 1; L.partner[3 * slot + 1] = 3 * slot;
+            L.bias[3 * slot + 2] = mu; L.kind[3 * slot + 2] = own_mu ? -1 : 2; L.partner[3 * slot + 2] = 3 * slot;
+        }
+        touch[GENERIC ? ch : 0] = __ballot(kept);
+        ncont = min(ncont + __popcll(hits), W_MAXC);
+    }
+    // terrain: lane = collision proxy against the static boxes (the same for every env; wave-uniform loop, boxes whose
+    // x range misses the chunk's proxies are skipped by the whole wave); per proxy the deepest box, first on ties. Slots
+    // after the ground contacts; the friction rows carry the contact's coefficient in their (otherwise zero) bias slot, kind -1.
+    if (GENERIC && prm.n_terrain_boxes > 0)
+        for (int ch = 0; ch < nchunk && ncont < W_MAXC; ++ch) {
+            const int g = ch * WV + lane;
+            double rad = 0.0, sx = 0.0, sy = 0.0, sz = 0.0;
+            if (g < ns) {
+                const int b = L.sbody[g];
+                const V3 xw = ldv(L.o, b) + mulMv(L.R + 9 * b, ld3(m.sph_pos() + 3 * g));
+                rad = m.sph_r()[g];
+                sx = xw.x; sy = xw.y; sz = xw.z;
+            }
+            double lo = g < ns ? sx - rad : 1e300, hi = g < ns ? sx + rad : -1e300;
+            for (int off = 32; off > 0; off >>= 1) {
+                lo = fmin(lo, __shfl_xor(lo, off));
+                hi = fmax(hi, __shfl_xor(hi, off));
+            }
+            double bdepth = 0.0, bmu = 0.0;
+            V3 bn{0, 0, 1}, bx{0, 0, 0};
+            for (int bi = 0; bi < prm.n_terrain_boxes; ++bi) {
+                const double *B = prm.terrain + (size_t)MG_WALKER_BOX_DOUBLES * bi;
+                const V3 bp{B[0], B[1], B[2]}, bh{B[12], B[13], B[14]};
+                const double ex = fabs(B[3]) * bh.x + fabs(B[4]) * bh.y + fabs(B[5]) * bh.z;      // world x half extent
+                if (bp.x + ex < lo || bp.x - ex > hi) continue;
+                if (g < ns) {
+                    const V3 rel = V3{sx, sy, sz} - bp;
+                    const V3 l{B[3] * rel.x + B[6] * rel.y + B[9] * rel.z, B[4] * rel.x + B[7] * rel.y + B[10] * rel.z,
+                               B[5] * rel.x + B[8] * rel.y + B[11] * rel.z};                       // R^T (x - p)
+                    V3 c{fmin(fmax(l.x, -bh.x), bh.x), fmin(fmax(l.y, -bh.y), bh.y), fmin(fmax(l.z, -bh.z), bh.z)};
+                    const V3 dv = l - c;
+                    const double dist2 = dot(dv, dv);
+                    double dpt;
+                    V3 nl;
+                    if (dist2 > 0.0) {
+                        const double dist = sqrt(dist2);
+                        dpt = rad - dist;
+                        nl = (1.0 / dist) * dv;
+                    } else {            // centre inside the box: out through the face of least penetration (x, y, z order on ties)
+                        const double px = bh.x - fabs(l.x), py = bh.y - fabs(l.y), pz = bh.z - fabs(l.z);
+                        const int k = (px <= py && px <= pz) ? 0 : (py <= pz ? 1 : 2);
+                        const double lk = k == 0 ? l.x : (k == 1 ? l.y : l.z), sg = lk >= 0.0 ? 1.0 : -1.0;
+                        nl = V3{k == 0 ? sg : 0.0, k == 1 ? sg : 0.0, k == 2 ? sg : 0.0};
+                        if (k == 0) c.x = sg * bh.x; else if (k == 1) c.y = sg * bh.y; else c.z = sg * bh.z;
+                        dpt = rad + (k == 0 ? px : (k == 1 ? py : pz));
+                    }
+                    if (dpt > bdepth) {
+                        bdepth = dpt; bmu = B[15];
+                        bn = V3{B[3] * nl.x + B[4] * nl.y + B[5] * nl.z, B[6] * nl.x + B[7] * nl.y + B[8] * nl.z,
+                                B[9] * nl.x + B[10] * nl.y + B[11] * nl.z};                        // R n
+                        bx = bp + V3{B[3] * c.x + B[4] * c.y + B[5] * c.z, B[6] * c.x + B[7] * c.y + B[8] * c.z,
+                                     B[9] * c.x + B[10] * c.y + B[11] * c.z};
+                    }
                 }
             }
+            const bool th = bdepth > 0.0;
+            const unsigned long long th_mask = __ballot(th);
+            const int slot = ncont + __popcll(th_mask & lt_mask);
+            const bool kept = th && slot < W_MAXC;
+            if (kept) {
+                if (own_mu) bmu *= prm.sphere_friction[g];
+                double *cc = L.cx + 6 * slot;
+                cc[0] = bx.x; cc[1] = bx.y; cc[2] = bx.z; cc[3] = bn.x; cc[4] = bn.y; cc[5] = bn.z;
+                L.csphere[2 * slot] = L.sbody[g]; L.csphere[2 * slot + 1] = -2;       // one body against the world
+                L.bias[3 * slot] = prm.erp * bdepth / dt; L.kind[3 * slot] = 0; L.partner[3 * slot] = -1;
+                L.bias[3 * slot + 1] = bmu; L.kind[3 * slot + 1] = -1; L.partner[3 * slot + 1] = 3 * slot;
+                L.bias[3 * slot + 2] = bmu; L.kind[3 * slot + 2] = -1; L.partner[3 * slot + 2] = 3 * slot;
+            }
+            touch[ch] |= __ballot(kept);
+            ncont = min(ncont + __popcll(th_mask), W_MAXC);
         }
-        const bool th = bdepth > 0.0;
-        const unsigned long long th_mask = __ballot(th);
-        const int slot = ncont + __popcll(th_mask & ((1ull << lane) - 1ull));
-        const bool kept = th && slot < W_MAXC;
-        if (kept) {
-            double *cc = L.cx + 6 * slot;
-            cc[0] = bx.x; cc[1] = bx.y; cc[2] = bx.z; cc[3] = bn.x; cc[4] = bn.y; cc[5] = bn.z;
-            L.csphere[2 * slot] = L.sbody[lane]; L.csphere[2 * slot + 1] = -2;       // one body against the world
-            L.bias[3 * slot] = prm.erp * bdepth / dt; L.kind[3 * slot] = 0; L.partner[3 * slot] = -1;
-            L.bias[3 * slot + 1] = bmu; L.kind[3 * slot + 1] = -1; L.partner[3 * slot + 1] = 3 * slot;
-            L.bias[3 * slot + 2] = bmu; L.kind[3 * slot + 2] = -1; L.partner[3 * slot + 2] = 3 * slot;
-        }
-        touch_mask |= __ballot(kept);
-        ncont = min(ncont + __popcll(th_mask), W_MAXC);
-    }
     // self-collision: lane = geom pair (in pair order, 64 at a time); slots after the ground and terrain contacts
     if (prm.self_collision)
         for (int base = 0; base < tp.n_pairs && ncont < W_MAXC; base += WV) {
@@ -1202,7 +1238,7 @@ __device__ __forceinline__ void wave_substep(const mg_walker_topology &tp, const
         const int c = t / n, d = t % n;
         const double *cc = L.cx + 6 * c;
         const int other = L.csphere[2 * c + 1];
-        if (TERRAIN ? other == -1 : other < 0) { // ground: point on the plane under the sphere
+        if (GENERIC ? other == -1 : other < 0) { // ground: point on the plane under the sphere
             const unsigned mk = (unsigned)L.mask[L.sbody[L.csphere[2 * c]]];
             const V3 jc = wjac_lin(L, mk, V3{cc[0], cc[1], 0.0}, d);
             L.J[(size_t)(3 * c) * n + d] = jc.z;
@@ -1211,7 +1247,7 @@ __device__ __forceinline__ void wave_substep(const mg_walker_topology &tp, const
         } else {                                 // self contact: relative velocity of the two bodies at xc; terrain (-2): one body
             const V3 xc{cc[0], cc[1], cc[2]}, nrm{cc[3], cc[4], cc[5]};
             V3 jd = wjac_lin(L, (unsigned)L.mask[L.csphere[2 * c]], xc, d);
-            if (!TERRAIN || other >= 0) jd = jd - wjac_lin(L, (unsigned)L.mask[other], xc, d);
+            if (!GENERIC || other >= 0) jd = jd - wjac_lin(L, (unsigned)L.mask[other], xc, d);
             V3 t1, t2;
             tangent_basis(nrm, t1, t2);
             L.J[(size_t)(3 * c) * n + d] = dot(nrm, jd);
@@ -1269,7 +1305,7 @@ __device__ __forceinline__ void wave_substep(const mg_walker_topology &tp, const
             if (!(idg > 0.0)) continue;
             const double jv = NMAX <= 32 ? wave_sum32(jh * u_d) : wave_sum(jh * u_d);   // J_r u = Jh_r . y
             const double lr = L.lam[rr];
-            const bool tfric = TERRAIN && rkind < 0;                     // a terrain friction row keeps its mu in `bias`
+            const bool tfric = GENERIC && rkind < 0;                     // a terrain friction row keeps its mu in `bias`
             double x = lr - (jv - (tfric ? 0.0 : bias)) * idg;
             if (rkind == 0 || rkind >= 4) x = x > 0.0 ? x : 0.0;
             else {
@@ -1378,9 +1414,13 @@ __global__ __launch_bounds__(WV) __attribute__((amdgpu_waves_per_eu(2))) void wa
     unsigned slab_off = 0;
     asm volatile("" : "+v"(slab_off));
     unsigned char *slab = smem + slab_off;
-    const WaveLds L = carve(slab, nb, nj, ns, maxr, overlay);
+    constexpr bool GENERIC = SH::nb == 0;      // shape-generic instantiation: terrain, > 64 proxies, per-proxy friction, body damping
+    const WaveLds L = carve(slab, nb, nj, ns, maxr, overlay, GENERIC ? 15 : 12);
     if (lane < nb) L.parent[lane] = tp.body_parent[lane];
-    if (lane < ns) L.sbody[lane] = tp.sphere_body[lane];
+    for (int g = lane; g < ns; g += WV) {
+        L.sbody[g] = tp.sphere_body[g];
+        L.sfoot[g] = tp.sphere_foot[g];
+    }
     WSYNC();
     // tree bookkeeping (lane 0) + state load (lanes)
     if (lane == 0) {
@@ -1420,14 +1460,22 @@ __global__ __launch_bounds__(WV) __attribute__((amdgpu_waves_per_eu(2))) void wa
     }
     WSYNC();
     const int max_depth = L.misc[0];
-    unsigned long long touch = 0ull;
+    unsigned long long touch[2] = {0ull, 0ull};     // proxies in contact with the ground / terrain in the last sub-step
 #ifdef MG_WALKER_PROFILE
     unsigned long long ph_k0 = __builtin_readcyclecounter();
 #endif
     const double pd_cmd = (prm.actuation != 0 && lane < nj) ? prm.pd_command[(size_t)lane * n_envs + e] : 0.0;
     for (int it = 0; it < prm.frame_skip; ++it) {
         double *log_row = prm.substep_log ? prm.substep_log + ((size_t)it * (3 * nj + 7)) * n_envs + e : nullptr;
-        wave_substep<NMAX, SH::nb == 0>(tp, m, prm, L, lane, max_depth, maxr, touch, pd_cmd, log_row, n_envs);
+        wave_substep<NMAX, GENERIC>(tp, m, prm, L, lane, max_depth, maxr, touch, pd_cmd, log_row, n_envs);
+    }
+    if (st.bad_contacts != nullptr) {       // a1.py:314-323 GetBadFootContacts: contact points on links that are no foot
+        int bad = 0;
+        for (int ch = 0; ch < (GENERIC ? (ns + WV - 1) / WV : 1); ++ch) {
+            const int g = ch * WV + lane;
+            bad += __popcll(__ballot(g < ns && ((touch[GENERIC ? ch : 0] >> lane) & 1ull) && L.sfoot[g] < 0));
+        }
+        if (lane == 0) st.bad_contacts[e] = bad;
     }
     // ---- calc_state (walker_base.py:31-64) on the current configuration ------------------------------
     // after_reset = false: post-step state; the obs carries the PREVIOUS step's feet flags and the flags
@@ -1437,7 +1485,7 @@ __global__ __launch_bounds__(WV) __attribute__((amdgpu_waves_per_eu(2))) void wa
     float *ob = obs + (size_t)e * obs_dim;
     float head[8];
     auto calc_state = [&](bool after_reset, double &dist, int &at_limit, bool &all_finite) {
-        wave_kinematics(m, L, lane, max_depth, false);
+        wave_kinematics<false>(m, L, lane, max_depth, false);
         const int pw = lane < nb ? part_weight(tp, lane) : 0;
         const double sxm = wave_sum(pw * (lane < nb ? L.o[3 * lane] : 0.0)), sym = wave_sum(pw * (lane < nb ? L.o[3 * lane + 1] : 0.0));
         const int parts = (int)wave_sum((double)pw) + (prm.floor_in_parts ? 1 : 0);
@@ -1461,7 +1509,7 @@ __global__ __launch_bounds__(WV) __attribute__((amdgpu_waves_per_eu(2))) void wa
                 ob[8 + 2 * nj + lane] = clip5(prev);
                 float cnow = 0.0f;
                 for (int g = 0; g < ns; ++g)
-                    if (((touch >> g) & 1ull) && L.sbody[g] == tp.foot_body[lane]) cnow = 1.0f;
+                    if (((touch[GENERIC ? g >> 6 : 0] >> (g & 63)) & 1ull) && L.sfoot[g] == lane) cnow = 1.0f;
                 st.feet_contact[(size_t)lane * n_envs + e] = cnow;
             }
         }
@@ -1618,13 +1666,26 @@ extern "C" int mg_walker_step(const mg_walker_topology *tp, const mg_walker_mode
     MG_REQUIRE_PTR(done);
     mg::DeviceGuard guard(mg::device_of(st->pos));
     if (prm->mapping == 0) {   // lane-per-env reference mapping (private-memory work set)
+        if (tp->n_spheres > 64 || prm->sphere_friction != nullptr || prm->body_linear_damping != 0.0 || prm->body_angular_damping != 0.0)
+            return mg::set_error(MG_ERR_UNSUPPORTED, "per-proxy friction, body damping and > 64 collision proxies need the wave mapping");
         hipLaunchKernelGGL(walker_step_kernel, dim3((n + WK_BLOCK - 1) / WK_BLOCK), dim3(WK_BLOCK), 0,
                            (hipStream_t)stream, *tp, *ms, *prm, *st, n, action, obs, reward, rewards5, done);
         return mg::check_launch("walker_step_kernel");
     }
-    if (tp->n_spheres > 64 || 6 + tp->n_joints > 64)
-        return mg::set_error(MG_ERR_BAD_SIZE, "wave mapping needs <= 64 spheres and <= 58 joints");
+    if (tp->n_spheres > 128 || 6 + tp->n_joints > 64)
+        return mg::set_error(MG_ERR_BAD_SIZE, "wave mapping needs <= 128 collision proxies and <= 58 joints");
     const int maxr = 3 * W_MAXC + tp->n_joints;
+    using Humanoid = Shape<13, 17, 29, 17, 1>;
+    using Ant = Shape<13, 8, 25, 13, 1>;
+    // (terrain boxes, per-proxy friction, body damping and > 64 proxies are compiled into the shape-generic instantiations
+    // only: the two tuned kernels keep their registers)
+    const bool generic_only = prm->n_terrain_boxes != 0 || prm->sphere_friction != nullptr || prm->body_linear_damping != 0.0 ||
+                              prm->body_angular_damping != 0.0;
+    auto shape_is = [&](int b, int j, int s, int g) {
+        return !generic_only && tp->n_bodies == b && tp->n_joints == j && tp->n_spheres == s && tp->n_geoms == g;
+    };
+    bool tuned = shape_is(Humanoid::nb, Humanoid::nj, Humanoid::ns, Humanoid::ng) || shape_is(Ant::nb, Ant::nj, Ant::ns, Ant::ng);
+    int fd = tuned ? 12 : 15;           // velocity-product frame doubles per body (wave_lds_doubles)
     // scratch use of the Jh block during the M / h assembly: the composite-rigid-body tables from the front and, when
     // they also fit, the 12 doubles per body of velocity-product frames from the back
     bool overlay = false;
@@ -1633,9 +1694,14 @@ extern "C" int mg_walker_step(const mg_walker_topology *tp, const mg_walker_mode
         if (need > block)
             return mg::set_error(MG_ERR_UNSUPPORTED, "walker topology needs %zu scratch doubles for the mass-matrix "
                                  "assembly, the wave mapping has %zu: use mapping = lane", need, block);
-        overlay = need + 12 * (size_t)tp->n_bodies <= block;
+        overlay = need + fd * (size_t)tp->n_bodies <= block;
+        if (tuned && !overlay) {        // (cannot happen for the two shipped shapes; keeps host and kernel layouts in step)
+            tuned = false;
+            fd = 15;
+            overlay = need + fd * (size_t)tp->n_bodies <= block;
+        }
     }
-    const size_t lds = wave_lds_doubles(tp->n_bodies, tp->n_joints, maxr, overlay) * sizeof(double) +
+    const size_t lds = wave_lds_doubles(tp->n_bodies, tp->n_joints, maxr, overlay, fd) * sizeof(double) +
                        wave_lds_ints(tp->n_bodies, tp->n_spheres, maxr) * sizeof(int);
     const int maxr_flags = overlay ? -maxr : maxr;
     if (lds > 160 * 1024) return mg::set_error(MG_ERR_BAD_SIZE, "walker needs %zu B of LDS", lds);
@@ -1645,12 +1711,7 @@ extern "C" int mg_walker_step(const mg_walker_topology *tp, const mg_walker_mode
     // 14 = ant, 23 = humanoid, 30 = the ABI maximum
     // ... and so is the whole robot shape for the two robots MetaLocomotion ships (LDS addresses and model-table
     // offsets become literals); any other topology runs the shape-generic instantiations
-    using Humanoid = Shape<13, 17, 29, 17, 1>;
-    using Ant = Shape<13, 8, 25, 13, 1>;
-    // (terrain boxes are compiled into the shape-generic instantiations only: the two tuned kernels keep their registers)
-    auto is_shape = [&](int b, int j, int s, int g) {
-        return overlay && prm->n_terrain_boxes == 0 && tp->n_bodies == b && tp->n_joints == j && tp->n_spheres == s && tp->n_geoms == g;
-    };
+    auto is_shape = [&](int b, int j, int s, int g) { return tuned && shape_is(b, j, s, g); };
 #define MG_WALKER_LAUNCH(NMAX_, SHAPE_)                                                                                  \
     hipLaunchKernelGGL((walker_step_wave_kernel<NMAX_, SHAPE_>), dim3(n), dim3(WV), lds, (hipStream_t)stream, *tp, *ms, \
                        *prm, *st, n, maxr_flags, action, obs, reward, rewards5, done)

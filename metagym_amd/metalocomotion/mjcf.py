@@ -102,7 +102,26 @@ class Model(object):
         return m
 
 
-def load_mjcf(path_or_string, foot_names=("right_foot", "left_foot")):
+def _aabb_box_inertia(mass, geoms, com):
+    """What btCompoundShape::calculateLocalInertia returns for a body's shapes: the solid-box formula on the extents of
+    their axis-aligned bounding box (in the body's axes), m/12 (ly^2 + lz^2, lx^2 + lz^2, lx^2 + ly^2), diagonal."""
+    lo, hi = np.full(3, np.inf), np.full(3, -np.inf)
+    for p0, p1, r in geoms:
+        lo = np.minimum(lo, np.minimum(p0, p1) - r)
+        hi = np.maximum(hi, np.maximum(p0, p1) + r)
+    l = hi - lo
+    return np.diag(mass / 12.0 * np.array([l[1] ** 2 + l[2] ** 2, l[0] ** 2 + l[2] ** 2, l[0] ** 2 + l[1] ** 2]))
+
+
+def load_mjcf(path_or_string, foot_names=("right_foot", "left_foot"), inertia="geom", com="geom"):
+    """inertia: 'geom' (default) — exact solid capsule / sphere tensors at the geoms' density, MuJoCo's documented
+    `inertiafromgeom`; 'bullet_box' — what PyBullet's loader does with a body's shapes when it is not told to trust the
+    file (robot_bases.py:119 passes no URDF_USE_INERTIA_FROM_FILE): the solid-box formula on the bounding box of the
+    body's geoms, diagonal in the body's axes (btCompoundShape::calculateLocalInertia); masses stay volume x density.
+    com: 'geom' — mass-weighted geom centroid (MuJoCo); 'body_origin' — the body frame's origin, where Bullet's MJCF
+    importer is believed to leave the inertial frame of a body without an <inertial> element (unverifiable here)."""
+    assert inertia in ("geom", "bullet_box") and com in ("geom", "body_origin")
+    inertia_mode, com_mode = inertia, com
     text = path_or_string
     if "<mujoco" not in text:
         with open(path_or_string, "r") as f:
@@ -124,7 +143,7 @@ def load_mjcf(path_or_string, foot_names=("right_foot", "left_foot")):
         b = len(bodies)
         pos = np.array(_floats(elem.get("pos", "0 0 0"), 3))
         rot = _quat_to_mat(_floats(elem.get("quat", "1 0 0 0"), 4))
-        masses, coms, inertias = [], [], []
+        masses, coms, inertias, extents = [], [], [], []
         for g in elem.findall("geom"):
             a = dict(gdef)
             a.update(g.attrib)
@@ -137,11 +156,13 @@ def load_mjcf(path_or_string, foot_names=("right_foot", "left_foot")):
                 spheres.append((b, np.array(ft[:3]), size[0], a.get("name", "")))
                 spheres.append((b, np.array(ft[3:]), size[0], a.get("name", "")))
                 geoms.append((b, np.array(ft[:3]), np.array(ft[3:]), size[0]))
+                extents.append((np.array(ft[:3]), np.array(ft[3:]), size[0]))
             elif a.get("type", "sphere") == "sphere":
                 c = np.array(_floats(a.get("pos", "0 0 0"), 3))
                 m, inertia = _sphere_inertia(size[0], density)
                 spheres.append((b, c, size[0], a.get("name", "")))
                 geoms.append((b, c, c, size[0]))
+                extents.append((c, c, size[0]))
             else:
                 raise ValueError("unsupported geom type %r" % a.get("type"))
             masses.append(m)
@@ -153,6 +174,10 @@ def load_mjcf(path_or_string, foot_names=("right_foot", "left_foot")):
         for m, c, i3 in zip(masses, coms, inertias):
             d = c - com
             inertia += i3 + m * (np.dot(d, d) * np.eye(3) - np.outer(d, d))
+        if com_mode == "body_origin":
+            com = np.zeros(3)
+        if inertia_mode == "bullet_box" and mass > 0:
+            inertia = _aabb_box_inertia(mass, extents, com)
         bodies.append(dict(name=elem.get("name", "body%d" % b), parent=parent, pos=pos, rot=rot, mass=mass, com=com,
                            inertia=inertia))
         for j in elem.findall("joint"):

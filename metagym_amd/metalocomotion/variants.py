@@ -246,17 +246,18 @@ def task_names(robot, split):
     return ["%s_var_%s_%03d.xml" % (robot, tag, i) for i in range(len(patterns(robot, tag)))]
 
 
-def model(robot, split=None, index=0):
-    """Parsed `Model` of the base robot (`split=None`) or of variant `index` of a split."""
-    key = (robot, SPLITS.get(split, split), int(index) if split is not None else -1)
+def model(robot, split=None, index=0, inertia="geom", com="geom"):
+    """Parsed `Model` of the base robot (`split=None`) or of variant `index` of a split. `inertia` / `com`: the loader's
+    options (mjcf.load_mjcf: MuJoCo's documented semantics by default, Bullet's bounding-box inertia on request)."""
+    key = (robot, SPLITS.get(split, split), int(index) if split is not None else -1, inertia, com)
     if key not in _cache:
         pat = None if split is None else patterns(robot, split)[int(index)]
-        _cache[key] = load_mjcf(mjcf_text(robot, pat), foot_names=FEET[robot])
+        _cache[key] = load_mjcf(mjcf_text(robot, pat), foot_names=FEET[robot], inertia=inertia, com=com)
     return _cache[key]
 
 
-def models(robot, split):
-    return [model(robot, split, i) for i in range(len(patterns(robot, split)))]
+def models(robot, split, inertia="geom", com="geom"):
+    return [model(robot, split, i, inertia=inertia, com=com) for i in range(len(patterns(robot, split)))]
 
 
 _NAME = re.compile(r"^(humanoid|ant)(?:_var_(tra|tst|ood)_(\d{3}))?\.xml$")

@@ -56,7 +56,8 @@ class WalkerBatchEnv(object):
 
     def __init__(self, num_envs=1, device="cuda", frame_skip=4, time_step=0.005, enable_render=False,
                  max_steps=2000, assets_dir=None, solver_iterations=5, mapping="wave", self_collision=True,
-                 auto_reset=False, seed=0, env_id_base=0):
+                 auto_reset=False, seed=0, env_id_base=0, gravity=GRAVITY, ground_friction=GROUND_FRICTION,
+                 body_damping=(0.0, 0.0), per_proxy_friction=False, contact_erp=CONTACT_ERP):
         self._lib = _lib.load()
         self.num_envs = int(num_envs)
         self.device = torch.device(device)
@@ -66,6 +67,18 @@ class WalkerBatchEnv(object):
         self.frame_skip, self.time_step, self.max_steps = int(frame_skip), float(time_step), int(max_steps)
         self.solver_iterations = int(solver_iterations)
         self.self_collision = bool(self_collision)     # the reference loads the MJCF with URDF_USE_SELF_COLLISION
+        # World options beyond the MetaLocomotion defaults (all handled by the shape-generic wave kernels):
+        #   gravity / ground_friction   the Bullet world's (quadrupedal: 10 and 5, locomotion_gym_env.py:251,258)
+        #   body_damping = (lin, ang)   btMultiBody's velocity damping of every body; PyBullet's default is (0.04, 0.04), which
+        #                               MetaLocomotion never changes — (0, 0), the default here, is the documented MuJoCo-style
+        #                               reading of the MJCF (DESIGN.md §3.4 lists both)
+        #   per_proxy_friction          every collision proxy carries its own link's coefficient (Model.sph_friction)
+        self.gravity, self.ground_friction = float(gravity), float(ground_friction)
+        self.body_damping = (float(body_damping[0]), float(body_damping[1]))
+        self.per_proxy_friction = bool(per_proxy_friction)
+        #   contact_erp                 0.9 for MetaLocomotion (scene_bases.py:55 setDefaultContactERP); a world that never calls it
+        #                               keeps Bullet's default 0.2 (btContactSolverInfo::m_erp2) — the quadrupedal one
+        self.contact_erp = float(contact_erp)
         assert mapping in ("wave", "lane")
         self.mapping = mapping    # 'wave': one wavefront per env, LDS-resident (default); 'lane': one lane per env
         self.assets_dir = assets_dir or os.environ.get("METAGYM_LOCOMOTION_ASSETS")
@@ -131,8 +144,17 @@ class WalkerBatchEnv(object):
         for i, v in enumerate(m0.joint_body): tp.joint_body[i] = int(v)
         for i, v in enumerate(m0.sph_body): tp.sphere_body[i] = int(v)
         for i, v in enumerate(m0.foot_body): tp.foot_body[i] = int(v)
+        # which feet_contact flag a proxy reports to: its own link's when the model says so (URDF robots with merged fixed
+        # links), else the MetaLocomotion rule — a foot is a whole body (walker_base_env.py:57-63)
+        sph_foot = getattr(m0, "sph_foot", None)
+        if sph_foot is None:
+            sph_foot = [next((f for f, fb in enumerate(m0.foot_body) if int(fb) == int(b)), -1) for b in m0.sph_body]
+        for m in models:
+            assert np.array_equal(getattr(m, "sph_foot", sph_foot), sph_foot), "all tasks of a batch must share one topology"
+        for i, v in enumerate(sph_foot): tp.sphere_foot[i] = int(v)
         tp.n_geoms, tp.n_pairs = len(m0.geom_body), len(m0.pair_a)
         assert tp.n_geoms <= _lib.WALKER_MAX_GEOMS and tp.n_pairs <= _lib.WALKER_MAX_PAIRS
+        assert nb <= _lib.WALKER_MAX_BODIES and nj <= _lib.WALKER_MAX_JOINTS and ns <= _lib.WALKER_MAX_SPHERES and nf <= _lib.WALKER_MAX_FEET
         for i, v in enumerate(m0.geom_body): tp.geom_body[i] = int(v)
         for i, (a, b) in enumerate(zip(m0.pair_a, m0.pair_b)): tp.pair_a[i], tp.pair_b[i] = int(a), int(b)
         self._topo = tp
@@ -156,16 +178,26 @@ class WalkerBatchEnv(object):
         self.q, self.qd, self.potential = f64(nj, N), f64(nj, N), f64(N)
         self.feet_contact = torch.zeros(nf, N, dtype=torch.float32, device=dev)
         self.steps = torch.zeros(N, dtype=torch.int32, device=dev)
+        self.bad_contacts = torch.zeros(N, dtype=torch.int32, device=dev)    # contact points on proxies that are no foot
         st = _lib.WalkerState()
-        for k in ("task_id", "pos", "rot", "vel", "omega", "q", "qd", "potential", "feet_contact", "steps"):
+        for k in ("task_id", "pos", "rot", "vel", "omega", "q", "qd", "potential", "feet_contact", "steps", "bad_contacts"):
             setattr(st, k, getattr(self, k).data_ptr())
         self._state_c = st
         p = _lib.WalkerParams()
         p.time_step, p.frame_skip, p.solver_iterations = self.time_step, self.frame_skip, self.solver_iterations
         # Bullet multiplies the two bodies' lateral friction: ground 0.8 (stadium.py:23) x geom friction (MJCF)
         p.limit_erp = 0.2                                          # Bullet's default constraint ERP
-        p.erp, p.gravity, p.friction = CONTACT_ERP, GRAVITY, GROUND_FRICTION * float(m0.geom_friction)
+        p.erp, p.gravity = self.contact_erp, self.gravity
         self._geom_friction = float(m0.geom_friction)
+        if self.per_proxy_friction:          # the plane's own coefficient; the kernel multiplies with the proxy's link
+            mu = np.asarray(getattr(m0, "sph_friction", np.full(ns, float(m0.geom_friction))), np.float64)
+            assert mu.shape == (ns,)
+            self._sphere_friction = torch.from_numpy(mu.copy()).to(dev)
+            p.friction, p.sphere_friction = self.ground_friction, self._sphere_friction.data_ptr()
+        else:
+            self._sphere_friction = None
+            p.friction, p.sphere_friction = self.ground_friction * float(m0.geom_friction), None
+        p.body_linear_damping, p.body_angular_damping = self.body_damping
         p.alive_z, p.alive_bonus, p.dead_bonus = self.alive_z, self.alive_bonus, -1.0
         p.initial_z = float(self.initial_z if self.initial_z is not None else m0.body_pos[0][2])
         p.joints_at_limit_cost = -0.1                              # walker_base_env.py:22
@@ -274,7 +306,7 @@ class WalkerBatchEnv(object):
             R = [1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y), 2 * (x * y + w * z), 1 - 2 * (x * x + z * z),
                  2 * (y * z - w * x), 2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)]
             rows[i, 0:3], rows[i, 3:12], rows[i, 12:15] = pos, R, half
-            rows[i, 15] = float(friction) * float(self._geom_friction)
+            rows[i, 15] = float(friction) * (1.0 if self.per_proxy_friction else float(self._geom_friction))
         self._terrain_t = torch.as_tensor(rows, dtype=torch.float64, device=self.device).contiguous()
         p.n_terrain_boxes, p.terrain = len(spec), self._terrain_t.data_ptr()
 

@@ -5,8 +5,9 @@ everything it computes in Python on the device, composed in the reference's orde
     [ActionFilter] -> 13 x (ApplyAction -> PHYSICS -> ReceiveObservation) -> info (pose, rot_mat, foot FK, energy) ->
     sensors -> observation[37] -> RewardShaping -> reward, done
 
-The physics is NOT part of this package: `a1/a1.urdf` ships with pybullet_data and the dynamics are PyBullet's, neither is
-in the reference tree. `physics` is the caller's batched simulator:
+The robot file is NOT part of this package (`a1/a1.urdf` ships with pybullet_data, not with the reference): pass
+`urdf=<path>` and the env runs it on this package's articulated-body engine (`A1Physics`, a1_physics.py — the reference's world
+parameters, dynamics parity with PyBullet unpinned), or pass `physics=`, any batched simulator with this protocol:
 
     physics.reset(mask)      -> q[N,12], qd[N,12], base_quat[N,4] (relative to the initial orientation), rpy_rate[N,3] (body
                                 frame) after Minitaur.Reset (minitaur.py:398-444)
@@ -43,15 +44,20 @@ SENSOR_MODE = {"dis": 1, "motor": 1, "imu": 1, "contact": 1, "footpose": 0, "ETG
 
 
 class A1GymEnv(object):
-    def __init__(self, num_envs, physics, device="cuda:0", ETG=0, ETG_T=0.5, ETG_H=20, ETG_path="", ETG_w=None, ETG_b=None,
+    def __init__(self, num_envs, physics=None, device="cuda:0", ETG=0, ETG_T=0.5, ETG_H=20, ETG_path="", ETG_w=None, ETG_b=None,
                  act_mode="traj", task="plane", normal=0, action_space=0, reward_param=Param_Dict, reward_p=1.0, vel_d=0.6,
                  filter_=0, control_latency=0.002, motor_kp=None, motor_kd=None, env_info=None,
-                 motor_control_mode=MotorControlMode.POSITION, sensor_mode=SENSOR_MODE, auto_reset=False):
+                 motor_control_mode=MotorControlMode.POSITION, sensor_mode=SENSOR_MODE, auto_reset=False, urdf=None,
+                 urdf_options=None):
+        if physics is None and urdf is not None:       # the robot file on this repo's own articulated-body engine
+            from .a1_physics import A1Physics
+            physics = A1Physics(num_envs, urdf=urdf, device=device, **dict(urdf_options or {}))
         if physics is None:
             raise _lib.MetaGymHipError(
-                "quadrupedal-v0 needs a `physics` object (see metagym_amd/quadrupedal/a1_env.py): the A1 body is not part of this "
-                "package — a1/a1.urdf ships with pybullet_data and the dynamics are PyBullet's, neither is in the reference tree. "
-                "Everything around the physics (motor model, latency, ETG, sensors, reward) runs on the GPU.")
+                "quadrupedal-v0 needs the robot: pass urdf=<path to a1/a1.urdf> (the file ships with pybullet_data, not with the "
+                "reference; it then runs on this package's articulated-body engine, metagym_amd.quadrupedal.A1Physics) or your own "
+                "batched simulator as physics=<object> (protocol: metagym_amd/quadrupedal/a1_env.py). Everything around the "
+                "physics (motor model, latency, ETG, sensors, reward) runs on the GPU either way.")
         self.num_envs, self.device, self.physics = int(num_envs), torch.device(device), physics
         self.task = task
         self.add_height, task_env_info, self.terrain_boxes = task_terrain(task)

@@ -1,0 +1,154 @@
+"""`A1Physics` — the `physics` object of `A1GymEnv` on this repo's articulated-body engine (metagym_amd/csrc/walker.hip),
+for a robot read from a URDF file: what `quadrupedal-v0` needs to run without a caller-supplied simulator.
+
+    env = metagym_amd.make("quadrupedal-v0", num_envs=8192, urdf="/path/to/a1/a1.urdf")
+
+The reference (metagym/quadrupedal) gets the same from PyBullet: `loadURDF("a1/a1.urdf")` (robots/a1.py:266-277; the file
+ships with pybullet_data, NOT with the reference — bring your own copy) and `stepSimulation()` 13 times per env step
+(robots/minitaur.py:232-238, envs/env_builder.py:45). Here:
+
+  world      gravity 10 (locomotion_gym_env.py:251), 2 ms sub-steps, 300 / 13 = 23 solver iterations (:113-115), contact ERP 0.2
+             (Bullet's default: no setDefaultContactERP call anywhere in quadrupedal/), plane
+             friction 5 (:258), terrain boxes friction 5 (utilities/terrain.py:14), feet friction 1 (:408 SetFootFriction),
+             pyramid friction (:413 enableConeFriction=0), no body velocity damping (minitaur.py:346-353 at :419), no self
+             collision (minitaur.py:83)
+  robot      URDF -> Model (urdf.py): hinge order = a1.MOTOR_NAMES, toe links = feet (a1.py:76-80 name patterns), every
+             other link's contact points are "bad" contacts (a1.py:314-323), inertia recomputed from the collision shapes'
+             bounding box like loadURDF without URDF_USE_INERTIA_FROM_FILE
+  reset      base to [x, y, 0.28 + add_height] (the BASE position PyBullet reports / resets is that of the root link's
+             inertial frame, hence the a1.py:61 COM_OFFSET), joints to INIT_MOTOR_ANGLES, all velocities zero
+             (minitaur.py:425-431, a1.py:360-383); reset_time = 0 in env resets, so nothing settles
+  step       either one engine launch per 2 ms sub-step with the torques `A1Actuators` computed, or (`fused=True`) all 13
+             sub-steps in ONE launch with the reference's PD motor model evaluated inside the engine before each of them
+
+**Dynamics parity with PyBullet is UNPINNED** (DESIGN.md §3.4): this is the repo's own reduced-coordinate engine run with
+the reference's parameters, not Bullet's solver or its convex-convex collision."""
+import numpy as np
+import torch
+
+from ..metalocomotion.mjcf import Model
+from ..metalocomotion.walker_env import WalkerBatchEnv
+from .a1_actuators import INIT_MOTOR_ANGLES, MOTOR_NAMES, SoA
+from .urdf import load_urdf
+
+TORQUE_LIMIT = 33.5                                  # minitaur.py:88
+TOE_LINKS = ("FR_toe", "FL_toe", "RR_toe", "RL_toe")  # the child links of the a1.py:79 TOE_NAME_PATTERN joints, leg order of MOTOR_NAMES
+GRAVITY, GROUND_FRICTION, FOOT_FRICTION = 10.0, 5.0, 1.0   # locomotion_gym_env.py:251, :258, :338 + :408
+CONTACT_ERP = 0.2     # Bullet's default (btContactSolverInfo::m_erp2): unlike MetaLocomotion (scene_bases.py:55) the quadrupedal
+#                       reference never calls setDefaultContactERP
+
+
+class _A1Walker(WalkerBatchEnv):
+    variant_prefix = None
+    foot_list = ()
+    power, motor_power = TORQUE_LIMIT / 100.0, None   # (action mode only, unused here) engine torque = 100 * power * clip(action)
+    alive_z, alive_bonus = -1.0e9, 0.0                # the MetaLocomotion walker rules are not used: never "dead"
+
+
+def guess_foot_links(model_or_names):
+    """The toe links of a URDF by the reference's own rule (a1.py:79 TOE_NAME_PATTERN on the JOINT names, whose child links
+    carry the same stem in every published A1 file): link names matching `<leg>_toe`, in FR, FL, RR, RL order."""
+    names = model_or_names.link_names if isinstance(model_or_names, Model) else list(model_or_names)
+    out = []
+    for leg in ("FR", "FL", "RR", "RL"):
+        cands = [n for n in names if n.startswith(leg + "_") and ("toe" in n or "foot" in n)]
+        if len(cands) != 1:
+            raise ValueError("cannot tell the %s foot link among %r: pass foot_links=(...)" % (leg, cands or names))
+        out.append(cands[0])
+    return tuple(out)
+
+
+class A1Physics(object):
+    def __init__(self, num_envs, urdf=None, device="cuda:0", model=None, foot_links=None, inertia="bullet_aabb", armature=0.0,
+                 solver_iterations=23, fused=True, gravity=GRAVITY, ground_friction=GROUND_FRICTION, foot_friction=FOOT_FRICTION,
+                 body_damping=(0.0, 0.0), init_motor_angles=INIT_MOTOR_ANGLES, contact_erp=CONTACT_ERP):
+        if (urdf is None) == (model is None):
+            raise ValueError("A1Physics needs exactly one of urdf=<path or text> and model=<Model>")
+        if model is None:
+            if foot_links is None:
+                import xml.etree.ElementTree as ET
+                text = urdf if "<robot" in urdf else open(urdf).read()
+                foot_links = guess_foot_links([l.get("name") for l in ET.fromstring(text).findall("link")])
+            model = load_urdf(urdf, foot_links=foot_links, inertia=inertia, armature=armature, joint_order=MOTOR_NAMES)
+        m = model
+        if list(m.joint_names) != list(MOTOR_NAMES):
+            raise ValueError("the robot's hinges %r are not the A1's motors %r (a1.py:27-40)" % (list(m.joint_names), MOTOR_NAMES))
+        assert len(m.foot_body) == 4, "four feet expected"
+        if not hasattr(m, "sph_friction"):                       # an MJCF model: one coefficient for every geom
+            m.sph_friction = np.full(len(m.sph_body), float(m.geom_friction))
+        if not hasattr(m, "sph_foot"):
+            m.sph_foot = np.array([next((f for f, fb in enumerate(m.foot_body) if int(fb) == int(b)), -1) for b in m.sph_body], np.int8)
+        if foot_friction is not None:                            # SetFootFriction: the toe links' own coefficient
+            m.sph_friction = np.where(np.asarray(m.sph_foot) >= 0, float(foot_friction), m.sph_friction)
+        self.model = m
+        self.n, self.device = int(num_envs), torch.device(device)
+        self.env = _A1Walker(num_envs=num_envs, device=device, frame_skip=1, time_step=0.002, max_steps=2 ** 30,
+                             solver_iterations=solver_iterations, self_collision=False, gravity=gravity,
+                             ground_friction=ground_friction, body_damping=body_damping, per_proxy_friction=True,
+                             contact_erp=contact_erp)
+        self.env.set_task([m])
+        f64 = dict(dtype=torch.float64, device=self.device)
+        self._init = torch.as_tensor(np.tile(np.asarray(init_motor_angles, np.float64), (self.n, 1)), **f64)
+        # PyBullet's base position is the root link's inertial frame origin (for the A1: a1.py:61 COM_OFFSET)
+        frame = getattr(m, "root_inertial_pos", np.zeros(3))
+        self._base_offset = torch.as_tensor(np.asarray(frame, np.float64), **f64).reshape(3, 1)
+        self._default_pose = torch.tensor([0.0, 0.0, 0.28], **f64).reshape(3, 1)
+        if fused:                                  # A1GymEnv takes the one-launch path when the physics offers it
+            self.fused_step = self._fused_step
+
+    # ---- the protocol of A1GymEnv (a1_env.py) -------------------------------------------------------------------
+    def set_terrain(self, boxes, default_pose):
+        """The task's static boxes (metagym_amd.quadrupedal.terrain — what the reference creates in its Bullet world) go to the
+        engine with their own friction; the reset pose is [x, y, 0.28 + add_height] (locomotion_gym_env.py:337)."""
+        self.env.set_terrain(boxes)
+        self._default_pose = torch.tensor([float(v) for v in default_pose], dtype=torch.float64, device=self.device).reshape(3, 1)
+
+    def _base_quat_rate(self):
+        e = self.env
+        R = e.rot.t().reshape(self.n, 3, 3)
+        tr = R[:, 0, 0] + R[:, 1, 1] + R[:, 2, 2]
+        w = 0.5 * torch.sqrt(torch.clamp(1.0 + tr, min=1e-12))
+        quat = torch.stack([(R[:, 2, 1] - R[:, 1, 2]) / (4 * w), (R[:, 0, 2] - R[:, 2, 0]) / (4 * w),
+                            (R[:, 1, 0] - R[:, 0, 1]) / (4 * w), w], dim=1)
+        rate = torch.einsum("nij,ni->nj", R, e.omega.t())                      # body-frame angular velocity R^T omega
+        return quat.contiguous(), rate.contiguous()
+
+    def reset(self, mask):
+        e = self.env
+        e.reset(mask=mask, joint_noise=self._init)                             # joints at (0, 0.9, -1.8) x 4, velocities zero
+        # base: resetBasePositionAndOrientation places the root link's INERTIAL frame at the default pose, identity attitude
+        m = torch.ones(self.n, dtype=torch.bool, device=self.device) if mask is None else torch.as_tensor(mask, device=self.device).bool()
+        target = self._default_pose - self._base_offset                        # the root body origin (R = identity at reset)
+        e.pos.copy_(torch.where(m.reshape(1, -1), target.expand(3, self.n), e.pos))
+        e.bad_contacts.mul_((~m).to(torch.int32))                               # no contact points yet (feet flags: the reset kernel)
+        quat, rate = self._base_quat_rate()
+        return e.q.t().contiguous(), e.qd.t().contiguous(), quat, rate
+
+    def substep(self, torques):
+        """One 2 ms sub-step with the motor torques A1Actuators computed (raw torques, in-launch actuation mode 2); the
+        observation handed back is the engine's own sub-step log, so the fused path sees bit-identical numbers."""
+        t = torch.as_tensor(torques, dtype=torch.float64, device=self.device)
+        assert tuple(t.shape) == (self.n, 12)
+        t = t.t().contiguous()
+        if not hasattr(self, "_log1"):
+            self._log1 = torch.empty(1, 43, self.n, dtype=torch.float64, device=self.device)
+        self.env.step_actuated(t, raw_torque=True, n_substeps=1, log=self._log1)
+        g = self._log1[0]
+        return SoA(g[0:12]), SoA(g[12:24]), SoA(g[36:40]), SoA(g[40:43])
+
+    def _fused_step(self, command, actuators):
+        """13 sub-steps in one engine launch, the PD motor model (laikago_motor.py:136-168) evaluated inside it before each."""
+        kp, kd, strength, limit = actuators.motor_model_parameters()
+        k = actuators._action_repeat
+        if not hasattr(self, "_log") or self._log.shape[0] != k:
+            self._log = torch.empty(k, 43, self.n, dtype=torch.float64, device=self.device)
+        self.env.step_actuated(command, kp, kd, strength, limit, n_substeps=k, log=self._log)
+        return self._log
+
+    def world(self):
+        """base = GetBasePosition (the root link's inertial frame origin), contact = GetFootContacts (a1.py:299-312: toe links
+        against anything that is not the robot), bad = GetBadFootContacts (a1.py:314-323: contact points on any other link)."""
+        e = self.env
+        R = e.rot.t().reshape(self.n, 3, 3)
+        base = e.pos.t() + torch.einsum("nij,j->ni", R, self._base_offset.reshape(3))
+        return dict(base=base.contiguous(), contact=e.feet_contact.t().to(torch.float64).contiguous(), bad=e.bad_contacts)

@@ -115,9 +115,15 @@ def angular_jacobian(m, kin, b):
     return J
 
 
-def mass_matrix_and_bias(m, s, kin=None):
-    """M(q) (with armature) and h(q,u) such that M du/dt + h = tau_generalised (gravity inside h)."""
+def mass_matrix_and_bias(m, s, kin=None, gravity=None, body_damping=(0.0, 0.0)):
+    """M(q) (with armature) and h(q,u) such that M du/dt + h = tau_generalised (gravity inside h).
+    body_damping = (k_lin, k_ang): btMultiBody's velocity damping of every body — force -m v (k + k |v|) at the centre of
+    mass, torque -I w (k + k |w|) (btMultiBody::computeAccelerationsArticulatedBodyAlgorithmMultiDof adds exactly this to
+    every link's zero-acceleration force, DAMPING_K1 = DAMPING_K2 = m_linearDamping / m_angularDamping, default 0.04)."""
     kin = kin or kinematics(m, s)
+    grav = GRAVITY if gravity is None else np.array([0.0, 0.0, -float(gravity)])
+    k_lin, k_ang = body_damping
+    u_all = s.u()
     nb, nj = len(m.body_parent), len(m.joint_body)
     n = 6 + nj
     M = np.zeros((n, n))
@@ -143,7 +149,11 @@ def mass_matrix_and_bias(m, s, kin=None):
         Jv = point_jacobian(m, kin, b, kin["c"][b])
         Jw = angular_jacobian(m, kin, b)
         M += m.body_mass[b] * Jv.T @ Jv + Jw.T @ Iw @ Jw
-        h += Jv.T @ (m.body_mass[b] * (a_c - GRAVITY)) + Jw.T @ (Iw @ al + np.cross(w, Iw @ w))
+        h += Jv.T @ (m.body_mass[b] * (a_c - grav)) + Jw.T @ (Iw @ al + np.cross(w, Iw @ w))
+        if k_lin != 0.0 or k_ang != 0.0:
+            vc = Jv @ u_all
+            h += Jv.T @ (m.body_mass[b] * (k_lin + k_lin * np.linalg.norm(vc)) * vc) \
+                + Jw.T @ ((k_ang + k_ang * np.linalg.norm(w)) * (Iw @ w))
     M[np.arange(6, n), np.arange(6, n)] += m.joint_armature
     return M, h, kin, frame
 
@@ -158,8 +168,14 @@ def integrate_positions(s, dt):
 
 class Params(object):
     def __init__(self, dt=0.005, substeps=4, iterations=5, erp=0.9, friction=0.8 * 0.8, power=0.41, max_contacts=12,
-                 limit_erp=0.2, self_collision=True, self_friction=0.8 * 0.8, terrain=()):
+                 limit_erp=0.2, self_collision=True, self_friction=0.8 * 0.8, terrain=(), gravity=None, sphere_friction=None,
+                 body_damping=(0.0, 0.0)):
         self.terrain = list(terrain)          # static boxes on top of the ground plane: (position[3], R[3,3] box->world, half_extents[3], mu)
+        self.gravity = None if gravity is None else float(gravity)      # None: the module's GRAVITY (9.8, env_bases.py:48)
+        # per-proxy lateral friction (mg_walker_params.sphere_friction): `friction` is then the ground's own coefficient and
+        # every terrain box's mu its own; the contact's coefficient is the product with the proxy's link (Bullet multiplies)
+        self.sphere_friction = None if sphere_friction is None else np.asarray(sphere_friction, float)
+        self.body_damping = (float(body_damping[0]), float(body_damping[1]))
         self.dt, self.substeps, self.iterations, self.erp, self.friction, self.power = dt, substeps, iterations, erp, friction, power
         self.limit_erp = limit_erp            # Bullet's default constraint ERP (btContactSolverInfo::m_erp2 = 0.2);
         #                                       setDefaultContactERP(0.9) only changes the contact ERP
@@ -236,8 +252,13 @@ def constraint_rows(m, s, kin, prm):
             Jc = point_jacobian(m, kin, b, xc)
             k = len(rows)
             rows.append((Jc[2], prm.erp * depth / prm.dt, 0, -1, g))
-            rows.append((Jc[0], 0.0, 1, k, g))
-            rows.append((Jc[1], 0.0, 2, k, g))
+            if prm.sphere_friction is None:
+                rows.append((Jc[0], 0.0, 1, k, g))
+                rows.append((Jc[1], 0.0, 2, k, g))
+            else:
+                mu = prm.friction * prm.sphere_friction[g]
+                rows.append((Jc[0], 0.0, -1, k, g, mu))
+                rows.append((Jc[1], 0.0, -1, k, g, mu))
     # terrain: per collision sphere the deepest static box (first on ties); friction rows carry the box's own coefficient
     if prm.terrain:
         for g in range(len(m.sph_body)):
@@ -252,6 +273,8 @@ def constraint_rows(m, s, kin, prm):
                     best = (depth, nrm, xc, box[3])
             if best is not None:
                 depth, nrm, xc, mu = best
+                if prm.sphere_friction is not None:
+                    mu = mu * prm.sphere_friction[g]
                 Jc = point_jacobian(m, kin, b, xc)
                 t1, t2 = tangent_basis(nrm)
                 k = len(rows)
@@ -316,7 +339,7 @@ def pgs(A, rhs, rows, friction, iterations):
 
 def substep(m, s, tau_motor, prm):
     """One 5 ms sub-step. Returns the set of sphere indices in contact."""
-    M, h, kin, _ = mass_matrix_and_bias(m, s)
+    M, h, kin, _ = mass_matrix_and_bias(m, s, gravity=prm.gravity, body_damping=prm.body_damping)
     n = M.shape[0]
     tau = np.zeros(n)
     tau[6:] = tau_motor - m.joint_damping * s.qd - m.joint_stiffness * s.q
@@ -467,8 +490,13 @@ class WalkerEnv(object):
         # the reference computes the state BEFORE refreshing feet_contact (walker_base_env.py:46 vs
         # :57-63), so the observation carries the previous step's contact flags
         state = self.calc_state()
+        sph_foot = getattr(m, "sph_foot", None)                              # URDF robots: the proxy's own LINK decides
         for i, fb in enumerate(m.foot_body):                                 # walker_base_env.py:57-63
-            self.feet_contact[i] = 1.0 if any(m.sph_body[g] == fb for g in touching) else 0.0
+            if sph_foot is None:
+                self.feet_contact[i] = 1.0 if any(m.sph_body[g] == fb for g in touching) else 0.0
+            else:
+                self.feet_contact[i] = 1.0 if any(sph_foot[g] == i for g in touching) else 0.0
+        self.bad_contacts = 0 if sph_foot is None else sum(1 for g in touching if sph_foot[g] < 0)     # a1.py:314-323
         # walker_base_env.py:47: alive_bonus(state[0] + initial_z, ...) — float32 + python float stays float32
         # (humanoid), float32 + numpy float64 is float64 (ant: initial_z came out of calc_state)
         if self.initial_z_cfg is not None:

@@ -95,6 +95,7 @@ def test_unsupported_sensor_modes_are_refused_loudly():
 
 
 def test_quadrupedal_without_physics_explains_itself():
+    """(neither `physics=` nor `urdf=`: the only case that is refused)"""
     with pytest.raises(Exception, match="a1.urdf"):
         metagym_amd.make("quadrupedal-v0", num_envs=4, device=DEV)
 

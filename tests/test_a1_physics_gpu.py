@@ -1,0 +1,192 @@
+"""GPU: SURVEY.md §8(f)-2's physics half — `quadrupedal-v0` from a URDF on the articulated-body engine (`A1Physics`),
+without a caller-supplied simulator. What can be pinned is pinned: the URDF path against the MJCF path of the same body
+(bit for bit), the engine against its numpy oracle on a terrain course (> 64 contact proxies, per-link friction, feet / bad
+contact bookkeeping), the loader options against the oracle. Dynamics parity with PyBullet stays UNPINNED: the fixtures
+are this repo's own (tests/urdf_fixture.py), the reference's a1.urdf ships with pybullet_data."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import metagym_amd
+from metagym_amd.metalocomotion import MetaHumanoidEnv, variants
+from metagym_amd.metalocomotion.mjcf import load_mjcf
+from metagym_amd.quadrupedal import MOTOR_NAMES, A1Physics, load_urdf
+from metagym_amd.quadrupedal.terrain import task_terrain
+from oracle import abd
+from urdf_fixture import A1_LIKE_TOES, a1_like_urdf, model_to_urdf
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+STANDIN_XML = os.path.join(ROOT, "examples", "a1_standin", "a1_standin.xml")
+CALVES = ("FR_calf", "FL_calf", "RR_calf", "RL_calf")
+
+
+@pytest.mark.parametrize("fused", [True, False])
+def test_urdf_path_equals_mjcf_path_bit_for_bit(fused):
+    """The stand-in body as MJCF (parsed by mjcf.py) and as the URDF tests/urdf_fixture.py writes from it (explicit inertias,
+    capsule collisions, per-link friction; parsed by urdf.py): the two `A1Physics` must give the same closed-loop env —
+    observations, rewards, torques and engine state bit for bit, on the flat ground and on a `task=` terrain."""
+    n = 96
+    w = np.tile([[0.02], [0.0], [0.015]], (1, 20)) * np.sin(np.linspace(0, 2 * np.pi, 20))
+    for task in ("plane", "slopestair"):
+        m = load_mjcf(STANDIN_XML, foot_names=CALVES)
+        envs = []
+        for phys in (A1Physics(n, model=m, device=DEV, fused=fused),
+                     A1Physics(n, urdf=model_to_urdf(m), device=DEV, fused=fused, foot_links=CALVES, inertia="file", armature=0.01)):
+            envs.append(metagym_amd.make("quadrupedal-v0", num_envs=n, physics=phys, device=DEV, ETG=1, ETG_w=w, ETG_b=np.zeros(3),
+                                         task=task, control_latency=0.0057))
+        o0, _ = envs[0].reset()
+        o1, _ = envs[1].reset()
+        assert torch.equal(o0, o1)
+        rs = np.random.RandomState(3)
+        for k in range(6):
+            a = torch.as_tensor(rs.uniform(-0.2, 0.2, (n, 12)), device=DEV)
+            r0, r1 = envs[0].step(a), envs[1].step(a)
+            assert torch.equal(r0[0], r1[0]), "observation, step %d" % k
+            assert torch.equal(r0[1], r1[1]) and torch.equal(r0[2], r1[2])
+            assert torch.equal(envs[0].last_torques, envs[1].last_torques), "torques, step %d" % k
+            for key in ("pos", "rot", "vel", "omega", "q", "qd", "feet_contact", "bad_contacts"):
+                assert torch.equal(getattr(envs[0].physics.env, key), getattr(envs[1].physics.env, key)), key
+        assert torch.isfinite(r0[0]).all() and float(r0[3]["real_contact"].sum()) > 0
+
+
+def _oracle_boxes(spec):
+    out = []
+    for half, pos, (x, y, z, w), mu in spec:
+        nq = np.sqrt(x * x + y * y + z * z + w * w)
+        x, y, z, w = x / nq, y / nq, z / nq, w / nq
+        R = np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y)],
+                      [2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x)],
+                      [2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)]])
+        out.append((np.array(pos, float), R, np.array(half, float), float(mu)))
+    return out
+
+
+def test_urdf_robot_on_a_terrain_course_matches_the_oracle():
+    """The A1-shaped URDF fixture (box / cylinder / sphere links, merged fixed links, 124 contact proxies = two lane chunks,
+    per-link friction, bounding-box inertias) dropped along the reference's `slopestair` course and driven by torques:
+    GPU == oracle/abd.py (2e-7 over 150 sub-steps), the toe flags and the bad-contact counts identical sub-step by sub-step."""
+    n = 8
+    phys = A1Physics(n, urdf=a1_like_urdf(), device=DEV, foot_links=A1_LIKE_TOES)
+    m = phys.model
+    assert len(m.sph_body) == 124 and list(m.joint_names) == MOTOR_NAMES
+    add_h, env_info, boxes = task_terrain("slopestair")
+    phys.set_terrain(boxes, [0.0, 0.0, 0.28 + add_h])
+    phys.reset(None)
+    e = phys.env
+    # spread the robots over the course (start platform, up-slope, top, down-stair) and tip two of them over so that trunk /
+    # hip / thigh proxies hit the ground too ("bad" contacts)
+    xs = np.array([0.0, 0.6, 1.2, 1.9, 2.6, 3.3, 0.3, 1.5])
+    rs = np.random.RandomState(0)
+    pos = e.pos.cpu().numpy()
+    pos[0] += xs
+    pos[2] += 0.25
+    rot = e.rot.cpu().numpy()
+    for k in (6, 7):
+        c, s_ = np.cos(1.3), np.sin(1.3)
+        rot[:, k] = np.array([[1, 0, 0], [0, c, -s_], [0, s_, c]]).reshape(9)       # rolled onto its side
+    e.pos.copy_(torch.as_tensor(pos))
+    e.rot.copy_(torch.as_tensor(rot))
+    prm = abd.Params(dt=0.002, substeps=1, iterations=23, erp=0.2, friction=5.0, sphere_friction=m.sph_friction,
+                     self_collision=False, gravity=10.0, terrain=_oracle_boxes(boxes))
+    states = []
+    q0 = e.q.cpu().numpy()
+    for k in range(n):
+        s = abd.State(m)
+        s.pos, s.rot, s.q = pos[:, k].copy(), rot[:, k].reshape(3, 3).copy(), q0[:, k].copy()
+        states.append(s)
+    target = np.array([0, 0.9, -1.8] * 4, float)
+    log = torch.empty(1, 43, n, dtype=torch.float64, device=DEV)
+    worst, bad_seen, feet_seen = 0.0, 0, 0
+    for t in range(150):
+        q, qd = e.q.cpu().numpy(), e.qd.cpu().numpy()
+        tau = np.clip(80.0 * (target[:, None] - q) - 1.5 * qd + rs.uniform(-2, 2, (12, n)), -33.5, 33.5)
+        e.step_actuated(torch.as_tensor(tau, device=DEV), raw_torque=True, n_substeps=1, log=log)
+        gq, gp = e.q.cpu().numpy(), e.pos.cpu().numpy()
+        feet, bad = e.feet_contact.cpu().numpy(), e.bad_contacts.cpu().numpy()
+        for k in range(n):
+            touching = abd.substep(m, states[k], tau[:, k], prm)
+            s = states[k]
+            worst = max(worst, np.abs(gq[:, k] - s.q).max(), np.abs(gp[:, k] - s.pos).max())
+            assert np.allclose(gq[:, k], s.q, rtol=0, atol=2e-7) and np.allclose(gp[:, k], s.pos, rtol=0, atol=2e-7), (t, k, worst)
+            o_feet = [float(any(m.sph_foot[g] == f for g in touching)) for f in range(4)]
+            o_bad = sum(1 for g in touching if m.sph_foot[g] < 0)
+            assert list(feet[:, k]) == o_feet and int(bad[k]) == o_bad, (t, k)
+            bad_seen += o_bad
+            feet_seen += int(sum(o_feet))
+    assert bad_seen > 50 and feet_seen > 500                      # both kinds of contact happened
+    print("a1-like URDF on slopestair: max |state diff| GPU vs oracle %.2e; %d toe / %d bad contact points" % (worst, feet_seen, bad_seen))
+
+
+def test_quadrupedal_v0_runs_closed_loop_from_a_urdf():
+    """`make("quadrupedal-v0", num_envs=..., urdf=...)` — no physics object: the robot file on the engine, 13 fused sub-steps
+    per launch with the PD model inside. Zero actions hold (0, 0.9, -1.8) x 4: the robot stands on its four toes, nothing
+    else touches, nothing terminates; on `slopestair` it stands on the start platform; an ETG gait moves it forward."""
+    n = 512
+    env = metagym_amd.make("quadrupedal-v0", num_envs=n, urdf=a1_like_urdf(), device=DEV)
+    assert hasattr(env.physics, "fused_step")
+    obs, info = env.reset()
+    a = torch.zeros(n, 12, dtype=torch.float64, device=DEV)
+    for _ in range(25):
+        obs, reward, done, info = env.step(a)
+        assert torch.isfinite(obs).all() and not bool(done.any())
+    z = info["base"][:, 2]
+    assert 0.2 < float(z.min()) and float(z.max()) < 0.3
+    assert float(info["real_contact"].sum(dim=1).min()) >= 3.0 and int(info["bad"].max()) == 0
+    assert float((env.robot.GetMotorAngles() - torch.as_tensor([0, 0.9, -1.8] * 4, device=DEV)).abs().max()) < 0.15
+    env = metagym_amd.make("quadrupedal-v0", num_envs=n, urdf=a1_like_urdf(), device=DEV, task="slopestair")
+    obs, info = env.reset()
+    for _ in range(15):
+        obs, reward, done, info = env.step(a)
+    assert float(info["base"][:, 2].min()) > 0.2 + env.add_height - 0.05 and not bool(done.any())
+    # ETG open-loop trot with hand-set weights: the base advances
+    w = np.tile([[0.03], [0.0], [0.02]], (1, 20)) * np.sin(np.linspace(0, 2 * np.pi, 20))
+    env = metagym_amd.make("quadrupedal-v0", num_envs=n, urdf=a1_like_urdf(), device=DEV, ETG=1, ETG_w=w, ETG_b=np.zeros(3))
+    obs, info = env.reset()
+    x0 = info["base"][:, 0].clone()
+    for _ in range(40):
+        obs, reward, done, info = env.step(a)
+    assert torch.isfinite(obs).all() and float((info["base"][:, 0] - x0).abs().mean()) > 0.01
+
+
+def test_quadrupedal_without_a_robot_explains_itself():
+    with pytest.raises(Exception, match="urdf="):
+        metagym_amd.make("quadrupedal-v0", num_envs=4, device=DEV)
+
+
+def test_body_damping_and_bullet_box_inertia_on_the_engine_match_the_oracle():
+    """The two PyBullet-default behaviours DESIGN.md §3.4 lists as options, on the GPU (shape-generic wave kernel): humanoids
+    with btMultiBody's 0.04 / 0.04 velocity damping and bounding-box inertias follow the oracle run with the same options
+    (1e-9 over 10 env steps), and differ from the undamped run."""
+    models = [variants.model("humanoid", inertia="bullet_box"), variants.model("humanoid", "TRAIN", 7, inertia="bullet_box")]
+    n = 6
+    env = MetaHumanoidEnv(num_envs=n, device=DEV, body_damping=(0.04, 0.04))
+    plain = MetaHumanoidEnv(num_envs=n, device=DEV)
+    rs = np.random.RandomState(1)
+    noise = rs.uniform(-0.1, 0.1, (n, 17))
+    oenvs = []
+    for e_, mods in ((env, models), (plain, models)):
+        e_.set_task(mods)
+        e_.reset(joint_noise=noise)
+    ids = env.task_id.cpu().numpy()
+    for k in range(n):
+        m = models[ids[k]]
+        o = abd.WalkerEnv(m, prm=abd.Params(friction=0.8 * float(m.geom_friction), self_friction=float(m.geom_friction) ** 2,
+                                            body_damping=(0.04, 0.04)))
+        o.reset(noise[k])
+        oenvs.append(o)
+    worst = 0.0
+    for t in range(10):
+        a = rs.uniform(-1, 1, (n, 17)).astype(np.float32)
+        env.step(torch.as_tensor(a))
+        plain.step(torch.as_tensor(a))
+        q, pos = env.q.cpu().numpy().T, env.pos.cpu().numpy().T
+        for k in range(n):
+            oenvs[k].step(a[k])
+            worst = max(worst, np.abs(q[k] - oenvs[k].s.q).max(), np.abs(pos[k] - oenvs[k].s.pos).max())
+    assert worst < 1e-9, worst
+    assert float((env.q - plain.q).abs().max()) > 1e-4            # the option does something
+    print("humanoid, body damping 0.04 + bullet_box inertia: max |state diff| GPU vs oracle over 10 steps %.2e" % worst)
