@@ -67,8 +67,12 @@ def _oracle_boxes(spec):
 
 def test_urdf_robot_on_a_terrain_course_matches_the_oracle():
     """The A1-shaped URDF fixture (box / cylinder / sphere links, merged fixed links, 124 contact proxies = two lane chunks,
-    per-link friction, bounding-box inertias) dropped along the reference's `slopestair` course and driven by torques:
-    GPU == oracle/abd.py (2e-7 over 150 sub-steps), the toe flags and the bad-contact counts identical sub-step by sub-step."""
+    per-link friction, bounding-box inertias) dropped along the reference's `slopestair` course and driven by torques, two
+    robots rolled onto their sides so trunk / hip / thigh proxies touch too. Every one of 150 sub-steps is checked on its
+    own: the oracle (oracle/abd.py) steps from the state the GPU had before the sub-step and must land on the GPU's state
+    (1e-9: positions, velocities, joint angles and rates), with identical toe flags and bad-contact counts. (A 150-sub-step
+    free-running comparison is not a test of the kernel: a contact that closes one sub-step earlier on one side — a 1e-12
+    difference in a depth — moves the trajectories 1e-5 apart.)"""
     n = 8
     phys = A1Physics(n, urdf=a1_like_urdf(), device=DEV, foot_links=A1_LIKE_TOES)
     m = phys.model
@@ -77,9 +81,7 @@ def test_urdf_robot_on_a_terrain_course_matches_the_oracle():
     phys.set_terrain(boxes, [0.0, 0.0, 0.28 + add_h])
     phys.reset(None)
     e = phys.env
-    # spread the robots over the course (start platform, up-slope, top, down-stair) and tip two of them over so that trunk /
-    # hip / thigh proxies hit the ground too ("bad" contacts)
-    xs = np.array([0.0, 0.6, 1.2, 1.9, 2.6, 3.3, 0.3, 1.5])
+    xs = np.array([0.0, 0.6, 1.2, 1.9, 2.6, 3.3, 0.3, 1.5])      # start platform, up-slope, top, down-stair
     rs = np.random.RandomState(0)
     pos = e.pos.cpu().numpy()
     pos[0] += xs
@@ -92,33 +94,35 @@ def test_urdf_robot_on_a_terrain_course_matches_the_oracle():
     e.rot.copy_(torch.as_tensor(rot))
     prm = abd.Params(dt=0.002, substeps=1, iterations=23, erp=0.2, friction=5.0, sphere_friction=m.sph_friction,
                      self_collision=False, gravity=10.0, terrain=_oracle_boxes(boxes))
-    states = []
-    q0 = e.q.cpu().numpy()
-    for k in range(n):
-        s = abd.State(m)
-        s.pos, s.rot, s.q = pos[:, k].copy(), rot[:, k].reshape(3, 3).copy(), q0[:, k].copy()
-        states.append(s)
     target = np.array([0, 0.9, -1.8] * 4, float)
     log = torch.empty(1, 43, n, dtype=torch.float64, device=DEV)
-    worst, bad_seen, feet_seen = 0.0, 0, 0
+    keys = ("pos", "rot", "vel", "omega", "q", "qd")
+    worst, bad_seen, feet_seen, terrain_seen = 0.0, 0, 0, 0
     for t in range(150):
-        q, qd = e.q.cpu().numpy(), e.qd.cpu().numpy()
-        tau = np.clip(80.0 * (target[:, None] - q) - 1.5 * qd + rs.uniform(-2, 2, (12, n)), -33.5, 33.5)
+        st = {k: getattr(e, k).cpu().numpy() for k in keys}
+        tau = np.clip(80.0 * (target[:, None] - st["q"]) - 1.5 * st["qd"] + rs.uniform(-2, 2, (12, n)), -33.5, 33.5)
         e.step_actuated(torch.as_tensor(tau, device=DEV), raw_torque=True, n_substeps=1, log=log)
-        gq, gp = e.q.cpu().numpy(), e.pos.cpu().numpy()
+        g = {k: getattr(e, k).cpu().numpy() for k in keys}
         feet, bad = e.feet_contact.cpu().numpy(), e.bad_contacts.cpu().numpy()
         for k in range(n):
-            touching = abd.substep(m, states[k], tau[:, k], prm)
-            s = states[k]
-            worst = max(worst, np.abs(gq[:, k] - s.q).max(), np.abs(gp[:, k] - s.pos).max())
-            assert np.allclose(gq[:, k], s.q, rtol=0, atol=2e-7) and np.allclose(gp[:, k], s.pos, rtol=0, atol=2e-7), (t, k, worst)
-            o_feet = [float(any(m.sph_foot[g] == f for g in touching)) for f in range(4)]
-            o_bad = sum(1 for g in touching if m.sph_foot[g] < 0)
+            s = abd.State(m)
+            s.pos, s.rot, s.v, s.w = st["pos"][:, k].copy(), st["rot"][:, k].reshape(3, 3).copy(), st["vel"][:, k].copy(), st["omega"][:, k].copy()
+            s.q, s.qd = st["q"][:, k].copy(), st["qd"][:, k].copy()
+            rows = abd.constraint_rows(m, s, abd.kinematics(m, s), prm)
+            terrain_seen += sum(1 for r in rows if r[2] == 0 and len(r) == 5 and r[4] >= 0 and any(len(q_) == 6 for q_ in rows))
+            touching = abd.substep(m, s, tau[:, k], prm)
+            d = max(np.abs(g["q"][:, k] - s.q).max(), np.abs(g["qd"][:, k] - s.qd).max(), np.abs(g["pos"][:, k] - s.pos).max(),
+                    np.abs(g["vel"][:, k] - s.v).max(), np.abs(g["omega"][:, k] - s.w).max(), np.abs(g["rot"][:, k] - s.rot.reshape(9)).max())
+            worst = max(worst, d)
+            assert d < 1e-9, (t, k, d)
+            o_feet = [float(any(m.sph_foot[g_] == f for g_ in touching)) for f in range(4)]
+            o_bad = sum(1 for g_ in touching if m.sph_foot[g_] < 0)
             assert list(feet[:, k]) == o_feet and int(bad[k]) == o_bad, (t, k)
             bad_seen += o_bad
             feet_seen += int(sum(o_feet))
-    assert bad_seen > 50 and feet_seen > 500                      # both kinds of contact happened
-    print("a1-like URDF on slopestair: max |state diff| GPU vs oracle %.2e; %d toe / %d bad contact points" % (worst, feet_seen, bad_seen))
+    assert bad_seen > 50 and feet_seen > 500 and terrain_seen > 100           # toe, non-toe and terrain-box contacts all happened
+    print("a1-like URDF on slopestair: max one-sub-step |state diff| GPU vs oracle %.2e over 150 sub-steps x 8 robots; %d toe / %d bad "
+          "contact points" % (worst, feet_seen, bad_seen))
 
 
 def test_quadrupedal_v0_runs_closed_loop_from_a_urdf():
