@@ -532,6 +532,28 @@ def secondary_workloads(dev):
                     "no physics in this figure"}
         del env
         torch.cuda.empty_cache()
+        # quadrupedal-v0 WITH physics: a URDF robot on the articulated-body engine (metagym_amd.quadrupedal.A1Physics), 13 fused
+        # sub-steps per launch with the PD motor model inside, 23 solver iterations. The file is the repo's A1-shaped demo
+        # robot (examples/a1_like: NOT pybullet_data's a1.urdf, which is absent from the reference tree).
+        import metagym_amd
+        n3 = 8192
+        urdf = os.path.join(ROOT, "examples", "a1_like", "a1_like.urdf")
+        w = np.tile([[0.03], [0.0], [0.02]], (1, 20)) * np.sin(np.linspace(0, 2 * np.pi, 20))
+        env = metagym_amd.make("quadrupedal-v0", num_envs=n3, urdf=urdf, device=dev, ETG=1, ETG_w=w, ETG_b=np.zeros(3), auto_reset=True)
+        env.reset()
+        a3 = torch.zeros(n3, 12, **f64)
+        s3 = _time_steps(lambda i: env.step(a3), 20, 5)
+        replay = env.capture_step()
+        env.reset()
+        s3g = _time_steps(lambda i: replay(a3), 20, 5)
+        out["quadrupedal_v0_urdf_%denvs" % n3] = {
+            "env_steps_per_s": n3 / s3, "ms_per_env_step": s3 * 1e3, "ms_per_env_step_hipgraph": s3g * 1e3,
+            "env_steps_per_s_hipgraph": n3 / s3g, "physics_substeps_per_s_hipgraph": 13 * n3 / s3g,
+            "robot": "examples/a1_like/a1_like.urdf (13 bodies, 12 hinges, 124 contact proxies)",
+            "note": "A1GymEnv.step end to end (ETG + IK, 13 x 2 ms engine sub-steps with the PD motor model inside one launch, "
+                    "observation history, sensors, reward, fused per-robot reset); dynamics parity with PyBullet unpinned"}
+        del env
+        torch.cuda.empty_cache()
     except Exception as e:
         out["a1_error"] = repr(e)
     return out

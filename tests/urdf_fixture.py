@@ -111,3 +111,13 @@ def a1_like_urdf(shuffle_legs=False):
         joint(leg + "_toe_fixed", "fixed", leg + "_lower", leg + "_toe", (0, 0, -0.2))
     o.append('</robot>')
     return "\n".join(o)
+
+
+if __name__ == "__main__":      # python tests/urdf_fixture.py examples/a1_like/a1_like.urdf
+    import sys
+    header = ("<!-- A1-SHAPED TEST / DEMO ROBOT, written by tests/urdf_fixture.py:a1_like_urdf(). NOT the reference's robot file: that is\n"
+              "     pybullet_data/a1/a1.urdf, which is not in the reference tree. Leg geometry and joint ranges are the constants the\n"
+              "     reference's own Python states (robots/a1.py:61-63,88-123,158-196); masses, inertias and collision shapes are made up. -->\n")
+    text = a1_like_urdf()
+    first, rest = text.split("\n", 1)
+    open(sys.argv[1], "w").write(first + "\n" + header + rest + "\n")
