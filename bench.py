@@ -222,25 +222,64 @@ def cpu_baseline_maze3d(seconds=4.0, res=256):
                       % (sum(counts), res, res, el)}
 
 
-def cpu_baseline_walker(seconds=3.0):
-    """Secondary CPU figure for C4: the numpy restatement of the walker engine (oracle/abd.py — the checker the
-    GPU kernels are tested against, NOT PyBullet, which the reference calls and which is not in its tree), one
-    env on one core."""
-    from oracle import abd
+def cpu_baseline_walker(seconds=10.0, envs_per_thread=32):
+    """CPU figure for C4 ("own C++ restatement on P cores"): oracle/walker_oracle.c — this engine's env step
+    in scalar C (the wave kernel's algorithm; pinned to the numpy restatement oracle/abd.py to 1e-12 per sub-step by
+    tests/test_oracle_walker_c.py), NOT PyBullet, which the reference calls and which is not in its tree. One thread per usable
+    core, each stepping its own humanoids (the 256 TRAIN variants round-robin, random actions, finished episodes restart); the
+    timed loop runs inside C (ctypes releases the GIL)."""
+    import ctypes as C
+    from oracle import abd, walker_c
     from metagym_amd.metalocomotion import variants
-    m = variants.model("humanoid", "TRAIN", 0)
-    env = abd.WalkerEnv(m, prm=abd.Params(friction=0.8 * float(m.geom_friction), self_friction=float(m.geom_friction) ** 2))
+    lib = walker_c.load()
+    cores = usable_cpus()
+    models = variants.models("humanoid", "TRAIN")
+    power = abd.HUMANOID_MOTOR_POWER * 0.41
+    packed = [walker_c.make_model(m, power) for m in models]
+    cmodels = (walker_c.Model * len(packed))(*[p[0] for p in packed])
+    prm = walker_c.humanoid_params(models[0], max_steps=1000)
     rs = np.random.RandomState(0)
-    env.reset(rs.uniform(-0.1, 0.1, len(m.joint_lo)))
-    n, t0 = 0, time.perf_counter()
-    while time.perf_counter() - t0 < seconds:
-        _, _, done, _ = env.step(rs.uniform(-1, 1, len(m.joint_lo)))
-        if done:
-            env.reset(rs.uniform(-0.1, 0.1, len(m.joint_lo)))
-        n += 1
+    actions = np.ascontiguousarray(rs.uniform(-1, 1, (4096, 17)).astype(np.float32))
+    blocks = []
+    for t in range(cores):
+        envs = (walker_c.Env * envs_per_thread)()
+        ids = (C.c_int * envs_per_thread)(*[(t * envs_per_thread + i) % len(models) for i in range(envs_per_thread)])
+        for i in range(envs_per_thread):
+            noise = np.ascontiguousarray(rs.uniform(-0.1, 0.1, 17))
+            lib.wo_env_reset(C.byref(cmodels[ids[i]]), C.byref(prm), C.byref(envs[i]), noise.ctypes.data_as(C.POINTER(C.c_double)), None)
+        blocks.append((envs, ids))
+    counts = [0] * cores
+    stop = time.perf_counter() + seconds
+
+    def work(i):
+        envs, ids = blocks[i]
+        total = 0
+        while time.perf_counter() < stop:
+            total += lib.wo_run(cmodels, ids, C.byref(prm), envs, envs_per_thread, 8, actions.ctypes.data_as(C.POINTER(C.c_float)), 4096)
+        counts[i] = total
+
+    t0 = time.perf_counter()
+    threads = [threading.Thread(target=work, args=(i,)) for i in range(cores)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
     el = time.perf_counter() - t0
-    return {"value": n / el, "unit": "env-steps/s", "cores": 1, "kind": "port",
-            "sample": "%d env steps of one humanoid, %.1f s wall, numpy restatement of this engine (oracle/abd.py)" % (n, el)}
+    return {"value": sum(counts) / el, "unit": "env-steps/s", "cores": cores, "kind": "port",
+            "sample": "%d env steps of humanoids over the 256 TRAIN variants (%d envs per thread, random actions, finished episodes "
+                      "restart), %.1f s wall, oracle/walker_oracle.c gcc -O2 scalar, one thread per core; this engine's algorithm, not "
+                      "PyBullet (absent from the reference tree)" % (sum(counts), envs_per_thread, el)}
+
+
+def walker_flops(robot="humanoid"):
+    """Counted f64 operations per env step (oracle/count_walker_flops.py: the instrumented C restatement of the wave kernel's
+    algorithm over a rollout of this workload), from the committed profiles/<round>/walker_flops.json."""
+    for rnd in sorted((d for d in os.listdir(os.path.join(ROOT, "profiles")) if d.startswith("r") and d[1:].isdigit()), reverse=True):
+        p = os.path.join(ROOT, "profiles", rnd, "walker_flops.json")
+        if os.path.exists(p):
+            rec = json.load(open(p))[robot]
+            return float(rec["flop_per_env_step"]), "profiles/%s/walker_flops.json (%s)" % (rnd, rec["source"]), rec["per_env_step"]
+    return None, None, None
 
 
 # ---------------------------------------------------------------------------------------- GPU timing helpers
@@ -457,16 +496,20 @@ def secondary_workloads(dev):
         env.reset(seed=0)
         acts = [torch.rand(n, env.n_joints, device=dev) * 2 - 1 for _ in range(4)]
         s = _time_steps(lambda i: env.step(acts[i % 4]), 12, 3)
-        byt, flop = 625, 1.0e5                                    # SURVEY.md §8(d) C4 per env-step figures
+        byt = 625                                                 # SURVEY.md §8(d) C4 bytes per env-step
+        flop, flop_src, flop_mix = walker_flops("humanoid")
+        if flop is None:
+            flop, flop_src = 1.0e5, "SURVEY.md §8(d) estimate (no counted figure found under profiles/)"
         out["C4_humanoid_8192envs_256variants"] = {
             "env_steps_per_s": n / s, "ms_per_launch": s * 1e3,
             "roofline": {"bound": "valu", "achieved": flop * n / s / 1e12, "peak": FP64_VALU_PEAK_TFLOPS,
                          "unit": "TFLOP/s", "frac": flop * n / s / 1e12 / FP64_VALU_PEAK_TFLOPS,
-                         "algorithmic_flop_per_env_step": flop,
+                         "algorithmic_flop_per_env_step": flop, "flop_source": flop_src, "flop_mix_per_env_step": flop_mix,
                          "achieved_hbm_gbs": byt * n / s / 1e9, "hbm_frac": byt * n / s / 1e9 / HBM_PEAK_GBS,
                          "algorithmic_bytes_per_env_step": byt,
-                         "note": "f64 VALU peak; flop and byte figures are SURVEY.md §8(d)'s estimates for the "
-                                 "articulated-body step (4 sub-steps x [dynamics + contacts + 5 PGS sweeps])"},
+                         "note": "f64 VALU peak; the flop figure is COUNTED (add + mul + 2 fma + div + sqrt + trig of the scalar C "
+                                 "restatement of this kernel's algorithm, averaged over a rollout of this workload); one wave "
+                                 "per env uses <= 29 of 64 lanes in every phase, so lane utilisation bounds this fraction at ~0.4"},
             "note": "physics parity unpinned (PyBullet is not in the reference tree)"}
         del env, acts
         torch.cuda.empty_cache()

@@ -1,0 +1,110 @@
+"""ctypes front-end of oracle/walker_oracle.c — TEST INFRASTRUCTURE (see oracle/__init__.py): the native CPU baseline of
+bench.py's C4 entry and the flop counter. Pinned to oracle/abd.py by tests/test_oracle_walker_c.py."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from . import quadrotor as _q
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+MAX_BODIES, MAX_JOINTS, MAX_SPHERES, MAX_FEET, MAX_GEOMS, MAX_PAIRS = 16, 24, 128, 6, 24, 128
+
+
+class Model(C.Structure):
+    _fields_ = [("nb", C.c_int32), ("nj", C.c_int32), ("ns", C.c_int32), ("nf", C.c_int32), ("ng", C.c_int32), ("npairs", C.c_int32),
+                ("body_parent", C.c_int32 * MAX_BODIES), ("joint_body", C.c_int32 * MAX_JOINTS), ("sphere_body", C.c_int32 * MAX_SPHERES),
+                ("foot_body", C.c_int32 * MAX_FEET), ("geom_body", C.c_int32 * MAX_GEOMS),
+                ("pair_a", C.c_uint8 * MAX_PAIRS), ("pair_b", C.c_uint8 * MAX_PAIRS), ("table", C.POINTER(C.c_double))]
+
+
+class Params(C.Structure):
+    _fields_ = [("dt", C.c_double), ("substeps", C.c_int32), ("iterations", C.c_int32), ("erp", C.c_double), ("limit_erp", C.c_double),
+                ("gravity", C.c_double), ("friction", C.c_double), ("self_friction", C.c_double), ("self_collision", C.c_int32),
+                ("max_steps", C.c_int32), ("alive_z", C.c_double), ("alive_bonus", C.c_double), ("initial_z", C.c_double),
+                ("walk_target_x", C.c_double), ("walk_target_y", C.c_double), ("initial_z_from_state", C.c_int32),
+                ("floor_in_parts", C.c_int32), ("torque_f32", C.c_int32), ("height_f32", C.c_int32)]
+
+
+class State(C.Structure):
+    _fields_ = [("pos", C.c_double * 3), ("rot", C.c_double * 9), ("vel", C.c_double * 3), ("omega", C.c_double * 3),
+                ("q", C.c_double * MAX_JOINTS), ("qd", C.c_double * MAX_JOINTS)]
+
+
+class Env(C.Structure):
+    _fields_ = [("s", State), ("potential", C.c_double), ("initial_z", C.c_double), ("feet_contact", C.c_float * MAX_FEET),
+                ("steps", C.c_int32), ("floor_known", C.c_int32), ("initial_z_unset", C.c_int32)]
+
+
+_libs = {}
+
+
+def load(count_flops=False):
+    """The oracle library (built with the other *_oracle.c files); `count_flops=True`: a second build of walker_oracle.c
+    alone with -DWO_COUNT_FLOPS (every arithmetic helper bumps a counter)."""
+    if count_flops not in _libs:
+        if count_flops:
+            out = os.path.join(_HERE, "libwalker_oracle_count.so")
+            src = os.path.join(_HERE, "walker_oracle.c")
+            if not os.path.exists(out) or os.path.getmtime(src) > os.path.getmtime(out):
+                subprocess.check_call(["gcc", "-O2", "-fPIC", "-std=c11", "-mfma", "-ffp-contract=off", "-DWO_COUNT_FLOPS", "-shared",
+                                       "-o", out, src, "-lm"])
+            lib = C.CDLL(out)
+        else:
+            lib = C.CDLL(_q.build())
+        lib.wo_substep.restype = C.c_int
+        lib.wo_substep.argtypes = [C.POINTER(Model), C.POINTER(Params), C.POINTER(State), C.POINTER(C.c_double), C.POINTER(C.c_ulonglong)]
+        lib.wo_env_reset.restype = None
+        lib.wo_env_reset.argtypes = [C.POINTER(Model), C.POINTER(Params), C.POINTER(Env), C.POINTER(C.c_double), C.POINTER(C.c_float)]
+        lib.wo_env_step.restype = C.c_int
+        lib.wo_env_step.argtypes = [C.POINTER(Model), C.POINTER(Params), C.POINTER(Env), C.POINTER(C.c_float), C.POINTER(C.c_float),
+                                    C.POINTER(C.c_double), C.POINTER(C.c_double)]
+        lib.wo_run.restype = C.c_long
+        lib.wo_run.argtypes = [C.POINTER(Model), C.POINTER(C.c_int), C.POINTER(Params), C.POINTER(Env), C.c_int, C.c_int,
+                               C.POINTER(C.c_float), C.c_int]
+        lib.wo_flops_read.restype = C.c_int
+        lib.wo_flops_read.argtypes = [C.POINTER(C.c_ulonglong), C.c_int]
+        _libs[count_flops] = lib
+    return _libs[count_flops]
+
+
+def pack_table(m, motor_torque):
+    parts = [m.body_pos, m.body_rot, m.body_mass, m.body_com, m.body_inertia, m.joint_anchor, m.joint_axis, m.joint_lo, m.joint_hi,
+             m.joint_armature, m.joint_damping, m.joint_stiffness, motor_torque, m.sph_pos, m.sph_radius, m.geom_p0, m.geom_p1,
+             m.geom_radius]
+    return np.ascontiguousarray(np.concatenate([np.asarray(p, np.float64).reshape(-1) for p in parts]))
+
+
+def make_model(m, motor_torque):
+    """-> (Model, table array to keep alive)"""
+    cm = Model()
+    cm.nb, cm.nj, cm.ns, cm.nf = len(m.body_parent), len(m.joint_body), len(m.sph_body), len(m.foot_body)
+    cm.ng, cm.npairs = len(m.geom_body), len(m.pair_a)
+    for name, src in (("body_parent", m.body_parent), ("joint_body", m.joint_body), ("sphere_body", m.sph_body), ("foot_body", m.foot_body),
+                      ("geom_body", m.geom_body), ("pair_a", m.pair_a), ("pair_b", m.pair_b)):
+        arr = getattr(cm, name)
+        for i, v in enumerate(src):
+            arr[i] = int(v)
+    table = pack_table(m, motor_torque)
+    cm.table = table.ctypes.data_as(C.POINTER(C.c_double))
+    return cm, table
+
+
+def humanoid_params(m, **over):
+    """abd.WalkerEnv's humanoid defaults (HUMANOID_MOTOR_POWER x 0.41 goes into the model table as motor_torque)."""
+    p = Params()
+    p.dt, p.substeps, p.iterations, p.erp, p.limit_erp, p.gravity = 0.005, 4, 5, 0.9, 0.2, 9.8
+    p.friction, p.self_friction, p.self_collision = 0.8 * float(m.geom_friction), float(m.geom_friction) ** 2, 1
+    p.max_steps, p.alive_z, p.alive_bonus, p.initial_z = 2000, 0.50, 2.0, 0.8
+    p.walk_target_x, p.walk_target_y, p.initial_z_from_state, p.floor_in_parts, p.torque_f32, p.height_f32 = 1e3, 0.0, 0, 1, 1, 1
+    for k, v in over.items():
+        setattr(p, k, v)
+    return p
+
+
+def ant_params(m, **over):
+    p = humanoid_params(m, alive_z=0.26, alive_bonus=1.0, initial_z=0.0, initial_z_from_state=1, torque_f32=0, height_f32=0)
+    for k, v in over.items():
+        setattr(p, k, v)
+    return p
