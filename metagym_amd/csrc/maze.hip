@@ -463,6 +463,9 @@ __device__ ColRec column_pass(const ViewK &vk, const Task &t, const EnvShared &e
         int e2 = to_int_clamped((vk.half_v + bv) / vk.pixel_size, -1, vk.V - 1);
         if (s2 < 0) s2 = 0;
         if (e2 > vk.V) e2 = vk.V;
+        // range(v_s, v_e) of the reference is empty here (also for the -1 that stands for a negative / NaN bound): no pixel
+        // can be touched, and a negative e2 must not reach the packed words below (its sign bits would overwrite the cell field)
+        if (e2 <= s2) return;
         // compact record (one word: 12-bit span bounds, 8-bit cell) when the frame has < 4096 rows and the maze
         // <= 256 cells — half the LDS of the overlay records, which is what bounds the resident envs per CU
         if (REC == 1) entries[n_tr * vk.slab + lane] = (unsigned)s2 | ((unsigned)e2 << 12) | ((unsigned)cell << 24);

@@ -210,7 +210,10 @@ class WalkerBatchEnv(object):
         p.seed, p.env_id_base = self.seed_value & 0xFFFFFFFFFFFFFFFF, self.env_id_base
         p.torque_f32 = int(self.torque_f32)
         p.height_f32 = int(self.initial_z is not None)     # python-float initial_z: float32 alive sum (walker_base_env.py:47)
-        self._first_reset = True                           # the floor link is not in robot.parts yet (walker_base_env.py:30-31)
+        # the floor link joins robot.parts after an env's FIRST reset (walker_base_env.py:30-31) — per env: a masked first
+        # reset must not change what the other envs' own first reset will see
+        self._floor_known = torch.zeros(N, dtype=torch.bool, device=dev)
+        self._all_floor_known = False                      # host mirror: True once every env went through a reset
         self._params_c = p
         self._apply_terrain()
         self._obs = torch.zeros(N, self.obs_dim, dtype=torch.float32, device=dev)
@@ -223,23 +226,30 @@ class WalkerBatchEnv(object):
                                      dtype=np.float32)
         self._robot_set = True
 
-    _STATE_KEYS = ("pos", "rot", "vel", "omega", "q", "qd", "potential", "feet_contact", "steps")
+    _STATE_KEYS = ("pos", "rot", "vel", "omega", "q", "qd", "potential", "feet_contact", "steps", "bad_contacts")
 
     def state_dict(self):
         """Simulator arrays + what a bit-identical continuation also needs: which model every env runs (task_id), the
-        auto-reset stream position (global_step is the Philox step index) and the host RandomState behind reset()."""
+        auto-reset stream position (global_step is the Philox step index), the host RandomState behind reset() and which envs
+        have been reset at least once (the floor-in-parts quirk of the first reset, walker_base_env.py:30-31)."""
         sd = {k: getattr(self, k).clone() for k in self._STATE_KEYS}
         sd["task_id"] = self.task_id.clone()
+        sd["floor_known"] = self._floor_known.clone()      # which envs' robot.parts already hold the floor link
         sd["global_step"] = int(self.global_step)
         sd["np_random"] = self.np_random.get_state()
         return sd
 
     def load_state_dict(self, sd):
         for k in self._STATE_KEYS + (("task_id",) if "task_id" in sd else ()):
+            if k == "bad_contacts" and k not in sd:
+                continue                           # checkpoints written before ABI 4
             dst, src = getattr(self, k), torch.as_tensor(sd[k])
             if tuple(src.shape) != tuple(dst.shape):
                 raise ValueError("state_dict[%r] has shape %s, this env holds %s" % (k, tuple(src.shape), tuple(dst.shape)))
             dst.copy_(src.to(dst.dtype))
+        if "floor_known" in sd:
+            self._floor_known.copy_(torch.as_tensor(sd["floor_known"]).to(self.device))
+            self._all_floor_known = bool(self._floor_known.all())     # (load time, not on the step path)
         if "global_step" in sd:
             self.global_step = int(sd["global_step"])
         if "np_random" in sd:
@@ -264,12 +274,23 @@ class WalkerBatchEnv(object):
             m = torch.as_tensor(mask, device=dev).to(torch.uint8).contiguous()
         # WalkerBaseEnv.reset adds the floor to robot.parts AFTER robot.reset() computed the reset observation and
         # potential (walker_base_env.py:24-31): the first reset after set_task averages over the robot's parts only
-        self._params_c.floor_in_parts = 0 if self._first_reset else 1
-        rc = self._lib.mg_walker_reset(self._topo, self._models_c, self._params_c, N, self._state_c, _lib.ptr(m),
-                                       _lib.ptr(jn), _lib.ptr(self._obs), _lib.current_stream(dev))
-        self._params_c.floor_in_parts = 1
-        self._first_reset = False
-        _lib.check(rc, "mg_walker_reset")
+        # (per env: `_floor_known`. While some env has not been reset yet, the masked reset runs as two masked launches —
+        # first-timers with floor_in_parts = 0, the others with 1 — so nothing here reads a device value on the host.)
+        def launch(mask_t, floor):
+            self._params_c.floor_in_parts = floor
+            rc = self._lib.mg_walker_reset(self._topo, self._models_c, self._params_c, N, self._state_c, _lib.ptr(mask_t),
+                                           _lib.ptr(jn), _lib.ptr(self._obs), _lib.current_stream(dev))
+            self._params_c.floor_in_parts = 1
+            _lib.check(rc, "mg_walker_reset")
+        if self._all_floor_known:
+            launch(m, 1)
+        else:
+            sel = torch.ones(N, dtype=torch.bool, device=dev) if m is None else m.bool()
+            launch((sel & ~self._floor_known).to(torch.uint8).contiguous(), 0)
+            launch((sel & self._floor_known).to(torch.uint8).contiguous(), 1)
+            self._floor_known |= sel
+            if m is None:
+                self._all_floor_known = True
         return self._obs
 
     def step(self, action):

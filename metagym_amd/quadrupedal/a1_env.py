@@ -202,9 +202,13 @@ class A1GymEnv(object):
                 self.step(static_action)
         torch.cuda.current_stream(d).wait_stream(side)
         graph = torch.cuda.CUDAGraph()
+        robot, repeat = self.robot, 13
+        host_mirror = (robot._step_counter, robot._last_action)
         with torch.cuda.graph(graph):
             out = self.step(static_action)
-        robot, repeat = self.robot, 13
+        # capture RECORDS the launches without running them, but Step / StepFused advanced the host-side mirror of the device
+        # clock (get_time_since_reset, the filter's `_step_counter == 0` test): put it back where the device is
+        robot._step_counter, robot._last_action = host_mirror
 
         def replay(action):
             static_action.copy_(action)
@@ -213,6 +217,41 @@ class A1GymEnv(object):
             return out
         replay.graph = graph
         return replay
+
+    # ------------------------------------------------------------------ checkpoint
+    def state_dict(self):
+        """Everything a bit-identical continuation of the env needs, aggregated over its parts: the actuators (observation
+        history ring, counters, last action), the robot-level action filter, the ETG's previous output, the sensor stack, the
+        reward bookkeeping, the RNN frame history, the device-side sub-step clock, the pending auto-reset mask and — when the
+        physics offers `state_dict()` (A1Physics does) — the simulator state."""
+        sd = dict(robot=self.robot.state_dict(), etg_last_act=self.path.last_ETG_act.clone(),
+                  sensors={k: t.clone() for k, t in self.sensors._t.items()}, shaping=self.shaping.state_dict(),
+                  substeps=self._substeps_dev.clone(), pending=self._pending.clone(),
+                  last_torques=None if self.last_torques is None else self.last_torques.clone())
+        if self.robot._action_filter is not None:
+            sd["action_filter"] = dict(xhist=self.robot._action_filter.xhist.clone(), yhist=self.robot._action_filter.yhist.clone())
+        if self._rnn is not None:
+            sd["obs_history"] = self._obs_history.clone()
+        if hasattr(self.physics, "state_dict"):
+            sd["physics"] = self.physics.state_dict()
+        return sd
+
+    def load_state_dict(self, sd):
+        self.robot.load_state_dict(sd["robot"])
+        self.path.last_ETG_act.copy_(sd["etg_last_act"])
+        for k, t in self.sensors._t.items():
+            t.copy_(sd["sensors"][k])
+        self.shaping.load_state_dict(sd["shaping"])
+        self._substeps_dev.copy_(sd["substeps"])
+        self._pending.copy_(sd["pending"])
+        self.last_torques = None if sd.get("last_torques") is None else sd["last_torques"].clone()
+        if self.robot._action_filter is not None and "action_filter" in sd:
+            self.robot._action_filter.xhist.copy_(sd["action_filter"]["xhist"])
+            self.robot._action_filter.yhist.copy_(sd["action_filter"]["yhist"])
+        if self._rnn is not None and "obs_history" in sd:
+            self._obs_history.copy_(sd["obs_history"])
+        if "physics" in sd and hasattr(self.physics, "load_state_dict"):
+            self.physics.load_state_dict(sd["physics"])
 
     def _begin_partial_reset(self, m):
         """The first half of A1GymEnv.reset() for the robots in `m` only (device bool `[N]`), everyone else untouched: robot

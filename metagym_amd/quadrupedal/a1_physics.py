@@ -145,6 +145,12 @@ class A1Physics(object):
         self.env.step_actuated(command, kp, kd, strength, limit, n_substeps=k, log=self._log)
         return self._log
 
+    def state_dict(self):
+        return self.env.state_dict()
+
+    def load_state_dict(self, sd):
+        self.env.load_state_dict(sd)
+
     def world(self):
         """base = GetBasePosition (the root link's inertial frame origin), contact = GetFootContacts (a1.py:299-312: toe links
         against anything that is not the robot), bad = GetBadFootContacts (a1.py:314-323: contact points on any other link)."""

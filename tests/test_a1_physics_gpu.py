@@ -194,3 +194,33 @@ def test_body_damping_and_bullet_box_inertia_on_the_engine_match_the_oracle():
     assert worst < 1e-9, worst
     assert float((env.q - plain.q).abs().max()) > 1e-4            # the option does something
     print("humanoid, body damping 0.04 + bullet_box inertia: max |state diff| GPU vs oracle over 10 steps %.2e" % worst)
+
+
+def test_a1_gym_env_checkpoint_continues_bit_for_bit():
+    """A1GymEnv.state_dict / load_state_dict (actuator history ring and counters, action filter, ETG output, sensor stack,
+    reward bookkeeping, RNN frames, device clock, pending auto-reset mask, engine state): a fresh env loaded from a mid-episode
+    checkpoint reproduces the original's next steps exactly, episodes ending (auto_reset) inside them."""
+    n = 64
+    w = np.tile([[0.03], [0.0], [0.02]], (1, 20)) * np.sin(np.linspace(0, 2 * np.pi, 20))
+    mk = lambda: metagym_amd.make("quadrupedal-v0", num_envs=n, urdf=a1_like_urdf(), device=DEV, ETG=1, ETG_w=w, ETG_b=np.zeros(3),
+                                  filter_=1, control_latency=0.0057, auto_reset=True,
+                                  sensor_mode=dict(dis=1, motor=1, imu=1, contact=1, ETG=1, RNN=dict(time_steps=2, time_interval=1, mode="stack")))
+    a = mk()
+    a.reset()
+    rs = np.random.RandomState(0)
+    acts = [torch.as_tensor(rs.uniform(-0.5, 0.5, (n, 12)), device=DEV) for _ in range(10)]
+    acts[2][::4] = 3.0                                      # every fourth robot is thrown off balance: episodes end
+    for k in range(4):
+        a.step(acts[k])
+    sd = a.state_dict()
+    outs = [a.step(acts[k]) for k in range(4, 10)]
+    outs = [(o.clone(), r.clone(), d.clone()) for o, r, d, _ in outs]
+    b = mk()
+    b.reset()
+    b.load_state_dict(sd)
+    ends = 0
+    for k in range(4, 10):
+        o, r, d, _ = b.step(acts[k])
+        assert torch.equal(o, outs[k - 4][0]) and torch.equal(r, outs[k - 4][1]) and torch.equal(d, outs[k - 4][2]), k
+        ends += int(d.sum())
+    assert ends > 0

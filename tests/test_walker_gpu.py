@@ -411,3 +411,31 @@ def test_terrain_needs_the_wave_mapping():
     env.reset()
     with pytest.raises(Exception, match="wave mapping"):
         env.step(torch.zeros(4, env.n_joints))
+
+
+def test_first_reset_rule_is_per_env_and_survives_a_checkpoint():
+    """WalkerBaseEnv.reset adds the floor link to robot.parts AFTER the first reset's observation (walker_base_env.py:24-31):
+    per env. A masked reset as the first call must leave the other envs' own first reset untouched, and state_dict carries
+    which envs have been through one."""
+    models = [MODELS["humanoid"], MODELS["humanoid_tra_137"]]
+    n = 8
+    rs = np.random.RandomState(2)
+    n1, n2 = rs.uniform(-0.1, 0.1, (n, 17)), rs.uniform(-0.1, 0.1, (n, 17))
+    a, b = _make("MetaHumanoidEnv", models, n), _make("MetaHumanoidEnv", models, n)
+    first = a.reset(joint_noise=n1).clone()
+    pot_first = a.potential.clone()
+    half = torch.arange(n, device="cuda:0") < n // 2
+    b.reset(mask=half, joint_noise=n1)
+    sd = b.state_dict()                                  # checkpoint between the two partial first resets
+    c = _make("MetaHumanoidEnv", models, n)
+    c.load_state_dict(sd)
+    for env in (b, c):
+        ob = env.reset(mask=~half, joint_noise=n1)
+        assert torch.equal(ob, first) and torch.equal(env.potential, pot_first)       # every env saw ITS first reset
+    second = a.reset(joint_noise=n2).clone()
+    assert not torch.equal(second, a.reset(joint_noise=n1))                           # sanity: noise matters
+    a.reset(joint_noise=n2)
+    for env in (b, c):
+        assert torch.equal(env.reset(joint_noise=n2), second) and torch.equal(env.potential, a.potential)
+    fresh = _make("MetaHumanoidEnv", models, n)
+    assert not torch.equal(fresh.reset(joint_noise=n2), second)                       # first vs later reset do differ (the floor link)
