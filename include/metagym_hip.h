@@ -590,13 +590,14 @@ int mg_a1_etg_action(const mg_a1_etg_config *cfg, int32_t n_envs, double *last_e
 
 #define MG_A1_MAX_SEGMENTS 32   /* the reference task terrains report up to 26 stretches (stairslope, slopeslope) */
 
-/* RewardShaping (MonitorEnv.py:275-519), vel_mode "max". */
+/* RewardShaping (MonitorEnv.py:275-519). */
 typedef struct mg_a1_reward_config {
     double w_torso, w_up, w_feet, w_tau, w_badfoot, w_footcontact;   /* Param_Dict MonitorEnv.py:12 */
     double reward_p, vel_d;        /* 1.0, 0.6 */
     double cw_half, cw_04;         /* arctanh(sqrt(0.95)) / 0.5 and / 0.4: c_prec's w (:421-425), host (numpy) values */
     int32_t n_segments;            /* info["env_info"] rows (locomotion_gym_env.py:76): x0, x1, upslope, downslope, angle */
     double seg[MG_A1_MAX_SEGMENTS][5];
+    int32_t vel_mode;              /* 0 "max": min(vel_d, v) (the default); 1 "equal": exp(-5 |v - vel_d|)  (MonitorEnv.py:512-518) */
 } mg_a1_reward_config;
 
 typedef struct mg_a1_reward_state {

@@ -415,7 +415,8 @@ __global__ __launch_bounds__(A1_BLOCK) void a1_reward_step_kernel(RewK k, mg_a1_
     direction(c, d_yaw, b[0], vd0, vd1, vd2);
     st.vd2[e] = vd2;
     double v_ = (v[0] * vd0 + v[1] * vd1) + v[2] * vd2;
-    const double torso = c.w_torso * re_rot(c, yaw, d_yaw, fmin(c.vel_d, v_));
+    const double v_reward = c.vel_mode == 1 ? exp(-5.0 * fabs(v_ - c.vel_d)) : fmin(c.vel_d, v_);   // :512-518
+    const double torso = c.w_torso * re_rot(c, yaw, d_yaw, v_reward);
     const double kk = 1 - c_prec(fmin(v[0], c.vel_d), c.vel_d, c.cw_half);       // :377
     // up :394-409
     int up_f, down_f; double ang;

@@ -48,7 +48,7 @@ class A1GymEnv(object):
                  act_mode="traj", task="plane", normal=0, action_space=0, reward_param=Param_Dict, reward_p=1.0, vel_d=0.6,
                  filter_=0, control_latency=0.002, motor_kp=None, motor_kd=None, env_info=None,
                  motor_control_mode=MotorControlMode.POSITION, sensor_mode=SENSOR_MODE, auto_reset=False, urdf=None,
-                 urdf_options=None):
+                 urdf_options=None, vel_mode="max"):
         if physics is None and urdf is not None:       # the robot file on this repo's own articulated-body engine
             from .a1_physics import A1Physics
             physics = A1Physics(num_envs, urdf=urdf, device=device, **dict(urdf_options or {}))
@@ -75,7 +75,8 @@ class A1GymEnv(object):
         self.path = EtgActionPath(num_envs, device, ETG=ETG, ETG_T=ETG_T, ETG_H=ETG_H, ETG_w=ETG_w, ETG_b=ETG_b, act_mode=act_mode,
                                   task_mode="gallop" if task == "gallop" else "normal", action_space=action_space)
         self.sensors = SensorStack(num_envs, device, normal=normal)
-        self.shaping = RewardShaping(num_envs, device, param=reward_param, reward_p=reward_p, vel_d=vel_d, env_info=self.env_info)
+        self.shaping = RewardShaping(num_envs, device, param=reward_param, reward_p=reward_p, vel_d=vel_d, env_info=self.env_info,
+                                     vel_mode=vel_mode)
         self._lib = _lib.load()
         self.last_torques = None
         self._fusable = motor_control_mode is MotorControlMode.POSITION and motor_kp is None
@@ -87,14 +88,29 @@ class A1GymEnv(object):
         self._pending = torch.zeros(self.num_envs, dtype=torch.bool, device=self.device)
         self._configure_observation(dict(sensor_mode), bool(ETG), int(ETG_H), int(normal))
 
+    # FootPoseSensor's normalisation constants, robot_sensors.py:601-606
+    FOOTPOSE_MEAN = [1.7454079e-01, -1.5465108e-01, -2.0661314e-01, 1.7080666e-01, 1.6490668e-01, -2.0865265e-01,
+                     -1.9902834e-01, -1.2880404e-01, -2.3593837e-01, -2.0215839e-01, 1.3673349e-01, -2.3642859e-01]
+    FOOTPOSE_STD = [3.9058894e-02, 2.4757426e-02, 4.2747084e-02, 4.1128017e-02, 2.7591322e-02, 4.3003809e-02,
+                    4.3018311e-02, 2.8423777e-02, 4.7990609e-02, 4.6113804e-02, 2.8037265e-02, 4.9409315e-02]
+
     def _configure_observation(self, mode, etg, etg_h, normal):
-        """env_builder.py:62-80 picks the sensors from `sensor_mode`, ObservationWrapper (MonitorEnv.py:77-221) appends to
-        their observation. The sensor stack here is the default one; the wrapper's own entries are all there except the two
-        that come out of PyBullet-side randomisation (force_vec, dynamic_vec)."""
-        if not (mode.get("dis") == 1 and mode.get("imu") == 1 and mode.get("motor") == 1 and mode.get("contact") == 1) \
-                or mode.get("footpose") or mode.get("noise"):
-            raise _lib.MetaGymHipError("sensor_mode %r: only the default sensor stack (dis / imu / motor / contact = 1, no footpose, "
-                                       "no noise) is built on the device" % (mode,))
+        """env_builder.py:62-80 picks the sensors from `sensor_mode`: BaseDisplacementSensor (dis), IMUSensor with all six
+        channels (imu 1) or the three rates (imu 2), MotorAngleAccSensor (motor 1) or MotorAngleSensor (motor 2),
+        FootContactSensor (contact 1) or SimpleFootForceSensor (contact 2: needs `world()["foot_force"]` from the physics),
+        FootPoseSensor (footpose); 0 switches a sensor off. ObservationWrapper (MonitorEnv.py:77-221) appends its own
+        entries — all built except the two that come out of PyBullet-side randomisation (force_vec, dynamic_vec). Sensor
+        noise (`noise`: Gaussian draws from numpy's global stream inside every sensor) is not built."""
+        if mode.get("noise"):
+            raise _lib.MetaGymHipError("sensor_mode['noise']: per-sensor Gaussian noise from numpy's global RNG is not built on the device")
+        sel = (int(mode.get("dis", 0)), int(mode.get("imu", 0)), int(mode.get("motor", 0)), int(mode.get("contact", 0)),
+               int(bool(mode.get("footpose", 0))))
+        if sel[1] not in (0, 1, 2) or sel[2] not in (0, 1, 2) or sel[3] not in (0, 1, 2) or sel[0] not in (0, 1):
+            raise ValueError("sensor_mode %r: dis 0/1, imu 0/1/2, motor 0/1/2, contact 0/1/2 (env_builder.py:62-80)" % (mode,))
+        self._sensor_sel = sel
+        self._sensor_width = 3 * sel[0] + (0, 6, 3)[sel[1]] + (0, 24, 12)[sel[2]] + (0, 4, 8)[sel[3]] + 12 * sel[4]
+        f64 = dict(dtype=torch.float64, device=self.device)
+        self._fp_mean, self._fp_std = torch.tensor(self.FOOTPOSE_MEAN, **f64), torch.tensor(self.FOOTPOSE_STD, **f64)
         for key in ("force_vec", "dynamic_vec"):
             if mode.get(key):
                 raise _lib.MetaGymHipError("sensor_mode[%r] reads the reference's PyBullet-side randomisation (RandomWrapper / "
@@ -102,7 +118,7 @@ class A1GymEnv(object):
         self._extras = ((_lib.A1_EXTRA_ETG if etg and mode.get("ETG") else 0) | (_lib.A1_EXTRA_ETG_OBS if etg and mode.get("ETG_obs") else 0)
                         | (_lib.A1_EXTRA_YAW if mode.get("yaw") else 0))
         self._etg_h, self._normal = etg_h, normal
-        width = _lib.A1_SENSOR_OBS_DIM + (12 if self._extras & _lib.A1_EXTRA_ETG else 0) \
+        width = self._sensor_width + (12 if self._extras & _lib.A1_EXTRA_ETG else 0) \
             + (etg_h if self._extras & _lib.A1_EXTRA_ETG_OBS else 0) + (2 if self._extras & _lib.A1_EXTRA_YAW else 0)
         rnn = mode.get("RNN")
         self._rnn = None
@@ -116,7 +132,7 @@ class A1GymEnv(object):
         """ObservationWrapper.reset (MonitorEnv.py:136-179) / step (:181-221) on the sensor observation `[N, 37]`."""
         N, d = self.num_envs, self.device
         if self._extras:
-            extra = torch.empty(N, self.observation_width - _lib.A1_SENSOR_OBS_DIM, dtype=torch.float64, device=d)
+            extra = torch.empty(N, self.observation_width - self._sensor_width, dtype=torch.float64, device=d)
             p = pose.t().contiguous()
             eo = None if etg_obs is None else etg_obs.t().contiguous()
             dy = None if d_yaw is None else torch.as_tensor(d_yaw, dtype=torch.float64, device=d).expand(N).contiguous()
@@ -137,6 +153,36 @@ class A1GymEnv(object):
             if mode == "stack":
                 obs = obs.reshape(N, -1)
         return obs
+
+    def _select_sensors(self, obs37, info, world):
+        """The configured sensors' blocks in sensor-NAME order (locomotion_gym_env.py:621-632): BaseDisplacement,
+        FootContactSensor | FootForceSensor, FootPoseSensor, IMU, MotorAngle | MotorAngleAcc. `obs37` is the default stack's
+        observation (mg_a1_observation: dis 3, contact 4, imu 6, motor 24); the alternatives are values `info` already holds."""
+        dis, imu, motor, contact, footpose = self._sensor_sel
+        if self._sensor_sel == (1, 1, 1, 1, 0):
+            return obs37
+        parts = []
+        if dis:
+            parts.append(obs37[:, 0:3])
+        if contact == 1:
+            parts.append(obs37[:, 3:7])
+        elif contact == 2:          # SimpleFootForceSensor robot_sensors.py:546-548 = GetFootContactsForce('simple') a1.py:325-356
+            if "foot_force" not in world:
+                raise _lib.MetaGymHipError("sensor_mode['contact'] = 2 (SimpleFootForceSensor) needs world()['foot_force'] "
+                                           "([N, 4] normal-force magnitudes in newtons) from the physics")
+            parts.append(torch.cat([world["contact"], world["foot_force"] / 100.0], dim=1))
+        if footpose:                # FootPoseSensor :607-611
+            fp = info["footposition"]
+            parts.append((fp - self._fp_mean) / self._fp_std if self._normal else fp)
+        if imu == 1:
+            parts.append(obs37[:, 7:13])
+        elif imu == 2:              # IMUSensor(channels dR dP dY) is built without `normal` (env_builder.py:67): raw rates
+            parts.append(info["drpy"])
+        if motor == 1:
+            parts.append(obs37[:, 13:37])
+        elif motor == 2:            # MotorAngleSensor :74-84
+            parts.append(info["joint_angle"])
+        return torch.cat(parts, dim=1) if parts else obs37[:, 0:0]
 
     def get_time_since_reset(self):
         return self.robot.GetTimeSinceReset()
@@ -165,6 +211,7 @@ class A1GymEnv(object):
         info.update(base=world["base"], real_contact=world["contact"], bad=world["bad"], real_action=cmd, ETG_obs=etg_obs,
                     ETG_act=self.path.last_ETG_act.t())
         obs = self.sensors.observe(world["base"], info["pose"], info["drpy"], info["joint_angle"], world["contact"], reset_mask)
+        obs = self._select_sensors(obs, info, world)
         return self._wrap_observation(obs, info["pose"], etg_obs, d_yaw, False), info
 
     def reset(self, d_yaw=None):
@@ -179,6 +226,7 @@ class A1GymEnv(object):
         world, info = self.physics.world(), self._info()
         every = torch.ones(N, dtype=torch.bool, device=d)
         obs0 = self.sensors.observe(world["base"], info["pose"], info["drpy"], info["joint_angle"], world["contact"], every)
+        obs0 = self._select_sensors(obs0, info, world)
         etg_obs0 = self.path.reset(self.get_time_since_reset())
         self._wrap_observation(obs0, info["pose"], etg_obs0, d_yaw, True)
         obs, _ = self._env_step(torch.zeros(N, 12, dtype=torch.float64, device=d))
@@ -263,6 +311,7 @@ class A1GymEnv(object):
         world, info = self.physics.world(), self._info()
         two = torch.where(m, torch.ones_like(m, dtype=torch.uint8), torch.full_like(m, 2, dtype=torch.uint8))     # 1 reset, 2 untouched
         obs0 = self.sensors.observe(world["base"], info["pose"], info["drpy"], info["joint_angle"], world["contact"], two)
+        obs0 = self._select_sensors(obs0, info, world)
         etg_obs0 = self.path.reset(self._substeps_dev * self.robot.time_step, mask=m)
         if self._rnn is not None:       # ObservationWrapper.reset for these robots: an empty frame history holding the reset observation
             rnn, self._rnn = self._rnn, None

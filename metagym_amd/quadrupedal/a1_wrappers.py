@@ -90,13 +90,14 @@ class RewardShaping(object):
         self.device = torch.device(device)
         if self.device.type != "cuda":
             raise _lib.MetaGymHipError("metagym_amd has no CPU path: device must be a ROCm GPU, got %r" % (device,))
-        if vel_mode != "max":
-            raise NotImplementedError("vel_mode %r: only the reference default 'max' is built" % (vel_mode,))
+        if vel_mode not in ("max", "equal"):       # MonitorEnv.py:512-518 knows these two
+            raise ValueError("vel_mode %r: the reference has 'max' and 'equal'" % (vel_mode,))
         self._lib = _lib.load()
         self.num_envs = N = int(num_envs)
         c = self._cfg = _lib.A1RewardConfig()
         c.w_torso, c.w_up, c.w_feet, c.w_tau = param['torso'], param['up'], param['feet'], param['tau']
         c.w_badfoot, c.w_footcontact, c.reward_p, c.vel_d = param['badfoot'], param['footcontact'], reward_p, vel_d
+        c.vel_mode = 1 if vel_mode == "equal" else 0
         c.cw_half = float(np.arctanh(np.sqrt(0.95)) / 0.5)          # c_prec's w (:421-425) for m = 0.5 and m = 0.4
         c.cw_04 = float(np.arctanh(np.sqrt(0.95)) / 0.4)
         assert len(env_info) <= _lib.A1_MAX_SEGMENTS

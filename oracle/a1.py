@@ -226,9 +226,11 @@ class EtgActionPath(object):
 
 
 class RewardShaping(object):
-    """One robot's RewardShaping wrapper, MonitorEnv.py:275-519 (vel_mode "max")."""
+    """One robot's RewardShaping wrapper, MonitorEnv.py:275-519 (vel_mode "max" or "equal", :512-518)."""
 
-    def __init__(self, param, reward_p=1.0, vel_d=0.6, segments=((-100, 100, 1, 0, 0.0),)):
+    def __init__(self, param, reward_p=1.0, vel_d=0.6, segments=((-100, 100, 1, 0, 0.0),), vel_mode="max"):
+        assert vel_mode in ("max", "equal")
+        self.vel_mode = vel_mode
         self.p = dict(zip(("torso", "up", "feet", "tau", "badfoot", "footcontact"), param))
         self.reward_p, self.vel_d, self.segments = reward_p, vel_d, [tuple(s) for s in segments]
         self.vd_torso, self.vd_feet = [1, 0, 0], [1, 0, 0]              # the mutable default arguments of :475 and :430
@@ -278,7 +280,8 @@ class RewardShaping(object):
         # torso :475-506
         vd = self.direction(self.vd_torso, d_yaw, base)
         v_ = v[0] * vd[0] + v[1] * vd[1] + v[2] * vd[2]
-        torso = self.p["torso"] * self.re_rot(pose[-1], d_yaw, min(self.vel_d, v_))
+        v_reward = min(self.vel_d, v_) if self.vel_mode == "max" else np.exp(-5 * abs(v_ - self.vel_d))      # :512-518
+        torso = self.p["torso"] * self.re_rot(pose[-1], d_yaw, v_reward)
         k = 1 - self.c_prec(min(v[0], self.vel_d), self.vel_d, 0.5)
         # up :394-409
         up_flag, down_flag, ang = self.env_vec(base[0])
@@ -415,6 +418,39 @@ class A1Env(object):
         rnn = self.mode.get("RNN")
         self.rnn = (rnn["time_steps"], rnn["time_interval"], rnn["mode"]) if rnn and rnn["time_steps"] > 0 else None
 
+    FOOTPOSE_MEAN = np.array([1.7454079e-01, -1.5465108e-01, -2.0661314e-01, 1.7080666e-01, 1.6490668e-01, -2.0865265e-01,   # robot_sensors.py:601-603
+                              -1.9902834e-01, -1.2880404e-01, -2.3593837e-01, -2.0215839e-01, 1.3673349e-01, -2.3642859e-01])
+    FOOTPOSE_STD = np.array([3.9058894e-02, 2.4757426e-02, 4.2747084e-02, 4.1128017e-02, 2.7591322e-02, 4.3003809e-02,       # :604-606
+                             4.3018311e-02, 2.8423777e-02, 4.7990609e-02, 4.6113804e-02, 2.8037265e-02, 4.9409315e-02])
+
+    def select_sensors(self, obs37, inf, world):
+        """The sensor list env_builder.py:62-80 builds from sensor_mode, flattened in sensor-NAME order
+        (locomotion_gym_env.py:621-632): BaseDisplacement, FootContactSensor | FootForceSensor, FootPoseSensor, IMU,
+        MotorAngle | MotorAngleAcc. `obs37` is the default stack (dis, contact, imu 6, motor angle + acceleration)."""
+        m = self.mode
+        dis, imu, motor, contact, footpose = m.get("dis", 1), m.get("imu", 1), m.get("motor", 1), m.get("contact", 1), m.get("footpose", 0)
+        if (dis, imu, motor, contact, bool(footpose)) == (1, 1, 1, 1, False):
+            return obs37
+        parts = []
+        if dis:
+            parts.append(obs37[0:3])
+        if contact == 1:
+            parts.append(obs37[3:7])
+        elif contact == 2:                                   # SimpleFootForceSensor robot_sensors.py:546-548: flags + |normal force| / 100
+            parts.append(np.asarray(world["force"], float))
+        if footpose:                                         # FootPoseSensor :607-611
+            fp = np.asarray(inf["footposition"]).reshape(-1)
+            parts.append((fp - self.FOOTPOSE_MEAN) / self.FOOTPOSE_STD if self.normal else fp)
+        if imu == 1:
+            parts.append(obs37[7:13])
+        elif imu == 2:                                       # IMUSensor(channels dR dP dY), built WITHOUT `normal` (env_builder.py:67)
+            parts.append(np.asarray(inf["drpy"], float))
+        if motor == 1:
+            parts.append(obs37[13:37])
+        elif motor == 2:                                     # MotorAngleSensor :74-84 (no normalisation)
+            parts.append(np.asarray(inf["joint_angle"], float))
+        return np.concatenate(parts) if parts else np.zeros(0)
+
     def wrap_observation(self, obs, yaw, etg_obs, d_yaw, on_reset):
         """ObservationWrapper.reset :136-179 / step :181-221."""
         if self.etg and self.mode.get("ETG"):
@@ -472,6 +508,7 @@ class A1Env(object):
         self.act.receive_observation(t[None, 0:12], t[None, 12:24], t[None, 36:40], t[None, 40:43])
         inf = self.info(reset_world)
         obs0 = self.sensors.observe(reset_world["base"], reset_world["pose"], inf["drpy"], inf["joint_angle"], reset_world["contact"], True)
+        obs0 = self.select_sensors(obs0, inf, reset_world)
         etg_obs0 = self.path.reset(self.time_since_reset())
         self.wrap_observation(obs0, reset_world["pose"][-1], etg_obs0, d_yaw, True)
         cmd, torques, obs, _ = self._step(np.zeros(12), hidden_true_obs, hidden_world, shaped=False)
@@ -483,6 +520,7 @@ class A1Env(object):
         torques = self.robot_step(cmd, true_obs)
         inf = self.info(world)
         obs = self.sensors.observe(world["base"], world["pose"], inf["drpy"], inf["joint_angle"], world["contact"], False)
+        obs = self.select_sensors(obs, inf, world)
         obs = self.wrap_observation(obs, world["pose"][-1], etg_obs, d_yaw, False)
         out = None
         if shaped:

@@ -188,14 +188,17 @@ def main():
                dict(name="reward_tumble", seed=15, mode="tumble", env_info=flat, d_yaw=0.0, n=25),
                dict(name="reward_feet_up", seed=16, mode="feet_up", env_info=flat, d_yaw=0.0, n=25,
                     param={'torso': 0.7, 'up': 0.5, 'feet': 0.3, 'tau': 0.02, 'done': 1, 'velx': 0, 'badfoot': 0.2, 'footcontact': 0.15},
-                    reward_p=5.0, vel_d=0.4)]
+                    reward_p=5.0, vel_d=0.4),
+               # vel_mode "equal" (MonitorEnv.py:515-518): exp(-5 |v - vel_d|) instead of min(vel_d, v)
+               dict(name="reward_walk_equal", seed=17, mode="walk", env_info=flat, d_yaw=0.0, n=50, vel_mode="equal"),
+               dict(name="reward_slopes_equal", seed=18, mode="walk", env_info=slopes, d_yaw=0.3, n=60, vel_mode="equal", vel_d=0.45)]
     for c in c_cases:
         rs = np.random.RandomState(c["seed"])
         infos = scripted_infos(rs, c["n"], c["env_info"], c["mode"])
         robot = Robot(a1)
         inner = InnerEnv(robot, infos)
         env = MonitorEnv.RewardShaping(env=inner, param=c.get("param", MonitorEnv.Param_Dict), reward_p=c.get("reward_p", 1.0),
-                                       vel_d=c.get("vel_d", 0.6), vel_mode="max")
+                                       vel_d=c.get("vel_d", 0.6), vel_mode=c.get("vel_mode", "max"))
         kw = dict(d_yaw=c["d_yaw"]) if c["d_yaw"] else {}
         env.reset(**kw)
         rec = collections.defaultdict(list)
@@ -223,6 +226,7 @@ def main():
         p = c.get("param", MonitorEnv.Param_Dict)
         out[c["name"] + "/param"] = np.array([p[t] for t in ("torso", "up", "feet", "tau", "badfoot", "footcontact")], dtype=np.float64)
         out[c["name"] + "/config"] = np.array([c.get("reward_p", 1.0), c.get("vel_d", 0.6), c["d_yaw"]], dtype=np.float64)
+        out[c["name"] + "/vel_mode"] = np.array(c.get("vel_mode", "max"))
         out[c["name"] + "/segments"] = np.array([[s[0], s[1], s[2][0], s[2][1], s[2][4]] for s in c["env_info"]], dtype=np.float64)
     out["c_cases"] = np.array([c["name"] for c in c_cases])
     np.savez_compressed(OUT, **out)

@@ -105,7 +105,13 @@ def main():
              dict(name="env_obs_extras_stack", seed=7, ETG=1, wscale=0.04, n_steps=16, normal=1, d_yaw=0.3,
                   sensor_mode={"ETG": 1, "ETG_obs": 1, "yaw": 1, "RNN": {"time_steps": 2, "time_interval": 3, "mode": "stack"}}),
              dict(name="env_obs_extras_gru", seed=8, ETG=1, wscale=0.04, n_steps=10, normal=0, d_yaw=-0.2,
-                  sensor_mode={"ETG": 1, "yaw": 1, "RNN": {"time_steps": 3, "time_interval": 1, "mode": "GRU"}})]
+                  sensor_mode={"ETG": 1, "yaw": 1, "RNN": {"time_steps": 3, "time_interval": 1, "mode": "GRU"}}),
+             # the other sensors env_builder.py:62-80 can pick: MotorAngleSensor (motor 2), the rate-only IMU (imu 2), SimpleFootForceSensor
+             # (contact 2), FootPoseSensor (normalised), and sensors switched off
+             dict(name="env_sensors_alt", seed=9, ETG=1, wscale=0.04, n_steps=14, normal=1,
+                  sensor_mode={"dis": 0, "motor": 2, "imu": 2, "contact": 2, "footpose": 1}),
+             dict(name="env_sensors_min", seed=10, ETG=0, wscale=0.0, n_steps=12, normal=0,
+                  sensor_mode={"dis": 1, "motor": 0, "imu": 0, "contact": 0, "footpose": 1, "ETG_obs": 1})]
     from metagym.quadrupedal.envs.utilities import terrain
     from gen_golden_a1_terrain import Recorder
     for c in cases:

@@ -47,13 +47,13 @@ def test_etg_action_path_matches_reference(g, idx):
             assert np.allclose(p.last_ETG_act.t().cpu().numpy()[0], g[name + "/etg_act"][k], **TOL), "%s ETG_act, step %d" % (name, k)
 
 
-@pytest.mark.parametrize("idx", range(6))
+@pytest.mark.parametrize("idx", range(8))
 def test_reward_shaping_matches_reference(g, idx):
     name, n = str(g["c_cases"][idx]), 3
     reward_p, vel_d, d_yaw = g[name + "/config"]
     seg = [[s[0], s[1], np.array([s[2], s[3], 0, 0, s[4], 0, 0])] for s in g[name + "/segments"]]
     pm = dict(zip(("torso", "up", "feet", "tau", "badfoot", "footcontact"), g[name + "/param"]))
-    r = RewardShaping(n, DEV, param=pm, reward_p=reward_p, vel_d=vel_d, env_info=seg)
+    r = RewardShaping(n, DEV, param=pm, reward_p=reward_p, vel_d=vel_d, env_info=seg, vel_mode=str(g[name + "/vel_mode"]))
     # RewardShaping.reset keeps the RESET info's base and world-frame feet: hand the recorded world feet over as
     # base-frame feet under an identity attitude and zero base, then put the base back
     eye = np.eye(3).reshape(-1)

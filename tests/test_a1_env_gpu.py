@@ -48,10 +48,12 @@ class ReplayPhysics(object):
     def world(self):
         g, name, k = self.g, self.name, self.world_idx
         return dict(base=self._t(g[name + "/loco_base"][k]), contact=self._t(g[name + "/loco_real_contact"][k]),
-                    bad=torch.full((self.n,), int(g[name + "/loco_bad"][k]), dtype=torch.int32, device=DEV))
+                    bad=torch.full((self.n,), int(g[name + "/loco_bad"][k]), dtype=torch.int32, device=DEV),
+                    # |normal force| per foot in newtons: GetFootContactsForce('simple') reports it / 100 (a1.py:352-353)
+                    foot_force=self._t(g[name + "/loco_contact_force"][k][4:8] * 100.0))
 
 
-@pytest.mark.parametrize("idx", range(8))
+@pytest.mark.parametrize("idx", range(10))
 def test_a1_gym_env_matches_the_unmodified_reference_env(idx):
     g = np.load(GOLDEN)
     name, n = str(g["cases"][idx]), 3
@@ -88,8 +90,10 @@ def test_a1_gym_env_matches_the_unmodified_reference_env(idx):
 
 
 def test_unsupported_sensor_modes_are_refused_loudly():
-    for mode in ({"dis": 1, "motor": 2, "imu": 1, "contact": 1, "footpose": 0}, {"dis": 1, "motor": 1, "imu": 1, "contact": 1, "footpose": 1},
-                 {"dis": 1, "motor": 1, "imu": 1, "contact": 1, "footpose": 0, "force_vec": 1}):
+    """What is still refused by name: the PyBullet-side randomisation vectors, sensor noise, values outside env_builder.py:62-80."""
+    for mode in ({"dis": 1, "motor": 1, "imu": 1, "contact": 1, "footpose": 0, "force_vec": 1},
+                 {"dis": 1, "motor": 1, "imu": 1, "contact": 1, "footpose": 0, "noise": 1},
+                 {"dis": 1, "motor": 3, "imu": 1, "contact": 1, "footpose": 0}):
         with pytest.raises(Exception, match="sensor_mode"):
             metagym_amd.make("quadrupedal-v0", num_envs=2, device=DEV, physics=object(), sensor_mode=mode)
 

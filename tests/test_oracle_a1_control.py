@@ -40,11 +40,11 @@ def test_action_path_matches_reference(g, idx):
 
 def reward_case(g, name):
     reward_p, vel_d, d_yaw = g[name + "/config"]
-    r = oa.RewardShaping(g[name + "/param"], reward_p, vel_d, g[name + "/segments"])
+    r = oa.RewardShaping(g[name + "/param"], reward_p, vel_d, g[name + "/segments"], vel_mode=str(g[name + "/vel_mode"]))
     return r, d_yaw
 
 
-@pytest.mark.parametrize("idx", range(6))
+@pytest.mark.parametrize("idx", range(8))
 def test_reward_shaping_matches_reference(g, idx):
     name = str(g["c_cases"][idx])
     r, d_yaw = reward_case(g, name)

@@ -15,7 +15,7 @@ GOLDEN = os.path.join(os.path.dirname(__file__), "golden", "a1_env.npz")
 
 def world(g, name, k):
     return dict(base=g[name + "/loco_base"][k], pose=g[name + "/loco_pose"][k], rot_mat=g[name + "/loco_rot_mat"][k],
-                contact=g[name + "/loco_real_contact"][k], bad=g[name + "/loco_bad"][k])
+                contact=g[name + "/loco_real_contact"][k], bad=g[name + "/loco_bad"][k], force=g[name + "/loco_contact_force"][k])
 
 
 def make_env(g, name):
@@ -37,7 +37,7 @@ def make_env(g, name):
     return env, spec.get("d_yaw", 0)
 
 
-@pytest.mark.parametrize("idx", range(8))
+@pytest.mark.parametrize("idx", range(10))
 def test_composed_env_matches_reference(idx):
     g = np.load(GOLDEN)
     name = str(g["cases"][idx])
