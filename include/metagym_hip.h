@@ -458,6 +458,9 @@ typedef struct mg_walker_state {
     float *feet_contact;  /* [nf][N] */
     int32_t *steps;       /* [N] */
     int32_t *bad_contacts; /* [N] or NULL: ground / terrain contact points of the last sub-step on proxies that are no foot */
+    double *foot_force;    /* [nf][N] or NULL (shape-generic wave kernels): |sum of normal impulse x contact normal| / time_step over
+                              each foot's ground / terrain contact points in the last sub-step, newtons — what a1.py:325-356
+                              GetFootContactsForce adds up from PyBullet's contact points (SimpleFootForceSensor) */
 } mg_walker_state;
 
 /* WalkerBaseEnv.reset: base to its model pose, joints to joint_noise (f64 [nj][N], the caller draws

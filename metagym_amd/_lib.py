@@ -130,7 +130,7 @@ class WalkerState(C.Structure):
     """mg_walker_state (device pointers)"""
     _fields_ = [("task_id", C.c_void_p), ("pos", C.c_void_p), ("rot", C.c_void_p), ("vel", C.c_void_p),
                 ("omega", C.c_void_p), ("q", C.c_void_p), ("qd", C.c_void_p), ("potential", C.c_void_p),
-                ("feet_contact", C.c_void_p), ("steps", C.c_void_p), ("bad_contacts", C.c_void_p)]
+                ("feet_contact", C.c_void_p), ("steps", C.c_void_p), ("bad_contacts", C.c_void_p), ("foot_force", C.c_void_p)]
 
 
 A1_NUM_MOTORS, A1_OBS_DIM = 12, 43

@@ -879,7 +879,8 @@ __device__ __forceinline__ void wave_kinematics(const ModelW &m, const WaveLds &
 template <int NMAX, bool GENERIC>
 __device__ __forceinline__ void wave_substep(const mg_walker_topology &tp, const ModelW &m, const mg_walker_params &prm,
                                              const WaveLds &L, int lane, int max_depth, int maxr,
-                                             unsigned long long (&touch)[2], double pd_cmd, double *log_row, int n_envs) {
+                                             unsigned long long (&touch)[2], double pd_cmd, double *log_row, int n_envs,
+                                             double *foot_force, int nf) {
     const int nb = m.nb, nj = m.nj, ns = m.ns, n = 6 + nj;
     const double dt = prm.time_step;
     // A fresh copy of the lane id per sub-step: the ~140 lane predicates of the unrolled Cholesky / substitution
@@ -1172,7 +1173,7 @@ __device__ __forceinline__ void wave_substep(const mg_walker_topology &tp, const
                 if (own_mu) bmu *= prm.sphere_friction[g];
                 double *cc = L.cx + 6 * slot;
                 cc[0] = bx.x; cc[1] = bx.y; cc[2] = bx.z; cc[3] = bn.x; cc[4] = bn.y; cc[5] = bn.z;
-                L.csphere[2 * slot] = L.sbody[g]; L.csphere[2 * slot + 1] = -2;       // one body against the world
+                L.csphere[2 * slot] = g; L.csphere[2 * slot + 1] = -2;                // proxy g against the world
                 L.bias[3 * slot] = prm.erp * bdepth / dt; L.kind[3 * slot] = 0; L.partner[3 * slot] = -1;
                 L.bias[3 * slot + 1] = bmu; L.kind[3 * slot + 1] = -1; L.partner[3 * slot + 1] = 3 * slot;
                 L.bias[3 * slot + 2] = bmu; L.kind[3 * slot + 2] = -1; L.partner[3 * slot + 2] = 3 * slot;
@@ -1246,7 +1247,8 @@ __device__ __forceinline__ void wave_substep(const mg_walker_topology &tp, const
             L.J[(size_t)(3 * c + 2) * n + d] = jc.y;
         } else {                                 // self contact: relative velocity of the two bodies at xc; terrain (-2): one body
             const V3 xc{cc[0], cc[1], cc[2]}, nrm{cc[3], cc[4], cc[5]};
-            V3 jd = wjac_lin(L, (unsigned)L.mask[L.csphere[2 * c]], xc, d);
+            const int b0 = (GENERIC && other == -2) ? L.sbody[L.csphere[2 * c]] : L.csphere[2 * c];
+            V3 jd = wjac_lin(L, (unsigned)L.mask[b0], xc, d);
             if (!GENERIC || other >= 0) jd = jd - wjac_lin(L, (unsigned)L.mask[other], xc, d);
             V3 t1, t2;
             tangent_basis(nrm, t1, t2);
@@ -1320,6 +1322,19 @@ __device__ __forceinline__ void wave_substep(const mg_walker_topology &tp, const
         }
     }
     PHASE(8);
+    if (GENERIC && foot_force != nullptr) {     // normal force per foot (mg_walker_state.foot_force): lane = foot
+        WSYNC();                                // lane 0 wrote the multipliers
+        if (lane < nf) {
+            V3 f{0, 0, 0};
+            for (int c = 0; c < ncont; ++c) {
+                const int other = L.csphere[2 * c + 1];
+                if (other >= 0 || L.sfoot[L.csphere[2 * c]] != lane) continue;      // self contact / another link's proxy
+                const double lam_n = L.lam[3 * c];
+                f = f + lam_n * (other == -1 ? V3{0, 0, 1} : V3{L.cx[6 * c + 3], L.cx[6 * c + 4], L.cx[6 * c + 5]});
+            }
+            foot_force[(size_t)lane * n_envs] = sqrt(dot(f, f)) / dt;
+        }
+    }
     // ---- back to generalized velocities: u = L^-T y (column of L in registers, reciprocal diagonal from the
     //      owning lane: no LDS inside the dependent chain) ------------------------------------------------------
     {
@@ -1467,7 +1482,8 @@ __global__ __launch_bounds__(WV) __attribute__((amdgpu_waves_per_eu(2))) void wa
     const double pd_cmd = (prm.actuation != 0 && lane < nj) ? prm.pd_command[(size_t)lane * n_envs + e] : 0.0;
     for (int it = 0; it < prm.frame_skip; ++it) {
         double *log_row = prm.substep_log ? prm.substep_log + ((size_t)it * (3 * nj + 7)) * n_envs + e : nullptr;
-        wave_substep<NMAX, GENERIC>(tp, m, prm, L, lane, max_depth, maxr, touch, pd_cmd, log_row, n_envs);
+        wave_substep<NMAX, GENERIC>(tp, m, prm, L, lane, max_depth, maxr, touch, pd_cmd, log_row, n_envs,
+                                    (st.foot_force != nullptr && it == prm.frame_skip - 1) ? st.foot_force + e : nullptr, nf);
     }
     if (st.bad_contacts != nullptr) {       // a1.py:314-323 GetBadFootContacts: contact points on links that are no foot
         int bad = 0;
@@ -1666,7 +1682,8 @@ extern "C" int mg_walker_step(const mg_walker_topology *tp, const mg_walker_mode
     MG_REQUIRE_PTR(done);
     mg::DeviceGuard guard(mg::device_of(st->pos));
     if (prm->mapping == 0) {   // lane-per-env reference mapping (private-memory work set)
-        if (tp->n_spheres > 64 || prm->sphere_friction != nullptr || prm->body_linear_damping != 0.0 || prm->body_angular_damping != 0.0)
+        if (tp->n_spheres > 64 || prm->sphere_friction != nullptr || prm->body_linear_damping != 0.0 || prm->body_angular_damping != 0.0 ||
+            st->foot_force != nullptr)
             return mg::set_error(MG_ERR_UNSUPPORTED, "per-proxy friction, body damping and > 64 collision proxies need the wave mapping");
         hipLaunchKernelGGL(walker_step_kernel, dim3((n + WK_BLOCK - 1) / WK_BLOCK), dim3(WK_BLOCK), 0,
                            (hipStream_t)stream, *tp, *ms, *prm, *st, n, action, obs, reward, rewards5, done);
@@ -1680,7 +1697,7 @@ extern "C" int mg_walker_step(const mg_walker_topology *tp, const mg_walker_mode
     // (terrain boxes, per-proxy friction, body damping and > 64 proxies are compiled into the shape-generic instantiations
     // only: the two tuned kernels keep their registers)
     const bool generic_only = prm->n_terrain_boxes != 0 || prm->sphere_friction != nullptr || prm->body_linear_damping != 0.0 ||
-                              prm->body_angular_damping != 0.0;
+                              prm->body_angular_damping != 0.0 || st->foot_force != nullptr;
     auto shape_is = [&](int b, int j, int s, int g) {
         return !generic_only && tp->n_bodies == b && tp->n_joints == j && tp->n_spheres == s && tp->n_geoms == g;
     };

@@ -57,7 +57,7 @@ class WalkerBatchEnv(object):
     def __init__(self, num_envs=1, device="cuda", frame_skip=4, time_step=0.005, enable_render=False,
                  max_steps=2000, assets_dir=None, solver_iterations=5, mapping="wave", self_collision=True,
                  auto_reset=False, seed=0, env_id_base=0, gravity=GRAVITY, ground_friction=GROUND_FRICTION,
-                 body_damping=(0.0, 0.0), per_proxy_friction=False, contact_erp=CONTACT_ERP):
+                 body_damping=(0.0, 0.0), per_proxy_friction=False, contact_erp=CONTACT_ERP, foot_force=False):
         self._lib = _lib.load()
         self.num_envs = int(num_envs)
         self.device = torch.device(device)
@@ -79,6 +79,9 @@ class WalkerBatchEnv(object):
         #   contact_erp                 0.9 for MetaLocomotion (scene_bases.py:55 setDefaultContactERP); a world that never calls it
         #                               keeps Bullet's default 0.2 (btContactSolverInfo::m_erp2) — the quadrupedal one
         self.contact_erp = float(contact_erp)
+        #   foot_force                  also report each foot's normal-force magnitude (mg_walker_state.foot_force; quadrupedal
+        #                               SimpleFootForceSensor, a1.py:325-356)
+        self.want_foot_force = bool(foot_force)
         assert mapping in ("wave", "lane")
         self.mapping = mapping    # 'wave': one wavefront per env, LDS-resident (default); 'lane': one lane per env
         self.assets_dir = assets_dir or os.environ.get("METAGYM_LOCOMOTION_ASSETS")
@@ -182,6 +185,8 @@ class WalkerBatchEnv(object):
         st = _lib.WalkerState()
         for k in ("task_id", "pos", "rot", "vel", "omega", "q", "qd", "potential", "feet_contact", "steps", "bad_contacts"):
             setattr(st, k, getattr(self, k).data_ptr())
+        self.foot_force = torch.zeros(nf, N, dtype=torch.float64, device=dev) if self.want_foot_force else None
+        st.foot_force = self.foot_force.data_ptr() if self.want_foot_force else None
         self._state_c = st
         p = _lib.WalkerParams()
         p.time_step, p.frame_skip, p.solver_iterations = self.time_step, self.frame_skip, self.solver_iterations

@@ -85,7 +85,7 @@ class A1Physics(object):
         self.env = _A1Walker(num_envs=num_envs, device=device, frame_skip=1, time_step=0.002, max_steps=2 ** 30,
                              solver_iterations=solver_iterations, self_collision=False, gravity=gravity,
                              ground_friction=ground_friction, body_damping=body_damping, per_proxy_friction=True,
-                             contact_erp=contact_erp)
+                             contact_erp=contact_erp, foot_force=True)
         self.env.set_task([m])
         f64 = dict(dtype=torch.float64, device=self.device)
         self._init = torch.as_tensor(np.tile(np.asarray(init_motor_angles, np.float64), (self.n, 1)), **f64)
@@ -121,6 +121,7 @@ class A1Physics(object):
         target = self._default_pose - self._base_offset                        # the root body origin (R = identity at reset)
         e.pos.copy_(torch.where(m.reshape(1, -1), target.expand(3, self.n), e.pos))
         e.bad_contacts.mul_((~m).to(torch.int32))                               # no contact points yet (feet flags: the reset kernel)
+        e.foot_force.mul_((~m).to(torch.float64).reshape(1, -1))
         quat, rate = self._base_quat_rate()
         return e.q.t().contiguous(), e.qd.t().contiguous(), quat, rate
 
@@ -153,8 +154,10 @@ class A1Physics(object):
 
     def world(self):
         """base = GetBasePosition (the root link's inertial frame origin), contact = GetFootContacts (a1.py:299-312: toe links
-        against anything that is not the robot), bad = GetBadFootContacts (a1.py:314-323: contact points on any other link)."""
+        against anything that is not the robot), bad = GetBadFootContacts (a1.py:314-323: contact points on any other link),
+        foot_force = the normal-force magnitudes GetFootContactsForce (a1.py:325-356) sums per toe."""
         e = self.env
         R = e.rot.t().reshape(self.n, 3, 3)
         base = e.pos.t() + torch.einsum("nij,j->ni", R, self._base_offset.reshape(3))
-        return dict(base=base.contiguous(), contact=e.feet_contact.t().to(torch.float64).contiguous(), bad=e.bad_contacts)
+        return dict(base=base.contiguous(), contact=e.feet_contact.t().to(torch.float64).contiguous(), bad=e.bad_contacts,
+                    foot_force=e.foot_force.t().contiguous())       # newtons (GetFootContactsForce reports it / 100)

@@ -251,7 +251,7 @@ def constraint_rows(m, s, kin, prm):
             xc = np.array([x[0], x[1], 0.0])           # contact point on the ground plane
             Jc = point_jacobian(m, kin, b, xc)
             k = len(rows)
-            rows.append((Jc[2], prm.erp * depth / prm.dt, 0, -1, g))
+            rows.append((Jc[2], prm.erp * depth / prm.dt, 0, -1, g, np.array([0.0, 0.0, 1.0])))     # (.., proxy, contact normal)
             if prm.sphere_friction is None:
                 rows.append((Jc[0], 0.0, 1, k, g))
                 rows.append((Jc[1], 0.0, 2, k, g))
@@ -278,7 +278,7 @@ def constraint_rows(m, s, kin, prm):
                 Jc = point_jacobian(m, kin, b, xc)
                 t1, t2 = tangent_basis(nrm)
                 k = len(rows)
-                rows.append((nrm @ Jc, prm.erp * depth / prm.dt, 0, -1, g))
+                rows.append((nrm @ Jc, prm.erp * depth / prm.dt, 0, -1, g, nrm))
                 rows.append((t1 @ Jc, 0.0, -1, k, g, mu))
                 rows.append((t2 @ Jc, 0.0, -1, k, g, mu))
     # self-collision between the capsule geoms of bodies that are neither ancestor-related nor welded
@@ -337,8 +337,20 @@ def pgs(A, rhs, rows, friction, iterations):
     return lam
 
 
-def substep(m, s, tau_motor, prm):
-    """One 5 ms sub-step. Returns the set of sphere indices in contact."""
+def foot_forces(m, rows, lam, dt):
+    """|sum over a foot's contact points of normal impulse x normal| / dt, per foot (newtons): what a1.py:325-356
+    GetFootContactsForce adds up from PyBullet's contact points (contact[9] normalForce x contact[7] normal)."""
+    sph_foot = np.asarray(m.sph_foot)
+    f = np.zeros((len(m.foot_body), 3))
+    for r, row in enumerate(rows):
+        if row[2] == 0 and row[4] >= 0 and sph_foot[row[4]] >= 0:
+            f[sph_foot[row[4]]] += lam[r] * row[5]
+    return np.linalg.norm(f, axis=1) / dt
+
+
+def substep(m, s, tau_motor, prm, out=None):
+    """One 5 ms sub-step. Returns the set of sphere indices in contact. `out` (a dict) receives the constraint rows and their
+    multipliers."""
     M, h, kin, _ = mass_matrix_and_bias(m, s, gravity=prm.gravity, body_damping=prm.body_damping)
     n = M.shape[0]
     tau = np.zeros(n)
@@ -357,6 +369,12 @@ def substep(m, s, tau_motor, prm):
         lam = pgs(A, rhs, rows, (prm.friction, prm.self_friction), prm.iterations)
         u_star = u_star + MinvJT @ lam
         touching = {r[4] for r in rows if r[2] == 0 and r[4] >= 0}
+        if out is not None:
+            out["lam"] = lam
+    if out is not None:
+        out["rows"] = rows
+        if not rows:
+            out["lam"] = np.zeros(0)
     s.v, s.w, s.qd = u_star[0:3].copy(), u_star[3:6].copy(), u_star[6:].copy()
     integrate_positions(s, prm.dt)
     return touching

@@ -97,20 +97,20 @@ def test_urdf_robot_on_a_terrain_course_matches_the_oracle():
     target = np.array([0, 0.9, -1.8] * 4, float)
     log = torch.empty(1, 43, n, dtype=torch.float64, device=DEV)
     keys = ("pos", "rot", "vel", "omega", "q", "qd")
-    worst, bad_seen, feet_seen, terrain_seen = 0.0, 0, 0, 0
+    worst, bad_seen, feet_seen, terrain_seen, force_seen = 0.0, 0, 0, 0, 0.0
     for t in range(150):
         st = {k: getattr(e, k).cpu().numpy() for k in keys}
         tau = np.clip(80.0 * (target[:, None] - st["q"]) - 1.5 * st["qd"] + rs.uniform(-2, 2, (12, n)), -33.5, 33.5)
         e.step_actuated(torch.as_tensor(tau, device=DEV), raw_torque=True, n_substeps=1, log=log)
         g = {k: getattr(e, k).cpu().numpy() for k in keys}
-        feet, bad = e.feet_contact.cpu().numpy(), e.bad_contacts.cpu().numpy()
+        feet, bad, force = e.feet_contact.cpu().numpy(), e.bad_contacts.cpu().numpy(), e.foot_force.cpu().numpy()
         for k in range(n):
             s = abd.State(m)
             s.pos, s.rot, s.v, s.w = st["pos"][:, k].copy(), st["rot"][:, k].reshape(3, 3).copy(), st["vel"][:, k].copy(), st["omega"][:, k].copy()
             s.q, s.qd = st["q"][:, k].copy(), st["qd"][:, k].copy()
-            rows = abd.constraint_rows(m, s, abd.kinematics(m, s), prm)
-            terrain_seen += sum(1 for r in rows if r[2] == 0 and len(r) == 5 and r[4] >= 0 and any(len(q_) == 6 for q_ in rows))
-            touching = abd.substep(m, s, tau[:, k], prm)
+            out = {}
+            touching = abd.substep(m, s, tau[:, k], prm, out=out)
+            terrain_seen += sum(1 for r in out["rows"] if r[2] == 0 and r[4] >= 0 and r[5][2] != 1.0)     # a tilted contact normal: a box
             d = max(np.abs(g["q"][:, k] - s.q).max(), np.abs(g["qd"][:, k] - s.qd).max(), np.abs(g["pos"][:, k] - s.pos).max(),
                     np.abs(g["vel"][:, k] - s.v).max(), np.abs(g["omega"][:, k] - s.w).max(), np.abs(g["rot"][:, k] - s.rot.reshape(9)).max())
             worst = max(worst, d)
@@ -118,9 +118,13 @@ def test_urdf_robot_on_a_terrain_course_matches_the_oracle():
             o_feet = [float(any(m.sph_foot[g_] == f for g_ in touching)) for f in range(4)]
             o_bad = sum(1 for g_ in touching if m.sph_foot[g_] < 0)
             assert list(feet[:, k]) == o_feet and int(bad[k]) == o_bad, (t, k)
+            o_force = abd.foot_forces(m, out["rows"], out["lam"], prm.dt)
+            assert np.allclose(force[:, k], o_force, rtol=1e-7, atol=1e-7), (t, k, force[:, k], o_force)      # newtons
+            force_seen = max(force_seen, o_force.max())
             bad_seen += o_bad
             feet_seen += int(sum(o_feet))
-    assert bad_seen > 50 and feet_seen > 500 and terrain_seen > 100           # toe, non-toe and terrain-box contacts all happened
+    assert bad_seen > 50 and feet_seen > 500 and terrain_seen > 20            # toe, non-toe and tilted terrain-box contacts all happened
+    assert force_seen > 20.0                                                  # (a 12.6 kg robot landing on its toes)
     print("a1-like URDF on slopestair: max one-sub-step |state diff| GPU vs oracle %.2e over 150 sub-steps x 8 robots; %d toe / %d bad "
           "contact points" % (worst, feet_seen, bad_seen))
 
@@ -141,6 +145,17 @@ def test_quadrupedal_v0_runs_closed_loop_from_a_urdf():
     assert 0.2 < float(z.min()) and float(z.max()) < 0.3
     assert float(info["real_contact"].sum(dim=1).min()) >= 3.0 and int(info["bad"].max()) == 0
     assert float((env.robot.GetMotorAngles() - torch.as_tensor([0, 0.9, -1.8] * 4, device=DEV)).abs().max()) < 0.15
+    # standing still the four toes carry the weight: sum of the normal forces = m g (12.621 kg x 10)
+    total = env.physics.world()["foot_force"].sum(dim=1)
+    assert float((total - 126.21).abs().max()) < 0.15 * 126.21
+    # ... and the SimpleFootForceSensor stack (contact = 2) reports flags + force / 100 in its 8 entries
+    env2 = metagym_amd.make("quadrupedal-v0", num_envs=n, urdf=a1_like_urdf(), device=DEV,
+                            sensor_mode=dict(dis=1, motor=1, imu=1, contact=2, footpose=0))
+    obs2, _ = env2.reset()
+    for _ in range(25):
+        obs2, _, _, info2 = env2.step(a)
+    assert obs2.shape == (n, 41) and torch.equal(obs2[:, 3:7], info2["real_contact"])
+    assert float((obs2[:, 7:11].sum(dim=1) * 100.0 - 126.21).abs().max()) < 0.15 * 126.21
     env = metagym_amd.make("quadrupedal-v0", num_envs=n, urdf=a1_like_urdf(), device=DEV, task="slopestair")
     obs, info = env.reset()
     for _ in range(15):
