@@ -430,8 +430,9 @@ def test_first_reset_rule_is_per_env_and_survives_a_checkpoint():
     c = _make("MetaHumanoidEnv", models, n)
     c.load_state_dict(sd)
     for env in (b, c):
-        ob = env.reset(mask=~half, joint_noise=n1)
-        assert torch.equal(ob, first) and torch.equal(env.potential, pot_first)       # every env saw ITS first reset
+        ob = env.reset(mask=~half, joint_noise=n1)      # (a masked reset writes the rows it resets: `c` never saw the first half's)
+        assert torch.equal(ob[~half], first[~half]) and torch.equal(env.potential, pot_first)       # every env saw ITS first reset
+    assert torch.equal(b._obs, first)
     second = a.reset(joint_noise=n2).clone()
     assert not torch.equal(second, a.reset(joint_noise=n1))                           # sanity: noise matters
     a.reset(joint_noise=n2)
