@@ -417,8 +417,13 @@ typedef struct mg_walker_params {
      *   1  position control: torque_j = LaikagoMotorModel.convert_to_torque (quadrupedal/robots/laikago_motor.py:136-168,
      *      the same expression as mg_a1_apply_action) of the CURRENT joint state (pd latency 0, the A1 default) and the
      *      desired angles in pd_command — what Minitaur.Step does 13 times per env step around stepSimulation;
-     *   2  raw torques from pd_command (the caller ran the motor model itself).
-     * pd_command: DEVICE f64 [nj][N]. substep_log: DEVICE f64 [frame_skip][3 nj + 7][N] or NULL — after every sub-step the
+     *   2  raw torques from pd_command (the caller ran the motor model itself);
+     *   3  (shape-generic kernels) HYBRID commands, laikago_motor.py:143-153: pd_command is [5 nj][N], row 5 j + k of motor j =
+     *      desired angle, kp, desired rate, kd, additional torque; strength and torque limit as in mode 1;
+     *   4  TORQUE mode, laikago_motor.py:125-128: torque_j = strength_j * pd_command_j, no limit.
+     * pd_kp_env / pd_kd_env (shape-generic kernels; DEVICE f64 [nj][N] or NULL): per-robot gains for mode 1, what
+     * locomotion_gym_env.py:388-392 draws when the dynamics are randomised.
+     * pd_command: DEVICE f64 [nj][N] ([5 nj][N] in mode 3). substep_log: DEVICE f64 [frame_skip][3 nj + 7][N] or NULL — after every sub-step the
      * joint angles, rates, applied torques, the base quaternion (x y z w) and the body-frame angular velocity, i.e. one
      * Minitaur.GetTrueObservation (minitaur.py:1175-1182) per sub-step, ready for mg_a1_receive_log. */
     int32_t actuation;
@@ -444,6 +449,7 @@ typedef struct mg_walker_params {
      * Shape-generic wave kernels only. The quadrupedal reference switches it off (minitaur.py:346-353 at :419); MetaLocomotion
      * never touches it, so PyBullet's default applies there — an option of metalocomotion.mjcf / WalkerBatchEnv. */
     double body_linear_damping, body_angular_damping;
+    const double *pd_kp_env, *pd_kd_env;
 } mg_walker_params;
 
 /* Per-env state, SoA doubles: component c of env e at base[c*N + e]. */

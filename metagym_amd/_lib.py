@@ -123,7 +123,8 @@ class WalkerParams(C.Structure):
                 ("pd_kp", C.c_double * WALKER_MAX_JOINTS), ("pd_kd", C.c_double * WALKER_MAX_JOINTS),
                 ("pd_strength", C.c_double * WALKER_MAX_JOINTS), ("pd_limit", C.c_double * WALKER_MAX_JOINTS),
                 ("substep_log", C.c_void_p), ("n_terrain_boxes", C.c_int32), ("terrain", C.c_void_p),
-                ("sphere_friction", C.c_void_p), ("body_linear_damping", C.c_double), ("body_angular_damping", C.c_double)]
+                ("sphere_friction", C.c_void_p), ("body_linear_damping", C.c_double), ("body_angular_damping", C.c_double),
+                ("pd_kp_env", C.c_void_p), ("pd_kd_env", C.c_void_p)]
 
 
 class WalkerState(C.Structure):

@@ -427,7 +427,18 @@ __device__ __forceinline__ double motor_torque(const mg_walker_params &prm, doub
 #pragma clang fp contract(off)
 __device__ __forceinline__ double actuator_torque(const mg_walker_params &prm, int j, double q, double qd, double cmd) {
     if (prm.actuation == 2) return cmd;
+    if (prm.actuation == 4) return prm.pd_strength[j] * cmd;                         // TORQUE mode :125-128
     double t = (-1.0 * (prm.pd_kp[j] * (q - cmd)) - prm.pd_kd[j] * (qd - 0.0)) + 0.0;
+    t = prm.pd_strength[j] * t;
+    return fmin(fmax(t, -1.0 * prm.pd_limit[j]), prm.pd_limit[j]);
+}
+// The shape-generic kernels' actuator: the lane's own command block read once per launch — POSITION with shared or per-robot
+// gains, HYBRID (five numbers per motor), TORQUE, raw. Same expression, same order.
+struct ActLane { double q_des, kp, qd_des, kd, extra; };
+__device__ __forceinline__ double actuator_torque_lane(const mg_walker_params &prm, int j, double q, double qd, const ActLane &a) {
+    if (prm.actuation == 2) return a.q_des;
+    if (prm.actuation == 4) return prm.pd_strength[j] * a.q_des;
+    double t = (-1.0 * (a.kp * (q - a.q_des)) - a.kd * (qd - a.qd_des)) + a.extra;     // laikago_motor.py:157-158
     t = prm.pd_strength[j] * t;
     return fmin(fmax(t, -1.0 * prm.pd_limit[j]), prm.pd_limit[j]);
 }
@@ -879,7 +890,7 @@ __device__ __forceinline__ void wave_kinematics(const ModelW &m, const WaveLds &
 template <int NMAX, bool GENERIC>
 __device__ __forceinline__ void wave_substep(const mg_walker_topology &tp, const ModelW &m, const mg_walker_params &prm,
                                              const WaveLds &L, int lane, int max_depth, int maxr,
-                                             unsigned long long (&touch)[2], double pd_cmd, double *log_row, int n_envs,
+                                             unsigned long long (&touch)[2], const ActLane &act, double *log_row, int n_envs,
                                              double *foot_force, int nf) {
     const int nb = m.nb, nj = m.nj, ns = m.ns, n = 6 + nj;
     const double dt = prm.time_step;
@@ -889,7 +900,8 @@ __device__ __forceinline__ void wave_substep(const mg_walker_topology &tp, const
     asm volatile("" : "+v"(lane));
     PHASE_BEGIN();
     if (prm.actuation != 0 && lane < nj)      // read by lane 6 + j after the kinematics' barriers
-        L.tau[lane] = actuator_torque(prm, lane, L.q[lane], L.qd[lane], pd_cmd);
+        L.tau[lane] = GENERIC ? actuator_torque_lane(prm, lane, L.q[lane], L.qd[lane], act)
+                              : actuator_torque(prm, lane, L.q[lane], L.qd[lane], act.q_des);
     wave_kinematics<GENERIC>(m, L, lane, max_depth, true);
     PHASE(0);
     // ---- M and h by the composite-rigid-body algorithm (Featherstone RBDA ch. 6) in world coordinates, all spatial
@@ -1479,10 +1491,22 @@ __global__ __launch_bounds__(WV) __attribute__((amdgpu_waves_per_eu(2))) void wa
 #ifdef MG_WALKER_PROFILE
     unsigned long long ph_k0 = __builtin_readcyclecounter();
 #endif
-    const double pd_cmd = (prm.actuation != 0 && lane < nj) ? prm.pd_command[(size_t)lane * n_envs + e] : 0.0;
+    ActLane act{0.0, 0.0, 0.0, 0.0, 0.0};
+    if (prm.actuation != 0 && lane < nj) {
+        if (GENERIC && prm.actuation == 3) {          // HYBRID: desired angle, kp, desired rate, kd, additional torque
+            const double *c5 = prm.pd_command + ((size_t)5 * lane) * n_envs + e;
+            act = ActLane{c5[0], c5[(size_t)n_envs], c5[2 * (size_t)n_envs], c5[3 * (size_t)n_envs], c5[4 * (size_t)n_envs]};
+        } else {
+            act.q_des = prm.pd_command[(size_t)lane * n_envs + e];
+            if (GENERIC) {
+                act.kp = prm.pd_kp_env ? prm.pd_kp_env[(size_t)lane * n_envs + e] : prm.pd_kp[lane];
+                act.kd = prm.pd_kd_env ? prm.pd_kd_env[(size_t)lane * n_envs + e] : prm.pd_kd[lane];
+            }
+        }
+    }
     for (int it = 0; it < prm.frame_skip; ++it) {
         double *log_row = prm.substep_log ? prm.substep_log + ((size_t)it * (3 * nj + 7)) * n_envs + e : nullptr;
-        wave_substep<NMAX, GENERIC>(tp, m, prm, L, lane, max_depth, maxr, touch, pd_cmd, log_row, n_envs,
+        wave_substep<NMAX, GENERIC>(tp, m, prm, L, lane, max_depth, maxr, touch, act, log_row, n_envs,
                                     (st.foot_force != nullptr && it == prm.frame_skip - 1) ? st.foot_force + e : nullptr, nf);
     }
     if (st.bad_contacts != nullptr) {       // a1.py:314-323 GetBadFootContacts: contact points on links that are no foot
@@ -1668,7 +1692,7 @@ extern "C" int mg_walker_step(const mg_walker_topology *tp, const mg_walker_mode
     if (int rc = check_walker(tp, ms, prm, st, n)) return rc;
     if (prm->actuation == 0) MG_REQUIRE_PTR(action);
     else {
-        if (prm->actuation != 1 && prm->actuation != 2) return mg::set_error(MG_ERR_BAD_CONFIG, "walker actuation %d", prm->actuation);
+        if (prm->actuation < 1 || prm->actuation > 4) return mg::set_error(MG_ERR_BAD_CONFIG, "walker actuation %d", prm->actuation);
         if (prm->mapping == 0) return mg::set_error(MG_ERR_UNSUPPORTED, "in-launch actuators need the wave mapping");
         MG_REQUIRE_PTR(prm->pd_command);
     }
@@ -1697,7 +1721,8 @@ extern "C" int mg_walker_step(const mg_walker_topology *tp, const mg_walker_mode
     // (terrain boxes, per-proxy friction, body damping and > 64 proxies are compiled into the shape-generic instantiations
     // only: the two tuned kernels keep their registers)
     const bool generic_only = prm->n_terrain_boxes != 0 || prm->sphere_friction != nullptr || prm->body_linear_damping != 0.0 ||
-                              prm->body_angular_damping != 0.0 || st->foot_force != nullptr;
+                              prm->body_angular_damping != 0.0 || st->foot_force != nullptr || prm->actuation == 3 ||
+                              prm->pd_kp_env != nullptr || prm->pd_kd_env != nullptr;
     auto shape_is = [&](int b, int j, int s, int g) {
         return !generic_only && tp->n_bodies == b && tp->n_joints == j && tp->n_spheres == s && tp->n_geoms == g;
     };

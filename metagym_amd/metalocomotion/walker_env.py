@@ -336,22 +336,33 @@ class WalkerBatchEnv(object):
         self._terrain_t = torch.as_tensor(rows, dtype=torch.float64, device=self.device).contiguous()
         p.n_terrain_boxes, p.terrain = len(spec), self._terrain_t.data_ptr()
 
-    def step_actuated(self, command, kp=None, kd=None, strength=None, limit=None, raw_torque=False, n_substeps=None, log=None):
+    def step_actuated(self, command, kp=None, kd=None, strength=None, limit=None, raw_torque=False, n_substeps=None, log=None,
+                      mode="position", kp_env=None, kd_env=None):
         """The engine's in-launch actuators (mg_walker_params.actuation): `n_substeps` physics sub-steps in ONE launch, the
         joint torques re-evaluated before each of them — position control with the reference's PD motor model
         (quadrupedal/robots/laikago_motor.py:136-168) on the current joint state and the desired angles `command`
-        (float64 `[n_joints, num_envs]`, SoA), or `raw_torque=True`: `command` are the torques themselves. `log` (float64
+        (float64 `[n_joints, num_envs]`, SoA), or `raw_torque=True`: `command` are the torques themselves. `mode="hybrid"`
+        (laikago_motor.py:143-153; `command` is `[5 n_joints, num_envs]`: desired angle, kp, desired rate, kd, extra torque per
+        motor) and `mode="torque"` (:125-128: strength x command, no limit) are the model's other two modes; `kp_env` / `kd_env`
+        (`[n_joints, num_envs]`) are per-robot position gains. `log` (float64
         `[n_substeps, 3 n_joints + 7, num_envs]`) receives one true observation per sub-step (joint angles, rates, torques,
         base quaternion x y z w, body-frame angular velocity). The MetaLocomotion outputs (obs / reward / done) of the launch
         are those of the walker rules and are returned for completeness."""
         nj, p = self.n_joints, self._params_c
         cmd = torch.as_tensor(command, dtype=torch.float64, device=self.device)
-        assert cmd.shape == (nj, self.num_envs) and cmd.is_contiguous(), "command must be a contiguous [n_joints, num_envs] float64 tensor"
+        assert mode in ("position", "hybrid", "torque")
+        rows = 5 * nj if (mode == "hybrid" and not raw_torque) else nj
+        assert cmd.shape == (rows, self.num_envs) and cmd.is_contiguous(), "command must be a contiguous [%d, num_envs] float64 tensor" % rows
         k = self.frame_skip if n_substeps is None else int(n_substeps)
         if log is not None:
             assert log.shape == (k, 3 * nj + 7, self.num_envs) and log.is_contiguous() and log.dtype == torch.float64
         saved = (p.frame_skip, p.actuation)
-        p.frame_skip, p.actuation, p.pd_command = k, 2 if raw_torque else 1, cmd.data_ptr()
+        p.frame_skip, p.pd_command = k, cmd.data_ptr()
+        p.actuation = 2 if raw_torque else {"position": 1, "hybrid": 3, "torque": 4}[mode]
+        for name, t in (("pd_kp_env", kp_env), ("pd_kd_env", kd_env)):
+            if t is not None and not raw_torque:
+                assert t.shape == (nj, self.num_envs) and t.is_contiguous() and t.dtype == torch.float64
+            setattr(p, name, t.data_ptr() if (t is not None and not raw_torque) else None)
         p.substep_log = None if log is None else log.data_ptr()
         if not raw_torque:
             for name, v, dflt in (("pd_kp", kp, 0.0), ("pd_kd", kd, 0.0), ("pd_strength", strength, 1.0), ("pd_limit", limit, 1e30)):
@@ -364,6 +375,7 @@ class WalkerBatchEnv(object):
                                           _lib.current_stream(self.device))
         finally:
             p.frame_skip, p.actuation, p.pd_command, p.substep_log = saved[0], saved[1], None, None
+            p.pd_kp_env, p.pd_kd_env = None, None
         _lib.check(rc, "mg_walker_step (actuated)")
         return self._obs, self._reward, self._done, {"rewards": self._rewards5, "steps": self.steps}
 

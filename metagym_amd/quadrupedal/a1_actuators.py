@@ -241,20 +241,21 @@ class A1Actuators(object):
     def StepFused(self, action, fused_physics, filter_init_mask=None):
         """Minitaur.Step when the physics can run the whole action-repeat loop in one launch with the PD motor model evaluated
         inside it (`fused_physics(command_soa, actuators) -> log`, float64 `[action_repeat, 43, num_envs]`: one true
-        observation per sub-step, torques included — e.g. WalkerBatchEnv.step_actuated). POSITION mode, pd latency 0, no
-        command clip, no interpolation (the reference's A1 configuration, env_builder.py:44-52); any control latency. The log
-        is pushed on the history in one launch (mg_a1_receive_log). Returns the applied torques `[action_repeat, num_envs, 12]`."""
+        observation per sub-step, torques included — e.g. WalkerBatchEnv.step_actuated). All three motor modes (POSITION with
+        shared or per-robot gains, HYBRID, TORQUE), pd latency 0, no command clip, no interpolation (the reference's A1
+        configuration, env_builder.py:44-52); any control latency. The log is pushed on the history in one launch
+        (mg_a1_receive_log). Returns the applied torques `[action_repeat, num_envs, 12]`."""
         c = self._cfg
-        if (self._motor_control_mode is not MotorControlMode.POSITION or c.pd_latency != 0.0 or c.pd_latency_env or c.clip_commands
-                or self._enable_action_interpolation or c.kp_env or c.kd_env):
-            raise _lib.MetaGymHipError("StepFused covers POSITION mode with pd latency 0, shared gains, no clip / interpolation; use Step")
+        if c.pd_latency != 0.0 or c.pd_latency_env or c.clip_commands or self._enable_action_interpolation:
+            raise _lib.MetaGymHipError("StepFused needs pd latency 0 and no command clip / interpolation (the motor model is evaluated "
+                                       "on the CURRENT joint state inside the physics launch); use Step")
         if self._action_filter is not None:
             if self._step_counter == 0:
                 self._action_filter.init_history(self.GetMotorAngles())
             elif filter_init_mask is not None:
                 self._action_filter.init_history(self.GetMotorAngles(), filter_init_mask)
             action = self._action_filter.filter(action)
-        act = self._soa(action, NUM_MOTORS)
+        act = self._soa(action, 5 * NUM_MOTORS if self._motor_control_mode is MotorControlMode.HYBRID else NUM_MOTORS)
         log = fused_physics(act, self)
         assert log.shape == (self._action_repeat, _lib.A1_OBS_DIM, self.num_envs) and log.is_contiguous()
         with torch.cuda.device(self.device):
@@ -264,6 +265,14 @@ class A1Actuators(object):
         self._step_counter += self._action_repeat
         self._last_action = act
         return log[:, 2 * NUM_MOTORS:3 * NUM_MOTORS, :].permute(0, 2, 1)
+
+    def fused_spec(self):
+        """What a physics needs to evaluate this motor model itself (WalkerBatchEnv.step_actuated's keyword arguments)."""
+        c = self._cfg
+        kp, kd, strength, limit = self.motor_model_parameters()
+        return dict(kp=kp, kd=kd, strength=strength, limit=limit,
+                    mode={MotorControlMode.POSITION: "position", MotorControlMode.HYBRID: "hybrid", MotorControlMode.TORQUE: "torque"}[self._motor_control_mode],
+                    kp_env=self._keep.get("kp") if c.kp_env else None, kd_env=self._keep.get("kd") if c.kd_env else None)
 
     def motor_model_parameters(self):
         """(kp, kd, strength, torque limit) per motor, for a physics that evaluates the PD model itself."""

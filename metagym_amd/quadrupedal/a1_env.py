@@ -79,7 +79,10 @@ class A1GymEnv(object):
                                      vel_mode=vel_mode)
         self._lib = _lib.load()
         self.last_torques = None
-        self._fusable = motor_control_mode is MotorControlMode.POSITION and motor_kp is None
+        # the physics' one-launch path (fused_step) takes every motor mode and per-robot gains when it is A1Physics; a caller's
+        # own fused_step is only assumed to know the reference's default (POSITION, shared gains) unless it says `fused_modes = "all"`
+        self._fusable = (motor_control_mode is MotorControlMode.POSITION and motor_kp is None) or \
+            getattr(physics, "fused_modes", None) == "all"
         # sub-steps since reset, on the device (exact in float64): the ETG's clock without a host value inside step(), so a
         # step can be captured into a hipGraph (capture_step)
         self._substeps_dev = torch.zeros(self.num_envs, dtype=torch.float64, device=self.device)

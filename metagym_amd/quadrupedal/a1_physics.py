@@ -95,6 +95,7 @@ class A1Physics(object):
         self._default_pose = torch.tensor([0.0, 0.0, 0.28], **f64).reshape(3, 1)
         if fused:                                  # A1GymEnv takes the one-launch path when the physics offers it
             self.fused_step = self._fused_step
+            self.fused_modes = "all"               # POSITION (shared / per-robot gains), HYBRID, TORQUE
 
     # ---- the protocol of A1GymEnv (a1_env.py) -------------------------------------------------------------------
     def set_terrain(self, boxes, default_pose):
@@ -139,11 +140,10 @@ class A1Physics(object):
 
     def _fused_step(self, command, actuators):
         """13 sub-steps in one engine launch, the PD motor model (laikago_motor.py:136-168) evaluated inside it before each."""
-        kp, kd, strength, limit = actuators.motor_model_parameters()
         k = actuators._action_repeat
         if not hasattr(self, "_log") or self._log.shape[0] != k:
             self._log = torch.empty(k, 43, self.n, dtype=torch.float64, device=self.device)
-        self.env.step_actuated(command, kp, kd, strength, limit, n_substeps=k, log=self._log)
+        self.env.step_actuated(command, n_substeps=k, log=self._log, **actuators.fused_spec())      # any of the three motor modes
         return self._log
 
     def state_dict(self):

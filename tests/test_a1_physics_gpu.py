@@ -239,3 +239,46 @@ def test_a1_gym_env_checkpoint_continues_bit_for_bit():
         assert torch.equal(o, outs[k - 4][0]) and torch.equal(r, outs[k - 4][1]) and torch.equal(d, outs[k - 4][2]), k
         ends += int(d.sum())
     assert ends > 0
+
+
+@pytest.mark.parametrize("mode", ["position_env_gains", "hybrid", "torque"])
+def test_fused_actuation_modes_equal_the_substep_path_bit_for_bit(mode):
+    """The engine's in-launch actuators beyond the A1 default: POSITION with per-robot gains (what
+    locomotion_gym_env.py:388-392 draws), HYBRID (laikago_motor.py:143-153) and TORQUE (:125-128) — 13 fused sub-steps against
+    the same loop run sub-step by sub-step through mg_a1_apply_action (whose motor model is pinned to the reference, all three
+    modes): torques, observation history and engine state identical."""
+    from metagym_amd.quadrupedal import A1Actuators, MotorControlMode
+    n = 48
+    rs = np.random.RandomState(5)
+    cmode = {"position_env_gains": MotorControlMode.POSITION, "hybrid": MotorControlMode.HYBRID, "torque": MotorControlMode.TORQUE}[mode]
+    runs = []
+    for fused in (True, False):
+        phys = A1Physics(n, urdf=a1_like_urdf(), device=DEV, fused=fused)
+        act = A1Actuators(n, DEV, motor_control_mode=cmode, control_latency=0.0041)
+        if mode == "position_env_gains":
+            act.SetMotorGains(torch.as_tensor(np.random.RandomState(1).uniform(60, 110, (n, 12)), device=DEV),
+                              torch.as_tensor(np.random.RandomState(2).uniform(1.0, 4.0, (n, 12)), device=DEV))
+        act.SetMotorStrengthRatios(np.linspace(0.8, 1.1, 12))
+        act.Reset()
+        act.ReceiveObservation(*phys.reset(None))
+        runs.append((phys, act))
+    target = np.array([0, 0.9, -1.8] * 4)
+    for k in range(6):
+        if mode == "torque":
+            cmd = rs.uniform(-8, 8, (n, 12))
+        elif mode == "hybrid":
+            cmd = np.zeros((n, 12, 5))
+            cmd[..., 0] = target + rs.uniform(-0.2, 0.2, (n, 12)); cmd[..., 1] = rs.uniform(50, 100, (n, 12))
+            cmd[..., 2] = rs.uniform(-0.5, 0.5, (n, 12)); cmd[..., 3] = rs.uniform(1, 3, (n, 12)); cmd[..., 4] = rs.uniform(-2, 2, (n, 12))
+            cmd = cmd.reshape(n, 60)
+        else:
+            cmd = target + rs.uniform(-0.2, 0.2, (n, 12))
+        a = torch.as_tensor(cmd, device=DEV)
+        (pf, af), (pu, au) = runs
+        tf = af.StepFused(a, pf.fused_step)
+        tu = au.Step(a, pu.substep)
+        assert torch.equal(tf, tu), (mode, k)
+        assert torch.equal(af.GetControlObservation(), au.GetControlObservation())
+        for key in ("pos", "rot", "vel", "omega", "q", "qd"):
+            assert torch.equal(getattr(pf.env, key), getattr(pu.env, key)), (mode, k, key)
+    assert torch.isfinite(tf).all() and float(tf.abs().max()) > 1.0
