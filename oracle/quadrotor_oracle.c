@@ -159,6 +159,17 @@ int qo_failed(const qo_consts *c, const qo_state *s) {
     return 0;
 }
 
+/* NumPy-pin switch (test infrastructure of test infrastructure). Everything in this file is the reference as NumPy >= 2
+ * (NEP 50) evaluates it — the only way it runs in the build container. The reference's own pin is numpy==1.22
+ * (requirements.txt:4), whose value-based casting differs in ONE kind of expression: a python float combined with a
+ * float32 SCALAR (an element read out of an array, np.sum's result) gives float64 there and float32 here; python float
+ * with a float32 ARRAY is float32 under both. With the switch on, those scalar mixes are evaluated in float64, hand-derived
+ * line by line from quadrotorsim.py:136-156 and env.py:217,237-241 (the motor chain phi_w, me, power, d_prop_w, w_m and the
+ * thrust polynomial; dt * power, hovering_range - z_move). tests/test_oracle_quadrotor.py bounds the gap between the two
+ * readings over every golden rollout (north_star tolerance 1e-5). Not thread-safe; never set outside that test. */
+static int qo_legacy_promotion = 0;
+void qo_set_legacy_promotion(int on) { qo_legacy_promotion = on; }
+
 void qo_substep(const qo_consts *c, qo_state *s, const double act[4]) {
     float prop_force_z = 0.0f;               /* prop_force[0], [1] stay 0 (:124,159) */
     float prop_torque[3] = {0, 0, 0};
@@ -178,11 +189,22 @@ void qo_substep(const qo_consts *c, qo_state *s, const double act[4]) {
         else if (eff_act < c->min_voltage) eff_act = c->min_voltage;
         const float eff32 = (float)eff_act;
 
-        float phi_w = phi32 * s->propw[i];                                 /* :136 f32 */
-        me[i] = phi_over_ra32 * (eff32 - phi_w);                           /* :137-138 f32 */
-        prop_powers[i] = fabsf(me[i] / phi32 * eff32);                     /* :139 f32 */
-        float d_prop_w = inv_jm32 * (me[i] - mm32);                        /* :141-142 f32 */
-        float w_m = s->propw[i] + prec32 * d_prop_w;                       /* :144-145 f32 */
+        float w_m;
+        double w_m64 = 0.0;
+        if (!qo_legacy_promotion) {
+            float phi_w = phi32 * s->propw[i];                             /* :136 f32 */
+            me[i] = phi_over_ra32 * (eff32 - phi_w);                       /* :137-138 f32 */
+            prop_powers[i] = fabsf(me[i] / phi32 * eff32);                 /* :139 f32 */
+            float d_prop_w = inv_jm32 * (me[i] - mm32);                    /* :141-142 f32 */
+            w_m = s->propw[i] + prec32 * d_prop_w;                         /* :144-145 f32 */
+        } else {        /* numpy 1.22: python float (op) float32 scalar -> float64; the f32 arrays round on store */
+            const double phi_w = c->phi * (double)s->propw[i];
+            me[i] = (float)(c->phi / c->ra * (eff_act - phi_w));
+            prop_powers[i] = (float)fabs((double)me[i] / c->phi * eff_act);
+            const double d_prop_w = 1.0 / c->jm * ((double)me[i] - c->mm);
+            w_m64 = (double)s->propw[i] + c->precision * d_prop_w;
+            w_m = (float)w_m64;                                            /* what :158 stores */
+        }
         float l_m = norm3_f32(&c->prop_coord[3 * i]);                      /* :146 f32 */
 
         double body_velocity[3];                                           /* :147-148 f64 */
@@ -199,6 +221,8 @@ void qo_substep(const qo_consts *c, qo_state *s, const double act[4]) {
         double t1 = (double)(ct1_32 * w_m) * v_1;
         double t2 = ((c->ct2 * v_1) * v_1) * sign;
         double thrust = ((double)t0 + t1) + t2;
+        if (qo_legacy_promotion)                                          /* w_m is a float64 scalar there: all three terms f64 */
+            thrust = ((c->ct0 * w_m64) * w_m64 + (c->ct1 * w_m64) * v_1) + t2;
 
         s->propw[i] = w_m;                                                 /* :158 */
         prop_force_z = (float)((double)prop_force_z + thrust);             /* :159 f64 add, f32 store */
@@ -442,6 +466,8 @@ int qo_env_step(const qo_consts *c, qo_state *s, int *ct, const float act[4],
        evaluates in f32 (weak python float); the picked object keeps its own precision */
     if ((float)c->healthy_reward < energy) r = -c->healthy_reward;
     else r = -(double)energy;
+    const double energy64 = c->dt * (double)s->power;        /* numpy 1.22: float64 */
+    if (qo_legacy_promotion) r = (c->healthy_reward < energy64) ? -c->healthy_reward : -energy64;
     double task_reward = is_collision ? 0.0 : c->healthy_reward;
     if (c->task == QO_TASK_HOVERING) {
         double velocity_norm = norm3_f64(s->vel);
@@ -451,10 +477,11 @@ int qo_env_step(const qo_consts *c, qo_state *s, int *ct, const float act[4],
         if (z_move < 0.5f) task_reward += 10;
         else {
             float o = 0.5f - z_move;                          /* weak 0.5 - f32 -> f32 */
-            task_reward += (-20.0 > (double)o) ? -20.0 : (double)o;   /* max(-20, o) */
+            const double o64 = qo_legacy_promotion ? 0.5 - (double)z_move : (double)o;    /* numpy 1.22: float64 */
+            task_reward += (-20.0 > o64) ? -20.0 : o64;       /* max(-20, o) */
         }
     }
-    if (c->task == QO_TASK_HOVERING || ((float)c->healthy_reward < energy)) {
+    if (c->task == QO_TASK_HOVERING || qo_legacy_promotion || ((float)c->healthy_reward < energy)) {
         r += task_reward;                 /* np.float64 task_reward (hovering) or python floats only */
     } else {
         /* no_collision: np.float32(-energy) + python float -> the python float is weak, f32 add */

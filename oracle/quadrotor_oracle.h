@@ -74,6 +74,8 @@ void qo_batch_env_step_autoreset(const qo_consts *c, const qo_autoreset *ar, int
 size_t qo_sizeof_state(void);
 size_t qo_sizeof_consts(void);
 
+void qo_set_legacy_promotion(int on);   /* numpy 1.22 reading of the python-float x float32-scalar mixes; tests only */
+
 #ifdef __cplusplus
 }
 #endif
