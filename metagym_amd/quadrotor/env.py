@@ -115,7 +115,7 @@ class Quadrotor(object):
 
     def __init__(self, num_envs=1, device="cuda", dt=0.01, nt=1000, seed=0, task="no_collision",
                  map_file=None, simulator_conf=None, healthy_reward=1.0, auto_reset=False, env_id_base=0,
-                 exact_reward=True, **kwargs):
+                 exact_reward=True, copy_outputs=False, **kwargs):
         assert task in TASKS, "Invalid task setting"
         self._lib = _lib.load()
         self.num_envs = int(num_envs)
@@ -124,6 +124,10 @@ class Quadrotor(object):
             raise _lib.MetaGymHipError("metagym_amd runs on an AMD GPU only (got device %r); there "
                                        "is no CPU path" % (device,))
         self.dt, self.nt, self.task, self.healthy_reward = dt, nt, task, healthy_reward
+        # step() / reset() hand back the SAME output tensors every call (the kernel writes into them; a hipGraph replays on
+        # them): keep `obs` across steps only as `obs.clone()`. `copy_outputs=True` returns fresh tensors like the reference's
+        # fresh numpy arrays, at the price of four device copies per step.
+        self.copy_outputs = bool(copy_outputs)
         if simulator_conf is None:
             self.sim_config = json.loads(json.dumps(DEFAULT_SIM_CONFIG))
         else:
@@ -261,7 +265,8 @@ class Quadrotor(object):
 
     def step(self, action):
         """action: float32 [N,4] tensor (or array-like). Returns (obs [N,16] f32, reward [N] f32,
-        done [N] bool, info dict of [N] tensors)."""
+        done [N] bool, info dict of [N] tensors). The four are views of persistent output buffers unless the env was built
+        with `copy_outputs=True`: `.clone()` what you keep across steps."""
         a = action
         if not (isinstance(a, torch.Tensor) and a.dtype == torch.float32 and a.device == self.device
                 and a.is_contiguous()):
@@ -276,6 +281,9 @@ class Quadrotor(object):
                              torch.cuda.current_stream(self.device).cuda_stream)
         if rc != 0:
             _lib.check(rc, "mg_quadrotor_plan_step")
+        if self.copy_outputs:
+            obs = self._obs.clone()
+            return obs, self._reward.clone(), self._done.clone(), _LazyInfo(obs, self._failed.clone())
         return self._obs, self._reward, self._done, self._info_obj
 
     def rollout(self, actions):

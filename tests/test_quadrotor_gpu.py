@@ -578,3 +578,19 @@ def test_autoreset_full_size_sampled_against_oracle():
     for cols, scale in ((slice(0, 3), 2.0), (slice(9, 12), 5.0)):
         x = o[:, cols] / scale
         assert abs(np.mean(x > 0) - 0.5) < 0.01 and abs(np.mean(np.abs(x)) - 0.5) < 0.01
+
+
+def test_step_outputs_alias_unless_copy_outputs():
+    """DESIGN.md §7: step() returns the same four tensors every call (no allocation on the hot path, hipGraph-replayable);
+    `copy_outputs=True` gives fresh ones like the reference's fresh numpy arrays."""
+    import metagym_amd
+    a = torch.full((8, 4), 2.0, device="cuda:0")
+    for copy in (False, True):
+        env = metagym_amd.make("quadrotor-v0", num_envs=8, device="cuda:0", task="hovering_control", copy_outputs=copy)
+        env.reset(seed=0)
+        o1, r1, d1, i1 = env.step(a)
+        keep = o1.clone()
+        o2, r2, d2, i2 = env.step(a)
+        assert (o1.data_ptr() == o2.data_ptr()) == (not copy)
+        assert torch.equal(o1, keep) == copy                      # without copies the first observation was overwritten
+        assert torch.equal(i2["z"], o2[:, 15])
