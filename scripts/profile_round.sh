@@ -4,8 +4,8 @@
 # everything into gpurun_out/<round>/; scripts/summarize_profiles.py <round> condenses it into profiles/<round>/.
 export TMPDIR=/tmp
 cd "${GRAFT_REPO_ROOT:-.}"
-R=${1:-r02}; shift
-PARTS=${@:-quad maze walker a1 bench}
+R=${1:-r03}; shift
+PARTS=${@:-quad north maze walker a1 bench}
 OUT=gpurun_out/$R
 mkdir -p $OUT
 has() { [[ " $PARTS " == *" $1 "* ]]; }
@@ -20,6 +20,15 @@ if has quad; then
   # the default (hipGraph replay) run under the tracer as well: same kernel, same average expected
   timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/quad_graph_trace -o q -- \
           python bench.py --no-cpu-baseline --no-secondary --steps 100 --warmup 10 > $OUT/quad_graph_trace.log 2>&1
+fi
+if has north; then
+  # north_star's own batch sizes on one GPU: 2^17 (its per-GPU share on 8 GPUs) and 2^20 (the whole batch), eager launches
+  for NN in 131072 1048576; do
+    B="python bench.py --no-cpu-baseline --no-secondary --steps 100 --warmup 10 --launch eager --envs-per-gpu $NN"
+    timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/quad_${NN}_trace -o q -- $B > $OUT/quad_${NN}_trace.log 2>&1
+    timeout 300 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_INSTS_SALU \
+              --output-format csv -d $OUT/quad_${NN}_pmc_sq -o q -- $B > $OUT/quad_${NN}_pmc_sq.log 2>&1
+  done
 fi
 if has maze; then
   for V in discrete continuous; do

@@ -15,7 +15,7 @@ import os
 import shutil
 import sys
 
-rnd = sys.argv[1] if len(sys.argv) > 1 else "r02"
+rnd = sys.argv[1] if len(sys.argv) > 1 else "r03"
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 R = os.path.join(ROOT, "gpurun_out", rnd)
 P = os.path.join(ROOT, "profiles", rnd)
@@ -71,6 +71,24 @@ for src, dst in (("quad_trace/q_kernel_stats.csv", "quadrotor_bench_kernel_stats
                  ("bench_walker.jsonl", "bench_walker.jsonl")):
     if os.path.exists(os.path.join(R, src)):
         shutil.copy(os.path.join(R, src), os.path.join(P, dst))
+# north_star batch sizes (2^17 / 2^20 quadrotors on one GPU): kernel-stats CSV + the SQ counters of a separate --pmc pass
+north = {}
+for nn in (131072, 1048576):
+    src = os.path.join(R, "quad_%d_trace" % nn, "q_kernel_stats.csv")
+    if os.path.exists(src):
+        shutil.copy(src, os.path.join(P, "quadrotor_%denvs_kernel_stats.csv" % nn))
+    a, meta = agg(os.path.join(R, "quad_%d_pmc_sq" % nn, "q_counter_collection.csv"), "quadrotor_step_kernel")
+    m = a.get("quadrotor_step_kernel", {})
+    if "SQ_WAVES" in m:
+        w = m["SQ_WAVES"]
+        m["valu_insts_per_wave"] = m.get("SQ_INSTS_VALU", 0) / w
+        m["valu_active_frac"] = m.get("SQ_ACTIVE_INST_VALU", 0) / max(m.get("SQ_WAVE_CYCLES", 1), 1)
+        m["wait_any_frac"] = m.get("SQ_WAIT_ANY", 0) / max(m.get("SQ_WAVE_CYCLES", 1), 1)
+        m["dispatch"] = meta
+        north[str(nn)] = m
+if north:
+    json.dump(north, open(os.path.join(P, "pmc_quadrotor_north_star.json"), "w"), indent=1)
+    print(json.dumps(north, indent=1))
 if "hbm_bytes_per_launch" in summary.get("quadrotor_step_kernel", {}):
     q = summary["quadrotor_step_kernel"]
     json.dump({"round": rnd, "kernel": "quadrotor_step_kernel", "envs": 65536,
