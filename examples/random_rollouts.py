@@ -65,13 +65,33 @@ def main():
     cont.set_task(tasks9)
     run("meta-maze-continuous-3D-v0", cont, lambda: torch.rand(m3, 2, device=dev) * 2 - 1, args.steps)
 
+    # the 384 body variants per robot are regenerated from their generator patterns (no asset directory needed);
+    # METAGYM_LOCOMOTION_ASSETS=<reference>/metagym/metalocomotion/envs/assets reads the reference's MJCF files instead
     assets = os.environ.get("METAGYM_LOCOMOTION_ASSETS")
-    if assets:      # the MJCF body variants ship with the reference (metagym/metalocomotion/envs/assets)
-        hum = metagym_amd.make("meta-humanoid-v0", num_envs=m3, device=dev, assets_dir=assets, auto_reset=True)
-        hum.set_task(hum.sample_task())
-        run("meta-humanoid-v0", hum, lambda: torch.rand(m3, hum.n_joints, device=dev) * 2 - 1, args.steps)
-    else:
-        print("meta-humanoid-v0: set METAGYM_LOCOMOTION_ASSETS=<reference>/metagym/metalocomotion/envs/assets to run it")
+    for ident in ("meta-humanoid-v0", "meta-ant-v0"):
+        walker = metagym_amd.make(ident, num_envs=m3, device=dev, assets_dir=assets, auto_reset=True)
+        walker.set_task([walker.sample_task("TRAIN") for _ in range(16)])       # 16 body variants, env e runs variant e % 16
+        run(ident, walker, lambda: torch.rand(m3, walker.n_joints, device=dev) * 2 - 1, args.steps)
+
+    # quadrupedal-v0 from a URDF on the articulated-body engine. METAGYM_A1_URDF=<pybullet_data>/a1/a1.urdf is the reference's
+    # robot (it ships with pybullet_data, not with the reference); the default is this repo's A1-shaped demo robot
+    urdf = os.environ.get("METAGYM_A1_URDF", os.path.join(os.path.dirname(os.path.abspath(__file__)), "a1_like", "a1_like.urdf"))
+    import numpy as np
+    w = np.tile([[0.03], [0.0], [0.02]], (1, 20)) * np.sin(np.linspace(0, 2 * np.pi, 20))      # hand-set ETG weights: an open-loop trot
+    a1 = metagym_amd.make("quadrupedal-v0", num_envs=m3, device=dev, urdf=urdf, ETG=1, ETG_w=w, ETG_b=np.zeros(3), task="slopestair",
+                          auto_reset=True)
+    a1.reset()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    total, ended = 0.0, 0
+    for _ in range(args.steps):
+        obs, reward, done, info = a1.step(torch.rand(m3, 12, device=dev, dtype=torch.float64) * 0.2 - 0.1)
+        total += float(reward.sum())
+        ended += int(done.sum())
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    print("%-28s %8d envs  %6.0f steps/s  %.3g env-steps/s  mean reward/step %+.4f  episodes ended %d  (13 physics sub-steps per step)"
+          % ("quadrupedal-v0 (slopestair)", m3, args.steps / dt, m3 * args.steps / dt, total / (m3 * args.steps), ended))
 
 
 if __name__ == "__main__":
