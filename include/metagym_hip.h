@@ -450,6 +450,12 @@ typedef struct mg_walker_params {
      * never touches it, so PyBullet's default applies there — an option of metalocomotion.mjcf / WalkerBatchEnv. */
     double body_linear_damping, body_angular_damping;
     const double *pd_kp_env, *pd_kd_env;
+    /* External push on the base body during the FIRST sub-step of the launch only (shape-generic kernels; NULL = none):
+     * DEVICE f64 [6][N] — force (3) and application point (3), both in the base BODY frame. What
+     * pybullet.applyExternalForce(body, -1, force, pos, LINK_FRAME) followed by 13 stepSimulation() calls does: Bullet clears
+     * external forces after every stepSimulation (RandomWrapper, quadrupedal/envs/env_wrappers/MonitorEnv.py:530-535,644-660;
+     * the caller adds the root link's inertial offset to pos: PyBullet's link frame is the inertial frame). */
+    const double *ext_wrench;
 } mg_walker_params;
 
 /* Per-env state, SoA doubles: component c of env e at base[c*N + e]. */

@@ -891,7 +891,7 @@ template <int NMAX, bool GENERIC>
 __device__ __forceinline__ void wave_substep(const mg_walker_topology &tp, const ModelW &m, const mg_walker_params &prm,
                                              const WaveLds &L, int lane, int max_depth, int maxr,
                                              unsigned long long (&touch)[2], const ActLane &act, double *log_row, int n_envs,
-                                             double *foot_force, int nf) {
+                                             double *foot_force, int nf, const double *ext_wrench) {
     const int nb = m.nb, nj = m.nj, ns = m.ns, n = 6 + nj;
     const double dt = prm.time_step;
     // A fresh copy of the lane id per sub-step: the ~140 lane predicates of the unrolled Cholesky / substitution
@@ -1032,6 +1032,13 @@ __device__ __forceinline__ void wave_substep(const mg_walker_topology &tp, const
             u_d = L.qd[j];
         } else {
             u_d = L.base[d < 3 ? 12 + d : 15 + (d - 3)];
+            if (GENERIC && ext_wrench != nullptr) {     // a push on the base body (mg_walker_params.ext_wrench): F on v_O, r x F on omega
+                const double *R = L.base + 3;
+                const V3 f{ext_wrench[0], ext_wrench[(size_t)n_envs], ext_wrench[2 * (size_t)n_envs]};
+                const V3 pl{ext_wrench[3 * (size_t)n_envs], ext_wrench[4 * (size_t)n_envs], ext_wrench[5 * (size_t)n_envs]};
+                const V3 F = mulMv(R, f), r = mulMv(R, pl), T = cross(r, F);
+                x_d += d == 0 ? F.x : d == 1 ? F.y : d == 2 ? F.z : d == 3 ? T.x : d == 4 ? T.y : T.z;
+            }
         }
     }
     const int lrow = lane < n ? lane : n - 1;
@@ -1507,7 +1514,8 @@ __global__ __launch_bounds__(WV) __attribute__((amdgpu_waves_per_eu(2))) void wa
     for (int it = 0; it < prm.frame_skip; ++it) {
         double *log_row = prm.substep_log ? prm.substep_log + ((size_t)it * (3 * nj + 7)) * n_envs + e : nullptr;
         wave_substep<NMAX, GENERIC>(tp, m, prm, L, lane, max_depth, maxr, touch, act, log_row, n_envs,
-                                    (st.foot_force != nullptr && it == prm.frame_skip - 1) ? st.foot_force + e : nullptr, nf);
+                                    (st.foot_force != nullptr && it == prm.frame_skip - 1) ? st.foot_force + e : nullptr, nf,
+                                    (GENERIC && prm.ext_wrench != nullptr && it == 0) ? prm.ext_wrench + e : nullptr);
     }
     if (st.bad_contacts != nullptr) {       // a1.py:314-323 GetBadFootContacts: contact points on links that are no foot
         int bad = 0;
@@ -1707,7 +1715,7 @@ extern "C" int mg_walker_step(const mg_walker_topology *tp, const mg_walker_mode
     mg::DeviceGuard guard(mg::device_of(st->pos));
     if (prm->mapping == 0) {   // lane-per-env reference mapping (private-memory work set)
         if (tp->n_spheres > 64 || prm->sphere_friction != nullptr || prm->body_linear_damping != 0.0 || prm->body_angular_damping != 0.0 ||
-            st->foot_force != nullptr)
+            st->foot_force != nullptr || prm->ext_wrench != nullptr)
             return mg::set_error(MG_ERR_UNSUPPORTED, "per-proxy friction, body damping and > 64 collision proxies need the wave mapping");
         hipLaunchKernelGGL(walker_step_kernel, dim3((n + WK_BLOCK - 1) / WK_BLOCK), dim3(WK_BLOCK), 0,
                            (hipStream_t)stream, *tp, *ms, *prm, *st, n, action, obs, reward, rewards5, done);
@@ -1722,7 +1730,7 @@ extern "C" int mg_walker_step(const mg_walker_topology *tp, const mg_walker_mode
     // only: the two tuned kernels keep their registers)
     const bool generic_only = prm->n_terrain_boxes != 0 || prm->sphere_friction != nullptr || prm->body_linear_damping != 0.0 ||
                               prm->body_angular_damping != 0.0 || st->foot_force != nullptr || prm->actuation == 3 ||
-                              prm->pd_kp_env != nullptr || prm->pd_kd_env != nullptr;
+                              prm->pd_kp_env != nullptr || prm->pd_kd_env != nullptr || prm->ext_wrench != nullptr;
     auto shape_is = [&](int b, int j, int s, int g) {
         return !generic_only && tp->n_bodies == b && tp->n_joints == j && tp->n_spheres == s && tp->n_geoms == g;
     };

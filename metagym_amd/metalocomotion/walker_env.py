@@ -185,6 +185,7 @@ class WalkerBatchEnv(object):
         st = _lib.WalkerState()
         for k in ("task_id", "pos", "rot", "vel", "omega", "q", "qd", "potential", "feet_contact", "steps", "bad_contacts"):
             setattr(st, k, getattr(self, k).data_ptr())
+        self.ext_wrench = None      # optional [6][N] push on the base body, first sub-step of every launch (set_external_wrench)
         self.foot_force = torch.zeros(nf, N, dtype=torch.float64, device=dev) if self.want_foot_force else None
         st.foot_force = self.foot_force.data_ptr() if self.want_foot_force else None
         self._state_c = st
@@ -309,6 +310,15 @@ class WalkerBatchEnv(object):
                                       _lib.current_stream(self.device))
         _lib.check(rc, "mg_walker_step")
         return self._obs, self._reward, self._done, {"rewards": self._rewards5, "steps": self.steps}
+
+    def set_external_wrench(self, wrench):
+        """A push on the base body during the first sub-step of every following launch (mg_walker_params.ext_wrench): float64
+        `[6, num_envs]` — force and application point in the base body frame — or None. The tensor is read at launch time, so
+        it can be rewritten in place between steps (also inside a captured hipGraph)."""
+        if wrench is not None:
+            assert wrench.shape == (6, self.num_envs) and wrench.dtype == torch.float64 and wrench.is_contiguous()
+        self.ext_wrench = wrench
+        self._params_c.ext_wrench = None if wrench is None else wrench.data_ptr()
 
     def set_terrain(self, boxes):
         """Static boxes on top of the ground plane, shared by every env (mg_walker_params.terrain; wave mapping only) — e.g. the

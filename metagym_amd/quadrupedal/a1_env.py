@@ -48,10 +48,38 @@ class A1GymEnv(object):
                  act_mode="traj", task="plane", normal=0, action_space=0, reward_param=Param_Dict, reward_p=1.0, vel_d=0.6,
                  filter_=0, control_latency=0.002, motor_kp=None, motor_kd=None, env_info=None,
                  motor_control_mode=MotorControlMode.POSITION, sensor_mode=SENSOR_MODE, auto_reset=False, urdf=None,
-                 urdf_options=None, vel_mode="max"):
+                 urdf_options=None, vel_mode="max", random_param=None, dynamic_param=None, random_dynamic=False, seed=0,
+                 force_source=None):
+        # ---- dynamics handed in explicitly (`dynamic_param`, locomotion_gym_env.py:349-380) ---------------------------------
+        dyn = dict(dynamic_param or {})
+        for key in dyn:
+            if key not in ("control_latency", "footfriction", "basemass", "motor_kp", "motor_kd", "gravity"):
+                raise _lib.MetaGymHipError("dynamic_param[%r]: of locomotion_gym_env.py:354-380's keys control_latency, footfriction, basemass, "
+                                           "motor_kp / motor_kd and gravity are built; per-link inertia / leg-mass ratios are not" % key)
+        if random_dynamic:
+            raise _lib.MetaGymHipError("random_dynamic=True redraws latency, friction, masses, inertias, gains and gravity from numpy's global "
+                                       "stream at every reset (locomotion_gym_env.py:381-405): not built; pass the values as dynamic_param")
+        if "control_latency" in dyn:
+            control_latency = 0.001 * float(dyn["control_latency"])                 # milliseconds (:354-355)
+        if "motor_kp" in dyn and "motor_kd" in dyn:
+            motor_kp, motor_kd = dyn["motor_kp"], dyn["motor_kd"]
+        footfriction, basemass_ratio = float(dyn.get("footfriction", 1.0)), float(dyn.get("basemass", 1.0))      # :338-339,356-359
+        gravity = dyn.get("gravity")
+        if gravity is not None and (float(gravity[0]) != 0.0 or float(gravity[1]) != 0.0):
+            raise _lib.MetaGymHipError("dynamic_param['gravity']: only (0, 0, -g) is built")
         if physics is None and urdf is not None:       # the robot file on this repo's own articulated-body engine
             from .a1_physics import A1Physics
-            physics = A1Physics(num_envs, urdf=urdf, device=device, **dict(urdf_options or {}))
+            opts = dict(urdf_options or {})
+            opts.setdefault("foot_friction", footfriction)
+            opts.setdefault("base_mass_ratio", basemass_ratio)
+            if gravity is not None:
+                opts.setdefault("gravity", -float(gravity[2]))
+            physics = A1Physics(num_envs, urdf=urdf, device=device, **opts)
+        elif physics is not None and (("footfriction" in dyn) or ("basemass" in dyn) or gravity is not None):
+            if not hasattr(physics, "set_dynamics"):
+                raise _lib.MetaGymHipError("dynamic_param footfriction / basemass / gravity change the SIMULATOR: give your physics a "
+                                           "set_dynamics(dict) method, or let A1GymEnv build A1Physics from urdf=")
+            physics.set_dynamics({k: dyn[k] for k in ("footfriction", "basemass", "gravity") if k in dyn})
         if physics is None:
             raise _lib.MetaGymHipError(
                 "quadrupedal-v0 needs the robot: pass urdf=<path to a1/a1.urdf> (the file ships with pybullet_data, not with the "
@@ -89,6 +117,26 @@ class A1GymEnv(object):
         # robots whose episode ended at the last step (auto_reset): one persistent buffer, so a captured step keeps reading it
         self.auto_reset = bool(auto_reset)
         self._pending = torch.zeros(self.num_envs, dtype=torch.bool, device=self.device)
+        # ---- RandomWrapper (MonitorEnv.py:521-662): pushes on the base, and what the observation reports about the dynamics ----
+        f64 = dict(dtype=torch.float64, device=self.device)
+        self._random_force = bool((random_param or {}).get("random_force"))
+        if (random_param or {}).get("random_dynamics"):
+            raise _lib.MetaGymHipError("random_param['random_dynamics'] (MonitorEnv.py:568-575: a control latency redrawn from numpy's "
+                                       "global stream at every reset) is not built; per-robot latencies go in as control_latency=[N] tensors")
+        if self._random_force and not hasattr(physics, "apply_external_force"):
+            raise _lib.MetaGymHipError("random_param['random_force'] needs physics.apply_external_force(force[N,3], position[N,3]) "
+                                       "(pybullet.applyExternalForce on the base, LINK_FRAME; A1Physics has it)")
+        self._force_pos, self._force_vec = torch.zeros(self.num_envs, 3, **f64), torch.zeros(self.num_envs, 3, **f64)
+        self._force_on = torch.zeros(self.num_envs, dtype=torch.bool, device=self.device)      # a push precedes the next env step
+        self._env_steps = torch.zeros(self.num_envs, dtype=torch.int64, device=self.device)    # LocomotionGymEnv._env_step_counter, per robot
+        self._force_gen = torch.Generator(device=self.device)
+        self._force_gen.manual_seed(int(seed) + 0x5eed)
+        self._force_source = force_source            # tests: a callable returning the (position, force) draws instead of the generator
+        self._force_scale = torch.tensor([0.2, 0.05, 0.05], **f64)
+        base_mass = getattr(physics, "base_mass", None)
+        lat = torch.as_tensor(control_latency, **f64).expand(self.num_envs) if not torch.is_tensor(control_latency) else control_latency.to(**f64)
+        self._dynamics = None if base_mass is None else torch.stack(                     # info["dynamics"] MonitorEnv.py:632: latency, foot friction, base mass
+            [lat, torch.full((self.num_envs,), footfriction, **f64), torch.full((self.num_envs,), float(base_mass), **f64)], dim=1)
         self._configure_observation(dict(sensor_mode), bool(ETG), int(ETG_H), int(normal))
 
     # FootPoseSensor's normalisation constants, robot_sensors.py:601-606
@@ -114,15 +162,16 @@ class A1GymEnv(object):
         self._sensor_width = 3 * sel[0] + (0, 6, 3)[sel[1]] + (0, 24, 12)[sel[2]] + (0, 4, 8)[sel[3]] + 12 * sel[4]
         f64 = dict(dtype=torch.float64, device=self.device)
         self._fp_mean, self._fp_std = torch.tensor(self.FOOTPOSE_MEAN, **f64), torch.tensor(self.FOOTPOSE_STD, **f64)
-        for key in ("force_vec", "dynamic_vec"):
-            if mode.get(key):
-                raise _lib.MetaGymHipError("sensor_mode[%r] reads the reference's PyBullet-side randomisation (RandomWrapper / "
-                                           "LocomotionGymEnv dynamics); append your physics' own vector to the observation" % key)
+        self._obs_force, self._obs_dyn = bool(mode.get("force_vec")), bool(mode.get("dynamic_vec"))
+        if self._obs_dyn and self._dynamics is None:
+            raise _lib.MetaGymHipError("sensor_mode['dynamic_vec'] reports [control latency, foot friction, base mass] (MonitorEnv.py:632): "
+                                       "the physics must expose `base_mass` (A1Physics does)")
         self._extras = ((_lib.A1_EXTRA_ETG if etg and mode.get("ETG") else 0) | (_lib.A1_EXTRA_ETG_OBS if etg and mode.get("ETG_obs") else 0)
                         | (_lib.A1_EXTRA_YAW if mode.get("yaw") else 0))
         self._etg_h, self._normal = etg_h, normal
         width = self._sensor_width + (12 if self._extras & _lib.A1_EXTRA_ETG else 0) \
-            + (etg_h if self._extras & _lib.A1_EXTRA_ETG_OBS else 0) + (2 if self._extras & _lib.A1_EXTRA_YAW else 0)
+            + (etg_h if self._extras & _lib.A1_EXTRA_ETG_OBS else 0) + (2 if self._extras & _lib.A1_EXTRA_YAW else 0) \
+            + (6 if self._obs_force else 0) + (3 if self._obs_dyn else 0)
         rnn = mode.get("RNN")
         self._rnn = None
         if rnn and rnn["time_steps"] > 0:                                              # MonitorEnv.py:126-134
@@ -134,8 +183,11 @@ class A1GymEnv(object):
     def _wrap_observation(self, obs, pose, etg_obs, d_yaw, on_reset):
         """ObservationWrapper.reset (MonitorEnv.py:136-179) / step (:181-221) on the sensor observation `[N, 37]`."""
         N, d = self.num_envs, self.device
+        extra_w = (12 if self._extras & _lib.A1_EXTRA_ETG else 0) + (self._etg_h if self._extras & _lib.A1_EXTRA_ETG_OBS else 0) \
+            + (2 if self._extras & _lib.A1_EXTRA_YAW else 0)
+        parts = [obs]
         if self._extras:
-            extra = torch.empty(N, self.observation_width - self._sensor_width, dtype=torch.float64, device=d)
+            extra = torch.empty(N, extra_w, dtype=torch.float64, device=d)
             p = pose.t().contiguous()
             eo = None if etg_obs is None else etg_obs.t().contiguous()
             dy = None if d_yaw is None else torch.as_tensor(d_yaw, dtype=torch.float64, device=d).expand(N).contiguous()
@@ -143,7 +195,17 @@ class A1GymEnv(object):
                 rc = self._lib.mg_a1_observation_extras(N, self._extras, self._normal, self._etg_h, _lib.ptr(self.path.last_ETG_act),
                                                         _lib.ptr(eo), _lib.ptr(p), _lib.ptr(dy), _lib.ptr(extra), _lib.current_stream(d))
             _lib.check(rc, "mg_a1_observation_extras")
-            obs = torch.cat([obs, extra], dim=1)
+            k = extra_w - (2 if self._extras & _lib.A1_EXTRA_YAW else 0)     # the yaw pair comes last, after force_vec / dynamic_vec
+            parts.append(extra[:, :k])
+        if self._obs_force:                                                    # MonitorEnv.py:150-152,194-196
+            on = self._force_on.reshape(-1, 1).to(torch.float64)
+            parts.append(torch.cat([self._force_pos / self._force_scale, self._force_vec / 50.0], dim=1) * on)
+        if self._obs_dyn:                                                      # :154-156,198-200
+            parts.append(self._dynamics)
+        if self._extras & _lib.A1_EXTRA_YAW:
+            parts.append(extra[:, extra_w - 2:])
+        if len(parts) > 1:
+            obs = torch.cat(parts, dim=1)
         if self._rnn is not None:
             steps, interval, mode = self._rnn
             if on_reset:
@@ -202,17 +264,66 @@ class A1GymEnv(object):
         _lib.check(rc, "mg_a1_info")
         return {k: (v if v.dim() == 1 else v.t()) for k, v in o.items()}
 
+    # ---- RandomWrapper's pushes (MonitorEnv.py:530-535, 634-640, 644-660) --------------------------------------------------
+    def _draw_force(self):
+        """generate_randomforce() for every robot: position (U - 0.5) * 2 * (0.2, 0.05, 0.05), direction U(-1, 1)^3 * (0.5, 1, 0.05)
+        normalised, magnitude U(20, 50). The reference draws from numpy's global stream; here a device generator seeded by the
+        env (`seed`) — same distribution, not the same numbers."""
+        if self._force_source is not None:
+            pos, vec = self._force_source()
+            f64 = dict(dtype=torch.float64, device=self.device)
+            return torch.as_tensor(pos, **f64).expand(self.num_envs, 3), torch.as_tensor(vec, **f64).expand(self.num_envs, 3)
+        u = torch.rand(self.num_envs, 7, generator=self._force_gen, dtype=torch.float64, device=self.device)
+        pos = (u[:, 0:3] - 0.5) * 2.0 * self._force_scale
+        v = (u[:, 3:6] * 2.0 - 1.0) * torch.tensor([0.5, 1.0, 0.05], dtype=torch.float64, device=self.device)
+        return pos, v / v.norm(dim=1, keepdim=True) * (20.0 + 30.0 * u[:, 6:7])
+
+    def _new_force(self, mask):
+        """RandomWrapper.reset for the robots in `mask` (None: all): counter to 0, a fresh force, applied before the next env step."""
+        pos, vec = self._draw_force()
+        if mask is None:
+            self._env_steps.zero_()
+            self._force_pos, self._force_vec = pos.clone(), vec.clone()
+            self._force_on.fill_(self._random_force)
+        else:
+            m = mask.reshape(-1, 1)
+            self._env_steps.mul_((~mask).to(torch.int64))
+            self._force_pos, self._force_vec = torch.where(m, pos, self._force_pos), torch.where(m, vec, self._force_vec)
+            self._force_on = torch.where(mask, torch.full_like(mask, self._random_force), self._force_on)
+
+    def _force_after_step(self):
+        """RandomWrapper.step after the inner env.step: the counter was incremented; a new force every 100 env steps, applied
+        (again) while counter % 100 < 50. Nothing here reads a device value on the host."""
+        self._env_steps += 1
+        if not self._random_force:
+            return
+        c = self._env_steps % 100
+        new, keep = c == 0, c < 50
+        pos, vec = self._draw_force()
+        self._force_pos = torch.where(new.reshape(-1, 1), pos, self._force_pos)
+        self._force_vec = torch.where(new.reshape(-1, 1), vec, self._force_vec)
+        self._force_on = new | keep
+
     def _env_step(self, action, reset_mask=None, d_yaw=None, filter_init_mask=None):
         """LocomotionGymEnv.step below the wrappers (locomotion_gym_env.py:461-546)."""
+        if self._random_force:      # applyExternalForce acts during the NEXT stepSimulation only: the first sub-step of this env step
+            on = self._force_on.reshape(-1, 1).to(torch.float64)
+            self.physics.apply_external_force(self._force_vec * on, self._force_pos * on)
         cmd, etg_obs = self.path.step(action, self._substeps_dev * self.robot.time_step)   # == get_time_since_reset()
         self._substeps_dev += 13.0
         if hasattr(self.physics, "fused_step") and self._fusable:      # 13 sub-steps + PD model inside one physics launch
             self.last_torques = self.robot.StepFused(cmd, self.physics.fused_step, filter_init_mask=filter_init_mask)
         else:
             self.last_torques = self.robot.Step(cmd, self.physics.substep, filter_init_mask=filter_init_mask)
+        self._force_after_step()
         world, info = self.physics.world(), self._info()
         info.update(base=world["base"], real_contact=world["contact"], bad=world["bad"], real_action=cmd, ETG_obs=etg_obs,
                     ETG_act=self.path.last_ETG_act.t())
+        if self._random_force:
+            info["force_vec"] = torch.cat([self._force_pos / self._force_scale, self._force_vec / 50.0], dim=1) \
+                * self._force_on.reshape(-1, 1).to(torch.float64)
+        if self._dynamics is not None:
+            info["dynamics"] = self._dynamics
         obs = self.sensors.observe(world["base"], info["pose"], info["drpy"], info["joint_angle"], world["contact"], reset_mask)
         obs = self._select_sensors(obs, info, world)
         return self._wrap_observation(obs, info["pose"], etg_obs, d_yaw, False), info
@@ -231,6 +342,7 @@ class A1GymEnv(object):
         obs0 = self.sensors.observe(world["base"], info["pose"], info["drpy"], info["joint_angle"], world["contact"], every)
         obs0 = self._select_sensors(obs0, info, world)
         etg_obs0 = self.path.reset(self.get_time_since_reset())
+        self._new_force(None)
         self._wrap_observation(obs0, info["pose"], etg_obs0, d_yaw, True)
         obs, _ = self._env_step(torch.zeros(N, 12, dtype=torch.float64, device=d))
         self.shaping.reset(world["base"], info["rot_mat"], info["footposition"])
@@ -278,6 +390,8 @@ class A1GymEnv(object):
         sd = dict(robot=self.robot.state_dict(), etg_last_act=self.path.last_ETG_act.clone(),
                   sensors={k: t.clone() for k, t in self.sensors._t.items()}, shaping=self.shaping.state_dict(),
                   substeps=self._substeps_dev.clone(), pending=self._pending.clone(),
+                  force=dict(pos=self._force_pos.clone(), vec=self._force_vec.clone(), on=self._force_on.clone(),
+                             env_steps=self._env_steps.clone(), rng=self._force_gen.get_state()),
                   last_torques=None if self.last_torques is None else self.last_torques.clone())
         if self.robot._action_filter is not None:
             sd["action_filter"] = dict(xhist=self.robot._action_filter.xhist.clone(), yhist=self.robot._action_filter.yhist.clone())
@@ -295,6 +409,11 @@ class A1GymEnv(object):
         self.shaping.load_state_dict(sd["shaping"])
         self._substeps_dev.copy_(sd["substeps"])
         self._pending.copy_(sd["pending"])
+        if "force" in sd:
+            f = sd["force"]
+            self._force_pos, self._force_vec, self._force_on = f["pos"].clone(), f["vec"].clone(), f["on"].clone()
+            self._env_steps.copy_(f["env_steps"])
+            self._force_gen.set_state(f["rng"])
         self.last_torques = None if sd.get("last_torques") is None else sd["last_torques"].clone()
         if self.robot._action_filter is not None and "action_filter" in sd:
             self.robot._action_filter.xhist.copy_(sd["action_filter"]["xhist"])
@@ -316,6 +435,7 @@ class A1GymEnv(object):
         obs0 = self.sensors.observe(world["base"], info["pose"], info["drpy"], info["joint_angle"], world["contact"], two)
         obs0 = self._select_sensors(obs0, info, world)
         etg_obs0 = self.path.reset(self._substeps_dev * self.robot.time_step, mask=m)
+        self._new_force(m)
         if self._rnn is not None:       # ObservationWrapper.reset for these robots: an empty frame history holding the reset observation
             rnn, self._rnn = self._rnn, None
             first = self._wrap_observation(obs0, info["pose"], etg_obs0, None, True)

@@ -61,7 +61,7 @@ def guess_foot_links(model_or_names):
 class A1Physics(object):
     def __init__(self, num_envs, urdf=None, device="cuda:0", model=None, foot_links=None, inertia="bullet_aabb", armature=0.0,
                  solver_iterations=23, fused=True, gravity=GRAVITY, ground_friction=GROUND_FRICTION, foot_friction=FOOT_FRICTION,
-                 body_damping=(0.0, 0.0), init_motor_angles=INIT_MOTOR_ANGLES, contact_erp=CONTACT_ERP):
+                 body_damping=(0.0, 0.0), init_motor_angles=INIT_MOTOR_ANGLES, contact_erp=CONTACT_ERP, base_mass_ratio=1.0):
         if (urdf is None) == (model is None):
             raise ValueError("A1Physics needs exactly one of urdf=<path or text> and model=<Model>")
         if model is None:
@@ -80,6 +80,21 @@ class A1Physics(object):
             m.sph_foot = np.array([next((f for f, fb in enumerate(m.foot_body) if int(fb) == int(b)), -1) for b in m.sph_body], np.int8)
         if foot_friction is not None:                            # SetFootFriction: the toe links' own coefficient
             m.sph_friction = np.where(np.asarray(m.sph_foot) >= 0, float(foot_friction), m.sph_friction)
+        self.foot_friction = foot_friction
+        if base_mass_ratio != 1.0:                               # SetBaseMasses([mass x ratio]) minitaur.py:999-1017: changeDynamics(mass=)
+            import copy                                          # scales the ROOT LINK's mass, inertia untouched (Bullet keeps the
+            m = copy.deepcopy(m)                                 # localInertiaDiagonal it had); the merged imu link keeps its own mass
+            root_mass = float(getattr(m, "root_link_mass", m.body_mass[0]))
+            add = root_mass * (float(base_mass_ratio) - 1.0)
+            c_root = np.asarray(getattr(m, "root_inertial_pos", m.body_com[0]), float)
+            new_mass = m.body_mass[0] + add
+            new_com = (m.body_mass[0] * m.body_com[0] + add * c_root) / new_mass
+            par = lambda mm, d: mm * (np.dot(d, d) * np.eye(3) - np.outer(d, d))
+            m.body_inertia[0] = m.body_inertia[0] + par(m.body_mass[0], m.body_com[0] - new_com) + par(add, c_root - new_com)
+            m.body_mass[0], m.body_com[0] = new_mass, new_com
+            self.base_mass = root_mass * float(base_mass_ratio)
+        else:
+            self.base_mass = float(getattr(m, "root_link_mass", m.body_mass[0]))
         self.model = m
         self.n, self.device = int(num_envs), torch.device(device)
         self.env = _A1Walker(num_envs=num_envs, device=device, frame_skip=1, time_step=0.002, max_steps=2 ** 30,
@@ -93,6 +108,8 @@ class A1Physics(object):
         frame = getattr(m, "root_inertial_pos", np.zeros(3))
         self._base_offset = torch.as_tensor(np.asarray(frame, np.float64), **f64).reshape(3, 1)
         self._default_pose = torch.tensor([0.0, 0.0, 0.28], **f64).reshape(3, 1)
+        self._ext = torch.zeros(6, self.n, **f64)                # pending push on the base (apply_external_force)
+        self.env.set_external_wrench(self._ext)
         if fused:                                  # A1GymEnv takes the one-launch path when the physics offers it
             self.fused_step = self._fused_step
             self.fused_modes = "all"               # POSITION (shared / per-robot gains), HYBRID, TORQUE
@@ -103,6 +120,14 @@ class A1Physics(object):
         engine with their own friction; the reset pose is [x, y, 0.28 + add_height] (locomotion_gym_env.py:337)."""
         self.env.set_terrain(boxes)
         self._default_pose = torch.tensor([float(v) for v in default_pose], dtype=torch.float64, device=self.device).reshape(3, 1)
+
+    def apply_external_force(self, force, position):
+        """pybullet.applyExternalForce(robot, -1, force, position, LINK_FRAME) for every robot (`[N, 3]` each, base link frame =
+        its inertial frame): acts during the next sub-step only, like Bullet's (cleared after one stepSimulation)."""
+        f = torch.as_tensor(force, dtype=torch.float64, device=self.device)
+        p = torch.as_tensor(position, dtype=torch.float64, device=self.device)
+        self._ext[0:3].copy_(f.t())
+        self._ext[3:6].copy_(p.t() + self._base_offset)
 
     def _base_quat_rate(self):
         e = self.env
@@ -135,6 +160,7 @@ class A1Physics(object):
         if not hasattr(self, "_log1"):
             self._log1 = torch.empty(1, 43, self.n, dtype=torch.float64, device=self.device)
         self.env.step_actuated(t, raw_torque=True, n_substeps=1, log=self._log1)
+        self._ext.zero_()                                                      # Bullet clears external forces after a stepSimulation
         g = self._log1[0]
         return SoA(g[0:12]), SoA(g[12:24]), SoA(g[36:40]), SoA(g[40:43])
 
@@ -144,6 +170,7 @@ class A1Physics(object):
         if not hasattr(self, "_log") or self._log.shape[0] != k:
             self._log = torch.empty(k, 43, self.n, dtype=torch.float64, device=self.device)
         self.env.step_actuated(command, n_substeps=k, log=self._log, **actuators.fused_spec())      # any of the three motor modes
+        self._ext.zero_()                                                      # (the kernel applied it in the first sub-step only)
         return self._log
 
     def state_dict(self):

@@ -305,5 +305,6 @@ def load_urdf(path_or_string, foot_links=(), inertia="bullet_aabb", armature=0.0
     m.rim_points = int(rim_points) if n_cyl else 0
     # PyBullet reports / resets the BASE at the root link's inertial frame origin (getBasePositionAndOrientation)
     m.root_inertial_pos = links[roots[0]]["pi"].copy()
+    m.root_link_mass = float(links[roots[0]]["mass"])           # getDynamicsInfo(robot, -1)[0]: the base LINK's own mass
     assert all(m.body_parent[i] < i for i in range(nb)) and np.all(np.diff(m.joint_body) >= 0)
     return m

@@ -406,7 +406,14 @@ class A1Env(object):
     ETG_STD = np.array([4.5967497e-02, 2.0340437e-01, 3.7410179e-01, 4.6187632e-02, 1.9441207e-01, 3.9488649e-01,
                         4.5966785e-02, 2.0323379e-01, 3.7382501e-01, 4.6188373e-02, 1.9457331e-01, 3.9302582e-01])
 
-    def __init__(self, w, b, etg=True, normal=0, control_latency=0.002, action_filter=None, segments=None, sensor_mode=None):
+    def __init__(self, w, b, etg=True, normal=0, control_latency=0.002, action_filter=None, segments=None, sensor_mode=None,
+                 force_draws=None, dynamics=None):
+        # RandomWrapper (MonitorEnv.py:521-662): `force_draws` = the (position, force) pairs its generate_randomforce() would draw
+        # (numpy's global stream in the reference; an input here) — None: random_force off. `dynamics` = info["dynamics"] of
+        # LocomotionGymEnv.reset (latency s, foot friction, base mass; locomotion_gym_env.py:452-454, MonitorEnv.py:632)
+        self.force_draws = None if force_draws is None else iter(force_draws)
+        self.dynamics = None if dynamics is None else np.asarray(dynamics, float)
+        self.pushes, self.force_info, self.env_steps = [], np.zeros(6), 0
         self.filter = action_filter                                                # Minitaur._BuildActionFilter minitaur.py:1438-1443
         self.path = EtgActionPath(w, b, enabled=etg)
         self.act = A1Actuation(1, control_latency=control_latency)                # POSITION, kp/kd of a1.py:63-68
@@ -460,6 +467,10 @@ class A1Env(object):
             obs = np.concatenate((obs, out), axis=0)
         if self.etg and self.mode.get("ETG_obs"):
             obs = np.concatenate((obs, etg_obs), axis=0)
+        if self.mode.get("force_vec"):                                              # :150-152 / :194-196
+            obs = np.concatenate((obs, self.force_info), axis=0)
+        if self.mode.get("dynamic_vec"):                                            # :154-156 / :198-200
+            obs = np.concatenate((obs, self.dynamics), axis=0)
         if self.mode.get("yaw"):
             obs = np.concatenate((obs, np.array([np.cos(d_yaw - yaw), np.sin(d_yaw - yaw)])), axis=0)
         if self.rnn:
@@ -475,6 +486,24 @@ class A1Env(object):
 
     def time_since_reset(self):
         return self.substeps * 0.002                                               # GetTimeSinceReset minitaur.py:228-230
+
+    def _push(self, new):
+        """RandomWrapper: applyExternalForce(base, force, position, LINK_FRAME) — it acts during the NEXT stepSimulation only."""
+        if new:
+            self.force_pos, self.force_vec = [np.asarray(x, float) for x in next(self.force_draws)]
+        self.pushes.append((self.total_substeps, self.force_vec.copy(), self.force_pos.copy()))
+        self.force_info = np.concatenate((self.force_pos / np.array([0.2, 0.05, 0.05]), self.force_vec / 50))
+
+    def _random_force_after_step(self):
+        """RandomWrapper.step :644-660, after the inner env.step (env_step_counter already incremented)."""
+        self.force_info = np.zeros(6)
+        if self.force_draws is None:
+            return
+        c = self.env_steps
+        if c % 100 == 0:
+            self._push(True)
+        elif c % 100 < 50:
+            self._push(False)
 
     def robot_step(self, command, true_obs):
         """Minitaur.Step with the world's 13 recorded sub-step states; returns the 13 x 12 torques."""
@@ -502,6 +531,8 @@ class A1Env(object):
         ETGWrapper.reset, then RewardShaping.reset's hidden zero-action step (MonitorEnv.py:305-318).
         Returns (the hidden step's command, torques, the observation reset() returns)."""
         self.act.reset(); self.substeps = 0
+        self.env_steps = 0                                                         # LocomotionGymEnv._env_step_counter :414
+        self.total_substeps = getattr(self, "total_substeps", 0)
         if self.filter is not None:
             self.filter.reset()                                                    # _ResetActionFilter (Minitaur.Reset :443-444)
         t = reset_true_obs
@@ -510,6 +541,9 @@ class A1Env(object):
         obs0 = self.sensors.observe(reset_world["base"], reset_world["pose"], inf["drpy"], inf["joint_angle"], reset_world["contact"], True)
         obs0 = self.select_sensors(obs0, inf, reset_world)
         etg_obs0 = self.path.reset(self.time_since_reset())
+        self.force_info = np.zeros(6)
+        if self.force_draws is not None:                                           # RandomWrapper.reset :634-640: a fresh force, applied
+            self._push(True)
         self.wrap_observation(obs0, reset_world["pose"][-1], etg_obs0, d_yaw, True)
         cmd, torques, obs, _ = self._step(np.zeros(12), hidden_true_obs, hidden_world, shaped=False)
         self.shaping.reset(reset_world["base"], reset_world["rot_mat"], inf["footposition"])
@@ -518,6 +552,9 @@ class A1Env(object):
     def _step(self, action, true_obs, world, shaped=True, d_yaw=0):
         cmd, etg_obs = self.path.step(action, self.time_since_reset())
         torques = self.robot_step(cmd, true_obs)
+        self.env_steps += 1
+        self.total_substeps += 13
+        self._random_force_after_step()
         inf = self.info(world)
         obs = self.sensors.observe(world["base"], world["pose"], inf["drpy"], inf["joint_angle"], world["contact"], False)
         obs = self.select_sensors(obs, inf, world)

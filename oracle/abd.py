@@ -348,13 +348,18 @@ def foot_forces(m, rows, lam, dt):
     return np.linalg.norm(f, axis=1) / dt
 
 
-def substep(m, s, tau_motor, prm, out=None):
+def substep(m, s, tau_motor, prm, out=None, ext=None):
     """One 5 ms sub-step. Returns the set of sphere indices in contact. `out` (a dict) receives the constraint rows and their
-    multipliers."""
+    multipliers. `ext` = (force[3], point[3]) in the base body frame: an external push on the base during this sub-step
+    (pybullet.applyExternalForce(..., LINK_FRAME); mg_walker_params.ext_wrench)."""
     M, h, kin, _ = mass_matrix_and_bias(m, s, gravity=prm.gravity, body_damping=prm.body_damping)
     n = M.shape[0]
     tau = np.zeros(n)
     tau[6:] = tau_motor - m.joint_damping * s.qd - m.joint_stiffness * s.q
+    if ext is not None:
+        F, r = s.rot @ np.asarray(ext[0], float), s.rot @ np.asarray(ext[1], float)
+        tau[0:3] += F
+        tau[3:6] += np.cross(r, F)
     u = s.u()
     L = np.linalg.cholesky(M)
     solve = lambda rhs: np.linalg.solve(L.T, np.linalg.solve(L, rhs))

@@ -71,7 +71,14 @@ class ScriptedWorld(ga.ScriptedBullet):
                 2 * (y * z - w * x), 2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y))
     def getContactPoints(self, bodyA=None):
         return list(self.contacts)
+    def applyExternalForce(self, objectUniqueId=None, linkIndex=None, forceObj=None, posObj=None, flags=None):
+        # RandomWrapper's pushes (MonitorEnv.py:530-535,644-660): recorded with the number of stepSimulation calls so far, so the
+        # checkers know which sub-step each one precedes; the scripted world itself does not react to them
+        self.records["push"].append(np.concatenate(([self.n_sim_steps, linkIndex, flags], np.asarray(forceObj, float), np.asarray(posObj, float))))
+    n_sim_steps = 0
+
     def stepSimulation(self):
+        self.n_sim_steps += 1
         super(ScriptedWorld, self).stepSimulation()
         self.base_pos = list(np.asarray(self.base_pos) + self.dt * (self.v_base + 0.2 * np.sin(3 * self.t + np.arange(3))))
     def new_contacts(self):
@@ -111,7 +118,12 @@ def main():
              dict(name="env_sensors_alt", seed=9, ETG=1, wscale=0.04, n_steps=14, normal=1,
                   sensor_mode={"dis": 0, "motor": 2, "imu": 2, "contact": 2, "footpose": 1}),
              dict(name="env_sensors_min", seed=10, ETG=0, wscale=0.0, n_steps=12, normal=0,
-                  sensor_mode={"dis": 1, "motor": 0, "imu": 0, "contact": 0, "footpose": 1, "ETG_obs": 1})]
+                  sensor_mode={"dis": 1, "motor": 0, "imu": 0, "contact": 0, "footpose": 1, "ETG_obs": 1}),
+             # RandomWrapper's pushes (a new force every 100 env steps, applied for 50) and explicit dynamics (`dynamic_param`:
+             # control latency in ms, foot friction, base-mass ratio), with the observation entries that report them
+             dict(name="env_random_force", seed=11, ETG=1, wscale=0.03, n_steps=108, normal=0, random_param={"random_dynamics": 0, "random_force": 1},
+                  dynamic_param={"control_latency": 17.0, "footfriction": 1.7, "basemass": 1.1},
+                  sensor_mode={"ETG": 1, "force_vec": 1, "dynamic_vec": 1, "yaw": 1}, d_yaw=0.1)]
     from metagym.quadrupedal.envs.utilities import terrain
     from gen_golden_a1_terrain import Recorder
     for c in cases:
@@ -175,8 +187,10 @@ def main():
             return r
         locomotion_gym_env.LocomotionGymEnv.reset, locomotion_gym_env.LocomotionGymEnv.step = lreset, lstep
         try:
+            np.random.seed(1000 + c["seed"])      # RandomWrapper draws its pushes from numpy's global stream; they are recorded as inputs
             env = a1_gym_env.A1GymEnv(ETG=c["ETG"], ETG_path=path, normal=c["normal"], dynamic_param=c.get("dynamic_param", {}),
                                       filter_=c.get("filter_", 0), task=c.get("task", "plane"),
+                                      **({"random_param": c["random_param"]} if "random_param" in c else {}),
                                       sensor_mode=dict({"dis": 1, "motor": 1, "imu": 1, "contact": 1, "footpose": 0, "ETG": 0},
                                                        **c.get("sensor_mode", {})))
             n_before_reset = len(rec["all_true_obs"])
@@ -184,6 +198,9 @@ def main():
             step_kw = {"d_yaw": c["d_yaw"]} if "d_yaw" in c else {}
             obs, info = env.reset(**step_kw)
             rec["reset_pose_z"].append(world.base_pos_at_reset[2])
+            rec["reset_force_vec"].append(np.array(info.get("force_vec", np.zeros(6)), dtype=np.float64))
+            rec["reset_dynamics"].append(np.array(info.get("dynamics", np.zeros(3)), dtype=np.float64))
+            rec["n_sim_steps_after_reset"].append(world.n_sim_steps)
             rec["reset_obs"].append(np.array(obs, dtype=np.float64))
             rec["n_true_obs_before_reset"].append(n_before_reset)
             rec["n_true_obs_after_reset"].append(len(rec["all_true_obs"]))
@@ -200,15 +217,18 @@ def main():
                 for key in ("base", "pose", "rot_mat", "footposition", "real_contact", "energy", "drpy", "joint_angle"):
                     rec["info_" + key].append(np.array(info[key], dtype=np.float64))
                 rec["bad"].append(env.robot.GetBadFootContacts())
+                rec["force_vec"].append(np.array(info.get("force_vec", np.zeros(6)), dtype=np.float64))
         finally:
             locomotion_gym_env.LocomotionGymEnv.reset, locomotion_gym_env.LocomotionGymEnv.step = orig_lreset, orig_lstep
             minitaur.Minitaur.Step, minitaur.Minitaur.ApplyAction, minitaur.Minitaur.ReceiveObservation = orig_step, orig_apply, orig_recv
+        if world.records["push"]:
+            rec["push"] = world.records["push"]
         rec["reset_true_obs"] = [rec["all_true_obs"][rec["n_true_obs_before_reset"][0]]]      # robot.Reset's one observation
         del rec["all_true_obs"]                                                               # (500 settle sub-steps of __init__)
         for k2, v in rec.items():
             out[c["name"] + "/" + k2] = np.array(v)
         out[c["name"] + "/w"], out[c["name"] + "/b"] = w, b
-        out[c["name"] + "/spec"] = np.array(json.dumps({k: c[k] for k in ("task", "sensor_mode", "d_yaw") if k in c}))
+        out[c["name"] + "/spec"] = np.array(json.dumps({k: c[k] for k in ("task", "sensor_mode", "d_yaw", "random_param", "dynamic_param") if k in c}))
         out[c["name"] + "/config"] = np.array([c["ETG"], c["normal"], c.get("dynamic_param", {}).get("control_latency", -1.0),
                                                c.get("filter_", 0)], dtype=np.float64)
         print(c["name"], "steps", len(rec["obs"]), "obs dim", np.array(rec["obs"]).shape, "dones", int(np.sum(rec["done"])),

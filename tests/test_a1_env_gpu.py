@@ -37,6 +37,7 @@ class ReplayPhysics(object):
         return self._obs(self.g[self.name + "/reset_true_obs"][0])
 
     def substep(self, torques):
+        self.n_sub = getattr(self, "n_sub", 0) + 1
         self.torques.append(torques.cpu().numpy().copy())
         t = self.g[self.name + "/true_obs"][self.step_idx][self.sub_idx]
         self.sub_idx += 1
@@ -53,7 +54,7 @@ class ReplayPhysics(object):
                     foot_force=self._t(g[name + "/loco_contact_force"][k][4:8] * 100.0))
 
 
-@pytest.mark.parametrize("idx", range(10))
+@pytest.mark.parametrize("idx", range(11))
 def test_a1_gym_env_matches_the_unmodified_reference_env(idx):
     g = np.load(GOLDEN)
     name, n = str(g["cases"][idx]), 3
@@ -64,6 +65,24 @@ def test_a1_gym_env_matches_the_unmodified_reference_env(idx):
     if "sensor_mode" in spec:
         kw["sensor_mode"] = dict({"dis": 1, "motor": 1, "imu": 1, "contact": 1, "footpose": 0, "ETG": 0}, **spec["sensor_mode"])
     phys = ReplayPhysics(g, name, n)
+    if spec.get("random_param", {}).get("random_force"):
+        # RandomWrapper's pushes: the forces the reference drew from numpy's global stream are inputs (`force_source`), the
+        # replayed world records every apply_external_force with the number of sub-steps run so far
+        push = g[name + "/push"]
+        draws = [(push[i, 6:9], push[i, 3:6]) for i in range(len(push)) if i == 0 or not np.array_equal(push[i, 3:9], push[i - 1, 3:9])]
+        calls = {"n": 0}
+
+        def source():
+            calls["n"] += 1
+            return draws[min(calls["n"] - 1, len(draws) - 1)]       # the first call is reset()'s draw, every later one the redraw at c % 100 == 0
+        kw.update(random_param=spec["random_param"], force_source=source)
+        phys.pushes, phys.n_sub = [], 0
+        phys.apply_external_force = lambda f, p: phys.pushes.append((phys.n_sub, f.cpu().numpy().copy(), p.cpu().numpy().copy()))
+    if "dynamic_param" in spec:
+        kw["dynamic_param"] = spec["dynamic_param"]
+        phys.base_mass = float(g[name + "/reset_dynamics"][0][2])
+        phys.set_dynamics = lambda d: None
+        lat_ms = -1.0                                               # (the latency comes in through dynamic_param)
     env = metagym_amd.make("quadrupedal-v0", num_envs=n, physics=phys, device=DEV, ETG=int(etg), ETG_w=g[name + "/w"], ETG_b=g[name + "/b"],
                            normal=int(normal), control_latency=0.002 if lat_ms < 0 else 0.001 * lat_ms, filter_=int(filt), **kw)
     assert isinstance(env, A1GymEnv)
@@ -87,6 +106,17 @@ def test_a1_gym_env_matches_the_unmodified_reference_env(idx):
         assert np.allclose(terms, g[name + "/terms"][k], **TOL), "%s reward terms, step %d" % (name, k)
         assert np.allclose(reward.cpu().numpy(), g[name + "/reward"][k], **TOL)
         assert bool(done.cpu().numpy()[0]) == bool(g[name + "/done"][k])
+        if "force_vec" in info and name + "/force_vec" in g.files:
+            assert np.allclose(info["force_vec"].cpu().numpy()[0], g[name + "/force_vec"][k], **TOL)
+    if name + "/push" in g.files and hasattr(phys, "pushes"):
+        # the reference calls applyExternalForce only while a push is on; here every env step hands the physics a (possibly zero)
+        # force: the non-zero ones must be the reference's calls — same sub-step count, force and position
+        ref = g[name + "/push"]
+        mine = [(n_sub, f[0], p_[0]) for n_sub, f, p_ in phys.pushes if np.abs(f).max() > 0]
+        assert len(mine) == len(ref)
+        base = int(ref[0, 0])
+        for (n_sub, f, p_), row in zip(mine, ref):
+            assert n_sub + base == int(row[0]) and np.allclose(f, row[3:6], **TOL) and np.allclose(p_, row[6:9], **TOL)
 
 
 def test_unsupported_sensor_modes_are_refused_loudly():

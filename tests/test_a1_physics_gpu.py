@@ -282,3 +282,76 @@ def test_fused_actuation_modes_equal_the_substep_path_bit_for_bit(mode):
         for key in ("pos", "rot", "vel", "omega", "q", "qd"):
             assert torch.equal(getattr(pf.env, key), getattr(pu.env, key)), (mode, k, key)
     assert torch.isfinite(tf).all() and float(tf.abs().max()) > 1.0
+
+
+def test_external_push_on_the_engine_matches_the_oracle_and_newton():
+    """mg_walker_params.ext_wrench (RandomWrapper's applyExternalForce on the base, LINK_FRAME): acts in the first sub-step of a
+    launch only. One sub-step against the oracle (1e-9), and in free flight the robot's momentum changes by R f dt, once."""
+    n = 16
+    phys = A1Physics(n, urdf=a1_like_urdf(), device=DEV, foot_links=A1_LIKE_TOES, gravity=0.0)
+    m = phys.model
+    phys.reset(None)
+    e = phys.env
+    e.pos[2] += 5.0                                              # free flight
+    rs = np.random.RandomState(3)
+    e.vel.copy_(torch.as_tensor(rs.uniform(-0.5, 0.5, (3, n))))
+    e.omega.copy_(torch.as_tensor(rs.uniform(-1, 1, (3, n))))
+    e.qd.copy_(torch.as_tensor(rs.uniform(-1, 1, (12, n))))
+    force, pos = rs.uniform(-40, 40, (n, 3)), rs.uniform(-0.2, 0.2, (n, 3))
+    keys = ("pos", "rot", "vel", "omega", "q", "qd")
+    st = {k: getattr(e, k).cpu().numpy() for k in keys}
+    prm = abd.Params(dt=0.002, substeps=1, iterations=23, erp=0.2, friction=5.0, sphere_friction=m.sph_friction, self_collision=False, gravity=0.0)
+    phys.apply_external_force(torch.as_tensor(force), torch.as_tensor(pos))
+    tau = np.zeros((12, n))
+    log = torch.empty(3, 43, n, dtype=torch.float64, device=DEV)
+    e.step_actuated(torch.as_tensor(tau, device=DEV), raw_torque=True, n_substeps=3, log=log)        # 3 sub-steps, pushed in the first
+    worst = 0.0
+    for k in range(n):
+        s = abd.State(m)
+        s.pos, s.rot, s.v, s.w = st["pos"][:, k].copy(), st["rot"][:, k].reshape(3, 3).copy(), st["vel"][:, k].copy(), st["omega"][:, k].copy()
+        s.q, s.qd = st["q"][:, k].copy(), st["qd"][:, k].copy()
+        P0, _ = abd.momentum(m, s)
+        R0 = s.rot.copy()
+        abd.substep(m, s, tau[:, k], prm, ext=(force[k], pos[k] + m.root_inertial_pos))
+        P1, _ = abd.momentum(m, s)
+        assert np.allclose(P1 - P0, R0 @ force[k] * 0.002, rtol=1e-6, atol=1e-9)        # impulse = F dt
+        abd.substep(m, s, tau[:, k], prm)
+        abd.substep(m, s, tau[:, k], prm)
+        P3, _ = abd.momentum(m, s)
+        assert np.allclose(P3, P1, rtol=1e-6, atol=1e-8)                                 # ... and only once
+        d = max(np.abs(e.q.cpu().numpy()[:, k] - s.q).max(), np.abs(e.pos.cpu().numpy()[:, k] - s.pos).max(),
+                np.abs(e.vel.cpu().numpy()[:, k] - s.v).max(), np.abs(e.omega.cpu().numpy()[:, k] - s.w).max())
+        worst = max(worst, d)
+    assert worst < 1e-9, worst
+    assert float(phys._ext.abs().max()) > 0                     # (step_actuated alone does not clear it; A1Physics.substep / fused_step do)
+
+
+def test_random_force_and_dynamic_param_closed_loop_on_the_engine():
+    """RandomWrapper's pushes (`random_param`) and explicit dynamics (`dynamic_param`) on the URDF robot: 20-50 N pushes every env
+    step for 50 of every 100, observation entries force_vec / dynamic_vec; the robots keep standing, the pushed ones drift."""
+    n = 256
+    mode = dict(dis=1, motor=1, imu=1, contact=1, footpose=0, force_vec=1, dynamic_vec=1)
+    env = metagym_amd.make("quadrupedal-v0", num_envs=n, urdf=a1_like_urdf(), device=DEV, sensor_mode=mode, seed=3,
+                           random_param={"random_force": 1}, dynamic_param={"control_latency": 17.0, "footfriction": 1.7, "basemass": 1.1})
+    quiet = metagym_amd.make("quadrupedal-v0", num_envs=n, urdf=a1_like_urdf(), device=DEV)
+    assert abs(env.physics.base_mass - 1.1 * 4.7) < 1e-12 and env.robot._cfg.control_latency == pytest.approx(0.017)
+    obs, info = env.reset()
+    quiet.reset()
+    assert obs.shape == (n, 37 + 6 + 3)
+    assert torch.allclose(obs[:, 43:46], torch.tensor([0.017, 1.7, 1.1 * 4.7], dtype=torch.float64, device=DEV).expand(n, 3))
+    a = torch.zeros(n, 12, dtype=torch.float64, device=DEV)
+    on_steps = 0
+    for k in range(60):
+        obs, reward, done, info = env.step(a)
+        quiet.step(a)
+        fv = obs[:, 37:43]
+        assert torch.equal(fv, info["force_vec"])
+        on = bool((fv.abs().sum(dim=1) > 0).all())
+        assert on == (k + 2 < 50)                               # counter = k + 2 after this step (the hidden step counted once)
+        on_steps += on
+        if on:
+            mag = (fv[:, 3:6] * 50.0).norm(dim=1)
+            assert float(mag.min()) >= 20.0 - 1e-9 and float(mag.max()) <= 50.0 + 1e-9
+    assert on_steps == 48 and torch.isfinite(obs).all()
+    drift = (env.physics.world()["base"][:, :2] - quiet.physics.world()["base"][:, :2]).norm(dim=1)
+    assert float(drift.mean()) > 1e-3 and float(done.double().mean()) < 0.2

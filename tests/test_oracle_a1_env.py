@@ -32,12 +32,19 @@ def make_env(g, name):
         add_height, env_info, _ = task_terrain(spec["task"])
         assert 0.28 + add_height == g[name + "/reset_pose_z"][0]                 # locomotion_gym_env.py:337
         segments = [(r[0], r[1], r[2][0], r[2][1], r[2][4]) for r in env_info]
+    kw = {}
+    if spec.get("random_param", {}).get("random_force"):      # the pushes RandomWrapper drew from numpy's global stream: inputs
+        push = g[name + "/push"]
+        kw["force_draws"] = [(push[i, 6:9], push[i, 3:6]) for i in range(len(push)) if i == 0 or not np.array_equal(push[i, 3:9], push[i - 1, 3:9])]
+    if "dynamic_param" in spec:
+        kw["dynamics"] = g[name + "/reset_dynamics"][0]
+        lat_ms = spec["dynamic_param"].get("control_latency", lat_ms)               # locomotion_gym_env.py:354-355
     env = oa.A1Env(g[name + "/w"], g[name + "/b"], bool(etg), int(normal), 0.002 if lat_ms < 0 else 0.001 * lat_ms, flt,
-                   segments=segments, sensor_mode=spec.get("sensor_mode"))
+                   segments=segments, sensor_mode=spec.get("sensor_mode"), **kw)
     return env, spec.get("d_yaw", 0)
 
 
-@pytest.mark.parametrize("idx", range(10))
+@pytest.mark.parametrize("idx", range(11))
 def test_composed_env_matches_reference(idx):
     g = np.load(GOLDEN)
     name = str(g["cases"][idx])
@@ -60,3 +67,9 @@ def test_composed_env_matches_reference(idx):
         assert np.allclose(terms, g[name + "/terms"][k], rtol=1e-13, atol=1e-15), "%s reward terms, step %d" % (name, k)
         assert reward == pytest.approx(g[name + "/reward"][k], rel=1e-13, abs=1e-15)
         assert done == bool(g[name + "/done"][k])
+    if name + "/push" in g.files:       # every applyExternalForce call: which stepSimulation it precedes, force, position (LINK_FRAME, base)
+        push = g[name + "/push"]
+        assert len(env.pushes) == len(push)
+        base = int(push[0, 0])                                    # sub-steps the reference's constructor had already run (500 settle steps)
+        for (n_sub, f, p_), row in zip(env.pushes, push):
+            assert n_sub + base == int(row[0]) and np.array_equal(f, row[3:6]) and np.array_equal(p_, row[6:9]) and row[1] == -1 and row[2] == 1
