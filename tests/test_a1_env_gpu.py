@@ -122,8 +122,17 @@ def test_a1_gym_env_matches_the_unmodified_reference_env(idx):
 
 
 def test_unsupported_sensor_modes_are_refused_loudly():
-    """What is still refused by name: the PyBullet-side randomisation vectors, sensor noise, values outside env_builder.py:62-80."""
-    for mode in ({"dis": 1, "motor": 1, "imu": 1, "contact": 1, "footpose": 0, "force_vec": 1},
+    """What is still refused by name: dynamic_vec without a physics that knows its base mass, sensor noise, values outside
+    env_builder.py:62-80; and pushes / simulator-side dynamics on a physics that cannot take them."""
+    with pytest.raises(Exception, match="random_force"):
+        metagym_amd.make("quadrupedal-v0", num_envs=2, device=DEV, physics=object(), random_param={"random_force": 1})
+    with pytest.raises(Exception, match="set_dynamics"):
+        metagym_amd.make("quadrupedal-v0", num_envs=2, device=DEV, physics=object(), dynamic_param={"footfriction": 2.0})
+    with pytest.raises(Exception, match="random_dynamic"):
+        metagym_amd.make("quadrupedal-v0", num_envs=2, device=DEV, physics=object(), random_dynamic=True)
+    with pytest.raises(Exception, match="leginertia"):
+        metagym_amd.make("quadrupedal-v0", num_envs=2, device=DEV, physics=object(), dynamic_param={"leginertia": [1.0] * 12})
+    for mode in ({"dis": 1, "motor": 1, "imu": 1, "contact": 1, "footpose": 0, "dynamic_vec": 1},
                  {"dis": 1, "motor": 1, "imu": 1, "contact": 1, "footpose": 0, "noise": 1},
                  {"dis": 1, "motor": 3, "imu": 1, "contact": 1, "footpose": 0}):
         with pytest.raises(Exception, match="sensor_mode"):
