@@ -280,16 +280,20 @@ class A1GymEnv(object):
 
     def _new_force(self, mask):
         """RandomWrapper.reset for the robots in `mask` (None: all): counter to 0, a fresh force, applied before the next env step."""
-        pos, vec = self._draw_force()
         if mask is None:
             self._env_steps.zero_()
+        else:
+            self._env_steps.mul_((~mask).to(torch.int64))
+        if not self._random_force:
+            return
+        pos, vec = self._draw_force()
+        if mask is None:
             self._force_pos, self._force_vec = pos.clone(), vec.clone()
-            self._force_on.fill_(self._random_force)
+            self._force_on.fill_(True)
         else:
             m = mask.reshape(-1, 1)
-            self._env_steps.mul_((~mask).to(torch.int64))
             self._force_pos, self._force_vec = torch.where(m, pos, self._force_pos), torch.where(m, vec, self._force_vec)
-            self._force_on = torch.where(mask, torch.full_like(mask, self._random_force), self._force_on)
+            self._force_on = self._force_on | mask
 
     def _force_after_step(self):
         """RandomWrapper.step after the inner env.step: the counter was incremented; a new force every 100 env steps, applied
@@ -365,6 +369,8 @@ class A1GymEnv(object):
                 self.step(static_action)
         torch.cuda.current_stream(d).wait_stream(side)
         graph = torch.cuda.CUDAGraph()
+        if self._random_force and self._force_source is None:      # the pushes' generator advances inside the captured step
+            graph.register_generator_state(self._force_gen)
         robot, repeat = self.robot, 13
         host_mirror = (robot._step_counter, robot._last_action)
         with torch.cuda.graph(graph):
