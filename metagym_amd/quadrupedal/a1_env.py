@@ -133,6 +133,7 @@ class A1GymEnv(object):
         self._force_gen.manual_seed(int(seed) + 0x5eed)
         self._force_source = force_source            # tests: a callable returning the (position, force) draws instead of the generator
         self._force_scale = torch.tensor([0.2, 0.05, 0.05], **f64)
+        self._force_dir_scale = torch.tensor([0.5, 1.0, 0.05], **f64)
         base_mass = getattr(physics, "base_mass", None)
         lat = torch.as_tensor(control_latency, **f64).expand(self.num_envs) if not torch.is_tensor(control_latency) else control_latency.to(**f64)
         self._dynamics = None if base_mass is None else torch.stack(                     # info["dynamics"] MonitorEnv.py:632: latency, foot friction, base mass
@@ -275,7 +276,7 @@ class A1GymEnv(object):
             return torch.as_tensor(pos, **f64).expand(self.num_envs, 3), torch.as_tensor(vec, **f64).expand(self.num_envs, 3)
         u = torch.rand(self.num_envs, 7, generator=self._force_gen, dtype=torch.float64, device=self.device)
         pos = (u[:, 0:3] - 0.5) * 2.0 * self._force_scale
-        v = (u[:, 3:6] * 2.0 - 1.0) * torch.tensor([0.5, 1.0, 0.05], dtype=torch.float64, device=self.device)
+        v = (u[:, 3:6] * 2.0 - 1.0) * self._force_dir_scale
         return pos, v / v.norm(dim=1, keepdim=True) * (20.0 + 30.0 * u[:, 6:7])
 
     def _new_force(self, mask):
@@ -287,13 +288,16 @@ class A1GymEnv(object):
         if not self._random_force:
             return
         pos, vec = self._draw_force()
+        # (persistent buffers are updated IN PLACE: a captured step must find its state where it left it)
         if mask is None:
-            self._force_pos, self._force_vec = pos.clone(), vec.clone()
+            self._force_pos.copy_(pos)
+            self._force_vec.copy_(vec)
             self._force_on.fill_(True)
         else:
             m = mask.reshape(-1, 1)
-            self._force_pos, self._force_vec = torch.where(m, pos, self._force_pos), torch.where(m, vec, self._force_vec)
-            self._force_on = self._force_on | mask
+            self._force_pos.copy_(torch.where(m, pos, self._force_pos))
+            self._force_vec.copy_(torch.where(m, vec, self._force_vec))
+            self._force_on.logical_or_(mask)
 
     def _force_after_step(self):
         """RandomWrapper.step after the inner env.step: the counter was incremented; a new force every 100 env steps, applied
@@ -304,9 +308,9 @@ class A1GymEnv(object):
         c = self._env_steps % 100
         new, keep = c == 0, c < 50
         pos, vec = self._draw_force()
-        self._force_pos = torch.where(new.reshape(-1, 1), pos, self._force_pos)
-        self._force_vec = torch.where(new.reshape(-1, 1), vec, self._force_vec)
-        self._force_on = new | keep
+        self._force_pos.copy_(torch.where(new.reshape(-1, 1), pos, self._force_pos))
+        self._force_vec.copy_(torch.where(new.reshape(-1, 1), vec, self._force_vec))
+        self._force_on.copy_(new | keep)
 
     def _env_step(self, action, reset_mask=None, d_yaw=None, filter_init_mask=None):
         """LocomotionGymEnv.step below the wrappers (locomotion_gym_env.py:461-546)."""
@@ -417,7 +421,9 @@ class A1GymEnv(object):
         self._pending.copy_(sd["pending"])
         if "force" in sd:
             f = sd["force"]
-            self._force_pos, self._force_vec, self._force_on = f["pos"].clone(), f["vec"].clone(), f["on"].clone()
+            self._force_pos.copy_(f["pos"])
+            self._force_vec.copy_(f["vec"])
+            self._force_on.copy_(f["on"])
             self._env_steps.copy_(f["env_steps"])
             self._force_gen.set_state(f["rng"])
         self.last_torques = None if sd.get("last_torques") is None else sd["last_torques"].clone()

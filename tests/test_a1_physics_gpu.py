@@ -356,3 +356,26 @@ def test_random_force_and_dynamic_param_closed_loop_on_the_engine():
     assert on_steps == 48 and torch.isfinite(obs).all()
     drift = (env.physics.world()["base"][:, :2] - quiet.physics.world()["base"][:, :2]).norm(dim=1)
     assert float(drift.mean()) > 1e-4 and float(done.double().mean()) < 0.2      # (a 35 N push for 2 ms is a 0.07 N s nudge per env step)
+
+
+def test_captured_step_with_pushes_keeps_drawing_forces():
+    """capture_step() with random_force on: the pushes' device generator is registered with the hipGraph, so replays keep
+    advancing it — a new force appears every 100 env steps, and the step stays finite."""
+    n = 64
+    mode = dict(dis=1, motor=1, imu=1, contact=1, footpose=0, force_vec=1)
+    env = metagym_amd.make("quadrupedal-v0", num_envs=n, urdf=a1_like_urdf(), device=DEV, sensor_mode=mode, seed=1,
+                           random_param={"random_force": 1})
+    env.reset()
+    replay = env.capture_step()
+    env.reset()
+    a = torch.zeros(n, 12, dtype=torch.float64, device=DEV)
+    forces = []
+    for k in range(205):
+        obs, reward, done, info = replay(a)
+        forces.append(obs[:, 37:43].clone())
+    assert torch.isfinite(obs).all()
+    on = torch.stack([(f.abs().sum(dim=1) > 0).all() for f in forces]).cpu().numpy()
+    c = np.arange(205) + 2                                              # counter after replay k (reset's hidden step counted once)
+    assert np.array_equal(on, (c % 100) < 50)
+    first, second, third = forces[0], forces[100], forces[199]          # counters 2, 102, 201: three different draws
+    assert not torch.equal(first, second) and not torch.equal(second, third)
