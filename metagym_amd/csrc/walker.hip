@@ -1758,7 +1758,7 @@ extern "C" int mg_walker_step(const mg_walker_topology *tp, const mg_walker_mode
     if (lds > 64 * 1024) return mg::set_error(MG_ERR_BAD_SIZE, "walker needs %zu B of LDS (> 64 KiB)", lds);
     const int ndof = 6 + tp->n_joints;
     // the substitution keeps its vector in registers, so the dof count is a template parameter:
-    // 14 = ant, 23 = humanoid, 30 = the ABI maximum
+    // 14 = ant, 18 = quadruped, 23 = humanoid, 30 = the ABI maximum
     // ... and so is the whole robot shape for the two robots MetaLocomotion ships (LDS addresses and model-table
     // offsets become literals); any other topology runs the shape-generic instantiations
     auto is_shape = [&](int b, int j, int s, int g) { return tuned && shape_is(b, j, s, g); };
@@ -1768,6 +1768,7 @@ extern "C" int mg_walker_step(const mg_walker_topology *tp, const mg_walker_mode
     if (is_shape(Humanoid::nb, Humanoid::nj, Humanoid::ns, Humanoid::ng)) MG_WALKER_LAUNCH(23, Humanoid);
     else if (is_shape(Ant::nb, Ant::nj, Ant::ns, Ant::ng)) MG_WALKER_LAUNCH(14, Ant);
     else if (ndof <= 14) MG_WALKER_LAUNCH(14, ShapeAny);
+    else if (ndof <= 18) MG_WALKER_LAUNCH(18, ShapeAny);      // a quadruped: 6 + 12 (the A1)
     else if (ndof <= 23) MG_WALKER_LAUNCH(23, ShapeAny);
     else MG_WALKER_LAUNCH(ND, ShapeAny);
 #undef MG_WALKER_LAUNCH
