@@ -728,6 +728,13 @@ struct WaveLds {   // pointers into the env's LDS slab
     double *sc;                              // sin / cos of every joint angle
     int *mask, *depth, *jstart, *jcount, *kids, *kind, *partner, *csphere, *misc, *dbody;
     int *parent, *sbody, *sfoot;             // topology tables copied out of the kernarg segment: body_parent, sphere_body, sphere_foot
+    // scan tables of the kinematics pass (wave_kinematics): a "hop" is one rigid transform of the chain — the fixed
+    // offset of body b (hop b) or the rotation of joint j (hop nb + j)
+    int *hanc;                               // [rh][nb + nj]: the 2^r-th ancestor hop, -1 past the root
+    int *janc;                               // [jr][nj]: the 2^r-th ancestor JOINT of a joint (r = 0: the previous joint on the chain)
+    int *bjoint;                             // [nb]: last joint on the chain from the base to body b inclusive, -1 for none
+    int *hbody;                              // [nb + nj]: body whose final frame this hop is, -1 for none
+    int rh, jr;                              // rounds of the two scans (host: scan_rounds())
 };
 
 // LDS layout. The solver works in Cholesky-whitened velocities y = L^T u (M = L L^T): with Jh = J L^-T
@@ -754,13 +761,16 @@ __host__ __device__ inline size_t wave_lds_doubles(int nb, int nj, int maxr, boo
            3 * (size_t)nj + 18 + (size_t)maxr * n + (wave_lds_alias2(nb, maxr) ? 1 : 3) * (size_t)maxr +
            6 * (size_t)W_MAXC + (2 * (size_t)nj <= 6 * (size_t)W_MAXC ? 0 : 2 * (size_t)nj);
 }
-__host__ __device__ inline size_t wave_lds_ints(int nb, int ns, int maxr) {
-    return 6 * (size_t)nb + 2 * (size_t)ns + 2 * (size_t)maxr + 2 * W_MAXC + 8 + ND;
+__host__ __device__ inline size_t wave_lds_ints(int nb, int nj, int ns, int maxr, int rh, int jr) {
+    return 6 * (size_t)nb + 2 * (size_t)ns + 2 * (size_t)maxr + 2 * W_MAXC + 8 + ND +
+           (size_t)(rh + 1) * (nb + nj) + (size_t)jr * nj + nb;      // scan tables: hanc, hbody, janc, bjoint
 }
+// doubles of the Jh block the kinematics pass uses as scratch: one 3x4 transform per hop (then the velocity scans)
+__host__ __device__ inline size_t wave_scan_doubles(int nb, int nj) { return 12 * (size_t)(nb + nj); }
 // doubles of the Jh block the M / h assembly uses as scratch (composite tables; + the frames when overlaid)
 __host__ __device__ inline size_t wave_assembly_doubles(int nb, int nj) { return 16 * (size_t)nb + 12 * (size_t)(6 + nj); }
 
-__device__ __forceinline__ WaveLds carve(unsigned char *smem, int nb, int nj, int ns, int maxr, bool overlay, int fd) {
+__device__ __forceinline__ WaveLds carve(unsigned char *smem, int nb, int nj, int ns, int maxr, bool overlay, int fd, int rh, int jr) {
     const int n = 6 + nj;
     WaveLds L;
     double *d = reinterpret_cast<double *>(smem);
@@ -784,6 +794,8 @@ __device__ __forceinline__ WaveLds carve(unsigned char *smem, int nb, int nj, in
     L.mask = i; i += nb; L.depth = i; i += nb; L.jstart = i; i += nb; L.jcount = i; i += nb; L.kids = i; i += nb;
     L.kind = i; i += maxr; L.partner = i; i += maxr; L.csphere = i; i += 2 * W_MAXC; L.misc = i; i += 8; L.dbody = i; i += ND;
     L.parent = i; i += nb; L.sbody = i; i += ns; L.sfoot = i; i += ns;
+    L.hanc = i; i += rh * (nb + nj); L.hbody = i; i += nb + nj; L.janc = i; i += jr * nj; L.bjoint = i; i += nb;
+    L.rh = rh; L.jr = jr;
     return L;
 }
 
@@ -817,6 +829,147 @@ __device__ __forceinline__ void rodrigues_sc(V3 k, double s, double c, double *R
     R[6] = k.z * k.x * v - k.y * s; R[7] = k.z * k.y * v + k.x * s; R[8] = c + k.z * k.z * v;
 }
 
+// One round of an inclusive scan along the chains of a tree (pointer jumping over static ancestor tables): every lane
+// adds the value its 2^r-th ancestor held after the previous round. The values travel through `buf` (K doubles per
+// item); reads of a round come before its writes in program order, which is all a single wavefront needs.
+template <int K>
+__device__ __forceinline__ void scan_add_round(double *buf, int item, int anc, double (&v)[K]) {
+    double x[K];
+    if (anc >= 0)
+        for (int i = 0; i < K; ++i) x[i] = buf[K * anc + i];
+    WSYNC();
+    if (anc >= 0)
+        for (int i = 0; i < K; ++i) { v[i] += x[i]; buf[K * item + i] = v[i]; }
+    WSYNC();
+}
+
+#ifndef MG_WALKER_LEVEL_KINEMATICS
+// Kinematics + velocity-product frames as SCANS over the kinematic tree, lane = hop (the fixed offset of a body or the
+// rotation of one joint: nb + nj <= 40 lanes), log2(chain length) rounds instead of one serial pass per tree level:
+//   1. every lane builds its hop's transform in the parent frame (joint lanes: sin / cos, Rodrigues, t = anchor - R anchor);
+//   2. rh rounds of  T_h <- T_anc(h) o T_h  (3x3 product + rotated offset) leave the WORLD transform after every hop;
+//      a joint's anchor and axis are invariant under its own rotation, so p_j = T_j anchor, a_j = R_j axis, and the
+//      final hop of a body carries that body's frame (R, o) and centre of mass;
+//   3. the velocity-product frames are sums along the chain of per-joint terms — w = w_base + sum qd_k a_k, then
+//      alpha = sum w_before x (qd_k a_k) and v_ref = v_base + sum w_before x r_k, then a_ref = sum alpha_before x r_k +
+//      w_before x (w_before x r_k), r_k the step from the previous joint anchor — three scans over the joints (jr rounds).
+// The level loop this replaces (kept under -DMG_WALKER_LEVEL_KINEMATICS) issued one full body + joint pass per tree level
+// with 1-4 lanes active: ~3 400 of the humanoid sub-step's ~7 200 VALU instructions.
+template <bool VEL>
+__device__ __forceinline__ void wave_kinematics(const ModelW &m, const WaveLds &L, int lane, int /*max_depth*/, bool with_frames) {
+    const int nb = m.nb, nj = m.nj, H = nb + nj;
+    double *T = L.J;                          // [H][12] hop transforms (rotation row-major, then offset); scratch of the Jh block
+    const bool is_hop = lane < H, is_joint = lane >= nb && lane < H;
+    const int j = lane - nb;
+    double R[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, tr[3] = {0, 0, 0};
+    V3 anchor{0, 0, 0}, axis{0, 0, 0};
+    PHASE_BEGIN();
+    if (is_hop) {
+        if (is_joint) {
+            anchor = ld3(m.joint_anchor() + 3 * j);
+            axis = ld3(m.joint_axis() + 3 * j);
+            const double qj = L.q[j];
+            rodrigues_sc(axis, sin(qj), cos(qj), R);
+            const V3 ra = mulMv(R, anchor);
+            tr[0] = anchor.x - ra.x; tr[1] = anchor.y - ra.y; tr[2] = anchor.z - ra.z;
+        } else if (lane == 0) {
+            for (int i = 0; i < 9; ++i) R[i] = L.base[3 + i];
+            for (int i = 0; i < 3; ++i) tr[i] = L.base[i];
+        } else {
+            for (int i = 0; i < 9; ++i) R[i] = m.body_rot()[9 * lane + i];
+            for (int i = 0; i < 3; ++i) tr[i] = m.body_pos()[3 * lane + i];
+        }
+        for (int i = 0; i < 9; ++i) T[12 * lane + i] = R[i];
+        for (int i = 0; i < 3; ++i) T[12 * lane + 9 + i] = tr[i];
+    }
+    WSYNC();
+    for (int r = 0; r < L.rh; ++r) {
+        const int anc = is_hop ? L.hanc[r * H + lane] : -1;
+        double A[12];
+        if (anc >= 0)
+            for (int i = 0; i < 12; ++i) A[i] = T[12 * anc + i];
+        WSYNC();
+        if (anc >= 0) {
+            double Rn[9];
+            mulMM(A, R, Rn);
+            const V3 tn = mulMv(A, V3{tr[0], tr[1], tr[2]});
+            for (int i = 0; i < 9; ++i) R[i] = Rn[i];
+            tr[0] = tn.x + A[9]; tr[1] = tn.y + A[10]; tr[2] = tn.z + A[11];
+            for (int i = 0; i < 9; ++i) T[12 * lane + i] = R[i];
+            for (int i = 0; i < 3; ++i) T[12 * lane + 9 + i] = tr[i];
+        }
+        WSYNC();
+    }
+    const V3 o_h{tr[0], tr[1], tr[2]};
+    V3 pj{0, 0, 0}, aj{0, 0, 0};
+    if (is_joint) {
+        pj = o_h + mulMv(R, anchor);
+        aj = mulMv(R, axis);
+        stv(L.p, j, pj);
+        stv(L.a, j, aj);
+    }
+    const int hb = is_hop ? L.hbody[lane] : -1;
+    if (hb >= 0) {
+        for (int i = 0; i < 9; ++i) L.R[9 * hb + i] = R[i];
+        stv(L.o, hb, o_h);
+        stv(L.c, hb, o_h + mulMv(R, ld3(m.body_com() + 3 * hb)));
+    }
+    WSYNC();
+    if (with_frames) {
+        double *Sw = T, *Sav = T + 3 * nj, *Sar = T + 9 * nj;       // [nj][3] w sums, [nj][6] alpha | v_ref sums, [nj][3] a_ref sums
+        const V3 wb{L.base[15], L.base[16], L.base[17]}, o0 = ldv(L.base, 0);
+        const int jp = is_joint ? L.janc[j] : -1;
+        const V3 wj = is_joint ? L.qd[j] * aj : V3{0, 0, 0};
+        double sw[3] = {wj.x, wj.y, wj.z};
+        if (is_joint) stv(Sw, j, wj);
+        WSYNC();
+        for (int r = 0; r < L.jr; ++r) scan_add_round<3>(Sw, j, is_joint ? L.janc[r * nj + j] : -1, sw);
+        V3 wbef = wb, rj{0, 0, 0};
+        if (is_joint) {
+            if (jp >= 0) wbef = wb + ldv(Sw, jp);
+            rj = pj - (jp >= 0 ? ldv(L.p, jp) : o0);
+        }
+        const V3 dal = cross(wbef, wj), dvr = cross(wbef, rj);
+        constexpr int KAV = VEL ? 6 : 3;                            // (v_ref is only kept by the shape-generic kernels)
+        double sav[6] = {dal.x, dal.y, dal.z, dvr.x, dvr.y, dvr.z};
+        if (is_joint)
+            for (int i = 0; i < KAV; ++i) Sav[6 * j + i] = sav[i];
+        WSYNC();
+        for (int r = 0; r < L.jr; ++r) {
+            const int anc = is_joint ? L.janc[r * nj + j] : -1;
+            double x[KAV];
+            if (anc >= 0)
+                for (int i = 0; i < KAV; ++i) x[i] = Sav[6 * anc + i];
+            WSYNC();
+            if (anc >= 0)
+                for (int i = 0; i < KAV; ++i) { sav[i] += x[i]; Sav[6 * j + i] = sav[i]; }
+            WSYNC();
+        }
+        V3 albef{0, 0, 0};
+        if (is_joint && jp >= 0) albef = V3{Sav[6 * jp], Sav[6 * jp + 1], Sav[6 * jp + 2]};
+        const V3 dar = cross(albef, rj) + cross(wbef, cross(wbef, rj));
+        double sar[3] = {dar.x, dar.y, dar.z};
+        if (is_joint) stv(Sar, j, dar);
+        WSYNC();
+        for (int r = 0; r < L.jr; ++r) scan_add_round<3>(Sar, j, is_joint ? L.janc[r * nj + j] : -1, sar);
+        if (lane < nb) {
+            const int b = lane, k = L.bjoint[b];
+            V3 w = wb, al{0, 0, 0}, xr = o0, ar{0, 0, 0}, vr{L.base[12], L.base[13], L.base[14]};
+            if (k >= 0) {
+                w = wb + ldv(Sw, k);
+                al = V3{Sav[6 * k], Sav[6 * k + 1], Sav[6 * k + 2]};
+                xr = ldv(L.p, k);
+                ar = ldv(Sar, k);
+                if (VEL) vr = vr + V3{Sav[6 * k + 3], Sav[6 * k + 4], Sav[6 * k + 5]};
+            }
+            stv(L.fw, b, w); stv(L.fal, b, al); stv(L.fxr, b, xr); stv(L.far_, b, ar);
+            if (VEL) stv(L.fvr, b, vr);
+        }
+        WSYNC();
+    }
+    PHASE(11);
+}
+#else
 // forceinline: with three call sites the compiler would otherwise emit a real call, which pushes the
 // kernels into scratch (ant: 1.04 -> 1.92 ms)
 template <bool VEL>
@@ -886,6 +1039,7 @@ __device__ __forceinline__ void wave_kinematics(const ModelW &m, const WaveLds &
     }
     PHASE(11);      // (profile builds) the level loop alone; phase 0 minus this = sin / cos
 }
+#endif
 
 template <int NMAX, bool GENERIC>
 __device__ __forceinline__ void wave_substep(const mg_walker_topology &tp, const ModelW &m, const mg_walker_params &prm,
@@ -1432,7 +1586,7 @@ __device__ __forceinline__ void wave_substep(const mg_walker_topology &tp, const
 template <int NMAX, class SH>
 __global__ __launch_bounds__(WV) __attribute__((amdgpu_waves_per_eu(2))) void walker_step_wave_kernel(mg_walker_topology tp, mg_walker_models ms,
                                                               mg_walker_params prm, mg_walker_state st, int n_envs,
-                                                              int maxr_flags, const float *action, float *obs,
+                                                              int maxr_flags, int scan_rounds, const float *action, float *obs,
                                                               float *reward, float *rewards5, uint8_t *done) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int e = mg::env_of_block(blockIdx.x, n_envs), lane = threadIdx.x;
@@ -1449,7 +1603,7 @@ __global__ __launch_bounds__(WV) __attribute__((amdgpu_waves_per_eu(2))) void wa
     asm volatile("" : "+v"(slab_off));
     unsigned char *slab = smem + slab_off;
     constexpr bool GENERIC = SH::nb == 0;      // shape-generic instantiation: terrain, > 64 proxies, per-proxy friction, body damping
-    const WaveLds L = carve(slab, nb, nj, ns, maxr, overlay, GENERIC ? 15 : 12);
+    const WaveLds L = carve(slab, nb, nj, ns, maxr, overlay, GENERIC ? 15 : 12, scan_rounds & 0xff, scan_rounds >> 8);
     if (lane < nb) L.parent[lane] = tp.body_parent[lane];
     for (int g = lane; g < ns; g += WV) {
         L.sbody[g] = tp.sphere_body[g];
@@ -1481,6 +1635,48 @@ __global__ __launch_bounds__(WV) __attribute__((amdgpu_waves_per_eu(2))) void wa
         for (int d = 0; d < 6; ++d) L.dbody[d] = 0;
     }
     WSYNC();
+    {   // scan tables of the kinematics pass (topology only; lane = hop / joint / body)
+        const int H = nb + nj;
+        int hp = -1, hb = -1;
+        if (lane < nb) {
+            const int pb = L.parent[lane];
+            if (pb >= 0) hp = L.jcount[pb] > 0 ? nb + L.jstart[pb] + L.jcount[pb] - 1 : pb;
+            hb = L.jcount[lane] == 0 ? lane : -1;
+        } else if (lane < H) {
+            const int j = lane - nb, b = L.dbody[6 + j];
+            hp = j > L.jstart[b] ? lane - 1 : b;
+            hb = j == L.jstart[b] + L.jcount[b] - 1 ? b : -1;
+        }
+        if (lane < H) {
+            L.hbody[lane] = hb;
+            if (L.rh > 0) L.hanc[lane] = hp;
+        }
+        // nearest joint at or above a hop (walks over bodies without joints)
+        auto joint_at_or_above = [&](int h) {
+            while (h >= 0 && h < nb) {
+                const int pb = L.parent[h];
+                h = pb < 0 ? -1 : (L.jcount[pb] > 0 ? nb + L.jstart[pb] + L.jcount[pb] - 1 : pb);
+            }
+            return h < 0 ? -1 : h - nb;
+        };
+        if (lane >= nb && lane < H && L.jr > 0) L.janc[lane - nb] = joint_at_or_above(hp);
+        if (lane < nb) L.bjoint[lane] = L.jcount[lane] > 0 ? L.jstart[lane] + L.jcount[lane] - 1 : joint_at_or_above(hp);
+        WSYNC();
+        for (int r = 1; r < L.rh; ++r) {
+            if (lane < H) {
+                const int a = L.hanc[(r - 1) * H + lane];
+                L.hanc[r * H + lane] = a >= 0 ? L.hanc[(r - 1) * H + a] : -1;
+            }
+            WSYNC();
+        }
+        for (int r = 1; r < L.jr; ++r) {
+            if (lane < nj) {
+                const int a = L.janc[(r - 1) * nj + lane];
+                L.janc[r * nj + lane] = a >= 0 ? L.janc[(r - 1) * nj + a] : -1;
+            }
+            WSYNC();
+        }
+    }
     if (lane < 3) {
         L.base[lane] = st.pos[(size_t)lane * n_envs + e];
         L.base[12 + lane] = st.vel[(size_t)lane * n_envs + e];
@@ -1751,8 +1947,29 @@ extern "C" int mg_walker_step(const mg_walker_topology *tp, const mg_walker_mode
             overlay = need + fd * (size_t)tp->n_bodies <= block;
         }
     }
+    // rounds of the kinematics scans: 2^rh >= longest chain of hops (body offsets + joints), 2^jr >= longest chain of joints
+    int rh = 0, jr = 0;
+    {
+        int hops[NB], joints[NB], max_h = 0, max_j = 0, j = 0;      // per body: hops / joints on the chain from the base, inclusive
+        for (int b = 0; b < tp->n_bodies; ++b) {
+            const int pb = tp->body_parent[b];
+            if (pb >= b) return mg::set_error(MG_ERR_BAD_CONFIG, "walker topology: body %d has parent %d (parents come first)", b, pb);
+            int cnt = 0;
+            while (j < tp->n_joints && tp->joint_body[j] == b) { ++j; ++cnt; }
+            hops[b] = (pb < 0 ? 0 : hops[pb]) + 1 + cnt;
+            joints[b] = (pb < 0 ? 0 : joints[pb]) + cnt;
+            max_h = hops[b] > max_h ? hops[b] : max_h;
+            max_j = joints[b] > max_j ? joints[b] : max_j;
+        }
+        while ((1 << rh) < max_h) ++rh;
+        while ((1 << jr) < max_j) ++jr;
+        if (wave_scan_doubles(tp->n_bodies, tp->n_joints) + (overlay ? fd * (size_t)tp->n_bodies : 0) > (size_t)maxr * ndof_of(tp))
+            return mg::set_error(MG_ERR_UNSUPPORTED, "walker topology: the kinematics scan needs %zu scratch doubles, the wave "
+                                 "mapping has %zu: use mapping = lane", wave_scan_doubles(tp->n_bodies, tp->n_joints),
+                                 (size_t)maxr * ndof_of(tp) - (overlay ? fd * (size_t)tp->n_bodies : 0));
+    }
     const size_t lds = wave_lds_doubles(tp->n_bodies, tp->n_joints, maxr, overlay, fd) * sizeof(double) +
-                       wave_lds_ints(tp->n_bodies, tp->n_spheres, maxr) * sizeof(int);
+                       wave_lds_ints(tp->n_bodies, tp->n_joints, tp->n_spheres, maxr, rh, jr) * sizeof(int);
     const int maxr_flags = overlay ? -maxr : maxr;
     if (lds > 160 * 1024) return mg::set_error(MG_ERR_BAD_SIZE, "walker needs %zu B of LDS", lds);
     if (lds > 64 * 1024) return mg::set_error(MG_ERR_BAD_SIZE, "walker needs %zu B of LDS (> 64 KiB)", lds);
@@ -1764,7 +1981,7 @@ extern "C" int mg_walker_step(const mg_walker_topology *tp, const mg_walker_mode
     auto is_shape = [&](int b, int j, int s, int g) { return tuned && shape_is(b, j, s, g); };
 #define MG_WALKER_LAUNCH(NMAX_, SHAPE_)                                                                                  \
     hipLaunchKernelGGL((walker_step_wave_kernel<NMAX_, SHAPE_>), dim3(n), dim3(WV), lds, (hipStream_t)stream, *tp, *ms, \
-                       *prm, *st, n, maxr_flags, action, obs, reward, rewards5, done)
+                       *prm, *st, n, maxr_flags, rh | (jr << 8), action, obs, reward, rewards5, done)
     if (is_shape(Humanoid::nb, Humanoid::nj, Humanoid::ns, Humanoid::ng)) MG_WALKER_LAUNCH(23, Humanoid);
     else if (is_shape(Ant::nb, Ant::nj, Ant::ns, Ant::ng)) MG_WALKER_LAUNCH(14, Ant);
     else if (ndof <= 14) MG_WALKER_LAUNCH(14, ShapeAny);
