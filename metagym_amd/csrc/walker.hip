@@ -868,8 +868,9 @@ __device__ __forceinline__ void wave_kinematics(const ModelW &m, const WaveLds &
         if (is_joint) {
             anchor = ld3(m.joint_anchor() + 3 * j);
             axis = ld3(m.joint_axis() + 3 * j);
-            const double qj = L.q[j];
-            rodrigues_sc(axis, sin(qj), cos(qj), R);
+            double sq, cq;
+            sincos(L.q[j], &sq, &cq);             // one range reduction for both
+            rodrigues_sc(axis, sq, cq, R);
             const V3 ra = mulMv(R, anchor);
             tr[0] = anchor.x - ra.x; tr[1] = anchor.y - ra.y; tr[2] = anchor.z - ra.z;
         } else if (lane == 0) {
@@ -1213,12 +1214,28 @@ __device__ __forceinline__ void wave_substep(const mg_walker_topology &tp, const
                 ipiv = ipiv * fma(-hv * ipiv, ipiv, 1.5);
                 const double lc = lane == c ? vc * ipiv : row[c] * ipiv;       // L[lane][c]
                 row[c] = lc;
+                constexpr int CG = 6;
+                // M[lane][k] -= L[lane][c] L[k][c], six columns at a time: the six broadcasts (v_readlane pairs into SGPRs)
+                // first, then the six FMAs — back to back, every FMA would wait two states on its own broadcast (s_nop),
+                // and unfenced the scheduler hoists all of a step's v_readlane ahead and spills the SGPRs it ran out of
+                if constexpr (GENERIC) {        // (shape-generic kernels: interleaved; batching costs them registers and time, A1 2.90 -> 3.00 ms)
 #pragma unroll
-                for (int k = c + 1; k < NMAX; ++k) {
-                    if (k < n) row[k] -= lc * lane_value(lc, k);               // M[lane][k] -= L[lane][c] L[k][c]
-                    // the broadcasts land in SGPRs: fence the scheduler every few columns, or it hoists all of a
-                    // step's v_readlane ahead of the FMAs and spills the SGPRs it ran out of
-                    if ((k - c) % 6 == 0) __builtin_amdgcn_sched_barrier(0);
+                    for (int k = c + 1; k < NMAX; ++k) {
+                        if (k < n) row[k] -= lc * lane_value(lc, k);
+                        if ((k - c) % 6 == 0) __builtin_amdgcn_sched_barrier(0);
+                    }
+                } else
+#pragma unroll
+                for (int k0 = c + 1; k0 < NMAX; k0 += CG) {
+                    double bc[CG];
+#pragma unroll
+                    for (int i = 0; i < CG; ++i)
+                        if (k0 + i < NMAX && k0 + i < n) bc[i] = lane_value(lc, k0 + i);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int i = 0; i < CG; ++i)
+                        if (k0 + i < NMAX && k0 + i < n) row[k0 + i] -= lc * bc[i];
+                    __builtin_amdgcn_sched_barrier(0);
                 }
                 idg_d = lane == c ? ipiv : idg_d;     // (no branch inside the column loop: the broadcasts above are
                                                       // convergent and stay put, the FMAs would sink below it)
@@ -1542,7 +1559,9 @@ __device__ __forceinline__ void wave_substep(const mg_walker_topology &tp, const
         if (wn * dt > 0.0) {
             double Rw[9], Rn[9], Ro[9];
             for (int i = 0; i < 9; ++i) Ro[i] = L.base[3 + i];
-            rodrigues((1.0 / wn) * om, wn * dt, Rw);
+            double sw, cw;
+            sincos(wn * dt, &sw, &cw);
+            rodrigues_sc((1.0 / wn) * om, sw, cw, Rw);
             mulMM(Rw, Ro, Rn);
             for (int i = 0; i < 9; ++i) L.base[3 + i] = Rn[i];
         }
