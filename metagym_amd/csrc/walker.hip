@@ -829,6 +829,14 @@ __device__ __forceinline__ void rodrigues_sc(V3 k, double s, double c, double *R
     R[6] = k.z * k.x * v - k.y * s; R[7] = k.z * k.y * v + k.x * s; R[8] = c + k.z * k.z * v;
 }
 
+// `p` again, as slab base + a byte offset the optimiser cannot see into: accesses at constant offsets from the result
+// share ONE base register (otherwise every offset beyond an instruction's immediate field gets its own v_add)
+__device__ __forceinline__ const double *opaque_base(const double *slab_base, const double *p) {
+    unsigned off = (unsigned)((const unsigned char *)p - (const unsigned char *)slab_base);
+    asm volatile("" : "+v"(off));
+    return (const double *)((const unsigned char *)slab_base + off);
+}
+
 // One round of an inclusive scan along the chains of a tree (pointer jumping over static ancestor tables): every lane
 // adds the value its 2^r-th ancestor held after the previous round. The values travel through `buf` (K doubles per
 // item); reads of a round come before its writes in program order, which is all a single wavefront needs.
@@ -1199,10 +1207,13 @@ __device__ __forceinline__ void wave_substep(const mg_walker_topology &tp, const
     const int lrow = lane < n ? lane : n - 1;
     {
         double row[NMAX];
+        // unconditional reads: a predicate per slot costs an exec-mask branch each and the 23 masks stay live (spilled)
+        // until the write-back below; slots above the diagonal may hold anything
+        // (and at unclamped addresses from one per-lane base: slot k > lane reads into the following rows, or just past the
+        // factor for the last row of a kernel with spare slots — valid LDS either way)
+        const double *Mrow = opaque_base(L.R, L.M + TRI(lrow, 0));
 #pragma unroll
-        // unconditional reads at clamped (always valid) indices: a predicate per slot costs an exec-mask branch each
-        // and the 23 masks stay live (spilled) until the write-back below; slots above the diagonal may hold anything
-        for (int k = 0; k < NMAX; ++k) row[k] = L.M[TRI(lrow, k < lrow ? k : lrow)];
+        for (int k = 0; k < NMAX; ++k) row[k] = Mrow[k];
         // right-looking: once column c is final every later column takes its rank-1 update at once — the n - c - 1
         // FMAs of a step are independent of each other (the left-looking form chained c dependent FMAs per column)
 #pragma unroll
@@ -1251,11 +1262,12 @@ __device__ __forceinline__ void wave_substep(const mg_walker_topology &tp, const
     }
     WSYNC();
     PHASE(3);
+    const double *Mcol = opaque_base(L.R, L.M + lrow);      // column `lane` of the packed factor: Mcol[TRI(r, 0)] = L[r][lane]
     {   // y = L^T u: y_d = sum_{r >= d} L[r][d] u_r; the lane's column of L is fetched in one batch of LDS reads
         double col[NMAX];
 #pragma unroll
-        for (int r = 0; r < NMAX; ++r) {
-            const double v = L.M[TRI(r > lrow ? (r < n ? r : n - 1) : lrow, lrow)];
+        for (int r = 0; r < NMAX; ++r) {     // (entries above the diagonal are read from wherever TRI(r, lane) lands and dropped)
+            const double v = r < n ? Mcol[TRI(r, 0)] : 0.0;
             col[r] = (r < n && r >= lane) ? v : 0.0;
         }
         double y_d = 0.0;
@@ -1457,19 +1469,27 @@ __device__ __forceinline__ void wave_substep(const mg_walker_topology &tp, const
         const int r = lane;
         double w[NMAX];
         const int rkind = L.kind[r];
-        const bool is_limit = rkind >= 4;
-        const int ldof = is_limit ? 6 + L.partner[r] : -1;
-        const double lsg = rkind == 4 ? 1.0 : -1.0;
         double *jr = L.J + (size_t)r * n;
+        if (rkind >= 4) {   // a joint-limit row is written out first (one branch; a select per element cost a branch each)
+            const int ldof = 6 + L.partner[r];
+            const double lsg = rkind == 4 ? 1.0 : -1.0;
 #pragma unroll
-        for (int d = 0; d < NMAX; ++d) w[d] = d < n ? (is_limit ? (d == ldof ? lsg : 0.0) : jr[d]) : 0.0;
+            for (int d = 0; d < NMAX; ++d)
+                if (d < n) jr[d] = d == ldof ? lsg : 0.0;
+        }
+#pragma unroll
+        for (int d = 0; d < NMAX; ++d) w[d] = d < n ? jr[d] : 0.0;
+        // the factor through a base register of its own: its packed offsets then fit the 8-bit fields of ds_read2_b64
+        const double *Mp = opaque_base(L.R, L.M);
         double dd = 0.0;
+        // (left-looking on purpose: the right-looking form — independent FMAs, one batch of factor reads per column — has fewer
+        // instructions and is slower, 0.634 -> 0.664 ms on the humanoid batch)
 #pragma unroll
         for (int d = 0; d < NMAX; ++d) {
             if (d < n) {
                 double v = w[d];
 #pragma unroll
-                for (int k = 0; k < d; ++k) v -= L.M[TRI(d, k)] * w[k];
+                for (int k = 0; k < d; ++k) v -= Mp[TRI(d, k)] * w[k];
                 w[d] = v * L.idg[d];
                 dd += w[d] * w[d];
                 jr[d] = w[d];
@@ -1531,7 +1551,7 @@ __device__ __forceinline__ void wave_substep(const mg_walker_topology &tp, const
         double col[NMAX];
 #pragma unroll
         for (int r = 0; r < NMAX; ++r) {
-            const double v = L.M[TRI(r > lrow ? (r < n ? r : n - 1) : lrow, lrow)];
+            const double v = r < n ? Mcol[TRI(r, 0)] : 0.0;
             col[r] = (r < n && r > lane) ? v : 0.0;
         }
 #pragma unroll
