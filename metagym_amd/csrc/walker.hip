@@ -1383,30 +1383,51 @@ __device__ __forceinline__ void wave_substep(const mg_walker_topology &tp, const
             touch[ch] |= __ballot(kept);
             ncont = min(ncont + __popcll(th_mask), W_MAXC);
         }
-    // self-collision: lane = geom pair (in pair order, 64 at a time); slots after the ground and terrain contacts
-    if (prm.self_collision)
+    // self-collision: lane = geom pair (in pair order, 64 at a time); slots after the ground and terrain contacts.
+    // The capsules' world end points are computed once per geom (lane = geom) into the idle Jh block; a pair then runs
+    // the closest-point routine only if its bounding spheres overlap (mid-point distance < half lengths + radii — exactly
+    // conservative), and a chunk whose pairs are all apart skips it as a wave (the humanoid's 66 pairs: the second
+    // chunk holds two).
+    if (prm.self_collision && tp.n_pairs > 0 && ncont < W_MAXC) {
+        double *seg = L.J;            // [ng][8]: p0 (3), p1 (3), radius, half length
+        for (int g = lane; g < m.ng; g += WV) {
+            const int b = tp.geom_body[g];
+            const V3 ob = ldv(L.o, b);
+            const V3 P0 = ob + mulMv(L.R + 9 * b, ld3(m.geom_p0() + 3 * g)), P1 = ob + mulMv(L.R + 9 * b, ld3(m.geom_p1() + 3 * g));
+            const V3 d = P1 - P0;
+            double *sg = seg + 8 * g;
+            sg[0] = P0.x; sg[1] = P0.y; sg[2] = P0.z; sg[3] = P1.x; sg[4] = P1.y; sg[5] = P1.z;
+            sg[6] = m.geom_r()[g]; sg[7] = 0.5 * sqrt(dot(d, d));
+        }
+        WSYNC();
         for (int base = 0; base < tp.n_pairs && ncont < W_MAXC; base += WV) {
             const int pr = base + lane;
-            bool sh = false;
+            bool sh = false, near = false;
             V3 xc{0, 0, 0}, nrm{0, 0, 1};
-            double sdepth = 0.0;
+            double sdepth = 0.0, ra = 0.0, rb = 0.0;
             int ba = 0, bb = 0;
+            V3 a0{0, 0, 0}, a1{0, 0, 0}, b0{0, 0, 0}, b1{0, 0, 0};
             if (pr < tp.n_pairs) {
                 const int ga = tp.pair_a[pr], gb = tp.pair_b[pr];
                 ba = tp.geom_body[ga];
                 bb = tp.geom_body[gb];
+                const double *sa = seg + 8 * ga, *sb = seg + 8 * gb;
+                a0 = ldv(sa, 0); a1 = ldv(sa, 1); b0 = ldv(sb, 0); b1 = ldv(sb, 1);
+                ra = sa[6]; rb = sb[6];
+                const V3 dm = 0.5 * ((a0 + a1) - (b0 + b1));
+                const double reach = (sa[7] + sb[7]) + (ra + rb) + 1e-9;
+                near = dot(dm, dm) < reach * reach;
+            }
+            if (near) {
                 V3 ca, cb;
-                segment_closest(ldv(L.o, ba) + mulMv(L.R + 9 * ba, ld3(m.geom_p0() + 3 * ga)),
-                                ldv(L.o, ba) + mulMv(L.R + 9 * ba, ld3(m.geom_p1() + 3 * ga)),
-                                ldv(L.o, bb) + mulMv(L.R + 9 * bb, ld3(m.geom_p0() + 3 * gb)),
-                                ldv(L.o, bb) + mulMv(L.R + 9 * bb, ld3(m.geom_p1() + 3 * gb)), ca, cb);
+                segment_closest(a0, a1, b0, b1, ca, cb);
                 const V3 dv = ca - cb;
                 const double dist = sqrt(dot(dv, dv));
-                sdepth = m.geom_r()[ga] + m.geom_r()[gb] - dist;
+                sdepth = ra + rb - dist;
                 sh = sdepth > 0.0 && dist > 1e-9;
                 if (sh) {
                     nrm = (1.0 / dist) * dv;
-                    xc = 0.5 * ((ca - m.geom_r()[ga] * nrm) + (cb + m.geom_r()[gb] * nrm));
+                    xc = 0.5 * ((ca - ra * nrm) + (cb + rb * nrm));
                 }
             }
             const unsigned long long sh_mask = __ballot(sh);
@@ -1421,6 +1442,7 @@ __device__ __forceinline__ void wave_substep(const mg_walker_topology &tp, const
             }
             ncont = min(ncont + __popcll(sh_mask), W_MAXC);
         }
+    }
     double lsgn = 0.0, viol = 0.0;
     if (lane < nj) {
         const double qj = L.q[lane];
