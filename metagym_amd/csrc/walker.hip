@@ -1665,35 +1665,40 @@ __global__ __launch_bounds__(WV) __attribute__((amdgpu_waves_per_eu(2))) void wa
     unsigned char *slab = smem + slab_off;
     constexpr bool GENERIC = SH::nb == 0;      // shape-generic instantiation: terrain, > 64 proxies, per-proxy friction, body damping
     const WaveLds L = carve(slab, nb, nj, ns, maxr, overlay, GENERIC ? 15 : 12, scan_rounds & 0xff, scan_rounds >> 8);
-    if (lane < nb) L.parent[lane] = tp.body_parent[lane];
+    // topology-only tables, built once per launch, lane-parallel (lane = body / joint): a body's first joint and joint
+    // count, its tree depth, the joints on its chain (mask), its children (kids), the body every generalized coordinate
+    // sits on (dbody)
+    if (lane < nb) {
+        L.parent[lane] = tp.body_parent[lane];
+        L.jstart[lane] = 0; L.jcount[lane] = 0; L.kids[lane] = 0;
+    }
+    if (lane < 6) L.dbody[lane] = 0;
+    if (lane == 0) L.misc[0] = 0;
     for (int g = lane; g < ns; g += WV) {
         L.sbody[g] = tp.sphere_body[g];
         L.sfoot[g] = tp.sphere_foot[g];
     }
     WSYNC();
-    // tree bookkeeping (lane 0) + state load (lanes)
-    if (lane == 0) {
-        int md = 0, j = 0;
-        for (int b = 0; b < nb; ++b) {
-            const int pb = L.parent[b];
-            L.depth[b] = pb < 0 ? 0 : L.depth[pb] + 1;
-            md = max(md, L.depth[b]);
-            L.jstart[b] = j;
-            while (j < nj && tp.joint_body[j] == b) ++j;
-            L.jcount[b] = j - L.jstart[b];
+    if (lane < nj) {        // joint_body is non-decreasing: a body's joints are one run
+        const int b = tp.joint_body[lane];
+        L.dbody[6 + lane] = b;
+        if (lane == 0 || tp.joint_body[lane - 1] != b) L.jstart[b] = lane;
+        if (lane == nj - 1 || tp.joint_body[lane + 1] != b) L.jcount[b] = lane + 1;      // (the run's end for now)
+    }
+    WSYNC();
+    if (lane < nb && L.jcount[lane] > 0) L.jcount[lane] -= L.jstart[lane];
+    WSYNC();
+    if (lane < nb) {
+        int d = -1;
+        unsigned mk = 0;
+        for (int x = lane; x >= 0; x = L.parent[x]) {
+            mk |= ((1u << L.jcount[x]) - 1u) << L.jstart[x];
+            ++d;
         }
-        L.misc[0] = md;
-        // topology-only tables of the mass-matrix assembly, built once per launch: the joints on each body's
-        // chain (mask), its children (kids), the body every generalized coordinate sits on (dbody)
-        for (int b = 0; b < nb; ++b) {
-            const int pb = L.parent[b];
-            unsigned mk = pb < 0 ? 0u : (unsigned)L.mask[pb];
-            for (int jj = L.jstart[b]; jj < L.jstart[b] + L.jcount[b]; ++jj) { mk |= 1u << jj; L.dbody[6 + jj] = b; }
-            L.mask[b] = (int)mk;
-            L.kids[b] = 0;
-            if (pb >= 0) L.kids[pb] |= 1 << b;
-        }
-        for (int d = 0; d < 6; ++d) L.dbody[d] = 0;
+        L.depth[lane] = d;
+        L.mask[lane] = (int)mk;
+        atomicMax(&L.misc[0], d);
+        if (L.parent[lane] >= 0) atomicOr(&L.kids[L.parent[lane]], 1 << lane);
     }
     WSYNC();
     {   // scan tables of the kinematics pass (topology only; lane = hop / joint / body)
@@ -1819,20 +1824,27 @@ __global__ __launch_bounds__(WV) __attribute__((amdgpu_waves_per_eu(2))) void wa
             }
         }
         dist = 0.0;
+        // the f64 inverse-trigonometric and trigonometric calls of the head (~150-200 instructions each), spread over lanes: the
+        // three atan2 run as ONE call on lanes 0-2, the two sin / cos pairs as ONE sincos on lanes 0-1 (they were eight calls on lane 0)
+        const double cnt = (double)parts;
+        const double bx = sxm / cnt, by = sym / cnt;
+        const double *R = L.R;
+        const double dx = prm.walk_target_x - bx, dy = prm.walk_target_y - by;
+        double at = 0.0;
+        if (lane < 3) at = atan2(lane == 0 ? R[7] : (lane == 1 ? R[3] : dy), lane == 0 ? R[8] : (lane == 1 ? R[0] : dx));
+        const double roll = lane_value(at, 0), yaw = lane_value(at, 1), theta = lane_value(at, 2);
+        const double ang = theta - yaw;
+        double s2 = 0.0, c2 = 1.0;
+        if (lane < 2) sincos(lane == 0 ? ang : -yaw, &s2, &c2);
+        const double sin_ang = lane_value(s2, 0), cos_ang = lane_value(c2, 0), sn = lane_value(s2, 1), c = lane_value(c2, 1);
         if (lane == 0) {
-            const double cnt = (double)parts;
-            const double bx = sxm / cnt, by = sym / cnt, z = L.o[2];
-            const double *R = L.R;
-            const double roll = atan2(R[7], R[8]);
+            const double z = L.o[2];
             double sp = -R[6];
             sp = sp < -1.0 ? -1.0 : (sp > 1.0 ? 1.0 : sp);
-            const double pitch = asin(sp), yaw = atan2(R[3], R[0]);
-            const double dx = prm.walk_target_x - bx, dy = prm.walk_target_y - by;
-            const double theta = atan2(dy, dx);
+            const double pitch = asin(sp);
             dist = sqrt(dy * dy + dx * dx);
-            const double ang = theta - yaw, c = cos(-yaw), sn = sin(-yaw);
             const double vx = c * L.base[12] - sn * L.base[13], vy = sn * L.base[12] + c * L.base[13], vz = L.base[14];
-            head[0] = clip5((float)(z - prm.initial_z)); head[1] = clip5((float)sin(ang)); head[2] = clip5((float)cos(ang));
+            head[0] = clip5((float)(z - prm.initial_z)); head[1] = clip5((float)sin_ang); head[2] = clip5((float)cos_ang);
             head[3] = clip5((float)(0.3 * vx)); head[4] = clip5((float)(0.3 * vy)); head[5] = clip5((float)(0.3 * vz));
             head[6] = clip5((float)roll); head[7] = clip5((float)pitch);
             for (int i = 0; i < 8; ++i) { ob[i] = head[i]; finite = finite && isfinite(head[i]); }
