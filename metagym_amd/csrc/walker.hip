@@ -1118,19 +1118,25 @@ __device__ __forceinline__ void wave_substep(const mg_walker_topology &tp, const
         cp[10] = F.x; cp[11] = F.y; cp[12] = F.z; cp[13] = NO.x; cp[14] = NO.y; cp[15] = NO.z;
     }
     WSYNC();
-    for (int level = max_depth - 1; level >= 0; --level) {      // subtree sums: a body pulls its finished children
-        if (lane < nb && L.depth[lane] == level) {
-            unsigned kids = (unsigned)L.kids[lane];
-            if (kids) {
-                double acc[16];
-                double *cp = comp + 16 * lane;
-                for (int i = 0; i < 16; ++i) acc[i] = cp[i];
-                for (; kids != 0; kids &= kids - 1) {
-                    const double *ck = comp + 16 * (__ffs(kids) - 1);
-                    for (int i = 0; i < 16; ++i) acc[i] += ck[i];
-                }
-                for (int i = 0; i < 16; ++i) cp[i] = acc[i];
+    {   // subtree sums, lane = (body, component): every item adds its component over the body's subtree (L.kids: the
+        // bodies of the subtree, the body itself included). All items are read before any is written back, so the
+        // sums are taken of the bodies' own values and the table is updated in place.
+        constexpr int ITEMS = (16 * NB + WV - 1) / WV;
+        double acc[ITEMS];
+#pragma unroll
+        for (int c = 0; c < ITEMS; ++c) {
+            const int it = c * WV + lane;
+            acc[c] = 0.0;
+            if (it < 16 * nb) {
+                const double *ci = comp + (it & 15);
+                for (unsigned sub = (unsigned)L.kids[it >> 4]; sub != 0; sub &= sub - 1) acc[c] += ci[16 * (__ffs(sub) - 1)];
             }
+        }
+        WSYNC();
+#pragma unroll
+        for (int c = 0; c < ITEMS; ++c) {
+            const int it = c * WV + lane;
+            if (it < 16 * nb) comp[it] = acc[c];
         }
         WSYNC();
     }
@@ -1160,9 +1166,9 @@ __device__ __forceinline__ void wave_substep(const mg_walker_topology &tp, const
     }
     WSYNC();
     for (int t = lane; t < n * (n + 1) / 2; t += WV) {      // packed lower triangle: every lane has an entry
-        int d = (int)((sqrtf(8.0f * (float)t + 1.0f) - 1.0f) * 0.5f);
-        while ((d + 1) * (d + 2) / 2 <= t) ++d;
-        while (d * (d + 1) / 2 > t) --d;
+        // row of packed entry t: floor((sqrt(8t + 1) - 1) / 2). With 1.5 under the root a first-of-row t = d(d+1)/2 lands
+        // 0.25 / (2d + 1) above 2d + 1 and the entry before it >= 0.06 below: 1-ulp errors of v_sqrt_f32 cannot flip the floor
+        const int d = (int)((sqrtf(8.0f * (float)t + 1.5f) - 1.0f) * 0.5f);
         const int e = t - d * (d + 1) / 2;
         double acc = 0.0;
         if (e < 6 || (((unsigned)L.mask[L.dbody[d]] >> (e - 6)) & 1u)) {
@@ -1666,7 +1672,7 @@ __global__ __launch_bounds__(WV) __attribute__((amdgpu_waves_per_eu(2))) void wa
     constexpr bool GENERIC = SH::nb == 0;      // shape-generic instantiation: terrain, > 64 proxies, per-proxy friction, body damping
     const WaveLds L = carve(slab, nb, nj, ns, maxr, overlay, GENERIC ? 15 : 12, scan_rounds & 0xff, scan_rounds >> 8);
     // topology-only tables, built once per launch, lane-parallel (lane = body / joint): a body's first joint and joint
-    // count, its tree depth, the joints on its chain (mask), its children (kids), the body every generalized coordinate
+    // count, its tree depth, the joints on its chain (mask), its subtree (kids), the body every generalized coordinate
     // sits on (dbody)
     if (lane < nb) {
         L.parent[lane] = tp.body_parent[lane];
@@ -1698,7 +1704,7 @@ __global__ __launch_bounds__(WV) __attribute__((amdgpu_waves_per_eu(2))) void wa
         L.depth[lane] = d;
         L.mask[lane] = (int)mk;
         atomicMax(&L.misc[0], d);
-        if (L.parent[lane] >= 0) atomicOr(&L.kids[L.parent[lane]], 1 << lane);
+        for (int x = lane; x >= 0; x = L.parent[x]) atomicOr(&L.kids[x], 1 << lane);      // kids[x]: the bodies of x's subtree, x included
     }
     WSYNC();
     {   // scan tables of the kinematics pass (topology only; lane = hop / joint / body)
@@ -1810,6 +1816,17 @@ __global__ __launch_bounds__(WV) __attribute__((amdgpu_waves_per_eu(2))) void wa
         at_limit = __popcll(__ballot(lim));
         if (lane < nj) { ob[8 + 2 * lane] = clip5(jp); ob[9 + 2 * lane] = clip5(jv); }
         bool finite = isfinite(jp) && isfinite(jv);
+        // feet in contact now: one ballot per foot over the proxies (lane = proxy), not a loop over the proxies per foot
+        float cnow = 0.0f;
+        if (!after_reset)
+            for (int f = 0; f < nf; ++f) {
+                bool any = false;
+                for (int ch = 0; ch < (GENERIC ? (ns + WV - 1) / WV : 1); ++ch) {
+                    const int g = ch * WV + lane;
+                    any = any || __ballot(g < ns && ((touch[GENERIC ? ch : 0] >> lane) & 1ull) && L.sfoot[g < ns ? g : 0] == f) != 0ull;
+                }
+                if (lane == f && any) cnow = 1.0f;
+            }
         if (lane < nf) {
             if (after_reset) {
                 ob[8 + 2 * nj + lane] = 0.0f;
@@ -1817,9 +1834,6 @@ __global__ __launch_bounds__(WV) __attribute__((amdgpu_waves_per_eu(2))) void wa
             } else {
                 const float prev = st.feet_contact[(size_t)lane * n_envs + e];
                 ob[8 + 2 * nj + lane] = clip5(prev);
-                float cnow = 0.0f;
-                for (int g = 0; g < ns; ++g)
-                    if (((touch[GENERIC ? g >> 6 : 0] >> (g & 63)) & 1ull) && L.sfoot[g] == lane) cnow = 1.0f;
                 st.feet_contact[(size_t)lane * n_envs + e] = cnow;
             }
         }
