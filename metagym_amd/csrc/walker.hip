@@ -638,6 +638,10 @@ constexpr int W_MAXC = 12;   // ground contacts kept per env (first W_MAXC penet
 template <int B, int J, int S, int G, int OVL>
 struct Shape { static constexpr int nb = B, nj = J, ns = S, ng = G, overlay = OVL; };
 using ShapeAny = Shape<0, 0, 0, 0, -1>;
+// shape-generic, but with the joint count fixed (= every slot of the NMAX-slot register arrays in use): the `slot < n`
+// tests of the unrolled Cholesky / substitution code fold away (a scalar compare + branch each otherwise)
+template <int J>
+using ShapeDof = Shape<0, J, 0, 0, -1>;
 
 struct ModelW {   // one task's table row (layout: mg_walker_models in metagym_hip.h); offsets fold when the shape is constant
     const double *p;
@@ -666,8 +670,9 @@ struct ModelW {   // one task's table row (layout: mg_walker_models in metagym_h
 // row_half_mirror, row_mirror), then the four row totals are fetched with v_readlane.
 template <int CTRL>
 __device__ __forceinline__ double dpp_add(double v) {
-    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, false);
-    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, false);
+    // (mov_dpp: no `old` operand to initialise — every lane of these permutations has a valid source)
+    const int lo = __builtin_amdgcn_mov_dpp(__double2loint(v), CTRL, 0xf, 0xf, true);
+    const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(v), CTRL, 0xf, 0xf, true);
     return v + __hiloint2double(hi, lo);
 }
 __device__ __forceinline__ double lane_value(double v, int lane) {
@@ -1531,33 +1536,41 @@ __device__ __forceinline__ void wave_substep(const mg_walker_topology &tp, const
     // ---- projected Gauss-Seidel on the whitened velocity y (wave-uniform row loop) --------------------
     //      The row's Jacobian element and scalars are fetched one row AHEAD, so their LDS latency hides behind
     //      the previous row's reduction; the reduction itself only spans the lanes that hold coordinates.
+    //      The multipliers live in registers (lane r holds lambda_r; the current row's is fetched with v_readlane at a scalar
+    //      index) and a friction row's partner is always the normal row swept just before it, whose new multiplier is carried
+    //      along: no LDS read sits between the reduction and the update any more (two exposed LDS latencies per row).
     if (nr > 0) {
         double jh_n = lane < n ? L.J[lane] : 0.0, idg_n = L.diag[0], bias_n = L.bias[0];
-        int kind_n = L.kind[0], partner_n = L.partner[0];
+        int kind_n = __builtin_amdgcn_readfirstlane(L.kind[0]);
+        double lamv = 0.0, lam_norm = 0.0;
         const int sweeps = prm.solver_iterations * nr;
         int r = 0;
         for (int s = 0; s < sweeps; ++s) {
             const double jh = jh_n, idg = idg_n, bias = bias_n;
-            const int rkind = kind_n, partner = partner_n, rr = r;
+            const int rkind = kind_n, rr = r;
             r = r + 1 < nr ? r + 1 : 0;
             jh_n = lane < n ? L.J[(size_t)r * n + lane] : 0.0;       // next row (wraps to row 0 of the next sweep)
-            idg_n = L.diag[r]; bias_n = L.bias[r]; kind_n = L.kind[r]; partner_n = L.partner[r];
-            if (!(idg > 0.0)) continue;
+            idg_n = L.diag[r]; bias_n = L.bias[r]; kind_n = __builtin_amdgcn_readfirstlane(L.kind[r]);
+            if (!(idg > 0.0)) {
+                if (rkind == 0) lam_norm = 0.0;                      // (an empty normal row keeps its zero multiplier)
+                continue;
+            }
             const double jv = NMAX <= 32 ? wave_sum32(jh * u_d) : wave_sum(jh * u_d);   // J_r u = Jh_r . y
-            const double lr = L.lam[rr];
+            const double lr = lane_value(lamv, rr);
             const bool tfric = GENERIC && rkind < 0;                     // a terrain friction row keeps its mu in `bias`
             double x = lr - (jv - (tfric ? 0.0 : bias)) * idg;
-            if (rkind == 0 || rkind >= 4) x = x > 0.0 ? x : 0.0;
-            else {
-                const double lim = (tfric ? bias : (rkind == 3 ? prm.self_friction : prm.friction)) * L.lam[partner];
+            if (rkind == 0 || rkind >= 4) {
+                x = x > 0.0 ? x : 0.0;
+                if (rkind == 0) lam_norm = x;
+            } else {
+                const double lim = (tfric ? bias : (rkind == 3 ? prm.self_friction : prm.friction)) * lam_norm;
                 x = x < -lim ? -lim : (x > lim ? lim : x);
             }
             const double dl = x - lr;
             u_d += jh * dl;                                          // y += Jh_r^T dlambda
-            // single-wave workgroup: LDS operations of one wavefront retire in program order, so every
-            // lane has read lam[r] / lam[partner] above before this store lands
-            if (lane == 0) L.lam[rr] = x;
+            lamv = lane == rr ? x : lamv;
         }
+        if (lane < nr) L.lam[lane] = lamv;                           // (read by the foot-force block)
     }
     PHASE(8);
     if (GENERIC && foot_force != nullptr) {     // normal force per foot (mg_walker_state.foot_force): lane = foot
@@ -1657,7 +1670,7 @@ __global__ __launch_bounds__(WV) __attribute__((amdgpu_waves_per_eu(2))) void wa
                                                               float *reward, float *rewards5, uint8_t *done) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int e = mg::env_of_block(blockIdx.x, n_envs), lane = threadIdx.x;
-    const int nb = SH::nb ? SH::nb : tp.n_bodies, nj = SH::nb ? SH::nj : tp.n_joints, ns = SH::nb ? SH::ns : tp.n_spheres;
+    const int nb = SH::nb ? SH::nb : tp.n_bodies, nj = SH::nj ? SH::nj : tp.n_joints, ns = SH::nb ? SH::ns : tp.n_spheres;
     const int nf = tp.n_feet, obs_dim = 8 + 2 * nj + nf;
     const ModelW m{ms.table + (size_t)st.task_id[e] * ms.model_stride, nb, nj, ns, SH::nb ? SH::ng : tp.n_geoms};
     // sign of the row-count argument: assembly scratch overlaid on Jh
@@ -2071,10 +2084,13 @@ extern "C" int mg_walker_step(const mg_walker_topology *tp, const mg_walker_mode
                        *prm, *st, n, maxr_flags, rh | (jr << 8), action, obs, reward, rewards5, done)
     if (is_shape(Humanoid::nb, Humanoid::nj, Humanoid::ns, Humanoid::ng)) MG_WALKER_LAUNCH(23, Humanoid);
     else if (is_shape(Ant::nb, Ant::nj, Ant::ns, Ant::ng)) MG_WALKER_LAUNCH(14, Ant);
-    else if (ndof <= 14) MG_WALKER_LAUNCH(14, ShapeAny);
-    else if (ndof <= 18) MG_WALKER_LAUNCH(18, ShapeAny);      // a quadruped: 6 + 12 (the A1)
-    else if (ndof <= 23) MG_WALKER_LAUNCH(23, ShapeAny);
-    else MG_WALKER_LAUNCH(ND, ShapeAny);
+    else if (ndof == 14) MG_WALKER_LAUNCH(14, ShapeDof<8>);
+    else if (ndof < 14) MG_WALKER_LAUNCH(14, ShapeAny);
+    else if (ndof == 18) MG_WALKER_LAUNCH(18, ShapeDof<12>);  // a quadruped: 6 + 12 (the A1)
+    else if (ndof < 18) MG_WALKER_LAUNCH(18, ShapeAny);
+    else if (ndof == 23) MG_WALKER_LAUNCH(23, ShapeDof<17>);
+    else if (ndof < 23) MG_WALKER_LAUNCH(23, ShapeAny);
+    else MG_WALKER_LAUNCH(ND, ShapeAny);                      // (a 30-dof exact instantiation spills VGPRs)
 #undef MG_WALKER_LAUNCH
     return mg::check_launch("walker_step_wave_kernel");
 }
