@@ -1315,7 +1315,7 @@ __device__ __forceinline__ void wave_substep(const mg_walker_topology &tp, const
         if (kept) {
             L.cx[6 * slot] = sx; L.cx[6 * slot + 1] = sy; L.cx[6 * slot + 2] = depth;
             L.csphere[2 * slot] = g; L.csphere[2 * slot + 1] = -1;       // ground contact of proxy g
-            const double mu = own_mu ? prm.friction * prm.sphere_friction[g] : 0.0;
+            const double mu = own_mu ? prm.friction * prm.sphere_friction[g] : prm.friction;   // every friction row carries its mu
             L.bias[3 * slot] = prm.erp * depth / dt; L.kind[3 * slot] = 0; L.partner[3 * slot] = -1;
             L.bias[3 * slot + 1] = mu; L.kind[3 * slot + 1] = own_mu ? -1 : 1; L.partner[3 * slot + 1] = 3 * slot;
             L.bias[3 * slot + 2] = mu; L.kind[3 * slot + 2] = own_mu ? -1 : 2; L.partner[3 * slot + 2] = 3 * slot;
@@ -1448,8 +1448,8 @@ __device__ __forceinline__ void wave_substep(const mg_walker_topology &tp, const
                 cc[0] = xc.x; cc[1] = xc.y; cc[2] = xc.z; cc[3] = nrm.x; cc[4] = nrm.y; cc[5] = nrm.z;
                 L.csphere[2 * slot] = ba; L.csphere[2 * slot + 1] = bb;
                 L.bias[3 * slot] = prm.erp * sdepth / dt; L.kind[3 * slot] = 0; L.partner[3 * slot] = -1;
-                L.bias[3 * slot + 1] = 0.0; L.kind[3 * slot + 1] = 3; L.partner[3 * slot + 1] = 3 * slot;
-                L.bias[3 * slot + 2] = 0.0; L.kind[3 * slot + 2] = 3; L.partner[3 * slot + 2] = 3 * slot;
+                L.bias[3 * slot + 1] = prm.self_friction; L.kind[3 * slot + 1] = 3; L.partner[3 * slot + 1] = 3 * slot;
+                L.bias[3 * slot + 2] = prm.self_friction; L.kind[3 * slot + 2] = 3; L.partner[3 * slot + 2] = 3 * slot;
             }
             ncont = min(ncont + __popcll(sh_mask), W_MAXC);
         }
@@ -1557,13 +1557,15 @@ __device__ __forceinline__ void wave_substep(const mg_walker_topology &tp, const
             }
             const double jv = NMAX <= 32 ? wave_sum32(jh * u_d) : wave_sum(jh * u_d);   // J_r u = Jh_r . y
             const double lr = lane_value(lamv, rr);
-            const bool tfric = GENERIC && rkind < 0;                     // a terrain friction row keeps its mu in `bias`
-            double x = lr - (jv - (tfric ? 0.0 : bias)) * idg;
-            if (rkind == 0 || rkind >= 4) {
+            // a friction row (kinds 1, 2, 3, -1) keeps its coefficient in the bias slot — its velocity target is zero — so the
+            // loop needs no per-kind coefficient (it came from the kernarg segment with an s_load + wait per row)
+            const bool fric = rkind != 0 && rkind < 4;
+            double x = lr - (jv - (fric ? 0.0 : bias)) * idg;
+            if (!fric) {
                 x = x > 0.0 ? x : 0.0;
                 if (rkind == 0) lam_norm = x;
             } else {
-                const double lim = (tfric ? bias : (rkind == 3 ? prm.self_friction : prm.friction)) * lam_norm;
+                const double lim = bias * lam_norm;
                 x = x < -lim ? -lim : (x > lim ? lim : x);
             }
             const double dl = x - lr;
