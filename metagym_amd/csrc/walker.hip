@@ -1240,7 +1240,7 @@ __device__ __forceinline__ void wave_substep(const mg_walker_topology &tp, const
                 // M[lane][k] -= L[lane][c] L[k][c], six columns at a time: the six broadcasts (v_readlane pairs into SGPRs)
                 // first, then the six FMAs — back to back, every FMA would wait two states on its own broadcast (s_nop),
                 // and unfenced the scheduler hoists all of a step's v_readlane ahead and spills the SGPRs it ran out of
-                if constexpr (GENERIC) {        // (shape-generic kernels: interleaved; batching costs them registers and time, A1 2.90 -> 3.00 ms)
+                if constexpr (GENERIC || NMAX <= 14) {        // (the ant runs three waves per SIMD on 168 VGPRs; shape-generic kernels: interleaved; batching costs them registers and time, A1 2.90 -> 3.00 ms)
 #pragma unroll
                     for (int k = c + 1; k < NMAX; ++k) {
                         if (k < n) row[k] -= lc * lane_value(lc, k);
@@ -1665,8 +1665,11 @@ __device__ __forceinline__ void wave_substep(const mg_walker_topology &tp, const
     }
 }
 
+// Waves per SIMD: two (<= 256 VGPRs) everywhere but in the tuned ant kernel — its 10.7 KB of LDS let 12 envs reside per CU, so
+// it is held to 168 VGPRs for a third wave (its 46 spilled VGPRs all sit after the sub-step loop): 0.402 -> 0.365 ms. The A1's
+// 18-slot kernel at 168 VGPRs spills inside the loop and loses (2.31 -> 2.45 ms); the humanoid is LDS-bound at 8 per CU.
 template <int NMAX, class SH>
-__global__ __launch_bounds__(WV) __attribute__((amdgpu_waves_per_eu(2))) void walker_step_wave_kernel(mg_walker_topology tp, mg_walker_models ms,
+__global__ __launch_bounds__(WV) __attribute__((amdgpu_waves_per_eu((NMAX <= 14 && SH::nb != 0) ? 3 : 2))) void walker_step_wave_kernel(mg_walker_topology tp, mg_walker_models ms,
                                                               mg_walker_params prm, mg_walker_state st, int n_envs,
                                                               int maxr_flags, int scan_rounds, const float *action, float *obs,
                                                               float *reward, float *rewards5, uint8_t *done) {
