@@ -1540,20 +1540,12 @@ __device__ __forceinline__ void wave_substep(const mg_walker_topology &tp, const
     //      index) and a friction row's partner is always the normal row swept just before it, whose new multiplier is carried
     //      along: no LDS read sits between the reduction and the update any more (two exposed LDS latencies per row).
     if (nr > 0) {
-        double jh_n = lane < n ? L.J[lane] : 0.0, idg_n = L.diag[0], bias_n = L.bias[0];
-        int kind_n = __builtin_amdgcn_readfirstlane(L.kind[0]);
         double lamv = 0.0, lam_norm = 0.0;
-        const int sweeps = prm.solver_iterations * nr;
-        int r = 0;
-        for (int s = 0; s < sweeps; ++s) {
-            const double jh = jh_n, idg = idg_n, bias = bias_n;
-            const int rkind = kind_n, rr = r;
-            r = r + 1 < nr ? r + 1 : 0;
-            jh_n = lane < n ? L.J[(size_t)r * n + lane] : 0.0;       // next row (wraps to row 0 of the next sweep)
-            idg_n = L.diag[r]; bias_n = L.bias[r]; kind_n = __builtin_amdgcn_readfirstlane(L.kind[r]);
+        // one row: Jh_r . y by a wave reduction, the projected multiplier update, y += Jh_r^T dlambda
+        auto row_step = [&](double jh, double idg, double bias, int rkind, int rr) {
             if (!(idg > 0.0)) {
                 if (rkind == 0) lam_norm = 0.0;                      // (an empty normal row keeps its zero multiplier)
-                continue;
+                return;
             }
             const double jv = NMAX <= 32 ? wave_sum32(jh * u_d) : wave_sum(jh * u_d);   // J_r u = Jh_r . y
             const double lr = lane_value(lamv, rr);
@@ -1568,9 +1560,29 @@ __device__ __forceinline__ void wave_substep(const mg_walker_topology &tp, const
                 const double lim = bias * lam_norm;
                 x = x < -lim ? -lim : (x > lim ? lim : x);
             }
-            const double dl = x - lr;
-            u_d += jh * dl;                                          // y += Jh_r^T dlambda
+            u_d += jh * (x - lr);                                    // y += Jh_r^T dlambda
             lamv = lane == rr ? x : lamv;
+        };
+        // the row's Jacobian element and scalars are fetched one row AHEAD into a second register set; the loop is unrolled by
+        // two so the sets swap roles instead of being copied (the copies were 8 of the row's ~90 instructions)
+        auto fetch = [&](int r, double &jh, double &idg, double &bias, int &kind) {
+            jh = lane < n ? L.J[(size_t)r * n + lane] : 0.0;
+            idg = L.diag[r]; bias = L.bias[r]; kind = __builtin_amdgcn_readfirstlane(L.kind[r]);
+        };
+        double jh_a, idg_a, bias_a, jh_b, idg_b, bias_b;
+        int kind_a, kind_b;
+        fetch(0, jh_a, idg_a, bias_a, kind_a);
+        const int sweeps = prm.solver_iterations * nr;
+        int r = 0;
+        for (int s = 0; s < sweeps; s += 2) {
+            const int r1 = r + 1 < nr ? r + 1 : 0;
+            fetch(r1, jh_b, idg_b, bias_b, kind_b);
+            row_step(jh_a, idg_a, bias_a, kind_a, r);
+            if (s + 1 >= sweeps) break;
+            const int r2 = r1 + 1 < nr ? r1 + 1 : 0;
+            fetch(r2, jh_a, idg_a, bias_a, kind_a);
+            row_step(jh_b, idg_b, bias_b, kind_b, r1);
+            r = r2;
         }
         if (lane < nr) L.lam[lane] = lamv;                           // (read by the foot-force block)
     }
