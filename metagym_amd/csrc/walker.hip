@@ -2080,6 +2080,7 @@ extern "C" int mg_walker_step(const mg_walker_topology *tp, const mg_walker_mode
         }
         while ((1 << rh) < max_h) ++rh;
         while ((1 << jr) < max_j) ++jr;
+        if (tp->n_joints > 0 && jr < 1) jr = 1;     // round 0 of the joint table is also the "previous joint" table: always there
         if (wave_scan_doubles(tp->n_bodies, tp->n_joints) + (overlay ? fd * (size_t)tp->n_bodies : 0) > (size_t)maxr * ndof_of(tp))
             return mg::set_error(MG_ERR_UNSUPPORTED, "walker topology: the kinematics scan needs %zu scratch doubles, the wave "
                                  "mapping has %zu: use mapping = lane", wave_scan_doubles(tp->n_bodies, tp->n_joints),

@@ -1,0 +1,105 @@
+"""Shape-generic instantiations of the walker engine: robots that are neither the humanoid, the ant nor the A1 — synthetic
+"centipedes" with 4 / 8 / 10 / 12 / 14 / 17 / 20 hinges (10 ... 26 generalized coordinates, i.e. every register-slot count
+14 / 18 / 23 / 30 both with spare slots and with the joint count equal to the slot count) — follow the numpy oracle
+(oracle/abd.py) to float64 round-off. Bodies without joints, chains of different lengths, up to 6 legs. GPU box only."""
+import xml.etree.ElementTree as ET
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import abd
+
+pytestmark = pytest.mark.gpu
+
+
+def _centipede(legs):
+    """Torso sphere + one leg per entry of `legs`: a jointless stub body, then a chain of capsule segments, segment s with
+    legs[i][s] hinges on it (1-3, different axes through the segment's origin), the last segment being the foot."""
+    from metagym_amd.metalocomotion.variants import _body, _capsule, _emit, _hinge, _sphere
+    items = [_sphere("torso_geom", (0, 0, 0), 0.25)]
+    feet = []
+    nl = len(legs)
+    for i, segs in enumerate(legs):
+        ang = 2.0 * np.pi * (i + 0.5) / nl
+        a, b = 0.22 * np.cos(ang), 0.22 * np.sin(ang)
+        axes = [((0, 0, 1), (-35, 35)), ((-b, a, 0), (10, 70)), ((a, b, 0.3), (-30, 30))]
+        chain = None
+        for s in reversed(range(len(segs))):        # build the chain from the foot inwards
+            name = "leg%d_seg%d" % (i, s) if s < len(segs) - 1 else "foot%d" % i
+            seg = [_hinge("j%d_%d_%d" % (i, s, h), axes[(h + s) % 3][0], *axes[(h + s) % 3][1]) for h in range(segs[s])]
+            last = s == len(segs) - 1
+            seg.append(_capsule("g%d_%d" % (i, s), (0, 0, 0, 0.5 * a if last else a, 0.5 * b if last else b, -0.32 if last else 0.0), 0.07))
+            if chain is not None:
+                seg.append(chain)
+            chain = _body(name, (a, b, 0.0), *seg)
+        items.append(_body("stub%d" % i, (0, 0, 0), _capsule("stub_geom%d" % i, (0, 0, 0, a, b, 0), 0.07), chain))
+        feet.append("foot%d" % i)
+    root = ET.Element("mujoco", model="centipede")
+    ET.SubElement(root, "compiler", angle="degree", inertiafromgeom="true")
+    d = ET.SubElement(root, "default")
+    ET.SubElement(d, "joint", limited="true", armature="0.5", damping="0.8")
+    ET.SubElement(d, "geom", condim="3", friction="1.2 0.1 0.1", density="8.0")
+    _emit(ET.SubElement(root, "worldbody"), _body("torso", (0, 0, 0.6), *items))
+    return ET.tostring(root, encoding="unicode"), tuple(feet)
+
+
+# hinges per segment per leg -> (generalized coordinates, kernel the launch picks)
+ROBOTS = {"4 hinges (10 dof, <14, any>)": [[1], [1], [1], [1]],
+          "8 hinges (14 dof, <14, 8 joints>)": [[2]] * 4,
+          "10 hinges (16 dof, <18, any>)": [[2, 1], [1, 1], [2, 1], [1, 1]],
+          "12 hinges (18 dof, <18, 12 joints>)": [[2, 1]] * 4,
+          "14 hinges (20 dof, <23, any>)": [[3, 1], [2, 1], [3, 1], [2, 1]],
+          "17 hinges (23 dof, <23, 17 joints>)": [[3, 2], [2, 2], [2, 2], [2, 2]],
+          "20 hinges (26 dof, <30, any>)": [[3, 2]] * 4}
+
+
+@pytest.mark.parametrize("name", list(ROBOTS))
+def test_generic_robot_follows_the_oracle(name):
+    import metagym_amd.metalocomotion as ml
+    from metagym_amd.metalocomotion.mjcf import load_mjcf
+    legs = ROBOTS[name]
+    text, feet = _centipede(legs)
+    m = load_mjcf(text, foot_names=feet)
+    nj = sum(sum(l) for l in legs)
+    assert len(m.joint_lo) == nj and len(m.body_parent) == 1 + len(legs) + sum(len(l) for l in legs)
+
+    class Centipede(ml.WalkerBatchEnv):
+        robot_dir = None
+        foot_list = feet
+        power = 0.4
+        motor_power = None
+        alive_z = 0.15
+        alive_bonus = 1.0
+        initial_z = None
+
+    n = 6
+    kw = {}
+    env = Centipede(num_envs=n, device="cuda:0", max_steps=1000, self_collision=False, **kw)
+    env.set_task([m])
+    rs = np.random.RandomState(len(legs) * 100 + nj)
+    noise = rs.uniform(-0.1, 0.1, (n, nj))
+    env.reset(joint_noise=noise)
+    oenvs = []
+    for e in range(n):
+        o = abd.WalkerEnv(m, prm=abd.Params(friction=0.8 * float(m.geom_friction), power=0.4, self_collision=False),
+                          motor_power=np.full(nj, 100.0), alive_z=0.15, alive_bonus=1.0, initial_z=None, torque_f32=False,
+                          max_steps=1000)
+        o.reset(noise[e])
+        oenvs.append(o)
+    worst, touched = 0.0, 0
+    for t in range(30):
+        a = rs.uniform(-0.7, 0.7, (n, nj)).astype(np.float32)
+        env.step(torch.as_tensor(a))
+        q, qd, pos = env.q.cpu().numpy().T, env.qd.cpu().numpy().T, env.pos.cpu().numpy().T
+        fc = env.feet_contact.cpu().numpy().T
+        for e in range(n):
+            oenvs[e].step(a[e])
+            s = oenvs[e].s
+            worst = max(worst, np.abs(q[e] - s.q).max(), np.abs(pos[e] - s.pos).max(), 0.01 * np.abs(qd[e] - s.qd).max())
+            assert np.allclose(q[e], s.q, rtol=0, atol=1e-8), (t, e, np.abs(q[e] - s.q).max())
+            assert np.allclose(pos[e], s.pos, rtol=0, atol=1e-8), (t, e)
+            assert np.array_equal(fc[e], oenvs[e].feet_contact), (t, e)
+            touched += int(fc[e].sum())
+    assert touched > 0            # somebody stood on a foot
+    print("%s: max |state diff| GPU vs oracle over 30 env steps %.2e" % (name, worst))
