@@ -51,7 +51,10 @@ ROBOTS = {"4 hinges (10 dof, <14, any>)": [[1], [1], [1], [1]],
           "12 hinges (18 dof, <18, 12 joints>)": [[2, 1]] * 4,
           "14 hinges (20 dof, <23, any>)": [[3, 1], [2, 1], [3, 1], [2, 1]],
           "17 hinges (23 dof, <23, 17 joints>)": [[3, 2], [2, 2], [2, 2], [2, 2]],
-          "20 hinges (26 dof, <30, any>)": [[3, 2]] * 4}
+          "20 hinges (26 dof, <30, any>)": [[3, 2]] * 4,
+          "24 hinges (30 dof, every slot of <30, any>)": [[3, 3]] * 4,
+          "snake: one 14-segment chain (29 hops deep: 5 + 4 scan rounds)": [[1] * 14],
+          "stiff: 4 one-hinge legs, joint chains one joint deep": [[1]] * 4}
 
 
 @pytest.mark.parametrize("name", list(ROBOTS))
