@@ -57,11 +57,12 @@ ROBOTS = {"4 hinges (10 dof, <14, any>)": [[1], [1], [1], [1]],
           "stiff: 4 one-hinge legs, joint chains one joint deep": [[1]] * 4}
 
 
-@pytest.mark.parametrize("name", list(ROBOTS))
+@pytest.mark.parametrize("name", list(ROBOTS) + ["self-collision: " + k for k in list(ROBOTS)[3:5]])
 def test_generic_robot_follows_the_oracle(name):
     import metagym_amd.metalocomotion as ml
     from metagym_amd.metalocomotion.mjcf import load_mjcf
-    legs = ROBOTS[name]
+    selfc = name.startswith("self-collision: ")
+    legs = ROBOTS[name[len("self-collision: "):] if selfc else name]
     text, feet = _centipede(legs)
     m = load_mjcf(text, foot_names=feet)
     nj = sum(sum(l) for l in legs)
@@ -78,14 +79,15 @@ def test_generic_robot_follows_the_oracle(name):
 
     n = 6
     kw = {}
-    env = Centipede(num_envs=n, device="cuda:0", max_steps=1000, self_collision=False, **kw)
+    env = Centipede(num_envs=n, device="cuda:0", max_steps=1000, self_collision=selfc, **kw)
     env.set_task([m])
     rs = np.random.RandomState(len(legs) * 100 + nj)
     noise = rs.uniform(-0.1, 0.1, (n, nj))
     env.reset(joint_noise=noise)
     oenvs = []
     for e in range(n):
-        o = abd.WalkerEnv(m, prm=abd.Params(friction=0.8 * float(m.geom_friction), power=0.4, self_collision=False),
+        o = abd.WalkerEnv(m, prm=abd.Params(friction=0.8 * float(m.geom_friction), power=0.4, self_collision=selfc,
+                                             self_friction=float(m.geom_friction) ** 2),
                           motor_power=np.full(nj, 100.0), alive_z=0.15, alive_bonus=1.0, initial_z=None, torque_f32=False,
                           max_steps=1000)
         o.reset(noise[e])
