@@ -611,12 +611,14 @@ __global__ __launch_bounds__(WK_BLOCK) void walker_reset_kernel(mg_walker_topolo
 
 // ======================================================================================================
 // Wave-per-env mapping (default). One 64-lane wavefront owns one env; its whole work set lives in LDS
-// (17.4 KB for the humanoid: kinematics, packed M, h, the whitened constraint rows Jh = J L^-T; blocks whose
-// lifetimes do not overlap share storage, see carve()), so eight envs are resident per CU — the kernel is
-// LDS-latency-bound at ~1 wave per SIMD, occupancy is what buys time (4 -> 8 envs per CU: 3.62 -> 1.86 ms at
-// 8 192 envs; register Cholesky and tighter assembly loops then took it to 1.46 ms) — and nothing spills to scratch. Lanes are dealt
-//   * bodies (tree level by tree level) for kinematics and the Newton-Euler pass,
-//   * matrix entries for M, rows/columns for the Cholesky factorisation and the triangular solves,
+// (18.3 KB for the humanoid: kinematics, packed M, h, the whitened constraint rows Jh = J L^-T, the scan tables; blocks whose
+// lifetimes do not overlap share storage, see carve()), so eight envs are resident per CU (two waves per SIMD, the register
+// file's cap too) and nothing spills to scratch in the sub-step loop. Serial, branchy sections are what cost time here
+// (DESIGN.md 3.4): every phase is written as a few lane-parallel passes. Lanes are dealt
+//   * hops (a body's fixed offset or one joint's rotation) for the kinematics and the velocity-product frames: scans over the
+//     kinematic tree, log2(chain length) rounds (wave_kinematics),
+//   * (body, component) items for the subtree sums, generalized coordinates and matrix entries for M, rows/columns for the
+//     Cholesky factorisation and the triangular solves,
 //   * collision spheres / joints for constraint detection (ballot + popcount gives every constraint
 //     its row index in sphere / joint order, the same order the oracle uses),
 //   * constraint rows for the whitening Jh = J L^-T (each lane forward-substitutes its own right-hand side),
@@ -856,7 +858,6 @@ __device__ __forceinline__ void scan_add_round(double *buf, int item, int anc, d
     WSYNC();
 }
 
-#ifndef MG_WALKER_LEVEL_KINEMATICS
 // Kinematics + velocity-product frames as SCANS over the kinematic tree, lane = hop (the fixed offset of a body or the
 // rotation of one joint: nb + nj <= 40 lanes), log2(chain length) rounds instead of one serial pass per tree level:
 //   1. every lane builds its hop's transform in the parent frame (joint lanes: sin / cos, Rodrigues, t = anchor - R anchor);
@@ -866,10 +867,11 @@ __device__ __forceinline__ void scan_add_round(double *buf, int item, int anc, d
 //   3. the velocity-product frames are sums along the chain of per-joint terms — w = w_base + sum qd_k a_k, then
 //      alpha = sum w_before x (qd_k a_k) and v_ref = v_base + sum w_before x r_k, then a_ref = sum alpha_before x r_k +
 //      w_before x (w_before x r_k), r_k the step from the previous joint anchor — three scans over the joints (jr rounds).
-// The level loop this replaces (kept under -DMG_WALKER_LEVEL_KINEMATICS) issued one full body + joint pass per tree level
-// with 1-4 lanes active: ~3 400 of the humanoid sub-step's ~7 200 VALU instructions.
+// The level loop this replaced (git history, before round 3's "kinematics ... as scans") issued one full body + joint pass per
+// tree level with 1-4 lanes active. forceinline: with two call sites the compiler would otherwise emit a real call, which
+// pushes the kernels into scratch.
 template <bool VEL>
-__device__ __forceinline__ void wave_kinematics(const ModelW &m, const WaveLds &L, int lane, int /*max_depth*/, bool with_frames) {
+__device__ __forceinline__ void wave_kinematics(const ModelW &m, const WaveLds &L, int lane, bool with_frames) {
     const int nb = m.nb, nj = m.nj, H = nb + nj;
     double *T = L.J;                          // [H][12] hop transforms (rotation row-major, then offset); scratch of the Jh block
     const bool is_hop = lane < H, is_joint = lane >= nb && lane < H;
@@ -983,81 +985,10 @@ __device__ __forceinline__ void wave_kinematics(const ModelW &m, const WaveLds &
     }
     PHASE(11);
 }
-#else
-// forceinline: with three call sites the compiler would otherwise emit a real call, which pushes the
-// kernels into scratch (ant: 1.04 -> 1.92 ms)
-template <bool VEL>
-__device__ __forceinline__ void wave_kinematics(const ModelW &m, const WaveLds &L, int lane, int max_depth, bool with_frames) {
-    const int nb = m.nb, nj = m.nj;
-    // the f64 sin/cos of all joint angles at once (lane = joint): the level loop below is serial in the
-    // tree depth and must not carry ~300 instructions of range reduction per joint
-    if (lane < nj) {
-        const double qj = L.q[lane];
-        L.sc[2 * lane] = sin(qj);
-        L.sc[2 * lane + 1] = cos(qj);
-    }
-    WSYNC();
-    PHASE_BEGIN();
-    for (int level = 0; level <= max_depth; ++level) {
-        if (lane < nb && L.depth[lane] == level) {
-            const int b = lane, pb = L.parent[b];
-            double Rc[9];
-            V3 oc, w, al, xr, ar, vr{0, 0, 0};
-            unsigned mk = 0;
-            if (pb < 0) {
-                for (int i = 0; i < 9; ++i) Rc[i] = L.base[3 + i];
-                oc = ldv(L.base, 0);
-                w = V3{L.base[15], L.base[16], L.base[17]};
-                al = v3(0, 0, 0); xr = oc; ar = v3(0, 0, 0);
-                if (VEL) vr = V3{L.base[12], L.base[13], L.base[14]};
-            } else {
-                mulMM(L.R + 9 * pb, m.body_rot() + 9 * b, Rc);
-                oc = ldv(L.o, pb) + mulMv(L.R + 9 * pb, ld3(m.body_pos() + 3 * b));
-                mk = (unsigned)L.mask[pb];
-                w = ldv(L.fw, pb); al = ldv(L.fal, pb); xr = ldv(L.fxr, pb); ar = ldv(L.far_, pb);
-                if (VEL && with_frames) vr = ldv(L.fvr, pb);
-            }
-            const int j0 = L.jstart[b], j1 = j0 + L.jcount[b];
-            for (int j = j0; j < j1; ++j) {
-                const V3 anchor = ld3(m.joint_anchor() + 3 * j), axis = ld3(m.joint_axis() + 3 * j);
-                const V3 pj = oc + mulMv(Rc, anchor), aj = mulMv(Rc, axis);
-                stv(L.p, j, pj);
-                stv(L.a, j, aj);
-                double Rj[9], Rn[9];
-                rodrigues_sc(axis, L.sc[2 * j], L.sc[2 * j + 1], Rj);
-                mulMM(Rc, Rj, Rn);
-                oc = pj - mulMv(Rn, anchor);
-                for (int i = 0; i < 9; ++i) Rc[i] = Rn[i];
-                mk |= 1u << j;
-                if (with_frames) {
-                    const V3 r = pj - xr;
-                    ar = ar + cross(al, r) + cross(w, cross(w, r));
-                    if (VEL) vr = vr + cross(w, r);      // velocity of the new reference point (the joint anchor)
-                    xr = pj;
-                    const V3 wj = L.qd[j] * aj;
-                    al = al + cross(w, wj);
-                    w = w + wj;
-                }
-            }
-            for (int i = 0; i < 9; ++i) L.R[9 * b + i] = Rc[i];
-            stv(L.o, b, oc);
-            const V3 cb = oc + mulMv(Rc, ld3(m.body_com() + 3 * b));
-            stv(L.c, b, cb);
-            L.mask[b] = (int)mk;
-            if (with_frames) {
-                stv(L.fw, b, w); stv(L.fal, b, al); stv(L.fxr, b, xr); stv(L.far_, b, ar);
-                if (VEL) stv(L.fvr, b, vr);
-            }
-        }
-        WSYNC();
-    }
-    PHASE(11);      // (profile builds) the level loop alone; phase 0 minus this = sin / cos
-}
-#endif
 
 template <int NMAX, bool GENERIC>
 __device__ __forceinline__ void wave_substep(const mg_walker_topology &tp, const ModelW &m, const mg_walker_params &prm,
-                                             const WaveLds &L, int lane, int max_depth, int maxr,
+                                             const WaveLds &L, int lane, int maxr,
                                              unsigned long long (&touch)[2], const ActLane &act, double *log_row, int n_envs,
                                              double *foot_force, int nf, const double *ext_wrench) {
     const int nb = m.nb, nj = m.nj, ns = m.ns, n = 6 + nj;
@@ -1070,7 +1001,7 @@ __device__ __forceinline__ void wave_substep(const mg_walker_topology &tp, const
     if (prm.actuation != 0 && lane < nj)      // read by lane 6 + j after the kinematics' barriers
         L.tau[lane] = GENERIC ? actuator_torque_lane(prm, lane, L.q[lane], L.qd[lane], act)
                               : actuator_torque(prm, lane, L.q[lane], L.qd[lane], act.q_des);
-    wave_kinematics<GENERIC>(m, L, lane, max_depth, true);
+    wave_kinematics<GENERIC>(m, L, lane, true);
     PHASE(0);
     // ---- M and h by the composite-rigid-body algorithm (Featherstone RBDA ch. 6) in world coordinates, all spatial
     //      quantities taken about the base origin O so that subtree sums are plain sums:
@@ -1702,14 +1633,13 @@ __global__ __launch_bounds__(WV) __attribute__((amdgpu_waves_per_eu((NMAX <= 14 
     constexpr bool GENERIC = SH::nb == 0;      // shape-generic instantiation: terrain, > 64 proxies, per-proxy friction, body damping
     const WaveLds L = carve(slab, nb, nj, ns, maxr, overlay, GENERIC ? 15 : 12, scan_rounds & 0xff, scan_rounds >> 8);
     // topology-only tables, built once per launch, lane-parallel (lane = body / joint): a body's first joint and joint
-    // count, its tree depth, the joints on its chain (mask), its subtree (kids), the body every generalized coordinate
+    // count, the joints on its chain (mask), its subtree (kids), the body every generalized coordinate
     // sits on (dbody)
     if (lane < nb) {
         L.parent[lane] = tp.body_parent[lane];
         L.jstart[lane] = 0; L.jcount[lane] = 0; L.kids[lane] = 0;
     }
     if (lane < 6) L.dbody[lane] = 0;
-    if (lane == 0) L.misc[0] = 0;
     for (int g = lane; g < ns; g += WV) {
         L.sbody[g] = tp.sphere_body[g];
         L.sfoot[g] = tp.sphere_foot[g];
@@ -1725,16 +1655,12 @@ __global__ __launch_bounds__(WV) __attribute__((amdgpu_waves_per_eu((NMAX <= 14 
     if (lane < nb && L.jcount[lane] > 0) L.jcount[lane] -= L.jstart[lane];
     WSYNC();
     if (lane < nb) {
-        int d = -1;
         unsigned mk = 0;
         for (int x = lane; x >= 0; x = L.parent[x]) {
             mk |= ((1u << L.jcount[x]) - 1u) << L.jstart[x];
-            ++d;
+            atomicOr(&L.kids[x], 1 << lane);      // kids[x]: the bodies of x's subtree, x included
         }
-        L.depth[lane] = d;
         L.mask[lane] = (int)mk;
-        atomicMax(&L.misc[0], d);
-        for (int x = lane; x >= 0; x = L.parent[x]) atomicOr(&L.kids[x], 1 << lane);      // kids[x]: the bodies of x's subtree, x included
     }
     WSYNC();
     {   // scan tables of the kinematics pass (topology only; lane = hop / joint / body)
@@ -1791,7 +1717,6 @@ __global__ __launch_bounds__(WV) __attribute__((amdgpu_waves_per_eu((NMAX <= 14 
         L.tau[lane] = prm.actuation != 0 ? 0.0 : motor_torque(prm, m.motor()[lane], action[(size_t)e * nj + lane]);
     }
     WSYNC();
-    const int max_depth = L.misc[0];
     unsigned long long touch[2] = {0ull, 0ull};     // proxies in contact with the ground / terrain in the last sub-step
 #ifdef MG_WALKER_PROFILE
     unsigned long long ph_k0 = __builtin_readcyclecounter();
@@ -1811,7 +1736,7 @@ __global__ __launch_bounds__(WV) __attribute__((amdgpu_waves_per_eu((NMAX <= 14 
     }
     for (int it = 0; it < prm.frame_skip; ++it) {
         double *log_row = prm.substep_log ? prm.substep_log + ((size_t)it * (3 * nj + 7)) * n_envs + e : nullptr;
-        wave_substep<NMAX, GENERIC>(tp, m, prm, L, lane, max_depth, maxr, touch, act, log_row, n_envs,
+        wave_substep<NMAX, GENERIC>(tp, m, prm, L, lane, maxr, touch, act, log_row, n_envs,
                                     (st.foot_force != nullptr && it == prm.frame_skip - 1) ? st.foot_force + e : nullptr, nf,
                                     (GENERIC && prm.ext_wrench != nullptr && it == 0) ? prm.ext_wrench + e : nullptr);
     }
@@ -1831,7 +1756,7 @@ __global__ __launch_bounds__(WV) __attribute__((amdgpu_waves_per_eu((NMAX <= 14 
     float *ob = obs + (size_t)e * obs_dim;
     float head[8];
     auto calc_state = [&](bool after_reset, double &dist, int &at_limit, bool &all_finite) {
-        wave_kinematics<false>(m, L, lane, max_depth, false);
+        wave_kinematics<false>(m, L, lane, false);
         const int pw = lane < nb ? part_weight(tp, lane) : 0;
         const double sxm = wave_sum(pw * (lane < nb ? L.o[3 * lane] : 0.0)), sym = wave_sum(pw * (lane < nb ? L.o[3 * lane + 1] : 0.0));
         const int parts = (int)wave_sum((double)pw) + (prm.floor_in_parts ? 1 : 0);
