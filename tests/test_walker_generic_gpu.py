@@ -57,12 +57,13 @@ ROBOTS = {"4 hinges (10 dof, <14, any>)": [[1], [1], [1], [1]],
           "stiff: 4 one-hinge legs, joint chains one joint deep": [[1]] * 4}
 
 
-@pytest.mark.parametrize("name", list(ROBOTS) + ["self-collision: " + k for k in list(ROBOTS)[3:5]])
+@pytest.mark.parametrize("name", list(ROBOTS) + ["self-collision: " + k for k in list(ROBOTS)[3:5]] +
+                         ["lane mapping: " + k for k in (list(ROBOTS)[0], list(ROBOTS)[4])])
 def test_generic_robot_follows_the_oracle(name):
     import metagym_amd.metalocomotion as ml
     from metagym_amd.metalocomotion.mjcf import load_mjcf
-    selfc = name.startswith("self-collision: ")
-    legs = ROBOTS[name[len("self-collision: "):] if selfc else name]
+    selfc, lane_map = name.startswith("self-collision: "), name.startswith("lane mapping: ")
+    legs = ROBOTS[name.split(": ", 1)[1] if (selfc or lane_map) else name]
     text, feet = _centipede(legs)
     m = load_mjcf(text, foot_names=feet)
     nj = sum(sum(l) for l in legs)
@@ -78,7 +79,7 @@ def test_generic_robot_follows_the_oracle(name):
         initial_z = None
 
     n = 6
-    kw = {}
+    kw = {"mapping": "lane"} if lane_map else {}
     env = Centipede(num_envs=n, device="cuda:0", max_steps=1000, self_collision=selfc, **kw)
     env.set_task([m])
     rs = np.random.RandomState(len(legs) * 100 + nj)
