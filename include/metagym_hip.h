@@ -347,7 +347,8 @@ int mg_maze3d_step(const mg_maze_tasks *tasks, const mg_maze_view *view, int32_t
 /* Topology shared by every task of a batch (all MetaLocomotion variants of one robot share it). */
 typedef struct mg_walker_topology {
     int32_t n_bodies, n_joints, n_spheres, n_feet;
-    int32_t body_parent[MG_WALKER_MAX_BODIES];     /* -1 for the floating base (body 0) */
+    int32_t body_parent[MG_WALKER_MAX_BODIES];     /* -1 for the floating base (body 0); a parent comes before its children
+                                                      (body_parent[b] < b), else MG_ERR_BAD_CONFIG */
     int32_t joint_body[MG_WALKER_MAX_JOINTS];      /* non-decreasing; joints of a body act in order */
     int32_t sphere_body[MG_WALKER_MAX_SPHERES];    /* collision spheres (capsule end caps, sphere geoms) */
     int32_t foot_body[MG_WALKER_MAX_FEET];         /* bodies whose ground contact sets feet_contact */

@@ -135,6 +135,31 @@ def test_walker_wave_mapping_rejects_topologies_its_lds_scratch_cannot_hold():
     assert b"mapping = lane" in lib.mg_last_error()
 
 
+def test_walker_wave_mapping_rejects_a_body_listed_before_its_parent():
+    """The kinematics scans (and the lane-parallel topology tables) walk body_parent[] upwards and rely on parents
+    coming first, like the reference's MJCF / URDF traversal orders produce them: a topology that breaks the rule is
+    refused by the host-side validation (no GPU needed), not run into an endless walk on the device."""
+    import ctypes as C
+    from metagym_amd import _lib
+    lib = _lib.load()
+    tp = _lib.WalkerTopology()
+    tp.n_bodies, tp.n_joints, tp.n_spheres, tp.n_feet = 3, 2, 0, 0
+    tp.body_parent[0], tp.body_parent[1], tp.body_parent[2] = -1, 2, 0          # body 1 hangs off body 2
+    tp.joint_body[0], tp.joint_body[1] = 1, 2
+    ms = _lib.WalkerModels()
+    fake = C.create_string_buffer(8)
+    ms.table, ms.n_tasks, ms.model_stride = C.addressof(fake), 1, 25 * 3 + 12 * 2
+    prm = _lib.WalkerParams()
+    prm.time_step, prm.frame_skip, prm.solver_iterations, prm.mapping = 0.005, 4, 5, 1
+    st = _lib.WalkerState()
+    for name, _ in _lib.WalkerState._fields_:
+        setattr(st, name, C.addressof(fake))
+    p = C.c_void_p(C.addressof(fake))
+    rc = lib.mg_walker_step(tp, ms, prm, 4, st, p, p, p, None, p, None)
+    assert rc == -1003, rc                                       # MG_ERR_BAD_CONFIG
+    assert b"parents come first" in lib.mg_last_error()
+
+
 def test_public_header_is_plain_c99(tmp_path):
     """The boundary is a C ABI: include/metagym_hip.h must compile as C99 (no C++-isms, no HIP or torch types)
     and a C program must be able to link the shared library's symbols."""
