@@ -6,7 +6,9 @@
  * (metalocomotion/envs/utils/scene_bases.py:45-50), which is not in its tree. What is restated is this repo's own engine,
  * the algorithm of metagym_amd/csrc/walker.hip's wave kernel step for step — composite-rigid-body M and bias about the
  * base origin, Cholesky, free motion, ground / self-collision / joint-limit rows, projected Gauss-Seidel in Cholesky-whitened
- * velocities, semi-implicit Euler — so the flop count is that of the algorithm the GPU executes. It is pinned to the
+ * velocities, semi-implicit Euler — so the flop count is that of the algorithm the GPU executes (the kernel reaches the
+ * same kinematics and subtree sums by parallel scans, which spend redundant lane-operations a serial count does not have:
+ * the count is the algorithm's work, a lower bound on the kernel's). It is pinned to the
  * numpy restatement oracle/abd.py (same physics in Jacobian form) to 1e-12 by tests/test_oracle_walker_c.py, and abd.py to
  * physical invariants and the HIP kernels.
  * The Python-side rules around the physics ARE the reference's and are restated exactly like abd.WalkerEnv:
