@@ -732,7 +732,6 @@ struct WaveLds {   // pointers into the env's LDS slab
     double *base;                            // pos[3] rot[9] vel[3] omega[3]
     double *J, *bias, *diag, *lam;            // J: constraint rows, whitened in place (Jh = J L^-T)
     double *cx;                              // per contact: ground (x, y, depth) or self (point xc, normal)
-    double *sc;                              // sin / cos of every joint angle
     int *mask, *depth, *jstart, *jcount, *kids, *kind, *partner, *csphere, *misc, *dbody;
     int *parent, *sbody, *sfoot;             // topology tables copied out of the kernarg segment: body_parent, sphere_body, sphere_foot
     // scan tables of the kinematics pass (wave_kinematics): a "hop" is one rigid transform of the chain — the fixed
@@ -748,25 +747,24 @@ struct WaveLds {   // pointers into the env's LDS slab
 //     J M^-1 J^T = Jh Jh^T,   J u = Jh y,   u += M^-1 J^T dl  <=>  y += Jh^T dl,
 // so ONE constraint matrix Jh (maxr rows of n doubles) replaces both J and W = M^-1 J^T, and a row costs one
 // forward substitution instead of a forward and a backward one. Blocks with disjoint lifetimes share storage:
-//  * the Jh block is scratch while M and h are assembled: the composite-rigid-body tables (16 doubles per body,
-//    12 per generalized coordinate) at its start, the velocity-product frames of the Newton-Euler pass
-//    (fw/fal/fxr/far: 12 doubles per body) at its end — all dead before the first constraint row is written
+//  * the Jh block is scratch until the first constraint row is written: the hop transforms and scan buffers of the
+//    kinematics pass (12 doubles per hop), then the composite-rigid-body tables (16 doubles per body, 12 per generalized
+//    coordinate), then the capsules' world end points of the self-collision pass, all from its start; the velocity-
+//    product frames (fw/fal/fxr/far: 12 doubles per body, + v_ref in the shape-generic kernels) at its end
 //    (`overlay` says whether the frames fit too; mg_walker_step computes it from the topology);
 //  * the solver's reciprocal diagonals and multipliers (diag, lam: 2 maxr doubles) are first written after the
 //    constraint rows are complete, when the body frames R / o / c (15 doubles per body) are dead until the
 //    next kinematics pass;
-//  * sin / cos of the joint angles live only inside the kinematics pass, the contact points only between
-//    detection and the Jacobian rows: one block serves both;
 //  * M and its Cholesky factor are only ever touched in the lower triangle: packed.
-// Humanoid: 33.2 KB in the first layout (4 envs per CU) -> 17.4 KB; the register file (2 waves per SIMD)
-// then caps the kernel at 8 envs per CU.
+// Humanoid: 33.2 KB in the first layout (4 envs per CU) -> 18.3 KB with the scan tables; the register file (2 waves per
+// SIMD) then caps the kernel at 8 envs per CU.
 __host__ __device__ inline bool wave_lds_alias2(int nb, int maxr) { return 2 * (size_t)maxr <= 15 * (size_t)nb; }
 // fd: doubles per body of velocity-product frames — 12 (w, alpha, x_ref, a_ref), 15 in the shape-generic kernels (+ v_ref)
 __host__ __device__ inline size_t wave_lds_doubles(int nb, int nj, int maxr, bool overlay, int fd = 12) {
     const int n = 6 + nj;
     return (size_t)nb * 15 + (size_t)nj * 6 + (overlay ? 0 : fd * (size_t)nb) + (size_t)n * (n + 1) / 2 + 2 * (size_t)n +
            3 * (size_t)nj + 18 + (size_t)maxr * n + (wave_lds_alias2(nb, maxr) ? 1 : 3) * (size_t)maxr +
-           6 * (size_t)W_MAXC + (2 * (size_t)nj <= 6 * (size_t)W_MAXC ? 0 : 2 * (size_t)nj);
+           6 * (size_t)W_MAXC;
 }
 __host__ __device__ inline size_t wave_lds_ints(int nb, int nj, int ns, int maxr, int rh, int jr) {
     return 6 * (size_t)nb + 2 * (size_t)ns + 2 * (size_t)maxr + 2 * W_MAXC + 8 + ND +
@@ -795,8 +793,6 @@ __device__ __forceinline__ WaveLds carve(unsigned char *smem, int nb, int nj, in
     if (wave_lds_alias2(nb, maxr)) { L.diag = L.R; L.lam = L.R + maxr; }
     else { L.diag = d; d += maxr; L.lam = d; d += maxr; }
     L.cx = d; d += 6 * W_MAXC;
-    if (2 * nj <= 6 * W_MAXC) L.sc = L.cx;
-    else { L.sc = d; d += 2 * nj; }
     int *i = reinterpret_cast<int *>(d);
     L.mask = i; i += nb; L.depth = i; i += nb; L.jstart = i; i += nb; L.jcount = i; i += nb; L.kids = i; i += nb;
     L.kind = i; i += maxr; L.partner = i; i += maxr; L.csphere = i; i += 2 * W_MAXC; L.misc = i; i += 8; L.dbody = i; i += ND;
@@ -828,7 +824,7 @@ __device__ __forceinline__ V3 wjac_ang(const WaveLds &L, unsigned mk, int d) {
     return ldv(L.a, j);
 }
 
-// kinematics + velocity-product frames, bodies of one tree level in parallel (lane = body)
+// Rodrigues rotation from the sine and cosine of the angle
 __device__ __forceinline__ void rodrigues_sc(V3 k, double s, double c, double *R) {
     const double v = 1.0 - c;
     R[0] = c + k.x * k.x * v;       R[1] = k.x * k.y * v - k.z * s; R[2] = k.x * k.z * v + k.y * s;
@@ -1007,7 +1003,7 @@ __device__ __forceinline__ void wave_substep(const mg_walker_topology &tp, const
     //      quantities taken about the base origin O so that subtree sums are plain sums:
     //        body b:  mass m, first moment m r, inertia about O  I_O = I_c + m (|r|^2 1 - r r^T),  r = c_b - O,
     //                 bias wrench (F, N_O = N + r x F) of the velocity-product accelerations;
-    //        subtree(b) = own + children, pulled level by level from the leaves;
+    //        subtree(b) = own + every descendant, one item per (body, component) over the subtree's bit mask;
     //        dof d on body b_d:  S_d = (v_O, w) = velocity of the point at O and angular velocity per unit u_d,
     //                 F_d = I^c_subtree(b_d) S_d = (m v + w x mr,  mr x v + I_O w),   h_d = S_d . (F, N_O)^c;
     //        M[d][e] = S_e . F_d  when dof e lies on the chain from the base to b_d (e <= d), else 0.
