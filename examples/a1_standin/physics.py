@@ -32,8 +32,8 @@ class StandinPhysics(object):
     def __init__(self, num_envs, device="cuda:0", solver_iterations=23, fused=True):
         # locomotion_gym_env.py:113-114: 300 / 13 = 23 solver iterations; 2 ms steps (locomotion_gym_config.py:18)
         self.env = _StandinWalker(num_envs=num_envs, device=device, frame_skip=1, time_step=0.002, max_steps=2 ** 30,
-                                  solver_iterations=solver_iterations, self_collision=False)
-        self.env.set_task([load_mjcf(XML, foot_names=FEET)])
+                                  solver_iterations=solver_iterations, self_collision=False, preset="mujoco")
+        self.env.set_task([load_mjcf(XML, foot_names=FEET, preset="mujoco")])      # the stand-in's MJCF means what MuJoCo says it means
         self.n, self.device = int(num_envs), torch.device(device)
         self._init = torch.as_tensor(np.tile(INIT_MOTOR_ANGLES, (self.n, 1)), dtype=torch.float64, device=self.device)
         if fused:                                  # A1GymEnv takes the one-launch path when the physics offers it

@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define MG_ABI_VERSION 4
+#define MG_ABI_VERSION 5
 
 #define MG_OK 0
 #define MG_ERR_NULL_POINTER (-1001)
@@ -447,8 +447,9 @@ typedef struct mg_walker_params {
     const double *sphere_friction;
     /* Velocity damping of every body, btMultiBody's m_linearDamping / m_angularDamping (default 0.04 each, what
      * pybullet.changeDynamics documents): force -m v (k + k |v|) at the centre of mass, torque -I w (k + k |w|). 0 = off.
-     * Shape-generic wave kernels only. The quadrupedal reference switches it off (minitaur.py:346-353 at :419); MetaLocomotion
-     * never touches it, so PyBullet's default applies there — an option of metalocomotion.mjcf / WalkerBatchEnv. */
+     * The quadrupedal reference switches it off (minitaur.py:346-353 at :419); MetaLocomotion never touches it, so PyBullet's
+     * default applies there — the `preset="bullet"` default of metalocomotion.mjcf / WalkerBatchEnv (the two tuned wave kernels
+     * have a damped instantiation each; the lane mapping carries it too). */
     double body_linear_damping, body_angular_damping;
     const double *pd_kp_env, *pd_kd_env;
     /* External push on the base body during the FIRST sub-step of the launch only (shape-generic kernels; NULL = none):
@@ -457,6 +458,19 @@ typedef struct mg_walker_params {
      * external forces after every stepSimulation (RandomWrapper, quadrupedal/envs/env_wrappers/MonitorEnv.py:530-535,644-660;
      * the caller adds the root link's inertial offset to pos: PyBullet's link frame is the inertial frame). */
     const double *ext_wrench;
+    /* (ABI 5) btMultiBody's m_maxCoordinateVelocity (default 100, never changed by the reference): at the end of every sub-step
+     * each of the 6 + nj generalized velocities is clamped to [-v, v] before the positions are integrated — the
+     * processDeltaVeeMultiDof2 -> applyDeltaVeeMultiDof application; Bullet clamps the unconstrained velocities the same way,
+     * which is not restated. 0 = off (the `preset="mujoco"` world). All three mappings. */
+    double max_coordinate_velocity;
+    /* (ABI 5) Per-robot terrains: with terrain_id != NULL, `terrain` is a TABLE of n_terrain_tables courses of n_terrain_boxes
+     * boxes each — DEVICE f64 [n_terrain_tables][n_terrain_boxes][MG_WALKER_BOX_DOUBLES], shorter courses padded with boxes of zero
+     * half extents parked far away (x = 1e30) — and robot e stands on course terrain_id[e] (DEVICE i32 [N], read at launch
+     * time: a masked reset may rewrite entries to move robots to another course, the maze task-table pattern). What
+     * LocomotionGymEnv.reset(hardset=True, mode=..., ...) does per episode for ONE robot (quadrupedal/envs/
+     * locomotion_gym_env.py:297-301): a new terrain task per episode. NULL: one course for the whole batch, as before. */
+    const int32_t *terrain_id;
+    int32_t n_terrain_tables;
 } mg_walker_params;
 
 /* Per-env state, SoA doubles: component c of env e at base[c*N + e]. */

@@ -8,7 +8,7 @@ import os
 
 from . import build as _build
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 MG_OK = 0
 
@@ -124,7 +124,8 @@ class WalkerParams(C.Structure):
                 ("pd_strength", C.c_double * WALKER_MAX_JOINTS), ("pd_limit", C.c_double * WALKER_MAX_JOINTS),
                 ("substep_log", C.c_void_p), ("n_terrain_boxes", C.c_int32), ("terrain", C.c_void_p),
                 ("sphere_friction", C.c_void_p), ("body_linear_damping", C.c_double), ("body_angular_damping", C.c_double),
-                ("pd_kp_env", C.c_void_p), ("pd_kd_env", C.c_void_p), ("ext_wrench", C.c_void_p)]
+                ("pd_kp_env", C.c_void_p), ("pd_kd_env", C.c_void_p), ("ext_wrench", C.c_void_p),
+                ("max_coordinate_velocity", C.c_double), ("terrain_id", C.c_void_p), ("n_terrain_tables", C.c_int32)]
 
 
 class WalkerState(C.Structure):

@@ -205,7 +205,7 @@ __device__ __forceinline__ V3 jac_ang(const Kin &k, unsigned mk, int d) {
 // Jacobians: M = sum_b m Jv^T Jv + Jw^T I Jw (+ armature), h = sum_b Jv^T m (a_c - g) + Jw^T (I alpha + w x I w)
 // where (alpha, a_c) are the velocity-product accelerations (du/dt = 0).
 __device__ void mass_and_bias(const mg_walker_topology &tp, const ModelRef &m, const Env &s, const Kin &k,
-                              double gravity, double *M, double *h, int n) {
+                              double gravity, double k_lin, double k_ang, double *M, double *h, int n) {
     const int nb = tp.n_bodies, nj = tp.n_joints;
     for (int i = 0; i < n * n; ++i) M[i] = 0.0;
     for (int i = 0; i < n; ++i) h[i] = 0.0;
@@ -234,10 +234,19 @@ __device__ void mass_and_bias(const mg_walker_topology &tp, const ModelRef &m, c
             for (int c0 = 0; c0 < 3; ++c0) Rt[3 * r0 + c0] = k.R[b][3 * c0 + r0];
         mulMM(RI, Rt, Iw);
         const double mass = m.body_mass[b];
-        const V3 F = mass * (a_c - v3(0, 0, -gravity));
+        V3 F = mass * (a_c - v3(0, 0, -gravity));
         const V3 Iw_w = mulMv(Iw, w);
-        const V3 Nn = mulMv(Iw, al) + cross(w, Iw_w);
+        V3 Nn = mulMv(Iw, al) + cross(w, Iw_w);
         const unsigned mk = k.mask[b];
+        if (k_lin != 0.0 || k_ang != 0.0) {
+            // btMultiBody's velocity damping (mg_walker_params.body_*_damping): force -m v_c (k + k |v_c|) at the centre of mass,
+            // torque -I w (k + k |w|); their negatives join the bias wrench. v_c = Jv(c_b) u.
+            V3 vc = s.vel + cross(s.omega, k.c[b] - k.o[0]);
+            for (int jj = 0; jj < nj; ++jj)
+                if ((mk >> jj) & 1u) vc = vc + s.qd[jj] * cross(k.a[jj], k.c[b] - k.p[jj]);
+            F = F + (mass * (k_lin + k_lin * sqrt(dot(vc, vc)))) * vc;
+            Nn = Nn + (k_ang + k_ang * sqrt(dot(w, w))) * Iw_w;
+        }
         for (int d = 0; d < n; ++d) {
             if (d >= 6 && !((mk >> (d - 6)) & 1u)) continue;
             const V3 jv = jac_lin(k, mk, k.c[b], d), jw = jac_ang(k, mk, d);
@@ -289,7 +298,7 @@ __device__ void substep(const mg_walker_topology &tp, const ModelRef &m, const m
     Kin k;
     kinematics(tp, m, s, k);
     double M[ND * ND], h[ND], u[ND];
-    mass_and_bias(tp, m, s, k, prm.gravity, M, h, n);
+    mass_and_bias(tp, m, s, k, prm.gravity, prm.body_linear_damping, prm.body_angular_damping, M, h, n);
     cholesky(M, n);
     // free motion: u* = u + dt M^-1 (tau - h); explicit damping / spring torques like the oracle
     double rhs[ND];
@@ -392,6 +401,8 @@ __device__ void substep(const mg_walker_topology &tp, const ModelRef &m, const m
             for (int d = 0; d < n; ++d) u[d] += W[r][d] * dl;
         }
     // ---- integrate ------------------------------------------------------------------------------
+    if (prm.max_coordinate_velocity > 0.0)        // btMultiBody::applyDeltaVeeMultiDof's clamp (mg_walker_params.max_coordinate_velocity)
+        for (int d = 0; d < n; ++d) u[d] = fmin(fmax(u[d], -prm.max_coordinate_velocity), prm.max_coordinate_velocity);
     s.vel = v3(u[0], u[1], u[2]);
     s.omega = v3(u[3], u[4], u[5]);
     for (int j = 0; j < nj; ++j) { s.qd[j] = u[6 + j]; s.q[j] += dt * s.qd[j]; }
@@ -538,11 +549,16 @@ __global__ __launch_bounds__(WK_BLOCK) void walker_step_kernel(mg_walker_topolog
     double dist;
     int at_limit;
     observe(tp, m, prm, s, fc, ob, dist, at_limit);
-    for (int f = 0; f < nf; ++f) {
+    for (int f = 0; f < nf; ++f) {        // which flag a proxy reports to: mg_walker_topology.sphere_foot, like the wave kernels
         float c = 0.0f;
         for (int g = 0; g < tp.n_spheres; ++g)
-            if (((touch >> g) & 1ull) && tp.sphere_body[g] == tp.foot_body[f]) c = 1.0f;
+            if (((touch >> g) & 1ull) && tp.sphere_foot[g] == f) c = 1.0f;
         st.feet_contact[(size_t)f * n_envs + e] = c;
+    }
+    if (st.bad_contacts != nullptr) {     // a1.py:314-323 GetBadFootContacts: contact points on links that are no foot
+        int bad = 0;
+        for (int g = 0; g < tp.n_spheres; ++g) bad += (((touch >> g) & 1ull) && tp.sphere_foot[g] < 0) ? 1 : 0;
+        st.bad_contacts[e] = bad;
     }
     const double alive = (alive_height(prm, ob[0]) > prm.alive_z) ? prm.alive_bonus : prm.dead_bonus;   // :47
     bool finite = true;
@@ -637,8 +653,10 @@ constexpr int W_MAXC = 12;   // ground contacts kept per env (first W_MAXC penet
 // and with the shape known at compile time every LDS address and every model-table offset below is a literal in the
 // instruction. Computed at run time they were ~40 LDS pointers and 18 table pointers held in SGPRs for the whole
 // sub-step: 413 SGPR spills to VGPR lanes in the humanoid kernel (v_writelane / v_readlane on the hot path).
-template <int B, int J, int S, int G, int OVL>
-struct Shape { static constexpr int nb = B, nj = J, ns = S, ng = G, overlay = OVL; };
+// DMP = 1: the tuned kernel also carries btMultiBody's body velocity damping (the `preset="bullet"` world of the MetaLocomotion
+// envs): the frames keep v_ref (15 instead of 12 doubles per body), everything else is the tuned kernel.
+template <int B, int J, int S, int G, int OVL, int DMP = 0>
+struct Shape { static constexpr int nb = B, nj = J, ns = S, ng = G, overlay = OVL, damp = DMP; };
 using ShapeAny = Shape<0, 0, 0, 0, -1>;
 // shape-generic, but with the joint count fixed (= every slot of the NMAX-slot register arrays in use): the `slot < n`
 // tests of the unrolled Cholesky / substitution code fold away (a scalar compare + branch each otherwise)
@@ -982,11 +1000,11 @@ __device__ __forceinline__ void wave_kinematics(const ModelW &m, const WaveLds &
     PHASE(11);
 }
 
-template <int NMAX, bool GENERIC>
+template <int NMAX, bool GENERIC, bool VELF>
 __device__ __forceinline__ void wave_substep(const mg_walker_topology &tp, const ModelW &m, const mg_walker_params &prm,
                                              const WaveLds &L, int lane, int maxr,
                                              unsigned long long (&touch)[2], const ActLane &act, double *log_row, int n_envs,
-                                             double *foot_force, int nf, const double *ext_wrench) {
+                                             double *foot_force, int nf, const double *ext_wrench, const double *terrain) {
     const int nb = m.nb, nj = m.nj, ns = m.ns, n = 6 + nj;
     const double dt = prm.time_step;
     // A fresh copy of the lane id per sub-step: the ~140 lane predicates of the unrolled Cholesky / substitution
@@ -997,7 +1015,7 @@ __device__ __forceinline__ void wave_substep(const mg_walker_topology &tp, const
     if (prm.actuation != 0 && lane < nj)      // read by lane 6 + j after the kinematics' barriers
         L.tau[lane] = GENERIC ? actuator_torque_lane(prm, lane, L.q[lane], L.qd[lane], act)
                               : actuator_torque(prm, lane, L.q[lane], L.qd[lane], act.q_des);
-    wave_kinematics<GENERIC>(m, L, lane, true);
+    wave_kinematics<VELF>(m, L, lane, true);
     PHASE(0);
     // ---- M and h by the composite-rigid-body algorithm (Featherstone RBDA ch. 6) in world coordinates, all spatial
     //      quantities taken about the base origin O so that subtree sums are plain sums:
@@ -1032,7 +1050,7 @@ __device__ __forceinline__ void wave_substep(const mg_walker_topology &tp, const
         const double mass = m.body_mass()[b];
         V3 F = mass * (a_c - v3(0, 0, -prm.gravity));
         V3 N = Ic(al) + cross(w, Ic(w));
-        if (GENERIC && (prm.body_linear_damping != 0.0 || prm.body_angular_damping != 0.0)) {
+        if (VELF && (prm.body_linear_damping != 0.0 || prm.body_angular_damping != 0.0)) {
             // btMultiBody's velocity damping (mg_walker_params.body_*_damping): an external force -m v (k + k |v|) at the
             // centre of mass and torque -I w (k + k |w|), i.e. their negatives join the bias wrench
             const V3 vc = ldv(L.fvr, b) + cross(w, rx);
@@ -1250,7 +1268,8 @@ __device__ __forceinline__ void wave_substep(const mg_walker_topology &tp, const
         touch[GENERIC ? ch : 0] = __ballot(kept);
         ncont = min(ncont + __popcll(hits), W_MAXC);
     }
-    // terrain: lane = collision proxy against the static boxes (the same for every env; wave-uniform loop, boxes whose
+    // terrain: lane = collision proxy against the static boxes (`terrain`: the batch's one course, or this env's course of
+    // the terrain table, mg_walker_params.terrain_id; wave-uniform loop either way: one wave = one env; boxes whose
     // x range misses the chunk's proxies are skipped by the whole wave); per proxy the deepest box, first on ties. Slots
     // after the ground contacts; the friction rows carry the contact's coefficient in their (otherwise zero) bias slot, kind -1.
     if (GENERIC && prm.n_terrain_boxes > 0)
@@ -1271,7 +1290,7 @@ __device__ __forceinline__ void wave_substep(const mg_walker_topology &tp, const
             double bdepth = 0.0, bmu = 0.0;
             V3 bn{0, 0, 1}, bx{0, 0, 0};
             for (int bi = 0; bi < prm.n_terrain_boxes; ++bi) {
-                const double *B = prm.terrain + (size_t)MG_WALKER_BOX_DOUBLES * bi;
+                const double *B = terrain + (size_t)MG_WALKER_BOX_DOUBLES * bi;
                 const V3 bp{B[0], B[1], B[2]}, bh{B[12], B[13], B[14]};
                 const double ex = fabs(B[3]) * bh.x + fabs(B[4]) * bh.y + fabs(B[5]) * bh.z;      // world x half extent
                 if (bp.x + ex < lo || bp.x - ex > hi) continue;
@@ -1545,6 +1564,8 @@ __device__ __forceinline__ void wave_substep(const mg_walker_topology &tp, const
         }
     }
     // ---- integrate -------------------------------------------------------------------------------------
+    if (prm.max_coordinate_velocity > 0.0)        // btMultiBody::applyDeltaVeeMultiDof's clamp (mg_walker_params.max_coordinate_velocity)
+        u_d = fmin(fmax(u_d, -prm.max_coordinate_velocity), prm.max_coordinate_velocity);
     if (lane < n) {
         if (lane >= 6) {
             const int j = lane - 6;
@@ -1626,8 +1647,9 @@ __global__ __launch_bounds__(WV) __attribute__((amdgpu_waves_per_eu((NMAX <= 14 
     unsigned slab_off = 0;
     asm volatile("" : "+v"(slab_off));
     unsigned char *slab = smem + slab_off;
-    constexpr bool GENERIC = SH::nb == 0;      // shape-generic instantiation: terrain, > 64 proxies, per-proxy friction, body damping
-    const WaveLds L = carve(slab, nb, nj, ns, maxr, overlay, GENERIC ? 15 : 12, scan_rounds & 0xff, scan_rounds >> 8);
+    constexpr bool GENERIC = SH::nb == 0;      // shape-generic instantiation: terrain, > 64 proxies, per-proxy friction
+    constexpr bool VELF = GENERIC || SH::damp != 0;     // frames keep v_ref: body velocity damping available
+    const WaveLds L = carve(slab, nb, nj, ns, maxr, overlay, VELF ? 15 : 12, scan_rounds & 0xff, scan_rounds >> 8);
     // topology-only tables, built once per launch, lane-parallel (lane = body / joint): a body's first joint and joint
     // count, the joints on its chain (mask), its subtree (kids), the body every generalized coordinate
     // sits on (dbody)
@@ -1717,6 +1739,10 @@ __global__ __launch_bounds__(WV) __attribute__((amdgpu_waves_per_eu((NMAX <= 14 
 #ifdef MG_WALKER_PROFILE
     unsigned long long ph_k0 = __builtin_readcyclecounter();
 #endif
+    // this env's terrain course (mg_walker_params.terrain_id: a table of courses, one per robot; else the batch's one course)
+    const double *terrain = prm.terrain;
+    if (GENERIC && prm.terrain_id != nullptr)
+        terrain += (size_t)__builtin_amdgcn_readfirstlane(prm.terrain_id[e]) * prm.n_terrain_boxes * MG_WALKER_BOX_DOUBLES;
     ActLane act{0.0, 0.0, 0.0, 0.0, 0.0};
     if (prm.actuation != 0 && lane < nj) {
         if (GENERIC && prm.actuation == 3) {          // HYBRID: desired angle, kp, desired rate, kd, additional torque
@@ -1732,9 +1758,9 @@ __global__ __launch_bounds__(WV) __attribute__((amdgpu_waves_per_eu((NMAX <= 14 
     }
     for (int it = 0; it < prm.frame_skip; ++it) {
         double *log_row = prm.substep_log ? prm.substep_log + ((size_t)it * (3 * nj + 7)) * n_envs + e : nullptr;
-        wave_substep<NMAX, GENERIC>(tp, m, prm, L, lane, maxr, touch, act, log_row, n_envs,
+        wave_substep<NMAX, GENERIC, VELF>(tp, m, prm, L, lane, maxr, touch, act, log_row, n_envs,
                                     (st.foot_force != nullptr && it == prm.frame_skip - 1) ? st.foot_force + e : nullptr, nf,
-                                    (GENERIC && prm.ext_wrench != nullptr && it == 0) ? prm.ext_wrench + e : nullptr);
+                                    (GENERIC && prm.ext_wrench != nullptr && it == 0) ? prm.ext_wrench + e : nullptr, terrain);
     }
     if (st.bad_contacts != nullptr) {       // a1.py:314-323 GetBadFootContacts: contact points on links that are no foot
         int bad = 0;
@@ -1894,6 +1920,16 @@ int check_walker(const mg_walker_topology *tp, const mg_walker_models *ms, const
                              tp->n_bodies, tp->n_joints, tp->n_spheres, tp->n_feet);
     if (tp->n_geoms < 0 || tp->n_geoms > MG_WALKER_MAX_GEOMS || tp->n_pairs < 0 || tp->n_pairs > MG_WALKER_MAX_PAIRS)
         return mg::set_error(MG_ERR_BAD_SIZE, "walker topology: geoms %d pairs %d", tp->n_geoms, tp->n_pairs);
+    for (int g = 0; g < tp->n_spheres; ++g)      // ABI 4 field: a zero-initialised topology would silently report every proxy to foot 0
+    {
+        if (tp->sphere_foot[g] < -1 || tp->sphere_foot[g] >= tp->n_feet)
+            return mg::set_error(MG_ERR_BAD_CONFIG, "walker topology: sphere_foot[%d] = %d (want -1 or a foot index < %d)", g,
+                                 tp->sphere_foot[g], tp->n_feet);
+        if (tp->sphere_foot[g] >= 0 && tp->sphere_body[g] != tp->foot_body[tp->sphere_foot[g]])
+            return mg::set_error(MG_ERR_BAD_CONFIG, "walker topology: proxy %d sits on body %d but reports to foot %d on body %d "
+                                 "(sphere_foot is new in ABI 4: -1 = no foot, else a foot whose body carries the proxy)", g,
+                                 tp->sphere_body[g], tp->sphere_foot[g], tp->foot_body[tp->sphere_foot[g]]);
+    }
     const int need = 25 * tp->n_bodies + 12 * tp->n_joints + 4 * tp->n_spheres + 7 * tp->n_geoms;
     if (!ms->table || ms->n_tasks < 1 || ms->model_stride < need)
         return mg::set_error(MG_ERR_BAD_SIZE, "walker model table: stride %d < %d", ms->model_stride, need);
@@ -1942,15 +1978,16 @@ extern "C" int mg_walker_step(const mg_walker_topology *tp, const mg_walker_mode
     if (prm->n_terrain_boxes > 0) {
         if (prm->mapping == 0) return mg::set_error(MG_ERR_UNSUPPORTED, "terrain boxes need the wave mapping");
         MG_REQUIRE_PTR(prm->terrain);
+        if (prm->terrain_id != nullptr && prm->n_terrain_tables < 1)
+            return mg::set_error(MG_ERR_BAD_SIZE, "walker terrain table: %d courses", prm->n_terrain_tables);
     }
     MG_REQUIRE_PTR(obs);
     MG_REQUIRE_PTR(reward);
     MG_REQUIRE_PTR(done);
     mg::DeviceGuard guard(mg::device_of(st->pos));
     if (prm->mapping == 0) {   // lane-per-env reference mapping (private-memory work set)
-        if (tp->n_spheres > 64 || prm->sphere_friction != nullptr || prm->body_linear_damping != 0.0 || prm->body_angular_damping != 0.0 ||
-            st->foot_force != nullptr || prm->ext_wrench != nullptr)
-            return mg::set_error(MG_ERR_UNSUPPORTED, "per-proxy friction, body damping and > 64 collision proxies need the wave mapping");
+        if (tp->n_spheres > 64 || prm->sphere_friction != nullptr || st->foot_force != nullptr || prm->ext_wrench != nullptr)
+            return mg::set_error(MG_ERR_UNSUPPORTED, "per-proxy friction, foot forces, pushes and > 64 collision proxies need the wave mapping");
         hipLaunchKernelGGL(walker_step_kernel, dim3((n + WK_BLOCK - 1) / WK_BLOCK), dim3(WK_BLOCK), 0,
                            (hipStream_t)stream, *tp, *ms, *prm, *st, n, action, obs, reward, rewards5, done);
         return mg::check_launch("walker_step_kernel");
@@ -1960,16 +1997,19 @@ extern "C" int mg_walker_step(const mg_walker_topology *tp, const mg_walker_mode
     const int maxr = 3 * W_MAXC + tp->n_joints;
     using Humanoid = Shape<13, 17, 29, 17, 1>;
     using Ant = Shape<13, 8, 25, 13, 1>;
-    // (terrain boxes, per-proxy friction, body damping and > 64 proxies are compiled into the shape-generic instantiations
-    // only: the two tuned kernels keep their registers)
-    const bool generic_only = prm->n_terrain_boxes != 0 || prm->sphere_friction != nullptr || prm->body_linear_damping != 0.0 ||
-                              prm->body_angular_damping != 0.0 || st->foot_force != nullptr || prm->actuation == 3 ||
+    using HumanoidDamped = Shape<13, 17, 29, 17, 1, 1>;     // + body velocity damping (the "bullet" preset, the envs' default)
+    using AntDamped = Shape<13, 8, 25, 13, 1, 1>;
+    // (terrain boxes, per-proxy friction and > 64 proxies are compiled into the shape-generic instantiations only: the
+    // tuned kernels keep their registers)
+    const bool damped = prm->body_linear_damping != 0.0 || prm->body_angular_damping != 0.0;
+    const bool generic_only = prm->n_terrain_boxes != 0 || prm->sphere_friction != nullptr ||
+                              st->foot_force != nullptr || prm->actuation == 3 ||
                               prm->pd_kp_env != nullptr || prm->pd_kd_env != nullptr || prm->ext_wrench != nullptr;
     auto shape_is = [&](int b, int j, int s, int g) {
         return !generic_only && tp->n_bodies == b && tp->n_joints == j && tp->n_spheres == s && tp->n_geoms == g;
     };
     bool tuned = shape_is(Humanoid::nb, Humanoid::nj, Humanoid::ns, Humanoid::ng) || shape_is(Ant::nb, Ant::nj, Ant::ns, Ant::ng);
-    int fd = tuned ? 12 : 15;           // velocity-product frame doubles per body (wave_lds_doubles)
+    int fd = (tuned && !damped) ? 12 : 15;           // velocity-product frame doubles per body (wave_lds_doubles)
     // scratch use of the Jh block during the M / h assembly: the composite-rigid-body tables from the front and, when
     // they also fit, the 12 doubles per body of velocity-product frames from the back
     bool overlay = false;
@@ -2021,8 +2061,13 @@ extern "C" int mg_walker_step(const mg_walker_topology *tp, const mg_walker_mode
 #define MG_WALKER_LAUNCH(NMAX_, SHAPE_)                                                                                  \
     hipLaunchKernelGGL((walker_step_wave_kernel<NMAX_, SHAPE_>), dim3(n), dim3(WV), lds, (hipStream_t)stream, *tp, *ms, \
                        *prm, *st, n, maxr_flags, rh | (jr << 8), action, obs, reward, rewards5, done)
-    if (is_shape(Humanoid::nb, Humanoid::nj, Humanoid::ns, Humanoid::ng)) MG_WALKER_LAUNCH(23, Humanoid);
-    else if (is_shape(Ant::nb, Ant::nj, Ant::ns, Ant::ng)) MG_WALKER_LAUNCH(14, Ant);
+    if (is_shape(Humanoid::nb, Humanoid::nj, Humanoid::ns, Humanoid::ng)) {
+        if (damped) MG_WALKER_LAUNCH(23, HumanoidDamped);
+        else MG_WALKER_LAUNCH(23, Humanoid);
+    } else if (is_shape(Ant::nb, Ant::nj, Ant::ns, Ant::ng)) {
+        if (damped) MG_WALKER_LAUNCH(14, AntDamped);
+        else MG_WALKER_LAUNCH(14, Ant);
+    }
     else if (ndof == 14) MG_WALKER_LAUNCH(14, ShapeDof<8>);
     else if (ndof < 14) MG_WALKER_LAUNCH(14, ShapeAny);
     else if (ndof == 18) MG_WALKER_LAUNCH(18, ShapeDof<12>);  // a quadruped: 6 + 12 (the A1)

@@ -2,8 +2,26 @@
 
 The reference hands the MJCF file to PyBullet (`loadMJCF`, metalocomotion/envs/utils/robot_bases.py:119),
 whose importer is not available here; this module reads the subset of MJCF the MetaLocomotion
-assets use (metalocomotion/envs/assets/humanoids/*.xml, ants/*.xml) and follows MuJoCo's documented
-semantics for it:
+assets use (metalocomotion/envs/assets/humanoids/*.xml, ants/*.xml).
+
+What the numbers in the file MEAN is a choice of `preset` (PRESETS below; DESIGN.md §3.4 has the table with the
+evidence for each row):
+
+  * `preset="bullet"` (DEFAULT) — the closest known reading of what the reference's backend does with the file:
+    link inertia recomputed from the collision shapes by the bounding-box rule (loadMJCF is called without
+    URDF_USE_INERTIA_FROM_FILE), the inertial frame left at the body origin, and the joint attributes `armature`,
+    `damping`, `stiffness` ignored: Bullet's MJCF importer reads a joint's type, axis, position, range and `limited`
+    only, and its joint record has no rotor-inertia or spring field at all. (Physical evidence for dropping `damping`
+    together with `armature`: ants/ant.xml:8 gives every ant hinge `armature="1" damping="1"`; without the armature an
+    ant leg's joint-space inertia is 0.0019 kg m^2, on which an explicit damping of 1 N m s diverges at any step above
+    3.8 ms — 5 ms here, 4.2 ms in pybullet_envs, whose ant runs on the same file.) The world adds btMultiBody's 0.04 / 0.04 linear / angular velocity damping of every link (PyBullet's
+    default, which MetaLocomotion never changes) and its clamp of every generalized velocity to +-100
+    (m_maxCoordinateVelocity; without it the ant — 0.07 kg legs, 250 N m motors, `armature="1"` gone — overflows in five
+    steps) — `Model.body_damping`, `Model.max_velocity`, picked up by the envs.
+  * `preset="mujoco"` — MuJoCo's documented semantics of the same attributes (below); what rounds 1-3 of this
+    repository ran, and what tests/golden/walker_rules.npz was recorded on.
+
+Neither can be compared with PyBullet here (parity of this path is unpinned). MuJoCo's documented semantics:
 
   * `<compiler angle="degree" inertiafromgeom="true">`: joint ranges are degrees; masses and inertia
     come from the geoms at the default density 1000 kg/m^3 (exact solid capsule / sphere formulas).
@@ -113,14 +131,45 @@ def _aabb_box_inertia(mass, geoms, com):
     return np.diag(mass / 12.0 * np.array([l[1] ** 2 + l[2] ** 2, l[0] ** 2 + l[2] ** 2, l[0] ** 2 + l[1] ** 2]))
 
 
-def load_mjcf(path_or_string, foot_names=("right_foot", "left_foot"), inertia="geom", com="geom"):
-    """inertia: 'geom' (default) — exact solid capsule / sphere tensors at the geoms' density, MuJoCo's documented
+# What each preset makes of the file; every entry can be overridden per call (load_mjcf keyword of the same name).
+PRESETS = {
+    "bullet": dict(inertia="bullet_box", com="body_origin", armature="ignore", damping="ignore", stiffness="ignore",
+                   body_damping=(0.04, 0.04), max_velocity=100.0),
+    "mujoco": dict(inertia="geom", com="geom", armature="diagonal", damping="explicit", stiffness="spring",
+                   body_damping=(0.0, 0.0), max_velocity=0.0),
+}
+DEFAULT_PRESET = "bullet"
+
+
+def preset_options(preset=None, **over):
+    """The option dict of a preset with the non-None overrides applied."""
+    preset = DEFAULT_PRESET if preset is None else preset
+    if preset not in PRESETS:
+        raise ValueError("unknown preset %r (%s)" % (preset, ", ".join(sorted(PRESETS))))
+    opt = dict(PRESETS[preset])
+    for k, v in over.items():
+        if v is not None:
+            opt[k] = v
+    return opt
+
+
+def load_mjcf(path_or_string, foot_names=("right_foot", "left_foot"), preset=None, inertia=None, com=None, armature=None,
+              damping=None, stiffness=None):
+    """preset: 'bullet' (default) | 'mujoco' — see the module docstring; the four keywords override single rows of it:
+    inertia: 'geom' — exact solid capsule / sphere tensors at the geoms' density, MuJoCo's documented
     `inertiafromgeom`; 'bullet_box' — what PyBullet's loader does with a body's shapes when it is not told to trust the
     file (robot_bases.py:119 passes no URDF_USE_INERTIA_FROM_FILE): the solid-box formula on the bounding box of the
     body's geoms, diagonal in the body's axes (btCompoundShape::calculateLocalInertia); masses stay volume x density.
     com: 'geom' — mass-weighted geom centroid (MuJoCo); 'body_origin' — the body frame's origin, where Bullet's MJCF
-    importer is believed to leave the inertial frame of a body without an <inertial> element (unverifiable here)."""
+    importer is believed to leave the inertial frame of a body without an <inertial> element (unverifiable here).
+    armature: 'diagonal' — added to the diagonal of the joint-space inertia (MuJoCo); 'ignore' — dropped.
+    damping: 'explicit' — torque -d qd evaluated at the start of the sub-step (MuJoCo's passive force, explicit here);
+    'ignore' — dropped.
+    stiffness: 'spring' — explicit torque -k q (MuJoCo, springref 0); 'ignore' — dropped."""
+    opt = preset_options(preset, inertia=inertia, com=com, armature=armature, damping=damping, stiffness=stiffness)
+    inertia, com, armature, damping, stiffness = opt["inertia"], opt["com"], opt["armature"], opt["damping"], opt["stiffness"]
     assert inertia in ("geom", "bullet_box") and com in ("geom", "body_origin")
+    assert armature in ("diagonal", "ignore") and damping in ("explicit", "ignore") and stiffness in ("spring", "ignore")
     inertia_mode, com_mode = inertia, com
     text = path_or_string
     if "<mujoco" not in text:
@@ -215,9 +264,14 @@ def load_mjcf(path_or_string, foot_names=("right_foot", "left_foot"), inertia="g
     m.joint_axis = np.array([j["axis"] for j in joints])
     m.joint_lo = np.array([j["lo"] for j in joints])
     m.joint_hi = np.array([j["hi"] for j in joints])
-    m.joint_armature = np.array([j["armature"] for j in joints])
-    m.joint_damping = np.array([j["damping"] for j in joints])
-    m.joint_stiffness = np.array([j["stiffness"] for j in joints])
+    m.joint_armature = np.array([j["armature"] if armature == "diagonal" else 0.0 for j in joints])
+    m.joint_damping = np.array([j["damping"] if damping == "explicit" else 0.0 for j in joints])
+    m.joint_stiffness = np.array([j["stiffness"] if stiffness == "spring" else 0.0 for j in joints])
+    # the world-side half of the preset: btMultiBody's (linear, angular) velocity damping of every link; the envs take it
+    # from their own `preset` / `body_damping` arguments, this copy records what the model was loaded for
+    m.body_damping = np.array(opt["body_damping"], np.float64)
+    m.max_velocity = np.array(float(opt["max_velocity"]))      # btMultiBody's m_maxCoordinateVelocity clamp (0 = off)
+    m.preset = np.array(DEFAULT_PRESET if preset is None else preset)
     m.sph_body = np.array([s[0] for s in spheres], np.int32)
     m.sph_pos = np.array([s[1] for s in spheres])
     m.sph_radius = np.array([s[2] for s in spheres])

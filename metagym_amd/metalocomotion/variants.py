@@ -25,7 +25,7 @@ import xml.etree.ElementTree as ET
 
 import numpy as np
 
-from .mjcf import load_mjcf
+from .mjcf import load_mjcf, preset_options
 
 SPLITS = {"TRAIN": "tra", "TEST": "tst", "OOD": "ood"}
 FEET = {"humanoid": ("right_foot", "left_foot"),
@@ -246,31 +246,32 @@ def task_names(robot, split):
     return ["%s_var_%s_%03d.xml" % (robot, tag, i) for i in range(len(patterns(robot, tag)))]
 
 
-def model(robot, split=None, index=0, inertia="geom", com="geom"):
-    """Parsed `Model` of the base robot (`split=None`) or of variant `index` of a split. `inertia` / `com`: the loader's
-    options (mjcf.load_mjcf: MuJoCo's documented semantics by default, Bullet's bounding-box inertia on request)."""
-    key = (robot, SPLITS.get(split, split), int(index) if split is not None else -1, inertia, com)
+def model(robot, split=None, index=0, preset=None, **options):
+    """Parsed `Model` of the base robot (`split=None`) or of variant `index` of a split. `preset` ('bullet', the default, or
+    'mujoco') and `options` (inertia / com / armature / stiffness): the loader's reading of the file, mjcf.load_mjcf."""
+    opt = preset_options(preset, **options)
+    key = (robot, SPLITS.get(split, split), int(index) if split is not None else -1) + tuple(sorted((k, str(v)) for k, v in opt.items()))
     if key not in _cache:
         pat = None if split is None else patterns(robot, split)[int(index)]
-        _cache[key] = load_mjcf(mjcf_text(robot, pat), foot_names=FEET[robot], inertia=inertia, com=com)
+        _cache[key] = load_mjcf(mjcf_text(robot, pat), foot_names=FEET[robot], preset=preset, **options)
     return _cache[key]
 
 
-def models(robot, split, inertia="geom", com="geom"):
-    return [model(robot, split, i, inertia=inertia, com=com) for i in range(len(patterns(robot, split)))]
+def models(robot, split, preset=None, **options):
+    return [model(robot, split, i, preset=preset, **options) for i in range(len(patterns(robot, split)))]
 
 
 _NAME = re.compile(r"^(humanoid|ant)(?:_var_(tra|tst|ood)_(\d{3}))?\.xml$")
 
 
-def model_from_task_name(name):
+def model_from_task_name(name, preset=None):
     """`humanoid_var_tra_017.xml` / `ant.xml` -> Model, or None if `name` is not one of the reference's file names."""
     m = _NAME.match(os.path.basename(name))
     if not m:
         return None
     robot, tag, idx = m.groups()
     if tag is None:
-        return model(robot)
+        return model(robot, preset=preset)
     if int(idx) >= len(patterns(robot, tag)):
         return None
-    return model(robot, tag, int(idx))
+    return model(robot, tag, int(idx), preset=preset)

@@ -14,7 +14,10 @@ machine without the reference tree. `assets_dir` (or $METAGYM_LOCOMOTION_ASSETS)
 of MJCF files (the reference's, or your own robots of the same topology); `Model` objects
 (metagym_amd.metalocomotion.load_mjcf) are accepted too.
 
-Physics parity with the reference is UNPINNED (the reference calls PyBullet); see DESIGN.md §3.5.
+Physics parity with the reference is UNPINNED (the reference calls PyBullet); see DESIGN.md §3.4. The envs default to
+`preset="bullet"`, the closest known reading of that backend (bounding-box link inertia, inertial frame at the body origin,
+0.04 / 0.04 body velocity damping, armature and stiffness ignored); `preset="mujoco"` is MuJoCo's documented reading of the
+same files (what rounds 1-3 ran).
 """
 import os
 import random
@@ -25,7 +28,7 @@ import torch
 from .. import _lib
 from ..spaces import Box
 from . import variants
-from .mjcf import Model, load_mjcf
+from .mjcf import DEFAULT_PRESET, Model, load_mjcf, preset_options
 
 
 # The Bullet world parameters the reference sets (tests/test_walker_rules.py checks them against what its own scene code
@@ -57,7 +60,8 @@ class WalkerBatchEnv(object):
     def __init__(self, num_envs=1, device="cuda", frame_skip=4, time_step=0.005, enable_render=False,
                  max_steps=2000, assets_dir=None, solver_iterations=5, mapping="wave", self_collision=True,
                  auto_reset=False, seed=0, env_id_base=0, gravity=GRAVITY, ground_friction=GROUND_FRICTION,
-                 body_damping=(0.0, 0.0), per_proxy_friction=False, contact_erp=CONTACT_ERP, foot_force=False):
+                 body_damping=None, per_proxy_friction=False, contact_erp=CONTACT_ERP, foot_force=False, preset=None,
+                 max_coordinate_velocity=None):
         self._lib = _lib.load()
         self.num_envs = int(num_envs)
         self.device = torch.device(device)
@@ -69,12 +73,21 @@ class WalkerBatchEnv(object):
         self.self_collision = bool(self_collision)     # the reference loads the MJCF with URDF_USE_SELF_COLLISION
         # World options beyond the MetaLocomotion defaults (all handled by the shape-generic wave kernels):
         #   gravity / ground_friction   the Bullet world's (quadrupedal: 10 and 5, locomotion_gym_env.py:251,258)
+        #   preset                      'bullet' (default) | 'mujoco': how task files are read (mjcf.PRESETS: inertia rule,
+        #                               inertial frame, armature, stiffness) and the default of `body_damping`
         #   body_damping = (lin, ang)   btMultiBody's velocity damping of every body; PyBullet's default is (0.04, 0.04), which
-        #                               MetaLocomotion never changes — (0, 0), the default here, is the documented MuJoCo-style
-        #                               reading of the MJCF (DESIGN.md §3.4 lists both)
+        #                               MetaLocomotion never changes — the 'bullet' preset's value; (0, 0) in the 'mujoco' one
         #   per_proxy_friction          every collision proxy carries its own link's coefficient (Model.sph_friction)
         self.gravity, self.ground_friction = float(gravity), float(ground_friction)
+        self.preset = DEFAULT_PRESET if preset is None else preset
+        if body_damping is None:
+            body_damping = preset_options(self.preset)["body_damping"]
         self.body_damping = (float(body_damping[0]), float(body_damping[1]))
+        #   max_coordinate_velocity     btMultiBody's clamp of every generalized velocity at the end of a sub-step (Bullet: 100,
+        #                               the 'bullet' preset's value; 0 = off, the 'mujoco' one)
+        if max_coordinate_velocity is None:
+            max_coordinate_velocity = preset_options(self.preset)["max_velocity"]
+        self.max_coordinate_velocity = float(max_coordinate_velocity)
         self.per_proxy_friction = bool(per_proxy_friction)
         #   contact_erp                 0.9 for MetaLocomotion (scene_bases.py:55 setDefaultContactERP); a world that never calls it
         #                               keeps Bullet's default 0.2 (btContactSolverInfo::m_erp2) — the quadrupedal one
@@ -127,10 +140,10 @@ class WalkerBatchEnv(object):
             return t
         path = t if os.path.isabs(t) or self._robot_assets() is None else os.path.join(self._robot_assets(), t)
         if not os.path.exists(path):
-            m = variants.model_from_task_name(t)     # one of the reference's file names: regenerate that variant
+            m = variants.model_from_task_name(t, preset=self.preset)     # one of the reference's file names: regenerate that variant
             if m is not None:
                 return m
-        return load_mjcf(path, foot_names=self.foot_list)
+        return load_mjcf(path, foot_names=self.foot_list, preset=self.preset)
 
     def set_task(self, task_file, task_ids=None):
         tasks = task_file if isinstance(task_file, (list, tuple)) else [task_file]
@@ -204,6 +217,7 @@ class WalkerBatchEnv(object):
             self._sphere_friction = None
             p.friction, p.sphere_friction = self.ground_friction * float(m0.geom_friction), None
         p.body_linear_damping, p.body_angular_damping = self.body_damping
+        p.max_coordinate_velocity = self.max_coordinate_velocity
         p.alive_z, p.alive_bonus, p.dead_bonus = self.alive_z, self.alive_bonus, -1.0
         p.initial_z = float(self.initial_z if self.initial_z is not None else m0.body_pos[0][2])
         p.joints_at_limit_cost = -0.1                              # walker_base_env.py:22

@@ -11,7 +11,8 @@ ships with pybullet_data, NOT with the reference — bring your own copy) and `s
              (Bullet's default: no setDefaultContactERP call anywhere in quadrupedal/), plane
              friction 5 (:258), terrain boxes friction 5 (utilities/terrain.py:14), feet friction 1 (:408 SetFootFriction),
              pyramid friction (:413 enableConeFriction=0), no body velocity damping (minitaur.py:346-353 at :419), no self
-             collision (minitaur.py:83)
+             collision (minitaur.py:83), btMultiBody's clamp of every generalized velocity to +-100 (m_maxCoordinateVelocity,
+             which nothing in the reference changes)
   robot      URDF -> Model (urdf.py): hinge order = a1.MOTOR_NAMES, toe links = feet (a1.py:76-80 name patterns), every
              other link's contact points are "bad" contacts (a1.py:314-323), inertia recomputed from the collision shapes'
              bounding box like loadURDF without URDF_USE_INERTIA_FROM_FILE
@@ -61,9 +62,13 @@ def guess_foot_links(model_or_names):
 class A1Physics(object):
     def __init__(self, num_envs, urdf=None, device="cuda:0", model=None, foot_links=None, inertia="bullet_aabb", armature=0.0,
                  solver_iterations=23, fused=True, gravity=GRAVITY, ground_friction=GROUND_FRICTION, foot_friction=FOOT_FRICTION,
-                 body_damping=(0.0, 0.0), init_motor_angles=INIT_MOTOR_ANGLES, contact_erp=CONTACT_ERP, base_mass_ratio=1.0):
+                 body_damping=(0.0, 0.0), init_motor_angles=INIT_MOTOR_ANGLES, contact_erp=CONTACT_ERP, base_mass_ratio=1.0,
+                 max_coordinate_velocity=100.0):
         if (urdf is None) == (model is None):
             raise ValueError("A1Physics needs exactly one of urdf=<path or text> and model=<Model>")
+        if model is not None:
+            import copy                                          # the caller's Model (possibly a shared, cached one) is never
+            model = copy.deepcopy(model)                         # written to: friction / foot tables below are per A1Physics
         if model is None:
             if foot_links is None:
                 import xml.etree.ElementTree as ET
@@ -82,8 +87,8 @@ class A1Physics(object):
             m.sph_friction = np.where(np.asarray(m.sph_foot) >= 0, float(foot_friction), m.sph_friction)
         self.foot_friction = foot_friction
         if base_mass_ratio != 1.0:                               # SetBaseMasses([mass x ratio]) minitaur.py:999-1017: changeDynamics(mass=)
-            import copy                                          # scales the ROOT LINK's mass, inertia untouched (Bullet keeps the
-            m = copy.deepcopy(m)                                 # localInertiaDiagonal it had); the merged imu link keeps its own mass
+            # scales the ROOT LINK's mass, inertia untouched (Bullet keeps the localInertiaDiagonal it had); the merged imu
+            # link keeps its own mass
             root_mass = float(getattr(m, "root_link_mass", m.body_mass[0]))
             add = root_mass * (float(base_mass_ratio) - 1.0)
             c_root = np.asarray(getattr(m, "root_inertial_pos", m.body_com[0]), float)
@@ -100,7 +105,8 @@ class A1Physics(object):
         self.env = _A1Walker(num_envs=num_envs, device=device, frame_skip=1, time_step=0.002, max_steps=2 ** 30,
                              solver_iterations=solver_iterations, self_collision=False, gravity=gravity,
                              ground_friction=ground_friction, body_damping=body_damping, per_proxy_friction=True,
-                             contact_erp=contact_erp, foot_force=True)
+                             contact_erp=contact_erp, foot_force=True, preset="mujoco",      # (preset: only read for defaults
+                             max_coordinate_velocity=max_coordinate_velocity)                # not given above; the Model is handed over)
         self.env.set_task([m])
         f64 = dict(dtype=torch.float64, device=self.device)
         self._init = torch.as_tensor(np.tile(np.asarray(init_motor_angles, np.float64), (self.n, 1)), **f64)

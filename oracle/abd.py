@@ -169,7 +169,9 @@ def integrate_positions(s, dt):
 class Params(object):
     def __init__(self, dt=0.005, substeps=4, iterations=5, erp=0.9, friction=0.8 * 0.8, power=0.41, max_contacts=12,
                  limit_erp=0.2, self_collision=True, self_friction=0.8 * 0.8, terrain=(), gravity=None, sphere_friction=None,
-                 body_damping=(0.0, 0.0)):
+                 body_damping=(0.0, 0.0), max_velocity=0.0):
+        self.max_velocity = float(max_velocity)   # btMultiBody's m_maxCoordinateVelocity (100 in Bullet): clamp of every generalized
+        #                                           velocity at the end of a sub-step (mg_walker_params.max_coordinate_velocity); 0 = off
         self.terrain = list(terrain)          # static boxes on top of the ground plane: (position[3], R[3,3] box->world, half_extents[3], mu)
         self.gravity = None if gravity is None else float(gravity)      # None: the module's GRAVITY (9.8, env_bases.py:48)
         # per-proxy lateral friction (mg_walker_params.sphere_friction): `friction` is then the ground's own coefficient and
@@ -380,6 +382,8 @@ def substep(m, s, tau_motor, prm, out=None, ext=None):
         out["rows"] = rows
         if not rows:
             out["lam"] = np.zeros(0)
+    if getattr(prm, "max_velocity", 0.0) > 0.0:
+        u_star = np.clip(u_star, -prm.max_velocity, prm.max_velocity)
     s.v, s.w, s.qd = u_star[0:3].copy(), u_star[3:6].copy(), u_star[6:].copy()
     integrate_positions(s, prm.dt)
     return touching

@@ -123,15 +123,15 @@ def main():
     out, digests = {}, {}
     for robot, sub, finder in (("humanoid", "humanoids", humanoid_pattern), ("ant", "ants", ant_pattern)):
         feet = variants.FEET[robot]
-        digests["%s.xml" % robot] = model_digest(load_mjcf(os.path.join(ASSETS, sub, "%s.xml" % robot), foot_names=feet))
+        digests["%s.xml" % robot] = model_digest(load_mjcf(os.path.join(ASSETS, sub, "%s.xml" % robot), foot_names=feet, preset="mujoco"))
         for tag, count in (("tra", 256), ("tst", 64), ("ood", 64)):
             pats = []
             for i in range(count):
                 name = "%s_var_%s_%03d.xml" % (robot, tag, i)
                 path = os.path.join(ASSETS, sub, name)
                 p = finder(path)
-                ref = load_mjcf(path, foot_names=feet)
-                mine = load_mjcf(variants.mjcf_text(robot, p), foot_names=feet)
+                ref = load_mjcf(path, foot_names=feet, preset="mujoco")
+                mine = load_mjcf(variants.mjcf_text(robot, p), foot_names=feet, preset="mujoco")
                 rd, md = ref.to_dict(), mine.to_dict()
                 for k in rd:
                     if not np.array_equal(rd[k], md[k]):

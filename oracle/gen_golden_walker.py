@@ -31,8 +31,11 @@ FILES = [("humanoid", "humanoids/humanoid.xml", ("right_foot", "left_foot")),
 
 out = {}
 for key, rel, feet in FILES:
-    m = load_mjcf(os.path.join(ASSETS, rel), foot_names=feet)
-    for k, v in m.to_dict().items():
-        out["%s/%s" % (key, k)] = v
-    print(key, "bodies", len(m.body_parent), "joints", len(m.joint_body), "mass %.3f" % m.body_mass.sum())
+    # "<key>": the loader's default preset ("bullet", what the envs run by default); "<key>@mujoco": MuJoCo's reading
+    for name, preset in ((key, None), (key + "@mujoco", "mujoco")):
+        m = load_mjcf(os.path.join(ASSETS, rel), foot_names=feet, preset=preset)
+        for k, v in m.to_dict().items():
+            out["%s/%s" % (name, k)] = v
+        print(name, str(m.preset), "bodies", len(m.body_parent), "joints", len(m.joint_body), "mass %.3f" % m.body_mass.sum(),
+              "inertia trace body 0 %.4f" % np.trace(m.body_inertia[0]))
 np.savez_compressed(os.path.join(ROOT, "tests", "golden", "walker_models.npz"), **out)

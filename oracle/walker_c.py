@@ -24,7 +24,8 @@ class Params(C.Structure):
                 ("gravity", C.c_double), ("friction", C.c_double), ("self_friction", C.c_double), ("self_collision", C.c_int32),
                 ("max_steps", C.c_int32), ("alive_z", C.c_double), ("alive_bonus", C.c_double), ("initial_z", C.c_double),
                 ("walk_target_x", C.c_double), ("walk_target_y", C.c_double), ("initial_z_from_state", C.c_int32),
-                ("floor_in_parts", C.c_int32), ("torque_f32", C.c_int32), ("height_f32", C.c_int32)]
+                ("floor_in_parts", C.c_int32), ("torque_f32", C.c_int32), ("height_f32", C.c_int32),
+                ("body_linear_damping", C.c_double), ("body_angular_damping", C.c_double), ("max_coordinate_velocity", C.c_double)]
 
 
 class State(C.Structure):
@@ -91,13 +92,23 @@ def make_model(m, motor_torque):
     return cm, table
 
 
+def world_of(m):
+    """The world half of the preset a Model was loaded with (mjcf.PRESETS): body damping and the velocity clamp."""
+    bd = getattr(m, "body_damping", (0.0, 0.0))
+    return dict(body_linear_damping=float(bd[0]), body_angular_damping=float(bd[1]),
+                max_coordinate_velocity=float(getattr(m, "max_velocity", 0.0)))
+
+
 def humanoid_params(m, **over):
-    """abd.WalkerEnv's humanoid defaults (HUMANOID_MOTOR_POWER x 0.41 goes into the model table as motor_torque)."""
+    """abd.WalkerEnv's humanoid defaults (HUMANOID_MOTOR_POWER x 0.41 goes into the model table as motor_torque); body damping
+    and the velocity clamp follow the preset the model was loaded with."""
     p = Params()
     p.dt, p.substeps, p.iterations, p.erp, p.limit_erp, p.gravity = 0.005, 4, 5, 0.9, 0.2, 9.8
     p.friction, p.self_friction, p.self_collision = 0.8 * float(m.geom_friction), float(m.geom_friction) ** 2, 1
     p.max_steps, p.alive_z, p.alive_bonus, p.initial_z = 2000, 0.50, 2.0, 0.8
     p.walk_target_x, p.walk_target_y, p.initial_z_from_state, p.floor_in_parts, p.torque_f32, p.height_f32 = 1e3, 0.0, 0, 1, 1, 1
+    for k, v in world_of(m).items():
+        setattr(p, k, v)
     for k, v in over.items():
         setattr(p, k, v)
     return p

@@ -13,7 +13,8 @@
  * physical invariants and the HIP kernels.
  * The Python-side rules around the physics ARE the reference's and are restated exactly like abd.WalkerEnv:
  * torques humanoids.py:50-54 / walker_base.py:26-29, calc_state walker_base.py:31-64, reward / done walker_base_env.py:43-82.
- * Terrain boxes, per-proxy friction and body damping (the shape-generic kernel's extras) are not part of C4 and not here. */
+ * Body velocity damping (btMultiBody's 0.04 / 0.04, part of the envs' default "bullet" preset) is here; terrain boxes and
+ * per-proxy friction (the shape-generic kernel's extras) are not part of C4 and not here. */
 #include "walker_oracle.h"
 
 #include <math.h>
@@ -82,6 +83,7 @@ typedef struct {
     v3 o[WO_MAX_BODIES], c[WO_MAX_BODIES];
     v3 p[WO_MAX_JOINTS], a[WO_MAX_JOINTS];
     v3 fw[WO_MAX_BODIES], fal[WO_MAX_BODIES], fxr[WO_MAX_BODIES], far_[WO_MAX_BODIES];   /* velocity-product frames */
+    v3 fvr[WO_MAX_BODIES];                                                               /* velocity of the frame's reference point (with_frames == 2) */
     unsigned mask[WO_MAX_BODIES];
     int dbody[WO_MAX_DOF];
 } kin_t;
@@ -92,18 +94,19 @@ static void kinematics(const wo_model *m, const wo_state *s, kin_t *k, int with_
     for (int d = 0; d < 6; ++d) k->dbody[d] = 0;
     for (int b = 0; b < NB; ++b) {
         double Rc[9];
-        v3 oc, w, al, xr, ar;
+        v3 oc, w, al, xr, ar, vr = V(0, 0, 0);
         unsigned mk = 0;
         const int pb = m->body_parent[b];
         if (pb < 0) {
             memcpy(Rc, s->rot, sizeof(Rc));
             oc = ld3(s->pos);
-            w = ld3(s->omega); al = V(0, 0, 0); xr = oc; ar = V(0, 0, 0);
+            w = ld3(s->omega); al = V(0, 0, 0); xr = oc; ar = V(0, 0, 0); vr = ld3(s->vel);
         } else {
             mulMM(k->R[pb], t_body_rot(m) + 9 * b, Rc);
             oc = vadd(k->o[pb], mulMv(k->R[pb], ld3(t_body_pos(m) + 3 * b)));
             mk = k->mask[pb];
             w = k->fw[pb]; al = k->fal[pb]; xr = k->fxr[pb]; ar = k->far_[pb];
+            if (with_frames == 2) vr = k->fvr[pb];
         }
         for (; j < NJ && m->joint_body[j] == b; ++j) {
             const v3 anchor = ld3(t_joint_anchor(m) + 3 * j), axis = ld3(t_joint_axis(m) + 3 * j);
@@ -120,6 +123,7 @@ static void kinematics(const wo_model *m, const wo_state *s, kin_t *k, int with_
             if (with_frames) {
                 const v3 r = vsub(pj, xr);
                 ar = vadd(vadd(ar, vcross(al, r)), vcross(w, vcross(w, r)));
+                if (with_frames == 2) vr = vadd(vr, vcross(w, r));
                 xr = pj;
                 const v3 wj = vscale(s->qd[j], aj);
                 al = vadd(al, vcross(w, wj));
@@ -130,7 +134,7 @@ static void kinematics(const wo_model *m, const wo_state *s, kin_t *k, int with_
         k->o[b] = oc;
         k->c[b] = vadd(oc, mulMv(Rc, ld3(t_body_com(m) + 3 * b)));
         k->mask[b] = mk;
-        k->fw[b] = w; k->fal[b] = al; k->fxr[b] = xr; k->far_[b] = ar;
+        k->fw[b] = w; k->fal[b] = al; k->fxr[b] = xr; k->far_[b] = ar; k->fvr[b] = vr;
     }
 }
 
@@ -179,7 +183,8 @@ int wo_substep(const wo_model *m, const wo_params *prm, wo_state *s, const doubl
     const int n = 6 + NJ, maxc = WO_MAX_CONTACTS;
     const double dt = prm->dt;
     kin_t k;
-    kinematics(m, s, &k, 1);
+    const int damped = prm->body_linear_damping != 0.0 || prm->body_angular_damping != 0.0;
+    kinematics(m, s, &k, damped ? 2 : 1);
     /* ---- M and h by the composite-rigid-body algorithm about the base origin O (walker.hip wave_substep) ---- */
     double comp[WO_MAX_BODIES][16];
     const v3 O = k.o[0];
@@ -194,8 +199,16 @@ int wo_substep(const wo_model *m, const wo_params *prm, wo_state *s, const doubl
         mulMM(RI, Rt, Ic);
         const double mass = t_body_mass(m)[b];
         FL(F_ADD, 1);
-        const v3 F = vscale(mass, V(a_c.x, a_c.y, a_c.z + prm->gravity));
-        const v3 N = vadd(mulMv(Ic, al), vcross(w, mulMv(Ic, w)));
+        v3 F = vscale(mass, V(a_c.x, a_c.y, a_c.z + prm->gravity));
+        v3 N = vadd(mulMv(Ic, al), vcross(w, mulMv(Ic, w)));
+        if (damped) {   /* btMultiBody's velocity damping: force -m v_c (k + k |v_c|) at the centre of mass, torque -I w (k + k |w|);
+                         * their negatives join the bias wrench (walker.hip wave_substep, oracle/abd.py mass_matrix_and_bias) */
+            const v3 vc = vadd(k.fvr[b], vcross(w, rx));
+            const double kl = prm->body_linear_damping, ka = prm->body_angular_damping;
+            FL(F_SQRT, 2); FL(F_MUL, 3); FL(F_ADD, 2);
+            F = vadd(F, vscale(mass * (kl + kl * sqrt(vdot(vc, vc))), vc));
+            N = vadd(N, vscale(ka + ka * sqrt(vdot(w, w)), mulMv(Ic, w)));
+        }
         const v3 r = vsub(cb, O);
         const v3 NO = vadd(N, vcross(r, F));
         const double rr = vdot(r, r);
@@ -389,6 +402,8 @@ int wo_substep(const wo_model *m, const wo_params *prm, wo_state *s, const doubl
         FL(F_MUL, 1);
         u[r] = v * idg[r];
     }
+    if (prm->max_coordinate_velocity > 0.0)      /* btMultiBody::applyDeltaVeeMultiDof's clamp of every generalized velocity */
+        for (int d = 0; d < n; ++d) u[d] = fmin(fmax(u[d], -prm->max_coordinate_velocity), prm->max_coordinate_velocity);
     for (int i = 0; i < 3; ++i) { s->vel[i] = u[i]; s->omega[i] = u[3 + i]; FL(F_FMA, 1); s->pos[i] += dt * u[i]; }
     for (int j = 0; j < NJ; ++j) { s->qd[j] = u[6 + j]; FL(F_FMA, 1); s->q[j] += dt * u[6 + j]; }
     const v3 om = ld3(s->omega);

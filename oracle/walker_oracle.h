@@ -29,6 +29,8 @@ typedef struct wo_params {
     double alive_z, alive_bonus, initial_z, walk_target_x, walk_target_y;
     int32_t initial_z_from_state;    /* ant: initial_z = first calc_state's z (walker_base.py:44-45) */
     int32_t floor_in_parts, torque_f32, height_f32;
+    double body_linear_damping, body_angular_damping;   /* btMultiBody velocity damping of every body (0.04 / 0.04 in the "bullet" preset) */
+    double max_coordinate_velocity;                     /* btMultiBody's clamp of every generalized velocity (100 in the "bullet" preset; 0 = off) */
 } wo_params;
 
 typedef struct wo_state { double pos[3], rot[9], vel[3], omega[3], q[WO_MAX_JOINTS], qd[WO_MAX_JOINTS]; } wo_state;

@@ -32,7 +32,7 @@ def test_urdf_path_equals_mjcf_path_bit_for_bit(fused):
     n = 96
     w = np.tile([[0.02], [0.0], [0.015]], (1, 20)) * np.sin(np.linspace(0, 2 * np.pi, 20))
     for task in ("plane", "slopestair"):
-        m = load_mjcf(STANDIN_XML, foot_names=CALVES)
+        m = load_mjcf(STANDIN_XML, foot_names=CALVES, preset="mujoco")        # (its URDF twin carries the same armature 0.01)
         envs = []
         for phys in (A1Physics(n, model=m, device=DEV, fused=fused),
                      A1Physics(n, urdf=model_to_urdf(m), device=DEV, fused=fused, foot_links=CALVES, inertia="file", armature=0.01)):
@@ -182,10 +182,11 @@ def test_body_damping_and_bullet_box_inertia_on_the_engine_match_the_oracle():
     """The two PyBullet-default behaviours DESIGN.md §3.4 lists as options, on the GPU (shape-generic wave kernel): humanoids
     with btMultiBody's 0.04 / 0.04 velocity damping and bounding-box inertias follow the oracle run with the same options
     (1e-9 over 10 env steps), and differ from the undamped run."""
-    models = [variants.model("humanoid", inertia="bullet_box"), variants.model("humanoid", "TRAIN", 7, inertia="bullet_box")]
+    models = [variants.model("humanoid", preset="mujoco", inertia="bullet_box"),
+              variants.model("humanoid", "TRAIN", 7, preset="mujoco", inertia="bullet_box")]
     n = 6
-    env = MetaHumanoidEnv(num_envs=n, device=DEV, body_damping=(0.04, 0.04))
-    plain = MetaHumanoidEnv(num_envs=n, device=DEV)
+    env = MetaHumanoidEnv(num_envs=n, device=DEV, preset="mujoco", body_damping=(0.04, 0.04))
+    plain = MetaHumanoidEnv(num_envs=n, device=DEV, preset="mujoco")
     rs = np.random.RandomState(1)
     noise = rs.uniform(-0.1, 0.1, (n, 17))
     oenvs = []

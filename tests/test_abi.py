@@ -196,6 +196,13 @@ def test_new_round2_entry_points_validate_before_they_launch():
     tp = _lib.WalkerTopology()
     tp.n_bodies, tp.n_joints, tp.n_spheres, tp.n_feet = 2, 1, 1, 0
     tp.body_parent[0], tp.body_parent[1] = -1, 0
+    # ABI 4's sphere_foot is validated: the zero-initialised table of a caller that predates it would report every proxy to
+    # foot 0 (here: a robot without feet), and a foot whose body does not carry the proxy is a mix-up
+    empty = (_lib.WalkerModels(), _lib.WalkerParams(), 4, _lib.WalkerState(), p, p, p, None, p, None)
+    assert lib.mg_walker_step(tp, *empty) == -1003 and b"sphere_foot" in lib.mg_last_error()
+    tp.n_feet, tp.foot_body[0], tp.sphere_body[0], tp.sphere_foot[0] = 1, 1, 0, 0
+    assert lib.mg_walker_step(tp, *empty) == -1003 and b"reports to foot" in lib.mg_last_error()
+    tp.n_feet, tp.sphere_foot[0] = 0, -1
     ms = _lib.WalkerModels()
     ms.table, ms.n_tasks, ms.model_stride = C.addressof(fake), 1, 25 * 2 + 12 + 4
     prm = _lib.WalkerParams()

@@ -298,6 +298,106 @@ def test_maze3d_full_size_properties():
         assert np.array_equal(ob[e], mo.observe_3d(otasks[idl[e]], tt, view, states[e], 0)), e
 
 
+def _c3_sample_envs(n):
+    """64 envs of an n-env batch: the first and the last workgroup group of 8, and one whole aligned group of 8 for every
+    value of the env -> XCD rotation mg::env_of_block applies (metagym_amd/csrc/mg_common.h), spread over the launch."""
+    rot = lambda q: (q + (q >> 3) + (q >> 6) + (q >> 9)) & 7
+    groups, seen = [0, n // 8 - 1], {rot(0), rot(n // 8 - 1)}
+    q = 37
+    while len(groups) < 8:
+        if rot(q) not in seen or len(seen) == 8:
+            groups.append(q)
+            seen.add(rot(q))
+        q = (q + 263) % (n // 8)
+    assert len({rot(g) for g in groups}) >= 6
+    return np.asarray(sorted(8 * g + x for g in groups for x in range(8)))
+
+
+@pytest.mark.parametrize("continuous", [False, True], ids=["discrete", "continuous"])
+def test_c3_timed_configuration_sampled_against_oracle(continuous):
+    """BASELINE configs[2] exactly as bench.py times it (secondary_workloads: 16 384 envs, 9x9 mazes, 64 tasks of
+    bench.maze_tasks(), SURVIVAL, 256x256 frames, fused auto-reset), with max_steps short enough that every env ends
+    episodes inside the 10 compared steps. 64 sampled envs are replayed on oracle/maze_oracle.c: reward, done, the whole
+    per-env state and EVERY pixel of every sampled frame. Discrete: bit-exact. Continuous: loc / heading within the
+    north-star 1e-5 (bit-equal in practice) and every pixel exact wherever the pose is bit-equal."""
+    import metagym_amd
+    from metagym_amd.metamaze import MazeTaskSampler, MAZE_TASK_MANAGER
+    n, res, max_steps, n_steps = 16384, 256, 4, 10
+    tasks = [MazeTaskSampler(n=9, allow_loops=False, step_reward=-0.01, goal_reward=1.0, food_density=0.06,
+                             food_interval=20, seed=s) for s in range(64)]            # == bench.maze_tasks()
+    ident = "meta-maze-continuous-3D-v0" if continuous else "meta-maze-discrete-3D-v0"
+    env = metagym_amd.make(ident, num_envs=n, device="cuda:0", max_steps=max_steps, resolution=(res, res),
+                           task_type="SURVIVAL", auto_reset=True)
+    env.set_task(tasks)
+    ids = env.task_id.cpu().numpy()
+    assert np.array_equal(ids, np.arange(n) % 64)
+    sample = _c3_sample_envs(n)
+    sample_t = torch.as_tensor(sample).cuda()
+    tt = mo.SURVIVAL
+    otasks = [mo.Task(**t._asdict()) for t in tasks]
+    states = {int(e): mo.State(otasks[ids[e]]) for e in sample}
+    for e in sample:
+        mo.reset(otasks[ids[e]], tt, states[int(e)])
+    view = mo.View(MAZE_TASK_MANAGER.grounds.astype(np.uint8), MAZE_TASK_MANAGER.ceil, res, res)
+
+    def frames_match(obs, t):
+        ob = obs[sample_t].cpu().numpy()
+        bad = total = 0
+        for k, e in enumerate(sample):
+            s = states[int(e)]
+            ref = mo.observe_3d(otasks[ids[e]], tt, view, s, int(continuous))
+            d = int((ob[k] != ref).sum())
+            if continuous:
+                loc, ori = env.loc[:, int(e)].cpu().numpy(), float(env.ori[int(e)])
+                assert np.allclose(loc, np.asarray(s.c.loc[:]), rtol=1e-5, atol=1e-5), (t, e)
+                assert abs(ori - s.c.ori) <= 1e-5 * max(1.0, abs(s.c.ori)), (t, e)
+                if np.array_equal(loc, np.asarray(s.c.loc[:], np.float32)) and ori == s.c.ori:
+                    assert d == 0, "step %d env %d: pose bit-equal but %d pixel values differ" % (t, e, d)
+            else:
+                assert d == 0, "step %d env %d: %d pixel values differ" % (t, e, d)
+            bad += d
+            total += ref.size
+        return bad, total
+
+    bad, total = frames_match(env.reset(), -1)
+    rs = np.random.RandomState(11 + int(continuous))
+    ends = 0
+    for t in range(n_steps):
+        if continuous:
+            a = np.stack([rs.uniform(-1.2, 1.2, n), rs.uniform(-0.5, 1.2, n)], 1).astype(np.float32)
+        else:
+            a = rs.choice(4, size=n, p=[0.2, 0.2, 0.1, 0.5]).astype(np.int32)
+        obs, rew, done, info = env.step(torch.as_tensor(a))
+        r64, d = env.reward64[sample_t].cpu().numpy(), done[sample_t].cpu().numpy()
+        for k, e in enumerate(sample):
+            s, task = states[int(e)], otasks[ids[e]]
+            if continuous:
+                r, dd = mo.step_cont3d(task, tt, max_steps, s, a[e][0], a[e][1])
+            else:
+                r, dd = mo.step_disc3d(task, tt, max_steps, s, a[e])
+            assert r == r64[k] and dd == bool(d[k]), (t, e)
+            if dd:                                          # fused auto-reset: the env restarts inside the launch
+                mo.reset(task, tt, s)
+                ends += 1
+        b, tot = frames_match(obs, t)
+        bad, total = bad + b, total + tot
+        # the whole per-env state of the sampled envs
+        grid, steps, life = env.grid[:, sample_t].cpu().numpy(), env.steps[sample_t].cpu().numpy(), env.life[sample_t].cpu().numpy()
+        food, wait, rev = (x[sample_t].cpu().numpy() for x in (env.cur_food, env.wait_refresh, env.revival))
+        oidx = env.ori_idx[sample_t].cpu().numpy()
+        for k, e in enumerate(sample):
+            s = states[int(e)]
+            assert (grid[0, k], grid[1, k], steps[k]) == (s.c.grid[0], s.c.grid[1], s.c.steps), (t, e)
+            assert life[k] == s.c.life, (t, e)
+            assert np.array_equal(food[k], s.cur_food) and np.array_equal(wait[k], s.wait) and np.array_equal(rev[k], s.revival), (t, e)
+            if not continuous:
+                assert oidx[k] == s.c.ori_idx, (t, e)
+    assert ends >= 2 * len(sample), "episode ends inside the compared steps: %d" % ends
+    print("C3 %s: %d sampled envs x %d frames, %d episode ends, pixel mismatches %d / %d"
+          % ("continuous" if continuous else "discrete", len(sample), n_steps + 1, ends, bad, total))
+    assert bad <= (1e-3 * total if continuous else 0)
+
+
 @pytest.mark.parametrize("n,res,cell", [(15, (64, 48), 2.0), (21, (32, 32), 2.0), (15, (32, 32), 0.75),
                                         # ragged frame on the 4-waves-per-env path: 136 columns = 4 slabs of 32 + 8,
                                         # 150 rows = 64 + 64 + 22; cell size not a power of two (true divisions)

@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 
 from oracle import abd, walker_c
-from walker_fixtures import load_models
+from walker_fixtures import load_models, world_kw
 
 MODELS = load_models()
 
@@ -23,9 +23,9 @@ def _c_env(m, ant):
 
 def _np_env(m, ant, **kw):
     if ant:
-        return abd.WalkerEnv(m, prm=abd.Params(friction=0.8 * float(m.geom_friction), power=2.5, self_friction=float(m.geom_friction) ** 2),
+        return abd.WalkerEnv(m, prm=abd.Params(friction=0.8 * float(m.geom_friction), power=2.5, self_friction=float(m.geom_friction) ** 2, **world_kw(m)),
                              motor_power=np.full(len(m.joint_lo), 100.0), alive_z=0.26, alive_bonus=1.0, initial_z=None, torque_f32=False, **kw)
-    return abd.WalkerEnv(m, prm=abd.Params(friction=0.8 * float(m.geom_friction), self_friction=float(m.geom_friction) ** 2), **kw)
+    return abd.WalkerEnv(m, prm=abd.Params(friction=0.8 * float(m.geom_friction), self_friction=float(m.geom_friction) ** 2, **world_kw(m)), **kw)
 
 
 def _state_err(cs, s, nj):
@@ -34,7 +34,7 @@ def _state_err(cs, s, nj):
                np.abs(np.array(cs.q[:nj]) - s.q).max(), np.abs(np.array(cs.qd[:nj]) - s.qd).max())
 
 
-@pytest.mark.parametrize("name", ["humanoid", "humanoid_tra_137", "ant", "ant_tra_005"])
+@pytest.mark.parametrize("name", ["humanoid", "humanoid_tra_137", "ant", "ant_tra_005", "humanoid@mujoco", "ant@mujoco"])
 def test_c_env_step_matches_numpy_trajectory(name):
     m = MODELS[name]
     ant = name.startswith("ant")
@@ -61,7 +61,7 @@ def test_c_env_step_matches_numpy_trajectory(name):
         assert np.array_equal(np.array(env.feet_contact[:len(m.foot_body)]), o.feet_contact)
 
 
-@pytest.mark.parametrize("name", ["humanoid", "ant"])
+@pytest.mark.parametrize("name", ["humanoid", "ant", "humanoid@mujoco", "ant@mujoco"])
 def test_c_substep_matches_numpy_one_substep_at_a_time(name):
     """Every sub-step from the numpy engine's own state: 1e-12 (no accumulation), with contacts, limits and self-collision rows."""
     m = MODELS[name]

@@ -34,7 +34,7 @@ def test_quarter_turns_are_exact():
 
 def test_urdf_of_the_standin_body_loads_to_the_same_model_bit_for_bit():
     """MJCF -> Model -> URDF text -> Model: every array identical (what lets the GPU test demand URDF path == MJCF path)."""
-    m = load_mjcf(STANDIN_XML, foot_names=CALVES)
+    m = load_mjcf(STANDIN_XML, foot_names=CALVES, preset="mujoco")       # (the stand-in's joints carry armature 0.01, like the URDF side)
     u = load_urdf(model_to_urdf(m), foot_links=CALVES, inertia="file", armature=0.01, root_pose=((0, 0, 0.28), None))
     for k in MODEL_ARRAYS:
         a, b = np.asarray(getattr(m, k)), np.asarray(getattr(u, k))
@@ -117,15 +117,38 @@ def test_mjcf_bullet_box_inertia_changes_inertias_only():
     """mjcf.load_mjcf(inertia='bullet_box'): what robot_bases.py:119's loadMJCF (no URDF_USE_INERTIA_FROM_FILE) makes of a
     body's capsules — masses, centres of mass, frames, joints and collision proxies are untouched, the inertia becomes the
     diagonal bounding-box one (a larger trace than the solid capsules')."""
-    g, b = variants.model("humanoid"), variants.model("humanoid", inertia="bullet_box")
+    g, b = variants.model("humanoid", preset="mujoco"), variants.model("humanoid", preset="mujoco", inertia="bullet_box")
     for k in MODEL_ARRAYS:
         if k != "body_inertia":
             assert np.array_equal(getattr(g, k), getattr(b, k)), k
     for Ig, Ib in zip(g.body_inertia, b.body_inertia):
         assert np.count_nonzero(Ib - np.diag(np.diag(Ib))) == 0
         assert np.trace(Ib) > np.trace(Ig)                               # a solid box around the shapes out-weighs them
-    o = variants.model("humanoid", com="body_origin")
+    o = variants.model("humanoid", preset="mujoco", com="body_origin")
     assert not o.body_com.any() and np.array_equal(o.body_mass, g.body_mass)
+
+
+def test_mjcf_presets_are_what_the_table_says():
+    """DESIGN.md §3.4's "default" column: the `bullet` preset (the loader's and the envs' default) = bounding-box inertia +
+    inertial frame at the body origin + armature, joint damping and stiffness ignored + 0.04 / 0.04 body damping + the +-100
+    velocity clamp; `mujoco` = MuJoCo's documented reading. Topology, frames, masses and the collision proxies agree."""
+    from metagym_amd.metalocomotion.mjcf import DEFAULT_PRESET, PRESETS
+    assert DEFAULT_PRESET == "bullet"
+    for robot in ("humanoid", "ant"):
+        d, b, mj = variants.model(robot, "TRAIN", 5), variants.model(robot, "TRAIN", 5, preset="bullet"), variants.model(robot, "TRAIN", 5, preset="mujoco")
+        assert d is b and str(b.preset) == "bullet" and str(mj.preset) == "mujoco"
+        combo = variants.model(robot, "TRAIN", 5, preset="mujoco", inertia="bullet_box", com="body_origin")
+        assert np.array_equal(b.body_inertia, combo.body_inertia) and not b.body_com.any()
+        assert not b.joint_armature.any() and not b.joint_stiffness.any() and not b.joint_damping.any()
+        assert mj.joint_armature.all() and mj.joint_damping.all()
+        assert tuple(b.body_damping) == (0.04, 0.04) and float(b.max_velocity) == 100.0
+        assert tuple(mj.body_damping) == (0.0, 0.0) and float(mj.max_velocity) == 0.0
+        for k in MODEL_ARRAYS:
+            if k not in ("body_inertia", "body_com", "joint_armature", "joint_damping", "joint_stiffness"):
+                assert np.array_equal(getattr(b, k), getattr(mj, k)), k
+    with pytest.raises(ValueError):
+        variants.model("humanoid", preset="havok")
+    assert set(PRESETS) == {"bullet", "mujoco"}
 
 
 def _free(m):
@@ -171,7 +194,7 @@ def test_body_damping_option_changes_only_the_bias_and_drains_energy():
     """Params.body_damping = btMultiBody's linear / angular damping (PyBullet default 0.04 each): M is untouched, the bias
     gains J^T of (m v (k + k|v|), I w (k + k|w|)) per body, a free-flying robot loses kinetic energy at the rate that wrench
     dissipates, and with (0, 0) nothing changes at all."""
-    m = _free(variants.model("humanoid"))
+    m = _free(variants.model("humanoid", preset="mujoco"))
     s = _random_state(m, 4)
     M0, h0, kin, _ = abd.mass_matrix_and_bias(m, s, gravity=0.0)
     M1, h1, _, _ = abd.mass_matrix_and_bias(m, s, gravity=0.0, body_damping=(0.04, 0.04))

@@ -65,7 +65,8 @@ def test_generic_robot_follows_the_oracle(name):
     selfc, lane_map = name.startswith("self-collision: "), name.startswith("lane mapping: ")
     legs = ROBOTS[name.split(": ", 1)[1] if (selfc or lane_map) else name]
     text, feet = _centipede(legs)
-    m = load_mjcf(text, foot_names=feet)
+    from walker_fixtures import world_kw
+    m = load_mjcf(text, foot_names=feet)                  # the default preset ("bullet": damped, clamped), like the env below
     nj = sum(sum(l) for l in legs)
     assert len(m.joint_lo) == nj and len(m.body_parent) == 1 + len(legs) + sum(len(l) for l in legs)
 
@@ -88,7 +89,7 @@ def test_generic_robot_follows_the_oracle(name):
     oenvs = []
     for e in range(n):
         o = abd.WalkerEnv(m, prm=abd.Params(friction=0.8 * float(m.geom_friction), power=0.4, self_collision=selfc,
-                                             self_friction=float(m.geom_friction) ** 2),
+                                             self_friction=float(m.geom_friction) ** 2, **world_kw(m)),
                           motor_power=np.full(nj, 100.0), alive_z=0.15, alive_bonus=1.0, initial_z=None, torque_f32=False,
                           max_steps=1000)
         o.reset(noise[e])

@@ -11,7 +11,7 @@ import pytest
 import torch
 
 from oracle import abd
-from walker_fixtures import load_models
+from walker_fixtures import load_models, preset_of, world_kw
 
 pytestmark = pytest.mark.gpu
 MODELS = load_models()
@@ -20,6 +20,7 @@ RULES = os.path.join(os.path.dirname(__file__), "golden", "walker_rules.npz")
 
 def _make(cls_name, models, n, task_ids=None, **kw):
     import metagym_amd.metalocomotion as ml
+    kw.setdefault("preset", preset_of(models[0]))         # the world (body damping, velocity clamp) the models were read for
     env = getattr(ml, cls_name)(num_envs=n, device="cuda:0", **kw)
     env.set_task(models, task_ids)
     return env
@@ -28,11 +29,11 @@ def _make(cls_name, models, n, task_ids=None, **kw):
 def _oracle_env(m, ant=False, **kw):
     if ant:
         return abd.WalkerEnv(m, prm=abd.Params(friction=0.8 * float(m.geom_friction), power=2.5,
-                                               self_friction=float(m.geom_friction) ** 2),
+                                               self_friction=float(m.geom_friction) ** 2, **world_kw(m)),
                              motor_power=np.full(len(m.joint_lo), 100.0), alive_z=0.26, alive_bonus=1.0,
                              initial_z=None, torque_f32=False, **kw)
     return abd.WalkerEnv(m, prm=abd.Params(friction=0.8 * float(m.geom_friction),
-                                           self_friction=float(m.geom_friction) ** 2), **kw)
+                                           self_friction=float(m.geom_friction) ** 2, **world_kw(m)), **kw)
 
 
 @pytest.mark.parametrize("mapping", ["wave", "lane"])
@@ -98,7 +99,9 @@ def test_gpu_reproduces_what_the_reference_computed(c, mapping):
     task = str(case["task"])
     cls = ml.MetaHumanoidEnv if task.startswith("humanoid") else ml.MetaAntEnv
     n = 3                                             # three identical envs: lanes / waves must agree with each other too
-    env = cls(num_envs=n, device="cuda:0", max_steps=int(case["max_steps"]), mapping=mapping)
+    # preset="mujoco": the golden was recorded (round 2) with the stand-in dynamics on MuJoCo's reading of the files; what it
+    # pins — the reference's Python-side rules — is the same under either reading
+    env = cls(num_envs=n, device="cuda:0", max_steps=int(case["max_steps"]), mapping=mapping, preset="mujoco")
     assert task in env.tra_tasks + env.tst_tasks + env.ood_tasks or task in ("humanoid.xml", "ant.xml")
     env.set_task(task)
     assert env.models[0].joint_names == [str(x) for x in case["joint_names"]]
@@ -137,7 +140,7 @@ def test_gpu_reproduces_what_the_reference_computed(c, mapping):
 def test_free_flight_invariants_on_gpu():
     """No gravity-free mode exists in the product API, so: in free fall (high above the ground) the
     total momentum of every env changes by exactly m*g*t and the joints keep moving smoothly."""
-    m = copy.deepcopy(MODELS["humanoid"])
+    m = copy.deepcopy(MODELS["humanoid@mujoco"])          # (no body damping: momentum is conserved)
     m.joint_damping[:] = 0
     m.joint_stiffness[:] = 0
     m.joint_lo[:] = -100
@@ -201,6 +204,90 @@ def test_full_size_properties_8192():
     for k in ("pos", "q", "qd", "vel"):
         assert torch.equal(before[k][:, keep], after[k][:, keep]), k
     assert (after["steps"][mask.cuda()] == 0).all() and (after["qd"][:, mask.cuda()] == 0).all()
+
+
+def _sample_envs(n, groups_wanted=8):
+    """Aligned groups of 8 envs: the first and the last of the batch and groups covering the env -> XCD rotations
+    mg::env_of_block applies (metagym_amd/csrc/mg_common.h)."""
+    rot = lambda q: (q + (q >> 3) + (q >> 6) + (q >> 9)) & 7
+    groups, seen, q = [0, n // 8 - 1], {rot(0), rot(n // 8 - 1)}, 37
+    while len(groups) < groups_wanted:
+        if rot(q) not in seen or len(seen) == 8:
+            groups.append(q)
+            seen.add(rot(q))
+        q = (q + 263) % (n // 8)
+    return np.asarray(sorted(8 * g + x for g in groups for x in range(8)))
+
+
+def test_c4_timed_configuration_sampled_against_oracle():
+    """BASELINE configs[3] exactly as bench.py times it (secondary_workloads: 8 192 humanoids, env e runs
+    humanoid_var_tra_<e mod 256>.xml, the envs' default preset, self-collision on, U(-1, 1) actions): 64 sampled envs
+    replayed on oracle/walker_oracle.c (the engine's scalar C restatement, pinned to oracle/abd.py by
+    tests/test_oracle_walker_c.py) for 10 env steps = 40 physics sub-steps. Every variant starts with its feet in the
+    ground (gen_variant_humanoids.py:44 lowers the torso by 0.20), so ground contacts, the ERP push-out and the landing
+    afterwards are all inside the compared steps. State 1e-7, float32 observation 2e-5, reward terms, done and feet flags."""
+    import ctypes as C
+    from metagym_amd.metalocomotion import MetaHumanoidEnv, variants
+    from oracle import walker_c
+    n, n_steps = 8192, 10
+    models = variants.models("humanoid", "TRAIN")                     # == bench.py's C4 input
+    assert len(models) == 256 and str(models[0].preset) == "bullet"
+    env = MetaHumanoidEnv(num_envs=n, device="cuda:0")
+    env.set_task(models)
+    assert env.body_damping == (0.04, 0.04) and env.max_coordinate_velocity == 100.0
+    ids = env.task_id.cpu().numpy()
+    assert np.array_equal(ids, np.arange(n) % 256)
+    rs = np.random.RandomState(4)
+    noise = rs.uniform(-0.1, 0.1, (n, 17))
+    obs = env.reset(joint_noise=noise).cpu().numpy()
+    sample = _sample_envs(n)
+    lib = walker_c.load()
+    power = abd.HUMANOID_MOTOR_POWER * 0.41
+    cenvs = {}
+    for e in sample:
+        m = models[ids[e]]
+        cm, table = walker_c.make_model(m, power)
+        prm = walker_c.humanoid_params(m, floor_in_parts=0)           # an env's first reset (walker_base_env.py:30-31)
+        assert prm.body_linear_damping == 0.04 and prm.max_coordinate_velocity == 100.0
+        ce = walker_c.Env()
+        o = np.zeros(44, np.float32)
+        lib.wo_env_reset(C.byref(cm), C.byref(prm), C.byref(ce), np.ascontiguousarray(noise[e]).ctypes.data_as(C.POINTER(C.c_double)),
+                         o.ctypes.data_as(C.POINTER(C.c_float)))
+        ce.floor_known = 1
+        prm.floor_in_parts = 1
+        assert np.allclose(obs[e], o, rtol=0, atol=1e-6), e
+        cenvs[int(e)] = (cm, table, prm, ce)
+    worst_state = worst_obs = 0.0
+    contacts = 0
+    zmax = 0.0
+    for t in range(n_steps):
+        a = rs.uniform(-1.0, 1.0, (n, 17)).astype(np.float32)
+        obs, rew, done, info = env.step(torch.as_tensor(a))
+        obs, rew, done, r5 = obs.cpu().numpy(), rew.cpu().numpy(), done.cpu().numpy(), info["rewards"].cpu().numpy()
+        st = {k: getattr(env, k).cpu().numpy() for k in ("pos", "rot", "vel", "omega", "q", "qd", "feet_contact")}
+        for e in sample:
+            cm, table, prm, ce = cenvs[int(e)]
+            o = np.zeros(44, np.float32)
+            r, r5c = C.c_double(), (C.c_double * 5)()
+            d = lib.wo_env_step(C.byref(cm), C.byref(prm), C.byref(ce), np.ascontiguousarray(a[e]).ctypes.data_as(C.POINTER(C.c_float)),
+                                o.ctypes.data_as(C.POINTER(C.c_float)), C.byref(r), r5c)
+            cs = ce.s
+            err = max(np.abs(st["pos"][:, e] - np.array(cs.pos[:])).max(), np.abs(st["rot"][:, e] - np.array(cs.rot[:])).max(),
+                      np.abs(st["q"][:, e] - np.array(cs.q[:17])).max(),
+                      1e-2 * np.abs(st["vel"][:, e] - np.array(cs.vel[:])).max(), 1e-2 * np.abs(st["omega"][:, e] - np.array(cs.omega[:])).max(),
+                      1e-2 * np.abs(st["qd"][:, e] - np.array(cs.qd[:17])).max())
+            worst_state, worst_obs = max(worst_state, err), max(worst_obs, float(np.abs(obs[e] - o).max()))
+            assert err < 1e-7, (t, e, err)
+            assert np.allclose(obs[e], o, rtol=0, atol=2e-5), (t, e, np.abs(obs[e] - o).max())
+            assert np.allclose(r5[e], list(r5c), rtol=1e-5, atol=1e-4) and abs(rew[e] - r.value) < 1e-4 * max(1.0, abs(r.value)), (t, e)
+            assert bool(done[e]) == bool(d), (t, e)
+            assert np.array_equal(st["feet_contact"][:, e], np.array(ce.feet_contact[:2])), (t, e)
+            contacts += int(st["feet_contact"][:, e].sum())
+            zmax = max(zmax, float(cs.pos[2]))
+    assert contacts > len(sample)                                     # feet on the ground inside the compared steps
+    assert np.isfinite(obs).all()
+    print("C4: %d sampled envs x %d env steps, max |state diff| GPU vs C oracle %.2e, obs %.2e, foot contacts %d, highest torso %.2f m"
+          % (len(sample), n_steps, worst_state, worst_obs, contacts, zmax))
 
 
 @pytest.mark.parametrize("mapping", ["wave", "lane"])
@@ -375,7 +462,7 @@ def test_terrain_boxes_match_oracle_trajectory(robot):
     for e in range(n):
         m = models[ids[e]]
         kw = dict(friction=0.8 * float(m.geom_friction), self_friction=float(m.geom_friction) ** 2,
-                  terrain=_oracle_boxes(spec, float(m.geom_friction)))
+                  terrain=_oracle_boxes(spec, float(m.geom_friction)), **world_kw(m))
         if ant:
             o = abd.WalkerEnv(m, prm=abd.Params(power=2.5, **kw), motor_power=np.full(nj, 100.0), alive_z=0.26, alive_bonus=1.0,
                               initial_z=None, torque_f32=False, max_steps=1000)

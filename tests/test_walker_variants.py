@@ -35,12 +35,12 @@ def test_all_768_variants_equal_the_shipped_files():
     want = json.load(open(os.path.join(GOLDEN, "walker_variant_digests.json")))["digests"]
     n = 0
     for robot in ("humanoid", "ant"):
-        assert _digest(variants.model(robot)) == want["%s.xml" % robot]
+        assert _digest(variants.model(robot, preset="mujoco")) == want["%s.xml" % robot]      # digests: MuJoCo's reading of the shipped files
         for split, count in (("TRAIN", 256), ("TEST", 64), ("OOD", 64)):
             names = variants.task_names(robot, split)
             assert len(names) == count
             for i, name in enumerate(names):
-                assert _digest(variants.model(robot, split, i)) == want[name], name
+                assert _digest(variants.model(robot, split, i, preset="mujoco")) == want[name], name
                 n += 1
     assert n == 768 and len(want) == 770
 
@@ -54,11 +54,12 @@ def test_variants_equal_the_reference_files_array_for_array():
         ours = sorted(variants.task_names(robot, "TRAIN") + variants.task_names(robot, "TEST") + variants.task_names(robot, "OOD"))
         assert listed == ours                                     # same task names as meta_humanoids_env.py:18-27 lists
         for name in ours[::7] + ["%s.xml" % robot]:
-            ref = load_mjcf(os.path.join(ASSETS, sub, name), foot_names=variants.FEET[robot]).to_dict()
-            mine = variants.model_from_task_name(name).to_dict()
-            assert set(ref) == set(mine)
-            for k in ref:
-                assert np.array_equal(ref[k], mine[k]), (name, k)
+            for preset in ("bullet", "mujoco"):
+                ref = load_mjcf(os.path.join(ASSETS, sub, name), foot_names=variants.FEET[robot], preset=preset).to_dict()
+                mine = variants.model_from_task_name(name, preset=preset).to_dict()
+                assert set(ref) == set(mine)
+                for k in ref:
+                    assert np.array_equal(ref[k], mine[k]), (name, preset, k)
 
 
 def test_fixture_models_are_the_regenerated_ones():
@@ -69,9 +70,10 @@ def test_fixture_models_are_the_regenerated_ones():
     for key, (robot, split, idx) in {"humanoid": ("humanoid", None, 0), "humanoid_tra_000": ("humanoid", "TRAIN", 0),
                                      "humanoid_tra_137": ("humanoid", "TRAIN", 137), "humanoid_ood_003": ("humanoid", "OOD", 3),
                                      "ant": ("ant", None, 0), "ant_tra_005": ("ant", "TRAIN", 5)}.items():
-        a, b = M[key].to_dict(), variants.model(robot, split, idx).to_dict()
-        for k in a:
-            assert np.array_equal(a[k], b[k]), (key, k)
+        for suffix, preset in (("", None), ("@mujoco", "mujoco")):       # the loader's default preset, and MuJoCo's reading
+            a, b = M[key + suffix].to_dict(), variants.model(robot, split, idx, preset=preset).to_dict()
+            for k in a:
+                assert np.array_equal(a[k], b[k]), (key + suffix, k)
 
 
 def test_pattern_ranges_and_split_rule():

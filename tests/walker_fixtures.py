@@ -1,4 +1,5 @@
-"""Load the parsed MetaLocomotion models committed under tests/golden/walker_models.npz."""
+"""Load the parsed MetaLocomotion models committed under tests/golden/walker_models.npz: "<name>" read with the loader's
+default preset ("bullet", what the envs run by default), "<name>@mujoco" with MuJoCo's reading of the same file."""
 import os
 
 import numpy as np
@@ -15,3 +16,14 @@ def load_models():
         name, field = k.split("/", 1)
         groups.setdefault(name, {})[field] = z[k]
     return {name: Model.from_dict(d) for name, d in groups.items()}
+
+
+def world_kw(m):
+    """The world half of the preset a Model was loaded with (mjcf.PRESETS) as oracle/abd.Params keywords: btMultiBody's body
+    velocity damping and its clamp of the generalized velocities ("bullet": 0.04 / 0.04 and 100; "mujoco": off)."""
+    bd = getattr(m, "body_damping", (0.0, 0.0))
+    return dict(body_damping=(float(bd[0]), float(bd[1])), max_velocity=float(getattr(m, "max_velocity", 0.0)))
+
+
+def preset_of(m):
+    return str(getattr(m, "preset", "mujoco"))
