@@ -318,10 +318,11 @@ def maze_tasks(n_tasks=64):
                             food_interval=20, seed=s) for s in range(n_tasks)]
 
 
-def latest_profile_round():
+def latest_profile_round(holding="pmc_summary.json"):
+    """The newest profiles/rNN/ that holds `holding`."""
     try:
-        rounds = sorted(d for d in os.listdir(os.path.join(ROOT, "profiles")) if d.startswith("r") and d[1:].isdigit())
-        return rounds[-1] if rounds else None
+        rounds = sorted((d for d in os.listdir(os.path.join(ROOT, "profiles")) if d.startswith("r") and d[1:].isdigit()), reverse=True)
+        return next((r for r in rounds if os.path.exists(os.path.join(ROOT, "profiles", r, holding))), None)
     except OSError:
         return None
 
@@ -365,15 +366,15 @@ def from_profiles(n, launch_s):
     return out
 
 
-def north_star_quadrotor(dev, sizes=(131072, 1048576), steps=60, warmup=10):
+def north_star_quadrotor(dev, sizes=(131072, 1048576), steps=60, warmup=10, valu_insts_per_wave=None):
     """north_star's own configuration — Quadrotor hovering_control at 2^20 parallel envs on 8 GPUs, i.e. 2^17 per GPU —
     and the whole 2^20 batch on ONE GPU, through the same QuadrotorShard (staggered clocks, steady-state pre-roll, fused
     auto-reset) as the headline. Both roofline fractions: HBM on the 317 B/env-step of SURVEY.md §8(d), and VALU issue
     from the per-wave instruction count of the committed PMC pass (a wave-instruction holds a SIMD for >= 4 cycles)."""
     out = {}
-    ipw, src = None, None
+    ipw, src = valu_insts_per_wave, "this run's rocprofv3 --pmc SQ_INSTS_VALU / SQ_WAVES pass at the headline batch size (the count is per wave)"
     rnd = latest_profile_round()
-    for r in ([rnd] if rnd else []) + ["r02"]:
+    for r in ([] if ipw else ([rnd] if rnd else []) + ["r03", "r02"]):
         try:
             ipw = float(json.load(open(os.path.join(ROOT, "profiles", r, "pmc_summary.json")))["quadrotor_step_kernel"]["valu_insts_per_wave"])
             src = "profiles/%s/pmc_summary.json" % r
@@ -397,14 +398,14 @@ def north_star_quadrotor(dev, sizes=(131072, 1048576), steps=60, warmup=10):
             e["valu_issue"] = {"valu_insts_per_wave": ipw, "waves_per_launch": waves, "waves_per_simd": waves / 1024.0,
                                "achieved_wave_insts_per_s": ipw * waves / s, "peak_wave_insts_per_s": peak_issue,
                                "frac": ipw * waves / s / peak_issue, "source": src,
-                               "note": "instruction count from the committed PMC pass, launch duration from this run"}
+                               "note": "instruction count per wave from the PMC pass named in `source`, launch duration from this run"}
         out["north_star_quadrotor_hovering_%denvs_1gpu" % n] = e
         del q
         torch.cuda.empty_cache()
     return out
 
 
-def secondary_workloads(dev):
+def secondary_workloads(dev, valu_insts_per_wave=None):
     """The other BASELINE configs on this GPU, each a few dozen launches (reported next to the headline,
     never folded into `value`): C3 MetaMazeDiscrete3D 9x9 at the registered 256x256 resolution with
     16 384 envs, C1 MetaMaze2D 15x15, C4 MetaLocomotion humanoid with 8 192 envs over the 256 TRAIN variants."""
@@ -412,7 +413,7 @@ def secondary_workloads(dev):
     from metagym_amd.metamaze import MazeTaskSampler
     out = {}
     try:
-        out.update(north_star_quadrotor(dev))
+        out.update(north_star_quadrotor(dev, valu_insts_per_wave=valu_insts_per_wave))
     except Exception as e:
         out["north_star_error"] = repr(e)
     try:
@@ -491,17 +492,28 @@ def secondary_workloads(dev):
     try:
         from metagym_amd.metalocomotion import MetaHumanoidEnv, variants
         n = 8192
-        env = MetaHumanoidEnv(num_envs=n, device=dev)
+        # the envs' default preset ("bullet"); fused auto-reset and a batch rolled to its STEADY STATE before
+        # anything is timed: every variant starts with its feet in the ground and is thrown into the air by the first sub-step's
+        # contact ERP, so the first ~150 steps after a reset are contact-free flight — timing those (rounds 1-3 did) flatters
+        # the kernel. After 250 steps the batch is a mix of robots landing, lying, tumbling and restarting.
+        env = MetaHumanoidEnv(num_envs=n, device=dev, auto_reset=True, max_steps=1000, seed=1)
         env.set_task(variants.models("humanoid", "TRAIN"))        # humanoid_var_tra_000..255, env e -> variant e % 256
         env.reset(seed=0)
-        acts = [torch.rand(n, env.n_joints, device=dev) * 2 - 1 for _ in range(4)]
-        s = _time_steps(lambda i: env.step(acts[i % 4]), 12, 3)
+        acts = [torch.rand(n, env.n_joints, device=dev) * 2 - 1 for _ in range(8)]
+        s_flight = _time_steps(lambda i: env.step(acts[i % 8]), 12, 3)
+        for i in range(250):
+            env.step(acts[i % 8])
+        on_ground = float((env.feet_contact.sum(0) > 0).float().mean())
+        low = float((env.pos[2] < 1.0).float().mean())
+        s = _time_steps(lambda i: env.step(acts[i % 8]), 24, 3)
         byt = 625                                                 # SURVEY.md §8(d) C4 bytes per env-step
         flop, flop_src, flop_mix = walker_flops("humanoid")
         if flop is None:
             flop, flop_src = 1.0e5, "SURVEY.md §8(d) estimate (no counted figure found under profiles/)"
         out["C4_humanoid_8192envs_256variants"] = {
-            "env_steps_per_s": n / s, "ms_per_launch": s * 1e3,
+            "env_steps_per_s": n / s, "ms_per_launch": s * 1e3, "preset": env.preset,
+            "steady_state": {"preroll_steps": 265, "frac_envs_with_a_foot_on_the_ground": on_ground, "frac_torsos_below_1m": low,
+                             "ms_per_launch_first_15_steps_after_reset_all_airborne": s_flight * 1e3},
             "roofline": {"bound": "valu", "achieved": flop * n / s / 1e12, "peak": FP64_VALU_PEAK_TFLOPS,
                          "unit": "TFLOP/s", "frac": flop * n / s / 1e12 / FP64_VALU_PEAK_TFLOPS,
                          "algorithmic_flop_per_env_step": flop, "flop_source": flop_src, "flop_mix_per_env_step": flop_mix,
@@ -516,7 +528,7 @@ def secondary_workloads(dev):
     except Exception as e:
         out["walker_error"] = repr(e)
     try:
-        # Quadrupedal: the A1 actuation sub-step around the (absent) physics — ApplyAction + ReceiveObservation
+        # Quadrupedal: the A1 actuation sub-step on its own — ApplyAction + ReceiveObservation
         from metagym_amd.quadrupedal import A1Actuators
         n = ENVS_PER_GPU
         act = A1Actuators(n, dev)                                 # POSITION mode, control latency 0.002 s, pd latency 0
@@ -542,7 +554,7 @@ def secondary_workloads(dev):
             "roofline": {"bound": "hbm", "achieved": byt * n / s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": byt * n / s / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes_per_robot_substep": byt},
             "note": "mg_a1_receive_and_apply (ReceiveObservation + the next sub-step's ApplyAction in one launch, four lanes per robot); bit-exact against the unmodified reference; "
-                    "the A1 body / physics is not built (a1.urdf and PyBullet are absent from the reference tree)"}
+                    "the actuation pair alone, no physics in this figure (quadrupedal_v0_urdf_* below runs the robot on the engine)"}
         del act
         torch.cuda.empty_cache()
         # the whole A1GymEnv.step composition (ETG + IK, 13 x (motor model, history), info, sensors, reward) around a NULL
@@ -599,6 +611,68 @@ def secondary_workloads(dev):
         torch.cuda.empty_cache()
     except Exception as e:
         out["a1_error"] = repr(e)
+    return out
+
+
+# ---------------------------------------------------------------------------------------- in-run counter passes
+PMC_PASSES = (("sq", ("SQ_INSTS_VALU", "SQ_WAVES")), ("fetch", ("FETCH_SIZE",)), ("write", ("WRITE_SIZE",)))
+
+
+def pmc_child(dev, n, preroll):
+    """`bench.py --pmc-child` (run under `rocprofv3 --pmc ...` by pmc_prepass): the headline workload — same shard plan,
+    same steady-state pre-roll — and 24 eager launches of the step kernel; prints nothing."""
+    q = QuadrotorShard(dev, shard_plan(0, 1, n, "quadrotor"), n, preroll=preroll)
+    for i in range(24):
+        q.step(i)
+    torch.cuda.synchronize(dev)
+
+
+def pmc_prepass(n, timeout_s=150):
+    """Hardware counters of quadrotor_step_kernel observed IN THIS RUN: three `rocprofv3 --pmc` child runs of this script
+    (separate passes — VALU instructions + waves, FETCH_SIZE, WRITE_SIZE — counters only, no trace domain, as
+    /opt/skills/guides/MI355X_MICROARCH.md prescribes), averaged over the LAST 24 dispatches of each (the steady-state
+    launches after the pre-roll). Returns {"valu_insts_per_wave", "hbm_bytes_per_launch", ...} with whatever passes worked,
+    and "errors" for those that did not (no rocprofv3 on the box, a timeout, ...): never raises."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    out, errors = {}, {}
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return {"errors": {"rocprofv3": "not found"}}
+    env = dict(os.environ, TMPDIR="/tmp")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "BENCH_FORCE_DIST"):
+        env.pop(k, None)
+    for tag, counters in PMC_PASSES:
+        d = tempfile.mkdtemp(prefix="mg_pmc_%s_" % tag, dir="/tmp")
+        cmd = [exe, "--pmc"] + list(counters) + ["--output-format", "csv", "-d", d, "-o", "q", "--", sys.executable,
+                                                  os.path.abspath(__file__), "--pmc-child", "--envs-per-gpu", str(n)]
+        try:
+            t0 = time.perf_counter()
+            subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=timeout_s, check=True)
+            vals = {}
+            for path in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+                for r in csv.DictReader(open(path)):
+                    if "quadrotor_step_kernel" in r["Kernel_Name"]:
+                        vals.setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
+            for c in counters:
+                if not vals.get(c):
+                    raise RuntimeError("no %s rows for quadrotor_step_kernel" % c)
+                out[c] = sum(vals[c][-24:]) / len(vals[c][-24:])
+            out.setdefault("pass_seconds", {})[tag] = time.perf_counter() - t0
+        except Exception as e:
+            errors[tag] = repr(e)[:200]
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    if "SQ_INSTS_VALU" in out and out.get("SQ_WAVES"):
+        out["valu_insts_per_wave"] = out["SQ_INSTS_VALU"] / out["SQ_WAVES"]
+    if "FETCH_SIZE" in out and "WRITE_SIZE" in out:
+        # both counters are in KB; on gfx950 FETCH_SIZE reports half the bytes of a coalesced read stream (the guide's correction)
+        out["hbm_bytes_per_launch"] = (2.0 * out["FETCH_SIZE"] + out["WRITE_SIZE"]) * 1024.0
+    if errors:
+        out["errors"] = errors
     return out
 
 
@@ -749,6 +823,8 @@ def main(argv=None):
                     help="untimed steps that bring the batch to its steady episode-age mix (default: nt = 1000)")
     ap.add_argument("--single-gpu-value", type=float, default=None,
                     help="a prior N=1 `value`; with it the line carries efficiency = value(N) / (N * value(1))")
+    ap.add_argument("--no-pmc", action="store_true", help="skip the in-run rocprofv3 --pmc passes (VALU instruction count, HBM traffic)")
+    ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--plan-only", action="store_true",
                     help="rendezvous + shard plans only, on CPU (what tests/test_distributed_cpu.py drives); no GPU work")
     args = ap.parse_args(argv)
@@ -804,6 +880,8 @@ def main(argv=None):
         if dist is not None:
             dist.destroy_process_group()
         return
+    if args.pmc_child:
+        return pmc_child(dev, n, args.preroll)
     quad = QuadrotorShard(dev, plan, n, preroll=args.preroll)
     maze = MazeShard(dev, plan, n) if mixed else None
     step = MixedStep(dev, quad, maze) if mixed else quad.step
@@ -895,8 +973,32 @@ def main(argv=None):
                                "traffic": None,
                                "kernel": "quadrotor_step_kernel", "avg_launch_us": launch_s * 1e6,
                                "algorithmic_bytes_per_launch": BYTES_PER_ENV_STEP * n,
-                               "note": "avg_launch_us = HIP events around the timed region / steps (includes "
-                                       "inter-launch gaps); traffic is not observed in this run, see from_profiles"}
+                               "note": "achieved / peak / frac: ALGORITHMIC bytes (317 B/env-step, SURVEY.md §8d) over the average "
+                                       "launch duration (HIP events around the timed region / steps, inter-launch gaps included) "
+                                       "against the 8 TB/s HBM peak. The kernel is NOT HBM-bound: `valu_issue` is the fraction of "
+                                       "the VALU issue rate (one wave-instruction per 4 clk per SIMD, 1024 SIMDs at 2.4 GHz) its "
+                                       "measured instruction count reaches in that same duration; `bound` names the larger"}
+            pmc = {} if (args.no_pmc or world != 1) else pmc_prepass(n)
+            if "hbm_bytes_per_launch" in pmc:
+                out["roofline"]["traffic"] = pmc["hbm_bytes_per_launch"]
+                out["roofline"]["traffic_over_algorithmic"] = pmc["hbm_bytes_per_launch"] / float(BYTES_PER_ENV_STEP * n)
+                out["roofline"]["traffic_source"] = ("this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate child passes of the same "
+                                                     "workload, (2 x FETCH_SIZE + WRITE_SIZE) KB per launch, last 24 launches")
+            if "valu_insts_per_wave" in pmc:
+                waves = (n + 63) // 64
+                peak_issue = 1024 * 2.4e9 / 4.0
+                ach = pmc["valu_insts_per_wave"] * waves / launch_s
+                out["roofline"]["valu_issue"] = {"achieved": ach, "peak": peak_issue, "unit": "wave-instr/s", "frac": ach / peak_issue,
+                                                 "valu_insts_per_wave": pmc["valu_insts_per_wave"], "waves_per_launch": waves,
+                                                 "source": "this run: rocprofv3 --pmc SQ_INSTS_VALU SQ_WAVES child pass of the same "
+                                                           "workload (last 24 launches), launch duration from the timed region"}
+                if ach / peak_issue > out["roofline"]["frac"]:
+                    out["roofline"]["bound"] = "valu_issue"
+                out["roofline"]["bound_frac"] = max(ach / peak_issue, out["roofline"]["frac"])
+            if pmc.get("errors") or not pmc:
+                out["roofline"]["pmc_passes"] = {"skipped": bool(args.no_pmc or world != 1), "errors": pmc.get("errors")}
+            elif "pass_seconds" in pmc:
+                out["roofline"]["pmc_pass_seconds"] = pmc["pass_seconds"]
         else:
             frame_b = 12 * 64 * 64 + 64
             byt = (BYTES_PER_ENV_STEP + frame_b) * n
@@ -922,7 +1024,31 @@ def main(argv=None):
         if world == 1 and not args.no_secondary and not mixed:
             del quad
             torch.cuda.empty_cache()
-            out["secondary"] = secondary_workloads(dev)
+            ipw_run = out.get("roofline", {}).get("valu_issue", {}).get("valu_insts_per_wave")
+            out["secondary"] = secondary_workloads(dev, valu_insts_per_wave=ipw_run)
+            # the other BASELINE configs as short top-level scalars (details under `secondary`)
+            sec = out["secondary"]
+
+            def pick(key, *path):
+                v = sec.get(key)
+                for k in path:
+                    v = v.get(k) if isinstance(v, dict) else None
+                return v if isinstance(v, (int, float)) else None
+            for name, key, path in (
+                    ("C3_maze3d_discrete_env_steps_per_s", "C3_maze3d_discrete_9x9_256x256_16384envs", ("env_steps_per_s",)),
+                    ("C3_maze3d_discrete_hbm_frac", "C3_maze3d_discrete_9x9_256x256_16384envs", ("roofline", "frac")),
+                    ("C3_maze3d_continuous_env_steps_per_s", "C3_maze3d_continuous_9x9_256x256_16384envs", ("env_steps_per_s",)),
+                    ("C3_maze3d_continuous_hbm_frac", "C3_maze3d_continuous_9x9_256x256_16384envs", ("roofline", "frac")),
+                    ("C4_humanoid_env_steps_per_s", "C4_humanoid_8192envs_256variants", ("env_steps_per_s",)),
+                    ("C4_humanoid_f64_valu_frac", "C4_humanoid_8192envs_256variants", ("roofline", "frac")),
+                    ("C5_share_env_steps_per_s", "C5_mixed_share_65536quad_plus_65536maze3d_64x64", ("env_steps_per_s_two_streams",)),
+                    ("C1_maze2d_1env_us_per_step_hipgraph", "C1_maze2d_15x15_escape_1env", ("us_per_step_hipgraph_100",)),
+                    ("north_star_2p17_env_steps_per_s", "north_star_quadrotor_hovering_131072envs_1gpu", ("env_steps_per_s",)),
+                    ("north_star_2p20_env_steps_per_s", "north_star_quadrotor_hovering_1048576envs_1gpu", ("env_steps_per_s",)),
+                    ("quadrupedal_v0_env_steps_per_s", "quadrupedal_v0_urdf_8192envs", ("env_steps_per_s_hipgraph",))):
+                v = pick(key, *path)
+                if v is not None:
+                    out[name] = v
         if world == 1 and not args.no_cpu_baseline:
             port = cpu_port()
             ref, why = cpu_reference()

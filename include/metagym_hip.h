@@ -225,6 +225,13 @@ typedef struct mg_maze_tasks {
     const int16_t *food_cells;     /* [T][max_food] */
     const int32_t *n_food;         /* [T] */
     int32_t max_food;
+    /* (ABI 5) The same list once more, laid out for the lane-per-env 2-D kernel whose neighbouring lanes run DIFFERENT tasks
+     * (NULL = not provided; needed when mg_maze_state.food_by_slot is set): cell_slot inverts food_cells; slot_food /
+     * slot_interval hold food_rewards / food_interval of the k-th listed cell of task t at [k * T + t], so lanes with consecutive
+     * task ids (the default assignment e mod T) read consecutive addresses. */
+    const int16_t *cell_slot;      /* [T][n*n]: index k of the cell in its task's list, -1 for a cell that can never hold food */
+    const double *slot_food;       /* [max_food][T] */
+    const int32_t *slot_interval;  /* [max_food][T] */
 } mg_maze_tasks;
 
 /* Per-env episode state (MazeBase.reset maze_base.py:40-63 + the 3-D cores). The SURVIVAL arrays
@@ -244,6 +251,12 @@ typedef struct mg_maze_state {
     uint8_t *wait_refresh;/* [N][n*n] SURVIVAL _food_wait_refresh (0/1) */
     int32_t *revival;     /* [N][n*n] SURVIVAL _food_revival_count */
     int64_t food_env_stride, food_cell_stride;   /* element strides of the three SURVIVAL arrays */
+    /* (ABI 5) 1: the SURVIVAL arrays hold `max_food` food SLOTS per env instead of n*n cells — slot k (the k-th cell of the env's
+     * task's food_cells list) of env e at e*food_env_stride + k*food_cell_stride; cells outside the list keep their task values
+     * for ever and are not stored. For mg_maze2d_step / mg_maze_reset with [max_food][N] arrays (env_stride 1, cell_stride N): lane
+     * e's k-th access is coalesced whatever task it runs — indexed by cell, every lane of a wave touched a different [n*n][N] row
+     * (22x slower than ESCAPE at 2^20 envs). Needs mg_maze_tasks.food_cells / cell_slot / slot_food / slot_interval. */
+    int32_t food_by_slot;
 } mg_maze_state;
 
 /* First-person renderer constants (MazeCoreDiscrete3D.__init__ maze_discrete_3d.py:18-37 and the

@@ -58,7 +58,8 @@ class MazeTasks(C.Structure):
     _fields_ = [("n", C.c_int32), ("n_tasks", C.c_int32), ("start", C.c_void_p), ("goal", C.c_void_p),
                 ("walls", C.c_void_p), ("texts", C.c_void_p), ("food_rewards", C.c_void_p),
                 ("food_interval", C.c_void_p), ("scalars", C.c_void_p),
-                ("food_cells", C.c_void_p), ("n_food", C.c_void_p), ("max_food", C.c_int32)]
+                ("food_cells", C.c_void_p), ("n_food", C.c_void_p), ("max_food", C.c_int32),
+                ("cell_slot", C.c_void_p), ("slot_food", C.c_void_p), ("slot_interval", C.c_void_p)]
 
 
 class MazeSampleParams(C.Structure):
@@ -76,7 +77,7 @@ class MazeState(C.Structure):
     _fields_ = [("task_id", C.c_void_p), ("grid", C.c_void_p), ("steps", C.c_void_p), ("ori_idx", C.c_void_p),
                 ("ori", C.c_void_p), ("loc", C.c_void_p), ("life", C.c_void_p), ("cur_food", C.c_void_p),
                 ("wait_refresh", C.c_void_p), ("revival", C.c_void_p),
-                ("food_env_stride", C.c_int64), ("food_cell_stride", C.c_int64)]
+                ("food_env_stride", C.c_int64), ("food_cell_stride", C.c_int64), ("food_by_slot", C.c_int32)]
 
 
 class MazeView(C.Structure):

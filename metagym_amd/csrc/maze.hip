@@ -52,6 +52,10 @@ struct Task {   // one row of the task table, resolved for an env
     const int32_t *interval;
     const int16_t *food_cells;   // optional compact list of the cells that can hold food (NULL = all cells)
     int n_food;
+    const int16_t *cell_slot;    // (slot layout) inverse of food_cells for this task: slot of a cell, -1 = never holds food
+    const double *slot_food;     // (slot layout) [k * slot_stride]: food_rewards of the task's k-th listed cell
+    const int32_t *slot_interval;
+    int slot_stride;
     int sx, sy, gx, gy;
     double cell_size, wall_h, agent_h, init_life, max_life, step_reward, goal_reward;
 };
@@ -67,6 +71,10 @@ __device__ __forceinline__ Task load_task(const mg_maze_tasks &T, int tid) {
     t.interval = T.food_interval ? T.food_interval + off : nullptr;
     t.food_cells = (T.food_cells != nullptr && T.n_food != nullptr) ? T.food_cells + (size_t)tid * T.max_food : nullptr;
     t.n_food = t.food_cells ? T.n_food[tid] : t.nn;
+    t.cell_slot = T.cell_slot ? T.cell_slot + off : nullptr;
+    t.slot_food = T.slot_food ? T.slot_food + tid : nullptr;
+    t.slot_interval = T.slot_interval ? T.slot_interval + tid : nullptr;
+    t.slot_stride = T.n_tasks;
     t.sx = T.start[2 * tid];
     t.sy = T.start[2 * tid + 1];
     t.gx = T.goal[2 * tid];
@@ -130,6 +138,15 @@ __device__ __forceinline__ size_t fidx(const mg_maze_state &st, int e, int c) {
 // nothing ever changes a cell whose food is <= 1e-2 and whose interval is 0.
 __device__ __forceinline__ void reset_cells(const Task &t, const mg_maze_state &st, int e, int first, int stride,
                                             bool full) {
+    if (st.food_by_slot) {            // slot layout: the listed cells are all there is
+        for (int k = first; k < t.n_food; k += stride) {
+            const size_t i = fidx(st, e, k);
+            st.wait_refresh[i] = 0;
+            st.cur_food[i] = t.slot_food[(size_t)k * t.slot_stride];
+            st.revival[i] = t.slot_interval[(size_t)k * t.slot_stride];
+        }
+        return;
+    }
     const bool listed = !full && t.food_cells != nullptr;
     const int count = listed ? t.n_food : t.nn;
     for (int k = first; k < count; k += stride) {
@@ -146,9 +163,11 @@ __device__ __forceinline__ int eval_scalar(const Task &t, const mg_maze_state &s
                                            int max_steps, Agent &a, double &reward) {
     a.steps += 1;
     if (task_type == MG_MAZE_SURVIVAL) {
-        const size_t g = fidx(st, e, a.gx * t.n + a.gy);
+        int c = a.gx * t.n + a.gy;
+        if (st.food_by_slot) c = t.cell_slot[c];            // a cell outside the list never holds more than 1e-2: nothing to eat
+        const size_t g = c >= 0 ? fidx(st, e, c) : 0;
         double r = 0.0;
-        const double f = st.cur_food[g];
+        const double f = c >= 0 ? st.cur_food[g] : 0.0;
         if (f > 1.0e-2) {                                   // :71-75
             r = f;
             st.wait_refresh[g] = 1;
@@ -169,6 +188,19 @@ __device__ __forceinline__ int eval_scalar(const Task &t, const mg_maze_state &s
 // interval * (food_rewards > 1e-3), maze_task.py:172): its wait flag stays 0 and its counter stays
 // 0, so skipping it is exact and saves the HBM round trip for the ~95 % of cells that are empty.
 __device__ __forceinline__ void eval_cells(const Task &t, const mg_maze_state &st, int e, int first, int stride) {
+    if (st.food_by_slot) {
+        for (int k = first; k < t.n_food; k += stride) {
+            const size_t i = fidx(st, e, k);
+            int rv = st.revival[i] - (int)st.wait_refresh[i];
+            if (rv < 0) {
+                st.cur_food[i] = t.slot_food[(size_t)k * t.slot_stride];
+                rv = t.slot_interval[(size_t)k * t.slot_stride];
+                st.wait_refresh[i] = 0;
+            }
+            st.revival[i] = rv;
+        }
+        return;
+    }
     for (int k = first; k < t.n_food; k += stride) {
         const int c = t.food_cells ? (int)t.food_cells[k] : k;
         const int interval = t.interval[c];
@@ -224,7 +256,14 @@ __global__ __launch_bounds__(MZ_BLOCK) void maze2d_step_kernel(mg_maze_tasks T, 
             float v = -1.0f;
             if (x >= 0 && x < t.n && y >= 0 && y < t.n) {
                 v = (float)(-(int)t.walls[x * t.n + y]);                                   // :113
-                if (task_type == MG_MAZE_SURVIVAL) v = (float)((double)v + st.cur_food[fidx(st, e, x * t.n + y)]);  // :117
+                if (task_type == MG_MAZE_SURVIVAL) {                                       // :117
+                    double food;
+                    if (st.food_by_slot) {
+                        const int k = t.cell_slot[x * t.n + y];
+                        food = k >= 0 ? st.cur_food[fidx(st, e, k)] : t.food[x * t.n + y];
+                    } else food = st.cur_food[fidx(st, e, x * t.n + y)];
+                    v = (float)((double)v + food);
+                }
                 else v = (float)((double)v + ((x == t.gx && y == t.gy) ? 1.0 : 0.0));       // :120
             }
             o[p * w + q] = v;
@@ -935,6 +974,14 @@ int check_mstate(const mg_maze_state *s, int task_type) {
     return MG_OK;
 }
 
+int check_slots(const mg_maze_tasks *T, const mg_maze_state *s, int task_type) {
+    if (task_type == MG_MAZE_SURVIVAL && s->food_by_slot &&
+        (!T->food_cells || !T->n_food || !T->cell_slot || !T->slot_food || !T->slot_interval || T->max_food < 1))
+        return mg::set_error(MG_ERR_NULL_POINTER, "mg_maze_state.food_by_slot needs mg_maze_tasks.food_cells / n_food / cell_slot / "
+                             "slot_food / slot_interval");
+    return MG_OK;
+}
+
 }  // namespace
 
 extern "C" int mg_maze_view_tables(int32_t res_h, double tan_half_fov, double l_focal, double *col_cos,
@@ -963,6 +1010,7 @@ extern "C" int mg_maze_reset(const mg_maze_tasks *T, int32_t task_type, int32_t 
     if (n <= 0) return mg::set_error(MG_ERR_BAD_SIZE, "n_envs=%d", n);
     if (int rc = check_tasks(T, task_type)) return rc;
     if (int rc = check_mstate(st, task_type)) return rc;
+    if (int rc = check_slots(T, st, task_type)) return rc;
     const long threads = (long)n * 64;
     mg::DeviceGuard guard(mg::device_of(st->grid));
     hipLaunchKernelGGL(maze_reset_kernel, dim3((unsigned)((threads + MZ_BLOCK - 1) / MZ_BLOCK)), dim3(MZ_BLOCK), 0,
@@ -980,6 +1028,7 @@ extern "C" int mg_maze2d_step(const mg_maze_tasks *T, int32_t task_type, int32_t
     if (n <= 0 || view_grid < 0) return mg::set_error(MG_ERR_BAD_SIZE, "n_envs=%d view_grid=%d", n, view_grid);
     if (int rc = check_tasks(T, task_type)) return rc;
     if (int rc = check_mstate(st, task_type)) return rc;
+    if (int rc = check_slots(T, st, task_type)) return rc;
     mg::DeviceGuard guard(mg::device_of(st->grid));
     hipLaunchKernelGGL(maze2d_step_kernel, dim3((n + MZ_BLOCK - 1) / MZ_BLOCK), dim3(MZ_BLOCK), 0, (hipStream_t)stream,
                        *T, *st, task_type, max_steps, view_grid, auto_reset, n, action, obs, reward, reward64, done);
@@ -998,6 +1047,8 @@ extern "C" int mg_maze3d_step(const mg_maze_tasks *T, const mg_maze_view *view, 
     if (n <= 0) return mg::set_error(MG_ERR_BAD_SIZE, "n_envs=%d", n);
     if (int rc = check_tasks(T, task_type)) return rc;
     if (int rc = check_mstate(st, task_type)) return rc;
+    if (task_type == MG_MAZE_SURVIVAL && st->food_by_slot)
+        return mg::set_error(MG_ERR_UNSUPPORTED, "mg_maze3d_step reads the SURVIVAL arrays by cell (food_by_slot is the 2-D kernel's layout)");
     if (continuous && (!st->ori || !st->loc)) return mg::set_error(MG_ERR_NULL_POINTER, "continuous needs ori / loc");
     if (!continuous && !st->ori_idx) return mg::set_error(MG_ERR_NULL_POINTER, "discrete needs ori_idx");
     if (view->res_h <= 0 || view->res_v <= 0 || view->res_v > 4095 || view->res_h > 32767)

@@ -104,6 +104,19 @@ class _MazeBatch(object):
         self._food_cells_t = order.to(torch.int16).contiguous()
         self._n_food_t = n_food.contiguous()
         c.food_cells, c.n_food, c.max_food = self._food_cells_t.data_ptr(), self._n_food_t.data_ptr(), max_food
+        self._max_food = max_food
+        if self._BY_SLOT:
+            # the list once more for the lane-per-env kernel (mg_maze_tasks.cell_slot / slot_food / slot_interval): the inverse
+            # map cell -> slot, and the listed cells' task values slot-major, [max_food][T]
+            listed = torch.arange(max_food, device=dev).unsqueeze(0) < n_food.unsqueeze(1)              # [T, max_food]
+            slot = torch.full((T, nn), -1, dtype=torch.int16, device=dev)
+            ks = torch.arange(max_food, device=dev, dtype=torch.int16).unsqueeze(0).expand(T, max_food)
+            slot.scatter_(1, order, torch.where(listed, ks, torch.full_like(ks, -1)))      # (a row of `order` holds distinct cells)
+            self._cell_slot_t = slot.contiguous()
+            self._slot_food_t = torch.gather(tt_food, 1, order).t().contiguous()
+            self._slot_interval_t = torch.gather(tt_int, 1, order).t().contiguous()
+            c.cell_slot, c.slot_food, c.slot_interval = (self._cell_slot_t.data_ptr(), self._slot_food_t.data_ptr(),
+                                                         self._slot_interval_t.data_ptr())
         self._tasks_c = c
         if task_ids is None:
             task_ids = torch.arange(N, dtype=torch.int32) % T
@@ -121,14 +134,16 @@ class _MazeBatch(object):
         st.ori_idx, st.ori, st.loc, st.life = (self.ori_idx.data_ptr(), self.ori.data_ptr(), self.loc.data_ptr(),
                                                self.life.data_ptr())
         if self._tt == TASK_TYPES["SURVIVAL"]:
-            # [N, nn] for the workgroup-per-env 3-D kernel, [nn, N] for the lane-per-env 2-D kernel
-            shape = (nn, N) if self._CELL_MAJOR else (N, nn)
+            # [N, nn] cells for the workgroup-per-env 3-D kernel; [max_food, N] food SLOTS for the lane-per-env 2-D kernel
+            # (mg_maze_state.food_by_slot: lane e's k-th access is coalesced whatever task it runs)
+            shape = (self._max_food, N) if self._BY_SLOT else (N, nn)
             self.cur_food = torch.zeros(*shape, dtype=torch.float64, device=dev)
             self.wait_refresh = torch.zeros(*shape, dtype=torch.uint8, device=dev)
             self.revival = torch.zeros(*shape, dtype=torch.int32, device=dev)
             st.cur_food, st.wait_refresh, st.revival = (self.cur_food.data_ptr(), self.wait_refresh.data_ptr(),
                                                         self.revival.data_ptr())
-            st.food_env_stride, st.food_cell_stride = (1, N) if self._CELL_MAJOR else (nn, 1)
+            st.food_env_stride, st.food_cell_stride = (1, N) if self._BY_SLOT else (nn, 1)
+            st.food_by_slot = int(self._BY_SLOT)
         self._state_c = st
         self._on_set_task()
         self.need_set_task = False
@@ -137,20 +152,49 @@ class _MazeBatch(object):
     def _on_set_task(self):
         pass
 
-    _CELL_MAJOR = False
+    _BY_SLOT = False
     _STATE_KEYS = ("grid", "steps", "ori_idx", "ori", "loc", "life", "cur_food", "wait_refresh", "revival")
+    _FOOD_KEYS = ("cur_food", "wait_refresh", "revival")
+
+    def _food_by_cell(self, key):
+        """(slot layout) the [n*n, N] by-cell view of a SURVIVAL array — the checkpoint format, independent of how the kernel
+        stores it: a listed cell's slot value, else what the cell holds for ever (its task's food value, wait 0, counter =
+        its interval)."""
+        tid = self.task_id.long()
+        slot = self._cell_slot_t[tid].t().long()                                   # [nn, N]
+        have = slot >= 0
+        val = torch.gather(getattr(self, key), 0, slot.clamp(min=0))
+        if key == "cur_food":
+            rest = self._task_t["food_rewards"][tid].t()
+        elif key == "revival":
+            rest = self._task_t["food_interval"][tid].t()
+        else:
+            rest = torch.zeros_like(val)
+        return torch.where(have, val, rest.to(val.dtype)).contiguous()
 
     def state_dict(self):
-        """Per-env arrays + task_id: the SURVIVAL food arrays only make sense next to the task they were drawn for."""
-        sd = {k: getattr(self, k).clone() for k in self._STATE_KEYS if hasattr(self, k)}
+        """Per-env arrays + task_id: the SURVIVAL food arrays only make sense next to the task they were drawn for. The food
+        arrays are always written by CELL ([n*n, N] for the 2-D env, [N, n*n] for the 3-D ones)."""
+        sd = {}
+        for k in self._STATE_KEYS:
+            if hasattr(self, k):
+                sd[k] = self._food_by_cell(k) if (self._BY_SLOT and k in self._FOOD_KEYS) else getattr(self, k).clone()
         if hasattr(self, "task_id"):
             sd["task_id"] = self.task_id.clone()
         return sd
 
     def load_state_dict(self, sd):
-        for k in self._STATE_KEYS + ("task_id",):
+        if "task_id" in sd and hasattr(self, "task_id"):          # first: the by-cell food arrays are read through the task's slots
+            self.task_id.copy_(torch.as_tensor(sd["task_id"]).to(self.task_id.dtype))
+        for k in self._STATE_KEYS:
             if hasattr(self, k) and k in sd:
-                dst, src = getattr(self, k), torch.as_tensor(sd[k])
+                dst, src = getattr(self, k), torch.as_tensor(sd[k]).to(self.device)
+                if self._BY_SLOT and k in self._FOOD_KEYS:
+                    if tuple(src.shape) != (self.n * self.n, self.num_envs):
+                        raise ValueError("state_dict[%r] has shape %s, expected the by-cell view %s" % (k, tuple(src.shape), (self.n * self.n, self.num_envs)))
+                    cells = self._food_cells_t[self.task_id.long()].t().long()   # [max_food, N]: the cell behind every slot
+                    dst.copy_(torch.gather(src, 0, cells).to(dst.dtype))           # (slots past a task's n_food are never read)
+                    continue
                 if tuple(src.shape) != tuple(dst.shape):
                     raise ValueError("state_dict[%r] has shape %s, this env holds %s (same num_envs and maze size n needed)"
                                      % (k, tuple(src.shape), tuple(dst.shape)))
@@ -187,7 +231,7 @@ class _MazeBatch(object):
 
 class MetaMaze2D(_MazeBatch):
     """maze_env.py:155-212. obs float32 [N, 2v+1, 2v+1]; action int in {0..3} per env."""
-    _CELL_MAJOR = True
+    _BY_SLOT = True       # SURVIVAL arrays per food slot, [max_food, N] (mg_maze_state.food_by_slot)
 
     def __init__(self, num_envs=1, device="cuda", enable_render=False, render_scale=480, max_steps=5000,
                  task_type="SURVIVAL", view_grid=2, auto_reset=False):

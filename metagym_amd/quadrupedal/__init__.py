@@ -1,7 +1,9 @@
-"""Batched Quadrupedal (Unitree A1) — the ACTUATION path of metagym/quadrupedal (robots/minitaur.py, a1.py,
-laikago_motor.py): motor model, observation history with latency, sensor getters — and the control-side wrappers of
-A1GymEnv.step (envs/env_wrappers/MonitorEnv.py): ETG action path, reward shaping. The A1 body / physics is not built:
-a1.urdf ships with pybullet_data and the dynamics are PyBullet's, neither is in the reference tree."""
+"""Batched Quadrupedal (Unitree A1), `quadrupedal-v0`: the actuation path of metagym/quadrupedal (robots/minitaur.py, a1.py,
+laikago_motor.py: motor model, observation history with latency, sensor getters), the control-side wrappers of A1GymEnv.step
+(envs/env_wrappers/MonitorEnv.py: ETG action path, reward shaping, pushes), the task terrains, and `A1Physics`: a URDF robot on
+this repo's articulated-body engine. Everything the reference computes in Python is pinned to it; the dynamics are an own
+engine (the reference calls PyBullet, and a1.urdf ships with pybullet_data — neither is in the reference tree: bring the
+file)."""
 from .a1_actuators import A1Actuators, MotorControlMode, SoA, INIT_MOTOR_ANGLES, MOTOR_NAMES
 from .a1_env import A1GymEnv
 from .a1_physics import A1Physics

@@ -40,6 +40,7 @@ register("meta-humanoid-v0", "metagym_amd.metalocomotion:MetaHumanoidEnv",
 register("meta-ant-v0", "metagym_amd.metalocomotion:MetaAntEnv",
          kwargs={"frame_skip": 4, "time_step": 0.005, "enable_render": False, "max_steps": 2000})
 
-# metagym/quadrupedal/__init__.py:6-21. The env needs the caller's batched physics (`physics=`): the A1 body and PyBullet
-# are not in the reference tree; everything around the physics runs on the GPU (metagym_amd/quadrupedal/a1_env.py).
+# metagym/quadrupedal/__init__.py:6-21. The robot file is the caller's (`urdf=`: a1/a1.urdf ships with pybullet_data, not with
+# the reference) and runs on this repo's articulated-body engine (metagym_amd.quadrupedal.A1Physics), or hand over a batched
+# simulator of your own (`physics=`).
 register("quadrupedal-v0", "metagym_amd.quadrupedal:A1GymEnv", kwargs={"physics": None, "ETG": 0, "ETG_T": 0.5, "ETG_H": 20, "task": "plane"})

@@ -171,6 +171,24 @@ def test_maze2d_batch_matches_oracle():
                 for e in np.nonzero(d)[0]:
                     mo.reset(otasks[ids[e]], tt, states[e])
         assert np.array_equal(env.grid.cpu().numpy().T, np.asarray([list(s.c.grid) for s in states]))
+        if task_type == "SURVIVAL":
+            # the kernel keeps the SURVIVAL arrays per food SLOT ([max_food, N], mg_maze_state.food_by_slot); state_dict hands
+            # them out by CELL like the reference's arrays — every cell of every env against the oracle — and reads them back
+            assert env.cur_food.shape == (env._max_food, n) and env._max_food < 15 * 15
+            sd = env.state_dict()
+            for key, get in (("cur_food", lambda s: s.cur_food), ("wait_refresh", lambda s: s.wait), ("revival", lambda s: s.revival)):
+                got = sd[key].cpu().numpy()
+                assert got.shape == (15 * 15, n)
+                assert np.array_equal(got.T, np.asarray([get(s) for s in states])), key
+            twin = metagym_amd.make("meta-maze-2D-v0", num_envs=n, device="cuda:0", max_steps=25, view_grid=1, task_type=task_type)
+            twin.set_task(tasks, task_ids=torch.zeros(n, dtype=torch.int32))      # (other tasks: load_state_dict brings task_id along)
+            twin.reset()
+            twin.load_state_dict(sd)
+            for t in range(6):
+                a = torch.as_tensor(rs.randint(0, 4, n))
+                ra, rb = env.step(a), twin.step(a)
+                assert torch.equal(ra[0], rb[0]) and torch.equal(env.reward64, twin.reward64) and torch.equal(ra[2], rb[2])
+                env.reset(mask=ra[2]); twin.reset(mask=rb[2])
 
 
 @pytest.mark.parametrize("continuous", [False, True])
