@@ -641,6 +641,13 @@ typedef struct mg_a1_reward_config {
     int32_t n_segments;            /* info["env_info"] rows (locomotion_gym_env.py:76): x0, x1, upslope, downslope, angle */
     double seg[MG_A1_MAX_SEGMENTS][5];
     int32_t vel_mode;              /* 0 "max": min(vel_d, v) (the default); 1 "equal": exp(-5 |v - vel_d|)  (MonitorEnv.py:512-518) */
+    /* (ABI 5) Per-robot terrains — the reference rebuilds its terrain, and with it info["env_info"], in reset(hardset=True, ...)
+     * (locomotion_gym_env.py:297-301): with terrain_id != NULL robot e's stretches are rows [0, seg_count[t]) of
+     * seg_table[t], t = terrain_id[e] (the same index mg_walker_params.terrain_id selects the boxes with), and n_segments /
+     * seg above are not read. */
+    const double *seg_table;       /* DEVICE f64 [T][MG_A1_MAX_SEGMENTS][5] */
+    const int32_t *seg_count;      /* DEVICE i32 [T] */
+    const int32_t *terrain_id;     /* DEVICE i32 [N] */
 } mg_a1_reward_config;
 
 typedef struct mg_a1_reward_state {

@@ -177,7 +177,8 @@ class A1RewardConfig(C.Structure):
     _fields_ = [("w_torso", C.c_double), ("w_up", C.c_double), ("w_feet", C.c_double), ("w_tau", C.c_double),
                 ("w_badfoot", C.c_double), ("w_footcontact", C.c_double), ("reward_p", C.c_double), ("vel_d", C.c_double),
                 ("cw_half", C.c_double), ("cw_04", C.c_double), ("n_segments", C.c_int32),
-                ("seg", (C.c_double * 5) * A1_MAX_SEGMENTS), ("vel_mode", C.c_int32)]
+                ("seg", (C.c_double * 5) * A1_MAX_SEGMENTS), ("vel_mode", C.c_int32),
+                ("seg_table", C.c_void_p), ("seg_count", C.c_void_p), ("terrain_id", C.c_void_p)]
 
 
 class A1RewardState(C.Structure):

@@ -340,8 +340,18 @@ __global__ __launch_bounds__(A1_BLOCK) void a1_etg_kernel(EtgK k, int n, double 
 
 struct RewK { mg_a1_reward_config c; };
 
-__device__ __forceinline__ void env_vec(const mg_a1_reward_config &c, double posex, int &up, int &down, double &ang) {
+__device__ __forceinline__ void env_vec(const mg_a1_reward_config &c, int e, double posex, int &up, int &down, double &ang) {
     up = 0; down = 0; ang = 0.0;
+    if (c.terrain_id != nullptr) {       // per-robot terrains: this robot's course of the segment table
+        const int t = c.terrain_id[e];
+        const double *seg = c.seg_table + (size_t)t * MG_A1_MAX_SEGMENTS * 5;
+        for (int s = 0; s < c.seg_count[t]; ++s)
+            if (posex + 0.2 >= seg[5 * s] && posex + 0.2 <= seg[5 * s + 1]) {
+                up = seg[5 * s + 2] != 0.0; down = seg[5 * s + 3] != 0.0; ang = seg[5 * s + 4];
+                return;
+            }
+        return;
+    }
     for (int s = 0; s < c.n_segments; ++s)
         if (posex + 0.2 >= c.seg[s][0] && posex + 0.2 <= c.seg[s][1]) {          // :328-333
             up = c.seg[s][2] != 0.0; down = c.seg[s][3] != 0.0; ang = c.seg[s][4];
@@ -360,11 +370,11 @@ __device__ __forceinline__ double re_rot(const mg_a1_reward_config &c, double ya
     return fmin(k * r, r);
 }
 // the direction block shared by re_torso (:481-497) and re_feet (:431-446); vd2 persists (mutable default argument)
-__device__ __forceinline__ void direction(const mg_a1_reward_config &c, double d_yaw, double posex, double &vd0, double &vd1,
+__device__ __forceinline__ void direction(const mg_a1_reward_config &c, int e, double d_yaw, double posex, double &vd0, double &vd1,
                                           double &vd2) {
     vd0 = cos(d_yaw); vd1 = sin(d_yaw);
     int up, down; double ang;
-    env_vec(c, posex, up, down, ang);
+    env_vec(c, e, posex, up, down, ang);
     if (up) { vd0 *= fabs(cos(ang)); vd1 *= fabs(cos(ang)); vd2 = fabs(sin(ang)); }
     else if (down) { vd0 *= fabs(cos(ang)); vd1 *= fabs(cos(ang)); vd2 = -fabs(sin(ang)); }
 }
@@ -412,7 +422,7 @@ __global__ __launch_bounds__(A1_BLOCK) void a1_reward_step_kernel(RewK k, mg_a1_
     const double roll = pose[e], pitch0 = pose[(size_t)n + e], yaw = pose[2 * (size_t)n + e];
     // torso :475-506
     double vd0, vd1, vd2 = st.vd2[e];
-    direction(c, d_yaw, b[0], vd0, vd1, vd2);
+    direction(c, e, d_yaw, b[0], vd0, vd1, vd2);
     st.vd2[e] = vd2;
     double v_ = (v[0] * vd0 + v[1] * vd1) + v[2] * vd2;
     const double v_reward = c.vel_mode == 1 ? exp(-5.0 * fabs(v_ - c.vel_d)) : fmin(c.vel_d, v_);   // :512-518
@@ -420,14 +430,14 @@ __global__ __launch_bounds__(A1_BLOCK) void a1_reward_step_kernel(RewK k, mg_a1_
     const double kk = 1 - c_prec(fmin(v[0], c.vel_d), c.vel_d, c.cw_half);       // :377
     // up :394-409
     int up_f, down_f; double ang;
-    env_vec(c, b[0], up_f, down_f, ang);
+    env_vec(c, e, b[0], up_f, down_f, ang);
     double pitch = pitch0;
     if (up_f) pitch += fabs(ang);
     else if (down_f) pitch -= fabs(ang);
     const double up = (c.w_up * (1 - c_prec(sqrt(roll * roll + pitch * pitch), 0.0, c.cw_04))) * kk;
     // feet :430-456
     double wd0, wd1, wd2 = st.vd2[(size_t)n + e];
-    direction(c, d_yaw, b[0], wd0, wd1, wd2);
+    direction(c, e, d_yaw, b[0], wd0, wd1, wd2);
     st.vd2[(size_t)n + e] = wd2;
     double fw[12];
     foot_world(rot, base, foot, n, e, fw);

@@ -343,8 +343,49 @@ class WalkerBatchEnv(object):
         if getattr(self, "_robot_set", False):
             self._apply_terrain()
 
+    def set_terrain_table(self, n_courses, max_boxes, terrain_id=None):
+        """Per-robot terrains (mg_walker_params.terrain_id): a table of `n_courses` courses of up to `max_boxes` boxes each and the
+        course every robot stands on (`terrain_id`: int32 [num_envs] device tensor, default all 0; kept by reference — rewrite it
+        in place, e.g. for the robots of a masked reset). Courses start empty; fill them with `write_course`."""
+        assert getattr(self, "_robot_set", False), "set_task first"
+        N, dev = self.num_envs, self.device
+        self._terrain_spec = None
+        tab = torch.zeros(int(n_courses), int(max_boxes), _lib.WALKER_BOX_DOUBLES, dtype=torch.float64, device=dev)
+        tab[:, :, 0] = 1.0e30                                    # an unused box: zero extent, parked far away (skipped by its x range)
+        tab[:, :, 3], tab[:, :, 7], tab[:, :, 11] = 1.0, 1.0, 1.0
+        self._terrain_t = tab
+        self.terrain_id = torch.zeros(N, dtype=torch.int32, device=dev) if terrain_id is None else terrain_id
+        assert self.terrain_id.dtype == torch.int32 and self.terrain_id.shape == (N,) and self.terrain_id.is_contiguous()
+        p = self._params_c
+        p.n_terrain_boxes, p.terrain, p.terrain_id, p.n_terrain_tables = int(max_boxes), tab.data_ptr(), self.terrain_id.data_ptr(), int(n_courses)
+
+    def write_course(self, index, boxes):
+        """Course `index` of the terrain table <- `boxes` ((half_extents, position, quaternion (x, y, z, w), friction) each, like
+        set_terrain; fewer than the table's max_boxes: the rest stay unused)."""
+        tab = self._terrain_t
+        assert tab is not None and tab.dim() == 3 and 0 <= index < tab.shape[0] and len(boxes) <= tab.shape[1], \
+            "course %d with %d boxes does not fit the terrain table %s" % (index, len(boxes), None if tab is None else tuple(tab.shape))
+        rows = np.zeros((tab.shape[1], _lib.WALKER_BOX_DOUBLES))
+        rows[:, 0], rows[:, 3], rows[:, 7], rows[:, 11] = 1.0e30, 1.0, 1.0, 1.0
+        if boxes:
+            rows[:len(boxes)] = self._box_rows(boxes)
+        tab[index].copy_(torch.as_tensor(rows, dtype=torch.float64, device=self.device))
+
+    def _box_rows(self, spec):
+        rows = np.zeros((len(spec), _lib.WALKER_BOX_DOUBLES))
+        for i, (half, pos, quat, friction) in enumerate(spec):
+            x, y, z, w = [float(v) for v in quat]
+            nq = np.sqrt(x * x + y * y + z * z + w * w)
+            x, y, z, w = x / nq, y / nq, z / nq, w / nq
+            R = [1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y), 2 * (x * y + w * z), 1 - 2 * (x * x + z * z),
+                 2 * (y * z - w * x), 2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)]
+            rows[i, 0:3], rows[i, 3:12], rows[i, 12:15] = pos, R, half
+            rows[i, 15] = float(friction) * (1.0 if self.per_proxy_friction else float(self._geom_friction))
+        return rows
+
     def _apply_terrain(self):
         spec, p = getattr(self, "_terrain_spec", None), self._params_c
+        p.terrain_id, p.n_terrain_tables = None, 0
         if not spec:
             self._terrain_t, p.n_terrain_boxes, p.terrain = None, 0, None
             return

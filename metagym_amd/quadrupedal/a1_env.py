@@ -37,10 +37,21 @@ import torch
 from .. import _lib
 from .a1_actuators import A1Actuators, MotorControlMode
 from .a1_wrappers import EtgActionPath, Param_Dict, RewardShaping, SensorStack
-from .terrain import task_terrain
+from .terrain import task_terrain, upstair_terrain
+from ..spaces import Box
 
 
 SENSOR_MODE = {"dis": 1, "motor": 1, "imu": 1, "contact": 1, "footpose": 0, "ETG": 0}      # a1_gym_env.py:13
+TERRAIN_MODES = ("stair-fix", "stair-var", "downstair", "slope", "random", "special", "upstair-random", "downstair-random",   # locomotion_gym_env.py:25-27
+                 "downslope-random", "upslope-random", "balance_beam", "cliff", "hurdle", "cave")
+# tasks whose terrain LocomotionGymEnv builds at its FIRST reset (locomotion_gym_env.py:309-325), after — and therefore over — a
+# `hardset` terrain asked for in that same call
+_FIRST_RESET_TASKS = ("stairslope", "stairstair", "slopestair", "slopeslope", "gallop", "cave", "balancebeam", "highstair")
+# LaikagoPoseOffsetGenerator's action space per `action_space` mode (simple_openloop.py:124-135)
+_ACTION_BOXES = {0: ([0.2, 0.7, 0.7] * 4, [-0.2, -0.7, -0.7] * 4),
+                 1: ([0.1, 0.5, 0.4] * 4, [-0.1, -0.3, -0.6] * 4),
+                 2: ([0.1, 0.5, 0.4, 0.1, 0.5, 0.4] + [0.1] * 6, [-0.1, -0.3, -0.6, -0.1, -0.3, -0.6] + [-0.1] * 6),
+                 3: ([0.1, 0.7, 0.7, 0.1, 0.7, 0.7] + [0.1] * 6, [-0.1, -0.7, -0.7, -0.1, -0.7, -0.7] + [-0.1] * 6)}
 
 
 class A1GymEnv(object):
@@ -49,7 +60,25 @@ class A1GymEnv(object):
                  filter_=0, control_latency=0.002, motor_kp=None, motor_kd=None, env_info=None,
                  motor_control_mode=MotorControlMode.POSITION, sensor_mode=SENSOR_MODE, auto_reset=False, urdf=None,
                  urdf_options=None, vel_mode="max", random_param=None, dynamic_param=None, random_dynamic=False, seed=0,
-                 force_source=None):
+                 force_source=None, action_limit=(0.75, 0.75, 0.75), render=False, on_rack=False, gait=0, step_y=0.05,
+                 terrain_slots=1, terrain_max_boxes=96, x_noise_source=None, **kwargs):
+        # ---- the rest of the reference's constructor signature (a1_gym_env.py:19-40; `gym.make('quadrupedal-v0')` registers
+        #      action_limit / render / on_rack / random_dynamic / ETG / ETG_T / ETG_H / ETG_path / task / dynamic_param,
+        #      quadrupedal/__init__.py:9-20) ---------------------------------------------------------------------------------
+        #   action_limit  accepted; it has NO effect in the reference either: env_builder.py:113 hands the trajectory generator a
+        #                 literal 0.75 ("#origin action_limit=action_limit") and LaikagoPoseOffsetGenerator derives its action space
+        #                 from `action_space` alone (simple_openloop.py:124-135)
+        #   step_y        accepted; no effect in the reference: ETG_model stores it in self.base_foot for task "balance"
+        #                 (ETG_model.py:90-94) but act_clip reads the module-level `base_foot` (:122)
+        #   render, on_rack, gait   viewers, the rack constraint and GaitGeneratorWrapperEnv are not built: refused by name
+        #   **kwargs      swallowed like the reference's own **kwargs (kept in `ignored_kwargs`)
+        if render:
+            raise NotImplementedError("render=True: rendering is out of scope for the batched engine (SURVEY.md §2)")
+        if on_rack:
+            raise _lib.MetaGymHipError("on_rack=True (the robot hung from a fixed constraint, minitaur.py:411-413) is not built")
+        if gait != 0:
+            raise _lib.MetaGymHipError("gait=%r: GaitGeneratorWrapperEnv (env_builder.py:92-94) is not built; gait=0 is the reference's default" % (gait,))
+        self.action_limit, self.step_y, self.ignored_kwargs = tuple(action_limit), float(step_y), dict(kwargs)
         # ---- dynamics handed in explicitly (`dynamic_param`, locomotion_gym_env.py:349-380) ---------------------------------
         dyn = dict(dynamic_param or {})
         for key in dyn:
@@ -91,7 +120,22 @@ class A1GymEnv(object):
         self.add_height, task_env_info, self.terrain_boxes = task_terrain(task)
         self.env_info = task_env_info if env_info is None else env_info
         self.default_pose = [0.0, 0.0, 0.28 + self.add_height]                      # locomotion_gym_env.py:337
-        if hasattr(physics, "set_terrain"):
+        # Terrains: one course for the whole batch (terrain_slots = 1, what the reference's single env has), or a TABLE of
+        # `terrain_slots` courses with a course index per robot, so that reset(mask=, hardset=True, ...) can give part of the
+        # batch a new course the way the reference's reset(hardset=True, ...) gives its one robot a new one per episode
+        self.terrain_slots, self._terrain_max_boxes = int(terrain_slots), int(terrain_max_boxes)
+        self._first_reset = True
+        if self.terrain_slots > 1:
+            if not hasattr(physics, "set_terrain_table"):
+                raise _lib.MetaGymHipError("terrain_slots > 1 needs physics.set_terrain_table / write_course / terrain_id (A1Physics has them)")
+            physics.set_terrain_table(self.terrain_slots, self._terrain_max_boxes)
+            physics.write_course(0, self.terrain_boxes)
+            self.terrain_id = physics.terrain_id                                    # int32 [N], shared with the engine and the reward
+            self._add_height_t = torch.zeros(self.terrain_slots, dtype=torch.float64, device=self.device)
+            self._add_height_t[0] = float(self.add_height)
+            self._courses = {0: (self.add_height, self.env_info)}
+            physics.set_reset_pose(self.default_pose)
+        elif hasattr(physics, "set_terrain"):
             physics.set_terrain(self.terrain_boxes, self.default_pose)
         if ETG and ETG_w is None and len(ETG_path) > 1 and os.path.exists(ETG_path):   # MonitorEnv.py:241-244
             saved = np.load(ETG_path)
@@ -105,6 +149,23 @@ class A1GymEnv(object):
         self.sensors = SensorStack(num_envs, device, normal=normal)
         self.shaping = RewardShaping(num_envs, device, param=reward_param, reward_p=reward_p, vel_d=vel_d, env_info=self.env_info,
                                      vel_mode=vel_mode)
+        if self.terrain_slots > 1:
+            self._seg_table = torch.zeros(self.terrain_slots, _lib.A1_MAX_SEGMENTS, 5, dtype=torch.float64, device=self.device)
+            self._seg_count = torch.zeros(self.terrain_slots, dtype=torch.int32, device=self.device)
+            rows, cnt = RewardShaping.pack_env_info(self.env_info)
+            self._seg_table[0].copy_(torch.as_tensor(rows))
+            self._seg_count[0] = cnt
+            self.shaping.set_terrain_table(self._seg_table, self._seg_count, self.terrain_id)
+        hi, lo = _ACTION_BOXES[int(action_space)]
+        self.action_space = Box(np.asarray(lo, np.float32), np.asarray(hi, np.float32), dtype=np.float32)   # simple_openloop.py:137
+        # reset(yaw=, x_noise=): start heading and position noise per robot (locomotion_gym_env.py:327-338)
+        self._x_noise = torch.zeros(self.num_envs, dtype=torch.bool, device=self.device)
+        self._x_noise_any = False
+        self._x_gen = torch.Generator(device=self.device)
+        self._x_gen.manual_seed(int(seed) + 0xa11)
+        self._x_noise_source = x_noise_source        # tests: a callable returning the add_x draws ([N] or scalar) instead of the generator
+        self._yaw_init = torch.zeros(self.num_envs, dtype=torch.float64, device=self.device)
+        self._pose_dirty = False
         self._lib = _lib.load()
         self.last_torques = None
         # the physics' one-launch path (fused_step) takes every motor mode and per-robot gains when it is A1Physics; a caller's
@@ -120,9 +181,9 @@ class A1GymEnv(object):
         # ---- RandomWrapper (MonitorEnv.py:521-662): pushes on the base, and what the observation reports about the dynamics ----
         f64 = dict(dtype=torch.float64, device=self.device)
         self._random_force = bool((random_param or {}).get("random_force"))
-        if (random_param or {}).get("random_dynamics"):
-            raise _lib.MetaGymHipError("random_param['random_dynamics'] (MonitorEnv.py:568-575: a control latency redrawn from numpy's "
-                                       "global stream at every reset) is not built; per-robot latencies go in as control_latency=[N] tensors")
+        # random_param["random_dynamics"]: accepted and, exactly like in the reference, without effect — RandomWrapper.random_dynamics
+        # (MonitorEnv.py:547-629) is the only reader of the flag and both of its call sites are commented out (:632, :641)
+        self._random_dynamics_flag = bool((random_param or {}).get("random_dynamics"))
         if self._random_force and not hasattr(physics, "apply_external_force"):
             raise _lib.MetaGymHipError("random_param['random_force'] needs physics.apply_external_force(force[N,3], position[N,3]) "
                                        "(pybullet.applyExternalForce on the base, LINK_FRAME; A1Physics has it)")
@@ -139,6 +200,108 @@ class A1GymEnv(object):
         self._dynamics = None if base_mass is None else torch.stack(                     # info["dynamics"] MonitorEnv.py:632: latency, foot friction, base mass
             [lat, torch.full((self.num_envs,), footfriction, **f64), torch.full((self.num_envs,), float(base_mass), **f64)], dim=1)
         self._configure_observation(dict(sensor_mode), bool(ETG), int(ETG_H), int(normal))
+        self.observation_space = Box(-np.inf * np.ones(self.observation_width, np.float32), np.inf * np.ones(self.observation_width, np.float32),
+                                     dtype=np.float32)
+
+    # ---- reset(**kwargs) of the reference: locomotion_gym_env.py:297-338 (terrain, yaw, x_noise), MonitorEnv.py:250-253 (ETG) ----
+    RESET_KEYS = ("yaw", "x_noise", "ETG_w", "ETG_b", "hardset", "mode", "stepwidth", "slope", "stepheight", "env_vec", "info", "dynamic_param")
+
+    def configure_reset(self, mask=None, terrain_rng=None, **kw):
+        """What the reference's `reset(**kwargs)` changes BEFORE it resets the robot, for the robots in `mask` (device bool [N];
+        None = all) — it takes effect at their next reset, explicit, masked or fused auto-reset:
+
+          hardset=True, mode=, stepwidth=, slope=, stepheight=, env_vec=   a new terrain (locomotion_gym_env.py:297-301): add_height,
+                      env_info and the boxes of terrain.upstair_terrain(...) replace these robots' course. With terrain_slots = 1
+                      only for the whole batch; else the course goes into a free slot of the terrain table. The reference never
+                      removes the previous terrain's bodies from its Bullet world (terrain.py only ever creates), so there old
+                      and new boxes pile up; here the course is REPLACED, which is what add_height / env_info do there too.
+          yaw=        start heading (rad; scalar or [N]); x_noise=  truthy: every reset draws add_x = U(-0.2, 0.1) for the start
+                      position (numpy's global stream in the reference; here a device generator, `x_noise_source` for tests)
+          ETG_w=, ETG_b=   new ETG parameters (MonitorEnv.py:250-253) — one set for the whole batch.
+        `dynamic_param` here (per-reset dynamics, locomotion_gym_env.py:349-352) is refused: pass it to the constructor."""
+        for k in kw:
+            if k not in self.RESET_KEYS:
+                raise TypeError("reset() got an unexpected keyword %r (the reference's: %s)" % (k, ", ".join(self.RESET_KEYS)))
+        if kw.get("dynamic_param"):
+            raise _lib.MetaGymHipError("reset(dynamic_param=...): per-reset dynamics are not built; pass dynamic_param to the constructor")
+        N, d = self.num_envs, self.device
+        m = None if mask is None else torch.as_tensor(mask, device=d).bool()
+        every = torch.ones(N, dtype=torch.bool, device=d) if m is None else m
+        if kw.get("ETG_w") is not None or kw.get("ETG_b") is not None:               # MonitorEnv.py:250-253
+            w = self.path.etg_w() if kw.get("ETG_w") is None else kw["ETG_w"]
+            b = self.path.etg_b() if kw.get("ETG_b") is None else kw["ETG_b"]
+            self.path.set_etg_parameters(w, b)
+        first_task_terrain = self._first_reset and self.task in _FIRST_RESET_TASKS
+        if kw.get("hardset") and "mode" in kw and kw["mode"] in TERRAIN_MODES and not first_task_terrain:
+            args = dict(stepwidth=kw["stepwidth"], slope=kw["slope"], stepheight=kw["stepheight"], mode=kw["mode"], env_vecs=kw["env_vec"])
+            if terrain_rng is not None:
+                args["rng"] = terrain_rng
+            add_height, env_info, boxes = upstair_terrain(**args)
+            self._set_course(m, add_height, env_info, boxes)
+        if "yaw" in kw or "x_noise" in kw or m is None:
+            yaw = torch.as_tensor(kw.get("yaw", 0.0), dtype=torch.float64, device=d).expand(N)
+            if "yaw" in kw or m is None:
+                self._yaw_init.copy_(torch.where(every, yaw, self._yaw_init))
+            if "x_noise" in kw or m is None:
+                self._x_noise.copy_(torch.where(every, torch.full_like(every, bool(kw.get("x_noise", False))), self._x_noise))
+                self._x_noise_any = bool(kw.get("x_noise", False)) or (m is not None and self._x_noise_any)
+        if float(torch.as_tensor(kw.get("yaw", 0.0)).abs().max()) != 0.0 or kw.get("x_noise"):
+            if not hasattr(self.physics, "set_reset_pose"):
+                raise _lib.MetaGymHipError("reset(yaw=, x_noise=) need physics.set_reset_pose(pose, mask, yaw) (A1Physics has it)")
+            self._pose_dirty = True
+
+    def _set_course(self, m, add_height, env_info, boxes):
+        """A new course (add_height, env_info, boxes) for the robots in `m` (None: the whole batch)."""
+        d = self.device
+        if self.terrain_slots <= 1:
+            if m is not None:
+                raise _lib.MetaGymHipError("a new terrain for PART of the batch needs a terrain table: construct the env with terrain_slots > 1")
+            self.add_height, self.env_info, self.terrain_boxes = add_height, env_info, boxes
+            self.default_pose = [0.0, 0.0, 0.28 + add_height]
+            if hasattr(self.physics, "set_terrain"):
+                self.physics.set_terrain(boxes, self.default_pose)
+            rows, cnt = RewardShaping.pack_env_info(env_info)
+            c = self.shaping._cfg
+            c.n_segments = cnt
+            for i in range(cnt):
+                c.seg[i][:] = list(rows[i])
+            return
+        if m is None:
+            slot = 0
+        else:       # a slot no robot outside `m` stands on (one host read: building a terrain is host work anyway)
+            used = set(int(x) for x in torch.unique(self.terrain_id[~m]).tolist())
+            free = [s for s in range(self.terrain_slots) if s not in used]
+            if not free:
+                raise _lib.MetaGymHipError("all %d terrain slots are in use by robots outside the mask: construct with more terrain_slots" % self.terrain_slots)
+            slot = free[0]
+        self.physics.write_course(slot, boxes)
+        rows, cnt = RewardShaping.pack_env_info(env_info)
+        self._seg_table[slot].copy_(torch.as_tensor(rows, dtype=torch.float64, device=d))
+        self._seg_count[slot] = cnt
+        self._add_height_t[slot] = float(add_height)
+        self._courses[slot] = (add_height, env_info)
+        if m is None:
+            self.terrain_id.zero_()
+            self.add_height, self.env_info = add_height, env_info
+        else:
+            self.terrain_id.copy_(torch.where(m, torch.full_like(self.terrain_id, slot), self.terrain_id))
+
+    def _place_for_reset(self, m):
+        """Hand the physics the reset pose of the robots in `m` (None: all): [add_x, 0, 0.28 + add_height of the robot's course] and
+        the start heading (locomotion_gym_env.py:331-338). Only when something differs from the construction-time pose."""
+        if not (self._x_noise_any or self.terrain_slots > 1 or self._pose_dirty) or not hasattr(self.physics, "set_reset_pose"):
+            return
+        self._pose_dirty = True         # (once a pose other than the construction-time one was handed over, keep handing them over)
+        N, d = self.num_envs, self.device
+        x = torch.zeros(N, dtype=torch.float64, device=d)
+        if self._x_noise_any:
+            if self._x_noise_source is not None:
+                draw = torch.as_tensor(self._x_noise_source(), dtype=torch.float64, device=d).expand(N)
+            else:
+                draw = -0.2 + 0.3 * torch.rand(N, generator=self._x_gen, dtype=torch.float64, device=d)     # np.random.uniform(-0.2, 0.1)
+            x = torch.where(self._x_noise, draw, x)
+        z = (0.28 + self._add_height_t[self.terrain_id.long()]) if self.terrain_slots > 1 else torch.full((N,), float(self.default_pose[2]), dtype=torch.float64, device=d)
+        self.physics.set_reset_pose(torch.stack([x, torch.zeros_like(x), z], dim=0), mask=m, yaw=self._yaw_init)
 
     # FootPoseSensor's normalisation constants, robot_sensors.py:601-606
     FOOTPOSE_MEAN = [1.7454079e-01, -1.5465108e-01, -2.0661314e-01, 1.7080666e-01, 1.6490668e-01, -2.0865265e-01,
@@ -336,11 +499,17 @@ class A1GymEnv(object):
         obs = self._select_sensors(obs, info, world)
         return self._wrap_observation(obs, info["pose"], etg_obs, d_yaw, False), info
 
-    def reset(self, d_yaw=None):
-        """A1GymEnv.reset(): robot.Reset and one observation, sensors reset, ETGWrapper.reset, then the hidden zero-action step
-        of RewardShaping.reset (MonitorEnv.py:305-318) whose observation is the one returned. `d_yaw` only reaches
-        ObservationWrapper.reset (the first frame of an RNN history): the hidden step runs without it."""
+    def reset(self, d_yaw=None, **kwargs):
+        """A1GymEnv.reset(**kwargs) for every robot: the reference's keywords (`configure_reset`: hardset / mode / stepwidth / slope /
+        stepheight / env_vec, yaw, x_noise, ETG_w, ETG_b — absent ones mean what they mean there: yaw 0, no x noise, terrain and
+        ETG parameters unchanged), then robot.Reset and one observation, sensors reset, ETGWrapper.reset, then the hidden zero-action
+        step of RewardShaping.reset (MonitorEnv.py:305-318) whose observation is the one returned. `d_yaw` only reaches
+        ObservationWrapper.reset (the first frame of an RNN history): the hidden step runs without it. For part of the batch:
+        `configure_reset(mask, ...)` and `step(action, reset_mask=mask)`."""
         N, d = self.num_envs, self.device
+        self.configure_reset(None, **kwargs)
+        self._first_reset = False
+        self._place_for_reset(None)
         self.robot.Reset()
         self._pending.zero_()
         self._substeps_dev.zero_()
@@ -354,7 +523,9 @@ class A1GymEnv(object):
         self._wrap_observation(obs0, info["pose"], etg_obs0, d_yaw, True)
         obs, _ = self._env_step(torch.zeros(N, 12, dtype=torch.float64, device=d))
         self.shaping.reset(world["base"], info["rot_mat"], info["footposition"])
-        info.update(base=world["base"], real_contact=world["contact"])
+        info.update(base=world["base"], real_contact=world["contact"], yaw_init=self._yaw_init.clone(), env_info=self.env_info)
+        if self.terrain_slots > 1:
+            info["terrain_id"] = self.terrain_id
         return obs, info
 
     def capture_step(self, warmup=2):
@@ -439,6 +610,7 @@ class A1GymEnv(object):
         """The first half of A1GymEnv.reset() for the robots in `m` only (device bool `[N]`), everyone else untouched: robot
         reset and its one observation, sensor reset, ObservationWrapper.reset, ETGWrapper.reset at t = 0. Returns what
         RewardShaping.reset needs once the hidden zero-action step (= the env step this call opens) is done."""
+        self._place_for_reset(m)
         self.robot.Reset(mask=m)
         self._substeps_dev.mul_((~m).to(torch.float64))
         self.robot.ReceiveObservation(*self.physics.reset(m), only_mask=m)
@@ -457,11 +629,14 @@ class A1GymEnv(object):
             self._obs_history[-1] = torch.where(m.reshape(-1, 1), first, self._obs_history[-1])
         return world["base"], info["rot_mat"], info["footposition"]
 
-    def step(self, action, d_yaw=None, reset_mask=None):
-        """A1GymEnv.step for every robot. `reset_mask` (device bool `[N]`; with `auto_reset=True` the robots whose episode
+    def step(self, action, d_yaw=None, reset_mask=None, donef=False, **kwargs):
+        """A1GymEnv.step for every robot. `donef` is accepted like the reference's (MonitorEnv.py:343) and, like there, changes
+        nothing: reward_shaping receives it and never reads it (:367-384). `reset_mask` (device bool `[N]`; with `auto_reset=True` the robots whose episode
         ended at the previous step): these robots run A1GymEnv.reset() INSIDE this step — robot / sensor / ETG reset, then the
         hidden zero-action env step of RewardShaping.reset (MonitorEnv.py:305-318), which is this very step: their action is
         ignored, the observation returned for them is the one reset() returns, reward 0, done False, info["reset"] True."""
+        if kwargs:
+            raise TypeError("step() got unexpected keywords %r (the reference's: d_yaw, donef)" % (sorted(kwargs),))
         m = reset_mask if reset_mask is not None else (self._pending if self.auto_reset else None)
         if m is not None:
             m = torch.as_tensor(m, device=self.device).bool()

@@ -113,7 +113,8 @@ class A1Physics(object):
         # PyBullet's base position is the root link's inertial frame origin (for the A1: a1.py:61 COM_OFFSET)
         frame = getattr(m, "root_inertial_pos", np.zeros(3))
         self._base_offset = torch.as_tensor(np.asarray(frame, np.float64), **f64).reshape(3, 1)
-        self._default_pose = torch.tensor([0.0, 0.0, 0.28], **f64).reshape(3, 1)
+        self._pose = torch.tensor([0.0, 0.0, 0.28], **f64).reshape(3, 1).repeat(1, self.n).contiguous()      # reset pose per robot
+        self._yaw = torch.zeros(self.n, **f64)                                                              # reset heading per robot
         self._ext = torch.zeros(6, self.n, **f64)                # pending push on the base (apply_external_force)
         self.env.set_external_wrench(self._ext)
         if fused:                                  # A1GymEnv takes the one-launch path when the physics offers it
@@ -125,7 +126,28 @@ class A1Physics(object):
         """The task's static boxes (metagym_amd.quadrupedal.terrain — what the reference creates in its Bullet world) go to the
         engine with their own friction; the reset pose is [x, y, 0.28 + add_height] (locomotion_gym_env.py:337)."""
         self.env.set_terrain(boxes)
-        self._default_pose = torch.tensor([float(v) for v in default_pose], dtype=torch.float64, device=self.device).reshape(3, 1)
+        self.set_reset_pose(default_pose)
+
+    def set_terrain_table(self, n_courses, max_boxes):
+        """Per-robot terrains: a table of courses in the engine (mg_walker_params.terrain / terrain_id) — `write_course(i, boxes)`
+        fills one, `terrain_id` (int32 [N] device tensor, shared with the caller) says which course each robot stands on."""
+        self.env.set_terrain_table(n_courses, max_boxes)
+        self.terrain_id = self.env.terrain_id
+
+    def write_course(self, index, boxes):
+        self.env.write_course(index, boxes)
+
+    def set_reset_pose(self, pose, mask=None, yaw=None):
+        """Where Minitaur.Reset places the robot (locomotion_gym_env.py:334-338: default_pose = [add_x, 0, 0.28 + add_height],
+        orientation = a rotation by `yaw` about z, minitaur.py:426): `pose` [3] or [3, N], `yaw` scalar or [N], for the robots
+        in `mask` (None = all). Takes effect at their next reset."""
+        f64 = dict(dtype=torch.float64, device=self.device)
+        p = torch.as_tensor(pose, **f64)
+        p = p.reshape(3, 1).expand(3, self.n) if p.numel() == 3 else p.reshape(3, self.n)
+        m = torch.ones(self.n, dtype=torch.bool, device=self.device) if mask is None else torch.as_tensor(mask, device=self.device).bool()
+        self._pose.copy_(torch.where(m.reshape(1, -1), p, self._pose))
+        if yaw is not None:
+            self._yaw.copy_(torch.where(m, torch.as_tensor(yaw, **f64).expand(self.n), self._yaw))
 
     def apply_external_force(self, force, position):
         """pybullet.applyExternalForce(robot, -1, force, position, LINK_FRAME) for every robot (`[N, 3]` each, base link frame =
@@ -148,10 +170,16 @@ class A1Physics(object):
     def reset(self, mask):
         e = self.env
         e.reset(mask=mask, joint_noise=self._init)                             # joints at (0, 0.9, -1.8) x 4, velocities zero
-        # base: resetBasePositionAndOrientation places the root link's INERTIAL frame at the default pose, identity attitude
+        # base: resetBasePositionAndOrientation places the root link's INERTIAL frame at the robot's reset pose, turned by its
+        # reset heading about z (minitaur.py:426; 0 unless reset(yaw=) said otherwise)
         m = torch.ones(self.n, dtype=torch.bool, device=self.device) if mask is None else torch.as_tensor(mask, device=self.device).bool()
-        target = self._default_pose - self._base_offset                        # the root body origin (R = identity at reset)
-        e.pos.copy_(torch.where(m.reshape(1, -1), target.expand(3, self.n), e.pos))
+        c, s, zero, one = torch.cos(self._yaw), torch.sin(self._yaw), torch.zeros_like(self._yaw), torch.ones_like(self._yaw)
+        R = torch.stack([c, -s, zero, s, c, zero, zero, zero, one], dim=0)     # [9, N] row-major Rz(yaw)
+        off = self._base_offset.reshape(3)
+        target = self._pose - torch.stack([R[0] * off[0] + R[1] * off[1] + R[2] * off[2], R[3] * off[0] + R[4] * off[1] + R[5] * off[2],
+                                           R[6] * off[0] + R[7] * off[1] + R[8] * off[2]], dim=0)      # the root body origin
+        e.pos.copy_(torch.where(m.reshape(1, -1), target, e.pos))
+        e.rot.copy_(torch.where(m.reshape(1, -1), R, e.rot))
         e.bad_contacts.mul_((~m).to(torch.int32))                               # no contact points yet (feet flags: the reset kernel)
         e.foot_force.mul_((~m).to(torch.float64).reshape(1, -1))
         quat, rate = self._base_quat_rate()

@@ -46,12 +46,19 @@ class EtgActionPath(object):
         self.last_ETG_act = torch.zeros(12, self.num_envs, dtype=torch.float64, device=self.device)
 
     def set_etg_parameters(self, w, b):
-        """ETG_w [3, H], ETG_b [3] (MonitorEnv.py:240-245, or reset(ETG_w=, ETG_b=) :250-253)."""
+        """ETG_w [3, H], ETG_b [3] (MonitorEnv.py:240-245, or reset(ETG_w=, ETG_b=) :250-253). They travel by value with every
+        launch: a step captured into a hipGraph keeps the parameters it was captured with."""
         w, b = np.asarray(w, dtype=np.float64), np.asarray(b, dtype=np.float64)
         assert w.shape == (3, self.H) and b.shape == (3,)
         for a in range(3):
             self._cfg.w[a][:self.H] = list(w[a])
         self._cfg.b[:] = list(b)
+
+    def etg_w(self):
+        return np.asarray([[self._cfg.w[a][h] for h in range(self.H)] for a in range(3)])
+
+    def etg_b(self):
+        return np.asarray([self._cfg.b[a] for a in range(3)])
 
     def _launch(self, action, t, command, etg_obs):
         tt = torch.as_tensor(t, dtype=torch.float64, device=self.device)
@@ -110,6 +117,26 @@ class RewardShaping(object):
         s = self._st = _lib.A1RewardState()
         for k, t in self._t.items():
             setattr(s, k, t.data_ptr())
+
+    @staticmethod
+    def pack_env_info(env_info):
+        """info["env_info"] (a list of [x0, x1, env_vec[7]]) as the [MG_A1_MAX_SEGMENTS][5] rows the kernels read + its length."""
+        assert len(env_info) <= _lib.A1_MAX_SEGMENTS, "%d terrain stretches (max %d)" % (len(env_info), _lib.A1_MAX_SEGMENTS)
+        rows = np.zeros((_lib.A1_MAX_SEGMENTS, 5))
+        for i, (x0, x1, vec) in enumerate(env_info):
+            rows[i] = [float(x0), float(x1), float(vec[0]), float(vec[1]), float(vec[4])]
+        return rows, len(env_info)
+
+    def set_terrain_table(self, seg_table, seg_count, terrain_id):
+        """Per-robot env_info (mg_a1_reward_config.seg_table): device tensors f64 [T, MG_A1_MAX_SEGMENTS, 5], i32 [T], i32 [N] —
+        robot e looks its stretches up in course terrain_id[e]. The tensors are read at launch time (A1GymEnv rewrites them in
+        place when a reset builds a new course)."""
+        assert seg_table.dtype == torch.float64 and seg_table.shape[1:] == (_lib.A1_MAX_SEGMENTS, 5) and seg_table.is_contiguous()
+        assert seg_count.dtype == torch.int32 and seg_count.shape == (seg_table.shape[0],)
+        assert terrain_id.dtype == torch.int32 and terrain_id.shape == (self.num_envs,)
+        self._seg_table, self._seg_count, self._terrain_id = seg_table, seg_count, terrain_id
+        c = self._cfg
+        c.seg_table, c.seg_count, c.terrain_id = seg_table.data_ptr(), seg_count.data_ptr(), terrain_id.data_ptr()
 
     def reset(self, base, rot_mat, footposition, mask=None):
         """RewardShaping.reset (:305-318) with the RESET info's base [N,3], rot_mat [N,9], footposition [N,12] (base frame)."""

@@ -43,4 +43,6 @@ register("meta-ant-v0", "metagym_amd.metalocomotion:MetaAntEnv",
 # metagym/quadrupedal/__init__.py:6-21. The robot file is the caller's (`urdf=`: a1/a1.urdf ships with pybullet_data, not with
 # the reference) and runs on this repo's articulated-body engine (metagym_amd.quadrupedal.A1Physics), or hand over a batched
 # simulator of your own (`physics=`).
-register("quadrupedal-v0", "metagym_amd.quadrupedal:A1GymEnv", kwargs={"physics": None, "ETG": 0, "ETG_T": 0.5, "ETG_H": 20, "task": "plane"})
+register("quadrupedal-v0", "metagym_amd.quadrupedal:A1GymEnv",
+         kwargs={"action_limit": (0.75, 0.75, 0.75), "render": False, "on_rack": False, "random_dynamic": False, "ETG": 0, "ETG_T": 0.5,
+                 "ETG_H": 20, "ETG_path": "", "task": "plane", "dynamic_param": {}})

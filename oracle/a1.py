@@ -526,10 +526,24 @@ class A1Env(object):
         ang, vel, tor, rate, energy = self.act.sensors()
         return dict(footposition=foot_positions_in_base_frame(ang[0]), joint_angle=ang[0], drpy=rate[0], energy=energy[0])
 
-    def reset(self, reset_true_obs, reset_world, hidden_true_obs, hidden_world, d_yaw=0):
-        """A1GymEnv.reset(): LocomotionGymEnv.reset (robot.Reset: history cleared, one observation; sensors reset),
-        ETGWrapper.reset, then RewardShaping.reset's hidden zero-action step (MonitorEnv.py:305-318).
+    @staticmethod
+    def reset_pose(add_height, yaw=0.0, add_x=0.0):
+        """What LocomotionGymEnv.reset hands Minitaur.Reset (locomotion_gym_env.py:327-338) and that hands
+        resetBasePositionAndOrientation (minitaur.py:426-429): position [add_x, 0, 0.28 + add_height], quaternion (x, y, z, w) of a
+        rotation by `yaw` about z. `add_x` is the U(-0.2, 0.1) draw of x_noise (numpy's global stream: an input)."""
+        return [0 + add_x, 0, 0.28 + add_height], [0, 0, np.sin(yaw / 2.0), np.cos(yaw / 2.0)]
+
+    def reset(self, reset_true_obs, reset_world, hidden_true_obs, hidden_world, d_yaw=0, ETG_w=None, ETG_b=None, segments=None):
+        """A1GymEnv.reset(**kwargs): LocomotionGymEnv.reset (a `hardset` terrain's env_info arrives as `segments`,
+        locomotion_gym_env.py:297-301; robot.Reset: history cleared, one observation; sensors reset), ETGWrapper.reset (new
+        parameters from ETG_w / ETG_b first, MonitorEnv.py:250-253), then RewardShaping.reset's hidden zero-action step (:305-318).
         Returns (the hidden step's command, torques, the observation reset() returns)."""
+        if segments is not None:
+            self.shaping.segments = [tuple(s) for s in segments]
+        if ETG_w is not None:
+            self.path.w = np.asarray(ETG_w)
+        if ETG_b is not None:
+            self.path.b = np.asarray(ETG_b)
         self.act.reset(); self.substeps = 0
         self.env_steps = 0                                                         # LocomotionGymEnv._env_step_counter :414
         self.total_substeps = getattr(self, "total_substeps", 0)

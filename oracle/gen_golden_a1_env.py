@@ -65,6 +65,7 @@ class ScriptedWorld(ga.ScriptedBullet):
     def resetBasePositionAndOrientation(self, body, pos, orn):
         self.base_pos = list(pos)
         self.base_pos_at_reset = list(pos)
+        self.base_orn_at_reset = list(orn)
     def getMatrixFromQuaternion(self, q):
         x, y, z, w = q
         return (1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y), 2 * (x * y + w * z), 1 - 2 * (x * x + z * z),
@@ -94,36 +95,64 @@ class ScriptedWorld(ga.ScriptedBullet):
         self.contacts = pts
 
 
+CASES = [dict(name="env_etg_traj", seed=1, ETG=1, wscale=0.04, n_steps=25, normal=0),
+         dict(name="env_plain", seed=2, ETG=0, wscale=0.0, n_steps=20, normal=1),
+         dict(name="env_latency", seed=3, ETG=1, wscale=0.05, n_steps=20, normal=0, dynamic_param={"control_latency": 13.7}),
+         dict(name="env_action_filter", seed=4, ETG=1, wscale=0.04, n_steps=20, normal=0, filter_=1),
+         # task terrains: env_info comes from the reference's own terrain builder (its pybullet calls go to a recorder)
+         # and the scripted base runs fast enough to cross flat / up-slope / flat / down-slope stretches
+         dict(name="env_slopeslope", seed=5, ETG=1, wscale=0.04, n_steps=40, normal=0, task="slopeslope", v_base=[2.6, 0.02, 0.0]),
+         dict(name="env_slopestair", seed=6, ETG=0, wscale=0.0, n_steps=40, normal=0, task="slopestair", v_base=[3.4, -0.01, 0.0]),
+         # ObservationWrapper's own entries (MonitorEnv.py:136-221): ETG output (normalised), ETG_obs, yaw target, RNN frames
+         dict(name="env_obs_extras_stack", seed=7, ETG=1, wscale=0.04, n_steps=16, normal=1, d_yaw=0.3,
+              sensor_mode={"ETG": 1, "ETG_obs": 1, "yaw": 1, "RNN": {"time_steps": 2, "time_interval": 3, "mode": "stack"}}),
+         dict(name="env_obs_extras_gru", seed=8, ETG=1, wscale=0.04, n_steps=10, normal=0, d_yaw=-0.2,
+              sensor_mode={"ETG": 1, "yaw": 1, "RNN": {"time_steps": 3, "time_interval": 1, "mode": "GRU"}}),
+         # the other sensors env_builder.py:62-80 can pick: MotorAngleSensor (motor 2), the rate-only IMU (imu 2), SimpleFootForceSensor
+         # (contact 2), FootPoseSensor (normalised), and sensors switched off
+         dict(name="env_sensors_alt", seed=9, ETG=1, wscale=0.04, n_steps=14, normal=1,
+              sensor_mode={"dis": 0, "motor": 2, "imu": 2, "contact": 2, "footpose": 1}),
+         dict(name="env_sensors_min", seed=10, ETG=0, wscale=0.0, n_steps=12, normal=0,
+              sensor_mode={"dis": 1, "motor": 0, "imu": 0, "contact": 0, "footpose": 1, "ETG_obs": 1}),
+         # RandomWrapper's pushes (a new force every 100 env steps, applied for 50) and explicit dynamics (`dynamic_param`:
+         # control latency in ms, foot friction, base-mass ratio), with the observation entries that report them
+         dict(name="env_random_force", seed=11, ETG=1, wscale=0.03, n_steps=108, normal=0, random_param={"random_dynamics": 0, "random_force": 1},
+              dynamic_param={"control_latency": 17.0, "footfriction": 1.7, "basemass": 1.1},
+              sensor_mode={"ETG": 1, "force_vec": 1, "dynamic_vec": 1, "yaw": 1}, d_yaw=0.1)]
+
+# Round 4: the keyword surface of reset() / step() (locomotion_gym_env.py:297-338, MonitorEnv.py:246-260,343) over SEVERAL
+# episodes of one env object, written to a1_env_episodes.npz (a1_env.npz above stays byte-identical):
+_UPSTAIR, _DOWNSLOPE, _PLANE = [0, 0, 1, 0, 0, 0.08, 0.25], [0, 1, 0, 0, 0.34, 0, 0], [0, 0, 0, 0, 0, 0, 0]
+EPISODE_CASES = [
+    # a new terrain per episode: reset(hardset=True, mode=, stepwidth=, slope=, stepheight=, env_vec=) rebuilds add_height / env_info
+    dict(name="env_hardset_terrains", seed=21, ETG=1, wscale=0.04, normal=0, v_base=[2.4, 0.01, 0.0], episodes=[
+        dict(n_steps=28, reset_kw=dict(hardset=True, mode="special", stepwidth=0.3, slope=0.34, stepheight=0.07,
+                                       env_vec=[_UPSTAIR, _DOWNSLOPE, _PLANE] * 3)),
+        dict(n_steps=24, reset_kw=dict(hardset=True, mode="downstair", stepwidth=0.28, slope=0.3, stepheight=0.06, env_vec=[])),
+        dict(n_steps=12, reset_kw=dict(hardset=False, mode="slope", stepwidth=0.3, slope=0.4, stepheight=0.05, env_vec=[])),   # hardset False: the terrain stays
+        dict(n_steps=14, reset_kw=dict(hardset=True, mode="slope", stepwidth=0.3, slope=0.4, stepheight=0.05, env_vec=[]))]),
+    # start heading and position noise: reset(yaw=, x_noise=); new ETG weights for the second episode: reset(ETG_w=, ETG_b=); step(donef=)
+    dict(name="env_yaw_xnoise_etg", seed=22, ETG=1, wscale=0.04, normal=0, d_yaw=0.25, sensor_mode={"yaw": 1}, episodes=[
+        dict(n_steps=14, reset_kw=dict(yaw=0.4, x_noise=True), step_kw=dict(donef=True)),
+        dict(n_steps=14, reset_kw=dict(yaw=-0.7, x_noise=True), new_etg=0.06),
+        dict(n_steps=8, reset_kw=dict(x_noise=False))]),
+    # the reference's own ETG fixture exactly as quadrupedal/test_ETG.py:5 uses it: task="stairstair", ETG=1,
+    # ETG_path="ESStair_origin.npz", zero policy action, 100 steps
+    dict(name="env_etg_fixture", seed=23, ETG=1, etg_file="ESStair_origin.npz", normal=0, task="stairstair", v_base=[0.5, 0.0, 0.0],
+         zero_action=True, episodes=[dict(n_steps=100, reset_kw={})])]
+
+
 def main():
+    record(CASES, OUT)
+    record(EPISODE_CASES, OUT.replace("a1_env.npz", "a1_env_episodes.npz"), episodes=True)
+
+
+def record(cases, out_path, episodes=False):
     a1, robot_config = ga.import_reference()
     import pybullet_utils.bullet_client as bullet_client
     from metagym.quadrupedal.envs.gym_envs import a1_gym_env
     from metagym.quadrupedal.robots import minitaur
     out = {"numpy_version": np.array(np.__version__)}
-    cases = [dict(name="env_etg_traj", seed=1, ETG=1, wscale=0.04, n_steps=25, normal=0),
-             dict(name="env_plain", seed=2, ETG=0, wscale=0.0, n_steps=20, normal=1),
-             dict(name="env_latency", seed=3, ETG=1, wscale=0.05, n_steps=20, normal=0, dynamic_param={"control_latency": 13.7}),
-             dict(name="env_action_filter", seed=4, ETG=1, wscale=0.04, n_steps=20, normal=0, filter_=1),
-             # task terrains: env_info comes from the reference's own terrain builder (its pybullet calls go to a recorder)
-             # and the scripted base runs fast enough to cross flat / up-slope / flat / down-slope stretches
-             dict(name="env_slopeslope", seed=5, ETG=1, wscale=0.04, n_steps=40, normal=0, task="slopeslope", v_base=[2.6, 0.02, 0.0]),
-             dict(name="env_slopestair", seed=6, ETG=0, wscale=0.0, n_steps=40, normal=0, task="slopestair", v_base=[3.4, -0.01, 0.0]),
-             # ObservationWrapper's own entries (MonitorEnv.py:136-221): ETG output (normalised), ETG_obs, yaw target, RNN frames
-             dict(name="env_obs_extras_stack", seed=7, ETG=1, wscale=0.04, n_steps=16, normal=1, d_yaw=0.3,
-                  sensor_mode={"ETG": 1, "ETG_obs": 1, "yaw": 1, "RNN": {"time_steps": 2, "time_interval": 3, "mode": "stack"}}),
-             dict(name="env_obs_extras_gru", seed=8, ETG=1, wscale=0.04, n_steps=10, normal=0, d_yaw=-0.2,
-                  sensor_mode={"ETG": 1, "yaw": 1, "RNN": {"time_steps": 3, "time_interval": 1, "mode": "GRU"}}),
-             # the other sensors env_builder.py:62-80 can pick: MotorAngleSensor (motor 2), the rate-only IMU (imu 2), SimpleFootForceSensor
-             # (contact 2), FootPoseSensor (normalised), and sensors switched off
-             dict(name="env_sensors_alt", seed=9, ETG=1, wscale=0.04, n_steps=14, normal=1,
-                  sensor_mode={"dis": 0, "motor": 2, "imu": 2, "contact": 2, "footpose": 1}),
-             dict(name="env_sensors_min", seed=10, ETG=0, wscale=0.0, n_steps=12, normal=0,
-                  sensor_mode={"dis": 1, "motor": 0, "imu": 0, "contact": 0, "footpose": 1, "ETG_obs": 1}),
-             # RandomWrapper's pushes (a new force every 100 env steps, applied for 50) and explicit dynamics (`dynamic_param`:
-             # control latency in ms, foot friction, base-mass ratio), with the observation entries that report them
-             dict(name="env_random_force", seed=11, ETG=1, wscale=0.03, n_steps=108, normal=0, random_param={"random_dynamics": 0, "random_force": 1},
-                  dynamic_param={"control_latency": 17.0, "footfriction": 1.7, "basemass": 1.1},
-                  sensor_mode={"ETG": 1, "force_vec": 1, "dynamic_vec": 1, "yaw": 1}, d_yaw=0.1)]
     from metagym.quadrupedal.envs.utilities import terrain
     from gen_golden_a1_terrain import Recorder
     for c in cases:
@@ -134,9 +163,14 @@ def main():
         bullet_client.BulletClient = lambda connection_mode=None, w=world: w
         rs = np.random.RandomState(100 + c["seed"])
         H = 20
-        w, b = rs.uniform(-1, 1, (3, H)) * c["wscale"], rs.uniform(-1, 1, 3) * c["wscale"] * 0.2
-        path = "/tmp/_etg_env_%s.npz" % c["name"]
-        np.savez(path, w=w, b=b)
+        if "etg_file" in c:       # a file the reference ships (quadrupedal/ESStair_origin.npz), loaded by ETGWrapper itself
+            path = os.path.join(os.path.dirname(a1_gym_env.__file__), "..", "..", c["etg_file"])
+            saved = np.load(path)
+            w, b = saved["w"], saved["b"]
+        else:
+            w, b = rs.uniform(-1, 1, (3, H)) * c["wscale"], rs.uniform(-1, 1, 3) * c["wscale"] * 0.2
+            path = "/tmp/_etg_env_%s.npz" % c["name"]
+            np.savez(path, w=w, b=b)
         rec = collections.defaultdict(list)
         # record what robot.Step receives and what each sub-step sees / produces, through the robot class's own methods
         orig_step, orig_apply, orig_recv = minitaur.Minitaur.Step, minitaur.Minitaur.ApplyAction, minitaur.Minitaur.ReceiveObservation
@@ -193,31 +227,51 @@ def main():
                                       **({"random_param": c["random_param"]} if "random_param" in c else {}),
                                       sensor_mode=dict({"dis": 1, "motor": 1, "imu": 1, "contact": 1, "footpose": 0, "ETG": 0},
                                                        **c.get("sensor_mode", {})))
-            n_before_reset = len(rec["all_true_obs"])
-            live["on"] = True
             step_kw = {"d_yaw": c["d_yaw"]} if "d_yaw" in c else {}
-            obs, info = env.reset(**step_kw)
-            rec["reset_pose_z"].append(world.base_pos_at_reset[2])
-            rec["reset_force_vec"].append(np.array(info.get("force_vec", np.zeros(6)), dtype=np.float64))
-            rec["reset_dynamics"].append(np.array(info.get("dynamics", np.zeros(3)), dtype=np.float64))
-            rec["n_sim_steps_after_reset"].append(world.n_sim_steps)
-            rec["reset_obs"].append(np.array(obs, dtype=np.float64))
-            rec["n_true_obs_before_reset"].append(n_before_reset)
-            rec["n_true_obs_after_reset"].append(len(rec["all_true_obs"]))
-            rec["n_commands_after_reset"].append(len(rec["command"]))
-            for k in range(c["n_steps"]):
-                action = rs.uniform(-0.3, 0.3, 12)
-                rec["action"].append(action)
-                rec["t"].append(env.get_time_since_reset())
-                obs, reward, done, info = env.step(action, **step_kw)
-                rec["obs"].append(np.array(obs, dtype=np.float64))
-                rec["reward"].append(float(reward))
-                rec["done"].append(bool(done))
-                rec["terms"].append(np.array([info[t] for t in ("torso", "up", "feet", "tau", "badfoot", "footcontact")]))
-                for key in ("base", "pose", "rot_mat", "footposition", "real_contact", "energy", "drpy", "joint_angle"):
-                    rec["info_" + key].append(np.array(info[key], dtype=np.float64))
-                rec["bad"].append(env.robot.GetBadFootContacts())
-                rec["force_vec"].append(np.array(info.get("force_vec", np.zeros(6)), dtype=np.float64))
+            for ep_i, ep in enumerate(c["episodes"] if episodes else [dict(n_steps=c["n_steps"], reset_kw={})]):
+                n_before_reset = len(rec["all_true_obs"])
+                live["on"] = True
+                reset_kw = dict(step_kw, **ep["reset_kw"])
+                if ep.get("new_etg"):                                      # ETGWrapper.reset(ETG_w=, ETG_b=) MonitorEnv.py:250-253
+                    reset_kw["ETG_w"] = rs.uniform(-1, 1, (3, H)) * ep["new_etg"]
+                    reset_kw["ETG_b"] = rs.uniform(-1, 1, 3) * ep["new_etg"] * 0.2
+                    rec["new_etg_w"].append(reset_kw["ETG_w"])
+                    rec["new_etg_b"].append(reset_kw["ETG_b"])
+                obs, info = env.reset(**reset_kw)
+                rec["reset_pose_z"].append(world.base_pos_at_reset[2])
+                if episodes:
+                    rec["reset_pos"].append(np.array(world.base_pos_at_reset, dtype=np.float64))
+                    rec["reset_orn"].append(np.array(world.base_orn_at_reset, dtype=np.float64))
+                    rec["reset_true_obs_all"].append(rec["all_true_obs"][n_before_reset])
+                    rec["episode_first_step"].append(len(rec["obs"]))
+                    ei = info["env_info"]
+                    rec["env_info_len"].append(len(ei))
+                    rows = np.zeros((32, 9))
+                    for i, (x0, x1, vec) in enumerate(ei):
+                        rows[i] = [x0, x1] + [float(v) for v in vec]
+                    rec["env_info"].append(rows)
+                    rec["yaw_init"].append(float(info["yaw_init"]))
+                rec["reset_force_vec"].append(np.array(info.get("force_vec", np.zeros(6)), dtype=np.float64))
+                rec["reset_dynamics"].append(np.array(info.get("dynamics", np.zeros(3)), dtype=np.float64))
+                rec["n_sim_steps_after_reset"].append(world.n_sim_steps)
+                rec["reset_obs"].append(np.array(obs, dtype=np.float64))
+                rec["n_true_obs_before_reset"].append(n_before_reset)
+                rec["n_true_obs_after_reset"].append(len(rec["all_true_obs"]))
+                rec["n_commands_after_reset"].append(len(rec["command"]))
+                ep_step_kw = dict(step_kw, **ep.get("step_kw", {}))
+                for k in range(ep["n_steps"]):
+                    action = np.zeros(12) if c.get("zero_action") else rs.uniform(-0.3, 0.3, 12)
+                    rec["action"].append(action)
+                    rec["t"].append(env.get_time_since_reset())
+                    obs, reward, done, info = env.step(action, **ep_step_kw)
+                    rec["obs"].append(np.array(obs, dtype=np.float64))
+                    rec["reward"].append(float(reward))
+                    rec["done"].append(bool(done))
+                    rec["terms"].append(np.array([info[t] for t in ("torso", "up", "feet", "tau", "badfoot", "footcontact")]))
+                    for key in ("base", "pose", "rot_mat", "footposition", "real_contact", "energy", "drpy", "joint_angle"):
+                        rec["info_" + key].append(np.array(info[key], dtype=np.float64))
+                    rec["bad"].append(env.robot.GetBadFootContacts())
+                    rec["force_vec"].append(np.array(info.get("force_vec", np.zeros(6)), dtype=np.float64))
         finally:
             locomotion_gym_env.LocomotionGymEnv.reset, locomotion_gym_env.LocomotionGymEnv.step = orig_lreset, orig_lstep
             minitaur.Minitaur.Step, minitaur.Minitaur.ApplyAction, minitaur.Minitaur.ReceiveObservation = orig_step, orig_apply, orig_recv
@@ -228,14 +282,15 @@ def main():
         for k2, v in rec.items():
             out[c["name"] + "/" + k2] = np.array(v)
         out[c["name"] + "/w"], out[c["name"] + "/b"] = w, b
-        out[c["name"] + "/spec"] = np.array(json.dumps({k: c[k] for k in ("task", "sensor_mode", "d_yaw", "random_param", "dynamic_param") if k in c}))
+        out[c["name"] + "/spec"] = np.array(json.dumps({k: c[k] for k in ("task", "sensor_mode", "d_yaw", "random_param", "dynamic_param", "episodes",
+                                                                            "zero_action", "etg_file") if k in c}))
         out[c["name"] + "/config"] = np.array([c["ETG"], c["normal"], c.get("dynamic_param", {}).get("control_latency", -1.0),
                                                c.get("filter_", 0)], dtype=np.float64)
         print(c["name"], "steps", len(rec["obs"]), "obs dim", np.array(rec["obs"]).shape, "dones", int(np.sum(rec["done"])),
               "reward range", np.min(rec["reward"]), np.max(rec["reward"]))
     out["cases"] = np.array([c["name"] for c in cases])
-    np.savez_compressed(OUT, **out)
-    print("wrote", OUT, os.path.getsize(OUT), "bytes")
+    np.savez_compressed(out_path, **out)
+    print("wrote", out_path, os.path.getsize(out_path), "bytes")
 
 
 if __name__ == "__main__":

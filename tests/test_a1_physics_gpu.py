@@ -131,6 +131,133 @@ def test_urdf_robot_on_a_terrain_course_matches_the_oracle():
           "contact points" % (worst, feet_seen, bad_seen))
 
 
+def test_two_courses_in_one_batch_match_the_oracle():
+    """Per-robot terrains (mg_walker_params.terrain_id): a terrain TABLE of three courses — the `slopestair` task course, a
+    `special` stair / slope course built with reset(hardset=True)'s arguments, an empty one — and eight robots spread over them.
+    Every sub-step is checked on its own against oracle/abd.py stepping the robot on ITS course (1e-8), with identical toe flags and
+    bad-contact counts; robots 0-3 and 4-7 start at the same x, so the two halves differ only by what they stand on."""
+    from metagym_amd.quadrupedal.terrain import upstair_terrain
+    n = 8
+    phys = A1Physics(n, urdf=a1_like_urdf(), device=DEV, foot_links=A1_LIKE_TOES)
+    m = phys.model
+    h_a, _, boxes_a = task_terrain("slopestair")
+    h_b, _, boxes_b = upstair_terrain(stepwidth=0.3, slope=0.34, stepheight=0.07, mode="special",
+                                      env_vecs=[[0, 0, 1, 0, 0, 0.08, 0.25], [0, 1, 0, 0, 0.34, 0, 0], [0, 0, 0, 0, 0, 0, 0]] * 3)
+    phys.set_terrain_table(3, 96)
+    phys.write_course(0, boxes_a)
+    phys.write_course(1, boxes_b)                       # (course 2 stays empty: the plain ground)
+    tid = np.array([0, 0, 0, 0, 1, 1, 1, 2], np.int32)
+    phys.terrain_id.copy_(torch.as_tensor(tid))
+    heights = np.array([h_a, h_b, 0.0])[tid]
+    phys.set_reset_pose(np.stack([np.zeros(n), np.zeros(n), 0.28 + heights]))
+    phys.reset(None)
+    e = phys.env
+    xs = np.array([0.0, 1.1, 2.2, 3.1, 0.0, 1.1, 2.2, 1.1])
+    pos = e.pos.cpu().numpy()
+    pos[0] += xs
+    pos[2] += 0.3
+    e.pos.copy_(torch.as_tensor(pos))
+    courses = [_oracle_boxes(boxes_a), _oracle_boxes(boxes_b), []]
+    prms = [abd.Params(dt=0.002, substeps=1, iterations=23, erp=0.2, friction=5.0, sphere_friction=m.sph_friction, self_collision=False,
+                       gravity=10.0, terrain=c, max_velocity=100.0) for c in courses]
+    target = np.array([0, 0.9, -1.8] * 4, float)
+    rs = np.random.RandomState(1)
+    keys = ("pos", "rot", "vel", "omega", "q", "qd")
+    log = torch.empty(1, 43, n, dtype=torch.float64, device=DEV)
+    worst, box_contacts = 0.0, np.zeros(3, int)
+    for t in range(120):
+        st = {k: getattr(e, k).cpu().numpy() for k in keys}
+        tau = np.clip(80.0 * (target[:, None] - st["q"]) - 1.5 * st["qd"] + rs.uniform(-2, 2, (12, n)), -33.5, 33.5)
+        e.step_actuated(torch.as_tensor(tau, device=DEV), raw_torque=True, n_substeps=1, log=log)
+        g = {k: getattr(e, k).cpu().numpy() for k in keys}
+        feet, bad = e.feet_contact.cpu().numpy(), e.bad_contacts.cpu().numpy()
+        for k in range(n):
+            s = abd.State(m)
+            s.pos, s.rot, s.v, s.w = st["pos"][:, k].copy(), st["rot"][:, k].reshape(3, 3).copy(), st["vel"][:, k].copy(), st["omega"][:, k].copy()
+            s.q, s.qd = st["q"][:, k].copy(), st["qd"][:, k].copy()
+            out = {}
+            touching = abd.substep(m, s, tau[:, k], prms[tid[k]], out=out)
+            box_contacts[tid[k]] += sum(1 for r in out["rows"] if r[2] == 0 and r[4] >= 0 and (s.pos[2] > 0.4 or r[5][2] != 1.0))
+            d = max(np.abs(g["q"][:, k] - s.q).max(), np.abs(g["qd"][:, k] - s.qd).max(), np.abs(g["pos"][:, k] - s.pos).max(),
+                    np.abs(g["vel"][:, k] - s.v).max(), np.abs(g["omega"][:, k] - s.w).max())
+            worst = max(worst, d)
+            assert d < 2e-8, (t, k, d)
+            assert list(feet[:, k]) == [float(any(m.sph_foot[g_] == f for g_ in touching)) for f in range(4)], (t, k)
+            assert int(bad[k]) == sum(1 for g_ in touching if m.sph_foot[g_] < 0), (t, k)
+    zs = e.pos[2].cpu().numpy()
+    assert abs(zs[1] - zs[5]) > 0.02 or abs(zs[2] - zs[6]) > 0.02      # same x, different course: different height under the feet
+    print("two courses in one batch: max one-sub-step |state diff| GPU vs oracle %.2e; z of robots 1 / 5 (x = 1.1): %.3f / %.3f; "
+          "2 / 6 (x = 2.2): %.3f / %.3f" % (worst, zs[1], zs[5], zs[2], zs[6]))
+
+
+def test_quadrupedal_v0_new_terrain_and_heading_for_part_of_the_batch():
+    """The batched form of the reference's "a new terrain task per episode" (reset(hardset=True, ...), locomotion_gym_env.py:297-301)
+    and reset(yaw=, x_noise=) (:327-338) on the engine: an env with a terrain table; half the robots get a new course, a start
+    heading and position noise through configure_reset(mask, ...) and restart INSIDE the next step (reset_mask); they then stand
+    at their course's height, turned by their heading, spread over the noise range — the others are untouched."""
+    n = 64
+    env = metagym_amd.make("quadrupedal-v0", num_envs=n, urdf=a1_like_urdf(), device=DEV, task="slopestair", terrain_slots=3, seed=5)
+    obs, info = env.reset()
+    a = torch.zeros(n, 12, dtype=torch.float64, device=DEV)
+    for _ in range(6):
+        obs, reward, done, info = env.step(a)
+    z_a = info["base"][:, 2].clone()
+    assert float((z_a - (0.28 + env.add_height)).abs().max()) < 0.06 and int(env.terrain_id.max()) == 0
+    m = torch.arange(n, device=DEV) % 2 == 1
+    env.configure_reset(m, hardset=True, mode="downstair", stepwidth=0.28, slope=0.3, stepheight=0.06, env_vec=[], yaw=0.5, x_noise=True)
+    assert sorted(set(env.terrain_id.cpu().tolist())) == [0, 1]
+    untouched = {k: getattr(env.physics.env, k)[:, ~m].clone() for k in ("q", "qd")}
+    obs, reward, done, info = env.step(a, reset_mask=m)
+    assert bool(info["reset"][m].all()) and not bool(info["reset"][~m].any())
+    for _ in range(6):
+        obs, reward, done, info = env.step(a)
+    add_b = env._courses[1][0]
+    z = info["base"][:, 2]
+    assert add_b > 1.0 and float((z[m] - (0.28 + add_b)).abs().max()) < 0.06          # on top of the down-stair course
+    assert float((z[~m] - z_a[~m]).abs().max()) < 0.02                               # the others still stand where they stood
+    yaw = info["pose"][:, 2]
+    assert float((yaw[m] - 0.5).abs().max()) < 0.05 and float(yaw[~m].abs().max()) < 0.05
+    x = info["base"][:, 0]
+    assert float(x[m].min()) > -0.25 and float(x[m].max()) < 0.15 and float(x[m].std()) > 0.03      # U(-0.2, 0.1)
+    assert not bool(done.any()) and torch.isfinite(obs).all()
+    # a third course for a few of the others; a fourth does not fit three slots while all are in use
+    m2 = torch.arange(n, device=DEV) < 4
+    env.configure_reset(m2 & ~m, hardset=True, mode="slope", stepwidth=0.3, slope=0.3, stepheight=0.05, env_vec=[])
+    assert sorted(set(env.terrain_id.cpu().tolist())) == [0, 1, 2]
+    with pytest.raises(Exception, match="terrain slots"):
+        env.configure_reset(torch.arange(n, device=DEV) == 7, hardset=True, mode="slope", stepwidth=0.3, slope=0.35, stepheight=0.05, env_vec=[])
+
+
+def test_reference_etg_fixture_walks_the_a1_like_robot_on_stairstair():
+    """The only quadrupedal artefact the reference ships, quadrupedal/ESStair_origin.npz (trained ETG weights), run the way
+    quadrupedal/test_ETG.py:5 runs it — task "stairstair", ETG=1, zero policy action, 100 steps — on THIS engine with the repo's
+    A1-shaped demo robot (examples/a1_like/a1_like.urdf; not pybullet_data's a1.urdf, which is absent). The Python side of that
+    run is pinned to the reference in tests/golden/a1_env_episodes.npz (env_etg_fixture); here: behaviour, reported in DESIGN.md
+    §3.7, nothing asserted against PyBullet — the gait moves the robot forward and no episode ends on a bad contact or a fall
+    in the first 40 steps."""
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "a1_env_episodes.npz"))
+    w, b = g["env_etg_fixture/w"], g["env_etg_fixture/b"]
+    n = 256
+    urdf = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples", "a1_like", "a1_like.urdf")
+    env = metagym_amd.make("quadrupedal-v0", num_envs=n, urdf=urdf, device=DEV, task="stairstair", ETG=1, ETG_w=w, ETG_b=b)
+    obs, info = env.reset()
+    x0 = info["base"][:, 0].clone()
+    a = torch.zeros(n, 12, dtype=torch.float64, device=DEV)
+    first_done, bad_total = None, 0
+    for k in range(100):
+        obs, reward, done, info = env.step(a)
+        bad_total += int(info["bad"].sum())
+        if first_done is None and bool(done.any()):
+            first_done = k
+        if k == 39:
+            x40, done40 = info["base"][:, 0].clone(), first_done
+    x100 = info["base"][:, 0]
+    print("ESStair_origin.npz on the a1-like robot, stairstair: forward progress %.3f m after 40 steps, %.3f m after 100; first done at step %s; "
+          "%d bad contact points in 100 steps x %d robots" % (float((x40 - x0).mean()), float((x100 - x0).mean()), first_done, bad_total, n))
+    assert torch.isfinite(obs).all()
+    assert float((x40 - x0).mean()) > 0.0 and done40 is None
+
+
 def test_quadrupedal_v0_runs_closed_loop_from_a_urdf():
     """`make("quadrupedal-v0", num_envs=..., urdf=...)` — no physics object: the robot file on the engine, 13 fused sub-steps
     per launch with the PD model inside. Zero actions hold (0, 0.9, -1.8) x 4: the robot stands on its four toes, nothing

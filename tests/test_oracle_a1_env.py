@@ -18,7 +18,7 @@ def world(g, name, k):
                 contact=g[name + "/loco_real_contact"][k], bad=g[name + "/loco_bad"][k], force=g[name + "/loco_contact_force"][k])
 
 
-def make_env(g, name):
+def make_env(g, name, golden_has_one_reset=True):
     etg, normal, lat_ms, filt = g[name + "/config"]
     flt = None
     if filt:
@@ -30,7 +30,8 @@ def make_env(g, name):
     if "task" in spec:      # the task's terrain stretches (the product's restatement of terrain.py, itself pinned by a1_terrain.npz)
         from metagym_amd.quadrupedal.terrain import task_terrain
         add_height, env_info, _ = task_terrain(spec["task"])
-        assert 0.28 + add_height == g[name + "/reset_pose_z"][0]                 # locomotion_gym_env.py:337
+        if golden_has_one_reset:
+            assert 0.28 + add_height == g[name + "/reset_pose_z"][0]             # locomotion_gym_env.py:337
         segments = [(r[0], r[1], r[2][0], r[2][1], r[2][4]) for r in env_info]
     kw = {}
     if spec.get("random_param", {}).get("random_force"):      # the pushes RandomWrapper drew from numpy's global stream: inputs
@@ -73,3 +74,71 @@ def test_composed_env_matches_reference(idx):
         base = int(push[0, 0])                                    # sub-steps the reference's constructor had already run (500 settle steps)
         for (n_sub, f, p_), row in zip(env.pushes, push):
             assert n_sub + base == int(row[0]) and np.array_equal(f, row[3:6]) and np.array_equal(p_, row[6:9]) and row[1] == -1 and row[2] == 1
+
+
+# ---- several episodes of one env object: the keyword surface of reset() / step() (tests/golden/a1_env_episodes.npz) ----------
+EPISODES = os.path.join(os.path.dirname(__file__), "golden", "a1_env_episodes.npz")
+
+
+def episode_terrain(g, name, spec, ep_i, current):
+    """(add_height, env_info) the reference holds after this episode's reset(**reset_kw): a `hardset` call rebuilds them with
+    terrain.upstair_terrain (locomotion_gym_env.py:297-301) — through the product's restatement of that builder, itself pinned by
+    a1_terrain.npz — except at the FIRST reset of a task that builds its own terrain (:309-325); otherwise they stay."""
+    from metagym_amd.quadrupedal.terrain import upstair_terrain
+    kw = spec["episodes"][ep_i]["reset_kw"]
+    if kw.get("hardset") and not (ep_i == 0 and spec.get("task", "plane") != "plane"):
+        add_height, env_info, _ = upstair_terrain(stepwidth=kw["stepwidth"], slope=kw["slope"], stepheight=kw["stepheight"], mode=kw["mode"],
+                                                  env_vecs=kw["env_vec"])
+        current = (add_height, env_info)
+    rows = g[name + "/env_info"][ep_i][:int(g[name + "/env_info_len"][ep_i])]
+    assert len(current[1]) == len(rows)
+    for (x0, x1, vec), row in zip(current[1], rows):
+        assert np.array_equal(np.asarray([x0, x1] + [float(v) for v in vec]), row)
+    return current
+
+
+@pytest.mark.parametrize("idx", range(3))
+def test_composed_env_matches_reference_over_several_episodes(idx):
+    """reset(hardset=True, mode=..., ...) -> new add_height / env_info per episode; reset(yaw=, x_noise=) -> the pose and heading
+    handed to the simulator; reset(ETG_w=, ETG_b=) -> new ETG parameters; step(donef=) changes nothing; and the reference's own
+    ETG fixture (quadrupedal/ESStair_origin.npz through test_ETG.py's call: task stairstair, zero action, 100 steps)."""
+    from metagym_amd.quadrupedal.terrain import task_terrain
+    g = np.load(EPISODES)
+    name = str(g["cases"][idx])
+    env, d_yaw = make_env(g, name, golden_has_one_reset=False)
+    spec = json.loads(str(g[name + "/spec"]))
+    if "etg_file" in spec:
+        assert spec["etg_file"] == "ESStair_origin.npz" and g[name + "/w"].shape == (3, 20) and spec["zero_action"]
+    ah, ei, _ = task_terrain(spec.get("task", "plane"))
+    current = (ah, ei)
+    first, kinds = list(g[name + "/episode_first_step"]) + [len(g[name + "/action"])], list(g[name + "/loco_kind"])
+    w_i, loco, sub, new_etg = 0, 0, 0, 0
+    for ep_i, ep in enumerate(spec["episodes"]):
+        kw = ep["reset_kw"]
+        current = episode_terrain(g, name, spec, ep_i, current)
+        add_x = g[name + "/reset_pos"][ep_i][0]                                    # the x_noise draw (an input); 0 without x_noise
+        assert (add_x != 0.0) == bool(kw.get("x_noise")) and -0.2 <= add_x <= 0.1
+        pos, orn = oa.A1Env.reset_pose(current[0], kw.get("yaw", 0.0), add_x)
+        assert np.array_equal(pos, g[name + "/reset_pos"][ep_i]) and np.array_equal(orn, g[name + "/reset_orn"][ep_i])
+        assert g[name + "/yaw_init"][ep_i] == kw.get("yaw", 0.0)
+        etg_kw = {}
+        if ep.get("new_etg"):
+            etg_kw = dict(ETG_w=g[name + "/new_etg_w"][new_etg], ETG_b=g[name + "/new_etg_b"][new_etg])
+            new_etg += 1
+        assert kinds[loco] == 0 and kinds[loco + 1] == 1
+        segments = [(r[0], r[1], r[2][0], r[2][1], r[2][4]) for r in current[1]]
+        cmd, torques, obs = env.reset(g[name + "/reset_true_obs_all"][ep_i], world(g, name, loco), g[name + "/true_obs"][sub], world(g, name, loco + 1),
+                                      d_yaw, segments=segments, **etg_kw)
+        assert np.array_equal(cmd, g[name + "/command"][sub]) and np.array_equal(torques, g[name + "/torques"][sub])
+        assert np.array_equal(obs, g[name + "/reset_obs"][ep_i]), "%s reset observation, episode %d" % (name, ep_i)
+        loco, sub = loco + 2, sub + 1
+        for k in range(first[ep_i], first[ep_i + 1]):
+            assert env.time_since_reset() == g[name + "/t"][k]
+            cmd, torques, obs, (shaped, inf) = env.step(g[name + "/action"][k], g[name + "/true_obs"][sub], world(g, name, loco), d_yaw)
+            assert np.array_equal(cmd, g[name + "/command"][sub]) and np.array_equal(torques, g[name + "/torques"][sub]), (name, k)
+            assert np.array_equal(obs, g[name + "/obs"][k]), "%s observation, step %d" % (name, k)
+            terms, reward, done = shaped
+            assert np.allclose(terms, g[name + "/terms"][k], rtol=1e-13, atol=1e-15), "%s reward terms, step %d" % (name, k)
+            assert reward == pytest.approx(g[name + "/reward"][k], rel=1e-13, abs=1e-15) and done == bool(g[name + "/done"][k])
+            loco, sub = loco + 1, sub + 1
+    assert loco == len(kinds) and sub == len(g[name + "/command"])
