@@ -210,11 +210,12 @@ class A1GymEnv(object):
         """What the reference's `reset(**kwargs)` changes BEFORE it resets the robot, for the robots in `mask` (device bool [N];
         None = all) — it takes effect at their next reset, explicit, masked or fused auto-reset:
 
-          hardset=True, mode=, stepwidth=, slope=, stepheight=, env_vec=   a new terrain (locomotion_gym_env.py:297-301): add_height,
-                      env_info and the boxes of terrain.upstair_terrain(...) replace these robots' course. With terrain_slots = 1
-                      only for the whole batch; else the course goes into a free slot of the terrain table. The reference never
-                      removes the previous terrain's bodies from its Bullet world (terrain.py only ever creates), so there old
-                      and new boxes pile up; here the course is REPLACED, which is what add_height / env_info do there too.
+          hardset=True, mode=, stepwidth=, slope=, stepheight=, env_vec=   a new terrain: the reference clears its Bullet world
+                      (resetSimulation(), a new plane and a new robot object, locomotion_gym_env.py:238-276) and, for a `mode` of
+                      its terrain_modes list, builds terrain.upstair_terrain(...) in it (:297-301) — add_height, env_info and the
+                      boxes REPLACE these robots' course. (hardset=True without such a mode leaves the bare plane but keeps the old
+                      add_height / env_info: replicated.) With terrain_slots = 1 only for the whole batch; else the course goes
+                      into a free slot of the terrain table.
           yaw=        start heading (rad; scalar or [N]); x_noise=  truthy: every reset draws add_x = U(-0.2, 0.1) for the start
                       position (numpy's global stream in the reference; here a device generator, `x_noise_source` for tests)
           ETG_w=, ETG_b=   new ETG parameters (MonitorEnv.py:250-253) — one set for the whole batch.
@@ -232,12 +233,18 @@ class A1GymEnv(object):
             b = self.path.etg_b() if kw.get("ETG_b") is None else kw["ETG_b"]
             self.path.set_etg_parameters(w, b)
         first_task_terrain = self._first_reset and self.task in _FIRST_RESET_TASKS
-        if kw.get("hardset") and "mode" in kw and kw["mode"] in TERRAIN_MODES and not first_task_terrain:
-            args = dict(stepwidth=kw["stepwidth"], slope=kw["slope"], stepheight=kw["stepheight"], mode=kw["mode"], env_vecs=kw["env_vec"])
-            if terrain_rng is not None:
-                args["rng"] = terrain_rng
-            add_height, env_info, boxes = upstair_terrain(**args)
-            self._set_course(m, add_height, env_info, boxes)
+        if kw.get("hardset") and not first_task_terrain:
+            if "mode" in kw and kw["mode"] in TERRAIN_MODES:
+                args = dict(stepwidth=kw["stepwidth"], slope=kw["slope"], stepheight=kw["stepheight"], mode=kw["mode"], env_vecs=kw["env_vec"])
+                if terrain_rng is not None:
+                    args["rng"] = terrain_rng
+                add_height, env_info, boxes = upstair_terrain(**args)
+                self._set_course(m, add_height, env_info, boxes)
+            else:       # the world is cleared, nothing is built in it; add_height and env_info are not touched (:297-301)
+                if m is None or self.terrain_slots <= 1:
+                    self._set_course(m, self.add_height, self.env_info, [])
+                else:
+                    raise _lib.MetaGymHipError("reset(hardset=True) without a terrain `mode` for part of the batch: give a mode of %r" % (TERRAIN_MODES,))
         if "yaw" in kw or "x_noise" in kw or m is None:
             yaw = torch.as_tensor(kw.get("yaw", 0.0), dtype=torch.float64, device=d).expand(N)
             if "yaw" in kw or m is None:

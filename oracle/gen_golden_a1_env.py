@@ -242,7 +242,10 @@ def record(cases, out_path, episodes=False):
                 if episodes:
                     rec["reset_pos"].append(np.array(world.base_pos_at_reset, dtype=np.float64))
                     rec["reset_orn"].append(np.array(world.base_orn_at_reset, dtype=np.float64))
-                    rec["reset_true_obs_all"].append(rec["all_true_obs"][n_before_reset])
+                    # robot.Reset's one observation: the one right before the hidden step's 13. (With hardset=True the reference
+                    # first rebuilds its whole world and robot, locomotion_gym_env.py:243-276 — resetSimulation(), a new robot object
+                    # whose constructor settles for 2 s — so 500-odd observations of the discarded settle phase come before it.)
+                    rec["reset_true_obs_all"].append(rec["all_true_obs"][len(rec["all_true_obs"]) - 14])
                     rec["episode_first_step"].append(len(rec["obs"]))
                     ei = info["env_info"]
                     rec["env_info_len"].append(len(ei))

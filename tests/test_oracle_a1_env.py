@@ -126,6 +126,11 @@ def test_composed_env_matches_reference_over_several_episodes(idx):
             etg_kw = dict(ETG_w=g[name + "/new_etg_w"][new_etg], ETG_b=g[name + "/new_etg_b"][new_etg])
             new_etg += 1
         assert kinds[loco] == 0 and kinds[loco + 1] == 1
+        # the recorded reset observation is robot.Reset's (with hardset=True the reference rebuilds world and robot first and 500-odd
+        # observations of the new robot's settle phase precede it): its quaternion is the attitude LocomotionGymEnv.reset reports
+        x, y, z, w = g[name + "/reset_true_obs_all"][ep_i][36:40]
+        rpy = [np.arctan2(2 * (w * x + y * z), 1 - 2 * (x * x + y * y)), np.arcsin(2 * (w * y - z * x)), np.arctan2(2 * (w * z + x * y), 1 - 2 * (y * y + z * z))]
+        assert np.allclose(rpy, g[name + "/loco_pose"][loco], rtol=0, atol=1e-12), (ep_i, rpy, g[name + "/loco_pose"][loco])
         segments = [(r[0], r[1], r[2][0], r[2][1], r[2][4]) for r in current[1]]
         cmd, torques, obs = env.reset(g[name + "/reset_true_obs_all"][ep_i], world(g, name, loco), g[name + "/true_obs"][sub], world(g, name, loco + 1),
                                       d_yaw, segments=segments, **etg_kw)
