@@ -282,6 +282,11 @@ typedef struct mg_maze_view {
                                       larger values, and 2n+1 > 127, are clamped to it */
     int32_t obs_format;            /* 0: int32 [N][res_h][res_v][3], the reference's dtype (values exceed 255);
                                       1: uint8 with saturation at 255 — a non-parity fast path (4x fewer HBM bytes) */
+    double uniform_cell_size;      /* (ABI 5) > 0: the caller vouches that EVERY task of the table has exactly this cell_size (tasks
+                                      of one sampler configuration do). The library then evaluates the renderer's power-of-two
+                                      conditions once, on the host, and runs its specialised kernel when they all hold (cell size,
+                                      texture size and resolution powers of two, int32 frames: the stock set-up) — same frames bit
+                                      for bit. 0: unknown, the general kernel decides per env. A wrong value gives wrong frames. */
 } mg_maze_view;
 
 /* Host helper: the per-column tables of ray_caster_utils.py:82-90 (tan_hp accumulated column by

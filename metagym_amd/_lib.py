@@ -87,7 +87,7 @@ class MazeView(C.Structure):
                 ("col_cos", C.c_void_p), ("col_sin", C.c_void_p), ("ori_sin", C.c_float * 4),
                 ("ori_cos", C.c_float * 4), ("textures", C.c_void_p), ("ceil_texture", C.c_void_p),
                 ("n_textures", C.c_int32), ("tex_size", C.c_int32), ("max_ray_records", C.c_int32),
-                ("obs_format", C.c_int32)]
+                ("obs_format", C.c_int32), ("uniform_cell_size", C.c_double)]
 
 
 WALKER_MAX_BODIES, WALKER_MAX_JOINTS, WALKER_MAX_SPHERES, WALKER_MAX_FEET = 16, 24, 128, 6

@@ -467,7 +467,7 @@ __device__ __forceinline__ ColRec bcast(const ColRec &r, int lane) {
 
 // Pass A, lane = screen column: ray_caster_utils.py:84-90 (direction tables), :11-62 (DDA_2D) and the
 // per-column parts of :155-205.
-template <int REC>
+template <int REC, bool STOCK>
 __device__ ColRec column_pass(const ViewK &vk, const Task &t, const EnvShared &es, const int8_t *walls,
                               const uint8_t *texts, const double *transp, int col, int lane,
                               uint32_t *entries /* [t_max][SLAB] records of REC words */, double cs, double inv_cs,
@@ -555,7 +555,7 @@ __device__ ColRec column_pass(const ViewK &vk, const Task &t, const EnvShared &e
         if (v_s < 0) v_s = 0;
         if (v_e > vk.V) v_e = vk.V;
         span = v_s | (v_e << 12);
-        double d_i = vk.text_size_pow2 ? local_h * vk.inv_text_size : local_h / vk.text_size;   // :184-188
+        double d_i = (STOCK || vk.text_size_pow2) ? local_h * vk.inv_text_size : local_h / vk.text_size;   // :184-188
         d_i -= floor(d_i);
         const int ti = (int)(vk.TS * d_i);
         texoff = (text_id * vk.TS + ti) * vk.TS;
@@ -574,6 +574,9 @@ struct RowK {   // per-lane constants of a screen row (they do not depend on the
     int kind;   // 0 untouched, 1 floor, 2 ceiling
     double distance, light, ys;
 };
+// the same as one 32-byte LDS row (two ds_read_b128 from ONE address; the table is padded to whole 64-row chunks with
+// kind-0 rows, so the pixel loop needs neither a clamp for the ragged last chunk nor a second table for `kind`)
+struct __attribute__((aligned(16))) RowRec { double distance, light, ys; int kind, pad; };
 
 __device__ __forceinline__ RowK row_constants(const ViewK &vk, const Task &t, int d_v) {
     RowK r;
@@ -599,7 +602,13 @@ __device__ __forceinline__ RowK row_constants(const ViewK &vk, const Task &t, in
 // Pass B, lane = screen row d_v, for screen column `col` (slot `k` of the wave's 64): the floor /
 // ceiling cast (:102-126 / :135-153), then the wall column (:181-192), then the translucent
 // overlays in ray order (:194-205), then the life bar (maze_discrete_3d.py:118-126).
-template <int REC>
+// WALL says what the wave already knows about this 64-row chunk and the column's wall span (both wave-uniform):
+//   0  the chunk misses the wall: no wall code at all;   1  it straddles an end of the wall (or the column has overlay
+//   records): per-lane tests;   2  every row of the chunk is wall and the column has no overlay records: wall code only.
+// The floor and the ceiling cast are ONE code path with per-lane selects (texture source, fog factor, translucency threshold,
+// "paint outside the maze"): a chunk that holds ceiling AND floor rows — every chunk of a frame up to 64 rows high — used
+// to run the cast twice, once per kind, each time with half its lanes.
+template <int REC, bool STOCK, int WALL>
 __device__ __forceinline__ void pixel_pass(const ViewK &vk, const Task &t, double pos_x, double pos_y, const RowK &rk,
                                            const uint8_t *texts, const double *transp, const ColRec &wc,
                                            const uint32_t *entries, int k, int d_v, double cs, double inv_cs,
@@ -609,12 +618,13 @@ __device__ __forceinline__ void pixel_pass(const ViewK &vk, const Task &t, doubl
     R = G = B = 0;
     bool tflag = false;
     const int span = wc.w_span;
-    const bool in_wall = d_v >= (span & 0xfff) && d_v < ((span >> 12) & 0xfff);
-    const int n_tr = (int)((unsigned)span >> 24);
+    const bool in_wall = WALL == 0 ? false : (WALL == 2 ? true : (d_v >= (span & 0xfff) && d_v < ((span >> 12) & 0xfff)));
+    const int n_tr = WALL == 2 ? 0 : (int)((unsigned)span >> 24);
     // A wall pixel overwrites whatever the floor / ceiling cast painted; the cast's only surviving
     // side effect is the transparent_array flag, which is read by the overlays alone. So the cast
     // can be skipped for wall pixels of columns without overlay records (bit-identical).
-    if (rk.kind != 0 && !(in_wall && n_tr == 0)) {
+    if (WALL != 2 && rk.kind != 0 && !(WALL == 1 && in_wall && n_tr == 0)) {
+        const bool fl = rk.kind == 1;                                         // floor :95-126, else ceiling :129-153
         const double eff = div_by(rk.distance, (double)wc.cos_hp, wc.rcos_hp);
         // fog a = clamp(2*eff/max_vision - 1, 0, 1): when 2*eff is clearly below max_vision the
         // rounded quotient cannot exceed 1, so a == 0 without performing the division
@@ -633,7 +643,7 @@ __device__ __forceinline__ void pixel_pass(const ViewK &vk, const Task &t, doubl
         // and one multiply + one convert + two integer ops per axis replace the chain of
         // divide / floor / subtract / scale steps (bit-identical; the general chain stays for other sizes).
         int i, j, ti, tj;
-        if (fast_tex && hit_x >= 0.0 && hit_y >= 0.0) {
+        if (__builtin_expect(fast_tex && hit_x >= 0.0 && hit_y >= 0.0, 1)) {
             const int xi = cell_index(hit_x * tex_scale), xj = cell_index(hit_y * tex_scale);
             i = xi >> cell_shift;
             j = xj >> cell_shift;
@@ -645,7 +655,7 @@ __device__ __forceinline__ void pixel_pass(const ViewK &vk, const Task &t, doubl
             i = cell_index(fi);
             j = cell_index(fj);
             double d_i, d_j;
-            if (rk.kind == 1) {                                               // floor :107-116
+            if (fl) {                                                         // floor :107-116
                 d_i = fi - floor(fi);
                 d_j = fj - floor(fj);
                 d_i = ttc_pow2 ? d_i * inv_ttc : d_i / text_to_cell;
@@ -653,8 +663,8 @@ __device__ __forceinline__ void pixel_pass(const ViewK &vk, const Task &t, doubl
                 d_i -= floor(d_i);
                 d_j -= floor(d_j);
             } else {                                                          // ceiling :139-143
-                const double gi = vk.text_size_pow2 ? hit_x * vk.inv_text_size : hit_x / vk.text_size;
-                const double gj = vk.text_size_pow2 ? hit_y * vk.inv_text_size : hit_y / vk.text_size;
+                const double gi = (STOCK || vk.text_size_pow2) ? hit_x * vk.inv_text_size : hit_x / vk.text_size;
+                const double gj = (STOCK || vk.text_size_pow2) ? hit_y * vk.inv_text_size : hit_y / vk.text_size;
                 d_i = gi - floor(gi);
                 d_j = gj - floor(gj);
             }
@@ -662,50 +672,39 @@ __device__ __forceinline__ void pixel_pass(const ViewK &vk, const Task &t, doubl
             tj = cell_index(d_j * TS);
         }
         const bool inside = (unsigned)i < (unsigned)n && (unsigned)j < (unsigned)n;
-        // 24-bit multiplies are full rate (v_mad_u32_u24); cells and texture rows are far below 2^24
-        const uint32_t cell = __umul24(i, n) + j;
-        if (rk.kind == 1) {
-            if (inside) {
-                const double alpha = a * rk.light;
-                const uint32_t tx = vk.tex[__umul24(__umul24((uint32_t)texts[cell], TS) + (uint32_t)ti, TS) + (uint32_t)tj];
-                const double oma = 1.0 - alpha;
-#ifdef MG_MAZE3D_KNOCKOUT_COLOR      /* timing experiment only: no colour arithmetic */
-                R = (int)(tx & 255u) + (int)oma; G = (int)((tx >> 8) & 255u); B = (int)(tx >> 16);
+        // the floor is painted inside the maze only (:117), the ceiling everywhere (:144-146)
+        if (inside || !fl) {
+            // 24-bit multiplies are full rate (v_mad_u32_u24); cells and texture rows are far below 2^24
+            const uint32_t cell = inside ? __umul24(i, n) + j : 0u;
+#ifdef MG_MAZE3D_KNOCKOUT_TEXADDR     /* timing experiment only: every lane fetches from one 256-byte stretch of the texture */
+            const uint32_t row = (uint32_t)tj & 63u;
 #else
-                R = (int)(rk.light * (oma * tex_r(tx)));
-                G = (int)(rk.light * (oma * tex_g(tx)));
-                B = (int)(rk.light * (oma * tex_b(tx)));
+            const uint32_t row = __umul24((uint32_t)ti, TS) + (uint32_t)tj;
 #endif
-                const double tr = transp[cell];
-                if (tr > 0.01) {
-                    const double tf = tr * 0.50 + 0.10, om = 1.0 - tf;
-                    R = (int)(om * (double)R);
-                    G = (int)(om * (double)G + tf * 255.0);
-                    B = (int)(om * (double)B);
-                    tflag = true;
-                }
-            }
-        } else {
-            const uint32_t tx = vk.ceil_tex[__umul24((uint32_t)ti, TS) + (uint32_t)tj];
-            const double oma = 1.0 - a;
+            const uint32_t *texel = fl ? vk.tex + (__umul24(__umul24((uint32_t)texts[cell], TS), TS) + row) : vk.ceil_tex + row;
+            const uint32_t tx = *texel;
+            const double alpha = fl ? a * rk.light : a;                       // :119 / :147
+            const double oma = 1.0 - alpha;
+#ifdef MG_MAZE3D_KNOCKOUT_COLOR      /* timing experiment only: no colour arithmetic */
+            R = (int)(tx & 255u) + (int)oma; G = (int)((tx >> 8) & 255u); B = (int)(tx >> 16);
+#else
             R = (int)(rk.light * (oma * tex_r(tx)));
             G = (int)(rk.light * (oma * tex_g(tx)));
             B = (int)(rk.light * (oma * tex_b(tx)));
-            if (inside) {
-                const double tr = transp[cell];
-                if (tr > 0) {
-                    const double tf = tr * 0.50 + 0.10, om = 1.0 - tf;
-                    R = (int)(om * (double)R);
-                    G = (int)(om * (double)G + tf * 255.0);
-                    B = (int)(om * (double)B);
-                    tflag = true;
-                }
+#endif
+            const double tr = transp[cell];
+            if (__builtin_expect(inside && tr > (fl ? 0.01 : 0.0), 0)) {      // :121-126 (> 0.01) / :148-153 (> 0)
+                const double tf = tr * 0.50 + 0.10, om = 1.0 - tf;
+                R = (int)(om * (double)R);
+                G = (int)(om * (double)G + tf * 255.0);
+                B = (int)(om * (double)B);
+                tflag = true;
             }
         }
     }
-    if (in_wall) {                                                            // :181-192
+    if (WALL != 0 && in_wall) {                                               // :181-192
         const double local_v = rk.ys * wc.w_ratio + t.agent_h;
-        double d_j = vk.text_size_pow2 ? local_v * vk.inv_text_size : local_v / vk.text_size;
+        double d_j = (STOCK || vk.text_size_pow2) ? local_v * vk.inv_text_size : local_v / vk.text_size;
         d_j -= floor(d_j);
         const uint32_t tx = vk.tex[(uint32_t)(wc.w_tex + (int)(TS * d_j))];
         const double oma = wc.w_oma, light = (double)wc.w_light;
@@ -740,7 +739,11 @@ __device__ __forceinline__ void py_slice(long a, long b, long len, int &lo, int 
 
 struct int3s { int x, y, z; };   // 12-byte pixel, stored with one dwordx3
 
-template <int REC>     // words per translucent-cell record: 1 (compact) or 2
+// REC: words per translucent-cell record, 1 (compact) or 2. STOCK: the stock renderer configuration, decided on the host
+// (mg_maze3d_step) — every task's cell size the same power of two, texture size and resolution powers of two, int32 frames: the
+// run-time `is this a power of two` flags of the general kernel become constants, and with them go the correctly-rounded
+// divisions nobody takes, their scalar branches, the byte-output path and a quarter-rate 32-bit multiply in the store address.
+template <int REC, bool STOCK>
 __global__ __launch_bounds__(MZ_BLOCK) void maze3d_step_kernel(mg_maze_tasks T, mg_maze_state st, ViewK vk,
                                                                int task_type, int max_steps, int continuous,
                                                                int pre_moved, int auto_reset, int n_envs,
@@ -765,9 +768,9 @@ __global__ __launch_bounds__(MZ_BLOCK) void maze3d_step_kernel(mg_maze_tasks T, 
     off += (nn + 15) & ~15;
     uint8_t *texts = reinterpret_cast<uint8_t *>(smem + off);
     off += (nn + 15) & ~15;
-    double *row_tab = reinterpret_cast<double *>(smem + off);      // [V][3]: distance, light, ys of a screen row
-    off += sizeof(double) * 3 * vk.V;
-    int8_t *row_kind = reinterpret_cast<int8_t *>(smem + off);     // [V]
+    off = (off + 15) & ~size_t(15);
+    RowRec *row_tab = reinterpret_cast<RowRec *>(smem + off);      // [V rounded up to 64]: distance, light, ys, kind of a screen row
+    const int v_pad = (vk.V + 63) & ~63;
 
     // ---- phase 0: transition + scalar part of evaluation_rule (one thread) ----------------------
     if (tid == 0) {
@@ -816,12 +819,10 @@ __global__ __launch_bounds__(MZ_BLOCK) void maze3d_step_kernel(mg_maze_tasks T, 
         }
     }
     // ---- phase 1: stage the task grids and the per-row constants in LDS ----------------------------
-    for (int r = tid; r < vk.V; r += n_threads) {
-        const RowK rk = row_constants(vk, t, r);
-        row_tab[3 * r] = rk.distance;
-        row_tab[3 * r + 1] = rk.light;
-        row_tab[3 * r + 2] = rk.ys;
-        row_kind[r] = (int8_t)rk.kind;
+    for (int r = tid; r < v_pad; r += n_threads) {
+        RowK rk{0, 0.0, 0.0, 0.0};
+        if (r < vk.V) rk = row_constants(vk, t, r);
+        row_tab[r] = RowRec{rk.distance, rk.light, rk.ys, rk.kind, 0};
     }
     for (int c = tid; c < nn; c += n_threads) {
         walls[c] = t.walls[c];
@@ -834,17 +835,17 @@ __global__ __launch_bounds__(MZ_BLOCK) void maze3d_step_kernel(mg_maze_tasks T, 
     // ---- phase 2: render ---------------------------------------------------------------------------
     const double cs = t.cell_size;
     int ex;
-    const int cs_pow2 = (frexp(cs, &ex) == 0.5);
+    const int cs_pow2 = STOCK ? 1 : (frexp(cs, &ex) == 0.5);
     const double inv_cs = 1.0 / cs;
     const double text_to_cell = vk.text_size / cs;
-    const int ttc_pow2 = (frexp(text_to_cell, &ex) == 0.5);
+    const int ttc_pow2 = STOCK ? 1 : (frexp(text_to_cell, &ex) == 0.5);
     const double inv_ttc = 1.0 / text_to_cell;
     // integer texel / cell addressing (see pixel_pass): all three sizes powers of two, cells at least one
     // texture wide, and every reachable coordinate times TS / text_size far below 2^31
     const double tex_scale = (double)vk.TS * vk.inv_text_size;
     const int ts_pow2 = (vk.TS & (vk.TS - 1)) == 0;
-    const int fast_tex = cs_pow2 && ttc_pow2 && vk.text_size_pow2 && ts_pow2 && inv_ttc >= 1.0 &&
-                         (vk.eff_max + cs * (double)t.n) * tex_scale < 1073741824.0;
+    const int fast_tex = STOCK ? 1 : (cs_pow2 && ttc_pow2 && vk.text_size_pow2 && ts_pow2 && inv_ttc >= 1.0 &&
+                                      (vk.eff_max + cs * (double)t.n) * tex_scale < 1073741824.0);
     const int cell_shift = fast_tex ? ilogb(inv_ttc * (double)vk.TS) : 0;
 
     int lb_x0 = 0, lb_x1 = 0, lb_y0 = 0, lb_y1 = 0;   // life bar rectangle, maze_discrete_3d.py:118-126
@@ -853,6 +854,10 @@ __global__ __launch_bounds__(MZ_BLOCK) void maze3d_step_kernel(mg_maze_tasks T, 
         const double sx = 0.10 * vk.V, sy = 0.10 * vk.V;
         py_slice((long)sx, (long)(sx + lifebar_l), vk.H, lb_x0, lb_x1);
         py_slice((long)sy, (long)(sy + 0.05 * vk.H), vk.V, lb_y0, lb_y1);
+        // the rectangle is the env's, i.e. wave-uniform, but it was computed from an LDS value: say so, and the per-column /
+        // per-chunk "does the bar cross here" tests below become scalar branches instead of five VALU ops on every pixel
+        lb_x0 = __builtin_amdgcn_readfirstlane(lb_x0); lb_x1 = __builtin_amdgcn_readfirstlane(lb_x1);
+        lb_y0 = __builtin_amdgcn_readfirstlane(lb_y0); lb_y1 = __builtin_amdgcn_readfirstlane(lb_y1);
     }
 
     uint32_t *entries = entries_all + (size_t)wave * vk.slab * vk.t_max * REC;
@@ -865,41 +870,58 @@ __global__ __launch_bounds__(MZ_BLOCK) void maze3d_step_kernel(mg_maze_tasks T, 
         const int ncols = min(slab, vk.H - cbase);
         ColRec mine{};
         if (lane < ncols)
-            mine = column_pass<REC>(vk, t, *es, walls, texts, transp, cbase + lane, lane, entries, cs, inv_cs, cs_pow2);
+            mine = column_pass<REC, STOCK>(vk, t, *es, walls, texts, transp, cbase + lane, lane, entries, cs, inv_cs, cs_pow2);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         // column-major walk: column k's record is broadcast ONCE (11 v_readlane + 4 converts) and then
         // reused by all V/64 row chunks; the per-row constants come from the LDS row table
-        const uint32_t px_bytes = vk.obs_u8 ? 3u : 12u;
+        const bool obs_u8 = !STOCK && vk.obs_u8;
+        const uint32_t px_bytes = obs_u8 ? 3u : 12u;
 #ifdef MG_MAZE3D_KNOCKOUT_PIXELS      /* timing experiment only: everything but the pixel loop */
         if (mine.w_span == 0x7fffffff) ((int *)obs)[e] = 1;
         continue;
 #endif
+        const RowRec *row_lane = row_tab + lane;                  // this lane's row of every 64-row chunk: one add per chunk away
         for (int k = 0; k < ncols; ++k) {
             const ColRec wc = bcast(mine, k);
-            const int col = cbase + k;
+            const int col = __builtin_amdgcn_readfirstlane(cbase + k);
             const bool in_lb_x = col >= lb_x0 && col < lb_x1;
-            const uint32_t col_off = (uint32_t)(col * vk.V) * px_bytes;      // frame-relative bytes (< 4 GiB)
-            for (int rbase = 0; rbase < vk.V; rbase += 64) {
+            // frame-relative byte offset of this lane's pixel in chunk 0 of the column (< 4 GiB); a chunk further down is a
+            // scalar away — no per-pixel multiply (a 32-bit one is quarter rate)
+            uint32_t pix_lane = ((uint32_t)(col * vk.V) + (uint32_t)lane) * px_bytes;
+            asm volatile("" : "+v"(pix_lane));      // (keep the product: folded into the chunk offset it is multiplied again per pixel)
+            uint32_t chunk_bytes = 0;                 // rbase * px_bytes, carried as a scalar of its own (an add per chunk)
+            for (int rbase = 0; rbase < vk.V; rbase += 64, chunk_bytes += 64u * px_bytes) {
+                asm volatile("" : "+s"(chunk_bytes));
                 const int d_v = rbase + lane;
                 const bool row_ok = d_v < vk.V;
-                const int d_r = row_ok ? d_v : 0;
+                const RowRec rr = row_lane[rbase];
                 RowK rk;
-                const uint32_t rt = __umul24((uint32_t)d_r, 3u);      // full-rate 24-bit multiply
-                rk.kind = row_kind[d_r];
-                rk.distance = row_tab[rt];
-                rk.light = row_tab[rt + 1];
-                rk.ys = row_tab[rt + 2];
+                rk.kind = rr.kind;
+                rk.distance = rr.distance;
+                rk.light = rr.light;
+                rk.ys = rr.ys;
                 int R, G, B;
-                pixel_pass<REC>(vk, t, pos_x, pos_y, rk, texts, transp, wc, entries, k, d_v, cs, inv_cs, cs_pow2, text_to_cell,
-                           inv_ttc, ttc_pow2, fast_tex, tex_scale, cell_shift, R, G, B);
-                if (in_lb_x) {          // wave-uniform: most columns are outside the life bar, ESCAPE tasks have none
+                // where the chunk lies relative to the column's wall span [v_s, v_e) — scalars, one branch per chunk
+                const int w_s = wc.w_span & 0xfff, w_e = (wc.w_span >> 12) & 0xfff;
+#define MG_PIXEL(WALL_)                                                                                                      \
+    pixel_pass<REC, STOCK, WALL_>(vk, t, pos_x, pos_y, rk, texts, transp, wc, entries, k, d_v, cs, inv_cs, cs_pow2, text_to_cell, \
+                                  inv_ttc, ttc_pow2, fast_tex, tex_scale, cell_shift, R, G, B)
+#ifdef MG_MAZE3D_KNOCKOUT_COMPUTE     /* timing experiment only: the frame stores alone, in the kernel's own pattern */
+                R = d_v + w_s; G = col; B = rr.kind;
+#else
+                if ((unsigned)wc.w_span < 0x1000000u && rbase >= w_s && rbase + 64 <= w_e) MG_PIXEL(2);
+                else if ((unsigned)wc.w_span < 0x1000000u && (rbase + 64 <= w_s || rbase >= w_e)) MG_PIXEL(0);
+                else MG_PIXEL(1);
+#endif
+#undef MG_PIXEL
+                if (in_lb_x && rbase < lb_y1 && rbase + 64 > lb_y0) {          // wave-uniform: the bar crosses this chunk
                     if (d_v >= lb_y0 && d_v < lb_y1) { R = 255; G = 0; B = 0; }
                 }
-                const uint32_t off = col_off + __umul24((uint32_t)d_v, px_bytes);   // (a 32-bit multiply is quarter rate)
+                const uint32_t off = pix_lane + chunk_bytes;
                 if (row_ok) {
-                    if (vk.obs_u8) {      // non-parity fast path: saturate to a byte
+                    if (obs_u8) {      // non-parity fast path: saturate to a byte
                         uint8_t *q = img8 + off;
                         __builtin_nontemporal_store((uint8_t)min(max(R, 0), 255), q);
                         __builtin_nontemporal_store((uint8_t)min(max(G, 0), 255), q + 1);
@@ -1122,7 +1144,7 @@ extern "C" int mg_maze3d_step(const mg_maze_tasks *T, const mg_maze_view *view, 
     const int rec = (vk.V < 4096 && T->n * T->n <= 256) ? 1 : 2;
     const size_t lds = ((sizeof(EnvShared) + 15) & ~size_t(15)) + sizeof(double) * T->n * T->n +
                        sizeof(uint32_t) * rec * vk.slab * vk.t_max * n_waves +
-                       2 * ((size_t)(T->n * T->n + 15) & ~size_t(15)) + (sizeof(double) * 3 + 1) * (size_t)vk.V + 16;
+                       2 * ((size_t)(T->n * T->n + 15) & ~size_t(15)) + sizeof(RowRec) * (size_t)((vk.V + 63) & ~63) + 32;
     if (lds > 160 * 1024) return mg::set_error(MG_ERR_BAD_SIZE, "maze n=%d needs %zu B of LDS (> 160 KiB)", T->n, lds);
     const int device = mg::device_of(obs);
     mg::DeviceGuard guard(device);
@@ -1131,8 +1153,10 @@ extern "C" int mg_maze3d_step(const mg_maze_tasks *T, const mg_maze_view *view, 
         static std::atomic<size_t> granted[MG_MAX_DEVICES];
         const int slot = (device >= 0 && device < MG_MAX_DEVICES) ? device : 0;
         if (device < 0 || device >= MG_MAX_DEVICES || lds > granted[slot].load(std::memory_order_relaxed)) {
-            for (const void *fn : {reinterpret_cast<const void *>(maze3d_step_kernel<1>),
-                                   reinterpret_cast<const void *>(maze3d_step_kernel<2>)}) {
+            for (const void *fn : {reinterpret_cast<const void *>(maze3d_step_kernel<1, false>),
+                                   reinterpret_cast<const void *>(maze3d_step_kernel<2, false>),
+                                   reinterpret_cast<const void *>(maze3d_step_kernel<1, true>),
+                                   reinterpret_cast<const void *>(maze3d_step_kernel<2, true>)}) {
                 hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
                 if (e != hipSuccess) return mg::check_hip(e, "hipFuncSetAttribute(maze3d_step_kernel)");
             }
@@ -1146,11 +1170,21 @@ extern "C" int mg_maze3d_step(const mg_maze_tasks *T, const mg_maze_view *view, 
         if (int rc = mg::check_launch("maze_cont_move_kernel")) return rc;
         pre_moved = 1;
     }
-    if (rec == 1)
-        hipLaunchKernelGGL(maze3d_step_kernel<1>, dim3(n), dim3(n_waves * mg::WAVE), lds, (hipStream_t)stream, *T, *st, vk,
-                           task_type, max_steps, continuous, pre_moved, auto_reset, n, action, obs, reward, reward64, done);
-    else
-        hipLaunchKernelGGL(maze3d_step_kernel<2>, dim3(n), dim3(n_waves * mg::WAVE), lds, (hipStream_t)stream, *T, *st, vk,
-                           task_type, max_steps, continuous, pre_moved, auto_reset, n, action, obs, reward, reward64, done);
+    // The stock configuration (maze3d_step_kernel<., true>): the caller vouches for ONE cell size for the whole task table
+    // (mg_maze_view.uniform_cell_size) and every flag the general kernel would evaluate per env comes out "power of two, integer
+    // texel addressing" — evaluated here exactly as the kernel evaluates them.
+    bool stock = false;
+    if (view->uniform_cell_size > 0.0 && !vk.obs_u8 && getenv("MG_MAZE3D_GENERIC") == nullptr) {
+        const double cs = view->uniform_cell_size, ttc = vk.text_size / cs, inv_ttc = 1.0 / ttc;
+        int e2;
+        stock = frexp(cs, &e2) == 0.5 && frexp(ttc, &e2) == 0.5 && vk.text_size_pow2 && (vk.TS & (vk.TS - 1)) == 0 && inv_ttc >= 1.0 &&
+                (vk.eff_max + cs * (double)T->n) * ((double)vk.TS * vk.inv_text_size) < 1073741824.0;
+    }
+#define MG_MAZE3D_LAUNCH(REC_, STOCK_)                                                                                        \
+    hipLaunchKernelGGL((maze3d_step_kernel<REC_, STOCK_>), dim3(n), dim3(n_waves * mg::WAVE), lds, (hipStream_t)stream, *T, *st, vk, \
+                       task_type, max_steps, continuous, pre_moved, auto_reset, n, action, obs, reward, reward64, done)
+    if (rec == 1) { if (stock) MG_MAZE3D_LAUNCH(1, true); else MG_MAZE3D_LAUNCH(1, false); }
+    else { if (stock) MG_MAZE3D_LAUNCH(2, true); else MG_MAZE3D_LAUNCH(2, false); }
+#undef MG_MAZE3D_LAUNCH
     return mg::check_launch("maze3d_step_kernel");
 }

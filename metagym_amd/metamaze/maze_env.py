@@ -65,6 +65,7 @@ class _MazeBatch(object):
             self._task_t = task_config.tensors
             self.tasks = task_config
             self._min_cell_size = float(task_config.cell_size)
+            self._uniform_cell_size = float(task_config.cell_size)       # one sampler configuration: one cell size
             host = task_config.tensors
         else:
             tasks = [task_config] if isinstance(task_config, tuple) and hasattr(task_config, "cell_walls") else list(task_config)
@@ -88,6 +89,8 @@ class _MazeBatch(object):
             self._task_t = {k: torch.from_numpy(np.ascontiguousarray(v)).to(dev) for k, v in host.items()}
             self.tasks = tasks
             self._min_cell_size = min(float(t.cell_size) for t in tasks)
+            sizes = set(float(t.cell_size) for t in tasks)
+            self._uniform_cell_size = sizes.pop() if len(sizes) == 1 else 0.0   # mg_maze_view.uniform_cell_size: 0 = tasks differ
         nn = n * n
         self.n = n
         c = _lib.MazeTasks()
@@ -308,6 +311,7 @@ class _Maze3D(_MazeBatch):
         # record at most 2*floor(mv/cs) + 4 translucent cells (incl. the start cell) whatever n is
         min_cs = self._min_cell_size
         v.max_ray_records = 2 * int(self.max_vision_range / min_cs) + 5
+        v.uniform_cell_size = self._uniform_cell_size
         self._view_c = v
         self._tex_version = MAZE_TASK_MANAGER.version
 
