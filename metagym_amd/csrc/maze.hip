@@ -744,7 +744,7 @@ struct int3s { int x, y, z; };   // 12-byte pixel, stored with one dwordx3
 // run-time `is this a power of two` flags of the general kernel become constants, and with them go the correctly-rounded
 // divisions nobody takes, their scalar branches, the byte-output path and a quarter-rate 32-bit multiply in the store address.
 template <int REC, bool STOCK>
-__global__ __launch_bounds__(MZ_BLOCK) void maze3d_step_kernel(mg_maze_tasks T, mg_maze_state st, ViewK vk,
+__global__ __launch_bounds__(MZ_BLOCK) __attribute__((amdgpu_waves_per_eu(6))) void maze3d_step_kernel(mg_maze_tasks T, mg_maze_state st, ViewK vk,
                                                                int task_type, int max_steps, int continuous,
                                                                int pre_moved, int auto_reset, int n_envs,
                                                                const void *action,
