@@ -489,6 +489,16 @@ typedef struct mg_walker_params {
      * locomotion_gym_env.py:297-301): a new terrain task per episode. NULL: one course for the whole batch, as before. */
     const int32_t *terrain_id;
     int32_t n_terrain_tables;
+    /* (ABI 5) Per-robot dynamics, what LocomotionGymEnv.reset redraws for its one robot when random_dynamic is set
+     * (quadrupedal/envs/locomotion_gym_env.py:381-413) — shape-generic wave kernels, NULL = the shared values above:
+     *   gravity_env        DEVICE f64 [3][N]: the world's gravity ACCELERATION vector for robot e (pybullet.setGravity(gx, gy, gz)
+     *                      :407; the scalar `gravity` above is (0, 0, -gravity)). The reference draws gz from U(8, 12) — positive,
+     *                      i.e. pointing up — and hands it to setGravity as it is.
+     *   foot_friction_env  DEVICE f64 [N]: the lateral friction of robot e's FOOT proxies (those with sphere_foot >= 0), replacing
+     *                      their sphere_friction entry (Minitaur.SetFootFriction :408); needs sphere_friction.
+     * Per-robot masses and inertias need no field: give every robot its own row of the model table (task_id[e] = e). */
+    const double *gravity_env;
+    const double *foot_friction_env;
 } mg_walker_params;
 
 /* Per-env state, SoA doubles: component c of env e at base[c*N + e]. */

@@ -1004,7 +1004,8 @@ template <int NMAX, bool GENERIC, bool VELF>
 __device__ __forceinline__ void wave_substep(const mg_walker_topology &tp, const ModelW &m, const mg_walker_params &prm,
                                              const WaveLds &L, int lane, int maxr,
                                              unsigned long long (&touch)[2], const ActLane &act, double *log_row, int n_envs,
-                                             double *foot_force, int nf, const double *ext_wrench, const double *terrain) {
+                                             double *foot_force, int nf, const double *ext_wrench, const double *terrain,
+                                             V3 gvec, double foot_mu) {
     const int nb = m.nb, nj = m.nj, ns = m.ns, n = 6 + nj;
     const double dt = prm.time_step;
     // A fresh copy of the lane id per sub-step: the ~140 lane predicates of the unrolled Cholesky / substitution
@@ -1048,7 +1049,7 @@ __device__ __forceinline__ void wave_substep(const mg_walker_topology &tp, const
         auto Ic = [&](V3 x) { return V3{ixx * x.x + ixy * x.y + ixz * x.z, ixy * x.x + iyy * x.y + iyz * x.z,
                                         ixz * x.x + iyz * x.y + izz * x.z}; };
         const double mass = m.body_mass()[b];
-        V3 F = mass * (a_c - v3(0, 0, -prm.gravity));
+        V3 F = mass * (a_c - gvec);              // gvec: the world's gravity acceleration, (0, 0, -gravity) or this robot's own
         V3 N = Ic(al) + cross(w, Ic(w));
         if (VELF && (prm.body_linear_damping != 0.0 || prm.body_angular_damping != 0.0)) {
             // btMultiBody's velocity damping (mg_walker_params.body_*_damping): an external force -m v (k + k |v|) at the
@@ -1260,7 +1261,8 @@ __device__ __forceinline__ void wave_substep(const mg_walker_topology &tp, const
         if (kept) {
             L.cx[6 * slot] = sx; L.cx[6 * slot + 1] = sy; L.cx[6 * slot + 2] = depth;
             L.csphere[2 * slot] = g; L.csphere[2 * slot + 1] = -1;       // ground contact of proxy g
-            const double mu = own_mu ? prm.friction * prm.sphere_friction[g] : prm.friction;   // every friction row carries its mu
+            // (every friction row carries its mu; a foot proxy takes the robot's own coefficient when there is one: foot_mu >= 0)
+            const double mu = own_mu ? prm.friction * ((foot_mu >= 0.0 && L.sfoot[g] >= 0) ? foot_mu : prm.sphere_friction[g]) : prm.friction;
             L.bias[3 * slot] = prm.erp * depth / dt; L.kind[3 * slot] = 0; L.partner[3 * slot] = -1;
             L.bias[3 * slot + 1] = mu; L.kind[3 * slot + 1] = own_mu ? -1 : 1; L.partner[3 * slot + 1] = 3 * slot;
             L.bias[3 * slot + 2] = mu; L.kind[3 * slot + 2] = own_mu ? -1 : 2; L.partner[3 * slot + 2] = 3 * slot;
@@ -1329,7 +1331,7 @@ __device__ __forceinline__ void wave_substep(const mg_walker_topology &tp, const
             const int slot = ncont + __popcll(th_mask & lt_mask);
             const bool kept = th && slot < W_MAXC;
             if (kept) {
-                if (own_mu) bmu *= prm.sphere_friction[g];
+                if (own_mu) bmu *= (foot_mu >= 0.0 && L.sfoot[g] >= 0) ? foot_mu : prm.sphere_friction[g];
                 double *cc = L.cx + 6 * slot;
                 cc[0] = bx.x; cc[1] = bx.y; cc[2] = bx.z; cc[3] = bn.x; cc[4] = bn.y; cc[5] = bn.z;
                 L.csphere[2 * slot] = g; L.csphere[2 * slot + 1] = -2;                // proxy g against the world
@@ -1743,6 +1745,12 @@ __global__ __launch_bounds__(WV) __attribute__((amdgpu_waves_per_eu((NMAX <= 14 
     const double *terrain = prm.terrain;
     if (GENERIC && prm.terrain_id != nullptr)
         terrain += (size_t)__builtin_amdgcn_readfirstlane(prm.terrain_id[e]) * prm.n_terrain_boxes * MG_WALKER_BOX_DOUBLES;
+    // per-robot dynamics (mg_walker_params.gravity_env / foot_friction_env), else the shared values
+    V3 gvec = v3(0, 0, -prm.gravity);
+    double foot_mu = -1.0;
+    if (GENERIC && prm.gravity_env != nullptr)
+        gvec = v3(prm.gravity_env[e], prm.gravity_env[(size_t)n_envs + e], prm.gravity_env[2 * (size_t)n_envs + e]);
+    if (GENERIC && prm.foot_friction_env != nullptr) foot_mu = prm.foot_friction_env[e];
     ActLane act{0.0, 0.0, 0.0, 0.0, 0.0};
     if (prm.actuation != 0 && lane < nj) {
         if (GENERIC && prm.actuation == 3) {          // HYBRID: desired angle, kp, desired rate, kd, additional torque
@@ -1760,7 +1768,7 @@ __global__ __launch_bounds__(WV) __attribute__((amdgpu_waves_per_eu((NMAX <= 14 
         double *log_row = prm.substep_log ? prm.substep_log + ((size_t)it * (3 * nj + 7)) * n_envs + e : nullptr;
         wave_substep<NMAX, GENERIC, VELF>(tp, m, prm, L, lane, maxr, touch, act, log_row, n_envs,
                                     (st.foot_force != nullptr && it == prm.frame_skip - 1) ? st.foot_force + e : nullptr, nf,
-                                    (GENERIC && prm.ext_wrench != nullptr && it == 0) ? prm.ext_wrench + e : nullptr, terrain);
+                                    (GENERIC && prm.ext_wrench != nullptr && it == 0) ? prm.ext_wrench + e : nullptr, terrain, gvec, foot_mu);
     }
     if (st.bad_contacts != nullptr) {       // a1.py:314-323 GetBadFootContacts: contact points on links that are no foot
         int bad = 0;
@@ -1986,8 +1994,9 @@ extern "C" int mg_walker_step(const mg_walker_topology *tp, const mg_walker_mode
     MG_REQUIRE_PTR(done);
     mg::DeviceGuard guard(mg::device_of(st->pos));
     if (prm->mapping == 0) {   // lane-per-env reference mapping (private-memory work set)
-        if (tp->n_spheres > 64 || prm->sphere_friction != nullptr || st->foot_force != nullptr || prm->ext_wrench != nullptr)
-            return mg::set_error(MG_ERR_UNSUPPORTED, "per-proxy friction, foot forces, pushes and > 64 collision proxies need the wave mapping");
+        if (tp->n_spheres > 64 || prm->sphere_friction != nullptr || st->foot_force != nullptr || prm->ext_wrench != nullptr ||
+            prm->gravity_env != nullptr)
+            return mg::set_error(MG_ERR_UNSUPPORTED, "per-proxy friction, foot forces, pushes, per-robot gravity and > 64 collision proxies need the wave mapping");
         hipLaunchKernelGGL(walker_step_kernel, dim3((n + WK_BLOCK - 1) / WK_BLOCK), dim3(WK_BLOCK), 0,
                            (hipStream_t)stream, *tp, *ms, *prm, *st, n, action, obs, reward, rewards5, done);
         return mg::check_launch("walker_step_kernel");
@@ -2002,7 +2011,9 @@ extern "C" int mg_walker_step(const mg_walker_topology *tp, const mg_walker_mode
     // (terrain boxes, per-proxy friction and > 64 proxies are compiled into the shape-generic instantiations only: the
     // tuned kernels keep their registers)
     const bool damped = prm->body_linear_damping != 0.0 || prm->body_angular_damping != 0.0;
-    const bool generic_only = prm->n_terrain_boxes != 0 || prm->sphere_friction != nullptr ||
+    if (prm->foot_friction_env != nullptr && prm->sphere_friction == nullptr)
+        return mg::set_error(MG_ERR_BAD_CONFIG, "walker: foot_friction_env needs sphere_friction (per-proxy friction)");
+    const bool generic_only = prm->n_terrain_boxes != 0 || prm->sphere_friction != nullptr || prm->gravity_env != nullptr ||
                               st->foot_force != nullptr || prm->actuation == 3 ||
                               prm->pd_kp_env != nullptr || prm->pd_kd_env != nullptr || prm->ext_wrench != nullptr;
     auto shape_is = [&](int b, int j, int s, int g) {

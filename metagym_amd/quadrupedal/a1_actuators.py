@@ -246,7 +246,7 @@ class A1Actuators(object):
         configuration, env_builder.py:44-52); any control latency. The log is pushed on the history in one launch
         (mg_a1_receive_log). Returns the applied torques `[action_repeat, num_envs, 12]`."""
         c = self._cfg
-        if c.pd_latency != 0.0 or c.pd_latency_env or c.clip_commands or self._enable_action_interpolation:
+        if not self.can_fuse():
             raise _lib.MetaGymHipError("StepFused needs pd latency 0 and no command clip / interpolation (the motor model is evaluated "
                                        "on the CURRENT joint state inside the physics launch); use Step")
         if self._action_filter is not None:
@@ -265,6 +265,11 @@ class A1Actuators(object):
         self._step_counter += self._action_repeat
         self._last_action = act
         return log[:, 2 * NUM_MOTORS:3 * NUM_MOTORS, :].permute(0, 2, 1)
+
+    def can_fuse(self):
+        """StepFused's preconditions: the motor model runs on the CURRENT joint state inside the physics launch."""
+        c = self._cfg
+        return not (c.pd_latency != 0.0 or c.pd_latency_env or c.clip_commands or self._enable_action_interpolation)
 
     def fused_spec(self):
         """What a physics needs to evaluate this motor model itself (WalkerBatchEnv.step_actuated's keyword arguments)."""

@@ -48,6 +48,7 @@ TERRAIN_MODES = ("stair-fix", "stair-var", "downstair", "slope", "random", "spec
 # `hardset` terrain asked for in that same call
 _FIRST_RESET_TASKS = ("stairslope", "stairstair", "slopestair", "slopeslope", "gallop", "cave", "balancebeam", "highstair")
 # LaikagoPoseOffsetGenerator's action space per `action_space` mode (simple_openloop.py:124-135)
+DYNAMIC_KEYS = ("control_latency", "footfriction", "basemass", "baseinertia", "legmass", "leginertia", "motor_kp", "motor_kd", "gravity")
 _ACTION_BOXES = {0: ([0.2, 0.7, 0.7] * 4, [-0.2, -0.7, -0.7] * 4),
                  1: ([0.1, 0.5, 0.4] * 4, [-0.1, -0.3, -0.6] * 4),
                  2: ([0.1, 0.5, 0.4, 0.1, 0.5, 0.4] + [0.1] * 6, [-0.1, -0.3, -0.6, -0.1, -0.3, -0.6] + [-0.1] * 6),
@@ -61,7 +62,8 @@ class A1GymEnv(object):
                  motor_control_mode=MotorControlMode.POSITION, sensor_mode=SENSOR_MODE, auto_reset=False, urdf=None,
                  urdf_options=None, vel_mode="max", random_param=None, dynamic_param=None, random_dynamic=False, seed=0,
                  force_source=None, action_limit=(0.75, 0.75, 0.75), render=False, on_rack=False, gait=0, step_y=0.05,
-                 terrain_slots=1, terrain_max_boxes=96, x_noise_source=None, **kwargs):
+                 terrain_slots=1, terrain_max_boxes=96, x_noise_source=None, per_robot_dynamics=False, dynamics_source=None,
+                 gravity_sign=1.0, **kwargs):
         # ---- the rest of the reference's constructor signature (a1_gym_env.py:19-40; `gym.make('quadrupedal-v0')` registers
         #      action_limit / render / on_rack / random_dynamic / ETG / ETG_T / ETG_H / ETG_path / task / dynamic_param,
         #      quadrupedal/__init__.py:9-20) ---------------------------------------------------------------------------------
@@ -79,32 +81,36 @@ class A1GymEnv(object):
         if gait != 0:
             raise _lib.MetaGymHipError("gait=%r: GaitGeneratorWrapperEnv (env_builder.py:92-94) is not built; gait=0 is the reference's default" % (gait,))
         self.action_limit, self.step_y, self.ignored_kwargs = tuple(action_limit), float(step_y), dict(kwargs)
-        # ---- dynamics handed in explicitly (`dynamic_param`, locomotion_gym_env.py:349-380) ---------------------------------
+        # ---- dynamics: handed in explicitly (`dynamic_param`, locomotion_gym_env.py:349-380) or redrawn per robot at every reset
+        #      (`random_dynamic`, :381-405; a1_dynamics.py) ---------------------------------------------------------------------
         dyn = dict(dynamic_param or {})
         for key in dyn:
-            if key not in ("control_latency", "footfriction", "basemass", "motor_kp", "motor_kd", "gravity"):
-                raise _lib.MetaGymHipError("dynamic_param[%r]: of locomotion_gym_env.py:354-380's keys control_latency, footfriction, basemass, "
-                                           "motor_kp / motor_kd and gravity are built; per-link inertia / leg-mass ratios are not" % key)
-        if random_dynamic:
-            raise _lib.MetaGymHipError("random_dynamic=True redraws latency, friction, masses, inertias, gains and gravity from numpy's global "
-                                       "stream at every reset (locomotion_gym_env.py:381-405): not built; pass the values as dynamic_param")
-        if "control_latency" in dyn:
+            if key not in DYNAMIC_KEYS:
+                raise _lib.MetaGymHipError("dynamic_param[%r]: the reference reads %s (locomotion_gym_env.py:354-380)" % (key, ", ".join(DYNAMIC_KEYS)))
+        self.random_dynamic = bool(random_dynamic)
+        if "control_latency" in dyn and not self.random_dynamic:
             control_latency = 0.001 * float(dyn["control_latency"])                 # milliseconds (:354-355)
-        if "motor_kp" in dyn and "motor_kd" in dyn:
+        if "motor_kp" in dyn and "motor_kd" in dyn and not self.random_dynamic:
             motor_kp, motor_kd = dyn["motor_kp"], dyn["motor_kd"]
         footfriction, basemass_ratio = float(dyn.get("footfriction", 1.0)), float(dyn.get("basemass", 1.0))      # :338-339,356-359
         gravity = dyn.get("gravity")
-        if gravity is not None and (float(gravity[0]) != 0.0 or float(gravity[1]) != 0.0):
-            raise _lib.MetaGymHipError("dynamic_param['gravity']: only (0, 0, -g) is built")
+        # per-link ratios, a tilted gravity, per-reset dynamic_param and random_dynamic all go through per-robot model rows
+        per_robot = self.random_dynamic or per_robot_dynamics or any(k in dyn for k in ("baseinertia", "legmass", "leginertia")) or \
+            (gravity is not None and (float(gravity[0]) != 0.0 or float(gravity[1]) != 0.0))
+        if per_robot and physics is not None and not hasattr(physics, "enable_per_robot_dynamics"):
+            raise _lib.MetaGymHipError("random_dynamic / per-link dynamic_param change the SIMULATOR's masses, inertias, friction and gravity per "
+                                       "robot: let A1GymEnv build A1Physics from urdf=, or give your physics the hooks of A1Physics "
+                                       "(enable_per_robot_dynamics, write_body_tables, write_gravity, write_foot_friction)")
         if physics is None and urdf is not None:       # the robot file on this repo's own articulated-body engine
             from .a1_physics import A1Physics
             opts = dict(urdf_options or {})
-            opts.setdefault("foot_friction", footfriction)
-            opts.setdefault("base_mass_ratio", basemass_ratio)
-            if gravity is not None:
-                opts.setdefault("gravity", -float(gravity[2]))
+            if not per_robot:
+                opts.setdefault("foot_friction", footfriction)
+                opts.setdefault("base_mass_ratio", basemass_ratio)
+                if gravity is not None:
+                    opts.setdefault("gravity", -float(gravity[2]))
             physics = A1Physics(num_envs, urdf=urdf, device=device, **opts)
-        elif physics is not None and (("footfriction" in dyn) or ("basemass" in dyn) or gravity is not None):
+        elif physics is not None and not per_robot and (("footfriction" in dyn) or ("basemass" in dyn) or gravity is not None):
             if not hasattr(physics, "set_dynamics"):
                 raise _lib.MetaGymHipError("dynamic_param footfriction / basemass / gravity change the SIMULATOR: give your physics a "
                                            "set_dynamics(dict) method, or let A1GymEnv build A1Physics from urdf=")
@@ -199,6 +205,27 @@ class A1GymEnv(object):
         lat = torch.as_tensor(control_latency, **f64).expand(self.num_envs) if not torch.is_tensor(control_latency) else control_latency.to(**f64)
         self._dynamics = None if base_mass is None else torch.stack(                     # info["dynamics"] MonitorEnv.py:632: latency, foot friction, base mass
             [lat, torch.full((self.num_envs,), footfriction, **f64), torch.full((self.num_envs,), float(base_mass), **f64)], dim=1)
+        # per-robot dynamics: every robot's own model row / gravity / foot friction in the engine, own latency and gains in the
+        # actuators. random_dynamic: a fresh set per robot at each of ITS resets; else the constructor's dynamic_param, which a
+        # reset(dynamic_param=) replaces for that one episode (locomotion_gym_env.py:349-352)
+        self.dynamics = None
+        if per_robot:
+            from .a1_dynamics import A1Dynamics
+            self.dynamics = A1Dynamics(physics, seed=seed, source=dynamics_source, gravity_sign=gravity_sign)
+            kp0, kd0, _, _ = self.robot.motor_model_parameters()
+            self._dyn_nominal = dict(control_latency=float(control_latency), motor_kp=np.asarray(kp0, np.float64), motor_kd=np.asarray(kd0, np.float64))
+            self._dyn_default = self._fixed_dynamics(dyn)
+            self._dyn_hold = torch.zeros(self.num_envs, dtype=torch.bool, device=self.device)      # robots carrying a reset(dynamic_param=) set
+            self._dyn_override_seen = False
+            self.dynamics.latency.fill_(float(control_latency))
+            self.dynamics.motor_kp.copy_(torch.as_tensor(np.asarray(kp0, np.float64), **f64).expand(self.num_envs, 12))
+            self.dynamics.motor_kd.copy_(torch.as_tensor(np.asarray(kd0, np.float64), **f64).expand(self.num_envs, 12))
+            self.robot.SetControlLatency(self.dynamics.latency.clone())                              # per-robot tensors from here on
+            self.robot.SetMotorGains(self.dynamics.motor_kp.clone(), self.dynamics.motor_kd.clone())
+            self._fusable = getattr(physics, "fused_modes", None) == "all"             # per-robot gains inside the physics launch
+            if not self.random_dynamic:
+                self.dynamics.apply(self._dyn_default)
+            self._push_dynamics()
         self._configure_observation(dict(sensor_mode), bool(ETG), int(ETG_H), int(normal))
         self.observation_space = Box(-np.inf * np.ones(self.observation_width, np.float32), np.inf * np.ones(self.observation_width, np.float32),
                                      dtype=np.float32)
@@ -219,15 +246,26 @@ class A1GymEnv(object):
           yaw=        start heading (rad; scalar or [N]); x_noise=  truthy: every reset draws add_x = U(-0.2, 0.1) for the start
                       position (numpy's global stream in the reference; here a device generator, `x_noise_source` for tests)
           ETG_w=, ETG_b=   new ETG parameters (MonitorEnv.py:250-253) — one set for the whole batch.
-        `dynamic_param` here (per-reset dynamics, locomotion_gym_env.py:349-352) is refused: pass it to the constructor."""
+          dynamic_param=   (envs with per-robot dynamics) this episode's dynamics for these robots instead of the constructor's
+                      (locomotion_gym_env.py:349-352); installed right away — call it directly before the reset. Never read when
+                      random_dynamic is set, like in the reference."""
         for k in kw:
             if k not in self.RESET_KEYS:
                 raise TypeError("reset() got an unexpected keyword %r (the reference's: %s)" % (k, ", ".join(self.RESET_KEYS)))
-        if kw.get("dynamic_param"):
-            raise _lib.MetaGymHipError("reset(dynamic_param=...): per-reset dynamics are not built; pass dynamic_param to the constructor")
         N, d = self.num_envs, self.device
         m = None if mask is None else torch.as_tensor(mask, device=d).bool()
         every = torch.ones(N, dtype=torch.bool, device=d) if m is None else m
+        if kw.get("dynamic_param") and not self.random_dynamic:      # (`if not self.random:` — with random_dynamic the keyword is never read)
+            if self.dynamics is None:
+                raise _lib.MetaGymHipError("reset(dynamic_param=...) gives single robots their own dynamics: construct the env with "
+                                           "per_robot_dynamics=True (or random_dynamic / per-link dynamic_param, which imply it)")
+            for key in kw["dynamic_param"]:
+                if key not in DYNAMIC_KEYS:
+                    raise _lib.MetaGymHipError("dynamic_param[%r]: the reference reads %s" % (key, ", ".join(DYNAMIC_KEYS)))
+            self.dynamics.apply(self._fixed_dynamics(kw["dynamic_param"]), every)
+            self._dyn_hold.logical_or_(every)
+            self._dyn_override_seen = True
+            self._push_dynamics()
         if kw.get("ETG_w") is not None or kw.get("ETG_b") is not None:               # MonitorEnv.py:250-253
             w = self.path.etg_w() if kw.get("ETG_w") is None else kw["ETG_w"]
             b = self.path.etg_b() if kw.get("ETG_b") is None else kw["ETG_b"]
@@ -292,6 +330,42 @@ class A1GymEnv(object):
             self.add_height, self.env_info = add_height, env_info
         else:
             self.terrain_id.copy_(torch.where(m, torch.full_like(self.terrain_id, slot), self.terrain_id))
+
+    def _fixed_dynamics(self, param):
+        """A `dynamic_param` dict (locomotion_gym_env.py:354-380) as a set for A1Dynamics.apply: absent keys = the nominal robot
+        (:340-346; latency / gains: the constructor's)."""
+        p, nom = dict(param or {}), self._dyn_nominal
+        gains = "motor_kp" in p and "motor_kd" in p                                     # :375-378: only when both are given
+        return self.dynamics.fixed(control_latency=0.001 * float(p["control_latency"]) if "control_latency" in p else nom["control_latency"],
+                                   footfriction=p.get("footfriction", 1.0), basemass=p.get("basemass", 1.0),
+                                   baseinertia=p.get("baseinertia", (1.0, 1.0, 1.0)), legmass=p.get("legmass", (1.0, 1.0, 1.0)),
+                                   leginertia=p.get("leginertia", (1.0,) * 12), motor_kp=p["motor_kp"] if gains else nom["motor_kp"],
+                                   motor_kd=p["motor_kd"] if gains else nom["motor_kd"], gravity=p.get("gravity", (0.0, 0.0, -10.0)))
+
+    def _push_dynamics(self):
+        """A1Dynamics' per-robot latency and gains into the actuators' device arrays, and the [latency, foot friction, base mass]
+        rows the observation / info report (MonitorEnv.py:632, locomotion_gym_env.py:451-453). In place: a captured step reads them."""
+        dy, keep = self.dynamics, self.robot._keep
+        keep["control_latency"].copy_(dy.latency)
+        keep["kp"].copy_(dy.motor_kp.t())
+        keep["kd"].copy_(dy.motor_kd.t())
+        if self._dynamics is not None:
+            self._dynamics.copy_(torch.stack([dy.latency, dy.footfriction, dy.basemass], dim=1))
+
+    def _dynamics_for_reset(self, m):
+        """The dynamics part of LocomotionGymEnv.reset (:340-412) for the robots in `m` (None: all): random_dynamic — a fresh draw
+        each; else back to the constructor's dynamic_param unless configure_reset(dynamic_param=) just gave them this episode's."""
+        if self.dynamics is None:
+            return
+        every = torch.ones(self.num_envs, dtype=torch.bool, device=self.device) if m is None else m
+        if self.random_dynamic:
+            self.dynamics.apply(self.dynamics.draw(), every)
+        elif self._dyn_override_seen:
+            self.dynamics.apply(self._dyn_default, every & ~self._dyn_hold)
+            self._dyn_hold.logical_and_(~every)
+        else:
+            return
+        self._push_dynamics()
 
     def _place_for_reset(self, m):
         """Hand the physics the reset pose of the robots in `m` (None: all): [add_x, 0, 0.28 + add_height of the robot's course] and
@@ -489,7 +563,7 @@ class A1GymEnv(object):
             self.physics.apply_external_force(self._force_vec * on, self._force_pos * on)
         cmd, etg_obs = self.path.step(action, self._substeps_dev * self.robot.time_step)   # == get_time_since_reset()
         self._substeps_dev += 13.0
-        if hasattr(self.physics, "fused_step") and self._fusable:      # 13 sub-steps + PD model inside one physics launch
+        if hasattr(self.physics, "fused_step") and self._fusable and self.robot.can_fuse():      # 13 sub-steps + PD model inside one physics launch
             self.last_torques = self.robot.StepFused(cmd, self.physics.fused_step, filter_init_mask=filter_init_mask)
         else:
             self.last_torques = self.robot.Step(cmd, self.physics.substep, filter_init_mask=filter_init_mask)
@@ -517,6 +591,7 @@ class A1GymEnv(object):
         self.configure_reset(None, **kwargs)
         self._first_reset = False
         self._place_for_reset(None)
+        self._dynamics_for_reset(None)
         self.robot.Reset()
         self._pending.zero_()
         self._substeps_dev.zero_()
@@ -553,6 +628,8 @@ class A1GymEnv(object):
         graph = torch.cuda.CUDAGraph()
         if self._random_force and self._force_source is None:      # the pushes' generator advances inside the captured step
             graph.register_generator_state(self._force_gen)
+        if self.random_dynamic and self.auto_reset and self.dynamics.source is None:      # ... and so does the dynamics' one
+            graph.register_generator_state(self.dynamics.gen)
         robot, repeat = self.robot, 13
         host_mirror = (robot._step_counter, robot._last_action)
         with torch.cuda.graph(graph):
@@ -581,6 +658,11 @@ class A1GymEnv(object):
                   force=dict(pos=self._force_pos.clone(), vec=self._force_vec.clone(), on=self._force_on.clone(),
                              env_steps=self._env_steps.clone(), rng=self._force_gen.get_state()),
                   last_torques=None if self.last_torques is None else self.last_torques.clone())
+        if self.dynamics is not None:
+            dy = self.dynamics
+            sd["dynamics"] = dict(latency=dy.latency.clone(), footfriction=dy.footfriction.clone(), basemass=dy.basemass.clone(),
+                                  motor_kp=dy.motor_kp.clone(), motor_kd=dy.motor_kd.clone(), rng=dy.gen.get_state(), hold=self._dyn_hold.clone(),
+                                  override_seen=self._dyn_override_seen)
         if self.robot._action_filter is not None:
             sd["action_filter"] = dict(xhist=self.robot._action_filter.xhist.clone(), yhist=self.robot._action_filter.yhist.clone())
         if self._rnn is not None:
@@ -612,12 +694,21 @@ class A1GymEnv(object):
             self._obs_history.copy_(sd["obs_history"])
         if "physics" in sd and hasattr(self.physics, "load_state_dict"):
             self.physics.load_state_dict(sd["physics"])
+        if "dynamics" in sd and self.dynamics is not None:
+            dy, f = self.dynamics, sd["dynamics"]
+            for k in ("latency", "footfriction", "basemass", "motor_kp", "motor_kd"):
+                getattr(dy, k).copy_(f[k])
+            dy.gen.set_state(f["rng"])
+            self._dyn_hold.copy_(f["hold"])
+            self._dyn_override_seen = bool(f["override_seen"])
+            self._push_dynamics()
 
     def _begin_partial_reset(self, m):
         """The first half of A1GymEnv.reset() for the robots in `m` only (device bool `[N]`), everyone else untouched: robot
         reset and its one observation, sensor reset, ObservationWrapper.reset, ETGWrapper.reset at t = 0. Returns what
         RewardShaping.reset needs once the hidden zero-action step (= the env step this call opens) is done."""
         self._place_for_reset(m)
+        self._dynamics_for_reset(m)
         self.robot.Reset(mask=m)
         self._substeps_dev.mul_((~m).to(torch.float64))
         self.robot.ReceiveObservation(*self.physics.reset(m), only_mask=m)

@@ -137,6 +137,42 @@ class A1Physics(object):
     def write_course(self, index, boxes):
         self.env.write_course(index, boxes)
 
+    # ---- per-robot dynamics (a1_dynamics.py; locomotion_gym_env.py:381-413) ----------------------------------------------------
+    def enable_per_robot_dynamics(self):
+        """Every robot gets its OWN row of the engine's model table (task_id[e] = e), its own gravity vector and its own foot
+        friction (mg_walker_params.gravity_env / foot_friction_env), all starting at the shared values. Idempotent."""
+        if getattr(self, "per_robot", False):
+            return
+        e, N = self.env, self.n
+        f64 = dict(dtype=torch.float64, device=self.device)
+        assert e._table.shape[0] == 1
+        e._table = e._table.expand(N, -1).contiguous()                         # ~4 KB per A1
+        e._models_c.table, e._models_c.n_tasks = e._table.data_ptr(), N
+        e.task_id.copy_(torch.arange(N, dtype=torch.int32, device=self.device))
+        self.gravity_env = torch.zeros(3, N, **f64)
+        self.gravity_env[2] = -e.gravity
+        self.foot_friction_env = torch.full((N,), float(self.foot_friction if self.foot_friction is not None else 1.0), **f64)
+        e._params_c.gravity_env, e._params_c.foot_friction_env = self.gravity_env.data_ptr(), self.foot_friction_env.data_ptr()
+        nb = len(self.model.body_parent)
+        self._row = dict(mass=slice(12 * nb, 13 * nb), com=slice(13 * nb, 16 * nb), inertia=slice(16 * nb, 25 * nb))   # walker_env.pack_model
+        self.base_mass_env = torch.full((N,), float(self.base_mass), **f64)
+        self.per_robot = True
+
+    def write_body_tables(self, mass, com, inertia, mask):
+        """Body mass [N, nb], centre of mass [N, nb, 3] and inertia about it [N, nb, 3, 3] (body frame) into the model rows of the
+        robots in `mask` (device bool [N]); on the device, in place."""
+        N, t, m = self.n, self.env._table, mask.reshape(-1, 1)
+        for key, v in (("mass", mass), ("com", com), ("inertia", inertia)):
+            s = self._row[key]
+            t[:, s] = torch.where(m, v.reshape(N, -1), t[:, s])
+
+    def write_gravity(self, g, mask):
+        """The world's gravity acceleration [N, 3] (what setGravity takes) for the robots in `mask`."""
+        self.gravity_env.copy_(torch.where(mask.reshape(1, -1), g.t(), self.gravity_env))
+
+    def write_foot_friction(self, mu, mask):
+        self.foot_friction_env.copy_(torch.where(mask, mu, self.foot_friction_env))
+
     def set_reset_pose(self, pose, mask=None, yaw=None):
         """Where Minitaur.Reset places the robot (locomotion_gym_env.py:334-338: default_pose = [add_x, 0, 0.28 + add_height],
         orientation = a rotation by `yaw` about z, minitaur.py:426): `pose` [3] or [3, N], `yaw` scalar or [N], for the robots
@@ -208,10 +244,18 @@ class A1Physics(object):
         return self._log
 
     def state_dict(self):
-        return self.env.state_dict()
+        sd = self.env.state_dict()
+        if getattr(self, "per_robot", False):       # the robots' own bodies and worlds are part of the state
+            sd["per_robot"] = dict(table=self.env._table.clone(), gravity=self.gravity_env.clone(), foot_friction=self.foot_friction_env.clone())
+        return sd
 
     def load_state_dict(self, sd):
-        self.env.load_state_dict(sd)
+        if "per_robot" in sd:
+            self.enable_per_robot_dynamics()
+            self.env._table.copy_(sd["per_robot"]["table"])
+            self.gravity_env.copy_(sd["per_robot"]["gravity"])
+            self.foot_friction_env.copy_(sd["per_robot"]["foot_friction"])
+        self.env.load_state_dict({k: v for k, v in sd.items() if k != "per_robot"})
 
     def world(self):
         """base = GetBasePosition (the root link's inertial frame origin), contact = GetFootContacts (a1.py:299-312: toe links

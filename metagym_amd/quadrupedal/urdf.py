@@ -152,6 +152,21 @@ def _link_inertia(link, mode):
     return Ri @ np.diag(diag) @ Ri.T
 
 
+def _link_principal(link, mode):
+    """(diag[3], Rp): the link's local inertia DIAGONAL — what pybullet.getDynamicsInfo(...)[2] reports and
+    changeDynamics(localInertiaDiagonal=) sets — and the rotation of its axes in the LINK frame, so that the tensor of
+    _link_inertia is Rp diag Rp^T. 'bullet_aabb': the bounding-box diagonal in the inertial frame; 'file': the URDF tensor's
+    principal axes (Bullet diagonalises a full tensor on load)."""
+    Ri = link["Ri"]
+    if mode == "bullet_aabb":
+        T = Ri.T @ _link_inertia(link, mode) @ Ri
+        return np.diag(T).copy(), Ri
+    w, V = np.linalg.eigh(link["tensor"])
+    if np.allclose(link["tensor"], np.diag(np.diag(link["tensor"]))):
+        w, V = np.diag(link["tensor"]).copy(), np.eye(3)
+    return w, Ri @ V
+
+
 def load_urdf(path_or_string, foot_links=(), inertia="bullet_aabb", armature=0.0, joint_order=None, rim_points="auto",
               mesh="error", root_pose=((0.0, 0.0, 0.0), None)):
     """-> `Model` (plus `link_names`, `link_body`, `link_frame`, `sph_link`, `sph_foot`, `sph_friction`, `joint_effort`,
@@ -290,6 +305,25 @@ def load_urdf(path_or_string, foot_links=(), inertia="bullet_aabb", armature=0.0
     m.link_names = list(link_order)
     m.link_body = dict(link_body)
     m.link_frame = dict(link_frame)
+    # every LINK's own inertial record inside the body it was merged into — what per-robot dynamics (a1_dynamics.py: masses and
+    # local inertia diagonals rescaled per link, like changeDynamics does) recompose the bodies from: body index, mass, centre of
+    # mass in the body frame, local inertia diagonal and its axes in the body frame
+    m.link_parts = {}
+    for name in link_order:
+        l, (R, p) = links[name], link_frame[name]
+        diag, Rp = _link_principal(l, inertia)
+        m.link_parts[name] = dict(body=link_body[name], mass=float(l["mass"]), com=p + R @ l["pi"], diag=diag, axes=R @ Rp)
+    # the URDF's joints (name, child link) in the order PyBullet numbers them — joint i carries link i: a pre-order walk of the tree
+    # from the root, a link's child joints in document order (URDF2Bullet's ComputeParentIndices)
+    m.urdf_joints = []
+
+    def number(parent):
+        for j in joints:
+            if j["parent"] == parent:
+                m.urdf_joints.append((j["name"], j["child"]))
+                number(j["child"])
+    number(roots[0])
+    m.root_link = roots[0]
     m.foot_names = list(foot_links)
     for f in foot_links:
         assert f in links, "foot link %r is not in the URDF" % (f,)

@@ -121,7 +121,8 @@ def mass_matrix_and_bias(m, s, kin=None, gravity=None, body_damping=(0.0, 0.0)):
     mass, torque -I w (k + k |w|) (btMultiBody::computeAccelerationsArticulatedBodyAlgorithmMultiDof adds exactly this to
     every link's zero-acceleration force, DAMPING_K1 = DAMPING_K2 = m_linearDamping / m_angularDamping, default 0.04)."""
     kin = kin or kinematics(m, s)
-    grav = GRAVITY if gravity is None else np.array([0.0, 0.0, -float(gravity)])
+    # gravity: None = the module's (0, 0, -9.8); a number g = (0, 0, -g); a 3-vector = the acceleration itself (setGravity(gx, gy, gz))
+    grav = GRAVITY if gravity is None else (np.asarray(gravity, float) if np.ndim(gravity) == 1 else np.array([0.0, 0.0, -float(gravity)]))
     k_lin, k_ang = body_damping
     u_all = s.u()
     nb, nj = len(m.body_parent), len(m.joint_body)
@@ -173,7 +174,7 @@ class Params(object):
         self.max_velocity = float(max_velocity)   # btMultiBody's m_maxCoordinateVelocity (100 in Bullet): clamp of every generalized
         #                                           velocity at the end of a sub-step (mg_walker_params.max_coordinate_velocity); 0 = off
         self.terrain = list(terrain)          # static boxes on top of the ground plane: (position[3], R[3,3] box->world, half_extents[3], mu)
-        self.gravity = None if gravity is None else float(gravity)      # None: the module's GRAVITY (9.8, env_bases.py:48)
+        self.gravity = None if gravity is None else (np.asarray(gravity, float) if np.ndim(gravity) == 1 else float(gravity))   # None: the module's GRAVITY (9.8, env_bases.py:48); a 3-vector: the acceleration itself
         # per-proxy lateral friction (mg_walker_params.sphere_friction): `friction` is then the ground's own coefficient and
         # every terrain box's mu its own; the contact's coefficient is the product with the proxy's link (Bullet multiplies)
         self.sphere_friction = None if sphere_friction is None else np.asarray(sphere_friction, float)

@@ -1,0 +1,163 @@
+"""GPU: quadrupedal-v0's randomised dynamics on the engine — every robot its own row of the model table, its own gravity vector and
+foot friction (mg_walker_params.gravity_env / foot_friction_env, ABI 5), its own latency and gains in the actuators; redrawn at each
+of ITS resets when `random_dynamic` is set (locomotion_gym_env.py:381-413). Pinned: the engine with per-robot dynamics against
+oracle/abd.py run per robot on the very same numbers (injected draws); the env-level bookkeeping. Dynamics parity with PyBullet
+itself stays UNPINNED like everything on A1Physics. The host side is tests/test_a1_dynamics.py."""
+import copy
+
+import numpy as np
+import pytest
+import torch
+
+import metagym_amd
+from metagym_amd.quadrupedal import A1Physics
+from metagym_amd.quadrupedal import a1_dynamics as ad
+from oracle import abd
+from urdf_fixture import A1_LIKE_TOES, a1_like_urdf
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def test_engine_with_per_robot_dynamics_matches_the_oracle_robot_by_robot():
+    """Eight robots, eight drawn sets (masses, inertia diagonals, foot friction, gravity — the reference's ranges, gravity turned
+    downwards so there are contacts; one robot keeps the upward one). Every 2 ms sub-step of every robot is replayed by oracle/abd.py on a
+    Model carrying THAT robot's body table, with its gravity vector and its foot coefficient: state 2e-8 per sub-step, identical toe
+    flags and bad-contact counts."""
+    n = 8
+    phys = A1Physics(n, urdf=a1_like_urdf(), device=DEV, foot_links=A1_LIKE_TOES)
+    m = phys.model
+    dyn = ad.A1Dynamics(phys, seed=5)
+    v = dyn.draw()
+    v["gravity"][:, 2] = -v["gravity"][:, 2]
+    v["gravity"][7, 2] = 9.0                                          # robot 7: the reference's upward gravity as drawn
+    mask = torch.ones(n, dtype=torch.bool, device=DEV)
+    mask[6] = False                                                    # robot 6 keeps the nominal robot and world
+    dyn.apply(v, mask)
+    assert phys.env.task_id.cpu().tolist() == list(range(n))
+    mass, com, inertia = (t.cpu().numpy() for t in dyn.body_tables(v))
+    nb = len(m.body_parent)
+    table = phys.env._table.cpu().numpy()
+    assert np.array_equal(table[3, 12 * nb:13 * nb], mass[3]) and np.array_equal(table[3, 16 * nb:25 * nb], inertia[3].reshape(-1))
+    models, prms = [], []
+    for k in range(n):
+        mk = copy.deepcopy(m)
+        mu = np.array(m.sph_friction, float)
+        g = np.array([0.0, 0.0, -10.0])
+        if k != 6:
+            mk.body_mass, mk.body_com, mk.body_inertia = mass[k].copy(), com[k].copy(), inertia[k].copy()
+            mu = np.where(np.asarray(m.sph_foot) >= 0, float(v["footfriction"][k]), mu)
+            g = v["gravity"][k].cpu().numpy()
+        else:
+            assert np.array_equal(table[6, 12 * nb:13 * nb], m.body_mass) and np.array_equal(table[6, 16 * nb:25 * nb], np.asarray(m.body_inertia).reshape(-1))
+        models.append(mk)
+        prms.append(abd.Params(dt=0.002, substeps=1, iterations=23, erp=0.2, friction=5.0, sphere_friction=mu, self_collision=False,
+                               gravity=g, max_velocity=100.0))
+    phys.reset(None)
+    e = phys.env
+    target = np.array([0, 0.9, -1.8] * 4, float)
+    rs = np.random.RandomState(2)
+    keys = ("pos", "rot", "vel", "omega", "q", "qd")
+    log = torch.empty(1, 43, n, dtype=torch.float64, device=DEV)
+    worst, contacts = 0.0, 0
+    for t in range(150):
+        st = {k: getattr(e, k).cpu().numpy() for k in keys}
+        tau = np.clip(80.0 * (target[:, None] - st["q"]) - 1.5 * st["qd"] + rs.uniform(-3, 3, (12, n)), -33.5, 33.5)
+        e.step_actuated(torch.as_tensor(tau, device=DEV), raw_torque=True, n_substeps=1, log=log)
+        got = {k: getattr(e, k).cpu().numpy() for k in keys}
+        feet, bad = e.feet_contact.cpu().numpy(), e.bad_contacts.cpu().numpy()
+        for k in range(n):
+            s = abd.State(models[k])
+            s.pos, s.rot, s.v, s.w = st["pos"][:, k].copy(), st["rot"][:, k].reshape(3, 3).copy(), st["vel"][:, k].copy(), st["omega"][:, k].copy()
+            s.q, s.qd = st["q"][:, k].copy(), st["qd"][:, k].copy()
+            touching = abd.substep(models[k], s, tau[:, k], prms[k])
+            d = max(np.abs(got["q"][:, k] - s.q).max(), np.abs(got["qd"][:, k] - s.qd).max(), np.abs(got["pos"][:, k] - s.pos).max(),
+                    np.abs(got["vel"][:, k] - s.v).max(), np.abs(got["omega"][:, k] - s.w).max())
+            worst = max(worst, d)
+            assert d < 2e-8, (t, k, d)
+            assert list(feet[:, k]) == [float(any(m.sph_foot[g_] == f for g_ in touching)) for f in range(4)], (t, k)
+            assert int(bad[k]) == sum(1 for g_ in touching if m.sph_foot[g_] < 0), (t, k)
+            contacts += len(touching) if k != 7 else 0
+    z = e.pos[2].cpu().numpy()
+    assert contacts > 100 and z[7] > z[:7].max() + 0.1            # the others stand on their feet; robot 7 falls upwards
+    # different robots really ran different bodies: the same torques, different joint angles
+    q = e.q.cpu().numpy()
+    assert np.abs(q[:, 0] - q[:, 1]).max() > 1e-4
+    print("per-robot dynamics: max one-sub-step |state diff| GPU vs oracle %.2e over 150 sub-steps x 8 robots; %d contact points; "
+          "z of the upward-gravity robot %.2f" % (worst, contacts, z[7]))
+
+
+def test_random_dynamic_redraws_per_robot_at_its_own_resets():
+    """quadrupedal-v0 with random_dynamic=True: every robot reports its own [latency, foot friction, base mass] inside the reference's
+    ranges; a masked reset redraws exactly the masked robots' sets (model rows, gravity, friction, latency, gains), the others keep
+    theirs bit for bit; the drawn gravity points UP like the reference's (z in [8, 12]), so the batch leaves the ground."""
+    n = 64
+    mode = dict(dis=1, motor=1, imu=1, contact=1, footpose=0, dynamic_vec=1)
+    env = metagym_amd.make("quadrupedal-v0", num_envs=n, urdf=a1_like_urdf(), device=DEV, random_dynamic=True, seed=11, sensor_mode=mode)
+    ph = env.physics
+    obs, info = env.reset()
+    dv = obs[:, 37:40].cpu().numpy()
+    assert (dv[:, 0] >= 0.035).all() and (dv[:, 0] <= 0.045).all() and (dv[:, 1] >= 1).all() and (dv[:, 1] <= 2).all()
+    assert (dv[:, 2] >= 0.8 * 4.7 - 1e-12).all() and (dv[:, 2] <= 1.2 * 4.7 + 1e-12).all() and np.unique(dv[:, 2]).size == n
+    assert torch.equal(env.robot._keep["control_latency"], env.dynamics.latency)
+    assert torch.equal(env.robot._keep["kp"], env.dynamics.motor_kp.t()) and float(env.dynamics.motor_kp.min()) >= 65.0
+    g = ph.gravity_env.clone()
+    assert float(g[2].min()) >= 8.0 and float(g[2].max()) <= 12.0 and float(g[:2].abs().max()) <= 1.0
+    nb = len(ph.model.body_parent)
+    trunk_mass = ph.env._table[:, 12 * nb]                               # body 0 = trunk + imu
+    assert torch.allclose(trunk_mass, torch.as_tensor(dv[:, 2], device=DEV) + 0.001, rtol=0, atol=1e-12)
+    before = dict(table=ph.env._table.clone(), g=g, mu=ph.foot_friction_env.clone(), lat=env.dynamics.latency.clone(),
+                  kd=env.robot._keep["kd"].clone())
+    a = torch.zeros(n, 12, dtype=torch.float64, device=DEV)
+    z0 = ph.world()["base"][:, 2].clone()
+    for _ in range(5):
+        env.step(a)
+    assert float((ph.world()["base"][:, 2] - z0).min()) > 0.05            # gravity points up: everybody rises
+    mask = torch.zeros(n, dtype=torch.bool, device=DEV)
+    mask[::4] = True
+    obs, reward, done, info = env.step(a, reset_mask=mask)
+    keep = ~mask
+    assert torch.equal(ph.env._table[keep], before["table"][keep]) and torch.equal(ph.gravity_env[:, keep], before["g"][:, keep])
+    assert torch.equal(ph.foot_friction_env[keep], before["mu"][keep]) and torch.equal(env.dynamics.latency[keep], before["lat"][keep])
+    assert torch.equal(env.robot._keep["kd"][:, keep], before["kd"][:, keep])
+    changed = (ph.env._table[mask] != before["table"][mask]).any(dim=1) & (ph.foot_friction_env[mask] != before["mu"][mask]) \
+        & (env.dynamics.latency[mask] != before["lat"][mask]) & (ph.gravity_env[2, mask] != before["g"][2, mask])
+    assert bool(changed.all())
+    assert torch.equal(obs[:, 37], env.dynamics.latency) and torch.equal(info["dynamics"][:, 1], ph.foot_friction_env)
+    # gravity_sign=-1: the same draws with z turned downwards — the robots stay on their feet
+    sane = metagym_amd.make("quadrupedal-v0", num_envs=n, urdf=a1_like_urdf(), device=DEV, random_dynamic=True, seed=11, gravity_sign=-1.0)
+    sane.reset()
+    for _ in range(40):
+        o, r, d, i = sane.step(a)
+    assert float(sane.physics.gravity_env[2].max()) <= -8.0 and float(d.double().mean()) < 0.1
+    assert float(sane.physics.world()["contact"].sum(dim=1).mean()) > 3.0
+
+
+def test_dynamic_param_per_link_keys_and_per_episode_sets():
+    """dynamic_param's per-link keys (baseinertia / legmass / leginertia, locomotion_gym_env.py:360-373) and a tilted gravity go
+    through the same per-robot rows — the same set for every robot; reset(dynamic_param=) gives this episode its own set and the
+    next reset goes back to the constructor's (:349-352)."""
+    n = 4
+    ctor = {"basemass": 1.1, "baseinertia": [0.5, 1.5, 1.0], "legmass": [1.2, 1.3, 0.9], "leginertia": [1.0 + 0.02 * i for i in range(12)],
+            "gravity": [0.5, 0.0, -9.0], "footfriction": 1.5, "control_latency": 20.0}
+    env = metagym_amd.make("quadrupedal-v0", num_envs=n, urdf=a1_like_urdf(), device=DEV, dynamic_param=ctor)
+    ph, dyn = env.physics, env.dynamics
+    want = dyn.body_tables(dyn.fixed(basemass=1.1, baseinertia=ctor["baseinertia"], legmass=ctor["legmass"], leginertia=ctor["leginertia"]))
+    nb = len(ph.model.body_parent)
+    rows = ph.env._table.clone()
+    assert torch.equal(rows[:, 12 * nb:13 * nb], want[0]) and torch.equal(rows[:, 16 * nb:25 * nb], want[2].reshape(n, -1))
+    assert torch.equal(ph.gravity_env[:, 2], torch.tensor([0.5, 0.0, -9.0], dtype=torch.float64, device=DEV))
+    assert float(ph.foot_friction_env[0]) == 1.5 and float(env.robot._keep["control_latency"][1]) == pytest.approx(0.020)
+    obs, info = env.reset()
+    assert torch.equal(ph.env._table, rows)
+    a = torch.zeros(n, 12, dtype=torch.float64, device=DEV)
+    for _ in range(10):
+        env.step(a)
+    assert float(ph.world()["base"][:, 0].min()) > 1e-4                   # the sideways pull moves them along +x
+    # this episode only: a heavier base for everybody
+    env.reset(dynamic_param={"basemass": 1.3})
+    assert abs(float(env.dynamics.basemass[0]) - 1.3 * 4.7) < 1e-12
+    assert abs(float(ph.env._table[0, 12 * nb]) - (1.3 * 4.7 + 0.001)) < 1e-12
+    assert torch.equal(ph.gravity_env[:, 0], torch.tensor([0.0, 0.0, -10.0], dtype=torch.float64, device=DEV))      # absent keys: nominal
+    env.reset()
+    assert torch.equal(ph.env._table, rows) and float(ph.gravity_env[0, 0]) == 0.5
