@@ -252,8 +252,10 @@ def test_unsupported_sensor_modes_are_refused_loudly():
         metagym_amd.make("quadrupedal-v0", num_envs=2, device=DEV, physics=object(), dynamic_param={"footfriction": 2.0})
     with pytest.raises(Exception, match="random_dynamic"):
         metagym_amd.make("quadrupedal-v0", num_envs=2, device=DEV, physics=object(), random_dynamic=True)
-    with pytest.raises(Exception, match="leginertia"):
+    with pytest.raises(Exception, match="per-link dynamic_param"):    # (needs the per-robot hooks of A1Physics)
         metagym_amd.make("quadrupedal-v0", num_envs=2, device=DEV, physics=object(), dynamic_param={"leginertia": [1.0] * 12})
+    with pytest.raises(Exception, match="jointfriction"):             # not one of locomotion_gym_env.py:354-380's keys
+        metagym_amd.make("quadrupedal-v0", num_envs=2, device=DEV, physics=object(), dynamic_param={"jointfriction": 0.1})
     for mode in ({"dis": 1, "motor": 1, "imu": 1, "contact": 1, "footpose": 0, "dynamic_vec": 1},
                  {"dis": 1, "motor": 1, "imu": 1, "contact": 1, "footpose": 0, "noise": 1},
                  {"dis": 1, "motor": 3, "imu": 1, "contact": 1, "footpose": 0}):
