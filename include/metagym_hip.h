@@ -703,6 +703,12 @@ typedef struct mg_a1_sensor_state {
     double *first_rpy;              /* DEVICE [3][N] */
     double *last_angle;             /* DEVICE [12][N] */
     int32_t *first;                 /* DEVICE [N] bit 0: IMU first_time, bit 1: MotorAngleAcc first_time */
+    /* (ABI 5) sensor_mode["noise"] (env_builder.py:60-71): this observation's Gaussian draws, DEVICE f64 [33][N], already scaled by
+     * their sigma, or NULL = no noise. Slots: displacement dx dy dz (sigma 1e-2, added BEFORE the rotation into the local frame,
+     * robot_sensors.py:281-284), rpy 3 (6e-2) and drpy 3 (1e-1) (:399-402), motor angles 12 (1e-2) and rates 12 (0.5) — added
+     * AFTER the rate was formed, and the noisy angles become last_angle (:146-149). The caller draws them (any generator);
+     * pinned by tests/golden/a1_sensors_noise.npz with the reference's own draws as inputs. */
+    const double *noise;
 } mg_a1_sensor_state;
 /* One observation per robot. reset_mask (u8 [N] or NULL = none; 2 = skip this robot, its sensor state and obs row stay): robots that were just reset — sensor.reset() + on_reset
  * (locomotion_gym_env.py:231-232,426-427) instead of on_step (:521-522). base [3][N] (GetBasePosition), rpy [3][N]

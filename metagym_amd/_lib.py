@@ -199,7 +199,7 @@ class A1SensorConfig(C.Structure):
 class A1SensorState(C.Structure):
     """mg_a1_sensor_state (device pointers)"""
     _fields_ = [("base_last", C.c_void_p), ("base_cur", C.c_void_p), ("yaw", C.c_void_p), ("first_rpy", C.c_void_p),
-                ("last_angle", C.c_void_p), ("first", C.c_void_p)]
+                ("last_angle", C.c_void_p), ("first", C.c_void_p), ("noise", C.c_void_p)]
 
 
 A1_FILTER_MAX_HIST = 4

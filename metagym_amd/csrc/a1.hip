@@ -515,7 +515,9 @@ __global__ __launch_bounds__(A1_BLOCK) void a1_observation_kernel(mg_a1_sensor_c
     for (int i = 0; i < 3; ++i) { st.base_last[(size_t)i * n + e] = last[i]; st.base_cur[(size_t)i * n + e] = cur[i]; }
     st.yaw[e] = yaw_last; st.yaw[(size_t)n + e] = yaw_cur;
     // BaseDisplacementSensor._get_observation :278-296
-    const double dx = (cur[0] - last[0]) / c.disp_dt, dy = (cur[1] - last[1]) / c.disp_dt, dz = (cur[2] - last[2]) / c.disp_dt;
+    const double *nz = st.noise;                                                 // [33][n] draws of sensor_mode["noise"], or none
+    double dx = (cur[0] - last[0]) / c.disp_dt, dy = (cur[1] - last[1]) / c.disp_dt, dz = (cur[2] - last[2]) / c.disp_dt;
+    if (nz != nullptr) { dx += nz[e]; dy += nz[(size_t)n + e]; dz += nz[2 * (size_t)n + e]; }     // :281-284, before the rotation
     const double cy = cos(yaw_last), sy = sin(yaw_last);
     double d0 = cy * dx + sy * dy, d1 = -sy * dx + cy * dy, d2 = dz;
     if (c.normal) { d0 = (d0 - 0.0) / 0.1; d1 = (d1 - 0.0) / 0.1; d2 = (d2 - 0.0) / 0.1; }
@@ -528,14 +530,17 @@ __global__ __launch_bounds__(A1_BLOCK) void a1_observation_kernel(mg_a1_sensor_c
         double fr = st.first_rpy[(size_t)i * n + e];
         if (first & 1) { fr = r; st.first_rpy[(size_t)i * n + e] = r; }
         double v = r - fr, w = drpy[(size_t)i * n + e];
+        if (nz != nullptr) { v += nz[(size_t)(3 + i) * n + e]; w += nz[(size_t)(6 + i) * n + e]; }   // :399-402
         if (c.normal) { v = (v - 0.0) / 0.1; w = (w - 0.0) / 0.5; }
         o[7 + i] = v; o[10 + i] = w;
     }
     // MotorAngleAccSensor._get_observation :136-158
     const double mean[3] = {0.0, 0.9, -1.8};
     for (int i = 0; i < NM; ++i) {
-        const double a = angles[(size_t)i * n + e];
+        double a = angles[(size_t)i * n + e];
         double acc = (first & 2) ? 0.0 : (a - st.last_angle[(size_t)i * n + e]) / c.motor_dt;
+        // :146-149: noise after the rate was formed; the NOISY angle is what the next rate starts from
+        if (nz != nullptr) { a += nz[(size_t)(9 + i) * n + e]; acc += nz[(size_t)(21 + i) * n + e]; }
         st.last_angle[(size_t)i * n + e] = a;
         double av = a;
         if (c.normal) { av = (a - mean[i % 3]) / 0.1; acc = (acc - 0.0) / 1.0; }

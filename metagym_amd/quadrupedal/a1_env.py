@@ -63,7 +63,7 @@ class A1GymEnv(object):
                  urdf_options=None, vel_mode="max", random_param=None, dynamic_param=None, random_dynamic=False, seed=0,
                  force_source=None, action_limit=(0.75, 0.75, 0.75), render=False, on_rack=False, gait=0, step_y=0.05,
                  terrain_slots=1, terrain_max_boxes=96, x_noise_source=None, per_robot_dynamics=False, dynamics_source=None,
-                 gravity_sign=1.0, **kwargs):
+                 gravity_sign=1.0, sensor_noise_source=None, **kwargs):
         # ---- the rest of the reference's constructor signature (a1_gym_env.py:19-40; `gym.make('quadrupedal-v0')` registers
         #      action_limit / render / on_rack / random_dynamic / ETG / ETG_T / ETG_H / ETG_path / task / dynamic_param,
         #      quadrupedal/__init__.py:9-20) ---------------------------------------------------------------------------------
@@ -152,7 +152,8 @@ class A1GymEnv(object):
                                  motor_control_mode=motor_control_mode, enable_action_filter=bool(filter_), **kw)
         self.path = EtgActionPath(num_envs, device, ETG=ETG, ETG_T=ETG_T, ETG_H=ETG_H, ETG_w=ETG_w, ETG_b=ETG_b, act_mode=act_mode,
                                   task_mode="gallop" if task == "gallop" else "normal", action_space=action_space)
-        self.sensors = SensorStack(num_envs, device, normal=normal)
+        self.sensors = SensorStack(num_envs, device, normal=normal, noise=bool(dict(sensor_mode).get("noise")), seed=seed,
+                                   noise_source=sensor_noise_source)
         self.shaping = RewardShaping(num_envs, device, param=reward_param, reward_p=reward_p, vel_d=vel_d, env_info=self.env_info,
                                      vel_mode=vel_mode)
         if self.terrain_slots > 1:
@@ -395,10 +396,9 @@ class A1GymEnv(object):
         channels (imu 1) or the three rates (imu 2), MotorAngleAccSensor (motor 1) or MotorAngleSensor (motor 2),
         FootContactSensor (contact 1) or SimpleFootForceSensor (contact 2: needs `world()["foot_force"]` from the physics),
         FootPoseSensor (footpose); 0 switches a sensor off. ObservationWrapper (MonitorEnv.py:77-221) appends its own
-        entries — all built except the two that come out of PyBullet-side randomisation (force_vec, dynamic_vec). Sensor
-        noise (`noise`: Gaussian draws from numpy's global stream inside every sensor) is not built."""
-        if mode.get("noise"):
-            raise _lib.MetaGymHipError("sensor_mode['noise']: per-sensor Gaussian noise from numpy's global RNG is not built on the device")
+        entries, force_vec / dynamic_vec included. `noise`: Gaussian draws inside every sensor (SensorStack: a device generator
+        instead of numpy's global stream; `sensor_noise_source` injects them)."""
+        self._sensor_noise = bool(mode.get("noise"))
         sel = (int(mode.get("dis", 0)), int(mode.get("imu", 0)), int(mode.get("motor", 0)), int(mode.get("contact", 0)),
                int(bool(mode.get("footpose", 0))))
         if sel[1] not in (0, 1, 2) or sel[2] not in (0, 1, 2) or sel[3] not in (0, 1, 2) or sel[0] not in (0, 1):
@@ -487,11 +487,11 @@ class A1GymEnv(object):
         if imu == 1:
             parts.append(obs37[:, 7:13])
         elif imu == 2:              # IMUSensor(channels dR dP dY) is built without `normal` (env_builder.py:67): raw rates
-            parts.append(info["drpy"])
+            parts.append(info["drpy"] + self.sensors._noise[6:9].t() if self._sensor_noise else info["drpy"])      # (+ its drpy draws)
         if motor == 1:
             parts.append(obs37[:, 13:37])
-        elif motor == 2:            # MotorAngleSensor :74-84
-            parts.append(info["joint_angle"])
+        elif motor == 2:            # MotorAngleSensor :74-84; its noise is N(0, 5e-3): the angle slots (sigma 1e-2) at half scale
+            parts.append(info["joint_angle"] + 0.5 * self.sensors._noise[9:21].t() if self._sensor_noise else info["joint_angle"])
         return torch.cat(parts, dim=1) if parts else obs37[:, 0:0]
 
     def get_time_since_reset(self):
@@ -628,6 +628,8 @@ class A1GymEnv(object):
         graph = torch.cuda.CUDAGraph()
         if self._random_force and self._force_source is None:      # the pushes' generator advances inside the captured step
             graph.register_generator_state(self._force_gen)
+        if self.sensors.noise and self.sensors._noise_source is None:
+            graph.register_generator_state(self.sensors.noise_gen)
         if self.random_dynamic and self.auto_reset and self.dynamics.source is None:      # ... and so does the dynamics' one
             graph.register_generator_state(self.dynamics.gen)
         robot, repeat = self.robot, 13
@@ -658,6 +660,8 @@ class A1GymEnv(object):
                   force=dict(pos=self._force_pos.clone(), vec=self._force_vec.clone(), on=self._force_on.clone(),
                              env_steps=self._env_steps.clone(), rng=self._force_gen.get_state()),
                   last_torques=None if self.last_torques is None else self.last_torques.clone())
+        if self.sensors.noise:
+            sd["sensor_noise_rng"] = self.sensors.noise_gen.get_state()
         if self.dynamics is not None:
             dy = self.dynamics
             sd["dynamics"] = dict(latency=dy.latency.clone(), footfriction=dy.footfriction.clone(), basemass=dy.basemass.clone(),
@@ -694,6 +698,8 @@ class A1GymEnv(object):
             self._obs_history.copy_(sd["obs_history"])
         if "physics" in sd and hasattr(self.physics, "load_state_dict"):
             self.physics.load_state_dict(sd["physics"])
+        if "sensor_noise_rng" in sd and self.sensors.noise:
+            self.sensors.noise_gen.set_state(sd["sensor_noise_rng"])
         if "dynamics" in sd and self.dynamics is not None:
             dy, f = self.dynamics, sd["dynamics"]
             for k in ("latency", "footfriction", "basemass", "motor_kp", "motor_kd"):

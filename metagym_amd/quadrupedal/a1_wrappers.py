@@ -181,7 +181,14 @@ class SensorStack(object):
     """The observation of `A1GymEnv` (37 float64): BaseDisplacementSensor (local frame), FootContactSensor, IMUSensor
     (R P Y dR dP dY), MotorAngleAccSensor in sensor-name order (envs/sensors/robot_sensors.py, locomotion_gym_env.py:621-632)."""
 
-    def __init__(self, num_envs, device="cuda:0", normal=0, num_action_repeat=13, sim_time_step=0.002):
+    NOISE_SIGMA = [1e-2] * 3 + [6e-2] * 3 + [1e-1] * 3 + [1e-2] * 12 + [0.5] * 12     # robot_sensors.py:281-284, 399-402, 146-148
+
+    def __init__(self, num_envs, device="cuda:0", normal=0, num_action_repeat=13, sim_time_step=0.002, noise=False, seed=0,
+                 noise_source=None):
+        """`noise` = sensor_mode["noise"] (env_builder.py:60-71): every observation adds Gaussian draws inside the sensors — 33 per
+        robot (NOISE_SIGMA). The reference takes them from numpy's global stream; here a device generator seeded by `seed`, or
+        `noise_source()` -> [33, N] already-scaled values (tests replay the reference's own draws through it)."""
+        self.noise, self._noise_source = bool(noise), noise_source
         self.device = torch.device(device)
         if self.device.type != "cuda":
             raise _lib.MetaGymHipError("metagym_amd has no CPU path: device must be a ROCm GPU, got %r" % (device,))
@@ -196,6 +203,12 @@ class SensorStack(object):
         s = self._st = _lib.A1SensorState()
         for k, t in self._t.items():
             setattr(s, k, t.data_ptr())
+        if self.noise:
+            self._noise = torch.zeros(33, N, **f64)               # persistent: a captured step keeps reading this buffer
+            self._sigma = torch.tensor(self.NOISE_SIGMA, **f64).reshape(33, 1)
+            self.noise_gen = torch.Generator(device=self.device)
+            self.noise_gen.manual_seed(int(seed) + 0x5e5)
+            s.noise = self._noise.data_ptr()
 
     def observe(self, base_position, base_rpy, base_rpy_rate, motor_angles, foot_contacts, reset_mask=None):
         """-> obs `[num_envs, 37]`. `reset_mask`: robots that were just reset (sensor.reset() + on_reset instead of on_step)."""
@@ -204,6 +217,11 @@ class SensorStack(object):
         a, ct = _soa(motor_angles, N, 12, d), _soa(foot_contacts, N, 4, d)
         m = None if reset_mask is None else torch.as_tensor(reset_mask, device=d).to(torch.uint8).contiguous()
         obs = torch.empty(N, _lib.A1_SENSOR_OBS_DIM, dtype=torch.float64, device=d)
+        if self.noise:
+            if self._noise_source is not None:
+                self._noise.copy_(torch.as_tensor(self._noise_source(), dtype=torch.float64, device=d).reshape(33, -1).expand(33, N))
+            else:
+                self._noise.copy_(torch.randn(33, N, generator=self.noise_gen, dtype=torch.float64, device=d) * self._sigma)
         with torch.cuda.device(d):
             rc = self._lib.mg_a1_observation(C.byref(self._cfg), N, C.byref(self._st), _lib.ptr(b), _lib.ptr(r), _lib.ptr(dr),
                                              _lib.ptr(a), _lib.ptr(ct), _lib.ptr(m), _lib.ptr(obs), _lib.current_stream(d))

@@ -330,29 +330,33 @@ class SensorStack(object):
         self.imu_first = self.motor_first = True
         self.last_angle = np.zeros(12)
 
-    def observe(self, base, rpy, drpy, angles, contact, was_reset):
+    def observe(self, base, rpy, drpy, angles, contact, was_reset, noise=None):
+        """`noise`: the 33 Gaussian draws of sensor_mode["noise"] for this observation (env_builder.py:60-71), as INPUTS, in slot
+        order displacement 3, rpy 3, drpy 3, motor angles 12, motor rates 12 (robot_sensors.py:281-284, 399-402, 146-148)."""
         base, rpy, angles = np.array(base, np.float64), np.array(rpy, np.float64), np.array(angles, np.float64)
+        nz = np.zeros(33) if noise is None else np.asarray(noise, np.float64)
         if was_reset:
             self.imu_first = self.motor_first = True                       # IMUSensor.reset :435-436, MotorAngleAccSensor.reset :159-162
             self.last_angle = np.zeros(12)
             self.cur, self.last, self.yaw_cur, self.yaw_last = base, base, rpy[2], rpy[2]       # on_reset :298-303
         else:
             self.last, self.cur, self.yaw_last, self.yaw_cur = self.cur, base, self.yaw_cur, rpy[2]   # on_step :305-310
-        dx, dy, dz = (self.cur - self.last) / self.disp_dt                 # :280
+        dx, dy, dz = (self.cur - self.last) / self.disp_dt + nz[0:3]       # :280-284 (noise BEFORE the rotation into the local frame)
         disp = np.array([np.cos(self.yaw_last) * dx + np.sin(self.yaw_last) * dy,
                          -np.sin(self.yaw_last) * dx + np.cos(self.yaw_last) * dy, dz])
         if self.normal:
             disp = (disp - np.array([0] * 3)) / np.array([0.1] * 3)
         if self.imu_first:                                                 # :388-390
             self.first_rpy, self.imu_first = rpy.copy(), False
-        imu = np.concatenate([rpy - self.first_rpy, drpy])
+        imu = np.concatenate([rpy - self.first_rpy + nz[3:6], np.asarray(drpy, np.float64) + nz[6:9]])      # :399-402
         if self.normal:
             imu = (imu - np.array([0] * 6)) / np.array([0.1] * 3 + [0.5] * 3)
         if self.motor_first:                                               # :141-145
             acc, self.motor_first = np.zeros(12), False
         else:
             acc = (angles - self.last_angle) / self.motor_dt
-        self.last_angle = angles
+        angles, acc = angles + nz[9:21], acc + nz[21:33]                   # :146-148, AFTER the rate was formed ...
+        self.last_angle = angles                                           # ... and the NOISY angles are what the next rate starts from (:149)
         motor = np.concatenate((angles, acc))
         if self.normal:
             motor = (motor - np.array([0, 0.9, -1.8] * 4 + [0] * 12)) / np.array([0.1] * 12 + [1] * 12)

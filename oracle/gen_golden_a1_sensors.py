@@ -27,6 +27,12 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 REF = os.environ.get("METAGYM_REFERENCE", "/root/reference")
 OUT = os.path.join(ROOT, "tests", "golden", "a1_sensors.npz")
+OUT_NOISE = os.path.join(ROOT, "tests", "golden", "a1_sensors_noise.npz")
+# sensor_mode["noise"] (env_builder.py:60-71): every sensor adds np.random.normal draws inside _get_observation. The noise cases
+# record them — np.random.normal is wrapped while the reference's sensors run — as 33 values per observation, slot order
+# displacement 3 (sigma 1e-2), rpy 3 (6e-2), drpy 3 (1e-1), motor angles 12 (1e-2), motor rates 12 (0.5)
+# (robot_sensors.py:281-284, 399-402, 146-148), so a replay needs no knowledge of numpy's stream.
+NOISE_SLOTS = {(1e-2, None): (0, 1), (6e-2, 3): (3, 3), (1e-1, 3): (6, 3), (1e-2, 12): (9, 12), (0.5, 12): (21, 12)}
 
 
 class Robot(object):
@@ -47,14 +53,20 @@ def main():
     from metagym.quadrupedal.envs import locomotion_gym_env
     from metagym.quadrupedal.envs.sensors import robot_sensors
     from metagym.quadrupedal.envs.utilities import env_utils
+    record([dict(name="sensors_raw", normal=0, seed=1), dict(name="sensors_normalised", normal=1, seed=2)], OUT, False,
+           locomotion_gym_env, robot_sensors, env_utils)
+    record([dict(name="sensors_noise_raw", normal=0, seed=3), dict(name="sensors_noise_normalised", normal=1, seed=4)], OUT_NOISE, True,
+           locomotion_gym_env, robot_sensors, env_utils)
+
+
+def record(cases, out_path, noise, locomotion_gym_env, robot_sensors, env_utils):
     out = {"numpy_version": np.array(np.__version__)}
-    cases = [dict(name="sensors_raw", normal=0, seed=1), dict(name="sensors_normalised", normal=1, seed=2)]
     for c in cases:
         rs = np.random.RandomState(c["seed"])
         dt = 13 * 0.002
-        sensors = [robot_sensors.BaseDisplacementSensor(convert_to_local_frame=True, normal=c["normal"], noise=False),
-                   robot_sensors.IMUSensor(channels=["R", "P", "Y", "dR", "dP", "dY"], normal=c["normal"], noise=False),
-                   robot_sensors.MotorAngleAccSensor(num_motors=12, normal=c["normal"], noise=False, dt=dt),
+        sensors = [robot_sensors.BaseDisplacementSensor(convert_to_local_frame=True, normal=c["normal"], noise=noise),
+                   robot_sensors.IMUSensor(channels=["R", "P", "Y", "dR", "dP", "dY"], normal=c["normal"], noise=noise),
+                   robot_sensors.MotorAngleAccSensor(num_motors=12, normal=c["normal"], noise=noise, dt=dt),
                    robot_sensors.FootContactSensor()]
         robot = Robot()
         for s in sensors:
@@ -64,6 +76,30 @@ def main():
             def all_sensors(self): return sensors
         env = Env()
         rec = collections.defaultdict(list)
+        drawn = np.zeros(33)
+        real_normal = np.random.normal
+
+        def recording_normal(loc, scale, size=None):
+            v = real_normal(loc, scale, size)
+            start, count = NOISE_SLOTS[(scale, size)]
+            if size is None:                                     # the three scalar draws of BaseDisplacementSensor, in dx dy dz order
+                start += recording_normal.scalars
+                recording_normal.scalars += 1
+            drawn[start:start + count] = v
+            return v
+
+        def observe():
+            drawn[:] = 0.0
+            recording_normal.scalars = 0
+            np.random.normal = recording_normal
+            try:
+                obs = env_utils.flatten_observations(locomotion_gym_env.LocomotionGymEnv._get_observation(env))[0]
+            finally:
+                np.random.normal = real_normal
+            if noise:
+                rec["in_noise"].append(drawn.copy())
+            return obs
+        np.random.seed(c["seed"] + 100)
 
         def world(k):
             robot.base = tuple(np.array([0.02 * k, 0.003 * k, 0.27]) + rs.uniform(-0.01, 0.01, 3))
@@ -81,22 +117,22 @@ def main():
                 s.reset()                                        # locomotion_gym_env.py:231-232
             for s in sensors:
                 s.on_reset(env)                                  # :426-427
-            obs = env_utils.flatten_observations(locomotion_gym_env.LocomotionGymEnv._get_observation(env))[0]
+            obs = observe()
             rec["kind"].append(0)
             rec["obs"].append(obs)
             for k in range(1, 15):
                 world(k)
                 for s in sensors:
                     s.on_step(env)                               # :521-522
-                obs = env_utils.flatten_observations(locomotion_gym_env.LocomotionGymEnv._get_observation(env))[0]
+                obs = observe()
                 rec["kind"].append(1)
                 rec["obs"].append(obs)
         for k, v in rec.items():
             out[c["name"] + "/" + k] = np.array(v)
         out[c["name"] + "/config"] = np.array([c["normal"], dt], dtype=np.float64)
     out["cases"] = np.array([c["name"] for c in cases])
-    np.savez_compressed(OUT, **out)
-    print("wrote", OUT, os.path.getsize(OUT), "bytes; obs dim", out["sensors_raw/obs"].shape)
+    np.savez_compressed(out_path, **out)
+    print("wrote", out_path, os.path.getsize(out_path), "bytes; obs", out[cases[0]["name"] + "/obs"].shape)
 
 
 if __name__ == "__main__":

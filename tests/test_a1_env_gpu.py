@@ -244,7 +244,7 @@ def test_quadrupedal_constructor_takes_the_reference_signature():
 
 
 def test_unsupported_sensor_modes_are_refused_loudly():
-    """What is still refused by name: dynamic_vec without a physics that knows its base mass, sensor noise, values outside
+    """What is still refused by name: dynamic_vec without a physics that knows its base mass, values outside
     env_builder.py:62-80; and pushes / simulator-side dynamics on a physics that cannot take them."""
     with pytest.raises(Exception, match="random_force"):
         metagym_amd.make("quadrupedal-v0", num_envs=2, device=DEV, physics=object(), random_param={"random_force": 1})
@@ -257,7 +257,6 @@ def test_unsupported_sensor_modes_are_refused_loudly():
     with pytest.raises(Exception, match="jointfriction"):             # not one of locomotion_gym_env.py:354-380's keys
         metagym_amd.make("quadrupedal-v0", num_envs=2, device=DEV, physics=object(), dynamic_param={"jointfriction": 0.1})
     for mode in ({"dis": 1, "motor": 1, "imu": 1, "contact": 1, "footpose": 0, "dynamic_vec": 1},
-                 {"dis": 1, "motor": 1, "imu": 1, "contact": 1, "footpose": 0, "noise": 1},
                  {"dis": 1, "motor": 3, "imu": 1, "contact": 1, "footpose": 0}):
         with pytest.raises(Exception, match="sensor_mode"):
             metagym_amd.make("quadrupedal-v0", num_envs=2, device=DEV, physics=object(), sensor_mode=mode)

@@ -69,15 +69,20 @@ def test_reward_goldens_cover_every_termination_rule(g):
     assert not done["reward_walk"][:5].any()
 
 
-@pytest.mark.parametrize("name", ["sensors_raw", "sensors_normalised"])
+@pytest.mark.parametrize("name", ["sensors_raw", "sensors_normalised", "sensors_noise_raw", "sensors_noise_normalised"])
 def test_sensor_stack_matches_reference(name):
-    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "a1_sensors.npz"))
+    """The noise cases (a1_sensors_noise.npz) are the reference's sensors built with noise=True (sensor_mode["noise"]), their
+    np.random.normal draws recorded as inputs."""
+    noisy = "noise" in name
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "a1_sensors_noise.npz" if noisy else "a1_sensors.npz"))
     normal, dt = g[name + "/config"]
     st = oa.SensorStack(int(normal), dt)
     for k in range(len(g[name + "/obs"])):
         obs = st.observe(g[name + "/in_base"][k], g[name + "/in_rpy"][k], g[name + "/in_drpy"][k], g[name + "/in_angles"][k],
-                         g[name + "/in_contact"][k], g[name + "/kind"][k] == 0)
+                         g[name + "/in_contact"][k], g[name + "/kind"][k] == 0, noise=g[name + "/in_noise"][k] if noisy else None)
         assert np.array_equal(obs, g[name + "/obs"][k]), "%s observation %d" % (name, k)
+    if noisy:
+        assert (np.abs(g[name + "/in_noise"]).max(axis=0) > 0).all()          # every one of the 33 slots was drawn
 
 
 @pytest.mark.parametrize("name", ["butter_default", "butter_bandpass", "exp"])
