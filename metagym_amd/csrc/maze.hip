@@ -1125,11 +1125,12 @@ extern "C" int mg_maze3d_step(const mg_maze_tasks *T, const mg_maze_view *view, 
     // more than 127 translucent cells on one ray needs n > 63 AND a vision range spanning them; capped, documented
     // in metagym_hip.h (mg_maze_view.max_ray_records)
     if (vk.t_max > 127) vk.t_max = 127;
-    // Waves per env (measured on MI355X, 16 384 envs, profiles/r01/maze3d_waves_sweep.txt): 64x64 frames
-    // run ~9 % faster with 2 waves per env (less per-env fixed work per pixel, more independent envs
-    // resident per CU), 128x128 is a tie, 256x256 is fastest with 4. 32-column slabs beat 64 everywhere
-    // (half the overlay-record LDS, more workgroups per CU).
-    int n_waves = ((long)vk.H * vk.V < 128L * 128L) ? 2 : MZ_WAVES;
+    // Waves per env (measured on MI355X, profiles/r04/maze3d_small_frames.txt; 256x256: profiles/r03/maze3d_waves_sweep.txt):
+    // up to 64x64 one wave per env is fastest (32x32: 0.52 vs 0.60 ms with two at 65 536 envs, 64x64: 0.91 vs 0.95 — no
+    // workgroup barrier partners, more independent envs resident per CU), 84x84 runs best with two, from 128x128 up with four.
+    // 32-column slabs beat 64 everywhere (half the overlay-record LDS, more workgroups per CU).
+    const long frame_px = (long)vk.H * vk.V;
+    int n_waves = frame_px <= 64L * 64L ? 1 : (frame_px < 128L * 128L ? 2 : MZ_WAVES);
     vk.slab = SLAB;
     {
         // tuning override MG_MAZE3D_WAVES="<waves>[,<slab>]", read ONCE per process (thread-safe static
