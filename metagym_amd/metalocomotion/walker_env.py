@@ -234,6 +234,8 @@ class WalkerBatchEnv(object):
         # reset must not change what the other envs' own first reset will see
         self._floor_known = torch.zeros(N, dtype=torch.bool, device=dev)
         self._all_floor_known = False                      # host mirror: True once every env went through a reset
+        self._floor_known_host = np.zeros(N, dtype=bool)   # ... fed by masks that arrive on the host
+        self._masked_first_resets = 0
         self._params_c = p
         self._apply_terrain()
         self._obs = torch.zeros(N, self.obs_dim, dtype=torch.float32, device=dev)
@@ -291,6 +293,10 @@ class WalkerBatchEnv(object):
         assert jn.shape == (self.n_joints, N)
         m = None
         if mask is not None:
+            if not (isinstance(mask, torch.Tensor) and mask.is_cuda) and not self._all_floor_known:
+                # a mask that arrives on the host also updates the host bitmap of envs that went through a reset, so a user who
+                # only ever resets with masks leaves the two-launch path as soon as every env had its first one
+                self._floor_known_host |= np.asarray(mask.cpu() if isinstance(mask, torch.Tensor) else mask).astype(bool).reshape(N)
             m = torch.as_tensor(mask, device=dev).to(torch.uint8).contiguous()
         # WalkerBaseEnv.reset adds the floor to robot.parts AFTER robot.reset() computed the reset observation and
         # potential (walker_base_env.py:24-31): the first reset after set_task averages over the robot's parts only
@@ -309,8 +315,12 @@ class WalkerBatchEnv(object):
             launch((sel & ~self._floor_known).to(torch.uint8).contiguous(), 0)
             launch((sel & self._floor_known).to(torch.uint8).contiguous(), 1)
             self._floor_known |= sel
-            if m is None:
+            self._masked_first_resets += 1
+            if m is None or bool(self._floor_known_host.all()):
                 self._all_floor_known = True
+            elif self._masked_first_resets % 64 == 0 and not torch.cuda.is_current_stream_capturing():
+                # device masks: look at the device bitmap once in a while (one host read per 64 masked resets, never in a capture)
+                self._all_floor_known = bool(self._floor_known.all())
         return self._obs
 
     def step(self, action):

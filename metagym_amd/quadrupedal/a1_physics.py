@@ -108,6 +108,10 @@ class A1Physics(object):
                              contact_erp=contact_erp, foot_force=True, preset="mujoco",      # (preset: only read for defaults
                              max_coordinate_velocity=max_coordinate_velocity)                # not given above; the Model is handed over)
         self.env.set_task([m])
+        # (the MetaLocomotion "floor joins robot.parts after the first reset" rule only shapes the walker observation, which nothing
+        # here reads: every reset is the one-launch kind from the start)
+        self.env._floor_known.fill_(True)
+        self.env._all_floor_known = True
         f64 = dict(dtype=torch.float64, device=self.device)
         self._init = torch.as_tensor(np.tile(np.asarray(init_motor_angles, np.float64), (self.n, 1)), **f64)
         # PyBullet's base position is the root link's inertial frame origin (for the A1: a1.py:61 COM_OFFSET)

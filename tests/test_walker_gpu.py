@@ -572,3 +572,21 @@ def test_first_reset_rule_is_per_env_and_survives_a_checkpoint():
         assert torch.equal(env.reset(joint_noise=n2), second) and torch.equal(env.potential, a.potential)
     fresh = _make("MetaHumanoidEnv", models, n)
     assert not torch.equal(fresh.reset(joint_noise=n2), second)                       # first vs later reset do differ (the floor link)
+
+
+def test_masked_resets_alone_leave_the_two_launch_path():
+    """Envs that are only ever reset through masks: once every env had its first reset, reset() is back to ONE launch — a host
+    bitmap follows masks that arrive on the host, the device bitmap is looked at every 64th masked reset otherwise."""
+    n = 4
+    env = _make("MetaHumanoidEnv", [MODELS["humanoid"]], n)
+    rs = np.random.RandomState(0)
+    noise = rs.uniform(-0.1, 0.1, (n, 17))
+    env.reset(mask=np.array([1, 1, 0, 0], bool), joint_noise=noise)
+    assert not env._all_floor_known
+    env.reset(mask=[False, False, True, True], joint_noise=noise)
+    assert env._all_floor_known
+    dev = _make("MetaHumanoidEnv", [MODELS["humanoid"]], n)
+    for k in range(64):
+        dev.reset(mask=torch.tensor([k % 2 == 0, k % 2 == 1, True, True], device="cuda:0"), joint_noise=noise)
+    assert dev._all_floor_known
+    assert torch.equal(dev.reset(joint_noise=noise), env.reset(joint_noise=noise))
