@@ -351,7 +351,7 @@ int mg_maze3d_step(const mg_maze_tasks *tasks, const mg_maze_view *view, int32_t
  * PARITY UNPINNED for the physics: PyBullet is not part of the reference tree. The engine is a
  * from-scratch reduced-coordinate multibody solver (joint-space inertia matrix + Newton-Euler bias,
  * semi-implicit Euler, projected Gauss-Seidel contacts / joint limits) run with the reference's
- * parameters; see DESIGN.md §3.5 for the stated assumptions. The Python-side rules (torques,
+ * parameters; see DESIGN.md §3.4 for the stated assumptions. The Python-side rules (torques,
  * observation, reward, done) follow the reference source exactly.
  * ======================================================================================== */
 
