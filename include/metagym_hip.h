@@ -229,7 +229,9 @@ typedef struct mg_maze_tasks {
      * (NULL = not provided; needed when mg_maze_state.food_by_slot is set): cell_slot inverts food_cells; slot_food /
      * slot_interval hold food_rewards / food_interval of the k-th listed cell of task t at [k * T + t], so lanes with consecutive
      * task ids (the default assignment e mod T) read consecutive addresses. */
-    const int16_t *cell_slot;      /* [T][n*n]: index k of the cell in its task's list, -1 for a cell that can never hold food */
+    const int16_t *cell_slot;      /* [T][n*n]: index k of the cell in its task's list; for a cell that can never hold food -1 when
+                                    * the task's food value there is exactly 0.0 (nothing is read for it), -2 when it is a nonzero
+                                    * value <= 1e-2 (read from `food` for the 2-D observation) */
     const double *slot_food;       /* [max_food][T] */
     const int32_t *slot_interval;  /* [max_food][T] */
 } mg_maze_tasks;
@@ -255,7 +257,10 @@ typedef struct mg_maze_state {
      * task's food_cells list) of env e at e*food_env_stride + k*food_cell_stride; cells outside the list keep their task values
      * for ever and are not stored. For mg_maze2d_step / mg_maze_reset with [max_food][N] arrays (env_stride 1, cell_stride N): lane
      * e's k-th access is coalesced whatever task it runs — indexed by cell, every lane of a wave touched a different [n*n][N] row
-     * (22x slower than ESCAPE at 2^20 envs). Needs mg_maze_tasks.food_cells / cell_slot / slot_food / slot_interval. */
+     * (22x slower than ESCAPE at 2^20 envs). Needs mg_maze_tasks.food_cells / cell_slot / slot_food / slot_interval.
+     * INVARIANT the slot path relies on: revival >= 0 wherever wait_refresh == 0 (true after every reset, renewal and step —
+     * the counter only counts down while its slot waits); a slot that is not waiting is then left untouched without reading its
+     * counter (maze_base.py:83-88 would renew a negative counter of a non-waiting cell: unreachable, and refused at load time). */
     int32_t food_by_slot;
 } mg_maze_state;
 

@@ -189,9 +189,13 @@ __device__ __forceinline__ int eval_scalar(const Task &t, const mg_maze_state &s
 // 0, so skipping it is exact and saves the HBM round trip for the ~95 % of cells that are empty.
 __device__ __forceinline__ void eval_cells(const Task &t, const mg_maze_state &st, int e, int first, int stride) {
     if (st.food_by_slot) {
+        // Only a WAITING slot changes: revival -= wait leaves a slot that is not waiting as it is, and its counter cannot be
+        // negative (it is >= 0 after every reset and renewal and only counts down while waiting; mg_maze_state documents the
+        // invariant and load_state_dict checks it). So the common case is one byte read per slot — no counter read, no store.
         for (int k = first; k < t.n_food; k += stride) {
             const size_t i = fidx(st, e, k);
-            int rv = st.revival[i] - (int)st.wait_refresh[i];
+            if (st.wait_refresh[i] == 0) continue;
+            int rv = st.revival[i] - 1;
             if (rv < 0) {
                 st.cur_food[i] = t.slot_food[(size_t)k * t.slot_stride];
                 rv = t.slot_interval[(size_t)k * t.slot_stride];
@@ -259,8 +263,10 @@ __global__ __launch_bounds__(MZ_BLOCK) void maze2d_step_kernel(mg_maze_tasks T, 
                 if (task_type == MG_MAZE_SURVIVAL) {                                       // :117
                     double food;
                     if (st.food_by_slot) {
+                        // (-1: not a food cell and its task value is exactly 0.0 — nothing to read; -2: not a food cell, a
+                        // nonzero value <= 1e-2 that never changes)
                         const int k = t.cell_slot[x * t.n + y];
-                        food = k >= 0 ? st.cur_food[fidx(st, e, k)] : t.food[x * t.n + y];
+                        food = k >= 0 ? st.cur_food[fidx(st, e, k)] : (k == -1 ? 0.0 : t.food[x * t.n + y]);
                     } else food = st.cur_food[fidx(st, e, x * t.n + y)];
                     v = (float)((double)v + food);
                 }

@@ -112,7 +112,10 @@ class _MazeBatch(object):
             # the list once more for the lane-per-env kernel (mg_maze_tasks.cell_slot / slot_food / slot_interval): the inverse
             # map cell -> slot, and the listed cells' task values slot-major, [max_food][T]
             listed = torch.arange(max_food, device=dev).unsqueeze(0) < n_food.unsqueeze(1)              # [T, max_food]
-            slot = torch.full((T, nn), -1, dtype=torch.int16, device=dev)
+            # cells outside the list: -1 when the task's value there is exactly 0.0 (the kernel then reads nothing for them), -2 when
+            # it is a nonzero value <= 1e-2 (never eaten, never renewed, but part of the 2-D observation: read from the task)
+            slot = torch.where(tt_food != 0.0, torch.full((T, nn), -2, dtype=torch.int16, device=dev),
+                               torch.full((T, nn), -1, dtype=torch.int16, device=dev))
             ks = torch.arange(max_food, device=dev, dtype=torch.int16).unsqueeze(0).expand(T, max_food)
             slot.scatter_(1, order, torch.where(listed, ks, torch.full_like(ks, -1)))      # (a row of `order` holds distinct cells)
             self._cell_slot_t = slot.contiguous()
@@ -202,6 +205,11 @@ class _MazeBatch(object):
                     raise ValueError("state_dict[%r] has shape %s, this env holds %s (same num_envs and maze size n needed)"
                                      % (k, tuple(src.shape), tuple(dst.shape)))
                 dst.copy_(src.to(dst.dtype))
+        if self._BY_SLOT and hasattr(self, "revival") and all(k in sd for k in ("revival", "wait_refresh")):
+            # the slot kernel never reads the counter of a slot that is not waiting (mg_maze_state.food_by_slot): a state with a
+            # negative counter there cannot come out of reset() / step() — refuse it instead of diverging from maze_base.py:83-88
+            if bool(((self.revival < 0) & (self.wait_refresh == 0)).any()):
+                raise ValueError("state_dict: a food counter below zero on a cell that is not waiting (unreachable by reset / step)")
 
     # ------------------------------------------------------------------ episode control
     def reset(self, mask=None):

@@ -191,6 +191,57 @@ def test_maze2d_batch_matches_oracle():
                 env.reset(mask=ra[2]); twin.reset(mask=rb[2])
 
 
+def test_maze2d_survival_crumbs_outside_the_food_list():
+    """Cells the per-slot layout does not store: a task value of exactly 0.0 is never read (cell_slot -1), a nonzero value
+    <= 1e-2 — never eaten (maze_base.py:71 needs > 1e-2), never renewed (interval 0) — still shows in the 2-D observation
+    (maze_2d.py:117) and is read from the task table (cell_slot -2). Hand-edited tasks with such crumbs on half of the free
+    cells, 40 steps, everything bit-exact against the oracle; and a checkpoint whose counters are negative where nothing waits
+    (unreachable by reset / step; the slot kernel would not see them) is refused."""
+    import metagym_amd
+    from metagym_amd.metamaze import MazeTaskSampler
+    tt = mo.TASK_TYPES["SURVIVAL"]
+    rs = np.random.RandomState(9)
+    tasks = []
+    for s_ in range(4):
+        t = MazeTaskSampler(n=9, allow_loops=True, step_reward=-0.01, goal_reward=1.0, food_density=0.08, food_interval=5, seed=s_)
+        food = np.array(t.food_rewards, np.float64)
+        free = (np.array(t.cell_walls) == 0) & (food == 0.0)
+        crumbs = free & (rs.rand(*food.shape) < 0.5)
+        food[crumbs] = rs.uniform(1e-4, 1e-2, int(crumbs.sum()))
+        tasks.append(t._replace(food_rewards=food))
+    n = 257
+    env = metagym_amd.make("meta-maze-2D-v0", num_envs=n, device="cuda:0", max_steps=30, view_grid=1, task_type="SURVIVAL")
+    env.set_task(tasks)
+    slots = env._cell_slot_t.cpu().numpy()
+    assert (slots == -2).sum() > 20 and (slots == -1).sum() > 20 and (slots >= 0).sum() > 4
+    ids = env.task_id.cpu().numpy()
+    otasks, states = _oracle_batch(tasks, ids, tt)
+    obs = env.reset().cpu().numpy()
+    seen_crumb = 0
+    for t in range(40):
+        a = rs.randint(0, 4, n)
+        obs, rew, done, info = env.step(torch.as_tensor(a))
+        r64, d, ob = env.reward64.cpu().numpy(), done.cpu().numpy(), obs.cpu().numpy()
+        for e in range(n):
+            r, dd = mo.step_2d(otasks[ids[e]], tt, 30, states[e], a[e])
+            assert r == r64[e] and dd == d[e], (t, e)
+            want = mo.observe_2d(otasks[ids[e]], tt, states[e], 1)
+            assert np.array_equal(ob[e], want), (t, e)
+            seen_crumb += int(((want > 0) & (want <= 1e-2)).any())
+        if d.any():
+            env.reset(mask=done)
+            for e in np.nonzero(d)[0]:
+                mo.reset(otasks[ids[e]], tt, states[e])
+    assert seen_crumb > n                                      # crumbs were in view all along
+    sd = env.state_dict()
+    bad = {k: v.clone() for k, v in sd.items()}
+    cell = int(np.argmax(slots[ids[0]] >= 0))                   # a listed cell of env 0's task
+    bad["wait_refresh"][cell, 0], bad["revival"][cell, 0] = 0, -3
+    with pytest.raises(ValueError, match="not waiting"):
+        env.load_state_dict(bad)
+    env.load_state_dict(sd)
+
+
 @pytest.mark.parametrize("continuous", [False, True])
 def test_maze3d_batch_matches_oracle(continuous):
     """9x9 mazes (config C3 geometry), 6 tasks x 96 envs, 64x64 and 40x24 frames, both task types;
