@@ -706,6 +706,23 @@ __device__ __forceinline__ double wave_sum(double v) {
     v = dpp_add<0x140>(v);   // row_mirror
     return (lane_value(v, 0) + lane_value(v, 16)) + (lane_value(v, 32) + lane_value(v, 48));
 }
+// wave-wide minimum / maximum, the result in every lane (four row-local DPP steps, then the four row results)
+template <int CTRL, bool MAX>
+__device__ __forceinline__ double dpp_minmax(double v) {
+    const int lo = __builtin_amdgcn_mov_dpp(__double2loint(v), CTRL, 0xf, 0xf, true);
+    const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(v), CTRL, 0xf, 0xf, true);
+    const double o = __hiloint2double(hi, lo);
+    return MAX ? fmax(v, o) : fmin(v, o);
+}
+template <bool MAX>
+__device__ __forceinline__ double wave_minmax(double v) {
+    v = dpp_minmax<0xB1, MAX>(v);
+    v = dpp_minmax<0x4E, MAX>(v);
+    v = dpp_minmax<0x141, MAX>(v);
+    v = dpp_minmax<0x140, MAX>(v);
+    const double a = lane_value(v, 0), b = lane_value(v, 16), c = lane_value(v, 32), d = lane_value(v, 48);
+    return MAX ? fmax(fmax(a, b), fmax(c, d)) : fmin(fmin(a, b), fmin(c, d));
+}
 // same when only lanes 0..31 can hold non-zero terms (at most 32 generalized coordinates)
 __device__ __forceinline__ double wave_sum32(double v) {
     v = dpp_add<0xB1>(v);
@@ -1284,18 +1301,29 @@ __device__ __forceinline__ void wave_substep(const mg_walker_topology &tp, const
                 rad = m.sph_r()[g];
                 sx = xw.x; sy = xw.y; sz = xw.z;
             }
-            double lo = g < ns ? sx - rad : 1e300, hi = g < ns ? sx + rad : -1e300;
-            for (int off = 32; off > 0; off >>= 1) {
-                lo = fmin(lo, __shfl_xor(lo, off));
-                hi = fmax(hi, __shfl_xor(hi, off));
-            }
+            // x range of this chunk's proxies, radius included (y / z ranges as well were measured: they cull nothing more on the
+            // reference's courses — rows of boxes along x, a cave the robot does touch — and cost 2 %)
+            const bool has = g < ns;
+            const double lo = wave_minmax<false>(has ? sx - rad : 1e300), hi = wave_minmax<true>(has ? sx + rad : -1e300);
             double bdepth = 0.0, bmu = 0.0;
             V3 bn{0, 0, 1}, bx{0, 0, 0};
-            for (int bi = 0; bi < prm.n_terrain_boxes; ++bi) {
+            // Broad phase, lane = box (64 per pass): a box whose world x extent misses the x range of this chunk's proxies cannot touch
+            // any of them. The survivors (a course is a row of boxes along x: two to five of the reference's 44 ... 68) are then
+            // visited in table order by a wave-uniform loop over the ballot's set bits — the same boxes, in the same order, as a
+            // serial walk over the table, whose one dependent 128-byte load + test per box was 40 % of the A1's step on `stairstair`.
+            for (int b0 = 0; b0 < prm.n_terrain_boxes; b0 += WV) {
+              bool near = false;
+              if (b0 + lane < prm.n_terrain_boxes) {
+                  const double *Bq = terrain + (size_t)MG_WALKER_BOX_DOUBLES * (b0 + lane);
+                  const double exq = fabs(Bq[3]) * Bq[12] + fabs(Bq[4]) * Bq[13] + fabs(Bq[5]) * Bq[14];    // world x half extent
+                  near = !(Bq[0] + exq < lo || Bq[0] - exq > hi);
+              }
+              unsigned long long todo = __ballot(near);
+              while (todo != 0ull) {
+                const int bi = b0 + __builtin_ctzll(todo);
+                todo &= todo - 1ull;
                 const double *B = terrain + (size_t)MG_WALKER_BOX_DOUBLES * bi;
                 const V3 bp{B[0], B[1], B[2]}, bh{B[12], B[13], B[14]};
-                const double ex = fabs(B[3]) * bh.x + fabs(B[4]) * bh.y + fabs(B[5]) * bh.z;      // world x half extent
-                if (bp.x + ex < lo || bp.x - ex > hi) continue;
                 if (g < ns) {
                     const V3 rel = V3{sx, sy, sz} - bp;
                     const V3 l{B[3] * rel.x + B[6] * rel.y + B[9] * rel.z, B[4] * rel.x + B[7] * rel.y + B[10] * rel.z,
@@ -1325,6 +1353,7 @@ __device__ __forceinline__ void wave_substep(const mg_walker_topology &tp, const
                                      B[9] * c.x + B[10] * c.y + B[11] * c.z};
                     }
                 }
+              }
             }
             const bool th = bdepth > 0.0;
             const unsigned long long th_mask = __ballot(th);
