@@ -607,6 +607,7 @@ def secondary_workloads(dev, valu_insts_per_wave=None):
         out["quadrupedal_v0_urdf_%denvs" % n3] = {
             "env_steps_per_s": n3 / s3, "ms_per_env_step": s3 * 1e3, "ms_per_env_step_hipgraph": s3g * 1e3,
             "env_steps_per_s_hipgraph": n3 / s3g, "physics_substeps_per_s_hipgraph": 13 * n3 / s3g,
+            "env_steps_per_s_best": n3 / min(s3, s3g), "best_launch_mode": "eager" if s3 <= s3g else "hipgraph",
             "robot": "examples/a1_like/a1_like.urdf (13 bodies, 12 hinges, 124 contact proxies)",
             "note": "A1GymEnv.step end to end (ETG + IK, 13 x 2 ms engine sub-steps with the PD motor model inside one launch, "
                     "observation history, sensors, reward, fused per-robot reset); dynamics parity with PyBullet unpinned"}
@@ -1065,7 +1066,7 @@ def main(argv=None):
                     ("C1_maze2d_1env_us_per_step_hipgraph", "C1_maze2d_15x15_escape_1env", ("us_per_step_hipgraph_100",)),
                     ("north_star_2p17_env_steps_per_s", "north_star_quadrotor_hovering_131072envs_1gpu", ("env_steps_per_s",)),
                     ("north_star_2p20_env_steps_per_s", "north_star_quadrotor_hovering_1048576envs_1gpu", ("env_steps_per_s",)),
-                    ("quadrupedal_v0_env_steps_per_s", "quadrupedal_v0_urdf_8192envs", ("env_steps_per_s_hipgraph",))):
+                    ("quadrupedal_v0_env_steps_per_s", "quadrupedal_v0_urdf_8192envs", ("env_steps_per_s_best",))):
                 v = pick(key, *path)
                 if v is not None:
                     out[name] = v

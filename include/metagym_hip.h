@@ -504,6 +504,12 @@ typedef struct mg_walker_params {
      * Per-robot masses and inertias need no field: give every robot its own row of the model table (task_id[e] = e). */
     const double *gravity_env;
     const double *foot_friction_env;
+    /* (ABI 5) mg_walker_reset only: where a reset places the base body instead of the model's own start pose — DEVICE f64
+     * reset_pos [3][N] (world position of the base body's origin) and reset_rot [9][N] (row-major rotation), each NULL = the model's.
+     * Minitaur.Reset(default_pose=, yaw=) (quadrupedal/robots/minitaur.py:425-431, envs/locomotion_gym_env.py:334-338). With either given, a
+     * reset also zeroes the reset robots' bad_contacts / foot_force entries (no contact points yet). */
+    const double *reset_pos;
+    const double *reset_rot;
 } mg_walker_params;
 
 /* Per-env state, SoA doubles: component c of env e at base[c*N + e]. */

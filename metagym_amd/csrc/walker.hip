@@ -605,6 +605,10 @@ __global__ __launch_bounds__(WK_BLOCK) void walker_reset_kernel(mg_walker_topolo
     Env s;
     s.pos = ld3(m.body_pos);
     for (int i = 0; i < 9; ++i) s.rot[i] = m.body_rot[i];
+    if (prm.reset_pos != nullptr)       // the caller's start pose (mg_walker_params.reset_pos / reset_rot)
+        s.pos = v3(prm.reset_pos[e], prm.reset_pos[(size_t)n_envs + e], prm.reset_pos[2 * (size_t)n_envs + e]);
+    if (prm.reset_rot != nullptr)
+        for (int i = 0; i < 9; ++i) s.rot[i] = prm.reset_rot[(size_t)i * n_envs + e];
     s.vel = v3(0, 0, 0);
     s.omega = v3(0, 0, 0);
     for (int j = 0; j < nj; ++j) {
@@ -613,6 +617,11 @@ __global__ __launch_bounds__(WK_BLOCK) void walker_reset_kernel(mg_walker_topolo
     }
     float fc[MG_WALKER_MAX_FEET];
     for (int f = 0; f < nf; ++f) { fc[f] = 0.0f; st.feet_contact[(size_t)f * n_envs + e] = 0.0f; }
+    if (prm.reset_pos != nullptr || prm.reset_rot != nullptr) {            // a robot placed by its caller: no contact points yet
+        if (st.bad_contacts != nullptr) st.bad_contacts[e] = 0;
+        if (st.foot_force != nullptr)
+            for (int f = 0; f < nf; ++f) st.foot_force[(size_t)f * n_envs + e] = 0.0;
+    }
     float ob[8 + 2 * NJ + MG_WALKER_MAX_FEET];
     double dist;
     int at_limit;

@@ -286,7 +286,9 @@ class WalkerBatchEnv(object):
             self.np_random = np.random.RandomState(seed)
         if joint_noise is None:                                    # walker_base.py:15, per env in joint order
             joint_noise = self.np_random.uniform(low=-0.1, high=0.1, size=(N, self.n_joints))
-        if isinstance(joint_noise, torch.Tensor):                  # a device tensor stays on the device (no host trip: capturable)
+        if isinstance(joint_noise, _lib.JointMajor):               # already [n_joints][N] float64 on the device: taken as it is
+            jn = joint_noise.t
+        elif isinstance(joint_noise, torch.Tensor):                # a device tensor stays on the device (no host trip: capturable)
             jn = joint_noise.to(device=dev, dtype=torch.float64).t().contiguous()
         else:
             jn = torch.as_tensor(np.ascontiguousarray(np.asarray(joint_noise, np.float64).T), device=dev)
@@ -297,7 +299,9 @@ class WalkerBatchEnv(object):
                 # a mask that arrives on the host also updates the host bitmap of envs that went through a reset, so a user who
                 # only ever resets with masks leaves the two-launch path as soon as every env had its first one
                 self._floor_known_host |= np.asarray(mask.cpu() if isinstance(mask, torch.Tensor) else mask).astype(bool).reshape(N)
-            m = torch.as_tensor(mask, device=dev).to(torch.uint8).contiguous()
+            m = torch.as_tensor(mask, device=dev)
+            # (a contiguous bool tensor IS a 0 / 1 byte array: reinterpret, no kernel)
+            m = m.view(torch.uint8) if (m.dtype == torch.bool and m.is_contiguous()) else m.to(torch.uint8).contiguous()
         # WalkerBaseEnv.reset adds the floor to robot.parts AFTER robot.reset() computed the reset observation and
         # potential (walker_base_env.py:24-31): the first reset after set_task averages over the robot's parts only
         # (per env: `_floor_known`. While some env has not been reset yet, the masked reset runs as two masked launches —

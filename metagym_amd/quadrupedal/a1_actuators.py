@@ -155,8 +155,8 @@ class A1Actuators(object):
             self._observed_torque.zero_()
         else:
             m = torch.as_tensor(mask, device=self.device).bool()
-            self._count.mul_((~m).to(self._count.dtype))                   # (no boolean indexing: nothing here syncs with the host)
-            self._observed_torque.mul_((~m).to(torch.float64))
+            self._count.masked_fill_(m, 0)                                 # (in place, one launch each, nothing syncs with the host)
+            self._observed_torque.masked_fill_(m, 0.0)
         if mask is None:                # the host-side scalars describe the batch as a whole: a partial reset leaves them
             self._step_counter = 0
             self._last_action = None
@@ -202,8 +202,11 @@ class A1Actuators(object):
         quat, rate = self._soa(base_orientation, 4), self._soa(base_rpy_rate, 3)
         cm = None if clear_mask is None else torch.as_tensor(clear_mask, device=self.device).to(torch.uint8).contiguous()
         if only_mask is not None:       # kernel mask values: 0 push, 1 clear + push, 2 untouched
-            om = torch.as_tensor(only_mask, device=self.device).bool()
-            cm = torch.where(om, torch.ones_like(om, dtype=torch.uint8), torch.full_like(om, 2, dtype=torch.uint8)).contiguous()
+            if only_mask.dtype == torch.uint8:      # the caller's ready-made code array (1 = this robot, 2 = untouched)
+                cm = only_mask
+            else:
+                om = torch.as_tensor(only_mask, device=self.device).bool()
+                cm = torch.where(om, torch.ones_like(om, dtype=torch.uint8), torch.full_like(om, 2, dtype=torch.uint8)).contiguous()
         with torch.cuda.device(self.device):
             rc = self._lib.mg_a1_receive_observation(C.byref(self._cfg), self.num_envs, C.byref(self._st), _lib.ptr(q),
                                                      _lib.ptr(qd), _lib.ptr(quat), _lib.ptr(rate), _lib.ptr(cm),

@@ -185,6 +185,8 @@ class A1GymEnv(object):
         # robots whose episode ended at the last step (auto_reset): one persistent buffer, so a captured step keeps reading it
         self.auto_reset = bool(auto_reset)
         self._pending = torch.zeros(self.num_envs, dtype=torch.bool, device=self.device)
+        self._u8_one = torch.ones(self.num_envs, dtype=torch.uint8, device=self.device)
+        self._u8_two = torch.full((self.num_envs,), 2, dtype=torch.uint8, device=self.device)
         # ---- RandomWrapper (MonitorEnv.py:521-662): pushes on the base, and what the observation reports about the dynamics ----
         f64 = dict(dtype=torch.float64, device=self.device)
         self._random_force = bool((random_param or {}).get("random_force"))
@@ -528,7 +530,7 @@ class A1GymEnv(object):
         if mask is None:
             self._env_steps.zero_()
         else:
-            self._env_steps.mul_((~mask).to(torch.int64))
+            self._env_steps.masked_fill_(mask, 0)
         if not self._random_force:
             return
         pos, vec = self._draw_force()
@@ -716,10 +718,10 @@ class A1GymEnv(object):
         self._place_for_reset(m)
         self._dynamics_for_reset(m)
         self.robot.Reset(mask=m)
-        self._substeps_dev.mul_((~m).to(torch.float64))
-        self.robot.ReceiveObservation(*self.physics.reset(m), only_mask=m)
+        self._substeps_dev.masked_fill_(m, 0.0)
+        two = torch.where(m, self._u8_one, self._u8_two)                       # 1 reset, 2 untouched: one array for both kernels
+        self.robot.ReceiveObservation(*self.physics.reset(m), only_mask=two)
         world, info = self.physics.world(), self._info()
-        two = torch.where(m, torch.ones_like(m, dtype=torch.uint8), torch.full_like(m, 2, dtype=torch.uint8))     # 1 reset, 2 untouched
         obs0 = self.sensors.observe(world["base"], info["pose"], info["drpy"], info["joint_angle"], world["contact"], two)
         obs0 = self._select_sensors(obs0, info, world)
         etg_obs0 = self.path.reset(self._substeps_dev * self.robot.time_step, mask=m)
@@ -745,14 +747,14 @@ class A1GymEnv(object):
         if m is not None:
             m = torch.as_tensor(m, device=self.device).bool()
             at_reset = self._begin_partial_reset(m)
-            action = torch.where(m.reshape(-1, 1), torch.zeros_like(action), action)
+            action = action.masked_fill(m.reshape(-1, 1), 0.0)
         obs, info = self._env_step(action, d_yaw=d_yaw, filter_init_mask=m)
         reward, done, terms = self.shaping.step(info["base"], info["pose"], info["rot_mat"], info["footposition"],
                                                 info["real_contact"], info["energy"], info["bad"], d_yaw)
         info.update(terms)
         if m is not None:
             self.shaping.reset(*at_reset, mask=m)
-            reward, done = torch.where(m, torch.zeros_like(reward), reward), done & ~m
+            reward, done = reward.masked_fill(m, 0.0), done.masked_fill(m, False)
             info["reset"] = m.clone()       # (m may be the persistent auto-reset buffer, overwritten just below)
         if self.auto_reset:
             self._pending.copy_(done)

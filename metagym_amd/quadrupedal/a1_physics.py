@@ -27,6 +27,7 @@ the reference's parameters, not Bullet's solver or its convex-convex collision."
 import numpy as np
 import torch
 
+from .. import _lib
 from ..metalocomotion.mjcf import Model
 from ..metalocomotion.walker_env import WalkerBatchEnv
 from .a1_actuators import INIT_MOTOR_ANGLES, MOTOR_NAMES, SoA
@@ -119,6 +120,15 @@ class A1Physics(object):
         self._base_offset = torch.as_tensor(np.asarray(frame, np.float64), **f64).reshape(3, 1)
         self._pose = torch.tensor([0.0, 0.0, 0.28], **f64).reshape(3, 1).repeat(1, self.n).contiguous()      # reset pose per robot
         self._yaw = torch.zeros(self.n, **f64)                                                              # reset heading per robot
+        # what a reset hands to the engine and back to the actuators, derived from (_pose, _yaw) whenever those change — never on
+        # the step path: the base body's origin and rotation (mg_walker_params.reset_pos / reset_rot), the observation of a robot
+        # that was just reset (joints at their start angles, zero rates, the heading's quaternion)
+        self._init_jm = _lib.JointMajor(self._init.t().contiguous())
+        self._reset_pos, self._reset_rot = torch.zeros(3, self.n, **f64), torch.zeros(9, self.n, **f64)
+        self._reset_quat, self._zero_rate = torch.zeros(4, self.n, **f64), torch.zeros(3, self.n, **f64)
+        self._zero_qd = torch.zeros(12, self.n, **f64)
+        self.env._params_c.reset_pos, self.env._params_c.reset_rot = self._reset_pos.data_ptr(), self._reset_rot.data_ptr()
+        self._derive_reset_state()
         self._ext = torch.zeros(6, self.n, **f64)                # pending push on the base (apply_external_force)
         self.env.set_external_wrench(self._ext)
         if fused:                                  # A1GymEnv takes the one-launch path when the physics offers it
@@ -188,6 +198,19 @@ class A1Physics(object):
         self._pose.copy_(torch.where(m.reshape(1, -1), p, self._pose))
         if yaw is not None:
             self._yaw.copy_(torch.where(m, torch.as_tensor(yaw, **f64).expand(self.n), self._yaw))
+        self._derive_reset_state()
+
+    def _derive_reset_state(self):
+        """(_pose, _yaw) -> the engine's reset pose and the reset observation's quaternion. resetBasePositionAndOrientation places
+        the root link's INERTIAL frame at the robot's reset pose, turned by its reset heading about z (minitaur.py:426)."""
+        c, s, zero, one = torch.cos(self._yaw), torch.sin(self._yaw), torch.zeros_like(self._yaw), torch.ones_like(self._yaw)
+        R = torch.stack([c, -s, zero, s, c, zero, zero, zero, one], dim=0)     # [9, N] row-major Rz(yaw)
+        off = self._base_offset.reshape(3)
+        self._reset_rot.copy_(R)
+        self._reset_pos.copy_(self._pose - torch.stack([R[0] * off[0] + R[1] * off[1] + R[2] * off[2],
+                                                        R[3] * off[0] + R[4] * off[1] + R[5] * off[2],
+                                                        R[6] * off[0] + R[7] * off[1] + R[8] * off[2]], dim=0))      # the root body origin
+        self._reset_quat.copy_(self._quat_of(self._reset_rot))
 
     def apply_external_force(self, force, position):
         """pybullet.applyExternalForce(robot, -1, force, position, LINK_FRAME) for every robot (`[N, 3]` each, base link frame =
@@ -197,33 +220,18 @@ class A1Physics(object):
         self._ext[0:3].copy_(f.t())
         self._ext[3:6].copy_(p.t() + self._base_offset)
 
-    def _base_quat_rate(self):
-        e = self.env
-        R = e.rot.t().reshape(self.n, 3, 3)
-        tr = R[:, 0, 0] + R[:, 1, 1] + R[:, 2, 2]
-        w = 0.5 * torch.sqrt(torch.clamp(1.0 + tr, min=1e-12))
-        quat = torch.stack([(R[:, 2, 1] - R[:, 1, 2]) / (4 * w), (R[:, 0, 2] - R[:, 2, 0]) / (4 * w),
-                            (R[:, 1, 0] - R[:, 0, 1]) / (4 * w), w], dim=1)
-        rate = torch.einsum("nij,ni->nj", R, e.omega.t())                      # body-frame angular velocity R^T omega
-        return quat.contiguous(), rate.contiguous()
+    @staticmethod
+    def _quat_of(rot):
+        """[9, N] row-major rotations -> [4, N] quaternions (x, y, z, w), the trace form (w > 0 for every upright robot)."""
+        w = 0.5 * torch.sqrt(torch.clamp(1.0 + rot[0] + rot[4] + rot[8], min=1e-12))
+        return torch.stack([(rot[7] - rot[5]) / (4 * w), (rot[2] - rot[6]) / (4 * w), (rot[3] - rot[1]) / (4 * w), w], dim=0)
 
     def reset(self, mask):
-        e = self.env
-        e.reset(mask=mask, joint_noise=self._init)                             # joints at (0, 0.9, -1.8) x 4, velocities zero
-        # base: resetBasePositionAndOrientation places the root link's INERTIAL frame at the robot's reset pose, turned by its
-        # reset heading about z (minitaur.py:426; 0 unless reset(yaw=) said otherwise)
-        m = torch.ones(self.n, dtype=torch.bool, device=self.device) if mask is None else torch.as_tensor(mask, device=self.device).bool()
-        c, s, zero, one = torch.cos(self._yaw), torch.sin(self._yaw), torch.zeros_like(self._yaw), torch.ones_like(self._yaw)
-        R = torch.stack([c, -s, zero, s, c, zero, zero, zero, one], dim=0)     # [9, N] row-major Rz(yaw)
-        off = self._base_offset.reshape(3)
-        target = self._pose - torch.stack([R[0] * off[0] + R[1] * off[1] + R[2] * off[2], R[3] * off[0] + R[4] * off[1] + R[5] * off[2],
-                                           R[6] * off[0] + R[7] * off[1] + R[8] * off[2]], dim=0)      # the root body origin
-        e.pos.copy_(torch.where(m.reshape(1, -1), target, e.pos))
-        e.rot.copy_(torch.where(m.reshape(1, -1), R, e.rot))
-        e.bad_contacts.mul_((~m).to(torch.int32))                               # no contact points yet (feet flags: the reset kernel)
-        e.foot_force.mul_((~m).to(torch.float64).reshape(1, -1))
-        quat, rate = self._base_quat_rate()
-        return e.q.t().contiguous(), e.qd.t().contiguous(), quat, rate
+        """ONE engine launch: joints at (0, 0.9, -1.8) x 4, velocities zero, base at the robot's reset pose and heading, contact
+        bookkeeping cleared (mg_walker_reset with mg_walker_params.reset_pos / reset_rot). Returns what Minitaur.ReceiveObservation
+        reads right after a reset — for the robots that were reset; the other rows are never looked at (only_mask)."""
+        self.env.reset(mask=mask, joint_noise=self._init_jm)
+        return SoA(self._init_jm.t), SoA(self._zero_qd), SoA(self._reset_quat), SoA(self._zero_rate)
 
     def substep(self, torques):
         """One 2 ms sub-step with the motor torques A1Actuators computed (raw torques, in-launch actuation mode 2); the
@@ -264,9 +272,10 @@ class A1Physics(object):
     def world(self):
         """base = GetBasePosition (the root link's inertial frame origin), contact = GetFootContacts (a1.py:299-312: toe links
         against anything that is not the robot), bad = GetBadFootContacts (a1.py:314-323: contact points on any other link),
-        foot_force = the normal-force magnitudes GetFootContactsForce (a1.py:325-356) sums per toe."""
+        foot_force = the normal-force magnitudes GetFootContactsForce (a1.py:325-356) sums per toe. `[N, k]` VIEWS of
+        component-major tensors: consumers that want `[k][N]` get it back without a copy."""
         e = self.env
-        R = e.rot.t().reshape(self.n, 3, 3)
-        base = e.pos.t() + torch.einsum("nij,j->ni", R, self._base_offset.reshape(3))
-        return dict(base=base.contiguous(), contact=e.feet_contact.t().to(torch.float64).contiguous(), bad=e.bad_contacts,
-                    foot_force=e.foot_force.t().contiguous())       # newtons (GetFootContactsForce reports it / 100)
+        off = self._base_offset.reshape(1, 3, 1)
+        base = e.pos + (e.rot.reshape(3, 3, self.n) * off).sum(dim=1)          # pos + R off, [3, N]
+        return dict(base=base.t(), contact=e.feet_contact.to(torch.float64).t(), bad=e.bad_contacts,
+                    foot_force=e.foot_force.t())       # newtons (GetFootContactsForce reports it / 100)

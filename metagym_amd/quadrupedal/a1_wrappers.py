@@ -17,6 +17,14 @@ Param_Dict = {'torso': 1.0, 'up': 0.3, 'feet': 0.2, 'tau': 0.1, 'done': 1, 'velx
 FLAT_GROUND = [[-100, 100, np.array([1, 0, 0, 0, 0, 0, 0])]]          # locomotion_gym_env.py:76 (env_info)
 
 
+def _u8(mask, device):
+    """A bool / uint8 mask as the contiguous uint8 array the kernels read (a contiguous bool tensor IS one: reinterpreted, no copy)."""
+    m = torch.as_tensor(mask, device=device)
+    if m.dtype == torch.bool and m.is_contiguous():
+        return m.view(torch.uint8)
+    return m.to(torch.uint8).contiguous()
+
+
 def _soa(x, n, k, device, dtype=torch.float64):
     x = torch.as_tensor(x, dtype=dtype, device=device)
     assert x.shape == (n, k), "expected [num_envs, %d], got %s" % (k, tuple(x.shape))
@@ -60,13 +68,13 @@ class EtgActionPath(object):
     def etg_b(self):
         return np.asarray([self._cfg.b[a] for a in range(3)])
 
-    def _launch(self, action, t, command, etg_obs):
+    def _launch(self, action, t, command, etg_obs, act=None):
         tt = torch.as_tensor(t, dtype=torch.float64, device=self.device)
         if tt.dim() == 0:
             tt = tt.expand(self.num_envs)
         tt = tt.contiguous()
         with torch.cuda.device(self.device):
-            rc = self._lib.mg_a1_etg_action(C.byref(self._cfg), self.num_envs, _lib.ptr(self.last_ETG_act), _lib.ptr(action),
+            rc = self._lib.mg_a1_etg_action(C.byref(self._cfg), self.num_envs, _lib.ptr(self.last_ETG_act if act is None else act), _lib.ptr(action),
                                             _lib.ptr(tt), _lib.ptr(command), _lib.ptr(etg_obs), _lib.current_stream(self.device))
         _lib.check(rc, "mg_a1_etg_action")
 
@@ -76,10 +84,14 @@ class EtgActionPath(object):
         if not self._cfg.enabled:
             return None
         obs = torch.empty(self.H, self.num_envs, dtype=torch.float64, device=self.device)
-        keep = None if mask is None else self.last_ETG_act.clone()
-        self._launch(None, t, None, obs)
-        if keep is not None:
-            self.last_ETG_act.copy_(torch.where(torch.as_tensor(mask, device=self.device).bool(), self.last_ETG_act, keep))
+        if mask is None:
+            self._launch(None, t, None, obs)
+        else:       # the reset output of every robot goes to a scratch array (a reset reads nothing of the previous output); the masked
+            #         robots' columns are then taken over: two launches
+            if not hasattr(self, "_reset_scratch"):
+                self._reset_scratch = torch.empty_like(self.last_ETG_act)
+            self._launch(None, t, None, obs, act=self._reset_scratch)
+            torch.where(torch.as_tensor(mask, device=self.device).bool(), self._reset_scratch, self.last_ETG_act, out=self.last_ETG_act)
         return obs.t()
 
     def step(self, action, t):
@@ -141,7 +153,7 @@ class RewardShaping(object):
     def reset(self, base, rot_mat, footposition, mask=None):
         """RewardShaping.reset (:305-318) with the RESET info's base [N,3], rot_mat [N,9], footposition [N,12] (base frame)."""
         N, d = self.num_envs, self.device
-        m = None if mask is None else torch.as_tensor(mask, device=d).to(torch.uint8).contiguous()
+        m = None if mask is None else _u8(mask, d)
         # (named locals: the SoA copies must outlive the launch call, _lib.ptr() only keeps their addresses)
         b, r, f = _soa(base, N, 3, d), _soa(rot_mat, N, 9, d), _soa(footposition, N, 12, d)
         with torch.cuda.device(d):
@@ -166,7 +178,7 @@ class RewardShaping(object):
                                              _lib.ptr(terms), _lib.ptr(reward), _lib.ptr(done), _lib.current_stream(d))
         _lib.check(rc, "mg_a1_reward_step")
         names = ("torso", "up", "feet", "tau", "badfoot", "footcontact")
-        return reward, done.bool(), {k: terms[i] for i, k in enumerate(names)}
+        return reward, done.view(torch.bool), {k: terms[i] for i, k in enumerate(names)}     # (0 / 1 bytes: reinterpreted)
 
     def state_dict(self):
         return {k: t.clone() for k, t in self._t.items()}
@@ -215,7 +227,7 @@ class SensorStack(object):
         N, d = self.num_envs, self.device
         b, r, dr = _soa(base_position, N, 3, d), _soa(base_rpy, N, 3, d), _soa(base_rpy_rate, N, 3, d)
         a, ct = _soa(motor_angles, N, 12, d), _soa(foot_contacts, N, 4, d)
-        m = None if reset_mask is None else torch.as_tensor(reset_mask, device=d).to(torch.uint8).contiguous()
+        m = None if reset_mask is None else _u8(reset_mask, d)
         obs = torch.empty(N, _lib.A1_SENSOR_OBS_DIM, dtype=torch.float64, device=d)
         if self.noise:
             if self._noise_source is not None:
