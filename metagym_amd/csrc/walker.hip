@@ -1026,6 +1026,36 @@ __device__ __forceinline__ void wave_kinematics(const ModelW &m, const WaveLds &
     PHASE(11);
 }
 
+// Projected Gauss-Seidel in multiplier space, KR rows per sweep fully unrolled (KR >= the row count: a row past the last one has
+// idg = bias = lambda = 0 in its lane, so its step is an exact no-op and needs no guard). Delta form, no branch on the row kind:
+// every lane forms the change d of ITS multiplier before projection and projects it onto its own bounds; row r's is taken.
+// Critical chain per row: fma -> max (-> min) -> readlane -> fmac.
+template <int KR, int NRA>
+__device__ __forceinline__ void delassus_sweep(const double (&a)[NRA], int iters, int lane, bool fric_l, double idg_l, double c0,
+                                               double mu_l, double &g, double &lam) {
+    static_assert(KR <= NRA, "rows kept in registers");
+    const double INF = __longlong_as_double(0x7ff0000000000000ll);
+    double lam_norm = 0.0;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int r = 0; r < KR; ++r) {
+            const double d = fma(-g, idg_l, c0);
+            double dl_c;
+            if (r % 3 == 0) dl_c = fmax(d, -lam);                // a normal or a joint-limit row: lambda >= 0
+            else {                                               // a friction row (its lane < 3 ncont) or a joint-limit row
+                const double lim = mu_l * lam_norm;
+                const double lo = fric_l ? -lim - lam : -lam, hi = fric_l ? lim - lam : INF;
+                dl_c = fmin(fmax(d, lo), hi);
+            }
+            const double dl = lane_value(dl_c, r);
+            g = fma(a[r], dl, g);
+            const double xn = lam + dl_c;
+            if (r % 3 == 0) lam_norm = lane_value(xn, r);        // (read by the friction rows right after a normal row only)
+            lam = lane == r ? xn : lam;
+        }
+    }
+}
+
 template <int NMAX, bool GENERIC, bool VELF>
 __device__ __forceinline__ void wave_substep(const mg_walker_topology &tp, const ModelW &m, const mg_walker_params &prm,
                                              const WaveLds &L, int lane, int maxr,
@@ -1484,9 +1514,17 @@ __device__ __forceinline__ void wave_substep(const mg_walker_topology &tp, const
     //      NMAX-slot array): through LDS every step of the substitution would wait on its own previous store.
     //      A joint-limit row starts as +-e_(6+j) and is never materialised before this point -------------------
     static_assert(3 * W_MAXC + NJ <= WV, "one lane per constraint row");
+    // (shape-generic instantiations: the whitened row stays in registers past this block — the Delassus sweep below builds its
+    // matrix from it)
+    constexpr bool ASPACE = GENERIC;
+    constexpr int NRA = NMAX <= 18 ? 30 : 24;    // constraint rows the multiplier-space sweep keeps in registers (one row of A per lane)
+    double w[NMAX];
+    if (ASPACE) {
+#pragma unroll
+        for (int d = 0; d < NMAX; ++d) w[d] = 0.0;
+    }
     if (lane < nr) {        // (not a lane-strided loop: its invariant L.M reads would be hoisted into ~500 VGPRs)
         const int r = lane;
-        double w[NMAX];
         const int rkind = L.kind[r];
         double *jr = L.J + (size_t)r * n;
         if (rkind >= 4) {   // a joint-limit row is written out first (one branch; a select per element cost a branch each)
@@ -1525,6 +1563,53 @@ __device__ __forceinline__ void wave_substep(const mg_walker_topology &tp, const
     //      The multipliers live in registers (lane r holds lambda_r; the current row's is fetched with v_readlane at a scalar
     //      index) and a friction row's partner is always the normal row swept just before it, whose new multiplier is carried
     //      along: no LDS read sits between the reduction and the update any more (two exposed LDS latencies per row).
+    //      Shape-generic instantiations with <= NRA rows (the A1: 12 contact rows + its joint limits, 23 iterations x 13
+    //      sub-steps) sweep in MULTIPLIER space instead (delassus_sweep): A = Jh Jh^T once (lane j keeps row j in registers, built
+    //      from its own whitened row and broadcast LDS reads of the others), g_j = Jh_j . y kept current by g += A[:, r] dlambda_r.
+    //      Every lane computes the projected change of ITS multiplier from per-lane data and row r's — whose g is current — is
+    //      taken: no reduction, no LDS, no branch on the row kind inside the sweep, and a dependent chain of four operations per row
+    //      (the velocity-space row: ~25). A wave runs this engine latency-bound — throughput follows the number of resident
+    //      waves, profiles/r04/walker_occupancy.txt — so the chain length is what counts: A1 2.04 -> 1.58 ms per env step.
+    //      Same iterates in exact arithmetic (different rounding); y receives sum_k Jh_k^T lambda_k once at the end.
+    const bool aspace = ASPACE && nr <= NRA;
+    if (ASPACE && nr > 0 && aspace) {
+        double a[NRA];
+#pragma unroll
+        for (int k = 0; k < NRA; ++k) {
+            a[k] = 0.0;
+            if (k < nr) {
+                const double *jk = L.J + (size_t)k * n;
+                double acc = 0.0;
+#pragma unroll
+                for (int d = 0; d < NMAX; ++d)
+                    if (d < n) acc += w[d] * jk[d];
+                a[k] = acc;
+            }
+        }
+        double g = 0.0;                                              // Jh_lane . y
+#pragma unroll
+        for (int d = 0; d < NMAX; ++d)
+            if (d < n) g += w[d] * lane_value(u_d, d);
+        const int nc3 = 3 * ncont;                                   // rows below: (normal, friction, friction) triplets; above: joint limits
+        const bool own = lane < nr;
+        const double idg_l = own ? L.diag[lane] : 0.0, bias_l = own ? L.bias[lane] : 0.0;
+        const bool fric_l = lane < nc3 && lane % 3 != 0;
+        const double c0 = fric_l ? 0.0 : bias_l * idg_l;             // d = (bias - g) idg: a friction row's target is zero (its bias slot is mu)
+        const double mu_l = fric_l ? bias_l : 0.0;
+        double lam = 0.0;
+        switch ((nr + 5) / 6) {             // sweep length = the row count rounded up to a multiple of six
+        case 1: delassus_sweep<6, NRA>(a, prm.solver_iterations, lane, fric_l, idg_l, c0, mu_l, g, lam); break;
+        case 2: delassus_sweep<12, NRA>(a, prm.solver_iterations, lane, fric_l, idg_l, c0, mu_l, g, lam); break;
+        case 3: delassus_sweep<18, NRA>(a, prm.solver_iterations, lane, fric_l, idg_l, c0, mu_l, g, lam); break;
+        default: delassus_sweep<NRA, NRA>(a, prm.solver_iterations, lane, fric_l, idg_l, c0, mu_l, g, lam); break;
+        case 4: delassus_sweep<24, NRA>(a, prm.solver_iterations, lane, fric_l, idg_l, c0, mu_l, g, lam); break;
+        }
+        for (int k = 0; k < nr; ++k) {                               // y += Jh^T lambda
+            const double lk = lane_value(lam, k);
+            if (lane < n) u_d += L.J[(size_t)k * n + lane] * lk;
+        }
+        if (own) L.lam[lane] = lam;                                  // (read by the foot-force block)
+    } else
     if (nr > 0) {
         double lamv = 0.0, lam_norm = 0.0;
         // one row: Jh_r . y by a wave reduction, the projected multiplier update, y += Jh_r^T dlambda
