@@ -1516,7 +1516,7 @@ __device__ __forceinline__ void wave_substep(const mg_walker_topology &tp, const
     static_assert(3 * W_MAXC + NJ <= WV, "one lane per constraint row");
     // (shape-generic instantiations: the whitened row stays in registers past this block — the Delassus sweep below builds its
     // matrix from it)
-    constexpr bool ASPACE = GENERIC;
+    constexpr bool ASPACE = true;
     constexpr int NRA = NMAX <= 18 ? 30 : 24;    // constraint rows the multiplier-space sweep keeps in registers (one row of A per lane)
     double w[NMAX];
     if (ASPACE) {
