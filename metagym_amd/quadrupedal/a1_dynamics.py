@@ -114,13 +114,13 @@ class A1Dynamics(object):
     # ---- the draws ---------------------------------------------------------------------------------------------------
     def draw(self):
         """One set per robot: dict name -> [N] or [N, k] float64 tensors (every robot draws; the caller keeps the masked ones)."""
-        if self.source is not None:
-            vals = self.source()
-            out = {}
+        if self.source is not None:       # injected draws: per name a scalar / [k] (the same for every robot) or [N] / [N, k]
+            vals, out = self.source(), {}
             for name, kind, a, b in RANGES:
+                k = len(a) if np.ndim(a) else 0
                 v = torch.as_tensor(np.asarray(vals[name], np.float64), **self._f64)
-                k = np.ndim(a) and len(a)
-                out[name] = v.expand(self.n, k).contiguous() if (k and v.dim() == 1) else (v.expand(self.n).contiguous() if not k and v.dim() == 0 else v)
+                want = (self.n, k) if k else (self.n,)
+                out[name] = v.expand(want).contiguous() if v.dim() <= (1 if k else 0) else v.reshape(want).contiguous()
             return out
         out = {}
         for name, kind, a, b in RANGES:
@@ -171,7 +171,7 @@ class A1Dynamics(object):
         mass, com, inertia = self.body_tables(v)
         self.physics.write_body_tables(mass, com, inertia, m)
         g = v["gravity"].clone()
-        g[:, 2] = g[:, 2] * self.gravity_sign if self.gravity_sign != 1.0 else g[:, 2]
+        g[:, 2] *= self.gravity_sign          # (+1: the reference's sign, drawn z in [8, 12] as it is)
         self.physics.write_gravity(g, m)
         self.physics.write_foot_friction(v["footfriction"], m)
         sel = lambda new, old: torch.where(m.reshape([-1] + [1] * (old.dim() - 1)), new, old)

@@ -152,3 +152,24 @@ def test_apply_only_touches_the_masked_robots():
     d2 = ad.A1Dynamics(ph2, seed=0, gravity_sign=-1.0)
     d2.apply(v, mask)
     assert torch.equal(ph2.gravity[:, 2], -v["gravity"][:, 2]) and torch.equal(ph2.gravity[:, :2], v["gravity"][:, :2])
+
+
+def test_injected_draws_replace_the_generator():
+    """`dynamics_source` (A1GymEnv) / `source` here: a callable returning the draws by name — scalars / [k] vectors for the whole batch
+    or [N] / [N, k] per robot — in place of the device generator (the `force_source` pattern)."""
+    m = _model()
+    n = 5
+    per_robot_kp = np.arange(n * 12, dtype=np.float64).reshape(n, 12) + 70.0
+    vals = dict(control_latency=0.04, footfriction=np.linspace(1.0, 2.0, n), basemass_ratio=1.1, baseinertia_ratio=[0.5, 1.5, 1.0],
+                legmass_ratio=[1.2, 1.3, 0.9], leginertia_ratio=np.linspace(0.9, 1.5, 12), motor_kp=per_robot_kp,
+                motor_kd=np.full(12, 2.0), gravity=[0.3, -0.2, 9.0])
+    ph = _Physics(m, n)
+    d = ad.A1Dynamics(ph, source=lambda: vals)
+    v = d.draw()
+    assert v["control_latency"].shape == (n,) and float(v["control_latency"][3]) == 0.04
+    assert torch.equal(v["footfriction"], torch.as_tensor(np.linspace(1.0, 2.0, n)))
+    assert v["baseinertia_ratio"].shape == (n, 3) and v["leginertia_ratio"].shape == (n, 12) and v["gravity"].shape == (n, 3)
+    assert torch.equal(v["motor_kp"], torch.as_tensor(per_robot_kp)) and float(v["motor_kd"][4, 7]) == 2.0
+    d.apply(v)
+    assert torch.equal(ph.mu, v["footfriction"]) and torch.equal(ph.gravity[2], torch.tensor([0.3, -0.2, 9.0], dtype=torch.float64))
+    assert torch.allclose(d.basemass, torch.full((n,), 1.1 * d.base_mass_nominal, dtype=torch.float64), rtol=1e-15, atol=0)
