@@ -673,21 +673,22 @@ template <int J>
 using ShapeDof = Shape<0, J, 0, 0, -1>;
 
 struct ModelW {   // one task's table row (layout: mg_walker_models in metagym_hip.h); offsets fold when the shape is constant
-    const double *p;
+    const double *p;          // the row in the model table (global memory)
+    const double *c;          // its body / joint constants: the same row (tuned kernels) or the launch's LDS copy (shape-generic ones)
     int nb, nj, ns, ng;
-    __device__ __forceinline__ const double *body_pos() const { return p; }
-    __device__ __forceinline__ const double *body_rot() const { return p + 3 * nb; }
-    __device__ __forceinline__ const double *body_mass() const { return p + 12 * nb; }
-    __device__ __forceinline__ const double *body_com() const { return p + 13 * nb; }
-    __device__ __forceinline__ const double *body_inertia() const { return p + 16 * nb; }
-    __device__ __forceinline__ const double *joint_anchor() const { return p + 25 * nb; }
-    __device__ __forceinline__ const double *joint_axis() const { return p + 25 * nb + 3 * nj; }
-    __device__ __forceinline__ const double *joint_lo() const { return p + 25 * nb + 6 * nj; }
-    __device__ __forceinline__ const double *joint_hi() const { return p + 25 * nb + 7 * nj; }
-    __device__ __forceinline__ const double *joint_arm() const { return p + 25 * nb + 8 * nj; }
-    __device__ __forceinline__ const double *joint_damp() const { return p + 25 * nb + 9 * nj; }
-    __device__ __forceinline__ const double *joint_stiff() const { return p + 25 * nb + 10 * nj; }
-    __device__ __forceinline__ const double *motor() const { return p + 25 * nb + 11 * nj; }
+    __device__ __forceinline__ const double *body_pos() const { return c; }
+    __device__ __forceinline__ const double *body_rot() const { return c + 3 * nb; }
+    __device__ __forceinline__ const double *body_mass() const { return c + 12 * nb; }
+    __device__ __forceinline__ const double *body_com() const { return c + 13 * nb; }
+    __device__ __forceinline__ const double *body_inertia() const { return c + 16 * nb; }
+    __device__ __forceinline__ const double *joint_anchor() const { return c + 25 * nb; }
+    __device__ __forceinline__ const double *joint_axis() const { return c + 25 * nb + 3 * nj; }
+    __device__ __forceinline__ const double *joint_lo() const { return c + 25 * nb + 6 * nj; }
+    __device__ __forceinline__ const double *joint_hi() const { return c + 25 * nb + 7 * nj; }
+    __device__ __forceinline__ const double *joint_arm() const { return c + 25 * nb + 8 * nj; }
+    __device__ __forceinline__ const double *joint_damp() const { return c + 25 * nb + 9 * nj; }
+    __device__ __forceinline__ const double *joint_stiff() const { return c + 25 * nb + 10 * nj; }
+    __device__ __forceinline__ const double *motor() const { return c + 25 * nb + 11 * nj; }
     __device__ __forceinline__ const double *sph_pos() const { return p + 25 * nb + 12 * nj; }
     __device__ __forceinline__ const double *sph_r() const { return p + 25 * nb + 12 * nj + 3 * ns; }
     __device__ __forceinline__ const double *geom_p0() const { return p + 25 * nb + 12 * nj + 4 * ns; }
@@ -814,6 +815,8 @@ __host__ __device__ inline size_t wave_lds_ints(int nb, int nj, int ns, int maxr
     return 6 * (size_t)nb + 2 * (size_t)ns + 2 * (size_t)maxr + 2 * W_MAXC + 8 + ND +
            (size_t)(rh + 1) * (nb + nj) + (size_t)jr * nj + nb;      // scan tables: hanc, hbody, janc, bjoint
 }
+// doubles of a model row that precede the collision proxies: body frames, masses, inertias, joint anchors / axes / limits / ...
+__host__ __device__ inline size_t wave_model_doubles(int nb, int nj) { return 25 * (size_t)nb + 12 * (size_t)nj; }
 // doubles of the Jh block the kinematics pass uses as scratch: one 3x4 transform per hop (then the velocity scans)
 __host__ __device__ inline size_t wave_scan_doubles(int nb, int nj) { return 12 * (size_t)(nb + nj); }
 // doubles of the Jh block the M / h assembly uses as scratch (composite tables; + the frames when overlaid)
@@ -1762,7 +1765,7 @@ __global__ __launch_bounds__(WV) __attribute__((amdgpu_waves_per_eu((NMAX <= 14 
     const int e = mg::env_of_block(blockIdx.x, n_envs), lane = threadIdx.x;
     const int nb = SH::nb ? SH::nb : tp.n_bodies, nj = SH::nj ? SH::nj : tp.n_joints, ns = SH::nb ? SH::ns : tp.n_spheres;
     const int nf = tp.n_feet, obs_dim = 8 + 2 * nj + nf;
-    const ModelW m{ms.table + (size_t)st.task_id[e] * ms.model_stride, nb, nj, ns, SH::nb ? SH::ng : tp.n_geoms};
+    const double *row = ms.table + (size_t)st.task_id[e] * ms.model_stride;
     // sign of the row-count argument: assembly scratch overlaid on Jh
     const bool overlay = SH::overlay >= 0 ? SH::overlay != 0 : maxr_flags < 0;
     const int maxr = SH::nb ? 3 * W_MAXC + SH::nj : (maxr_flags < 0 ? -maxr_flags : maxr_flags);
@@ -1774,7 +1777,18 @@ __global__ __launch_bounds__(WV) __attribute__((amdgpu_waves_per_eu((NMAX <= 14 
     unsigned char *slab = smem + slab_off;
     constexpr bool GENERIC = SH::nb == 0;      // shape-generic instantiation: terrain, > 64 proxies, per-proxy friction
     constexpr bool VELF = GENERIC || SH::damp != 0;     // frames keep v_ref: body velocity damping available
-    const WaveLds L = carve(slab, nb, nj, ns, maxr, overlay, VELF ? 15 : 12, scan_rounds & 0xff, scan_rounds >> 8);
+    const WaveLds L = carve(slab, nb, nj, ns, maxr, overlay, VELF ? 15 : 12, scan_rounds & 0xff, (scan_rounds >> 8) & 0xff);
+    // Shape-generic kernels of robots with up to 12 joints (the A1) copy the row's body / joint constants into LDS once per launch
+    // (behind the slab; its size arrives in the launch argument): every sub-step read them from global memory before — a wave runs
+    // latency-bound, and each of those loads was an exposed trip to L2. Worth 1 - 2.5 % of the A1's 13-sub-step launch; larger
+    // robots and the tuned kernels keep reading the table (their LDS decides how many envs fit a CU).
+    const double *mconst = row;
+    if (GENERIC && NMAX <= 18) {
+        double *mc = reinterpret_cast<double *>(slab + (size_t)(scan_rounds >> 16) * 16);
+        for (int i = lane; i < (int)wave_model_doubles(nb, nj); i += WV) mc[i] = row[i];
+        mconst = mc;
+    }
+    const ModelW m{row, mconst, nb, nj, ns, SH::nb ? SH::ng : tp.n_geoms};
     // topology-only tables, built once per launch, lane-parallel (lane = body / joint): a body's first joint and joint
     // count, the joints on its chain (mask), its subtree (kids), the body every generalized coordinate
     // sits on (dbody)
@@ -2181,8 +2195,16 @@ extern "C" int mg_walker_step(const mg_walker_topology *tp, const mg_walker_mode
                                  "mapping has %zu: use mapping = lane", wave_scan_doubles(tp->n_bodies, tp->n_joints),
                                  (size_t)maxr * ndof_of(tp) - (overlay ? fd * (size_t)tp->n_bodies : 0));
     }
-    const size_t lds = wave_lds_doubles(tp->n_bodies, tp->n_joints, maxr, overlay, fd) * sizeof(double) +
-                       wave_lds_ints(tp->n_bodies, tp->n_joints, tp->n_spheres, maxr, rh, jr) * sizeof(int);
+    size_t lds = wave_lds_doubles(tp->n_bodies, tp->n_joints, maxr, overlay, fd) * sizeof(double) +
+                 wave_lds_ints(tp->n_bodies, tp->n_joints, tp->n_spheres, maxr, rh, jr) * sizeof(int);
+    lds = (lds + 15) & ~size_t(15);
+    // shape-generic kernels of robots with <= 12 joints keep the body and joint constants of the env's model row in LDS for the whole
+    // launch (wave_model_doubles; the instantiations with NMAX <= 18)
+    const size_t lds_slab = lds;
+    if (!tuned && 6 + tp->n_joints <= 18) lds += wave_model_doubles(tp->n_bodies, tp->n_joints) * sizeof(double);
+#ifdef MG_WALKER_LDS_FLOOR      /* timing experiment only (scripts/walker_occupancy_probe.py): fewer resident envs per CU */
+    if (const char *fl = getenv("MG_WALKER_LDS_FLOOR")) { const size_t f = (size_t)atol(fl); if (f > lds && f <= 64 * 1024) lds = f; }
+#endif
     const int maxr_flags = overlay ? -maxr : maxr;
     if (lds > 160 * 1024) return mg::set_error(MG_ERR_BAD_SIZE, "walker needs %zu B of LDS", lds);
     if (lds > 64 * 1024) return mg::set_error(MG_ERR_BAD_SIZE, "walker needs %zu B of LDS (> 64 KiB)", lds);
@@ -2194,7 +2216,7 @@ extern "C" int mg_walker_step(const mg_walker_topology *tp, const mg_walker_mode
     auto is_shape = [&](int b, int j, int s, int g) { return tuned && shape_is(b, j, s, g); };
 #define MG_WALKER_LAUNCH(NMAX_, SHAPE_)                                                                                  \
     hipLaunchKernelGGL((walker_step_wave_kernel<NMAX_, SHAPE_>), dim3(n), dim3(WV), lds, (hipStream_t)stream, *tp, *ms, \
-                       *prm, *st, n, maxr_flags, rh | (jr << 8), action, obs, reward, rewards5, done)
+                       *prm, *st, n, maxr_flags, rh | (jr << 8) | ((int)(lds_slab / 16) << 16), action, obs, reward, rewards5, done)
     if (is_shape(Humanoid::nb, Humanoid::nj, Humanoid::ns, Humanoid::ng)) {
         if (damped) MG_WALKER_LAUNCH(23, HumanoidDamped);
         else MG_WALKER_LAUNCH(23, Humanoid);
