@@ -126,7 +126,18 @@ def cpu_port(seconds=12.0, n_envs_per_thread=256, max_threads=None):
 
 
 def reference_root():
-    return os.environ.get("METAGYM_REFERENCE", "/root/reference")
+    """Where the unmodified reference can be imported from: $METAGYM_REFERENCE, else oracle/_ref — the byte-compiled
+    reference packages oracle/make_ref.py builds in the build container (git-ignored; it travels to the GPU box with the
+    snapshot like the built .so files; bench.py never reads /root/reference at run time)."""
+    env = os.environ.get("METAGYM_REFERENCE")
+    if env:
+        return env
+    return os.path.join(ROOT, "oracle", "_ref")
+
+
+def _reference_has(ref, pkg):
+    d = os.path.join(ref, "metagym", pkg)
+    return os.path.isfile(os.path.join(d, "__init__.py")) or os.path.isfile(os.path.join(d, "__init__.pyc"))
 
 
 def _reference_worker(args):
@@ -167,9 +178,10 @@ def cpu_reference(seconds=12.0):
     SURVEY.md §8d C2). Only possible where the reference tree exists (the build container; the GPU box has no
     /root/reference and bench.py may not read it there): returns (result, None) or (None, reason)."""
     ref = reference_root()
-    if not os.path.isdir(os.path.join(ref, "metagym", "quadrotor")):
-        return None, ("no reference tree at %s on this machine (it is not shipped to the GPU box); the figure recorded "
-                      "in the build container is under from_profiles.reference_cpu" % ref)
+    if not _reference_has(ref, "quadrotor"):
+        return None, ("no importable reference at %s (oracle/make_ref.py builds it in the build container; "
+                      "__graft_entry__.build() calls it); the figure recorded in the build container is under "
+                      "from_profiles.reference_cpu" % ref)
     cores = usable_cpus()
     try:
         ctx = multiprocessing.get_context("fork")
@@ -181,8 +193,59 @@ def cpu_reference(seconds=12.0):
     wall = max(r[1] for r in res)
     return {"value": steps / wall, "unit": "env-steps/s", "cores": cores, "kind": "reference",
             "per_core": steps / wall / cores,
-            "sample": "%d env-steps, %d single-env workers of the unmodified metagym.quadrotor.env.Quadrotor "
-                      "(hovering_control, numpy %s, gym stubbed), %.1f s each" % (steps, cores, np.__version__, wall)}, None
+            "source": ("oracle/_ref (byte-code of the unmodified reference, oracle/make_ref.py)"
+                       if os.path.abspath(ref) == os.path.join(ROOT, "oracle", "_ref") else ref),
+            "sample": "%d env-steps, %d single-env workers (multiprocessing.Pool) of the unmodified "
+                      "metagym.quadrotor.env.Quadrotor.step (hovering_control, dt=0.01, nt=1000, U(0.1,15) actions, finished "
+                      "episodes reset; numpy %s, gym stubbed), %.1f s each" % (steps, cores, np.__version__, wall)}, None
+
+
+def _reference_maze_worker(args):
+    """One single-env worker of the unmodified MetaMazeDiscrete3D (maze_discrete_3d.py:44-126 through oracle/refstubs:
+    numba is not installed, so this is the un-jitted Python the stub runs — "for the record")."""
+    idx, ref, seconds, res = args
+    sys.path.insert(0, os.path.join(ROOT, "oracle", "refstubs"))
+    sys.path.insert(0, ref)
+    np.int = int
+    np.product = np.prod                # maze_task.py:101 uses the removed alias
+    import random
+    import gym
+    import metagym.metamaze  # noqa: F401
+    from metagym.metamaze import MazeTaskSampler
+    random.seed(idx)
+    np.random.seed(idx)
+    env = gym.make("meta-maze-discrete-3D-v0", enable_render=False, task_type="SURVIVAL", max_steps=200,
+                   resolution=(res, res))
+    env.set_task(MazeTaskSampler(n=9, allow_loops=False, step_reward=-0.01, goal_reward=1.0, food_density=0.06,
+                                 food_interval=20))
+    env.reset()
+    rs = np.random.RandomState(idx)
+    n = 0
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < seconds:
+        if env.step(int(rs.randint(4)))[2]:
+            env.reset()
+        n += 1
+    return n, time.perf_counter() - t0
+
+
+def cpu_reference_maze3d(seconds=5.0, res=256):
+    """C3 "for the record": the unmodified reference MetaMazeDiscrete3D.step (+ its 256x256 frame) on every host core.
+    numba is absent, so the ray caster runs un-jitted — this is NOT what a user of the reference with numba would see."""
+    ref = reference_root()
+    if not _reference_has(ref, "metamaze"):
+        return None
+    cores = usable_cpus()
+    try:
+        ctx = multiprocessing.get_context("fork")
+        with ctx.Pool(cores) as pool:
+            out = pool.map(_reference_maze_worker, [(i, ref, seconds, res) for i in range(cores)])
+    except Exception as e:
+        return {"error": repr(e)}
+    steps, wall = sum(r[0] for r in out), max(r[1] for r in out)
+    return {"value": steps / wall, "unit": "env-steps/s", "cores": cores, "kind": "reference (numba absent: un-jitted Python)",
+            "sample": "%d steps + %dx%d frames, %d single-env workers of the unmodified MetaMazeDiscrete3D, %.1f s each"
+                      % (steps, res, res, cores, wall)}
 
 
 def cpu_baseline_maze3d(seconds=4.0, res=256):
@@ -1093,6 +1156,10 @@ def main(argv=None):
                         sec[key]["cpu_baseline"] = fn()
                     except Exception as e:
                         sec[key]["cpu_baseline_error"] = repr(e)
+            if "C3_maze3d_discrete_9x9_256x256_16384envs" in sec:
+                r3 = cpu_reference_maze3d()
+                if r3 is not None:
+                    sec["C3_maze3d_discrete_9x9_256x256_16384envs"]["cpu_reference_unjitted"] = r3
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.destroy_process_group()

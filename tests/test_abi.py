@@ -86,6 +86,9 @@ def test_product_never_imports_the_oracle():
                 src = open(os.path.join(dirpath, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), f
                 assert "libmetagym_oracle" not in src, f
+                # oracle/_ref (the byte-compiled reference, oracle/make_ref.py) is for bench.py's cpu_baseline leg only
+                assert "_ref" + os.sep not in src and "oracle/_ref" not in src and "make_ref" not in src, f
+                assert not re.search(r"^\s*(from|import)\s+metagym\b", src, flags=re.M), f
 
 
 def test_integration_stub_structs_match_the_abi():
