@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define MG_ABI_VERSION 5
+#define MG_ABI_VERSION 6
 
 #define MG_OK 0
 #define MG_ERR_NULL_POINTER (-1001)
@@ -291,8 +291,19 @@ typedef struct mg_maze_view {
                                       of one sampler configuration do). The library then evaluates the renderer's power-of-two
                                       conditions once, on the host, and runs its specialised kernel when they all hold (cell size,
                                       texture size and resolution powers of two, int32 frames: the stock set-up) — same frames bit
-                                      for bit. 0: unknown, the general kernel decides per env. A wrong value gives wrong frames. */
+                                      for bit. 0: unknown, the general kernel decides per env. (ABI 6) The promise is CHECKED, not trusted:
+                                      see mg_maze_check_uniform_cell_size — a wrong value is MG_ERR_BAD_CONFIG, never wrong frames. */
 } mg_maze_view;
+
+/* (ABI 6) Check mg_maze_view.uniform_cell_size against a task table: reads the table's [T][8] scalar rows back to the host
+ * (T * 64 bytes; SYNCHRONOUS on `stream` — a set_task-time call, not a step-time one) and compares every task's cell_size
+ * (TaskConfig.cell_size, maze_task.py:15-17) with `uniform_cell_size`. MG_OK: the pair (tasks->scalars, value) is remembered
+ * and mg_maze3d_step accepts it without looking again. MG_ERR_BAD_CONFIG: some task differs (mg_last_error names it).
+ * mg_maze3d_step runs this check itself the first time it meets an unchecked (table, value) pair — one stream
+ * synchronisation, once — and refuses an unchecked pair under stream capture (where it cannot synchronise). A caller that
+ * rewrites a checked table IN PLACE must call this again (an explicit call always re-reads). `tasks->scalars` may be a host
+ * pointer (then it is read directly). */
+int mg_maze_check_uniform_cell_size(const mg_maze_tasks *tasks, double uniform_cell_size, void *stream);
 
 /* Host helper: the per-column tables of ray_caster_utils.py:82-90 (tan_hp accumulated column by
  * column exactly like the reference loop). Writes res_h doubles to each HOST array; the caller

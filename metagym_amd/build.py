@@ -39,20 +39,52 @@ def is_stale():
     return any(os.path.getmtime(d) > t for d in _deps())
 
 
-def build(force=False, verbose=True):
-    """Compile in-tree. Safe when several ranks of one job import the package at once: the build is
-    serialised by a file lock, re-checked under the lock, and the library appears by atomic rename."""
-    if not force and not is_stale():
+OBJ_DIR = os.path.join(LIB_DIR, "obj")
+COMPILE_FLAGS = [f for f in FLAGS if f != "-shared"]
+
+
+def _headers():
+    return [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")] + \
+        [os.path.join(os.path.dirname(HERE), "include", "metagym_hip.h"), os.path.abspath(__file__)]
+
+
+def _object_of(src):
+    return os.path.join(OBJ_DIR, os.path.basename(src)[:-4] + ".o")
+
+
+def build(force=False, verbose=True, extra_flags=()):
+    """Compile in-tree: one object per .hip (only the stale ones, in parallel — walker.hip alone is minutes), then one link.
+    Safe when several ranks of one job import the package at once: the build is serialised by a file lock, re-checked
+    under the lock, and the library appears by atomic rename. `extra_flags` (experiments: -D knock-outs) force a rebuild."""
+    if not force and not extra_flags and not is_stale():
         return LIB_PATH
     import fcntl
-    os.makedirs(LIB_DIR, exist_ok=True)
+    os.makedirs(OBJ_DIR, exist_ok=True)
     with open(os.path.join(LIB_DIR, ".build.lock"), "w") as lock:
         fcntl.flock(lock, fcntl.LOCK_EX)
         try:
-            if not force and not is_stale():      # another process built it while we waited
+            if not force and not extra_flags and not is_stale():      # another process built it while we waited
                 return LIB_PATH
+            hdr_t = max(os.path.getmtime(h) for h in _headers())
+            flags_file = os.path.join(OBJ_DIR, "flags.txt")
+            flags_now = " ".join(COMPILE_FLAGS + list(extra_flags))
+            same_flags = os.path.exists(flags_file) and open(flags_file).read() == flags_now
+            jobs = []
+            for src in sources():
+                obj = _object_of(src)
+                if force or not same_flags or not os.path.exists(obj) or \
+                        os.path.getmtime(obj) < max(os.path.getmtime(src), hdr_t):
+                    cmd = [HIPCC] + COMPILE_FLAGS + list(extra_flags) + ["-c", src, "-o", obj]
+                    if verbose:
+                        print(" ".join(cmd), flush=True)
+                    jobs.append((cmd, subprocess.Popen(cmd)))
+            for cmd, proc in jobs:
+                if proc.wait() != 0:
+                    raise subprocess.CalledProcessError(proc.returncode, cmd)
+            with open(flags_file, "w") as f:
+                f.write(flags_now)
             tmp = LIB_PATH + ".tmp.%d" % os.getpid()
-            cmd = [HIPCC] + FLAGS + sources() + ["-o", tmp]
+            cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC"] + [_object_of(x) for x in sources()] + ["-o", tmp]
             if verbose:
                 print(" ".join(cmd), flush=True)
             subprocess.check_call(cmd)

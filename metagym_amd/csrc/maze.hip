@@ -31,6 +31,8 @@
 #include <cstring>
 
 #include <atomic>
+#include <mutex>
+#include <vector>
 
 #include "mg_common.h"
 
@@ -1070,6 +1072,59 @@ extern "C" int mg_maze2d_step(const mg_maze_tasks *T, int32_t task_type, int32_t
     return mg::check_launch("maze2d_step_kernel");
 }
 
+// ---- mg_maze_view.uniform_cell_size is a promise about the task table; a wrong one would render wrong frames. The library
+// checks it once per (scalars pointer, n_tasks, value): the [T][8] scalar rows are read back (T * 64 bytes) and every
+// cell_size compared. Validated triples are remembered in a small process-wide table (mutex; 32 entries, oldest replaced).
+namespace {
+struct UniformEntry { const void *scalars; int n_tasks; double cs; };
+std::mutex g_uniform_mu;
+UniformEntry g_uniform[32];
+int g_uniform_n = 0, g_uniform_next = 0;
+
+bool uniform_cache_has(const void *scalars, int n_tasks, double cs) {
+    std::lock_guard<std::mutex> lk(g_uniform_mu);
+    for (int i = 0; i < g_uniform_n; ++i)
+        if (g_uniform[i].scalars == scalars && g_uniform[i].n_tasks == n_tasks && g_uniform[i].cs == cs) return true;
+    return false;
+}
+void uniform_cache_drop(const void *scalars) {
+    std::lock_guard<std::mutex> lk(g_uniform_mu);
+    for (int i = 0; i < g_uniform_n; ++i)
+        if (g_uniform[i].scalars == scalars) g_uniform[i] = UniformEntry{nullptr, 0, 0.0};
+}
+void uniform_cache_put(const void *scalars, int n_tasks, double cs) {
+    std::lock_guard<std::mutex> lk(g_uniform_mu);
+    for (int i = 0; i < g_uniform_n; ++i)
+        if (g_uniform[i].scalars == scalars) { g_uniform[i] = UniformEntry{scalars, n_tasks, cs}; return; }
+    const int slot = g_uniform_n < 32 ? g_uniform_n++ : (g_uniform_next++ & 31);
+    g_uniform[slot] = UniformEntry{scalars, n_tasks, cs};
+}
+}  // namespace
+
+extern "C" int mg_maze_check_uniform_cell_size(const mg_maze_tasks *T, double uniform_cell_size, void *stream) {
+    MG_REQUIRE_PTR(T);
+    MG_REQUIRE_PTR(T->scalars);
+    if (T->n_tasks <= 0) return mg::set_error(MG_ERR_BAD_SIZE, "n_tasks = %d", T->n_tasks);
+    if (!(uniform_cell_size > 0.0)) return mg::set_error(MG_ERR_BAD_CONFIG, "uniform_cell_size = %.17g is not a cell size", uniform_cell_size);
+    uniform_cache_drop(T->scalars);                     // an explicit call always re-reads the table
+    std::vector<double> rows((size_t)T->n_tasks * 8);
+    const int device = mg::device_of(T->scalars);
+    if (device >= 0) {
+        mg::DeviceGuard guard(device);
+        if (int rc = mg::check_hip(hipMemcpyAsync(rows.data(), T->scalars, rows.size() * sizeof(double), hipMemcpyDeviceToHost,
+                                                  (hipStream_t)stream), "hipMemcpyAsync(task scalars)")) return rc;
+        if (int rc = mg::check_hip(hipStreamSynchronize((hipStream_t)stream), "hipStreamSynchronize(task scalars)")) return rc;
+    } else {
+        memcpy(rows.data(), T->scalars, rows.size() * sizeof(double));      // a host table (CPU-side callers, tests)
+    }
+    for (int t = 0; t < T->n_tasks; ++t)
+        if (rows[(size_t)t * 8] != uniform_cell_size)
+            return mg::set_error(MG_ERR_BAD_CONFIG, "mg_maze_view.uniform_cell_size = %.17g but task %d of %d has cell_size %.17g: pass 0 "
+                                 "(tasks differ) or the table's one cell size", uniform_cell_size, t, T->n_tasks, rows[(size_t)t * 8]);
+    uniform_cache_put(T->scalars, T->n_tasks, uniform_cell_size);
+    return MG_OK;
+}
+
 extern "C" int mg_maze3d_step(const mg_maze_tasks *T, const mg_maze_view *view, int32_t task_type, int32_t max_steps,
                               int32_t continuous, int32_t auto_reset, int32_t n, const mg_maze_state *st,
                               const void *action, void *obs, float *reward, double *reward64, uint8_t *done,
@@ -1091,6 +1146,18 @@ extern "C" int mg_maze3d_step(const mg_maze_tasks *T, const mg_maze_view *view, 
     if (!view->col_cos || !view->col_sin || !view->textures || !view->ceil_texture)
         return mg::set_error(MG_ERR_NULL_POINTER, "mg_maze_view has a NULL table");
     if (view->tex_size <= 0 || view->n_textures <= 0) return mg::set_error(MG_ERR_BAD_SIZE, "texture table");
+    if (view->uniform_cell_size > 0.0) {
+        // Before anything is launched: the promise is checked, not trusted: once per (table, value) — see mg_maze_check_uniform_cell_size.
+        if (!uniform_cache_has(T->scalars, T->n_tasks, view->uniform_cell_size)) {
+            hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+            if (hipStreamIsCapturing((hipStream_t)stream, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone)
+                return mg::set_error(MG_ERR_BAD_CONFIG, "mg_maze3d_step under stream capture with an unchecked mg_maze_view.uniform_cell_size "
+                                     "= %.17g: call mg_maze_check_uniform_cell_size() on this task table before capturing",
+                                     view->uniform_cell_size);
+            (void)hipGetLastError();
+            if (int rc = mg_maze_check_uniform_cell_size(T, view->uniform_cell_size, stream)) return rc;
+        }
+    }
 
     ViewK vk;
     vk.H = view->res_h;
@@ -1188,7 +1255,9 @@ extern "C" int mg_maze3d_step(const mg_maze_tasks *T, const mg_maze_view *view, 
     // (mg_maze_view.uniform_cell_size) and every flag the general kernel would evaluate per env comes out "power of two, integer
     // texel addressing" — evaluated here exactly as the kernel evaluates them.
     bool stock = false;
-    if (view->uniform_cell_size > 0.0 && !vk.obs_u8 && getenv("MG_MAZE3D_GENERIC") == nullptr) {
+    // the ABI is re-entrant — the environment is read once, not on every step
+    static const bool force_generic = getenv("MG_MAZE3D_GENERIC") != nullptr;
+    if (view->uniform_cell_size > 0.0 && !vk.obs_u8 && !force_generic) {
         const double cs = view->uniform_cell_size, ttc = vk.text_size / cs, inv_ttc = 1.0 / ttc;
         int e2;
         stock = frexp(cs, &e2) == 0.5 && frexp(ttc, &e2) == 0.5 && vk.text_size_pow2 && (vk.TS & (vk.TS - 1)) == 0 && inv_ttc >= 1.0 &&

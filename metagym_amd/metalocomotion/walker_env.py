@@ -259,6 +259,13 @@ class WalkerBatchEnv(object):
         sd["floor_known"] = self._floor_known.clone()      # which envs' robot.parts already hold the floor link
         sd["global_step"] = int(self.global_step)
         sd["np_random"] = self.np_random.get_state()
+        # static terrain: the shared box list, or the per-robot course table with every robot's course index (a
+        # checkpoint taken on a terrain table used to resume every robot on course 0 of an empty table)
+        tab = getattr(self, "_terrain_t", None)
+        if tab is not None and tab.dim() == 3:
+            sd["terrain_table"], sd["terrain_id"] = tab.clone(), self.terrain_id.clone()
+        elif tab is not None:
+            sd["terrain_boxes"] = tab.clone()
         return sd
 
     def load_state_dict(self, sd):
@@ -272,6 +279,27 @@ class WalkerBatchEnv(object):
         if "floor_known" in sd:
             self._floor_known.copy_(torch.as_tensor(sd["floor_known"]).to(self.device))
             self._all_floor_known = bool(self._floor_known.all())     # (load time, not on the step path)
+            # the host bitmap of host-masked resets follows the checkpoint too: a stale all-True one would switch the remaining
+            # envs' FIRST reset to floor_in_parts = 1
+            self._floor_known_host = self._floor_known.cpu().numpy().astype(bool).copy()
+            self._masked_first_resets = 0
+        if "terrain_table" in sd:
+            src = torch.as_tensor(sd["terrain_table"])
+            tab = getattr(self, "_terrain_t", None)
+            if tab is None or tab.dim() != 3 or tuple(tab.shape) != tuple(src.shape):
+                self.set_terrain_table(src.shape[0], src.shape[1], terrain_id=getattr(self, "terrain_id", None))
+            self._terrain_t.copy_(src.to(self.device))
+            self.terrain_id.copy_(torch.as_tensor(sd["terrain_id"]).to(self.device))
+        elif "terrain_boxes" in sd:
+            src = torch.as_tensor(sd["terrain_boxes"]).to(self.device)
+            tab = getattr(self, "_terrain_t", None)
+            if tab is not None and tab.dim() == 2 and tuple(tab.shape) == tuple(src.shape):
+                tab.copy_(src)
+            else:                                   # boxes this env was not constructed with: install the checkpoint's rows
+                p = self._params_c
+                self._terrain_spec, self._terrain_t = None, src.contiguous().clone()
+                p.terrain_id, p.n_terrain_tables = None, 0
+                p.n_terrain_boxes, p.terrain = int(src.shape[0]), self._terrain_t.data_ptr()
         if "global_step" in sd:
             self.global_step = int(sd["global_step"])
         if "np_random" in sd:

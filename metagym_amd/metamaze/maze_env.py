@@ -117,13 +117,20 @@ class _MazeBatch(object):
             slot = torch.where(tt_food != 0.0, torch.full((T, nn), -2, dtype=torch.int16, device=dev),
                                torch.full((T, nn), -1, dtype=torch.int16, device=dev))
             ks = torch.arange(max_food, device=dev, dtype=torch.int16).unsqueeze(0).expand(T, max_food)
-            slot.scatter_(1, order, torch.where(listed, ks, torch.full_like(ks, -1)))      # (a row of `order` holds distinct cells)
+            # only the LISTED entries of a row are written: a task with n_food < max_food has non-food cells in the tail of its
+            # `order` row, and those keep their -1 / -2 (a -1 there would hide a nonzero crumb from the observation)
+            slot.scatter_(1, order, torch.where(listed, ks, slot.gather(1, order)))        # (a row of `order` holds distinct cells)
             self._cell_slot_t = slot.contiguous()
             self._slot_food_t = torch.gather(tt_food, 1, order).t().contiguous()
             self._slot_interval_t = torch.gather(tt_int, 1, order).t().contiguous()
             c.cell_slot, c.slot_food, c.slot_interval = (self._cell_slot_t.data_ptr(), self._slot_food_t.data_ptr(),
                                                          self._slot_interval_t.data_ptr())
         self._tasks_c = c
+        if self._uniform_cell_size > 0.0:
+            # the promise mg_maze_view.uniform_cell_size makes about THIS table, checked by the library against the uploaded
+            # cell_size column (synchronous, once per set_task; a hipGraph capture of step() later finds the pair checked)
+            _lib.check(self._lib.mg_maze_check_uniform_cell_size(c, self._uniform_cell_size, _lib.current_stream(dev)),
+                       "mg_maze_check_uniform_cell_size")
         if task_ids is None:
             task_ids = torch.arange(N, dtype=torch.int32) % T
         self.task_id = torch.as_tensor(task_ids, dtype=torch.int32).to(dev).contiguous()

@@ -121,7 +121,7 @@ class A1Dynamics(object):
                 v = torch.as_tensor(np.asarray(vals[name], np.float64), **self._f64)
                 want = (self.n, k) if k else (self.n,)
                 out[name] = v.expand(want).contiguous() if v.dim() <= (1 if k else 0) else v.reshape(want).contiguous()
-            return out
+            return self._signed(out)
         out = {}
         for name, kind, a, b in RANGES:
             k = len(a) if np.ndim(a) else 0
@@ -131,7 +131,18 @@ class A1Dynamics(object):
                 out[name] = lo + (hi - lo) * torch.rand(shape, generator=self.gen, **self._f64)
             else:                                                           # np.random.normal(mean, std)
                 out[name] = lo + hi * torch.randn(shape, generator=self.gen, **self._f64)
-        return out
+        return self._signed(out)
+
+    def _signed(self, drawn):
+        """`gravity_sign` acts on DRAWN sets only (the z in [8, 12] that locomotion_gym_env.py:406-407 hands to setGravity as it
+        is): +1 keeps the reference's upward gravity, -1 turns it down. A set from fixed() / dynamic_param already says which way
+        its gravity points (default (0, 0, -10)) and is installed unchanged — ADVICE r4: apply() used to flip those too, so
+        gravity_sign=-1 with per-link dynamic_param made robots fall upward."""
+        if self.gravity_sign != 1.0:
+            g = drawn["gravity"].clone()
+            g[:, 2] *= self.gravity_sign
+            drawn["gravity"] = g
+        return drawn
 
     def fixed(self, control_latency=None, footfriction=1.0, basemass=1.0, baseinertia=(1.0, 1.0, 1.0), legmass=(1.0, 1.0, 1.0),
               leginertia=(1.0,) * 12, motor_kp=None, motor_kd=None, gravity=(0.0, 0.0, -10.0)):
@@ -170,9 +181,7 @@ class A1Dynamics(object):
         m = torch.ones(N, dtype=torch.bool, device=self.device) if mask is None else torch.as_tensor(mask, device=self.device).bool()
         mass, com, inertia = self.body_tables(v)
         self.physics.write_body_tables(mass, com, inertia, m)
-        g = v["gravity"].clone()
-        g[:, 2] *= self.gravity_sign          # (+1: the reference's sign, drawn z in [8, 12] as it is)
-        self.physics.write_gravity(g, m)
+        self.physics.write_gravity(v["gravity"], m)       # as given: draw() has applied gravity_sign, fixed() sets never get it
         self.physics.write_foot_friction(v["footfriction"], m)
         sel = lambda new, old: torch.where(m.reshape([-1] + [1] * (old.dim() - 1)), new, old)
         if v.get("control_latency") is not None:

@@ -37,7 +37,7 @@ import torch
 from .. import _lib
 from .a1_actuators import A1Actuators, MotorControlMode
 from .a1_wrappers import EtgActionPath, Param_Dict, RewardShaping, SensorStack
-from .terrain import task_terrain, upstair_terrain
+from .terrain import TASK_NAMES, task_terrain, upstair_terrain
 from ..spaces import Box
 
 
@@ -53,6 +53,11 @@ _ACTION_BOXES = {0: ([0.2, 0.7, 0.7] * 4, [-0.2, -0.7, -0.7] * 4),
                  1: ([0.1, 0.5, 0.4] * 4, [-0.1, -0.3, -0.6] * 4),
                  2: ([0.1, 0.5, 0.4, 0.1, 0.5, 0.4] + [0.1] * 6, [-0.1, -0.3, -0.6, -0.1, -0.3, -0.6] + [-0.1] * 6),
                  3: ([0.1, 0.7, 0.7, 0.1, 0.7, 0.7] + [0.1] * 6, [-0.1, -0.7, -0.7, -0.1, -0.7, -0.7] + [-0.1] * 6)}
+
+
+def _env_info_copy(env_info):
+    """info["env_info"]: a list of [x0, x1, env_vec[7]] (locomotion_gym_env.py:76) — copied so a checkpoint does not alias it."""
+    return [[float(x0), float(x1), np.array(vec, dtype=np.float64, copy=True)] for x0, x1, vec in env_info]
 
 
 class A1GymEnv(object):
@@ -80,6 +85,15 @@ class A1GymEnv(object):
             raise _lib.MetaGymHipError("on_rack=True (the robot hung from a fixed constraint, minitaur.py:411-413) is not built")
         if gait != 0:
             raise _lib.MetaGymHipError("gait=%r: GaitGeneratorWrapperEnv (env_builder.py:92-94) is not built; gait=0 is the reference's default" % (gait,))
+        if task == "heightfield":
+            # locomotion_gym_env.py:97-98,160-164: HeightField(2)._generate_field = GEOM_HEIGHTFIELD from
+            # "heightmaps/wm_height_out.png" (envs/utilities/heightfield.py:35-37,89-104, mesh scale .05/.05/1.8, friction 5),
+            # a pybullet_data asset that is in neither tree; the engine's terrain path takes boxes only. Accepting the name and
+            # running on flat ground (what this class did until round 4) is a silent wrong answer: refused like gait / on_rack.
+            raise NotImplementedError(
+                "task='heightfield': the reference builds a PyBullet GEOM_HEIGHTFIELD from pybullet_data's "
+                "heightmaps/wm_height_out.png (envs/utilities/heightfield.py:89-104); neither the asset nor a height-field narrow "
+                "phase exists here — use one of the box courses (%s) or 'plane'" % ", ".join(sorted(TASK_NAMES)))
         self.action_limit, self.step_y, self.ignored_kwargs = tuple(action_limit), float(step_y), dict(kwargs)
         # ---- dynamics: handed in explicitly (`dynamic_param`, locomotion_gym_env.py:349-380) or redrawn per robot at every reset
         #      (`random_dynamic`, :381-405; a1_dynamics.py) ---------------------------------------------------------------------
@@ -634,6 +648,8 @@ class A1GymEnv(object):
             graph.register_generator_state(self.sensors.noise_gen)
         if self.random_dynamic and self.auto_reset and self.dynamics.source is None:      # ... and so does the dynamics' one
             graph.register_generator_state(self.dynamics.gen)
+        if self._x_noise_any and self._x_noise_source is None:      # reset(x_noise=True): add_x is drawn inside a reset the step performs
+            graph.register_generator_state(self._x_gen)             # (an unregistered generator under capture raises or freezes)
         robot, repeat = self.robot, 13
         host_mirror = (robot._step_counter, robot._last_action)
         with torch.cuda.graph(graph):
@@ -675,6 +691,22 @@ class A1GymEnv(object):
             sd["obs_history"] = self._obs_history.clone()
         if hasattr(self.physics, "state_dict"):
             sd["physics"] = self.physics.state_dict()
+        # ---- what reset(**kwargs) / configure_reset() left behind (none of this used to be saved, so a checkpoint
+        #      taken after hardset terrains, yaw, x_noise or new ETG parameters resumed on course 0 with the default pose) ----
+        course = dict(add_height=self.add_height, env_info=_env_info_copy(self.env_info), default_pose=list(self.default_pose),
+                      first_reset=self._first_reset)
+        if self.terrain_slots > 1:       # (the engine's box table and terrain_id travel with the physics' state)
+            course.update(seg_table=self._seg_table.clone(), seg_count=self._seg_count.clone(), add_height_t=self._add_height_t.clone(),
+                          courses={k: (h, _env_info_copy(info)) for k, (h, info) in self._courses.items()},
+                          terrain_id=self.terrain_id.clone())
+        else:
+            c = self.shaping._cfg
+            course.update(segments=[[float(x) for x in c.seg[i]] for i in range(c.n_segments)],
+                          boxes=[(list(map(float, h)), list(map(float, p)), list(map(float, q)), float(f)) for h, p, q, f in self.terrain_boxes])
+        sd["course"] = course
+        sd["start"] = dict(yaw=self._yaw_init.clone(), x_noise=self._x_noise.clone(), x_noise_any=self._x_noise_any,
+                           pose_dirty=self._pose_dirty, x_rng=self._x_gen.get_state())
+        sd["etg_parameters"] = dict(w=self.path.etg_w(), b=self.path.etg_b())
         return sd
 
     def load_state_dict(self, sd):
@@ -710,6 +742,37 @@ class A1GymEnv(object):
             self._dyn_hold.copy_(f["hold"])
             self._dyn_override_seen = bool(f["override_seen"])
             self._push_dynamics()
+        if "etg_parameters" in sd:
+            self.path.set_etg_parameters(sd["etg_parameters"]["w"], sd["etg_parameters"]["b"])
+        if "start" in sd:
+            st = sd["start"]
+            self._yaw_init.copy_(st["yaw"])
+            self._x_noise.copy_(st["x_noise"])
+            self._x_noise_any, self._pose_dirty = bool(st["x_noise_any"]), bool(st["pose_dirty"])
+            self._x_gen.set_state(st["x_rng"])
+        if "course" in sd:
+            co = sd["course"]
+            self.add_height, self.env_info = co["add_height"], _env_info_copy(co["env_info"])
+            self.default_pose, self._first_reset = list(co["default_pose"]), bool(co["first_reset"])
+            if self.terrain_slots > 1:
+                if "seg_table" not in co:
+                    raise ValueError("the checkpoint was taken with terrain_slots = 1, this env has a terrain table")
+                self._seg_table.copy_(co["seg_table"])
+                self._seg_count.copy_(co["seg_count"])
+                self._add_height_t.copy_(co["add_height_t"])
+                self._courses = {int(k): (h, _env_info_copy(info)) for k, (h, info) in co["courses"].items()}
+                self.terrain_id.copy_(co["terrain_id"])       # (also restored by the physics when it is A1Physics: the same tensor)
+            else:
+                if "segments" not in co:
+                    raise ValueError("the checkpoint was taken with a terrain table, this env has terrain_slots = 1")
+                c = self.shaping._cfg
+                c.n_segments = len(co["segments"])
+                for i, row in enumerate(co["segments"]):
+                    c.seg[i][:] = list(row)
+                self.terrain_boxes = list(co["boxes"])
+                # (the engine's boxes came back with the physics' state; a physics without state_dict gets them here)
+                if hasattr(self.physics, "set_terrain") and not ("physics" in sd and hasattr(self.physics, "load_state_dict")):
+                    self.physics.set_terrain(self.terrain_boxes, self.default_pose)
 
     def _begin_partial_reset(self, m):
         """The first half of A1GymEnv.reset() for the robots in `m` only (device bool `[N]`), everyone else untouched: robot

@@ -259,6 +259,9 @@ class A1Physics(object):
         sd = self.env.state_dict()
         if getattr(self, "per_robot", False):       # the robots' own bodies and worlds are part of the state
             sd["per_robot"] = dict(table=self.env._table.clone(), gravity=self.gravity_env.clone(), foot_friction=self.foot_friction_env.clone())
+        # where the next reset places each robot (reset(yaw=, x_noise=), per-course start heights): the engine's reset_pos /
+        # reset_rot buffers are derived from these two
+        sd["reset_pose"] = dict(pose=self._pose.clone(), yaw=self._yaw.clone())
         return sd
 
     def load_state_dict(self, sd):
@@ -267,7 +270,11 @@ class A1Physics(object):
             self.env._table.copy_(sd["per_robot"]["table"])
             self.gravity_env.copy_(sd["per_robot"]["gravity"])
             self.foot_friction_env.copy_(sd["per_robot"]["foot_friction"])
-        self.env.load_state_dict({k: v for k, v in sd.items() if k != "per_robot"})
+        if "reset_pose" in sd:
+            self._pose.copy_(sd["reset_pose"]["pose"])
+            self._yaw.copy_(sd["reset_pose"]["yaw"])
+            self._derive_reset_state()
+        self.env.load_state_dict({k: v for k, v in sd.items() if k not in ("per_robot", "reset_pose")})
 
     def world(self):
         """base = GetBasePosition (the root link's inertial frame origin), contact = GetFootContacts (a1.py:299-312: toe links

@@ -43,8 +43,8 @@ TASK_ENV_VECS = {                                    # :34-41
     "stairstair": (_upstair, _downstair, _plane) * 6,
     "slopeslope": (_upslope, _downslope, _plane) * 6,
 }
-TASKS = ("plane", "stairslope", "stairstair", "slopestair", "slopeslope", "gallop", "cave", "balancebeam", "highstair",
-         "heightfield")
+TASKS = ("plane", "stairslope", "stairstair", "slopestair", "slopeslope", "gallop", "cave", "balancebeam", "highstair")
+# the reference's tenth task, "heightfield" (a PyBullet GEOM_HEIGHTFIELD from a pybullet_data PNG), is refused by name: task_terrain()
 _IDENTITY = [0.0, 0.0, 0.0, 1]
 
 
@@ -234,10 +234,17 @@ def upstair_terrain(stepwidth=0.33, stepheight=0.05, slope=0.05, stepnum=40, mod
     return add_height, env_info, w.boxes
 
 
+# every `task=` that builds a box course (locomotion_gym_env.py:309-325); "plane" builds none
+TASK_NAMES = tuple(t for t in TASKS if t != "plane")
+
+
 def task_terrain(task):
     """What LocomotionGymEnv.reset builds on its first reset for `task_mode=task` (locomotion_gym_env.py:309-325): returns
-    (add_height, env_info, boxes). "plane" (and "heightfield", whose height field is PyBullet's) add nothing to the ground
-    plane: env_info stays the constructor's single up-slope-of-angle-0 stretch (:76)."""
+    (add_height, env_info, boxes). "plane" adds nothing to the ground plane: env_info stays the constructor's single
+    up-slope-of-angle-0 stretch (:76). "heightfield" (a PyBullet GEOM_HEIGHTFIELD from a pybullet_data PNG, :160-164) is not a box
+    course and is refused by name — A1GymEnv does the same before it gets here."""
+    if task == "heightfield":
+        raise NotImplementedError("task 'heightfield' is PyBullet's height field (envs/utilities/heightfield.py:89-104): not built")
     if task in TASK_ENV_VECS:
         return upstair_terrain(mode="special", env_vecs=TASK_ENV_VECS[task])
     if task == "gallop":

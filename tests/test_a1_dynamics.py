@@ -147,11 +147,22 @@ def test_apply_only_touches_the_masked_robots():
     assert bool((d.basemass[~mask] == d.base_mass_nominal).all())
     assert torch.equal(d.motor_kd[mask], v["motor_kd"][mask]) and bool((d.motor_kd[~mask] == 0).all())
     assert torch.equal(ph.gravity, v["gravity"])                       # (the physics masks what it writes)
-    # gravity_sign = -1: the drawn z turned downwards (not the reference's behaviour, offered for sane use)
+    # gravity_sign = -1: the DRAWN z turned downwards (not the reference's behaviour, offered for sane use) ...
     ph2 = _Physics(m, n)
     d2 = ad.A1Dynamics(ph2, seed=0, gravity_sign=-1.0)
-    d2.apply(v, mask)
-    assert torch.equal(ph2.gravity[:, 2], -v["gravity"][:, 2]) and torch.equal(ph2.gravity[:, :2], v["gravity"][:, :2])
+    v2 = d2.draw()                                                     # same seed, same numbers
+    assert torch.equal(v2["gravity"][:, 2], -v["gravity"][:, 2]) and torch.equal(v2["gravity"][:, :2], v["gravity"][:, :2])
+    assert bool((v2["gravity"][:, 2] <= -8.0).all())
+    d2.apply(v2, mask)
+    assert torch.equal(ph2.gravity, v2["gravity"])
+    # ... and ONLY the drawn one: a fixed() / dynamic_param set says which way its gravity points and is installed as given
+    # (it used to be flipped too, so per-link dynamic_param + gravity_sign=-1 made robots fall upward)
+    f = d2.fixed(legmass=(1.1, 1.0, 0.9))
+    d2.apply(f)
+    assert bool((ph2.gravity[:, 2] == -10.0).all()) and bool((ph2.gravity[:, :2] == 0.0).all())
+    f = d2.fixed(gravity=(0.5, 0.0, -9.0))
+    d2.apply(f)
+    assert bool((ph2.gravity[:, 2] == -9.0).all()) and bool((ph2.gravity[:, 0] == 0.5).all())
 
 
 def test_injected_draws_replace_the_generator():

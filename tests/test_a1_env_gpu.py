@@ -232,7 +232,8 @@ def test_quadrupedal_constructor_takes_the_reference_signature():
     assert env.observation_space.shape == (37,)
     obs, info = env.reset(yaw=0.0, x_noise=False)
     env.step(torch.zeros(2, 12, dtype=torch.float64, device=DEV), donef=True)
-    for bad, pat in ((dict(render=True), "render"), (dict(on_rack=True), "on_rack"), (dict(gait=1), "gait")):
+    for bad, pat in ((dict(render=True), "render"), (dict(on_rack=True), "on_rack"), (dict(gait=1), "gait"),
+                     (dict(task="heightfield"), "wm_height_out.png")):       # locomotion_gym_env.py:160-164: PyBullet's asset
         with pytest.raises(Exception, match=pat):
             metagym_amd.make("quadrupedal-v0", num_envs=2, device=DEV, physics=Null(2), **bad)
     with pytest.raises(TypeError, match="unexpected keyword"):

@@ -371,6 +371,63 @@ def test_a1_gym_env_checkpoint_continues_bit_for_bit():
     assert ends > 0
 
 
+@pytest.mark.parametrize("slots", [3, 1])
+def test_a1_gym_env_checkpoint_carries_courses_headings_and_start_noise(slots):
+    """what reset(**kwargs) / configure_reset() leave behind is part of the checkpoint — the terrain table and
+    every robot's course (or the batch's one hardset course), the reward's per-course stretches, start headings, the x-noise flags
+    and THEIR generator, new ETG parameters, the physics' reset pose. A fresh env (constructed on the task's default course, reset
+    with defaults) loaded from a checkpoint taken after all of those were changed continues bit for bit through auto-resets that
+    use them — and stands where the original stands, not on course 0 with the default pose."""
+    n = 48
+    w = np.tile([[0.03], [0.0], [0.02]], (1, 20)) * np.sin(np.linspace(0, 2 * np.pi, 20))
+    mk = lambda: metagym_amd.make("quadrupedal-v0", num_envs=n, urdf=a1_like_urdf(), device=DEV, task="slopestair", terrain_slots=slots,
+                                  ETG=1, ETG_w=w, ETG_b=np.zeros(3), auto_reset=True, seed=9)
+    a = mk()
+    a.reset()
+    zero = torch.zeros(n, 12, dtype=torch.float64, device=DEV)
+    course = dict(hardset=True, mode="downstair", stepwidth=0.28, slope=0.3, stepheight=0.06, env_vec=[])
+    if slots > 1:
+        m = torch.arange(n, device=DEV) % 2 == 1
+        a.configure_reset(m, yaw=0.5, x_noise=True, ETG_w=0.5 * w, **course)
+        a.step(zero, reset_mask=m)
+    else:
+        m = torch.ones(n, dtype=torch.bool, device=DEV)
+        a.reset(yaw=0.5, x_noise=True, ETG_w=0.5 * w, **course)
+    for _ in range(3):
+        a.step(zero)
+    sd = a.state_dict()
+    rs = np.random.RandomState(3)
+    acts = [torch.as_tensor(rs.uniform(-0.3, 0.3, (n, 12)), device=DEV) for _ in range(12)]
+    acts[1][::3] = 3.0                                       # every third robot falls: auto-resets with ITS course, heading, noise
+    acts[6][1::3] = 3.0
+    outs = []
+    for k in range(12):
+        o, r, d, info = a.step(acts[k])
+        outs.append((o.clone(), r.clone(), d.clone(), info["base"].clone(), info["pose"].clone()))
+    b = mk()
+    b.reset()
+    b.load_state_dict(sd)
+    assert b._first_reset is False and b._x_noise_any and np.array_equal(b.path.etg_w(), 0.5 * w)
+    if slots > 1:
+        assert torch.equal(b.terrain_id, a.terrain_id) and sorted(b._courses) == [0, 1] and b._courses[1][0] == a._courses[1][0]
+        assert torch.equal(b.physics.env._terrain_t, a.physics.env._terrain_t)
+    else:
+        assert b.add_height == a.add_height and b.default_pose == a.default_pose and len(b.terrain_boxes) == len(a.terrain_boxes)
+    ends = 0
+    for k in range(12):
+        o, r, d, info = b.step(acts[k])
+        want = outs[k]
+        assert torch.equal(o, want[0]) and torch.equal(r, want[1]) and torch.equal(d, want[2]), k
+        assert torch.equal(info["base"], want[3]) and torch.equal(info["pose"], want[4]), k
+        ends += int(d[m].sum())
+    assert ends > 0                                          # robots of the changed course restarted inside the compared steps ...
+    add_b = a._courses[1][0] if slots > 1 else a.add_height
+    z, yaw = info["base"][:, 2], info["pose"][:, 2]
+    assert add_b > 1.0 and float(z[m].min()) > add_b          # ... on the down-stair course's platform, not on course 0
+    fresh = m & (b._substeps_dev < 13 * 8)                   # those that restarted within the last 8 steps still face their heading
+    assert int(fresh.sum()) > 0 and float((yaw[fresh] - 0.5).abs().max()) < 0.2
+
+
 @pytest.mark.parametrize("mode", ["position_env_gains", "hybrid", "torque"])
 def test_fused_actuation_modes_equal_the_substep_path_bit_for_bit(mode):
     """The engine's in-launch actuators beyond the A1 default: POSITION with per-robot gains (what

@@ -58,3 +58,20 @@ def test_random_modes_follow_the_reference_draw_order_on_the_global_stream():
     np.random.seed(100)
     a = _flatten(*terrain.upstair_terrain(mode="random"))
     assert _same_bits(a[2], GOLD["random:random:0/bodies"])
+
+
+def test_heightfield_task_is_refused_by_name_not_run_on_flat_ground():
+    """locomotion_gym_env.py:97-98,160-164 + envs/utilities/heightfield.py:89-104: task "heightfield" is a PyBullet GEOM_HEIGHTFIELD
+    from a pybullet_data PNG. It used to fall through to "no boxes" (flat ground, silently wrong); now both the terrain builder and
+    the env constructor (before it needs a GPU or a robot) name what is missing."""
+    import pytest
+    from metagym_amd.quadrupedal import terrain
+    from metagym_amd.quadrupedal.a1_env import A1GymEnv
+    with pytest.raises(NotImplementedError, match="heightfield"):
+        terrain.task_terrain("heightfield")
+    with pytest.raises(NotImplementedError, match="wm_height_out.png"):
+        A1GymEnv(num_envs=2, task="heightfield")
+    assert "stairstair" in terrain.TASK_NAMES and "heightfield" not in terrain.TASK_NAMES
+    for name in terrain.TASK_NAMES:                       # every box course still builds
+        assert len(terrain.task_terrain(name)[2]) > 0
+    assert terrain.task_terrain("plane")[2] == []

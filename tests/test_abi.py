@@ -219,3 +219,27 @@ def test_new_round2_entry_points_validate_before_they_launch():
     assert lib.mg_walker_step(tp, ms, prm, 4, st, p, p, p, None, p, None) == -1001
     prm.terrain, prm.mapping = C.addressof(fake), 0
     assert lib.mg_walker_step(tp, ms, prm, 4, st, p, p, p, None, p, None) == -1004 and b"wave mapping" in lib.mg_last_error()
+
+
+def test_uniform_cell_size_promise_is_checked_not_trusted():
+    """include/metagym_hip.h mg_maze_view.uniform_cell_size: the caller's "every task has this cell size" is
+    compared with the table's cell_size column (TaskConfig.cell_size, maze_task.py:15-17). A wrong value is MG_ERR_BAD_CONFIG with
+    the offending task named — never wrong pixels. Host table here (no GPU needed); the device route is in test_maze_gpu.py."""
+    import numpy as np
+    from metagym_amd import _lib
+    lib = _lib.load()
+    sc = np.zeros((5, 8))
+    sc[:, 0] = 2.0
+    t = _lib.MazeTasks()
+    t.n, t.n_tasks, t.scalars = 9, 5, sc.ctypes.data
+    assert lib.mg_maze_check_uniform_cell_size(t, 2.0, None) == 0
+    assert lib.mg_maze_check_uniform_cell_size(t, 1.0, None) == -1003 and b"task 0 of 5 has cell_size 2" in lib.mg_last_error()
+    sc[3, 0] = 2.0000000000000004                                         # one ulp off in one task
+    assert lib.mg_maze_check_uniform_cell_size(t, 2.0, None) == -1003 and b"task 3" in lib.mg_last_error()
+    assert lib.mg_maze_check_uniform_cell_size(t, 0.0, None) == -1003     # 0 means "unknown": nothing to check
+    assert lib.mg_maze_check_uniform_cell_size(t, float("nan"), None) == -1003
+    assert lib.mg_maze_check_uniform_cell_size(None, 2.0, None) == -1001
+    t.scalars = None
+    assert lib.mg_maze_check_uniform_cell_size(t, 2.0, None) == -1001
+    t.scalars, t.n_tasks = sc.ctypes.data, 0
+    assert lib.mg_maze_check_uniform_cell_size(t, 2.0, None) == -1002

@@ -209,11 +209,29 @@ def test_maze2d_survival_crumbs_outside_the_food_list():
         crumbs = free & (rs.rand(*food.shape) < 0.5)
         food[crumbs] = rs.uniform(1e-4, 1e-2, int(crumbs.sum()))
         tasks.append(t._replace(food_rewards=food))
+    # a fifth task with MANY food cells: the other tasks' rows of the padded food list (max_food wide) then run on into their
+    # non-food cells — crumbs among them — and the cell -> slot table must leave those at -2 (a padding entry used
+    # to be scattered as -1, which hid the crumb from the observation)
+    t = MazeTaskSampler(n=9, allow_loops=True, step_reward=-0.01, goal_reward=1.0, food_density=0.5, food_interval=5, seed=11)
+    tasks.append(t)
     n = 257
     env = metagym_amd.make("meta-maze-2D-v0", num_envs=n, device="cuda:0", max_steps=30, view_grid=1, task_type="SURVIVAL")
     env.set_task(tasks)
     slots = env._cell_slot_t.cpu().numpy()
     assert (slots == -2).sum() > 20 and (slots == -1).sum() > 20 and (slots >= 0).sum() > 4
+    n_food, cells = env._n_food_t.cpu().numpy(), env._food_cells_t.cpu().numpy()
+    assert n_food.max() - n_food.min() >= 12
+    padded_crumbs = 0
+    for ti, tk in enumerate(tasks):
+        food = np.asarray(tk.food_rewards, np.float64).reshape(-1)
+        for c in cells[ti, n_food[ti]:]:
+            if 0.0 < food[c] <= 1e-2:
+                padded_crumbs += 1
+                assert slots[ti, c] == -2, (ti, c)
+        for c in range(81):
+            want = -2 if (0.0 < food[c] <= 1e-2) else (-1 if food[c] == 0.0 and slots[ti, c] < 0 else slots[ti, c])
+            assert slots[ti, c] == want, (ti, c)
+    assert padded_crumbs > 0                                  # the regression is exercised
     ids = env.task_id.cpu().numpy()
     otasks, states = _oracle_batch(tasks, ids, tt)
     obs = env.reset().cpu().numpy()
@@ -499,6 +517,77 @@ def test_maze3d_larger_mazes_match_oracle(n, res, cell):
         for e in range(t % 3, 12, 3):
             ref = mo.observe_3d(otasks[ids[e]], tt, view, states[e], 0)
             assert np.array_equal(ob[e], ref), (t, e, int((ob[e] != ref).sum()))
+
+
+def test_wrong_uniform_cell_size_is_an_error_code_not_wrong_pixels():
+    """mg_maze_view.uniform_cell_size through the C ABI: a task table whose cell sizes differ, stepped with a
+    view that vouches for one of them, comes back as MG_ERR_BAD_CONFIG from mg_maze3d_step itself (the library checks the pair the
+    first time it sees it); the right value — and 0, "unknown" — render the oracle's frames; a table rewritten in place is caught
+    by the explicit re-check; and a captured step finds the pair already checked by set_task."""
+    import metagym_amd
+    from metagym_amd import _lib
+    from metagym_amd.metamaze import MazeTaskSampler, MAZE_TASK_MANAGER
+    tt = mo.TASK_TYPES["ESCAPE"]
+    tasks = [MazeTaskSampler(n=9, allow_loops=False, step_reward=-0.01, goal_reward=1.0, seed=s_) for s_ in range(3)]
+    env = metagym_amd.make("meta-maze-discrete-3D-v0", num_envs=6, device="cuda:0", max_steps=20, resolution=(32, 32), task_type="ESCAPE")
+    env.set_task(tasks)
+    cs = float(tasks[0].cell_size)
+    assert env._uniform_cell_size == cs
+    want = env.reset().clone()
+    ids = env.task_id.cpu().numpy()
+    otasks, states = _oracle_batch(tasks, ids, tt)
+    view = mo.View(MAZE_TASK_MANAGER.grounds.astype(np.uint8), MAZE_TASK_MANAGER.ceil, 32, 32)
+    for e in range(6):
+        assert np.array_equal(want[e].cpu().numpy(), mo.observe_3d(otasks[ids[e]], tt, view, states[e], 0))
+    # (1) a wrong promise: an error code from the step, frames untouched
+    env._view_c.uniform_cell_size = cs * 0.5
+    env._obs.fill_(-7)
+    with pytest.raises(_lib.MetaGymHipError, match="uniform_cell_size"):
+        env.step(torch.zeros(6, dtype=torch.int32))
+    torch.cuda.synchronize()
+    assert int((env._obs != -7).sum()) == 0
+    # (2) "unknown" renders the same frames through the general kernel
+    env._view_c.uniform_cell_size = 0.0
+    assert torch.equal(env._observe(), want)
+    env._view_c.uniform_cell_size = cs
+    assert torch.equal(env._observe(), want)
+    # (3) the table rewritten in place: one task's cell size changes under a checked pair -> the explicit re-check refuses it
+    lib = env._lib
+    sc = env._task_t["scalars"]
+    keep = sc[1, 0].item()
+    sc[1, 0] = keep * 2.0
+    torch.cuda.synchronize()
+    assert lib.mg_maze_check_uniform_cell_size(env._tasks_c, cs, None) == -1003 and b"task 1 of 3" in lib.mg_last_error()
+    with pytest.raises(_lib.MetaGymHipError, match="task 1 of 3"):          # ... and the step no longer holds the pair as checked
+        env.step(torch.zeros(6, dtype=torch.int32))
+    sc[1, 0] = keep
+    torch.cuda.synchronize()
+    assert lib.mg_maze_check_uniform_cell_size(env._tasks_c, cs, None) == 0
+    # (4) mixed cell sizes through set_task: the Python layer passes 0 and the frames still match the oracle
+    mixed = [tasks[0], tasks[1]._replace(cell_size=cs * 0.75), tasks[2]]
+    env2 = metagym_amd.make("meta-maze-discrete-3D-v0", num_envs=6, device="cuda:0", max_steps=20, resolution=(32, 32), task_type="ESCAPE")
+    env2.set_task(mixed)
+    assert env2._uniform_cell_size == 0.0
+    f2 = env2.reset().cpu().numpy()
+    ids2 = env2.task_id.cpu().numpy()
+    ot2, st2 = _oracle_batch(mixed, ids2, tt)
+    for e in range(6):
+        assert np.array_equal(f2[e], mo.observe_3d(ot2[ids2[e]], tt, view, st2[e], 0))
+    # (5) a step captured into a hipGraph right after set_task: the pair is already checked, capture does not synchronise
+    env3 = metagym_amd.make("meta-maze-discrete-3D-v0", num_envs=6, device="cuda:0", max_steps=20, resolution=(32, 32), task_type="ESCAPE")
+    env3.set_task(tasks)
+    env3.reset()
+    act = torch.ones(6, dtype=torch.int32, device="cuda:0")
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        env3.step(act)
+    torch.cuda.current_stream().wait_stream(side)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        env3.step(act)
+    g.replay()
+    torch.cuda.synchronize()
 
 
 def test_maze3d_uint8_fast_path_is_the_clamped_reference_frame():
