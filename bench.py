@@ -337,15 +337,21 @@ def cpu_baseline_walker(seconds=10.0, envs_per_thread=32):
                       "PyBullet (absent from the reference tree)" % (sum(counts), envs_per_thread, el)}
 
 
-def walker_flops(robot="humanoid"):
+def walker_flops(robot="humanoid", full=False):
     """Counted f64 operations per env step (oracle/count_walker_flops.py: the instrumented C restatement of the wave kernel's
-    algorithm over a rollout of this workload), from the committed profiles/<round>/walker_flops.json."""
+    algorithm over a rollout of this workload), from the newest committed profiles/<round>/walker_flops.json that has the entry
+    (`humanoid`, `ant`: BASELINE C4's airborne rollout; `humanoid_grounded`, `humanoid_lying`: the contact-rich ones).
+    full=True also returns the whole record (constraint rows / contacts per sub-step)."""
+    none = (None, None, None, None) if full else (None, None, None)
     for rnd in sorted((d for d in os.listdir(os.path.join(ROOT, "profiles")) if d.startswith("r") and d[1:].isdigit()), reverse=True):
         p = os.path.join(ROOT, "profiles", rnd, "walker_flops.json")
         if os.path.exists(p):
-            rec = json.load(open(p))[robot]
-            return float(rec["flop_per_env_step"]), "profiles/%s/walker_flops.json (%s)" % (rnd, rec["source"]), rec["per_env_step"]
-    return None, None, None
+            rec = json.load(open(p)).get(robot)
+            if rec is None:
+                continue
+            res = (float(rec["flop_per_env_step"]), "profiles/%s/walker_flops.json (%s)" % (rnd, rec["source"]), rec["per_env_step"])
+            return res + (rec,) if full else res
+    return none
 
 
 # ---------------------------------------------------------------------------------------- GPU timing helpers
@@ -591,6 +597,58 @@ def secondary_workloads(dev, valu_insts_per_wave=None):
             "note": "physics parity unpinned (PyBullet is not in the reference tree)"}
         del env, acts
         torch.cuda.empty_cache()
+        # ---- C4, contact-rich: the same 8 192 x 256-variant batch, but every robot starts STANDING on the floor
+        #      (mjcf.grounded: the base lifted by the 9.3 cm the reference's variants start inside it) under U(-0.1, 0.1) actions and
+        #      without auto-reset — the batch sags, kneels, falls and then lies on the ground with many proxies down. Three timings:
+        #      the first 24 steps (standing -> kneeling), the lying steady state (after 200 steps), and the episodic auto-reset mix.
+        from metagym_amd.metalocomotion import mjcf
+        gmodels = [mjcf.grounded(m) for m in variants.models("humanoid", "TRAIN")]
+        genv = MetaHumanoidEnv(num_envs=n, device=dev, auto_reset=False, max_steps=1000, seed=1)
+        genv.set_task(gmodels)
+        genv.reset(seed=0)
+        gacts = [(torch.rand(n, genv.n_joints, device=dev) * 2 - 1) * 0.1 for _ in range(8)]
+        s_stand = _time_steps(lambda i: genv.step(gacts[i % 8]), 24, 0)
+        for i in range(176):
+            genv.step(gacts[i % 8])
+        s_lying = _time_steps(lambda i: genv.step(gacts[i % 8]), 24, 3)
+        g_feet = float((genv.feet_contact.sum(0) > 0).float().mean())
+        g_low = float((genv.pos[2] < 0.6).float().mean())
+        g_bad = float(genv.bad_contacts.float().mean()) if getattr(genv, "bad_contacts", None) is not None else None
+        g_flop, g_src, g_mix, g_rec = walker_flops("humanoid_lying", full=True)
+        del genv
+        torch.cuda.empty_cache()
+        eenv = MetaHumanoidEnv(num_envs=n, device=dev, auto_reset=True, max_steps=1000, seed=1)
+        eenv.set_task(gmodels)
+        eenv.reset(seed=0)
+        for i in range(120):                                      # three episode lengths (~44 steps each): a stationary mix
+            eenv.step(gacts[i % 8])
+        s_epi = _time_steps(lambda i: eenv.step(gacts[i % 8]), 24, 3)
+        e_feet = float((eenv.feet_contact.sum(0) > 0).float().mean())
+        e_flop, e_src, _, e_rec = walker_flops("humanoid_grounded", full=True)
+        del eenv, gacts
+        torch.cuda.empty_cache()
+        fl = g_flop if g_flop is not None else flop
+        out["C4_grounded_humanoid_8192envs_256variants"] = {
+            "env_steps_per_s": n / s_lying, "ms_per_launch": s_lying * 1e3, "preset": "bullet",
+            "workload": "C4's batch started standing on the floor (base lifted 9.3 cm), actions U(-0.1, 0.1), no auto-reset: timed "
+                        "after 200 steps, every robot lying on the ground",
+            "steady_state": {"preroll_steps": 203, "frac_envs_with_a_foot_on_the_ground": g_feet, "frac_torsos_below_0p6m": g_low,
+                             "mean_non_foot_contact_points_per_env": g_bad,
+                             "constraint_rows_per_substep_counted": None if g_rec is None else g_rec.get("constraint_rows_per_substep"),
+                             "contacts_per_substep_counted": None if g_rec is None else g_rec.get("contacts_per_substep")},
+            "ms_per_launch_first_24_steps_standing_to_kneeling": s_stand * 1e3,
+            "episodic_autoreset": {"ms_per_launch": s_epi * 1e3, "env_steps_per_s": n / s_epi, "frac_envs_with_a_foot_on_the_ground": e_feet,
+                                   "algorithmic_flop_per_env_step": e_flop, "flop_source": e_src,
+                                   "constraint_rows_per_substep_counted": None if e_rec is None else e_rec.get("constraint_rows_per_substep"),
+                                   "note": "same start, fused auto-reset: an episode ends when the torso sinks below 0.5 m (~44 steps), so "
+                                           "most of the mix is standing / folding robots whose resting contacts flicker"},
+            "roofline": {"bound": "valu", "achieved": fl * n / s_lying / 1e12, "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": fl * n / s_lying / 1e12 / FP64_VALU_PEAK_TFLOPS, "algorithmic_flop_per_env_step": fl,
+                         "flop_source": g_src if g_flop is not None else flop_src + " (the airborne rollout: no grounded count found)",
+                         "flop_mix_per_env_step": g_mix, "achieved_hbm_gbs": byt * n / s_lying / 1e9,
+                         "hbm_frac": byt * n / s_lying / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes_per_env_step": byt},
+            "note": "physics parity unpinned (PyBullet is not in the reference tree); under GPU parity against oracle/walker_oracle.c in "
+                    "tests/test_walker_gpu.py::test_c4_grounded_configuration_sampled_against_oracle"}
     except Exception as e:
         out["walker_error"] = repr(e)
     try:
@@ -766,6 +824,39 @@ def aggregate_throughput(dist, wall, envs_per_rank, steps):
     return world * envs_per_rank * steps / wall_max, wall_max
 
 
+def solo_wall_of(dist, rank, run):
+    """--self-baseline: `run()` (the K timed steps) on rank 0 while every other rank waits at a barrier — the N = 1 figure of
+    this very job (same box, process and launch mode), so the scaling efficiency needs no second invocation. Returns rank 0's
+    wall time on rank 0, None elsewhere."""
+    if dist is not None:
+        dist.barrier()
+    w = None
+    if rank == 0:
+        t0 = time.perf_counter()
+        run()
+        w = time.perf_counter() - t0
+    if dist is not None:
+        dist.barrier()
+    return w
+
+
+def scaling_fields(value, world, envs_per_rank, steps, rank_walls, solo_wall=None, single_gpu_value=None):
+    """What the line says about scaling, as plain numbers (rank 0): every rank's wall time of the timed region and its own
+    throughput over THAT time (`value` is the job's: all envs over the slowest rank's wall); with --self-baseline the solo
+    figure and efficiency = value(N) / (N x solo); with --single-gpu-value V the same against a prior N = 1 run."""
+    out = {"rank_wall_ms": [w * 1e3 for w in rank_walls],
+           "rank_value": [envs_per_rank * steps / w for w in rank_walls]}
+    if solo_wall is not None:
+        solo = envs_per_rank * steps / solo_wall
+        out["self_baseline"] = {"value": solo, "ms_per_step": solo_wall / steps * 1e3,
+                                "what": "rank 0 alone, same process / launch mode / K steps, the other ranks idle at a barrier"}
+        out["efficiency"] = value / (world * solo)
+    if single_gpu_value:
+        out["efficiency" if solo_wall is None else "efficiency_vs_single_gpu_value"] = value / (world * single_gpu_value)
+        out["single_gpu_value"] = single_gpu_value
+    return out
+
+
 def shard_env_ids(rank, world, envs_per_rank):
     """Global env ids owned by `rank` (contiguous shards)."""
     return np.arange(rank * envs_per_rank, (rank + 1) * envs_per_rank, dtype=np.int64)
@@ -893,6 +984,9 @@ def main(argv=None):
                     help="untimed steps that bring the batch to its steady episode-age mix (default: nt = 1000)")
     ap.add_argument("--single-gpu-value", type=float, default=None,
                     help="a prior N=1 `value`; with it the line carries efficiency = value(N) / (N * value(1))")
+    ap.add_argument("--self-baseline", action="store_true",
+                    help="with N > 1 ranks: rank 0 first times the same K steps ALONE (the other ranks idle at a barrier), so the line "
+                         "carries efficiency = value(N) / (N * solo value) without a prior --single-gpu-value run")
     ap.add_argument("--no-pmc", action="store_true", help="skip the in-run rocprofv3 --pmc passes (VALU instruction count, HBM traffic)")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--plan-only", action="store_true",
@@ -907,6 +1001,10 @@ def main(argv=None):
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     if not args.plan_only:
+        have = torch.cuda.device_count()
+        if have <= local_rank or (args.gpus > 1 and have < min(args.gpus, int(os.environ.get("LOCAL_WORLD_SIZE", args.gpus)))):
+            raise SystemExit("bench.py --gpus %d: rank %d (local rank %d) needs its own GPU but torch.cuda.device_count() == %d"
+                             % (args.gpus, rank, local_rank, have))
         torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
@@ -993,6 +1091,16 @@ def main(argv=None):
         barrier()
         return t1 - t0, ev0.elapsed_time(ev1)
 
+    def run_k_steps():
+        torch.cuda.synchronize(dev)
+        if graph is not None:
+            graph.replay()
+        else:
+            for i in range(args.steps):
+                step(i)
+        torch.cuda.synchronize(dev)
+
+    solo_wall = solo_wall_of(dist, rank, run_k_steps) if (args.self_baseline and world > 1) else None
     ep0 = quad.episodes()
     wall, dev_ms = timed_region()
     ep1 = quad.episodes()
@@ -1021,6 +1129,40 @@ def main(argv=None):
         if auto:
             other["chosen_by"] = "--launch auto: higher whole-job throughput of the two timed regions"
 
+    # What a short timed region pays on top of its kernels: the same env.step() launches as hipGraphs of K and
+    # of 10 K steps, each replayed a few times between synchronisations; T(K) = a + b K gives the per-step cost b of a long run and
+    # the fixed cost a of ONE timed region (graph launch, first-dispatch latency after an idle queue, completion wake-up).
+    graph_fit = None
+    if not mixed and world == 1 and args.launch != "eager":
+        try:
+            def replay_wall(g, reps=5):
+                best_w, best_d = 1e9, 1e9
+                for _ in range(reps):
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record(); e1.record()
+                    torch.cuda.synchronize(dev)
+                    t0 = time.perf_counter()
+                    e0.record()
+                    g.replay()
+                    e1.record()
+                    torch.cuda.synchronize(dev)
+                    best_w, best_d = min(best_w, time.perf_counter() - t0), min(best_d, e0.elapsed_time(e1) * 1e-3)
+                return best_w, best_d
+            k1, k2 = args.steps, min(10 * args.steps, 400)
+            g1 = graph if graph is not None else capture_steps(dev, step, k1)
+            g2 = capture_steps(dev, step, k2)
+            g2.replay()
+            torch.cuda.synchronize(dev)
+            (w1, d1), (w2, d2) = replay_wall(g1), replay_wall(g2)
+            b_w, b_d = (w2 - w1) / (k2 - k1), (d2 - d1) / (k2 - k1)
+            graph_fit = {"k": [k1, k2], "host_wall_us": [w1 * 1e6, w2 * 1e6], "hip_event_us": [d1 * 1e6, d2 * 1e6],
+                         "per_step_us_host_wall": b_w * 1e6, "per_step_us_hip_events": b_d * 1e6,
+                         "fixed_us_per_timed_region_host_wall": (w1 - b_w * k1) * 1e6,
+                         "fixed_us_per_timed_region_hip_events": (d1 - b_d * k1) * 1e6,
+                         "note": "best of 5 replays each; T(K) = fixed + per_step x K. ms_per_step of a K-step region = per_step + fixed / K"}
+            del g2
+        except Exception as e:
+            graph_fit = {"error": repr(e)}
     done_frac = float(quad.env._done.float().mean().item())
     failed_any = int(quad.env._failed.max().item())
     if rank == 0:
@@ -1038,11 +1180,8 @@ def main(argv=None):
             "vs_baseline": None,
             "dtype": "f32/f64 mixed (reference choreography)",
             "data": "synthetic",
-            "rank_wall_ms": [w * 1e3 for w in rank_walls],
         }
-        if args.single_gpu_value:
-            out["efficiency"] = value / (world * args.single_gpu_value)
-            out["single_gpu_value"] = args.single_gpu_value
+        out.update(scaling_fields(value, world, envs_per_rank, args.steps, rank_walls, solo_wall, args.single_gpu_value))
         if not mixed:
             achieved = BYTES_PER_ENV_STEP * n / launch_s / 1e9
             out["config"] = {"workload": "Quadrotor hovering_control, %d envs/GPU, dt=0.01 (10 Euler sub-steps), "
@@ -1102,7 +1241,10 @@ def main(argv=None):
                          "done_frac_timed_region": (ep1 - ep0) / float(n * args.steps),
                          "preroll_steps": quad.preroll_steps,
                          "host_wall_ms_per_step": wall / args.steps * 1e3, "launch_mode": launch_mode,
-                         "other_launch_mode": other}
+                         "other_launch_mode": other, "graph_launch_fit": graph_fit}
+        if graph_fit and "fixed_us_per_timed_region_host_wall" in graph_fit:
+            out["graph_launch_us"] = graph_fit["fixed_us_per_timed_region_host_wall"]
+            out["kernel_us_per_step_long_run"] = graph_fit["per_step_us_hip_events"]
         if not mixed:
             out["from_profiles"] = from_profiles(n, launch_s)
         if world == 1 and not args.no_secondary and not mixed:
@@ -1125,6 +1267,8 @@ def main(argv=None):
                     ("C3_maze3d_continuous_hbm_frac", "C3_maze3d_continuous_9x9_256x256_16384envs", ("roofline", "frac")),
                     ("C4_humanoid_env_steps_per_s", "C4_humanoid_8192envs_256variants", ("env_steps_per_s",)),
                     ("C4_humanoid_f64_valu_frac", "C4_humanoid_8192envs_256variants", ("roofline", "frac")),
+                    ("C4_grounded_env_steps_per_s", "C4_grounded_humanoid_8192envs_256variants", ("env_steps_per_s",)),
+                    ("C4_grounded_f64_valu_frac", "C4_grounded_humanoid_8192envs_256variants", ("roofline", "frac")),
                     ("C5_share_env_steps_per_s", "C5_mixed_share_65536quad_plus_65536maze3d_64x64", ("env_steps_per_s_two_streams",)),
                     ("C1_maze2d_1env_us_per_step_hipgraph", "C1_maze2d_15x15_escape_1env", ("us_per_step_hipgraph_100",)),
                     ("north_star_2p17_env_steps_per_s", "north_star_quadrotor_hovering_131072envs_1gpu", ("env_steps_per_s",)),

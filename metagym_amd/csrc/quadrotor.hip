@@ -25,7 +25,10 @@
 
 namespace {
 
-constexpr int BLOCK = 256;
+#ifndef MG_QUAD_BLOCK
+#define MG_QUAD_BLOCK 256     // launch-shape experiments (scripts/quad_variants.py; profiles/r05/quad_launch_shapes.txt): 64 / 128 / 256
+#endif
+constexpr int BLOCK = MG_QUAD_BLOCK;
 constexpr int WAVES_PER_BLOCK = BLOCK / mg::WAVE;
 constexpr int OBS_DIM = 16;
 

@@ -120,6 +120,34 @@ class Model(object):
         return m
 
 
+def rest_lowest_point(m):
+    """z of the lowest point of any collision proxy (sphere surface) with the robot in its reset pose: base at body_pos[0] /
+    body_rot[0], every joint at zero. For the reference's variant humanoids this is NEGATIVE: gen_variant_humanoids.py:44 lowers
+    the torso by 0.20 while the legs reach further down, so every episode starts with the feet ~9 cm inside the floor."""
+    nb = len(m.body_parent)
+    o, R = np.zeros((nb, 3)), np.zeros((nb, 3, 3))
+    for b in range(nb):                      # parents come first (check_walker requires body_parent[b] < b)
+        pos, rot = np.asarray(m.body_pos[b], np.float64), np.asarray(m.body_rot[b], np.float64).reshape(3, 3)
+        p = int(m.body_parent[b])
+        if p < 0:
+            o[b], R[b] = pos, rot
+        else:
+            o[b], R[b] = o[p] + R[p] @ pos, R[p] @ rot
+    z = [(o[int(b)] + R[int(b)] @ np.asarray(c, np.float64))[2] - float(r) for b, c, r in zip(m.sph_body, m.sph_pos, m.sph_radius)]
+    return float(min(z))
+
+
+def grounded(m, clearance=0.0):
+    """A copy of `m` whose base starts `clearance` above the height at which its lowest collision proxy just touches z = 0 in the
+    reset pose (negative: that far inside). The episode then begins STANDING on the floor instead of being ejected from it —
+    the contact-rich variant of a MetaLocomotion workload (bench.py `C4_grounded_*`). Everything else of the model is shared."""
+    import copy
+    g = copy.copy(m)
+    g.body_pos = np.array(m.body_pos, dtype=np.float64, copy=True)
+    g.body_pos[0, 2] += float(clearance) - rest_lowest_point(m)
+    return g
+
+
 def _aabb_box_inertia(mass, geoms, com):
     """What btCompoundShape::calculateLocalInertia returns for a body's shapes: the solid-box formula on the extents of
     their axis-aligned bounding box (in the body's axes), m/12 (ly^2 + lz^2, lx^2 + lz^2, lx^2 + ly^2), diagonal."""

@@ -18,11 +18,17 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
-def count(robot="humanoid", env_steps=400, variant=0, seed=0):
-    from metagym_amd.metalocomotion import variants
+def count(robot="humanoid", env_steps=400, variant=0, seed=0, grounded=False, action_scale=1.0, reset_on_done=True, skip=0):
+    """`grounded` + `action_scale` 0.1: the contact-rich variant bench.py times as C4_grounded_* — every episode starts standing
+    on the floor (mjcf.grounded) and small actions let the robot sag, kneel and fall with its proxies on the ground.
+    `reset_on_done=False` + `skip`: the robot is stepped on after its episode ended (what a batch without auto-reset does) and
+    the first `skip` steps are not counted — the robot LYING on the floor, the solver's heaviest steady state."""
+    from metagym_amd.metalocomotion import mjcf, variants
     from oracle import abd, walker_c
     lib = walker_c.load(count_flops=True)
     m = variants.model(robot, "TRAIN", variant)
+    if grounded:
+        m = mjcf.grounded(m)
     ant = robot == "ant"
     power = np.full(len(m.joint_lo), 100.0) * 2.5 if ant else abd.HUMANOID_MOTOR_POWER * 0.41
     cm, table = walker_c.make_model(m, power)
@@ -33,20 +39,25 @@ def count(robot="humanoid", env_steps=400, variant=0, seed=0):
     noise = rs.uniform(-0.1, 0.1, nj)
     obs = np.zeros(8 + 2 * nj + len(m.foot_body), np.float32)
     lib.wo_env_reset(C.byref(cm), C.byref(prm), C.byref(env), noise.ctypes.data_as(C.POINTER(C.c_double)), obs.ctypes.data_as(C.POINTER(C.c_float)))
-    out = (C.c_ulonglong * 6)()
+    out = (C.c_ulonglong * 9)()
     lib.wo_flops_read(out, 1)
     rew = C.c_double()
     episodes = 0
-    for t in range(env_steps):
-        a = rs.uniform(-1, 1, nj).astype(np.float32)
+    for t in range(skip + env_steps):
+        if t == skip:
+            lib.wo_flops_read(out, 1)
+        a = (action_scale * rs.uniform(-1, 1, nj)).astype(np.float32)
         if lib.wo_env_step(C.byref(cm), C.byref(prm), C.byref(env), a.ctypes.data_as(C.POINTER(C.c_float)), obs.ctypes.data_as(C.POINTER(C.c_float)),
-                           C.byref(rew), None):
+                           C.byref(rew), None) and reset_on_done:
             noise = rs.uniform(-0.1, 0.1, nj)
             lib.wo_env_reset(C.byref(cm), C.byref(prm), C.byref(env), noise.ctypes.data_as(C.POINTER(C.c_double)), None)
             episodes += 1
     assert lib.wo_flops_read(out, 0) == 1
-    add, mul, fma, div, sqrt, trig = [int(x) / float(env_steps) for x in out]
-    return {"robot": robot, "env_steps": env_steps, "episodes": episodes, "per_env_step": {"add": add, "mul": mul, "fma": fma, "div": div,
+    add, mul, fma, div, sqrt, trig = [int(x) / float(env_steps) for x in out[:6]]
+    substeps, rows, contacts = int(out[6]), int(out[7]), int(out[8])
+    return {"robot": robot, "env_steps": env_steps, "episodes": episodes, "grounded": bool(grounded), "action_scale": action_scale,
+            "reset_on_done": bool(reset_on_done), "uncounted_first_steps": skip, "variant": variant,
+            "constraint_rows_per_substep": rows / float(max(substeps, 1)), "contacts_per_substep": contacts / float(max(substeps, 1)), "per_env_step": {"add": add, "mul": mul, "fma": fma, "div": div,
             "sqrt": sqrt, "trig": trig}, "flop_per_env_step": add + mul + 2 * fma + div + sqrt + trig,
             "source": "oracle/walker_oracle.c -DWO_COUNT_FLOPS (the wave kernel's algorithm in scalar C), oracle/count_walker_flops.py"}
 
@@ -54,4 +65,21 @@ def count(robot="humanoid", env_steps=400, variant=0, seed=0):
 if __name__ == "__main__":
     robot = sys.argv[1] if len(sys.argv) > 1 else "humanoid"
     steps = int(sys.argv[2]) if len(sys.argv) > 2 else 400
-    print(json.dumps(count(robot, steps)))
+    def mean_over_variants(**kw):
+        """The bench batches run the 256 TRAIN variants round-robin: average a few of them."""
+        runs = [count(robot, steps, variant=v, seed=v, **kw) for v in (0, 37, 101, 200)]
+        out = dict(runs[0])
+        out["variant"] = [r["variant"] for r in runs]
+        out["episodes"] = sum(r["episodes"] for r in runs)
+        for k in ("constraint_rows_per_substep", "contacts_per_substep", "flop_per_env_step"):
+            out[k] = float(np.mean([r[k] for r in runs]))
+        out["per_env_step"] = {k: float(np.mean([r["per_env_step"][k] for r in runs])) for k in runs[0]["per_env_step"]}
+        return out
+    if "--grounded" in sys.argv:
+        print(json.dumps(mean_over_variants(grounded=True, action_scale=0.1)))
+    elif "--lying" in sys.argv:
+        print(json.dumps(mean_over_variants(grounded=True, action_scale=0.1, reset_on_done=False, skip=150)))
+    elif "--variants" in sys.argv:
+        print(json.dumps(mean_over_variants()))
+    else:
+        print(json.dumps(count(robot, steps)))

@@ -21,7 +21,8 @@
 #include <string.h>
 
 #ifdef WO_COUNT_FLOPS
-unsigned long long wo_flop_count[6];      /* add/sub, mul, fma (counts once), div, sqrt, sin/cos/atan2/asin */
+unsigned long long wo_flop_count[9];      /* add/sub, mul, fma (counts once), div, sqrt, sin/cos/atan2/asin; then the solver's
+                                           * load: [6] sub-steps, [7] constraint rows summed over them, [8] contacts (ground + self) */
 #define FL(k, n) (wo_flop_count[k] += (unsigned long long)(n))
 #else
 #define FL(k, n) ((void)0)
@@ -402,6 +403,9 @@ int wo_substep(const wo_model *m, const wo_params *prm, wo_state *s, const doubl
         FL(F_MUL, 1);
         u[r] = v * idg[r];
     }
+#ifdef WO_COUNT_FLOPS
+    wo_flop_count[6] += 1; wo_flop_count[7] += (unsigned long long)nr; wo_flop_count[8] += (unsigned long long)ncont;
+#endif
     if (prm->max_coordinate_velocity > 0.0)      /* btMultiBody::applyDeltaVeeMultiDof's clamp of every generalized velocity */
         for (int d = 0; d < n; ++d) u[d] = fmin(fmax(u[d], -prm->max_coordinate_velocity), prm->max_coordinate_velocity);
     for (int i = 0; i < 3; ++i) { s->vel[i] = u[i]; s->omega[i] = u[3 + i]; FL(F_FMA, 1); s->pos[i] += dt * u[i]; }
@@ -532,7 +536,7 @@ long wo_run(const wo_model *models, const int *task_id, const wo_params *prm, wo
     return done_steps;
 }
 
-int wo_flops_read(unsigned long long *out6, int clear) {
+int wo_flops_read(unsigned long long *out6 /* [9] */, int clear) {
 #ifdef WO_COUNT_FLOPS
     memcpy(out6, wo_flop_count, sizeof(wo_flop_count));
     if (clear) memset(wo_flop_count, 0, sizeof(wo_flop_count));

@@ -104,6 +104,49 @@ def test_two_ranks_build_and_step_their_shards_gloo():
     assert int(single["episode"].min()) == T_STEPS // NT                                   # episodes did restart
 
 
+def _solo_worker(rank, world, port, out):
+    import time
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    sys.path.insert(0, ROOT)
+    import bench
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    t0 = time.perf_counter()
+    solo = bench.solo_wall_of(dist, rank, lambda: time.sleep(0.05))          # rank 0 "steps" alone for 50 ms
+    waited = time.perf_counter() - t0
+    wall = 0.010 * (rank + 1)                                                # the all-rank region: rank 1 is the slow one
+    value, _ = bench.aggregate_throughput(dist, wall, envs_per_rank=N_PER_RANK, steps=T_STEPS)
+    walls = bench.gather_walls(dist, wall)
+    fields = bench.scaling_fields(value, world, N_PER_RANK, T_STEPS, walls, solo_wall=solo, single_gpu_value=1000.0) if rank == 0 else None
+    out[rank] = dict(solo=solo, waited=waited, fields=fields, value=value)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_self_baseline_and_per_rank_values_at_world_size_two():
+    """`bench.py --gpus N --self-baseline`: rank 0 times the K steps alone while the other ranks wait at a
+    barrier, and the line carries per-rank values and efficiency = value(N) / (N x solo) — the protocol over gloo, world size 2."""
+    world, port = 2, _free_port()
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_solo_worker, args=(world, port, out), nprocs=world, join=True)
+    assert out[1]["solo"] is None and 0.05 <= out[0]["solo"] < 0.5
+    assert out[1]["waited"] >= 0.045                                         # rank 1 did idle through rank 0's solo run
+    f = out[0]["fields"]
+    assert np.allclose(f["rank_wall_ms"], [10.0, 20.0])
+    assert np.allclose(f["rank_value"], [N_PER_RANK * T_STEPS / 0.010, N_PER_RANK * T_STEPS / 0.020])
+    solo_value = N_PER_RANK * T_STEPS / out[0]["solo"]
+    assert abs(f["self_baseline"]["value"] - solo_value) < 1e-6 * solo_value
+    assert abs(f["efficiency"] - out[0]["value"] / (2 * solo_value)) < 1e-12
+    assert abs(f["efficiency_vs_single_gpu_value"] - out[0]["value"] / 2000.0) < 1e-12
+    # without a solo run the prior-N=1 route keeps the plain name; and the flag parses on the plan-only path
+    sys.path.insert(0, ROOT)
+    import bench
+    g = bench.scaling_fields(100.0, 2, 8, 5, [0.1, 0.2], single_gpu_value=60.0)
+    assert abs(g["efficiency"] - 100.0 / 120.0) < 1e-12 and "self_baseline" not in g
+    bench.main(["--gpus", "1", "--plan-only", "--self-baseline", "--envs-per-gpu", "64"])
+
+
 def test_shard_invariant_env_ids():
     """bench.py gives rank r the global env ids [r*n, (r+1)*n): the union over ranks equals the
     single-process id range, so the Philox reset keys (seed; global env id, episode) are independent of
