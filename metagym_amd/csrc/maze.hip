@@ -751,8 +751,22 @@ struct int3s { int x, y, z; };   // 12-byte pixel, stored with one dwordx3
 // (mg_maze3d_step) — every task's cell size the same power of two, texture size and resolution powers of two, int32 frames: the
 // run-time `is this a power of two` flags of the general kernel become constants, and with them go the correctly-rounded
 // divisions nobody takes, their scalar branches, the byte-output path and a quarter-rate 32-bit multiply in the store address.
-template <int REC, bool STOCK>
-__global__ __launch_bounds__(MZ_BLOCK) __attribute__((amdgpu_waves_per_eu(6))) void maze3d_step_kernel(mg_maze_tasks T, mg_maze_state st, ViewK vk,
+//
+// TRANS: the small-frame renderer (one wave per env, V a multiple of TR_ROWS, int32 frames). Pass B keeps lane = screen COLUMN:
+// every lane renders ITS column with its own record in registers — no per-column broadcast at all (11 v_readlane + 4 converts +
+// span decode + offset set-up per column were 40 % of the pixel pass at one 64-row chunk per column, profiles/r04/
+// maze3d_small_knockouts.txt) — while the row's constants are wave-uniform. A screen row is then "all ceiling", "all wall" or mixed
+// ACROSS columns, which happens far less often than a 64-row column being mixed along its height (always, at 64 rows), so most
+// rows run one of the two code paths instead of both. The pixels of TR_ROWS rows go through an LDS tile [64 columns][TR_ROWS * 3 + 1]
+// and leave as linear dwordx4 stores: 96 contiguous bytes per column, full 32-byte sectors.
+constexpr int TR_ROWS = 8, TR_STRIDE = TR_ROWS * 3 + 1;
+typedef int mz_v4i __attribute__((ext_vector_type(4)));
+
+#ifndef MG_MAZE3D_TRANS_WAVES
+#define MG_MAZE3D_TRANS_WAVES 4     // register budget of the TRANS kernels (LDS bounds them at ~11 one-wave envs per CU anyway)
+#endif
+template <int REC, bool STOCK, bool TRANS = false>
+__global__ __launch_bounds__(MZ_BLOCK) __attribute__((amdgpu_waves_per_eu(TRANS ? MG_MAZE3D_TRANS_WAVES : 6))) void maze3d_step_kernel(mg_maze_tasks T, mg_maze_state st, ViewK vk,
                                                                int task_type, int max_steps, int continuous,
                                                                int pre_moved, int auto_reset, int n_envs,
                                                                const void *action,
@@ -779,6 +793,7 @@ __global__ __launch_bounds__(MZ_BLOCK) __attribute__((amdgpu_waves_per_eu(6))) v
     off = (off + 15) & ~size_t(15);
     RowRec *row_tab = reinterpret_cast<RowRec *>(smem + off);      // [V rounded up to 64]: distance, light, ys, kind of a screen row
     const int v_pad = (vk.V + 63) & ~63;
+    int32_t *tile = reinterpret_cast<int32_t *>(smem + off + sizeof(RowRec) * (size_t)v_pad);   // TRANS only: [64][TR_STRIDE]
 
     // ---- phase 0: transition + scalar part of evaluation_rule (one thread) ----------------------
     if (tid == 0) {
@@ -879,6 +894,72 @@ __global__ __launch_bounds__(MZ_BLOCK) __attribute__((amdgpu_waves_per_eu(6))) v
     // env instead of four streams 32 columns (98 KB at 256 x 256) apart. The frame stores alone (everything else knocked out) run
     // 6.5 % faster that way at 256 x 256 (2.37 -> 2.22 ms, profiles/r04/maze3d_store_pattern.txt); small frames (one or two waves
     // per env) keep consecutive columns per wave, which measured faster there.
+    if constexpr (TRANS) {
+        // (one wave per env: blockDim.x == 64, vk.slab == 64, vk.V % TR_ROWS == 0, int32 frames — mg_maze3d_step guarantees it)
+        for (int gbase = 0; gbase < vk.H; gbase += 64) {
+            const int ncols = min(64, vk.H - gbase);
+            // a lane past the last column shadows it (valid arithmetic everywhere, its pixels are never flushed)
+            const int col = gbase + min(lane, ncols - 1);
+            const ColRec mine = column_pass<REC, STOCK>(vk, t, *es, walls, texts, transp, col, lane, entries, cs, inv_cs, cs_pow2);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            const int w_s = mine.w_span & 0xfff, w_e = (mine.w_span >> 12) & 0xfff;
+            const bool has_rec = (unsigned)mine.w_span >= 0x1000000u;
+            const bool any_rec = __ballot(has_rec) != 0;
+            const bool in_lb_x = col >= lb_x0 && col < lb_x1;
+            int32_t *tile_lane = tile + lane * TR_STRIDE;
+            int32_t *img_cols = img + (size_t)gbase * vk.V * 3;            // first pixel of this group of columns
+            for (int r0 = 0; r0 < vk.V; r0 += TR_ROWS) {
+#pragma unroll 2
+                for (int rr_ = 0; rr_ < TR_ROWS; ++rr_) {
+                    const int d_v = r0 + rr_;
+                    const RowRec rr = row_tab[d_v];                         // one address for the wave: an LDS broadcast
+                    RowK rk;
+                    rk.kind = rr.kind;
+                    rk.distance = rr.distance;
+                    rk.light = rr.light;
+                    rk.ys = rr.ys;
+                    int R, G, B;
+                    const uint64_t in_wall = __ballot(d_v >= w_s && d_v < w_e);
+#define MG_PIXEL(WALL_)                                                                                                      \
+    pixel_pass<REC, STOCK, WALL_>(vk, t, pos_x, pos_y, rk, texts, transp, mine, entries, lane, d_v, cs, inv_cs, cs_pow2, text_to_cell, \
+                                  inv_ttc, ttc_pow2, fast_tex, tex_scale, cell_shift, R, G, B)
+                    if (!any_rec && in_wall == ~uint64_t(0)) MG_PIXEL(2);       // this row is wall in every column
+                    else if (!any_rec && in_wall == 0) MG_PIXEL(0);             // ... in none
+                    else MG_PIXEL(1);
+#undef MG_PIXEL
+                    if (d_v >= lb_y0 && d_v < lb_y1) {                          // wave-uniform: the life bar crosses this row
+                        if (in_lb_x) { R = 255; G = 0; B = 0; }
+                    }
+                    tile_lane[rr_ * 3] = R;
+                    tile_lane[rr_ * 3 + 1] = G;
+                    tile_lane[rr_ * 3 + 2] = B;
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                // flush: column c's TR_ROWS pixels are 6 pieces of 16 bytes, contiguous in the frame at (c * V + r0) * 12
+                constexpr int PPC = TR_ROWS * 3 / 4;
+#pragma unroll
+                for (int it = 0; it < PPC; ++it) {
+                    const uint32_t p = (uint32_t)(it * 64 + lane);
+                    const uint32_t c = (p * 43691u) >> 18;                      // p / 6 for p < 384
+                    const uint32_t part = p - c * PPC;
+                    if ((int)c < ncols) {
+                        const int32_t *src = tile + c * TR_STRIDE + part * 4;
+                        mz_v4i v;
+                        v.x = src[0]; v.y = src[1]; v.z = src[2]; v.w = src[3];
+                        __builtin_nontemporal_store(v, reinterpret_cast<mz_v4i *>(img_cols + ((size_t)c * vk.V + r0) * 3 + part * 4));
+                    }
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            }
+        }
+        return;
+    }
     const int col_step = n_waves >= 4 ? n_waves : 1;
     for (int gbase = 0; gbase < vk.H; gbase += n_waves * slab) {
         const int cbase = col_step == 1 ? gbase + wave * slab : gbase + wave;
@@ -1223,9 +1304,16 @@ extern "C" int mg_maze3d_step(const mg_maze_tasks *T, const mg_maze_view *view, 
         if (ov.waves) { n_waves = ov.waves; vk.slab = ov.slab; }
     }
     const int rec = (vk.V < 4096 && T->n * T->n <= 256) ? 1 : 2;
+    // the small-frame renderer (maze3d_step_kernel<., ., true>: lane = column in both passes, pixels through an LDS tile):
+    // one wave per env, whole tiles of TR_ROWS rows, the reference's int32 frames. MG_MAZE3D_NO_TRANS=1 keeps the general path
+    // (A/B timing and the bit-equality test of the two).
+    static const bool no_trans = getenv("MG_MAZE3D_NO_TRANS") != nullptr;
+    const bool trans = n_waves == 1 && vk.V % TR_ROWS == 0 && !vk.obs_u8 && !no_trans;
+    if (trans) vk.slab = 64;
     const size_t lds = ((sizeof(EnvShared) + 15) & ~size_t(15)) + sizeof(double) * T->n * T->n +
                        sizeof(uint32_t) * rec * vk.slab * vk.t_max * n_waves +
-                       2 * ((size_t)(T->n * T->n + 15) & ~size_t(15)) + sizeof(RowRec) * (size_t)((vk.V + 63) & ~63) + 32;
+                       2 * ((size_t)(T->n * T->n + 15) & ~size_t(15)) + sizeof(RowRec) * (size_t)((vk.V + 63) & ~63) + 32 +
+                       (trans ? sizeof(int32_t) * 64 * TR_STRIDE : 0);
     if (lds > 160 * 1024) return mg::set_error(MG_ERR_BAD_SIZE, "maze n=%d needs %zu B of LDS (> 160 KiB)", T->n, lds);
     const int device = mg::device_of(obs);
     mg::DeviceGuard guard(device);
@@ -1237,7 +1325,11 @@ extern "C" int mg_maze3d_step(const mg_maze_tasks *T, const mg_maze_view *view, 
             for (const void *fn : {reinterpret_cast<const void *>(maze3d_step_kernel<1, false>),
                                    reinterpret_cast<const void *>(maze3d_step_kernel<2, false>),
                                    reinterpret_cast<const void *>(maze3d_step_kernel<1, true>),
-                                   reinterpret_cast<const void *>(maze3d_step_kernel<2, true>)}) {
+                                   reinterpret_cast<const void *>(maze3d_step_kernel<2, true>),
+                                   reinterpret_cast<const void *>(maze3d_step_kernel<1, false, true>),
+                                   reinterpret_cast<const void *>(maze3d_step_kernel<2, false, true>),
+                                   reinterpret_cast<const void *>(maze3d_step_kernel<1, true, true>),
+                                   reinterpret_cast<const void *>(maze3d_step_kernel<2, true, true>)}) {
                 hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
                 if (e != hipSuccess) return mg::check_hip(e, "hipFuncSetAttribute(maze3d_step_kernel)");
             }
@@ -1263,11 +1355,16 @@ extern "C" int mg_maze3d_step(const mg_maze_tasks *T, const mg_maze_view *view, 
         stock = frexp(cs, &e2) == 0.5 && frexp(ttc, &e2) == 0.5 && vk.text_size_pow2 && (vk.TS & (vk.TS - 1)) == 0 && inv_ttc >= 1.0 &&
                 (vk.eff_max + cs * (double)T->n) * ((double)vk.TS * vk.inv_text_size) < 1073741824.0;
     }
-#define MG_MAZE3D_LAUNCH(REC_, STOCK_)                                                                                        \
-    hipLaunchKernelGGL((maze3d_step_kernel<REC_, STOCK_>), dim3(n), dim3(n_waves * mg::WAVE), lds, (hipStream_t)stream, *T, *st, vk, \
+#define MG_MAZE3D_LAUNCH(REC_, STOCK_, TRANS_)                                                                                \
+    hipLaunchKernelGGL((maze3d_step_kernel<REC_, STOCK_, TRANS_>), dim3(n), dim3(n_waves * mg::WAVE), lds, (hipStream_t)stream, *T, *st, vk, \
                        task_type, max_steps, continuous, pre_moved, auto_reset, n, action, obs, reward, reward64, done)
-    if (rec == 1) { if (stock) MG_MAZE3D_LAUNCH(1, true); else MG_MAZE3D_LAUNCH(1, false); }
-    else { if (stock) MG_MAZE3D_LAUNCH(2, true); else MG_MAZE3D_LAUNCH(2, false); }
+#define MG_MAZE3D_PICK(REC_)                                                                                                  \
+    do {                                                                                                                      \
+        if (trans) { if (stock) MG_MAZE3D_LAUNCH(REC_, true, true); else MG_MAZE3D_LAUNCH(REC_, false, true); }               \
+        else { if (stock) MG_MAZE3D_LAUNCH(REC_, true, false); else MG_MAZE3D_LAUNCH(REC_, false, false); }                  \
+    } while (0)
+    if (rec == 1) MG_MAZE3D_PICK(1); else MG_MAZE3D_PICK(2);
+#undef MG_MAZE3D_PICK
 #undef MG_MAZE3D_LAUNCH
     return mg::check_launch("maze3d_step_kernel");
 }

@@ -655,7 +655,10 @@ __global__ __launch_bounds__(WK_BLOCK) void walker_reset_kernel(mg_walker_topolo
 constexpr int WV = 64;
 // the joint-space inertia matrix and its Cholesky factor are only ever touched in the lower triangle: packed
 #define TRI(r, c) ((r) * ((r) + 1) / 2 + (c))
-constexpr int W_MAXC = 12;   // ground contacts kept per env (first W_MAXC penetrating spheres)
+#ifndef MG_W_MAXC
+#define MG_W_MAXC 12      // (timing experiments only — profiles/r05/walker_third_wave.txt: fewer kept contacts = a smaller Jh block)
+#endif
+constexpr int W_MAXC = MG_W_MAXC;   // ground contacts kept per env (first W_MAXC penetrating spheres)
 
 // Robot shape as template constants (all zero = read the topology at run time). Every MetaLocomotion variant of a
 // robot shares one shape (humanoid: 13 bodies, 17 hinges, 29 collision spheres, 17 capsules; ant: 13 / 8 / 25 / 13),
@@ -1520,7 +1523,10 @@ __device__ __forceinline__ void wave_substep(const mg_walker_topology &tp, const
     // (shape-generic instantiations: the whitened row stays in registers past this block — the Delassus sweep below builds its
     // matrix from it)
     constexpr bool ASPACE = true;
-    constexpr int NRA = NMAX <= 18 ? 30 : 24;    // constraint rows the multiplier-space sweep keeps in registers (one row of A per lane)
+#ifndef MG_WALKER_NRA_BIG
+#define MG_WALKER_NRA_BIG 24      // (experiments: 18 frees 12 VGPRs under a 168-VGPR cap; more rows take the velocity-space sweep)
+#endif
+    constexpr int NRA = NMAX <= 18 ? 30 : MG_WALKER_NRA_BIG;    // constraint rows the multiplier-space sweep keeps in registers (one row of A per lane)
     double w[NMAX];
     if (ASPACE) {
 #pragma unroll
@@ -1605,7 +1611,7 @@ __device__ __forceinline__ void wave_substep(const mg_walker_topology &tp, const
         case 2: delassus_sweep<12, NRA>(a, prm.solver_iterations, lane, fric_l, idg_l, c0, mu_l, g, lam); break;
         case 3: delassus_sweep<18, NRA>(a, prm.solver_iterations, lane, fric_l, idg_l, c0, mu_l, g, lam); break;
         default: delassus_sweep<NRA, NRA>(a, prm.solver_iterations, lane, fric_l, idg_l, c0, mu_l, g, lam); break;
-        case 4: delassus_sweep<24, NRA>(a, prm.solver_iterations, lane, fric_l, idg_l, c0, mu_l, g, lam); break;
+        case 4: delassus_sweep<(NRA < 24 ? NRA : 24), NRA>(a, prm.solver_iterations, lane, fric_l, idg_l, c0, mu_l, g, lam); break;
         }
         for (int k = 0; k < nr; ++k) {                               // y += Jh^T lambda
             const double lk = lane_value(lam, k);
@@ -1756,8 +1762,14 @@ __device__ __forceinline__ void wave_substep(const mg_walker_topology &tp, const
 // Waves per SIMD: two (<= 256 VGPRs) everywhere but in the tuned ant kernel — its 10.7 KB of LDS let 12 envs reside per CU, so
 // it is held to 168 VGPRs for a third wave (its 46 spilled VGPRs all sit after the sub-step loop): 0.402 -> 0.365 ms. The A1's
 // 18-slot kernel at 168 VGPRs spills inside the loop and loses (2.31 -> 2.45 ms); the humanoid is LDS-bound at 8 per CU.
+#ifndef MG_WALKER_HUM_WAVES
+#define MG_WALKER_HUM_WAVES 2     // waves per SIMD the tuned humanoid kernel is compiled for (experiments: 3 = a 168-VGPR cap)
+#endif
+#ifndef MG_WALKER_A1_WAVES
+#define MG_WALKER_A1_WAVES 2      // ... and the 12-hinge quadruped's (<18, ShapeDof<12>>)
+#endif
 template <int NMAX, class SH>
-__global__ __launch_bounds__(WV) __attribute__((amdgpu_waves_per_eu((NMAX <= 14 && SH::nb != 0) ? 3 : 2))) void walker_step_wave_kernel(mg_walker_topology tp, mg_walker_models ms,
+__global__ __launch_bounds__(WV) __attribute__((amdgpu_waves_per_eu((NMAX <= 14 && SH::nb != 0) ? 3 : (SH::nb != 0 ? MG_WALKER_HUM_WAVES : ((NMAX == 18 && SH::nj == 12) ? MG_WALKER_A1_WAVES : 2))))) void walker_step_wave_kernel(mg_walker_topology tp, mg_walker_models ms,
                                                               mg_walker_params prm, mg_walker_state st, int n_envs,
                                                               int maxr_flags, int scan_rounds, const float *action, float *obs,
                                                               float *reward, float *rewards5, uint8_t *done) {

@@ -308,6 +308,60 @@ def test_maze3d_batch_matches_oracle(continuous):
         assert bad == 0 if not continuous else bad <= 1e-3 * total
 
 
+@pytest.mark.parametrize("continuous", [False, True], ids=["discrete", "continuous"])
+@pytest.mark.parametrize("res", [(64, 64), (72, 40), (128, 32), (24, 24), (40, 24), (64, 48), (48, 20), (60, 60)],
+                         ids=lambda r: "%dx%d" % r)
+def test_maze3d_small_frame_renderer_every_pixel(res, continuous):
+    """The small-frame renderer of round 5 (maze3d_step_kernel<., ., TRANS>: one wave per env, lane = screen column in BOTH passes,
+    pixels through an LDS tile of 8 rows, linear dwordx4 stores; ray_caster_utils.py:66-209): every pixel of every frame against
+    the oracle for frame shapes that exercise its corners — 64 full lanes, a ragged last column group (72 = 64 + 8, 40 < 64), two
+    full groups (128), the smallest tile counts — next to shapes it does NOT take (20 and 60 rows are no multiple of 8: the general
+    path), both task types (life bar; translucent food cells / the goal overlay), SURVIVAL with food eaten and re-grown inside the
+    compared steps, discrete frames bit-identical and continuous ones too at these sizes."""
+    import metagym_amd
+    from metagym_amd.metamaze import MazeTaskSampler, MAZE_TASK_MANAGER
+    tex_u8 = MAZE_TASK_MANAGER.grounds.astype(np.uint8)
+    name = "meta-maze-continuous-3D-v0" if continuous else "meta-maze-discrete-3D-v0"
+    n = 48
+    for task_type in ("SURVIVAL", "ESCAPE"):
+        tt = mo.TASK_TYPES[task_type]
+        tasks = [MazeTaskSampler(n=9, allow_loops=False, step_reward=-0.01, goal_reward=1.0, food_density=0.15,
+                                 food_interval=3, seed=70 + s_) for s_ in range(6)]
+        env = metagym_amd.make(name, num_envs=n, device="cuda:0", max_steps=40, resolution=res, task_type=task_type)
+        env.set_task(tasks)
+        ids = env.task_id.cpu().numpy()
+        otasks, states = _oracle_batch(tasks, ids, tt)
+        view = mo.View(tex_u8, MAZE_TASK_MANAGER.ceil, res[0], res[1])
+        obs = env.reset().cpu().numpy()
+        rs = np.random.RandomState(res[0] * 100 + res[1])
+        bad = total = 0
+        for t in range(10):
+            for e in range(n):
+                want = mo.observe_3d(otasks[ids[e]], tt, view, states[e], int(continuous))
+                bad += int((obs[e] != want).sum())
+                total += want.size
+            if continuous:
+                a = np.stack([rs.uniform(-1.2, 1.2, n), rs.uniform(-0.5, 1.2, n)], 1).astype(np.float32)
+            else:
+                a = rs.choice(4, size=n, p=[0.2, 0.2, 0.1, 0.5])
+            obs, rew, done, info = env.step(torch.as_tensor(a))
+            obs, r64, d = obs.cpu().numpy(), env.reward64.cpu().numpy(), done.cpu().numpy()
+            for e in range(n):
+                if continuous:
+                    r, dd = mo.step_cont3d(otasks[ids[e]], tt, 40, states[e], float(a[e, 0]), float(a[e, 1]))
+                else:
+                    r, dd = mo.step_disc3d(otasks[ids[e]], tt, 40, states[e], int(a[e]))
+                assert r == r64[e] and dd == d[e], (task_type, t, e)
+            if d.any():
+                obs = env.reset(mask=done).cpu().numpy()
+                for e in np.nonzero(d)[0]:
+                    mo.reset(otasks[ids[e]], tt, states[e])
+        if continuous:
+            assert bad <= 1e-3 * total, (task_type, bad, total)
+        else:
+            assert bad == 0, (task_type, bad, total)
+
+
 def test_maze3d_ragged_batch_every_env_every_frame():
     """29 envs = three full groups of 8 (whose env -> workgroup assignment is rotated, mg::env_of_block) plus a
     ragged group of 5 (identity): every env's reward, done and full frame against the oracle on every step."""
