@@ -1077,6 +1077,12 @@ def main(argv=None):
         ev1 = torch.cuda.Event(enable_timing=True)
         ev0.record()
         ev1.record()
+        # the W untimed warm-up steps come IMMEDIATELY before the bracket (round 5): a timed region that starts after host-side
+        # bookkeeping (graph capture, episode counters) finds a GPU that has idled for milliseconds, and a 20-step region — 0.3 ms —
+        # then pays the clock ramp on every one of its launches (17.1 us per step single-shot against 15.7 us for the same 20
+        # eager steps repeated back to back, profiles/r05/quad_host_cost.txt)
+        for i in range(args.warmup):
+            step(i)
         barrier()
         torch.cuda.synchronize(dev)
         t0 = time.perf_counter()

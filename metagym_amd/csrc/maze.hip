@@ -402,6 +402,7 @@ struct ViewK {
     const double *col_cos, *col_sin;
     float ori_sin[4], ori_cos[4];
     const uint32_t *tex, *ceil_tex;
+    long long ceil_delta;   // ceil_tex - tex in texels: the cast selects an OFFSET from the one base `tex`, not one of two pointers
 };
 
 // int(x) truncation with python's unbounded ints replaced by clamping outside [lo-1, hi+1]
@@ -470,6 +471,31 @@ __device__ __forceinline__ ColRec bcast(const ColRec &r, int lane) {
     o.rcos_hp = bcast(r.rcos_hp, lane);
     o.w_oma = bcast(r.w_oma, lane); o.w_ratio = bcast(r.w_ratio, lane); o.w_light = bcast(r.w_light, lane);
     o.w_tex = bcast(r.w_tex, lane); o.w_span = bcast(r.w_span, lane);
+    return o;
+}
+
+// The record as the pixel pass consumes it: the float32 table values widened once per column, not once per pixel.
+struct ColRecD {
+    double cos_hp, cos_abs, sin_abs, rcos_hp, w_oma, w_ratio, w_light;
+    int w_tex, w_span;
+};
+__device__ __forceinline__ ColRecD widen(const ColRec &r) {
+    return ColRecD{(double)r.cos_hp, (double)r.cos_abs, (double)r.sin_abs, r.rcos_hp, r.w_oma, r.w_ratio, (double)r.w_light, r.w_tex, r.w_span};
+}
+// Broadcast of lane k's value through the LDS crossbar (ds_bpermute_b32 with one address for the wave): no LDS memory, no
+// VALU issue slot — the small-frame kernels are VALU-issue-bound and pay the broadcast once per 64-row column — and the value
+// arrives in a VGPR (uniform across the wave), which a VALU operand can be as well as an SGPR.
+__device__ __forceinline__ int xbar(int v, int lane4) { return __builtin_amdgcn_ds_bpermute(lane4, v); }
+__device__ __forceinline__ double xbar(double v, int lane4) {
+    return __hiloint2double(__builtin_amdgcn_ds_bpermute(lane4, __double2hiint(v)), __builtin_amdgcn_ds_bpermute(lane4, __double2loint(v)));
+}
+__device__ __forceinline__ ColRecD xbar(const ColRecD &r, int k) {
+    const int a = k << 2;
+    ColRecD o;
+    o.cos_hp = xbar(r.cos_hp, a); o.cos_abs = xbar(r.cos_abs, a); o.sin_abs = xbar(r.sin_abs, a); o.rcos_hp = xbar(r.rcos_hp, a);
+    o.w_oma = xbar(r.w_oma, a); o.w_ratio = xbar(r.w_ratio, a); o.w_light = xbar(r.w_light, a);
+    o.w_tex = xbar(r.w_tex, a);
+    o.w_span = bcast(r.w_span, k);        // the span steers scalar branches: this one word goes to an SGPR
     return o;
 }
 
@@ -616,34 +642,48 @@ __device__ __forceinline__ RowK row_constants(const ViewK &vk, const Task &t, in
 // The floor and the ceiling cast are ONE code path with per-lane selects (texture source, fog factor, translucency threshold,
 // "paint outside the maze"): a chunk that holds ceiling AND floor rows — every chunk of a frame up to 64 rows high — used
 // to run the cast twice, once per kind, each time with half its lanes.
-template <int REC, bool STOCK, int WALL>
+template <int REC, bool STOCK, int WALL, class Flush>
 __device__ __forceinline__ void pixel_pass(const ViewK &vk, const Task &t, double pos_x, double pos_y, const RowK &rk,
-                                           const uint8_t *texts, const double *transp, const ColRec &wc,
+                                           const uint8_t *texts, const double *transp, const ColRecD &wc,
                                            const uint32_t *entries, int k, int d_v, double cs, double inv_cs,
                                            int cs_pow2, double text_to_cell, double inv_ttc, int ttc_pow2,
-                                           int fast_tex, double tex_scale, int cell_shift, int &R, int &G, int &B) {
+                                           int fast_tex, double tex_scale, int cell_shift, Flush &&flush, int &R, int &G, int &B) {
     const int n = t.n, TS = vk.TS;
     R = G = B = 0;
     bool tflag = false;
     const int span = wc.w_span;
     const bool in_wall = WALL == 0 ? false : (WALL == 2 ? true : (d_v >= (span & 0xfff) && d_v < ((span >> 12) & 0xfff)));
     const int n_tr = WALL == 2 ? 0 : (int)((unsigned)span >> 24);
+    // ================= front half: every address and every fetch of this pixel ==========================================
+    // The wall texel first (its address needs the column record and the row only), then the cast's: in a chunk that holds wall
+    // AND floor / ceiling rows the two fetches travel together (round 5: they used to follow each other, and a third global
+    // load — see `ceil_delta` — stood in front of the cast's).
+    uint32_t wall_tx = 0;
+    if (WALL != 0 && in_wall) {                                               // :181-188
+        const double local_v = rk.ys * wc.w_ratio + t.agent_h;
+        double d_j = (STOCK || vk.text_size_pow2) ? local_v * vk.inv_text_size : local_v / vk.text_size;
+        d_j -= floor(d_j);
+        wall_tx = vk.tex[(uint32_t)(wc.w_tex + (int)(TS * d_j))];
+    }
     // A wall pixel overwrites whatever the floor / ceiling cast painted; the cast's only surviving
     // side effect is the transparent_array flag, which is read by the overlays alone. So the cast
     // can be skipped for wall pixels of columns without overlay records (bit-identical).
-    if (WALL != 2 && rk.kind != 0 && !(WALL == 1 && in_wall && n_tr == 0)) {
-        const bool fl = rk.kind == 1;                                         // floor :95-126, else ceiling :129-153
-        const double eff = div_by(rk.distance, (double)wc.cos_hp, wc.rcos_hp);
+    const bool cast = WALL != 2 && rk.kind != 0 && !(WALL == 1 && in_wall && n_tr == 0);
+    const bool fl = rk.kind == 1;                                             // floor :95-126, else ceiling :129-153
+    bool paint = false, inside = false;
+    uint32_t cast_tx = 0;
+    double a = 0.0, tr = 0.0;
+    if (cast) {
+        const double eff = div_by(rk.distance, wc.cos_hp, wc.rcos_hp);
         // fog a = clamp(2*eff/max_vision - 1, 0, 1): when 2*eff is clearly below max_vision the
         // rounded quotient cannot exceed 1, so a == 0 without performing the division
-        double a = 0.0;
         if (2.0 * eff > vk.max_vision_lo) {
             a = div_by(2.0 * eff, vk.max_vision, vk.inv_max_vision) - 1.0;
             a = a > 0.0 ? a : 0.0;
             a = a < 1.0 ? a : 1.0;
         }
-        const double hit_x = eff * (double)wc.cos_abs + pos_x;
-        const double hit_y = eff * (double)wc.sin_abs + pos_y;
+        const double hit_x = eff * wc.cos_abs + pos_x;
+        const double hit_y = eff * wc.sin_abs + pos_y;
         // Cell (i, j) and texel (ti, tj) of the hit point. When cell size, texture size and texture
         // resolution are powers of two (the stock task: 2.0, 1.0, 64) every scaling below is exact and
         // frac(frac(x / cs) * cs / ts) == frac(x / ts), so for x >= 0
@@ -679,9 +719,10 @@ __device__ __forceinline__ void pixel_pass(const ViewK &vk, const Task &t, doubl
             ti = cell_index(d_i * TS);
             tj = cell_index(d_j * TS);
         }
-        const bool inside = (unsigned)i < (unsigned)n && (unsigned)j < (unsigned)n;
+        inside = (unsigned)i < (unsigned)n && (unsigned)j < (unsigned)n;
         // the floor is painted inside the maze only (:117), the ceiling everywhere (:144-146)
-        if (inside || !fl) {
+        paint = inside || !fl;
+        if (paint) {
             // 24-bit multiplies are full rate (v_mad_u32_u24); cells and texture rows are far below 2^24
             const uint32_t cell = inside ? __umul24(i, n) + j : 0u;
 #ifdef MG_MAZE3D_KNOCKOUT_TEXADDR     /* timing experiment only: every lane fetches from one 256-byte stretch of the texture */
@@ -689,33 +730,43 @@ __device__ __forceinline__ void pixel_pass(const ViewK &vk, const Task &t, doubl
 #else
             const uint32_t row = __umul24((uint32_t)ti, TS) + (uint32_t)tj;
 #endif
-            const uint32_t *texel = fl ? vk.tex + (__umul24(__umul24((uint32_t)texts[cell], TS), TS) + row) : vk.ceil_tex + row;
-            const uint32_t tx = *texel;
-            const double alpha = fl ? a * rk.light : a;                       // :119 / :147
-            const double oma = 1.0 - alpha;
-#ifdef MG_MAZE3D_KNOCKOUT_COLOR      /* timing experiment only: no colour arithmetic */
-            R = (int)(tx & 255u) + (int)oma; G = (int)((tx >> 8) & 255u); B = (int)(tx >> 16);
-#else
-            R = (int)(rk.light * (oma * tex_r(tx)));
-            G = (int)(rk.light * (oma * tex_g(tx)));
-            B = (int)(rk.light * (oma * tex_b(tx)));
-#endif
-            const double tr = transp[cell];
-            if (__builtin_expect(inside && tr > (fl ? 0.01 : 0.0), 0)) {      // :121-126 (> 0.01) / :148-153 (> 0)
-                const double tf = tr * 0.50 + 0.10, om = 1.0 - tf;
-                R = (int)(om * (double)R);
-                G = (int)(om * (double)G + tf * 255.0);
-                B = (int)(om * (double)B);
-                tflag = true;
-            }
+            // (a select between the two kernarg POINTERS compiled into a select of their kernarg ADDRESSES and a vector load of the
+            // winner: a dependent global load in front of every texel fetch, at every frame size. One base, two offsets.)
+            const long long toff = fl ? (long long)(__umul24(__umul24((uint32_t)texts[cell], TS), TS) + row) : vk.ceil_delta + (long long)row;
+            cast_tx = vk.tex[toff];
+            tr = transp[cell];
         }
     }
-    if (WALL != 0 && in_wall) {                                               // :181-192
-        const double local_v = rk.ys * wc.w_ratio + t.agent_h;
-        double d_j = (STOCK || vk.text_size_pow2) ? local_v * vk.inv_text_size : local_v / vk.text_size;
-        d_j -= floor(d_j);
-        const uint32_t tx = vk.tex[(uint32_t)(wc.w_tex + (int)(TS * d_j))];
-        const double oma = wc.w_oma, light = (double)wc.w_light;
+    // ================= the PREVIOUS pixel's store goes out here ===========================================================
+    // gfx9-family vector memory returns in order and loads and stores share one counter (vmcnt): a wait for a texel fetched AFTER
+    // the previous chunk's frame store is also a wait for that store's acknowledgement from L2 — every chunk of every wave paid the
+    // write latency before its arithmetic could start (64 x 64 frames: stores alone 0.43 ms, everything but the stores ~0.5 ms, both
+    // 0.91 ms: no overlap at all). Issued here — after this pixel's fetches, before their first use — the store is the YOUNGEST
+    // operation in flight, the fetches are waited for with vmcnt(1), and the store's latency hides behind the colour arithmetic.
+    flush();
+    // ================= back half: colours =================================================================================
+    if (cast && paint) {
+        const uint32_t tx = cast_tx;
+        const double alpha = fl ? a * rk.light : a;                           // :119 / :147
+        const double oma = 1.0 - alpha;
+#ifdef MG_MAZE3D_KNOCKOUT_COLOR      /* timing experiment only: no colour arithmetic */
+        R = (int)(tx & 255u) + (int)oma; G = (int)((tx >> 8) & 255u); B = (int)(tx >> 16);
+#else
+        R = (int)(rk.light * (oma * tex_r(tx)));
+        G = (int)(rk.light * (oma * tex_g(tx)));
+        B = (int)(rk.light * (oma * tex_b(tx)));
+#endif
+        if (__builtin_expect(inside && tr > (fl ? 0.01 : 0.0), 0)) {          // :121-126 (> 0.01) / :148-153 (> 0)
+            const double tf = tr * 0.50 + 0.10, om = 1.0 - tf;
+            R = (int)(om * (double)R);
+            G = (int)(om * (double)G + tf * 255.0);
+            B = (int)(om * (double)B);
+            tflag = true;
+        }
+    }
+    if (WALL != 0 && in_wall) {                                               // :189-192
+        const uint32_t tx = wall_tx;
+        const double oma = wc.w_oma, light = wc.w_light;
         R = (int)(light * (oma * tex_r(tx)));
         G = (int)(light * (oma * tex_g(tx)));
         B = (int)(light * (oma * tex_b(tx)));
@@ -746,33 +797,30 @@ __device__ __forceinline__ void py_slice(long a, long b, long len, int &lo, int 
 }
 
 struct int3s { int x, y, z; };   // 12-byte pixel, stored with one dwordx3
+typedef int mz_v3i __attribute__((ext_vector_type(3)));
 
 // REC: words per translucent-cell record, 1 (compact) or 2. STOCK: the stock renderer configuration, decided on the host
 // (mg_maze3d_step) — every task's cell size the same power of two, texture size and resolution powers of two, int32 frames: the
 // run-time `is this a power of two` flags of the general kernel become constants, and with them go the correctly-rounded
 // divisions nobody takes, their scalar branches, the byte-output path and a quarter-rate 32-bit multiply in the store address.
-//
-// TRANS: the small-frame renderer (one wave per env, V a multiple of TR_ROWS, int32 frames). Pass B keeps lane = screen COLUMN:
-// every lane renders ITS column with its own record in registers — no per-column broadcast at all (11 v_readlane + 4 converts +
-// span decode + offset set-up per column were 40 % of the pixel pass at one 64-row chunk per column, profiles/r04/
-// maze3d_small_knockouts.txt) — while the row's constants are wave-uniform. A screen row is then "all ceiling", "all wall" or mixed
-// ACROSS columns, which happens far less often than a 64-row column being mixed along its height (always, at 64 rows), so most
-// rows run one of the two code paths instead of both. The pixels of TR_ROWS rows go through an LDS tile [64 columns][TR_ROWS * 3 + 1]
-// and leave as linear dwordx4 stores: 96 contiguous bytes per column, full 32-byte sectors.
-constexpr int TR_ROWS = 8, TR_STRIDE = TR_ROWS * 3 + 1;
-typedef int mz_v4i __attribute__((ext_vector_type(4)));
-
-#ifndef MG_MAZE3D_TRANS_WAVES
-#define MG_MAZE3D_TRANS_WAVES 4     // register budget of the TRANS kernels (LDS bounds them at ~11 one-wave envs per CU anyway)
+// SMALL: the one-wave-per-env instantiation (frames up to 64 x 64): a column is ONE 64-row chunk there, so what the general kernel
+// does once per column — the record's broadcast — is paid per chunk. It goes through the LDS crossbar instead of 13 v_readlane + 4
+// converts (xbar), and five waves per SIMD (all that the env's 8 KB of LDS admit) give the record's VGPR copy its registers.
+#ifndef MG_MAZE3D_PIPE_LARGE
+#define MG_MAZE3D_PIPE_LARGE 0     // (experiment knob: the deferred frame store in the multi-wave kernels too)
 #endif
-template <int REC, bool STOCK, bool TRANS = false>
-__global__ __launch_bounds__(MZ_BLOCK) __attribute__((amdgpu_waves_per_eu(TRANS ? MG_MAZE3D_TRANS_WAVES : 6))) void maze3d_step_kernel(mg_maze_tasks T, mg_maze_state st, ViewK vk,
+#ifndef MG_MAZE3D_LARGE_WAVES
+#define MG_MAZE3D_LARGE_WAVES 6
+#endif
+template <int REC, bool STOCK, bool SMALL = false>
+__global__ __launch_bounds__(MZ_BLOCK) __attribute__((amdgpu_waves_per_eu(SMALL ? 5 : MG_MAZE3D_LARGE_WAVES))) void maze3d_step_kernel(mg_maze_tasks T, mg_maze_state st, ViewK vk,
                                                                int task_type, int max_steps, int continuous,
                                                                int pre_moved, int auto_reset, int n_envs,
                                                                const void *action,
                                                                void *obs, float *reward, double *reward64,
                                                                uint8_t *done) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr bool PIPE = SMALL || MG_MAZE3D_PIPE_LARGE != 0;      // the frame store of a pixel is issued one chunk later (pixel_pass)
     const int e = mg::env_of_block(blockIdx.x, n_envs);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n_threads = blockDim.x, n_waves = n_threads >> 6;   // 1, 2 or 4 waves per env (host picks by frame size)
@@ -793,7 +841,6 @@ __global__ __launch_bounds__(MZ_BLOCK) __attribute__((amdgpu_waves_per_eu(TRANS 
     off = (off + 15) & ~size_t(15);
     RowRec *row_tab = reinterpret_cast<RowRec *>(smem + off);      // [V rounded up to 64]: distance, light, ys, kind of a screen row
     const int v_pad = (vk.V + 63) & ~63;
-    int32_t *tile = reinterpret_cast<int32_t *>(smem + off + sizeof(RowRec) * (size_t)v_pad);   // TRANS only: [64][TR_STRIDE]
 
     // ---- phase 0: transition + scalar part of evaluation_rule (one thread) ----------------------
     if (tid == 0) {
@@ -894,72 +941,6 @@ __global__ __launch_bounds__(MZ_BLOCK) __attribute__((amdgpu_waves_per_eu(TRANS 
     // env instead of four streams 32 columns (98 KB at 256 x 256) apart. The frame stores alone (everything else knocked out) run
     // 6.5 % faster that way at 256 x 256 (2.37 -> 2.22 ms, profiles/r04/maze3d_store_pattern.txt); small frames (one or two waves
     // per env) keep consecutive columns per wave, which measured faster there.
-    if constexpr (TRANS) {
-        // (one wave per env: blockDim.x == 64, vk.slab == 64, vk.V % TR_ROWS == 0, int32 frames — mg_maze3d_step guarantees it)
-        for (int gbase = 0; gbase < vk.H; gbase += 64) {
-            const int ncols = min(64, vk.H - gbase);
-            // a lane past the last column shadows it (valid arithmetic everywhere, its pixels are never flushed)
-            const int col = gbase + min(lane, ncols - 1);
-            const ColRec mine = column_pass<REC, STOCK>(vk, t, *es, walls, texts, transp, col, lane, entries, cs, inv_cs, cs_pow2);
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            const int w_s = mine.w_span & 0xfff, w_e = (mine.w_span >> 12) & 0xfff;
-            const bool has_rec = (unsigned)mine.w_span >= 0x1000000u;
-            const bool any_rec = __ballot(has_rec) != 0;
-            const bool in_lb_x = col >= lb_x0 && col < lb_x1;
-            int32_t *tile_lane = tile + lane * TR_STRIDE;
-            int32_t *img_cols = img + (size_t)gbase * vk.V * 3;            // first pixel of this group of columns
-            for (int r0 = 0; r0 < vk.V; r0 += TR_ROWS) {
-#pragma unroll 2
-                for (int rr_ = 0; rr_ < TR_ROWS; ++rr_) {
-                    const int d_v = r0 + rr_;
-                    const RowRec rr = row_tab[d_v];                         // one address for the wave: an LDS broadcast
-                    RowK rk;
-                    rk.kind = rr.kind;
-                    rk.distance = rr.distance;
-                    rk.light = rr.light;
-                    rk.ys = rr.ys;
-                    int R, G, B;
-                    const uint64_t in_wall = __ballot(d_v >= w_s && d_v < w_e);
-#define MG_PIXEL(WALL_)                                                                                                      \
-    pixel_pass<REC, STOCK, WALL_>(vk, t, pos_x, pos_y, rk, texts, transp, mine, entries, lane, d_v, cs, inv_cs, cs_pow2, text_to_cell, \
-                                  inv_ttc, ttc_pow2, fast_tex, tex_scale, cell_shift, R, G, B)
-                    if (!any_rec && in_wall == ~uint64_t(0)) MG_PIXEL(2);       // this row is wall in every column
-                    else if (!any_rec && in_wall == 0) MG_PIXEL(0);             // ... in none
-                    else MG_PIXEL(1);
-#undef MG_PIXEL
-                    if (d_v >= lb_y0 && d_v < lb_y1) {                          // wave-uniform: the life bar crosses this row
-                        if (in_lb_x) { R = 255; G = 0; B = 0; }
-                    }
-                    tile_lane[rr_ * 3] = R;
-                    tile_lane[rr_ * 3 + 1] = G;
-                    tile_lane[rr_ * 3 + 2] = B;
-                }
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                // flush: column c's TR_ROWS pixels are 6 pieces of 16 bytes, contiguous in the frame at (c * V + r0) * 12
-                constexpr int PPC = TR_ROWS * 3 / 4;
-#pragma unroll
-                for (int it = 0; it < PPC; ++it) {
-                    const uint32_t p = (uint32_t)(it * 64 + lane);
-                    const uint32_t c = (p * 43691u) >> 18;                      // p / 6 for p < 384
-                    const uint32_t part = p - c * PPC;
-                    if ((int)c < ncols) {
-                        const int32_t *src = tile + c * TR_STRIDE + part * 4;
-                        mz_v4i v;
-                        v.x = src[0]; v.y = src[1]; v.z = src[2]; v.w = src[3];
-                        __builtin_nontemporal_store(v, reinterpret_cast<mz_v4i *>(img_cols + ((size_t)c * vk.V + r0) * 3 + part * 4));
-                    }
-                }
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            }
-        }
-        return;
-    }
     const int col_step = n_waves >= 4 ? n_waves : 1;
     for (int gbase = 0; gbase < vk.H; gbase += n_waves * slab) {
         const int cbase = col_step == 1 ? gbase + wave * slab : gbase + wave;
@@ -967,6 +948,7 @@ __global__ __launch_bounds__(MZ_BLOCK) __attribute__((amdgpu_waves_per_eu(TRANS 
         ColRec mine{};
         if (lane < ncols)
             mine = column_pass<REC, STOCK>(vk, t, *es, walls, texts, transp, cbase + lane * col_step, lane, entries, cs, inv_cs, cs_pow2);
+        const ColRecD mine_d = widen(mine);       // (SMALL: widened here, once per lane = per column, and broadcast as doubles)
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -979,13 +961,59 @@ __global__ __launch_bounds__(MZ_BLOCK) __attribute__((amdgpu_waves_per_eu(TRANS 
         continue;
 #endif
         const RowRec *row_lane = row_tab + lane;                  // this lane's row of every 64-row chunk: one add per chunk away
+        const __amdgpu_buffer_rsrc_t frame = __builtin_amdgcn_make_buffer_rsrc(
+            obs_u8 ? static_cast<void *>(img8) : static_cast<void *>(img), 0, (int)((uint32_t)vk.H * (uint32_t)vk.V * px_bytes), 0x00020000);
+        // The pixel computed by one chunk iteration is stored DURING THE NEXT one (PIPE; see pixel_pass: after that pixel's texel
+        // fetches went out, before they are used), so a fetch never waits behind the frame store in the in-order vmcnt queue.
+        int p_r = 0, p_g = 0, p_b = 0;
+        uint32_t p_off = 0;
+        bool p_ok = false;
+        auto store_pixel = [&](int r_, int g_, int b_, uint32_t off_) {
+            if (obs_u8) {      // non-parity fast path: saturate to a byte
+                uint8_t *q = img8 + off_;
+                __builtin_nontemporal_store((uint8_t)min(max(r_, 0), 255), q);
+                __builtin_nontemporal_store((uint8_t)min(max(g_, 0), 255), q + 1);
+                __builtin_nontemporal_store((uint8_t)min(max(b_, 0), 255), q + 2);
+            } else {
+                // streaming stores: a 12.9 GB frame batch can never stay in the 32 MB of L2, but the
+                // textures and task tables it would evict are re-read by every pixel (-7 % at 256x256)
+                int *q = reinterpret_cast<int *>(reinterpret_cast<char *>(img) + off_);
+                __builtin_nontemporal_store(r_, q);
+                __builtin_nontemporal_store(g_, q + 1);
+                __builtin_nontemporal_store(b_, q + 2);
+            }
+        };
+        // PIPE: a BUFFER store with the frame as its range — a lane without a pending pixel (the first chunk; rows past V in a
+        // ragged last chunk) sends an out-of-range offset and the hardware drops its write. No branch around the store: the
+        // wait-count pass can then prove the store is in flight when the fetches are awaited and emits vmcnt(1); behind an
+        // `if (pending)` it has to assume the store may be missing and waits with vmcnt(0) — for the store as well.
+        auto flush = [&]() {
+            if constexpr (PIPE) {
+                const uint32_t o = p_ok ? p_off : 0x80000000u;      // (frames are < 2^31 bytes: res_h <= 32767, res_v <= 4095)
+                if (obs_u8) {
+                    __builtin_amdgcn_raw_buffer_store_b8((uint8_t)min(max(p_r, 0), 255), frame, o, 0, 2);
+                    __builtin_amdgcn_raw_buffer_store_b8((uint8_t)min(max(p_g, 0), 255), frame, o + 1u, 0, 2);
+                    __builtin_amdgcn_raw_buffer_store_b8((uint8_t)min(max(p_b, 0), 255), frame, o + 2u, 0, 2);
+                } else {
+                    mz_v3i v;
+                    v.x = p_r; v.y = p_g; v.z = p_b;
+                    __builtin_amdgcn_raw_buffer_store_b96(v, frame, o, 0, 2);       // aux 2 = nt, like the streaming global stores
+                }
+            }
+        };
         for (int k = 0; k < ncols; ++k) {
-            const ColRec wc = bcast(mine, k);
+            ColRecD wc;
+            if constexpr (SMALL) wc = xbar(mine_d, k);
+            else wc = widen(bcast(mine, k));
             const int col = __builtin_amdgcn_readfirstlane(cbase + k * col_step);
             const bool in_lb_x = col >= lb_x0 && col < lb_x1;
             // frame-relative byte offset of this lane's pixel in chunk 0 of the column (< 4 GiB); a chunk further down is a
             // scalar away — no per-pixel multiply (a 32-bit one is quarter rate)
-            uint32_t pix_lane = ((uint32_t)(col * vk.V) + (uint32_t)lane) * px_bytes;
+            const uint32_t px_index = (uint32_t)(col * vk.V) + (uint32_t)lane;
+            // (x * 12 as two full-rate shift-adds: v_mul_lo_u32 is quarter rate, and at one chunk per column this is per-chunk work)
+            uint32_t px3;
+            asm("v_lshl_add_u32 %0, %1, 1, %1" : "=v"(px3) : "v"(px_index));       // (spelled out: the optimiser folds it back into the multiply)
+            uint32_t pix_lane = obs_u8 ? px3 : px3 << 2;
             asm volatile("" : "+v"(pix_lane));      // (keep the product: folded into the chunk offset it is multiplied again per pixel)
             uint32_t chunk_bytes = 0;                 // rbase * px_bytes, carried as a scalar of its own (an add per chunk)
             for (int rbase = 0; rbase < vk.V; rbase += 64, chunk_bytes += 64u * px_bytes) {
@@ -1003,9 +1031,10 @@ __global__ __launch_bounds__(MZ_BLOCK) __attribute__((amdgpu_waves_per_eu(TRANS 
                 const int w_s = wc.w_span & 0xfff, w_e = (wc.w_span >> 12) & 0xfff;
 #define MG_PIXEL(WALL_)                                                                                                      \
     pixel_pass<REC, STOCK, WALL_>(vk, t, pos_x, pos_y, rk, texts, transp, wc, entries, k, d_v, cs, inv_cs, cs_pow2, text_to_cell, \
-                                  inv_ttc, ttc_pow2, fast_tex, tex_scale, cell_shift, R, G, B)
+                                  inv_ttc, ttc_pow2, fast_tex, tex_scale, cell_shift, flush, R, G, B)
 #ifdef MG_MAZE3D_KNOCKOUT_COMPUTE     /* timing experiment only: the frame stores alone, in the kernel's own pattern */
                 R = d_v + w_s; G = col; B = rr.kind;
+                flush();
 #else
                 if ((unsigned)wc.w_span < 0x1000000u && rbase >= w_s && rbase + 64 <= w_e) MG_PIXEL(2);
                 else if ((unsigned)wc.w_span < 0x1000000u && (rbase + 64 <= w_s || rbase >= w_e)) MG_PIXEL(0);
@@ -1016,23 +1045,15 @@ __global__ __launch_bounds__(MZ_BLOCK) __attribute__((amdgpu_waves_per_eu(TRANS 
                     if (d_v >= lb_y0 && d_v < lb_y1) { R = 255; G = 0; B = 0; }
                 }
                 const uint32_t off = pix_lane + chunk_bytes;
-                if (row_ok) {
-                    if (obs_u8) {      // non-parity fast path: saturate to a byte
-                        uint8_t *q = img8 + off;
-                        __builtin_nontemporal_store((uint8_t)min(max(R, 0), 255), q);
-                        __builtin_nontemporal_store((uint8_t)min(max(G, 0), 255), q + 1);
-                        __builtin_nontemporal_store((uint8_t)min(max(B, 0), 255), q + 2);
-                    } else {
-                        // streaming stores: a 12.9 GB frame batch can never stay in the 32 MB of L2, but the
-                        // textures and task tables it would evict are re-read by every pixel (-7 % at 256x256)
-                        int *q = reinterpret_cast<int *>(reinterpret_cast<char *>(img) + off);
-                        __builtin_nontemporal_store(R, q);
-                        __builtin_nontemporal_store(G, q + 1);
-                        __builtin_nontemporal_store(B, q + 2);
-                    }
+                if constexpr (PIPE) {
+                    p_r = R; p_g = G; p_b = B; p_off = off; p_ok = row_ok;
+                } else {
+                    if (row_ok) store_pixel(R, G, B, off);
                 }
             }
         }
+        flush();            // the last pixel of this group of columns
+        p_ok = false;
         __builtin_amdgcn_wave_barrier();
     }
 }
@@ -1271,6 +1292,7 @@ extern "C" int mg_maze3d_step(const mg_maze_tasks *T, const mg_maze_view *view, 
     for (int i = 0; i < 4; ++i) { vk.ori_sin[i] = view->ori_sin[i]; vk.ori_cos[i] = view->ori_cos[i]; }
     vk.tex = view->textures;
     vk.ceil_tex = view->ceil_texture;
+    vk.ceil_delta = (long long)(((intptr_t)view->ceil_texture - (intptr_t)view->textures) / (intptr_t)sizeof(uint32_t));
     // bound on translucent records per ray: one per DDA step plus the start cell. A ray advances
     // at least one cell per step and stops at max_vision or at the maze border.
     vk.t_max = 2 * T->n + 1;
@@ -1304,16 +1326,9 @@ extern "C" int mg_maze3d_step(const mg_maze_tasks *T, const mg_maze_view *view, 
         if (ov.waves) { n_waves = ov.waves; vk.slab = ov.slab; }
     }
     const int rec = (vk.V < 4096 && T->n * T->n <= 256) ? 1 : 2;
-    // the small-frame renderer (maze3d_step_kernel<., ., true>: lane = column in both passes, pixels through an LDS tile):
-    // one wave per env, whole tiles of TR_ROWS rows, the reference's int32 frames. MG_MAZE3D_NO_TRANS=1 keeps the general path
-    // (A/B timing and the bit-equality test of the two).
-    static const bool no_trans = getenv("MG_MAZE3D_NO_TRANS") != nullptr;
-    const bool trans = n_waves == 1 && vk.V % TR_ROWS == 0 && !vk.obs_u8 && !no_trans;
-    if (trans) vk.slab = 64;
     const size_t lds = ((sizeof(EnvShared) + 15) & ~size_t(15)) + sizeof(double) * T->n * T->n +
                        sizeof(uint32_t) * rec * vk.slab * vk.t_max * n_waves +
-                       2 * ((size_t)(T->n * T->n + 15) & ~size_t(15)) + sizeof(RowRec) * (size_t)((vk.V + 63) & ~63) + 32 +
-                       (trans ? sizeof(int32_t) * 64 * TR_STRIDE : 0);
+                       2 * ((size_t)(T->n * T->n + 15) & ~size_t(15)) + sizeof(RowRec) * (size_t)((vk.V + 63) & ~63) + 32;
     if (lds > 160 * 1024) return mg::set_error(MG_ERR_BAD_SIZE, "maze n=%d needs %zu B of LDS (> 160 KiB)", T->n, lds);
     const int device = mg::device_of(obs);
     mg::DeviceGuard guard(device);
@@ -1355,12 +1370,16 @@ extern "C" int mg_maze3d_step(const mg_maze_tasks *T, const mg_maze_view *view, 
         stock = frexp(cs, &e2) == 0.5 && frexp(ttc, &e2) == 0.5 && vk.text_size_pow2 && (vk.TS & (vk.TS - 1)) == 0 && inv_ttc >= 1.0 &&
                 (vk.eff_max + cs * (double)T->n) * ((double)vk.TS * vk.inv_text_size) < 1073741824.0;
     }
-#define MG_MAZE3D_LAUNCH(REC_, STOCK_, TRANS_)                                                                                \
-    hipLaunchKernelGGL((maze3d_step_kernel<REC_, STOCK_, TRANS_>), dim3(n), dim3(n_waves * mg::WAVE), lds, (hipStream_t)stream, *T, *st, vk, \
+    // one wave per env: the SMALL instantiation (record broadcast through the LDS crossbar). MG_MAZE3D_NO_SMALL=1 keeps the general
+    // one for A/B timing; the frames are the same bit for bit either way (same arithmetic, another route for the column record).
+    static const bool no_small = getenv("MG_MAZE3D_NO_SMALL") != nullptr;
+    const bool small = n_waves == 1 && !no_small;
+#define MG_MAZE3D_LAUNCH(REC_, STOCK_, SMALL_)                                                                                \
+    hipLaunchKernelGGL((maze3d_step_kernel<REC_, STOCK_, SMALL_>), dim3(n), dim3(n_waves * mg::WAVE), lds, (hipStream_t)stream, *T, *st, vk, \
                        task_type, max_steps, continuous, pre_moved, auto_reset, n, action, obs, reward, reward64, done)
 #define MG_MAZE3D_PICK(REC_)                                                                                                  \
     do {                                                                                                                      \
-        if (trans) { if (stock) MG_MAZE3D_LAUNCH(REC_, true, true); else MG_MAZE3D_LAUNCH(REC_, false, true); }               \
+        if (small) { if (stock) MG_MAZE3D_LAUNCH(REC_, true, true); else MG_MAZE3D_LAUNCH(REC_, false, true); }               \
         else { if (stock) MG_MAZE3D_LAUNCH(REC_, true, false); else MG_MAZE3D_LAUNCH(REC_, false, false); }                  \
     } while (0)
     if (rec == 1) MG_MAZE3D_PICK(1); else MG_MAZE3D_PICK(2);

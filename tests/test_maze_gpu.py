@@ -312,12 +312,14 @@ def test_maze3d_batch_matches_oracle(continuous):
 @pytest.mark.parametrize("res", [(64, 64), (72, 40), (128, 32), (24, 24), (40, 24), (64, 48), (48, 20), (60, 60)],
                          ids=lambda r: "%dx%d" % r)
 def test_maze3d_small_frame_renderer_every_pixel(res, continuous):
-    """The small-frame renderer of round 5 (maze3d_step_kernel<., ., TRANS>: one wave per env, lane = screen column in BOTH passes,
-    pixels through an LDS tile of 8 rows, linear dwordx4 stores; ray_caster_utils.py:66-209): every pixel of every frame against
-    the oracle for frame shapes that exercise its corners — 64 full lanes, a ragged last column group (72 = 64 + 8, 40 < 64), two
-    full groups (128), the smallest tile counts — next to shapes it does NOT take (20 and 60 rows are no multiple of 8: the general
-    path), both task types (life bar; translucent food cells / the goal overlay), SURVIVAL with food eaten and re-grown inside the
-    compared steps, discrete frames bit-identical and continuous ones too at these sizes."""
+    """The one-wave-per-env instantiation of the renderer (maze3d_step_kernel<., ., SMALL>, frames up to 64 x 64 pixels: the column
+    record broadcast through the LDS crossbar, the frame store deferred by one chunk and issued as a buffer store whose range is the
+    env's frame; ray_caster_utils.py:66-209): every pixel of every frame against the oracle for frame shapes that exercise its
+    corners — a full 64-row chunk per column, ragged last chunks (40, 24, 20, 60 rows: lanes past V must store nothing, and with a
+    deferred store "nothing" is an out-of-range buffer offset), several column groups per wave (72 = 32 + 32 + 8, 128), both task
+    types (life bar; translucent food cells / the goal overlay), food eaten and re-grown inside the compared steps; discrete
+    frames bit-identical, continuous ones to the usual 99.9 %. (Round 5 also built a transposed renderer on these shapes — lane =
+    column in the pixel pass too — which passed this test and was 2.7x slower: profiles/r05/maze3d_small_frames.txt.)"""
     import metagym_amd
     from metagym_amd.metamaze import MazeTaskSampler, MAZE_TASK_MANAGER
     tex_u8 = MAZE_TASK_MANAGER.grounds.astype(np.uint8)
