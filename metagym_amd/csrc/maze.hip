@@ -482,22 +482,14 @@ struct ColRecD {
 __device__ __forceinline__ ColRecD widen(const ColRec &r) {
     return ColRecD{(double)r.cos_hp, (double)r.cos_abs, (double)r.sin_abs, r.rcos_hp, r.w_oma, r.w_ratio, (double)r.w_light, r.w_tex, r.w_span};
 }
-// Broadcast of lane k's value through the LDS crossbar (ds_bpermute_b32 with one address for the wave): no LDS memory, no
-// VALU issue slot — the small-frame kernels are VALU-issue-bound and pay the broadcast once per 64-row column — and the value
-// arrives in a VGPR (uniform across the wave), which a VALU operand can be as well as an SGPR.
-__device__ __forceinline__ int xbar(int v, int lane4) { return __builtin_amdgcn_ds_bpermute(lane4, v); }
-__device__ __forceinline__ double xbar(double v, int lane4) {
-    return __hiloint2double(__builtin_amdgcn_ds_bpermute(lane4, __double2hiint(v)), __builtin_amdgcn_ds_bpermute(lane4, __double2loint(v)));
-}
-__device__ __forceinline__ ColRecD xbar(const ColRecD &r, int k) {
-    const int a = k << 2;
-    ColRecD o;
-    o.cos_hp = xbar(r.cos_hp, a); o.cos_abs = xbar(r.cos_abs, a); o.sin_abs = xbar(r.sin_abs, a); o.rcos_hp = xbar(r.rcos_hp, a);
-    o.w_oma = xbar(r.w_oma, a); o.w_ratio = xbar(r.w_ratio, a); o.w_light = xbar(r.w_light, a);
-    o.w_tex = xbar(r.w_tex, a);
-    o.w_span = bcast(r.w_span, k);        // the span steers scalar branches: this one word goes to an SGPR
-    return o;
-}
+// SMALL kernels: pass A leaves each column's widened record in LDS (64 bytes, one slot per lane of the slab) and the pixel pass
+// reads slot k with four ds_read_b128 at ONE address for the wave — LDS broadcasts, no bank conflict, no VALU issue slot (the
+// general kernel's 13 v_readlane + 4 converts per column are VALU work, and at one 64-row chunk per column the 64 x 64 kernel is
+// VALU-bound: 82 % busy, profiles/r05/pmc_maze3d_64x64.json). The values arrive in VGPRs, uniform across the wave; only the span
+// word, which steers scalar branches, is also lifted into an SGPR. (ds_bpermute_b32 broadcasts were tried first: 15 of them per
+// column saturate the LDS pipe — 106 % busy — and the kernel got 6 % slower.)
+struct __attribute__((aligned(16))) ColRecLds { double cos_hp, cos_abs, sin_abs, rcos_hp, w_oma, w_ratio, w_light; int w_tex, w_span; };
+static_assert(sizeof(ColRecLds) == 64, "four ds_read_b128");
 
 // Pass A, lane = screen column: ray_caster_utils.py:84-90 (direction tables), :11-62 (DDA_2D) and the
 // per-column parts of :155-205.
@@ -820,7 +812,10 @@ __global__ __launch_bounds__(MZ_BLOCK) __attribute__((amdgpu_waves_per_eu(SMALL 
                                                                void *obs, float *reward, double *reward64,
                                                                uint8_t *done) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    constexpr bool PIPE = SMALL || MG_MAZE3D_PIPE_LARGE != 0;      // the frame store of a pixel is issued one chunk later (pixel_pass)
+#ifndef MG_MAZE3D_PIPE_SMALL
+#define MG_MAZE3D_PIPE_SMALL 1
+#endif
+    constexpr bool PIPE = SMALL ? MG_MAZE3D_PIPE_SMALL != 0 : MG_MAZE3D_PIPE_LARGE != 0;      // the frame store of a pixel is issued one chunk later (pixel_pass)
     const int e = mg::env_of_block(blockIdx.x, n_envs);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n_threads = blockDim.x, n_waves = n_threads >> 6;   // 1, 2 or 4 waves per env (host picks by frame size)
@@ -841,6 +836,7 @@ __global__ __launch_bounds__(MZ_BLOCK) __attribute__((amdgpu_waves_per_eu(SMALL 
     off = (off + 15) & ~size_t(15);
     RowRec *row_tab = reinterpret_cast<RowRec *>(smem + off);      // [V rounded up to 64]: distance, light, ys, kind of a screen row
     const int v_pad = (vk.V + 63) & ~63;
+    ColRecLds *colrec = reinterpret_cast<ColRecLds *>(smem + off + sizeof(RowRec) * (size_t)v_pad);   // SMALL only: [slab]
 
     // ---- phase 0: transition + scalar part of evaluation_rule (one thread) ----------------------
     if (tid == 0) {
@@ -948,7 +944,10 @@ __global__ __launch_bounds__(MZ_BLOCK) __attribute__((amdgpu_waves_per_eu(SMALL 
         ColRec mine{};
         if (lane < ncols)
             mine = column_pass<REC, STOCK>(vk, t, *es, walls, texts, transp, cbase + lane * col_step, lane, entries, cs, inv_cs, cs_pow2);
-        const ColRecD mine_d = widen(mine);       // (SMALL: widened here, once per lane = per column, and broadcast as doubles)
+        if constexpr (SMALL) {                    // widened once per lane = per column, parked in LDS for the pixel pass
+            const ColRecD d = widen(mine);
+            colrec[lane] = ColRecLds{d.cos_hp, d.cos_abs, d.sin_abs, d.rcos_hp, d.w_oma, d.w_ratio, d.w_light, d.w_tex, d.w_span};
+        }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -1003,8 +1002,11 @@ __global__ __launch_bounds__(MZ_BLOCK) __attribute__((amdgpu_waves_per_eu(SMALL 
         };
         for (int k = 0; k < ncols; ++k) {
             ColRecD wc;
-            if constexpr (SMALL) wc = xbar(mine_d, k);
-            else wc = widen(bcast(mine, k));
+            if constexpr (SMALL) {
+                const ColRecLds r = colrec[k];                       // uniform address: LDS broadcast reads
+                wc = ColRecD{r.cos_hp, r.cos_abs, r.sin_abs, r.rcos_hp, r.w_oma, r.w_ratio, r.w_light, r.w_tex,
+                             __builtin_amdgcn_readfirstlane(r.w_span)};
+            } else wc = widen(bcast(mine, k));
             const int col = __builtin_amdgcn_readfirstlane(cbase + k * col_step);
             const bool in_lb_x = col >= lb_x0 && col < lb_x1;
             // frame-relative byte offset of this lane's pixel in chunk 0 of the column (< 4 GiB); a chunk further down is a
@@ -1033,7 +1035,7 @@ __global__ __launch_bounds__(MZ_BLOCK) __attribute__((amdgpu_waves_per_eu(SMALL 
     pixel_pass<REC, STOCK, WALL_>(vk, t, pos_x, pos_y, rk, texts, transp, wc, entries, k, d_v, cs, inv_cs, cs_pow2, text_to_cell, \
                                   inv_ttc, ttc_pow2, fast_tex, tex_scale, cell_shift, flush, R, G, B)
 #ifdef MG_MAZE3D_KNOCKOUT_COMPUTE     /* timing experiment only: the frame stores alone, in the kernel's own pattern */
-                R = d_v + w_s; G = col; B = rr.kind;
+                R = d_v + w_s; G = col; B = rk.kind;
                 flush();
 #else
                 if ((unsigned)wc.w_span < 0x1000000u && rbase >= w_s && rbase + 64 <= w_e) MG_PIXEL(2);
@@ -1326,9 +1328,12 @@ extern "C" int mg_maze3d_step(const mg_maze_tasks *T, const mg_maze_view *view, 
         if (ov.waves) { n_waves = ov.waves; vk.slab = ov.slab; }
     }
     const int rec = (vk.V < 4096 && T->n * T->n <= 256) ? 1 : 2;
+    static const bool no_small = getenv("MG_MAZE3D_NO_SMALL") != nullptr;
+    const bool small = n_waves == 1 && !no_small;       // one wave per env: the SMALL instantiation (column records parked in LDS)
     const size_t lds = ((sizeof(EnvShared) + 15) & ~size_t(15)) + sizeof(double) * T->n * T->n +
                        sizeof(uint32_t) * rec * vk.slab * vk.t_max * n_waves +
-                       2 * ((size_t)(T->n * T->n + 15) & ~size_t(15)) + sizeof(RowRec) * (size_t)((vk.V + 63) & ~63) + 32;
+                       2 * ((size_t)(T->n * T->n + 15) & ~size_t(15)) + sizeof(RowRec) * (size_t)((vk.V + 63) & ~63) + 32 +
+                       (small ? sizeof(ColRecLds) * (size_t)vk.slab : 0);
     if (lds > 160 * 1024) return mg::set_error(MG_ERR_BAD_SIZE, "maze n=%d needs %zu B of LDS (> 160 KiB)", T->n, lds);
     const int device = mg::device_of(obs);
     mg::DeviceGuard guard(device);
@@ -1370,10 +1375,8 @@ extern "C" int mg_maze3d_step(const mg_maze_tasks *T, const mg_maze_view *view, 
         stock = frexp(cs, &e2) == 0.5 && frexp(ttc, &e2) == 0.5 && vk.text_size_pow2 && (vk.TS & (vk.TS - 1)) == 0 && inv_ttc >= 1.0 &&
                 (vk.eff_max + cs * (double)T->n) * ((double)vk.TS * vk.inv_text_size) < 1073741824.0;
     }
-    // one wave per env: the SMALL instantiation (record broadcast through the LDS crossbar). MG_MAZE3D_NO_SMALL=1 keeps the general
-    // one for A/B timing; the frames are the same bit for bit either way (same arithmetic, another route for the column record).
-    static const bool no_small = getenv("MG_MAZE3D_NO_SMALL") != nullptr;
-    const bool small = n_waves == 1 && !no_small;
+    // (MG_MAZE3D_NO_SMALL=1 keeps the general instantiation for one-wave frames too, for A/B timing; the frames are the same bit
+    // for bit either way — same arithmetic, another route for the column record.)
 #define MG_MAZE3D_LAUNCH(REC_, STOCK_, SMALL_)                                                                                \
     hipLaunchKernelGGL((maze3d_step_kernel<REC_, STOCK_, SMALL_>), dim3(n), dim3(n_waves * mg::WAVE), lds, (hipStream_t)stream, *T, *st, vk, \
                        task_type, max_steps, continuous, pre_moved, auto_reset, n, action, obs, reward, reward64, done)
