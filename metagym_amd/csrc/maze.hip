@@ -788,8 +788,7 @@ __device__ __forceinline__ void py_slice(long a, long b, long len, int &lo, int 
     hi = (int)b;
 }
 
-struct int3s { int x, y, z; };   // 12-byte pixel, stored with one dwordx3
-typedef int mz_v3i __attribute__((ext_vector_type(3)));
+typedef int mz_v3i __attribute__((ext_vector_type(3)));   // 12-byte pixel, stored with one buffer_store_dwordx3
 
 // REC: words per translucent-cell record, 1 (compact) or 2. STOCK: the stock renderer configuration, decided on the host
 // (mg_maze3d_step) — every task's cell size the same power of two, texture size and resolution powers of two, int32 frames: the
@@ -798,24 +797,14 @@ typedef int mz_v3i __attribute__((ext_vector_type(3)));
 // SMALL: the one-wave-per-env instantiation (frames up to 64 x 64): a column is ONE 64-row chunk there, so what the general kernel
 // does once per column — the record's broadcast — is paid per chunk. It goes through the LDS crossbar instead of 13 v_readlane + 4
 // converts (xbar), and five waves per SIMD (all that the env's 8 KB of LDS admit) give the record's VGPR copy its registers.
-#ifndef MG_MAZE3D_PIPE_LARGE
-#define MG_MAZE3D_PIPE_LARGE 0     // (experiment knob: the deferred frame store in the multi-wave kernels too)
-#endif
-#ifndef MG_MAZE3D_LARGE_WAVES
-#define MG_MAZE3D_LARGE_WAVES 6
-#endif
 template <int REC, bool STOCK, bool SMALL = false>
-__global__ __launch_bounds__(MZ_BLOCK) __attribute__((amdgpu_waves_per_eu(SMALL ? 5 : MG_MAZE3D_LARGE_WAVES))) void maze3d_step_kernel(mg_maze_tasks T, mg_maze_state st, ViewK vk,
+__global__ __launch_bounds__(MZ_BLOCK) __attribute__((amdgpu_waves_per_eu(SMALL ? 5 : 6))) void maze3d_step_kernel(mg_maze_tasks T, mg_maze_state st, ViewK vk,
                                                                int task_type, int max_steps, int continuous,
                                                                int pre_moved, int auto_reset, int n_envs,
                                                                const void *action,
                                                                void *obs, float *reward, double *reward64,
                                                                uint8_t *done) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-#ifndef MG_MAZE3D_PIPE_SMALL
-#define MG_MAZE3D_PIPE_SMALL 1
-#endif
-    constexpr bool PIPE = SMALL ? MG_MAZE3D_PIPE_SMALL != 0 : MG_MAZE3D_PIPE_LARGE != 0;      // the frame store of a pixel is issued one chunk later (pixel_pass)
     const int e = mg::env_of_block(blockIdx.x, n_envs);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n_threads = blockDim.x, n_waves = n_threads >> 6;   // 1, 2 or 4 waves per env (host picks by frame size)
@@ -962,42 +951,27 @@ __global__ __launch_bounds__(MZ_BLOCK) __attribute__((amdgpu_waves_per_eu(SMALL 
         const RowRec *row_lane = row_tab + lane;                  // this lane's row of every 64-row chunk: one add per chunk away
         const __amdgpu_buffer_rsrc_t frame = __builtin_amdgcn_make_buffer_rsrc(
             obs_u8 ? static_cast<void *>(img8) : static_cast<void *>(img), 0, (int)((uint32_t)vk.H * (uint32_t)vk.V * px_bytes), 0x00020000);
-        // The pixel computed by one chunk iteration is stored DURING THE NEXT one (PIPE; see pixel_pass: after that pixel's texel
-        // fetches went out, before they are used), so a fetch never waits behind the frame store in the in-order vmcnt queue.
+        // The pixel computed by one chunk iteration is stored DURING THE NEXT one (see pixel_pass: after that pixel's texel fetches
+        // went out, before they are used), so a fetch never waits behind the frame store in the in-order vmcnt queue. The store is
+        // a BUFFER store with the env's frame as its range (streaming, `nt`: a 12.9 GB frame batch can never stay in the 32 MB of
+        // L2, but the textures and task tables it would evict are re-read by every pixel): a lane without a pending pixel — the
+        // first chunk; rows past V in a ragged last chunk — sends an out-of-range offset and the hardware drops its write. No
+        // branch around the store: the wait-count pass can then prove the store is in flight when the fetches are awaited and emits
+        // vmcnt(1); behind an `if (pending)` it has to assume the store may be missing and waits with vmcnt(0), store included.
+        // Worth 2.5 % at 64 x 64 and 0.7 % (discrete) / 1.7 % (continuous) at 256 x 256 (profiles/r05/maze3d_small_frames.txt).
         int p_r = 0, p_g = 0, p_b = 0;
         uint32_t p_off = 0;
         bool p_ok = false;
-        auto store_pixel = [&](int r_, int g_, int b_, uint32_t off_) {
-            if (obs_u8) {      // non-parity fast path: saturate to a byte
-                uint8_t *q = img8 + off_;
-                __builtin_nontemporal_store((uint8_t)min(max(r_, 0), 255), q);
-                __builtin_nontemporal_store((uint8_t)min(max(g_, 0), 255), q + 1);
-                __builtin_nontemporal_store((uint8_t)min(max(b_, 0), 255), q + 2);
-            } else {
-                // streaming stores: a 12.9 GB frame batch can never stay in the 32 MB of L2, but the
-                // textures and task tables it would evict are re-read by every pixel (-7 % at 256x256)
-                int *q = reinterpret_cast<int *>(reinterpret_cast<char *>(img) + off_);
-                __builtin_nontemporal_store(r_, q);
-                __builtin_nontemporal_store(g_, q + 1);
-                __builtin_nontemporal_store(b_, q + 2);
-            }
-        };
-        // PIPE: a BUFFER store with the frame as its range — a lane without a pending pixel (the first chunk; rows past V in a
-        // ragged last chunk) sends an out-of-range offset and the hardware drops its write. No branch around the store: the
-        // wait-count pass can then prove the store is in flight when the fetches are awaited and emits vmcnt(1); behind an
-        // `if (pending)` it has to assume the store may be missing and waits with vmcnt(0) — for the store as well.
         auto flush = [&]() {
-            if constexpr (PIPE) {
-                const uint32_t o = p_ok ? p_off : 0x80000000u;      // (frames are < 2^31 bytes: res_h <= 32767, res_v <= 4095)
-                if (obs_u8) {
-                    __builtin_amdgcn_raw_buffer_store_b8((uint8_t)min(max(p_r, 0), 255), frame, o, 0, 2);
-                    __builtin_amdgcn_raw_buffer_store_b8((uint8_t)min(max(p_g, 0), 255), frame, o + 1u, 0, 2);
-                    __builtin_amdgcn_raw_buffer_store_b8((uint8_t)min(max(p_b, 0), 255), frame, o + 2u, 0, 2);
-                } else {
-                    mz_v3i v;
-                    v.x = p_r; v.y = p_g; v.z = p_b;
-                    __builtin_amdgcn_raw_buffer_store_b96(v, frame, o, 0, 2);       // aux 2 = nt, like the streaming global stores
-                }
+            const uint32_t o = p_ok ? p_off : 0x80000000u;      // (frames are < 2^31 bytes: res_h <= 32767, res_v <= 4095)
+            if (obs_u8) {      // non-parity fast path: saturate to a byte
+                __builtin_amdgcn_raw_buffer_store_b8((uint8_t)min(max(p_r, 0), 255), frame, o, 0, 2);
+                __builtin_amdgcn_raw_buffer_store_b8((uint8_t)min(max(p_g, 0), 255), frame, o + 1u, 0, 2);
+                __builtin_amdgcn_raw_buffer_store_b8((uint8_t)min(max(p_b, 0), 255), frame, o + 2u, 0, 2);
+            } else {
+                mz_v3i v;
+                v.x = p_r; v.y = p_g; v.z = p_b;
+                __builtin_amdgcn_raw_buffer_store_b96(v, frame, o, 0, 2);       // aux 2 = nt
             }
         };
         for (int k = 0; k < ncols; ++k) {
@@ -1046,12 +1020,7 @@ __global__ __launch_bounds__(MZ_BLOCK) __attribute__((amdgpu_waves_per_eu(SMALL 
                 if (in_lb_x && rbase < lb_y1 && rbase + 64 > lb_y0) {          // wave-uniform: the bar crosses this chunk
                     if (d_v >= lb_y0 && d_v < lb_y1) { R = 255; G = 0; B = 0; }
                 }
-                const uint32_t off = pix_lane + chunk_bytes;
-                if constexpr (PIPE) {
-                    p_r = R; p_g = G; p_b = B; p_off = off; p_ok = row_ok;
-                } else {
-                    if (row_ok) store_pixel(R, G, B, off);
-                }
+                p_r = R; p_g = G; p_b = B; p_off = pix_lane + chunk_bytes; p_ok = row_ok;
             }
         }
         flush();            // the last pixel of this group of columns

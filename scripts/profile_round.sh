@@ -47,6 +47,11 @@ if has walker; then
   timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/walker_trace -o w -- python scripts/bench_walker.py > $OUT/walker_trace.log 2>&1
   timeout 300 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_INSTS_LDS SQ_INSTS_SALU \
             --output-format csv -d $OUT/walker_pmc_sq -o w -- python scripts/bench_walker.py humanoid > $OUT/walker_pmc_sq.log 2>&1
+  # the contact-rich batch (bench.py C4_grounded_*): everybody lying on the ground
+  python scripts/bench_walker.py humanoid --grounded > $OUT/bench_walker_grounded.jsonl 2> $OUT/bench_walker_grounded.err
+  timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/walker_grounded_trace -o w -- python scripts/bench_walker.py humanoid --grounded > $OUT/walker_grounded_trace.log 2>&1
+  timeout 300 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_INSTS_LDS SQ_INSTS_SALU \
+            --output-format csv -d $OUT/walker_grounded_pmc_sq -o w -- python scripts/bench_walker.py humanoid --grounded > $OUT/walker_grounded_pmc_sq.log 2>&1
 fi
 if has a1; then
   # every secondary workload of bench.py under the tracer: the a1_* kernels (Quadrupedal actuation / wrappers) among them
@@ -54,6 +59,7 @@ if has a1; then
           python bench.py --no-cpu-baseline --steps 50 --warmup 5 > $OUT/a1_trace.log 2>&1
 fi
 if has bench; then
+  python bench.py --steps 20 --warmup 5 > $OUT/bench_20steps.json 2> $OUT/bench_20steps.err      # the driver's command
   python bench.py > $OUT/bench.json 2> $OUT/bench.err
   python bench.py --launch eager --no-secondary --no-cpu-baseline > $OUT/bench_eager.json 2> $OUT/bench_eager.err
   BENCH_FORCE_DIST=1 python bench.py --no-secondary --no-cpu-baseline > $OUT/bench_force_dist.json 2> $OUT/bench_force_dist.err

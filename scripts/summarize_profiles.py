@@ -56,6 +56,17 @@ for kernel, prefix, stem in (("quadrotor_step_kernel", "quad", "q"), ("maze3d_st
         merged["wait_inst_frac"] = merged.get("SQ_WAIT_INST_ANY", 0) / max(merged.get("SQ_WAVE_CYCLES", 1), 1)
     merged["dispatch"] = meta
     summary[kernel] = merged
+# the contact-rich walker batch (bench.py C4_grounded_*): its own counters next to the airborne batch's
+g, gmeta = agg(os.path.join(R, "walker_grounded_pmc_sq", "w_counter_collection.csv"), "walker_step_wave_kernel")
+g = g.get("walker_step_wave_kernel", {})
+if "SQ_WAVES" in g:
+    w = g["SQ_WAVES"]
+    g["valu_insts_per_wave"] = g.get("SQ_INSTS_VALU", 0) / w
+    g["wave_cycles_per_wave"] = g.get("SQ_WAVE_CYCLES", 0) * 4 / w
+    g["valu_active_frac"] = g.get("SQ_ACTIVE_INST_VALU", 0) / max(g.get("SQ_WAVE_CYCLES", 1), 1)
+    g["wait_any_frac"] = g.get("SQ_WAIT_ANY", 0) / max(g.get("SQ_WAVE_CYCLES", 1), 1)
+    g["dispatch"] = gmeta
+    summary["walker_step_wave_kernel (C4 grounded: every robot lying on the ground)"] = g
 json.dump(summary, open(os.path.join(P, "pmc_summary.json"), "w"), indent=1)
 print(json.dumps(summary, indent=1))
 for src, dst in (("quad_trace/q_kernel_stats.csv", "quadrotor_bench_kernel_stats.csv"),
@@ -68,7 +79,9 @@ for src, dst in (("quad_trace/q_kernel_stats.csv", "quadrotor_bench_kernel_stats
                  ("walker_trace/w_kernel_stats.csv", "walker_bench_kernel_stats.csv"),
                  ("a1_trace/a_kernel_stats.csv", "bench_all_secondary_kernel_stats.csv"),
                  ("bench.json", "bench.json"), ("bench_maze.jsonl", "bench_maze.jsonl"),
-                 ("bench_walker.jsonl", "bench_walker.jsonl")):
+                 ("bench_walker.jsonl", "bench_walker.jsonl"),
+                 ("walker_grounded_trace/w_kernel_stats.csv", "walker_grounded_kernel_stats.csv"),
+                 ("bench_walker_grounded.jsonl", "bench_walker_grounded.jsonl"), ("bench_20steps.json", "bench_20steps.json")):
     if os.path.exists(os.path.join(R, src)):
         shutil.copy(os.path.join(R, src), os.path.join(P, dst))
 # north_star batch sizes (2^17 / 2^20 quadrotors on one GPU): kernel-stats CSV + the SQ counters of a separate --pmc pass
