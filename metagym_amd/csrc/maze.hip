@@ -795,8 +795,10 @@ typedef int mz_v3i __attribute__((ext_vector_type(3)));   // 12-byte pixel, stor
 // run-time `is this a power of two` flags of the general kernel become constants, and with them go the correctly-rounded
 // divisions nobody takes, their scalar branches, the byte-output path and a quarter-rate 32-bit multiply in the store address.
 // SMALL: the one-wave-per-env instantiation (frames up to 64 x 64): a column is ONE 64-row chunk there, so what the general kernel
-// does once per column — the record's broadcast — is paid per chunk. It goes through the LDS crossbar instead of 13 v_readlane + 4
-// converts (xbar), and five waves per SIMD (all that the env's 8 KB of LDS admit) give the record's VGPR copy its registers.
+// does once per column — the record's broadcast, 13 v_readlane + 4 converts — is paid per chunk, and at 64 x 64 the general kernel
+// is VALU-bound (82 % busy). Pass A parks the widened record in LDS (ColRecLds) and the pixel pass reads it back with four
+// broadcast ds_read_b128; five waves per SIMD give the record's VGPR copy its registers (the cap is not what bounds the resident
+// waves: 4 / 5 / 6 measured alike). 64 x 64 x 65 536 envs: 0.913 -> 0.865 ms (profiles/r05/maze3d_small_frames.txt).
 template <int REC, bool STOCK, bool SMALL = false>
 __global__ __launch_bounds__(MZ_BLOCK) __attribute__((amdgpu_waves_per_eu(SMALL ? 5 : 6))) void maze3d_step_kernel(mg_maze_tasks T, mg_maze_state st, ViewK vk,
                                                                int task_type, int max_steps, int continuous,
@@ -940,7 +942,7 @@ __global__ __launch_bounds__(MZ_BLOCK) __attribute__((amdgpu_waves_per_eu(SMALL 
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        // column-major walk: column k's record is broadcast ONCE (11 v_readlane + 4 converts) and then
+        // column-major walk: column k's record is broadcast ONCE (v_readlane + converts; SMALL: read back from LDS) and then
         // reused by all V/64 row chunks; the per-row constants come from the LDS row table
         const bool obs_u8 = !STOCK && vk.obs_u8;
         const uint32_t px_bytes = obs_u8 ? 3u : 12u;
