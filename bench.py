@@ -28,13 +28,13 @@ Prints ONE JSON line on rank 0.
   value        whole-job env-steps/s = envs stepped by all ranks * steps / max-over-ranks wall time
   roofline     algorithmic bytes per launch (317 B/env-step) / average kernel-launch
                duration measured with HIP events on the launching stream, vs the 8 TB/s HBM peak
-  cpu_baseline the reference's own Quadrotor.step in a multiprocessing.Pool when the reference tree is
-               importable (build container); otherwise the C port of it (oracle/) on the host cores
+  cpu_baseline the UNMODIFIED reference Quadrotor.step, one single-env worker process per host core (kind "reference":
+               imported from oracle/_ref, the byte-compiled copy oracle/make_ref.py builds and ships); the C port of it
+               (oracle/) beside it as cpu_port — and alone (kind "port") only if oracle/_ref is missing
 """
 import argparse
 import ctypes
 import json
-import multiprocessing
 import os
 import sys
 import threading
@@ -140,43 +140,36 @@ def _reference_has(ref, pkg):
     return os.path.isfile(os.path.join(d, "__init__.py")) or os.path.isfile(os.path.join(d, "__init__.pyc"))
 
 
-def _reference_worker(args):
-    """One single-env reference worker (metagym/quadrotor/env.py:127 `Quadrotor.step`, unmodified, imported through
-    oracle/refstubs because gym is not installed): 20 warm-up steps, then steps until the deadline."""
-    idx, ref, seconds = args
-    sys.path.insert(0, os.path.join(ROOT, "oracle", "refstubs"))
-    sys.path.insert(0, ref)
-    np.int = int                      # quadrotorsim.py:243,250 use the removed alias
-    import gym  # noqa: F401  (the stub)
-    from metagym.quadrotor.env import Quadrotor
-    np.random.seed(1000 + idx)
-    env = Quadrotor(task="hovering_control", nt=1000)
-    env.reset()
-    rs = np.random.RandomState(2000 + idx)
-    acts = rs.uniform(0.1, 15.0, (256, 4)).astype(np.float32)
-    n = 0
-
-    def one(k):
-        try:
-            _, _, done, _ = env.step(acts[k % 256])
-        except Exception:             # _check_failure raises out of step() (quadrotorsim.py:212-221)
-            done = True
-        if done:
-            env.reset()
-    for k in range(20):
-        one(k)
-    t0 = time.perf_counter()
-    while time.perf_counter() - t0 < seconds:
-        one(n)
-        n += 1
-    return n, time.perf_counter() - t0
+def _reference_pool(kind, ref, seconds, cores, *extra):
+    """`cores` independent single-env worker PROCESSES of the unmodified reference (oracle/ref_workers.py, one fresh interpreter
+    each: this process has torch and a live HIP runtime loaded, which a fork would copy and a multiprocessing spawn would
+    re-import per worker), all started together; -> [(steps, seconds)] per worker. A worker that does not report within
+    `seconds` + 120 s is killed and the whole leg fails loudly rather than hanging the bench."""
+    import subprocess
+    cmd = [sys.executable, os.path.join(ROOT, "oracle", "ref_workers.py"), kind]
+    env = dict(os.environ, OMP_NUM_THREADS="1", OPENBLAS_NUM_THREADS="1", MKL_NUM_THREADS="1")
+    procs = [subprocess.Popen(cmd + [str(i), ref, repr(float(seconds))] + list(extra), stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                              text=True, cwd=ROOT, env=env) for i in range(cores)]
+    out = []
+    try:
+        for p in procs:
+            so, se = p.communicate(timeout=seconds + 120.0)
+            if p.returncode != 0:
+                raise RuntimeError("reference worker failed: %s" % se.strip()[-400:])
+            n, t = so.split()[-2:]
+            out.append((int(n), float(t)))
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    return out
 
 
 def cpu_reference(seconds=12.0):
     """north_star: "the reference CPU path timed on the same box's host cores (core count stated) in the same
-    run" — a multiprocessing.Pool(P) of independent single-env `Quadrotor.step` workers (BASELINE.md §4,
-    SURVEY.md §8d C2). Only possible where the reference tree exists (the build container; the GPU box has no
-    /root/reference and bench.py may not read it there): returns (result, None) or (None, reason)."""
+    run" — P independent single-env `Quadrotor.step` worker processes, P = the usable cores (BASELINE.md §4,
+    SURVEY.md §8d C2: "env.step in a multiprocessing.Pool(P) of independent single-env workers"), imported from
+    reference_root() (oracle/_ref on the GPU box): returns (result, None) or (None, reason)."""
     ref = reference_root()
     if not _reference_has(ref, "quadrotor"):
         return None, ("no importable reference at %s (oracle/make_ref.py builds it in the build container; "
@@ -184,9 +177,7 @@ def cpu_reference(seconds=12.0):
                       "from_profiles.reference_cpu" % ref)
     cores = usable_cpus()
     try:
-        ctx = multiprocessing.get_context("fork")
-        with ctx.Pool(cores) as pool:
-            res = pool.map(_reference_worker, [(i, ref, seconds) for i in range(cores)])
+        res = _reference_pool("quadrotor", ref, seconds, cores)
     except Exception as e:
         return None, "reference import / run failed: %r" % (e,)
     steps = sum(r[0] for r in res)
@@ -195,38 +186,9 @@ def cpu_reference(seconds=12.0):
             "per_core": steps / wall / cores,
             "source": ("oracle/_ref (byte-code of the unmodified reference, oracle/make_ref.py)"
                        if os.path.abspath(ref) == os.path.join(ROOT, "oracle", "_ref") else ref),
-            "sample": "%d env-steps, %d single-env workers (multiprocessing.Pool) of the unmodified "
+            "sample": "%d env-steps, %d single-env worker processes of the unmodified "
                       "metagym.quadrotor.env.Quadrotor.step (hovering_control, dt=0.01, nt=1000, U(0.1,15) actions, finished "
                       "episodes reset; numpy %s, gym stubbed), %.1f s each" % (steps, cores, np.__version__, wall)}, None
-
-
-def _reference_maze_worker(args):
-    """One single-env worker of the unmodified MetaMazeDiscrete3D (maze_discrete_3d.py:44-126 through oracle/refstubs:
-    numba is not installed, so this is the un-jitted Python the stub runs — "for the record")."""
-    idx, ref, seconds, res = args
-    sys.path.insert(0, os.path.join(ROOT, "oracle", "refstubs"))
-    sys.path.insert(0, ref)
-    np.int = int
-    np.product = np.prod                # maze_task.py:101 uses the removed alias
-    import random
-    import gym
-    import metagym.metamaze  # noqa: F401
-    from metagym.metamaze import MazeTaskSampler
-    random.seed(idx)
-    np.random.seed(idx)
-    env = gym.make("meta-maze-discrete-3D-v0", enable_render=False, task_type="SURVIVAL", max_steps=200,
-                   resolution=(res, res))
-    env.set_task(MazeTaskSampler(n=9, allow_loops=False, step_reward=-0.01, goal_reward=1.0, food_density=0.06,
-                                 food_interval=20))
-    env.reset()
-    rs = np.random.RandomState(idx)
-    n = 0
-    t0 = time.perf_counter()
-    while time.perf_counter() - t0 < seconds:
-        if env.step(int(rs.randint(4)))[2]:
-            env.reset()
-        n += 1
-    return n, time.perf_counter() - t0
 
 
 def cpu_reference_maze3d(seconds=5.0, res=256):
@@ -237,9 +199,7 @@ def cpu_reference_maze3d(seconds=5.0, res=256):
         return None
     cores = usable_cpus()
     try:
-        ctx = multiprocessing.get_context("fork")
-        with ctx.Pool(cores) as pool:
-            out = pool.map(_reference_maze_worker, [(i, ref, seconds, res) for i in range(cores)])
+        out = _reference_pool("maze3d", ref, seconds, cores, str(res))
     except Exception as e:
         return {"error": repr(e)}
     steps, wall = sum(r[0] for r in out), max(r[1] for r in out)
