@@ -327,6 +327,17 @@ def ptr(t):
     return C.c_void_p(t.data_ptr())
 
 
+def canonical_device(device):
+    """torch.device(device) with an explicit index for a CUDA device ("cuda" -> the current device, cuda:0 unless the caller
+    changed it): tensors report `cuda:0`, so an env that kept the index-less spelling would see every tensor it is handed as
+    living "elsewhere" (`t.device == self.device` is False) — a slow path in Quadrotor.step, a refusal in A1Actuators."""
+    import torch
+    d = torch.device(device)
+    if d.type == "cuda" and d.index is None:
+        d = torch.device("cuda", torch.cuda.current_device() if torch.cuda.is_available() else 0)
+    return d
+
+
 def current_stream(device):
     import torch
     return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)

@@ -64,7 +64,7 @@ class WalkerBatchEnv(object):
                  max_coordinate_velocity=None):
         self._lib = _lib.load()
         self.num_envs = int(num_envs)
-        self.device = torch.device(device)
+        self.device = _lib.canonical_device(device)
         if self.device.type != "cuda":
             raise _lib.MetaGymHipError("metagym_amd runs on an AMD GPU only (got device %r); there is no CPU "
                                        "path" % (device,))

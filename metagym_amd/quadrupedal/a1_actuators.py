@@ -48,7 +48,7 @@ class A1Actuators(object):
                  pd_latency=0.0, motor_control_mode=MotorControlMode.POSITION, motor_kp=DEFAULT_KP, motor_kd=DEFAULT_KD,
                  motor_torque_limits=33.5, enable_action_interpolation=False, enable_clip_motor_commands=False,
                  enable_action_filter=False, history_len=100):
-        self.device = torch.device(device)
+        self.device = _lib.canonical_device(device)
         if self.device.type != "cuda":
             raise _lib.MetaGymHipError("metagym_amd has no CPU path: device must be a ROCm GPU, got %r" % (device,))
         self._lib = _lib.load()

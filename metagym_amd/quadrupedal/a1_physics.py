@@ -102,7 +102,7 @@ class A1Physics(object):
         else:
             self.base_mass = float(getattr(m, "root_link_mass", m.body_mass[0]))
         self.model = m
-        self.n, self.device = int(num_envs), torch.device(device)
+        self.n, self.device = int(num_envs), _lib.canonical_device(device)
         self.env = _A1Walker(num_envs=num_envs, device=device, frame_skip=1, time_step=0.002, max_steps=2 ** 30,
                              solver_iterations=solver_iterations, self_collision=False, gravity=gravity,
                              ground_friction=ground_friction, body_damping=body_damping, per_proxy_friction=True,

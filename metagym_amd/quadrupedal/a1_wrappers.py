@@ -34,7 +34,7 @@ def _soa(x, n, k, device, dtype=torch.float64):
 class EtgActionPath(object):
     def __init__(self, num_envs, device="cuda:0", ETG=1, ETG_T=0.5, ETG_T2=0.5, ETG_H=20, ETG_w=None, ETG_b=None, act_mode="traj",
                  task_mode="normal", action_space=0):
-        self.device = torch.device(device)
+        self.device = _lib.canonical_device(device)
         if self.device.type != "cuda":
             raise _lib.MetaGymHipError("metagym_amd has no CPU path: device must be a ROCm GPU, got %r" % (device,))
         assert act_mode in ("traj", "pose") and 1 <= ETG_H <= _lib.A1_ETG_MAX_H
@@ -106,7 +106,7 @@ class EtgActionPath(object):
 
 class RewardShaping(object):
     def __init__(self, num_envs, device="cuda:0", param=Param_Dict, reward_p=1, vel_d=0.6, vel_mode="max", env_info=FLAT_GROUND):
-        self.device = torch.device(device)
+        self.device = _lib.canonical_device(device)
         if self.device.type != "cuda":
             raise _lib.MetaGymHipError("metagym_amd has no CPU path: device must be a ROCm GPU, got %r" % (device,))
         if vel_mode not in ("max", "equal"):       # MonitorEnv.py:512-518 knows these two
@@ -201,7 +201,7 @@ class SensorStack(object):
         robot (NOISE_SIGMA). The reference takes them from numpy's global stream; here a device generator seeded by `seed`, or
         `noise_source()` -> [33, N] already-scaled values (tests replay the reference's own draws through it)."""
         self.noise, self._noise_source = bool(noise), noise_source
-        self.device = torch.device(device)
+        self.device = _lib.canonical_device(device)
         if self.device.type != "cuda":
             raise _lib.MetaGymHipError("metagym_amd has no CPU path: device must be a ROCm GPU, got %r" % (device,))
         self._lib = _lib.load()
@@ -247,7 +247,7 @@ class ActionFilter(object):
     (`Minitaur._BuildActionFilter`, minitaur.py:1438-1443: 2nd-order Butterworth low-pass at 4 Hz)."""
 
     def __init__(self, num_envs, a, b, device="cuda:0"):
-        self.device = torch.device(device)
+        self.device = _lib.canonical_device(device)
         if self.device.type != "cuda":
             raise _lib.MetaGymHipError("metagym_amd has no CPU path: device must be a ROCm GPU, got %r" % (device,))
         self._lib = _lib.load()

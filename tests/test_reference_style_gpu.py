@@ -97,3 +97,37 @@ def test_locomotion_envs_run_tasks_to_done(env_id, prefix):
             assert steps <= 2
         assert torch.isfinite(obs).all() and torch.isfinite(r).all()
     env.close()
+
+
+def test_every_env_family_takes_the_index_less_device_spelling():
+    """`device="cuda"` (what a user types; tensors then report `cuda:0`) must mean the same as `device="cuda:0"`: the envs
+    canonicalise the spelling once (`_lib.canonical_device`). Round 5's final validation found `quadrupedal-v0` refusing its own
+    physics' tensors ("SoA tensor must be ... on cuda, got ... on cuda:0") and Quadrotor.step taking its conversion path on every
+    call. One reset + a few steps per family, with device tensors as actions, and the fast-path precondition of Quadrotor.step."""
+    import metagym_amd
+    from metagym_amd.metamaze import MazeTaskSampler
+    from urdf_fixture import a1_like_urdf
+    n = 64
+    q = metagym_amd.make("quadrotor-v0", num_envs=n, device="cuda", task="hovering_control", auto_reset=True)
+    assert q.device == torch.device("cuda", torch.cuda.current_device()) and q.reset(seed=0).device == q.device
+    a = torch.rand(n, 4, device="cuda") * 10 + 1
+    assert a.device == q.device                                    # the zero-copy path of step() is taken
+    q.step(a)
+    for name in ("meta-maze-2D-v0", "meta-maze-discrete-3D-v0", "meta-maze-continuous-3D-v0"):
+        kw = {} if "2D" in name else dict(resolution=(32, 32))
+        m = metagym_amd.make(name, num_envs=n, device="cuda", max_steps=10, task_type="ESCAPE", **kw)
+        m.set_task([MazeTaskSampler(n=9, allow_loops=False, seed=s_) for s_ in range(3)])
+        m.reset()
+        act = torch.rand(n, 2, device="cuda") * 2 - 1 if "continuous" in name else torch.randint(0, 4, (n,), device="cuda")
+        obs = m.step(act)[0]
+        assert obs.device == m.device
+    for ident in ("meta-humanoid-v0", "meta-ant-v0"):
+        w = metagym_amd.make(ident, num_envs=n, device="cuda", auto_reset=True)
+        w.set_task([w.sample_task("TRAIN") for _ in range(4)])
+        w.reset(seed=0)
+        assert torch.isfinite(w.step(torch.rand(n, w.n_joints, device="cuda") * 2 - 1)[0]).all()
+    a1 = metagym_amd.make("quadrupedal-v0", num_envs=n, device="cuda", urdf=a1_like_urdf(), task="slopestair", auto_reset=True)
+    obs, info = a1.reset()
+    for _ in range(3):
+        obs, reward, done, info = a1.step(torch.zeros(n, 12, dtype=torch.float64, device="cuda"))
+    assert torch.isfinite(obs).all() and obs.device == a1.device
