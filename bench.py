@@ -1146,6 +1146,12 @@ def main(argv=None):
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "f32/f64 mixed (reference choreography)",
+            # what "the reference's arithmetic" means here, said in the line
+            "numerics": "every expression in the dtype NumPy 2.2.6 (NEP 50) evaluates it in — the only way the reference runs offline, "
+                        "and what every bit-exact statement of this repo is against. The reference pins numpy 1.22, where a python float "
+                        "times a float32 scalar is float64: measured gap between the two readings <= 4.1e-6 over 1 000 Euler sub-steps, "
+                        "1.5e-5 (state) / 8.3e-5 (Euler-angle observation) over tumbling 400 - 1 000-step rollouts "
+                        "(profiles/r03/numpy_pin_gap.txt); the kernel has no numpy-1.22 mode",
             "data": "synthetic",
         }
         out.update(scaling_fields(value, world, envs_per_rank, args.steps, rank_walls, solo_wall, args.single_gpu_value))
