@@ -300,9 +300,10 @@ typedef struct mg_maze_view {
  * (TaskConfig.cell_size, maze_task.py:15-17) with `uniform_cell_size`. MG_OK: the pair (tasks->scalars, value) is remembered
  * and mg_maze3d_step accepts it without looking again. MG_ERR_BAD_CONFIG: some task differs (mg_last_error names it).
  * mg_maze3d_step runs this check itself the first time it meets an unchecked (table, value) pair — one stream
- * synchronisation, once — and refuses an unchecked pair under stream capture (where it cannot synchronise). A caller that
- * rewrites a checked table IN PLACE must call this again (an explicit call always re-reads). `tasks->scalars` may be a host
- * pointer (then it is read directly). */
+ * synchronisation, once — and refuses an unchecked pair under stream capture (where it cannot synchronise). The memory of a
+ * checked pair is keyed by the ADDRESS of the scalar rows: a caller that rewrites a checked table in place, or frees it and
+ * uploads another one that lands at the same address, must call this again (an explicit call always re-reads; the Python layer
+ * calls it at every set_task). `tasks->scalars` may be a host pointer (then it is read directly). */
 int mg_maze_check_uniform_cell_size(const mg_maze_tasks *tasks, double uniform_cell_size, void *stream);
 
 /* Host helper: the per-column tables of ray_caster_utils.py:82-90 (tan_hp accumulated column by
