@@ -191,6 +191,25 @@ def cpu_reference(seconds=12.0):
                       "episodes reset; numpy %s, gym stubbed), %.1f s each" % (steps, cores, np.__version__, wall)}, None
 
 
+def cpu_reference_maze2d(seconds=2.0):
+    """BASELINE.json configs[0]: "MetaMaze2D 15x15 discrete, 1 env, reference CPU step()" — ONE single-env worker process of the
+    unmodified MetaMaze2D (maze_env.py:189-204) per task type, on one host core (the configuration is one env; more cores would
+    be more envs)."""
+    ref = reference_root()
+    if not _reference_has(ref, "metamaze"):
+        return None
+    out = {"cores": 1, "kind": "reference", "unit": "us per env.step() (episode resets inside the clock)"}
+    for tt in ("ESCAPE", "SURVIVAL"):
+        try:
+            (steps, wall), = _reference_pool("maze2d", ref, seconds, 1, tt)
+            out[tt] = {"us_per_step": wall / steps * 1e6, "env_steps_per_s": steps / wall,
+                       "sample": "%d steps of one unmodified MetaMaze2D (15x15, crowd_ratio 0.35, view_grid 1, max_steps 200, uniform "
+                                 "random actions), %.1f s" % (steps, wall)}
+        except Exception as e:
+            out[tt] = {"error": repr(e)}
+    return out
+
+
 def cpu_reference_maze3d(seconds=5.0, res=256):
     """C3 "for the record": the unmodified reference MetaMazeDiscrete3D.step (+ its 256x256 frame) on every host core.
     numba is absent, so the ray caster runs un-jitted — this is NOT what a user of the reference with numba would see."""
@@ -1210,8 +1229,9 @@ def main(argv=None):
                                "note": "rank 0's wall time per mixed step; per-kernel rooflines are in the "
                                        "single-workload run"}
         out["sanity"] = {"done_frac_last_step": done_frac, "failed_max": failed_any,
-                         "episode_ends_in_timed_region": ep1 - ep0,
-                         "done_frac_timed_region": (ep1 - ep0) / float(n * args.steps),
+                         # ep0 / ep1 bracket timed_region(), which runs the W warm-up steps and then the K timed ones
+                         "episode_ends_in_warmup_plus_timed_region": ep1 - ep0,
+                         "done_frac_timed_region": (ep1 - ep0) / float(n * (args.steps + args.warmup)),
                          "preroll_steps": quad.preroll_steps,
                          "host_wall_ms_per_step": wall / args.steps * 1e3, "launch_mode": launch_mode,
                          "other_launch_mode": other, "graph_launch_fit": graph_fit}
@@ -1273,6 +1293,14 @@ def main(argv=None):
                         sec[key]["cpu_baseline"] = fn()
                     except Exception as e:
                         sec[key]["cpu_baseline_error"] = repr(e)
+            if "C1_maze2d_15x15_escape_1env" in sec:
+                r1 = cpu_reference_maze2d()
+                if r1 is not None:
+                    sec["C1_maze2d_15x15_escape_1env"]["cpu_reference"] = r1
+                    if "us_per_step" in r1.get("ESCAPE", {}):
+                        out["C1_reference_cpu_us_per_step"] = r1["ESCAPE"]["us_per_step"]
+                    if "us_per_step" in r1.get("SURVIVAL", {}):
+                        out["C1_reference_cpu_us_per_step_survival"] = r1["SURVIVAL"]["us_per_step"]
             if "C3_maze3d_discrete_9x9_256x256_16384envs" in sec:
                 r3 = cpu_reference_maze3d()
                 if r3 is not None:

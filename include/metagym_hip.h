@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define MG_ABI_VERSION 6
+#define MG_ABI_VERSION 7
 
 #define MG_OK 0
 #define MG_ERR_NULL_POINTER (-1001)
@@ -305,6 +305,14 @@ typedef struct mg_maze_view {
  * uploads another one that lands at the same address, must call this again (an explicit call always re-reads; the Python layer
  * calls it at every set_task). `tasks->scalars` may be a host pointer (then it is read directly). */
 int mg_maze_check_uniform_cell_size(const mg_maze_tasks *tasks, double uniform_cell_size, void *stream);
+
+/* (ABI 7) Forget everything the library remembers about a task table (today: the checked (scalars address, value) pair above).
+ * ALLOCATOR-REUSE HAZARD: the memory of a checked pair is keyed by address; a caching allocator (torch's, a pool) readily hands
+ * the address of a freed table to the next one. A binding must call this BEFORE it frees a task table or rewrites its cell
+ * sizes in place — the next mg_maze3d_step on that address then re-reads the rows (or refuses under capture) instead of
+ * trusting a check made on other contents. The Python layer calls it from DeviceTaskTable's finaliser and re-checks at every
+ * set_task. Host-only, never fails on an unknown table. */
+int mg_maze_forget_tasks(const mg_maze_tasks *tasks);
 
 /* Host helper: the per-column tables of ray_caster_utils.py:82-90 (tan_hp accumulated column by
  * column exactly like the reference loop). Writes res_h doubles to each HOST array; the caller

@@ -8,7 +8,7 @@ import os
 
 from . import build as _build
 
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 MG_OK = 0
 
@@ -248,6 +248,7 @@ SIGNATURES = {
     "mg_maze2d_step": (C.c_int, [C.POINTER(MazeTasks), C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                  C.POINTER(MazeState), _P, _P, _P, _P, _P, _P]),
     "mg_maze_check_uniform_cell_size": (C.c_int, [C.POINTER(MazeTasks), C.c_double, _P]),
+    "mg_maze_forget_tasks": (C.c_int, [C.POINTER(MazeTasks)]),
     "mg_maze3d_step": (C.c_int, [C.POINTER(MazeTasks), C.POINTER(MazeView), C.c_int32, C.c_int32, C.c_int32,
                                  C.c_int32, C.c_int32, C.POINTER(MazeState), _P, _P, _P, _P, _P, _P]),
     "mg_walker_reset": (C.c_int, [C.POINTER(WalkerTopology), C.POINTER(WalkerModels), C.POINTER(WalkerParams),

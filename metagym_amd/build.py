@@ -35,6 +35,10 @@ def _deps():
 def is_stale():
     if not os.path.exists(LIB_PATH):
         return True
+    # a library left behind by build(extra_flags=...) (a knock-out / experiment build) is stale for the default build
+    flags_file = os.path.join(LIB_DIR, "obj", "flags.txt")
+    if os.path.exists(flags_file) and open(flags_file).read() != " ".join(f for f in FLAGS if f != "-shared"):
+        return True
     t = os.path.getmtime(LIB_PATH)
     return any(os.path.getmtime(d) > t for d in _deps())
 

@@ -936,8 +936,10 @@ __global__ __launch_bounds__(MZ_BLOCK) __attribute__((amdgpu_waves_per_eu(SMALL 
         if (lane < ncols)
             mine = column_pass<REC, STOCK>(vk, t, *es, walls, texts, transp, cbase + lane * col_step, lane, entries, cs, inv_cs, cs_pow2);
         if constexpr (SMALL) {                    // widened once per lane = per column, parked in LDS for the pixel pass
+            // the host reserves sizeof(ColRecLds) * vk.slab for colrec (mg_maze3d_step's `lds`), and ncols <= slab <= vk.slab:
+            // only lanes that own a column may store, lanes ncols..63 would write past the dynamic LDS allocation
             const ColRecD d = widen(mine);
-            colrec[lane] = ColRecLds{d.cos_hp, d.cos_abs, d.sin_abs, d.rcos_hp, d.w_oma, d.w_ratio, d.w_light, d.w_tex, d.w_span};
+            if (lane < ncols) colrec[lane] = ColRecLds{d.cos_hp, d.cos_abs, d.sin_abs, d.rcos_hp, d.w_oma, d.w_ratio, d.w_light, d.w_tex, d.w_span};
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -1171,10 +1173,18 @@ void uniform_cache_put(const void *scalars, int n_tasks, double cs) {
     std::lock_guard<std::mutex> lk(g_uniform_mu);
     for (int i = 0; i < g_uniform_n; ++i)
         if (g_uniform[i].scalars == scalars) { g_uniform[i] = UniformEntry{scalars, n_tasks, cs}; return; }
+    for (int i = 0; i < g_uniform_n; ++i)               // a slot emptied by uniform_cache_drop is reused before anything is evicted
+        if (g_uniform[i].scalars == nullptr) { g_uniform[i] = UniformEntry{scalars, n_tasks, cs}; return; }
     const int slot = g_uniform_n < 32 ? g_uniform_n++ : (g_uniform_next++ & 31);
     g_uniform[slot] = UniformEntry{scalars, n_tasks, cs};
 }
 }  // namespace
+
+extern "C" int mg_maze_forget_tasks(const mg_maze_tasks *T) {
+    MG_REQUIRE_PTR(T);
+    if (T->scalars) uniform_cache_drop(T->scalars);
+    return MG_OK;
+}
 
 extern "C" int mg_maze_check_uniform_cell_size(const mg_maze_tasks *T, double uniform_cell_size, void *stream) {
     MG_REQUIRE_PTR(T);

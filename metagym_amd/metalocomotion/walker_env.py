@@ -266,6 +266,8 @@ class WalkerBatchEnv(object):
             sd["terrain_table"], sd["terrain_id"] = tab.clone(), self.terrain_id.clone()
         elif tab is not None:
             sd["terrain_boxes"] = tab.clone()
+        # an explicit marker, so that loading a checkpoint taken WITHOUT terrain removes a terrain this env was built with
+        sd["terrain_kind"] = "none" if tab is None else ("table" if tab.dim() == 3 else "boxes")
         return sd
 
     def load_state_dict(self, sd):
@@ -291,15 +293,13 @@ class WalkerBatchEnv(object):
             self._terrain_t.copy_(src.to(self.device))
             self.terrain_id.copy_(torch.as_tensor(sd["terrain_id"]).to(self.device))
         elif "terrain_boxes" in sd:
-            src = torch.as_tensor(sd["terrain_boxes"]).to(self.device)
-            tab = getattr(self, "_terrain_t", None)
-            if tab is not None and tab.dim() == 2 and tuple(tab.shape) == tuple(src.shape):
-                tab.copy_(src)
-            else:                                   # boxes this env was not constructed with: install the checkpoint's rows
-                p = self._params_c
-                self._terrain_spec, self._terrain_t = None, src.contiguous().clone()
-                p.terrain_id, p.n_terrain_tables = None, 0
-                p.n_terrain_boxes, p.terrain = int(src.shape[0]), self._terrain_t.data_ptr()
+            # the checkpoint's rows BECOME the terrain spec: a later set_task() -> _apply_terrain() re-installs them
+            # instead of the constructor's boxes (same-shape case) or nothing (different-shape case)
+            self._terrain_spec, self._terrain_t = torch.as_tensor(sd["terrain_boxes"]).to(self.device).clone(), None
+            self._apply_terrain()
+        elif sd.get("terrain_kind") == "none":      # taken without terrain: whatever this env holds goes
+            self._terrain_spec, self._terrain_t = None, None
+            self._apply_terrain()
         if "global_step" in sd:
             self.global_step = int(sd["global_step"])
         if "np_random" in sd:
@@ -382,6 +382,7 @@ class WalkerBatchEnv(object):
         quaternion (x, y, z, w), friction); the contact's coefficient is friction x the robot's geom friction (Bullet
         multiplies the two bodies' lateral frictions). `None` / [] removes the terrain."""
         self._terrain_spec = list(boxes) if boxes else None
+        self._terrain_t = None                     # (a terrain table, if one was installed, goes too)
         if getattr(self, "_robot_set", False):
             self._apply_terrain()
 
@@ -427,7 +428,17 @@ class WalkerBatchEnv(object):
 
     def _apply_terrain(self):
         spec, p = getattr(self, "_terrain_spec", None), self._params_c
+        tab = getattr(self, "_terrain_t", None)
+        if spec is None and tab is not None and tab.dim() == 3:
+            # a per-robot terrain table (set_terrain_table / a restored checkpoint) survives set_task(): re-point the new params
+            p.n_terrain_boxes, p.terrain = int(tab.shape[1]), tab.data_ptr()
+            p.terrain_id, p.n_terrain_tables = self.terrain_id.data_ptr(), int(tab.shape[0])
+            return
         p.terrain_id, p.n_terrain_tables = None, 0
+        if isinstance(spec, torch.Tensor):          # box rows restored from a checkpoint (load_state_dict): installed as they are
+            self._terrain_t = spec.to(device=self.device, dtype=torch.float64).contiguous().clone()
+            p.n_terrain_boxes, p.terrain = int(self._terrain_t.shape[0]), self._terrain_t.data_ptr()
+            return
         if not spec:
             self._terrain_t, p.n_terrain_boxes, p.terrain = None, 0, None
             return

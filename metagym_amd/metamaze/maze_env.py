@@ -53,6 +53,13 @@ class _MazeBatch(object):
         self._done = torch.zeros(N, dtype=torch.bool, device=dev)
 
     # ------------------------------------------------------------------ tasks
+    def __del__(self):
+        try:
+            if self._tasks_c is not None:
+                self._lib.mg_maze_forget_tasks(self._tasks_c)
+        except Exception:
+            pass
+
     def set_task(self, task_config, task_ids=None):
         """task_config: one TaskConfig, a list of T TaskConfigs (uploaded once), or a DeviceTaskTable from
         `MazeTaskManager.sample_tasks_device` (already on the GPU). Env e plays task task_ids[e]
@@ -93,6 +100,10 @@ class _MazeBatch(object):
             self._uniform_cell_size = sizes.pop() if len(sizes) == 1 else 0.0   # mg_maze_view.uniform_cell_size: 0 = tasks differ
         nn = n * n
         self.n = n
+        if self._tasks_c is not None:
+            # the table this env held goes away (its tensors are released below): the library's address-keyed memory of a
+            # checked (table, uniform_cell_size) pair must not outlive it — torch's caching allocator reuses the address
+            self._lib.mg_maze_forget_tasks(self._tasks_c)
         c = _lib.MazeTasks()
         c.n, c.n_tasks = n, T
         for k in host:

@@ -81,10 +81,45 @@ def maze3d_worker(args):
     return n, time.perf_counter() - t0
 
 
-if __name__ == "__main__":      # python oracle/ref_workers.py quadrotor|maze3d <idx> <ref> <seconds> [<res>]  ->  "<steps> <seconds>"
+def maze2d_worker(args):
+    """BASELINE.json configs[0]: ONE unmodified MetaMaze2D (maze_env.py:147-204, `step` at :189-204 ->
+    maze_2d.py do_action / get_observation), 15x15, crowd_ratio 0.35, view_grid 1, `task_type` ESCAPE or SURVIVAL, uniform random
+    actions, a finished episode is reset (the reset is inside the clock, as it is for the other legs). -> (steps, seconds)"""
+    idx, ref, seconds, task_type = args
+    import random
+    import numpy as np
+    _paths(ref)
+    np.int = int
+    np.product = np.prod                # maze_task.py:101 uses the removed alias
+    import gym
+    import metagym.metamaze  # noqa: F401
+    from metagym.metamaze import MazeTaskSampler
+    random.seed(idx)
+    np.random.seed(idx)
+    env = gym.make("meta-maze-2D-v0", enable_render=False, task_type=task_type, max_steps=200, view_grid=1)
+    env.set_task(MazeTaskSampler(n=15, allow_loops=True, crowd_ratio=0.35, step_reward=-0.01, goal_reward=1.0,
+                                 food_density=0.06, food_interval=20))
+    env.reset()
+    rs = np.random.RandomState(idx)
+    acts = rs.randint(0, 4, 4096)
+    for k in range(200):                # warm-up (imports, first-call paths)
+        if env.step(int(acts[k]))[2]:
+            env.reset()
+    n = 0
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < seconds:
+        if env.step(int(acts[n & 4095]))[2]:
+            env.reset()
+        n += 1
+    return n, time.perf_counter() - t0
+
+
+if __name__ == "__main__":      # python oracle/ref_workers.py quadrotor|maze3d|maze2d <idx> <ref> <seconds> [<res> | <task_type>]  ->  "<steps> <seconds>"
     kind, idx, ref, seconds = sys.argv[1], int(sys.argv[2]), sys.argv[3], float(sys.argv[4])
     if kind == "quadrotor":
         out = quadrotor_worker((idx, ref, seconds))
+    elif kind == "maze2d":
+        out = maze2d_worker((idx, ref, seconds, sys.argv[5]))
     else:
         out = maze3d_worker((idx, ref, seconds, int(sys.argv[5])))
     print("%d %.6f" % out, flush=True)

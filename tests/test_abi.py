@@ -243,3 +243,11 @@ def test_uniform_cell_size_promise_is_checked_not_trusted():
     assert lib.mg_maze_check_uniform_cell_size(t, 2.0, None) == -1001
     t.scalars, t.n_tasks = sc.ctypes.data, 0
     assert lib.mg_maze_check_uniform_cell_size(t, 2.0, None) == -1002
+    # (ABI 7) mg_maze_forget_tasks: host-only, MG_OK for a known, an unknown and a scalar-less table; NULL is an error code
+    t.n_tasks = 5
+    sc[3, 0] = 2.0
+    assert lib.mg_maze_check_uniform_cell_size(t, 2.0, None) == 0
+    assert lib.mg_maze_forget_tasks(t) == 0 and lib.mg_maze_forget_tasks(t) == 0
+    t.scalars = None
+    assert lib.mg_maze_forget_tasks(t) == 0
+    assert lib.mg_maze_forget_tasks(None) == -1001

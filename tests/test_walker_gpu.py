@@ -648,6 +648,38 @@ def test_terrain_needs_the_wave_mapping():
         env.step(torch.zeros(4, env.n_joints))
 
 
+def test_terrain_checkpoint_survives_set_task_and_restores_no_terrain():
+    """a checkpoint's terrain boxes become the env's terrain spec — a later set_task() (which rebuilds the params and
+    calls _apply_terrain) must neither drop them nor bring back the boxes the env was constructed with; and a checkpoint taken
+    WITHOUT terrain removes a terrain the loading env holds."""
+    models = [MODELS["ant"]]
+    spec = _terrain_for_tests()
+    a = _make("MetaAntEnv", models, 4)
+    a.set_terrain(spec)
+    a.reset(seed=1)
+    sd = a.state_dict()
+    assert sd["terrain_kind"] == "boxes"
+    # (i) an env built with OTHER boxes of the same count, (ii) one built without terrain
+    other = [(h, [p[0] + 5.0, p[1], p[2]], q, f) for h, p, q, f in spec]
+    for prep in (lambda e: e.set_terrain(other), lambda e: None):
+        b = _make("MetaAntEnv", models, 4)
+        prep(b)
+        b.reset(seed=2)
+        b.load_state_dict(sd)
+        assert torch.equal(b._terrain_t, a._terrain_t)
+        b.set_task(models)                  # rebuilds mg_walker_params: the restored rows must be re-installed
+        assert b._terrain_t is not None and torch.equal(b._terrain_t, a._terrain_t)
+        assert b._params_c.n_terrain_boxes == len(spec) and b._params_c.terrain == b._terrain_t.data_ptr()
+    c = _make("MetaAntEnv", models, 4)
+    c.reset(seed=3)
+    sd0 = c.state_dict()
+    assert sd0["terrain_kind"] == "none"
+    a.load_state_dict(sd0)
+    assert a._terrain_t is None and a._params_c.n_terrain_boxes == 0
+    a.set_task(models)
+    assert a._terrain_t is None and a._params_c.n_terrain_boxes == 0
+
+
 def test_first_reset_rule_is_per_env_and_survives_a_checkpoint():
     """WalkerBaseEnv.reset adds the floor link to robot.parts AFTER the first reset's observation (walker_base_env.py:24-31):
     per env. A masked reset as the first call must leave the other envs' own first reset untouched, and state_dict carries
