@@ -530,6 +530,18 @@ typedef struct mg_walker_params {
      * reset also zeroes the reset robots' bad_contacts / foot_force entries (no contact points yet). */
     const double *reset_pos;
     const double *reset_rot;
+    /* (ABI 7) Bullet's contact-breaking margin (gContactBreakingThreshold = 0.02 m; 0 = penetration only, the behaviour up to ABI 6).
+     * A collision proxy whose surface is within contact_margin ABOVE the ground plane or a terrain box is a contact point, as in a
+     * Bullet manifold: (i) it gets a normal row whose bias is erp * depth / time_step while it penetrates (depth >= 0) and the
+     * SPECULATIVE depth / time_step (< 0, no ERP) while it is separated — btMultiBodyConstraintSolver::setupMultiBodyContactConstraint:
+     * `penetration = distance + slop > 0` -> velocityError -= penetration / dt — so the proxy may close at most its gap per
+     * sub-step and a resting contact keeps its rows instead of flickering; the two friction rows are bounded by mu x that
+     * normal multiplier as always; (ii) feet_contact / bad_contacts count EVERY proxy inside the margin — what
+     * getContactPoints returns (walker_base_env.py:57-63 via robot_bases.py:291-292) — whether or not the solver's cap kept it.
+     * Self-collision pairs stay penetration-only. The cap (all mappings, any margin): candidates are collected in candidate order
+     * (ground per proxy, terrain per proxy, self pairs; at most 48), and when more than 12 exist the 12 DEEPEST are kept (ties:
+     * the earlier candidate), in candidate order — penetrating points before speculative ones. */
+    double contact_margin;
 } mg_walker_params;
 
 /* Per-env state, SoA doubles: component c of env e at base[c*N + e]. */

@@ -127,7 +127,8 @@ class WalkerParams(C.Structure):
                 ("sphere_friction", C.c_void_p), ("body_linear_damping", C.c_double), ("body_angular_damping", C.c_double),
                 ("pd_kp_env", C.c_void_p), ("pd_kd_env", C.c_void_p), ("ext_wrench", C.c_void_p),
                 ("max_coordinate_velocity", C.c_double), ("terrain_id", C.c_void_p), ("n_terrain_tables", C.c_int32),
-                ("gravity_env", C.c_void_p), ("foot_friction_env", C.c_void_p), ("reset_pos", C.c_void_p), ("reset_rot", C.c_void_p)]
+                ("gravity_env", C.c_void_p), ("foot_friction_env", C.c_void_p), ("reset_pos", C.c_void_p), ("reset_rot", C.c_void_p),
+                ("contact_margin", C.c_double)]
 
 
 class JointMajor(object):

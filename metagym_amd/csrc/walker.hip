@@ -36,7 +36,8 @@ constexpr int NB = MG_WALKER_MAX_BODIES;
 constexpr int NJ = MG_WALKER_MAX_JOINTS;
 constexpr int NS = MG_WALKER_MAX_SPHERES;
 constexpr int ND = 6 + NJ;          // max generalized velocities
-constexpr int MAXC = 12;            // max simultaneous ground contacts per env (first MAXC penetrating spheres)
+constexpr int MAXC = 12;            // contacts the solver keeps per env: the MAXC deepest of the candidates
+constexpr int LANE_MAXCAND = 48;    // = W_MAXCAND below: contact candidates recorded per sub-step before the selection
 constexpr int MAXR = 3 * MAXC + NJ; // max constraint rows
 
 struct ModelRef {   // offsets into one task's table row
@@ -315,31 +316,28 @@ __device__ void substep(const mg_walker_topology &tp, const ModelRef &m, const m
     double J[MAXR][ND], W[MAXR][ND];   // W_r = M^-1 J_r^T
     double bias[MAXR], diag[MAXR], lam[MAXR];
     int kind[MAXR], partner[MAXR];
-    int nr = 0, ncontacts = 0;
+    // contact candidates in candidate order (ground per proxy, then self pairs; at most W_MAXCAND), then the MAXC deepest of them
+    // in candidate order — the wave kernel's two steps (and oracle/abd.py contact_candidates / select_contacts), serially
+    int nr = 0;
     touch_mask = 0ull;
-    for (int g = 0; g < ns && ncontacts < MAXC; ++g) {
+    double qx[LANE_MAXCAND][6], qdepth[LANE_MAXCAND];
+    int qid[LANE_MAXCAND][2];
+    int ncand = 0;
+    for (int g = 0; g < ns; ++g) {
         const int b = tp.sphere_body[g];
         const V3 x = k.o[b] + mulMv(k.R[b], ld3(m.sph_pos + 3 * g));
         const double depth = m.sph_r[g] - x.z;
-        if (depth > 0.0) {
-            const V3 xc{x.x, x.y, 0.0};
-            const unsigned mk = k.mask[b];
-            for (int d = 0; d < n; ++d) {
-                const V3 jc = jac_lin(k, mk, xc, d);
-                J[nr][d] = jc.z;
-                J[nr + 1][d] = jc.x;
-                J[nr + 2][d] = jc.y;
+        if (depth > -prm.contact_margin) {
+            touch_mask |= 1ull << g;                   // every proxy inside the margin: what getContactPoints reports
+            if (ncand < LANE_MAXCAND) {
+                qx[ncand][0] = x.x; qx[ncand][1] = x.y; qx[ncand][2] = 0.0;
+                qid[ncand][0] = g; qid[ncand][1] = -1; qdepth[ncand] = depth;
+                ++ncand;
             }
-            bias[nr] = prm.erp * depth / dt; kind[nr] = 0; partner[nr] = -1;
-            bias[nr + 1] = 0.0; kind[nr + 1] = 1; partner[nr + 1] = nr;
-            bias[nr + 2] = 0.0; kind[nr + 2] = 2; partner[nr + 2] = nr;
-            nr += 3;
-            ++ncontacts;
-            touch_mask |= 1ull << g;
         }
     }
     if (prm.self_collision)
-        for (int pr = 0; pr < tp.n_pairs && ncontacts < MAXC; ++pr) {
+        for (int pr = 0; pr < tp.n_pairs && ncand < LANE_MAXCAND; ++pr) {
             const int ga = tp.pair_a[pr], gb = tp.pair_b[pr], ba = tp.geom_body[ga], bb = tp.geom_body[gb];
             V3 ca, cb;
             segment_closest(k.o[ba] + mulMv(k.R[ba], ld3(m.geom_p0 + 3 * ga)), k.o[ba] + mulMv(k.R[ba], ld3(m.geom_p1 + 3 * ga)),
@@ -350,21 +348,46 @@ __device__ void substep(const mg_walker_topology &tp, const ModelRef &m, const m
             if (depth > 0.0 && dist > 1e-9) {
                 const V3 nrm = (1.0 / dist) * dv;
                 const V3 xc = 0.5 * ((ca - m.geom_r[ga] * nrm) + (cb + m.geom_r[gb] * nrm));
-                V3 t1, t2;
-                tangent_basis(nrm, t1, t2);
-                for (int d = 0; d < n; ++d) {
-                    const V3 jd = jac_lin(k, k.mask[ba], xc, d) - jac_lin(k, k.mask[bb], xc, d);
-                    J[nr][d] = dot(nrm, jd);
-                    J[nr + 1][d] = dot(t1, jd);
-                    J[nr + 2][d] = dot(t2, jd);
-                }
-                bias[nr] = prm.erp * depth / dt; kind[nr] = 0; partner[nr] = -1;
-                bias[nr + 1] = 0.0; kind[nr + 1] = 3; partner[nr + 1] = nr;
-                bias[nr + 2] = 0.0; kind[nr + 2] = 3; partner[nr + 2] = nr;
-                nr += 3;
-                ++ncontacts;
+                qx[ncand][0] = xc.x; qx[ncand][1] = xc.y; qx[ncand][2] = xc.z; qx[ncand][3] = nrm.x; qx[ncand][4] = nrm.y; qx[ncand][5] = nrm.z;
+                qid[ncand][0] = ba; qid[ncand][1] = bb; qdepth[ncand] = depth;
+                ++ncand;
             }
         }
+    for (int c = 0; c < ncand; ++c) {
+        if (ncand > MAXC) {
+            int rank = 0;
+            const double kc = floor(qdepth[c] * 1048576.0);      // (depths on a 2^-20 m grid: see the wave kernel's selection)
+            for (int o = 0; o < ncand; ++o) { const double ko = floor(qdepth[o] * 1048576.0); rank += (ko > kc || (ko == kc && o < c)) ? 1 : 0; }
+            if (rank >= MAXC) continue;
+        }
+        const V3 xc{qx[c][0], qx[c][1], qx[c][2]};
+        const double depth = qdepth[c];
+        if (qid[c][1] == -1) {                         // ground: point on the plane under the proxy
+            const unsigned mk = k.mask[tp.sphere_body[qid[c][0]]];
+            for (int d = 0; d < n; ++d) {
+                const V3 jc = jac_lin(k, mk, xc, d);
+                J[nr][d] = jc.z;
+                J[nr + 1][d] = jc.x;
+                J[nr + 2][d] = jc.y;
+            }
+        } else {
+            const V3 nrm{qx[c][3], qx[c][4], qx[c][5]};
+            const int ba = qid[c][0], bb = qid[c][1];
+            V3 t1, t2;
+            tangent_basis(nrm, t1, t2);
+            for (int d = 0; d < n; ++d) {
+                const V3 jd = jac_lin(k, k.mask[ba], xc, d) - jac_lin(k, k.mask[bb], xc, d);
+                J[nr][d] = dot(nrm, jd);
+                J[nr + 1][d] = dot(t1, jd);
+                J[nr + 2][d] = dot(t2, jd);
+            }
+        }
+        const int fk = qid[c][1] == -1 ? 1 : 3;
+        bias[nr] = (depth >= 0.0 ? prm.erp * depth : depth) / dt; kind[nr] = 0; partner[nr] = -1;
+        bias[nr + 1] = 0.0; kind[nr + 1] = fk; partner[nr + 1] = nr;
+        bias[nr + 2] = 0.0; kind[nr + 2] = fk == 1 ? 2 : 3; partner[nr + 2] = nr;
+        nr += 3;
+    }
     for (int j = 0; j < nj; ++j) {
         double sgn = 0.0, viol = 0.0;
         if (s.q[j] < m.joint_lo[j]) { sgn = 1.0; viol = m.joint_lo[j] - s.q[j]; }
@@ -658,7 +681,8 @@ constexpr int WV = 64;
 #ifndef MG_W_MAXC
 #define MG_W_MAXC 12      // (timing experiments only — profiles/r05/walker_third_wave.txt: fewer kept contacts = a smaller Jh block)
 #endif
-constexpr int W_MAXC = MG_W_MAXC;   // ground contacts kept per env (first W_MAXC penetrating spheres)
+constexpr int W_MAXC = MG_W_MAXC;   // contacts the solver keeps per env: the W_MAXC deepest of the candidates
+constexpr int W_MAXCAND = 48;       // contact candidates recorded per sub-step before the selection (abd.MAX_CANDIDATES, WO_MAX_CANDIDATES)
 
 // Robot shape as template constants (all zero = read the topology at run time). Every MetaLocomotion variant of a
 // robot shares one shape (humanoid: 13 bodies, 17 hinges, 29 collision spheres, 17 capsules; ant: 13 / 8 / 25 / 13),
@@ -1297,13 +1321,25 @@ __device__ __forceinline__ void wave_substep(const mg_walker_topology &tp, const
     }
     PHASE(4);
     // ---- constraint detection ------------------------------------------------------------------------
-    //      lane = collision proxy, 64 at a time (the two tuned shapes have at most 64: one pass). Slots in proxy order,
-    //      the first W_MAXC penetrating ones are kept. With per-proxy friction (mg_walker_params.sphere_friction) a ground
-    //      friction row carries its own coefficient in the (otherwise zero) bias slot, kind -1, like a terrain row.
+    //      Two steps (oracle/abd.py contact_candidates / select_contacts). (1) CANDIDATES, lane = collision proxy / geom pair, 64 at
+    //      a time, recorded in candidate order (ground per proxy, terrain per proxy, self pairs; ballot + popcount gives the
+    //      position) in the idle Jh block behind the capsule end points of the self-collision pass: cx layout (6 doubles), depth,
+    //      friction coefficient, and the two ids of csphere; at most cand_cap (W_MAXCAND, later ones dropped). A proxy is a ground /
+    //      terrain candidate while depth > -contact_margin (mg_walker_params.contact_margin, Bullet's contact-breaking
+    //      threshold), and `touch` = every such proxy, kept by the solver or not — what getContactPoints reports
+    //      (walker_base_env.py:57-63). Self pairs: penetration only. (2) SELECTION, lane = candidate: with more than W_MAXC
+    //      candidates the W_MAXC deepest stay (rank by depth, ties to the earlier candidate), in candidate order; each kept lane
+    //      writes its contact slot and its three rows. Normal-row bias: erp * depth / dt penetrating, the speculative
+    //      depth / dt (< 0) inside the margin. With per-proxy friction (mg_walker_params.sphere_friction) a ground friction row
+    //      carries its own coefficient in the (otherwise zero) bias slot, kind -1, like a terrain row.
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
     const int nchunk = GENERIC ? (ns + WV - 1) / WV : 1;
     const bool own_mu = GENERIC && prm.sphere_friction != nullptr;
-    int ncont = 0;
+    const double margin = prm.contact_margin;
+    const int cand_cap = min(W_MAXCAND, (maxr * n - 8 * m.ng) / 9);       // (mg_walker_step: = W_MAXCAND, or every possible candidate fits)
+    double *cand = L.J + 8 * m.ng;                                        // [cand_cap][8]
+    int *cand_id = reinterpret_cast<int *>(cand + 8 * cand_cap);          // [cand_cap][2]
+    int ncand = 0;
     touch[0] = 0ull;
     touch[1] = 0ull;
     for (int ch = 0; ch < nchunk; ++ch) {
@@ -1314,30 +1350,27 @@ __device__ __forceinline__ void wave_substep(const mg_walker_topology &tp, const
             const int b = L.sbody[g];
             const V3 xw = ldv(L.o, b) + mulMv(L.R + 9 * b, ld3(m.sph_pos() + 3 * g));
             depth = m.sph_r()[g] - xw.z;
-            hit = depth > 0.0;
+            hit = depth > -margin;
             sx = xw.x; sy = xw.y;
         }
         const unsigned long long hits = __ballot(hit);
-        const int slot = ncont + __popcll(hits & lt_mask);
-        const bool kept = hit && slot < W_MAXC;
-        if (kept) {
-            L.cx[6 * slot] = sx; L.cx[6 * slot + 1] = sy; L.cx[6 * slot + 2] = depth;
-            L.csphere[2 * slot] = g; L.csphere[2 * slot + 1] = -1;       // ground contact of proxy g
+        const int pos = ncand + __popcll(hits & lt_mask);
+        if (hit && pos < cand_cap) {
+            double *cc = cand + 8 * pos;
+            cc[0] = sx; cc[1] = sy; cc[2] = depth; cc[6] = depth;
             // (every friction row carries its mu; a foot proxy takes the robot's own coefficient when there is one: foot_mu >= 0)
-            const double mu = own_mu ? prm.friction * ((foot_mu >= 0.0 && L.sfoot[g] >= 0) ? foot_mu : prm.sphere_friction[g]) : prm.friction;
-            L.bias[3 * slot] = prm.erp * depth / dt; L.kind[3 * slot] = 0; L.partner[3 * slot] = -1;
-            L.bias[3 * slot + 1] = mu; L.kind[3 * slot + 1] = own_mu ? -1 : 1; L.partner[3 * slot + 1] = 3 * slot;
-            L.bias[3 * slot + 2] = mu; L.kind[3 * slot + 2] = own_mu ? -1 : 2; L.partner[3 * slot + 2] = 3 * slot;
+            cc[7] = own_mu ? prm.friction * ((foot_mu >= 0.0 && L.sfoot[g] >= 0) ? foot_mu : prm.sphere_friction[g]) : prm.friction;
+            cand_id[2 * pos] = g; cand_id[2 * pos + 1] = -1;             // ground contact of proxy g
         }
-        touch[GENERIC ? ch : 0] = __ballot(kept);
-        ncont = min(ncont + __popcll(hits), W_MAXC);
+        touch[GENERIC ? ch : 0] = hits;
+        ncand = min(ncand + __popcll(hits), cand_cap);
     }
     // terrain: lane = collision proxy against the static boxes (`terrain`: the batch's one course, or this env's course of
     // the terrain table, mg_walker_params.terrain_id; wave-uniform loop either way: one wave = one env; boxes whose
     // x range misses the chunk's proxies are skipped by the whole wave); per proxy the deepest box, first on ties. Slots
     // after the ground contacts; the friction rows carry the contact's coefficient in their (otherwise zero) bias slot, kind -1.
     if (GENERIC && prm.n_terrain_boxes > 0)
-        for (int ch = 0; ch < nchunk && ncont < W_MAXC; ++ch) {
+        for (int ch = 0; ch < nchunk && ncand < cand_cap; ++ch) {
             const int g = ch * WV + lane;
             double rad = 0.0, sx = 0.0, sy = 0.0, sz = 0.0;
             if (g < ns) {
@@ -1349,8 +1382,8 @@ __device__ __forceinline__ void wave_substep(const mg_walker_topology &tp, const
             // x range of this chunk's proxies, radius included (y / z ranges as well were measured: they cull nothing more on the
             // reference's courses — rows of boxes along x, a cave the robot does touch — and cost 2 %)
             const bool has = g < ns;
-            const double lo = wave_minmax<false>(has ? sx - rad : 1e300), hi = wave_minmax<true>(has ? sx + rad : -1e300);
-            double bdepth = 0.0, bmu = 0.0;
+            const double lo = wave_minmax<false>(has ? sx - rad - margin : 1e300), hi = wave_minmax<true>(has ? sx + rad + margin : -1e300);
+            double bdepth = -margin, bmu = 0.0;
             V3 bn{0, 0, 1}, bx{0, 0, 0};
             // Broad phase, lane = box (64 per pass): a box whose world x extent misses the x range of this chunk's proxies cannot touch
             // any of them. The survivors (a course is a row of boxes along x: two to five of the reference's 44 ... 68) are then
@@ -1400,28 +1433,24 @@ __device__ __forceinline__ void wave_substep(const mg_walker_topology &tp, const
                 }
               }
             }
-            const bool th = bdepth > 0.0;
+            const bool th = bdepth > -margin;
             const unsigned long long th_mask = __ballot(th);
-            const int slot = ncont + __popcll(th_mask & lt_mask);
-            const bool kept = th && slot < W_MAXC;
-            if (kept) {
+            const int pos = ncand + __popcll(th_mask & lt_mask);
+            if (th && pos < cand_cap) {
                 if (own_mu) bmu *= (foot_mu >= 0.0 && L.sfoot[g] >= 0) ? foot_mu : prm.sphere_friction[g];
-                double *cc = L.cx + 6 * slot;
-                cc[0] = bx.x; cc[1] = bx.y; cc[2] = bx.z; cc[3] = bn.x; cc[4] = bn.y; cc[5] = bn.z;
-                L.csphere[2 * slot] = g; L.csphere[2 * slot + 1] = -2;                // proxy g against the world
-                L.bias[3 * slot] = prm.erp * bdepth / dt; L.kind[3 * slot] = 0; L.partner[3 * slot] = -1;
-                L.bias[3 * slot + 1] = bmu; L.kind[3 * slot + 1] = -1; L.partner[3 * slot + 1] = 3 * slot;
-                L.bias[3 * slot + 2] = bmu; L.kind[3 * slot + 2] = -1; L.partner[3 * slot + 2] = 3 * slot;
+                double *cc = cand + 8 * pos;
+                cc[0] = bx.x; cc[1] = bx.y; cc[2] = bx.z; cc[3] = bn.x; cc[4] = bn.y; cc[5] = bn.z; cc[6] = bdepth; cc[7] = bmu;
+                cand_id[2 * pos] = g; cand_id[2 * pos + 1] = -2;                      // proxy g against the world
             }
-            touch[ch] |= __ballot(kept);
-            ncont = min(ncont + __popcll(th_mask), W_MAXC);
+            touch[ch] |= th_mask;
+            ncand = min(ncand + __popcll(th_mask), cand_cap);
         }
     // self-collision: lane = geom pair (in pair order, 64 at a time); slots after the ground and terrain contacts.
     // The capsules' world end points are computed once per geom (lane = geom) into the idle Jh block; a pair then runs
     // the closest-point routine only if its bounding spheres overlap (mid-point distance < half lengths + radii — exactly
     // conservative), and a chunk whose pairs are all apart skips it as a wave (the humanoid's 66 pairs: the second
     // chunk holds two).
-    if (prm.self_collision && tp.n_pairs > 0 && ncont < W_MAXC) {
+    if (prm.self_collision && tp.n_pairs > 0 && ncand < cand_cap) {
         double *seg = L.J;            // [ng][8]: p0 (3), p1 (3), radius, half length
         for (int g = lane; g < m.ng; g += WV) {
             const int b = tp.geom_body[g];
@@ -1433,7 +1462,7 @@ __device__ __forceinline__ void wave_substep(const mg_walker_topology &tp, const
             sg[6] = m.geom_r()[g]; sg[7] = 0.5 * sqrt(dot(d, d));
         }
         WSYNC();
-        for (int base = 0; base < tp.n_pairs && ncont < W_MAXC; base += WV) {
+        for (int base = 0; base < tp.n_pairs && ncand < cand_cap; base += WV) {
             const int pr = base + lane;
             bool sh = false, near = false;
             V3 xc{0, 0, 0}, nrm{0, 0, 1};
@@ -1464,16 +1493,44 @@ __device__ __forceinline__ void wave_substep(const mg_walker_topology &tp, const
                 }
             }
             const unsigned long long sh_mask = __ballot(sh);
-            const int slot = ncont + __popcll(sh_mask & ((1ull << lane) - 1ull));
-            if (sh && slot < W_MAXC) {
-                double *cc = L.cx + 6 * slot;
-                cc[0] = xc.x; cc[1] = xc.y; cc[2] = xc.z; cc[3] = nrm.x; cc[4] = nrm.y; cc[5] = nrm.z;
-                L.csphere[2 * slot] = ba; L.csphere[2 * slot + 1] = bb;
-                L.bias[3 * slot] = prm.erp * sdepth / dt; L.kind[3 * slot] = 0; L.partner[3 * slot] = -1;
-                L.bias[3 * slot + 1] = prm.self_friction; L.kind[3 * slot + 1] = 3; L.partner[3 * slot + 1] = 3 * slot;
-                L.bias[3 * slot + 2] = prm.self_friction; L.kind[3 * slot + 2] = 3; L.partner[3 * slot + 2] = 3 * slot;
+            const int pos = ncand + __popcll(sh_mask & lt_mask);
+            if (sh && pos < cand_cap) {
+                double *cc = cand + 8 * pos;
+                cc[0] = xc.x; cc[1] = xc.y; cc[2] = xc.z; cc[3] = nrm.x; cc[4] = nrm.y; cc[5] = nrm.z; cc[6] = sdepth; cc[7] = prm.self_friction;
+                cand_id[2 * pos] = ba; cand_id[2 * pos + 1] = bb;
             }
-            ncont = min(ncont + __popcll(sh_mask), W_MAXC);
+            ncand = min(ncand + __popcll(sh_mask), cand_cap);
+        }
+    }
+    // selection: lane = candidate (cand_cap <= 64)
+    const int ncont = min(ncand, W_MAXC);
+    if (ncand > 0) {
+        WSYNC();
+        bool keep = lane < ncand;
+        const double cdepth = keep ? cand[8 * lane + 6] : 0.0;
+        if (ncand > W_MAXC) {           // rank = candidates that go first: deeper ones, and equally deep earlier ones. Depths are
+            int rank = 0;               // compared on a 2^-20 m (0.95 um) grid (abd.depth_key): points equally deep by symmetry differ
+            const double ckey = floor(cdepth * 1048576.0);        // by round-off between implementations and must tie
+            for (int o = 0; o < ncand; ++o) {
+                const double okey = lane_value(ckey, o);
+                rank += (okey > ckey || (okey == ckey && o < lane)) ? 1 : 0;
+            }
+            keep = keep && rank < W_MAXC;
+        }
+        const unsigned long long keep_mask = __ballot(keep);
+        if (keep) {
+            const int slot = __popcll(keep_mask & lt_mask);
+            const double *cc = cand + 8 * lane;
+            double *cx = L.cx + 6 * slot;
+#pragma unroll
+            for (int i = 0; i < 6; ++i) cx[i] = cc[i];
+            const int id1 = cand_id[2 * lane + 1];
+            L.csphere[2 * slot] = cand_id[2 * lane]; L.csphere[2 * slot + 1] = id1;
+            const double mu = cc[7];
+            const int fk = id1 >= 0 ? 3 : ((id1 == -2 || own_mu) ? -1 : 1);         // self / own coefficient / the robot's one ground coefficient
+            L.bias[3 * slot] = (cdepth >= 0.0 ? prm.erp * cdepth : cdepth) / dt; L.kind[3 * slot] = 0; L.partner[3 * slot] = -1;
+            L.bias[3 * slot + 1] = mu; L.kind[3 * slot + 1] = fk; L.partner[3 * slot + 1] = 3 * slot;
+            L.bias[3 * slot + 2] = mu; L.kind[3 * slot + 2] = fk == 1 ? 2 : fk; L.partner[3 * slot + 2] = 3 * slot;
         }
     }
     double lsgn = 0.0, viol = 0.0;
@@ -2184,6 +2241,15 @@ extern "C" int mg_walker_step(const mg_walker_topology *tp, const mg_walker_mode
             fd = 15;
             overlay = need + fd * (size_t)tp->n_bodies <= block;
         }
+    }
+    {   // the detection pass records its contact candidates in the Jh block behind the capsules' end points (9 doubles each):
+        // either W_MAXCAND of them fit, or every candidate this topology can produce does — the oracle's cap is then never reached
+        const size_t block = (size_t)maxr * ndof_of(tp), seg = 8 * (size_t)tp->n_geoms;
+        const size_t cap = block > seg ? (block - seg) / 9 : 0;
+        const size_t possible = (size_t)tp->n_spheres * (prm->n_terrain_boxes > 0 ? 2 : 1) + (prm->self_collision ? (size_t)tp->n_pairs : 0);
+        if (cap < (size_t)W_MAXCAND && cap < possible)
+            return mg::set_error(MG_ERR_UNSUPPORTED, "walker topology: %zu contact candidates possible, the wave mapping has scratch for %zu "
+                                 "(< %d): use mapping = lane", possible, cap, W_MAXCAND);
     }
     // rounds of the kinematics scans: 2^rh >= longest chain of hops (body offsets + joints), 2^jr >= longest chain of joints
     int rh = 0, jr = 0;

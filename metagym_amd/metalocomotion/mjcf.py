@@ -162,9 +162,9 @@ def _aabb_box_inertia(mass, geoms, com):
 # What each preset makes of the file; every entry can be overridden per call (load_mjcf keyword of the same name).
 PRESETS = {
     "bullet": dict(inertia="bullet_box", com="body_origin", armature="ignore", damping="ignore", stiffness="ignore",
-                   body_damping=(0.04, 0.04), max_velocity=100.0),
+                   body_damping=(0.04, 0.04), max_velocity=100.0, contact_margin=0.02),
     "mujoco": dict(inertia="geom", com="geom", armature="diagonal", damping="explicit", stiffness="spring",
-                   body_damping=(0.0, 0.0), max_velocity=0.0),
+                   body_damping=(0.0, 0.0), max_velocity=0.0, contact_margin=0.0),
 }
 DEFAULT_PRESET = "bullet"
 
@@ -299,6 +299,7 @@ def load_mjcf(path_or_string, foot_names=("right_foot", "left_foot"), preset=Non
     # from their own `preset` / `body_damping` arguments, this copy records what the model was loaded for
     m.body_damping = np.array(opt["body_damping"], np.float64)
     m.max_velocity = np.array(float(opt["max_velocity"]))      # btMultiBody's m_maxCoordinateVelocity clamp (0 = off)
+    m.contact_margin = np.array(float(opt["contact_margin"]))  # Bullet's contact-breaking threshold (0 = penetration only)
     m.preset = np.array(DEFAULT_PRESET if preset is None else preset)
     m.sph_body = np.array([s[0] for s in spheres], np.int32)
     m.sph_pos = np.array([s[1] for s in spheres])

@@ -61,7 +61,7 @@ class WalkerBatchEnv(object):
                  max_steps=2000, assets_dir=None, solver_iterations=5, mapping="wave", self_collision=True,
                  auto_reset=False, seed=0, env_id_base=0, gravity=GRAVITY, ground_friction=GROUND_FRICTION,
                  body_damping=None, per_proxy_friction=False, contact_erp=CONTACT_ERP, foot_force=False, preset=None,
-                 max_coordinate_velocity=None):
+                 max_coordinate_velocity=None, contact_margin=None):
         self._lib = _lib.load()
         self.num_envs = int(num_envs)
         self.device = _lib.canonical_device(device)
@@ -88,6 +88,13 @@ class WalkerBatchEnv(object):
         if max_coordinate_velocity is None:
             max_coordinate_velocity = preset_options(self.preset)["max_velocity"]
         self.max_coordinate_velocity = float(max_coordinate_velocity)
+        #   contact_margin              Bullet's contact-breaking threshold (mg_walker_params.contact_margin): a proxy within it
+        #                               above the ground / a terrain box is a contact point — a speculative solver row and a
+        #                               feet_contact flag (walker_base_env.py:57-63 reads getContactPoints). 0.02 m in the
+        #                               'bullet' preset, 0 (penetration only) in the 'mujoco' one
+        if contact_margin is None:
+            contact_margin = preset_options(self.preset)["contact_margin"]
+        self.contact_margin = float(contact_margin)
         self.per_proxy_friction = bool(per_proxy_friction)
         #   contact_erp                 0.9 for MetaLocomotion (scene_bases.py:55 setDefaultContactERP); a world that never calls it
         #                               keeps Bullet's default 0.2 (btContactSolverInfo::m_erp2) — the quadrupedal one
@@ -218,6 +225,7 @@ class WalkerBatchEnv(object):
             p.friction, p.sphere_friction = self.ground_friction * float(m0.geom_friction), None
         p.body_linear_damping, p.body_angular_damping = self.body_damping
         p.max_coordinate_velocity = self.max_coordinate_velocity
+        p.contact_margin = self.contact_margin
         p.alive_z, p.alive_bonus, p.dead_bonus = self.alive_z, self.alive_bonus, -1.0
         p.initial_z = float(self.initial_z if self.initial_z is not None else m0.body_pos[0][2])
         p.joints_at_limit_cost = -0.1                              # walker_base_env.py:22

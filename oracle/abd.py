@@ -170,7 +170,10 @@ def integrate_positions(s, dt):
 class Params(object):
     def __init__(self, dt=0.005, substeps=4, iterations=5, erp=0.9, friction=0.8 * 0.8, power=0.41, max_contacts=12,
                  limit_erp=0.2, self_collision=True, self_friction=0.8 * 0.8, terrain=(), gravity=None, sphere_friction=None,
-                 body_damping=(0.0, 0.0), max_velocity=0.0):
+                 body_damping=(0.0, 0.0), max_velocity=0.0, contact_margin=0.0):
+        # Bullet's contact-breaking threshold (gContactBreakingThreshold = 0.02 m): a proxy within this distance ABOVE the ground or
+        # a terrain box is a contact point — a speculative solver row (contact_bias) and a feet_contact flag. 0 = penetration only
+        self.contact_margin = float(contact_margin)
         self.max_velocity = float(max_velocity)   # btMultiBody's m_maxCoordinateVelocity (100 in Bullet): clamp of every generalized
         #                                           velocity at the end of a sub-step (mg_walker_params.max_coordinate_velocity); 0 = off
         self.terrain = list(terrain)          # static boxes on top of the ground plane: (position[3], R[3,3] box->world, half_extents[3], mu)
@@ -183,7 +186,7 @@ class Params(object):
         self.limit_erp = limit_erp            # Bullet's default constraint ERP (btContactSolverInfo::m_erp2 = 0.2);
         #                                       setDefaultContactERP(0.9) only changes the contact ERP
         self.self_collision, self.self_friction = self_collision, self_friction   # geom friction squared
-        self.max_contacts = max_contacts      # engine limit (ground contacts first, then self contacts): the first max_contacts penetrating spheres are kept
+        self.max_contacts = max_contacts      # engine limit: of the ground, terrain and self-contact candidates the max_contacts DEEPEST are kept (select_contacts)
 
 
 def segment_closest(p1, q1, p2, q2):
@@ -241,55 +244,50 @@ def tangent_basis(nrm):
     return t1, np.cross(nrm, t1)
 
 
-def constraint_rows(m, s, kin, prm):
-    """Rows (J, bias, kind, partner): kind 0 = unilateral (lambda >= 0), 1/2 = friction rows whose
-    bound is friction * lambda[partner]. bias is the target velocity along the row."""
-    rows = []
-    n = 6 + len(m.joint_body)
+MAX_CANDIDATES = 48     # contact candidates collected per sub-step before the selection (walker.hip W_MAXCAND): later ones are dropped
+
+
+def contact_bias(depth, prm):
+    """Target velocity along a contact normal (the row is J u >= bias). Penetration (depth >= 0): Baumgarte push-out
+    erp * depth / dt. Separation inside the contact margin (depth < 0): the SPECULATIVE row of Bullet's
+    setupMultiBodyContactConstraint / setupContactConstraint — `penetration = distance + slop > 0`: positional error 0 and
+    velocityError -= penetration / dt — i.e. the proxy may approach the surface by at most its gap per step: depth / dt (< 0),
+    no ERP."""
+    return (prm.erp * depth if depth >= 0.0 else depth) / prm.dt
+
+
+def contact_candidates(m, s, kin, prm):
+    """Contact candidates of one configuration in CANDIDATE ORDER — ground plane per collision proxy (proxy order), then terrain
+    (per proxy the deepest box, first on ties), then self-collision pairs (pair order) — as dicts, and the set of proxies
+    `touching` = every proxy with a ground / terrain candidate: what pybullet.getContactPoints reports (walker_base_env.py:57-63
+    via robot_bases.py:291-292: all manifold points within the contact-breaking margin), whether or not the solver's contact
+    cap kept the point.
+
+    prm.contact_margin (mg_walker_params.contact_margin; Bullet's gContactBreakingThreshold = 0.02 m; 0 = penetration only):
+    a proxy is a ground / terrain candidate while depth > -margin. Self-collision pairs stay penetration-only."""
+    mg = float(getattr(prm, "contact_margin", 0.0))
+    cands, touching = [], set()
     for g in range(len(m.sph_body)):
         b = m.sph_body[g]
         x = kin["o"][b] + kin["R"][b] @ m.sph_pos[g]
         depth = m.sph_radius[g] - x[2]
-        if depth > 0.0 and len(rows) < 3 * prm.max_contacts:
-            xc = np.array([x[0], x[1], 0.0])           # contact point on the ground plane
-            Jc = point_jacobian(m, kin, b, xc)
-            k = len(rows)
-            rows.append((Jc[2], prm.erp * depth / prm.dt, 0, -1, g, np.array([0.0, 0.0, 1.0])))     # (.., proxy, contact normal)
-            if prm.sphere_friction is None:
-                rows.append((Jc[0], 0.0, 1, k, g))
-                rows.append((Jc[1], 0.0, 2, k, g))
-            else:
-                mu = prm.friction * prm.sphere_friction[g]
-                rows.append((Jc[0], 0.0, -1, k, g, mu))
-                rows.append((Jc[1], 0.0, -1, k, g, mu))
-    # terrain: per collision sphere the deepest static box (first on ties); friction rows carry the box's own coefficient
+        if depth > -mg:
+            touching.add(g)
+            cands.append(dict(cat=0, g=g, depth=depth, xc=np.array([x[0], x[1], 0.0]), nrm=np.array([0.0, 0.0, 1.0])))
     if prm.terrain:
         for g in range(len(m.sph_body)):
-            if len(rows) >= 3 * prm.max_contacts:
-                break
             b = m.sph_body[g]
             x = kin["o"][b] + kin["R"][b] @ m.sph_pos[g]
             best = None
             for box in prm.terrain:
                 depth, nrm, xc = sphere_box(x, m.sph_radius[g], box)
-                if depth > 0.0 and (best is None or depth > best[0]):
+                if depth > -mg and (best is None or depth > best[0]):
                     best = (depth, nrm, xc, box[3])
             if best is not None:
-                depth, nrm, xc, mu = best
-                if prm.sphere_friction is not None:
-                    mu = mu * prm.sphere_friction[g]
-                Jc = point_jacobian(m, kin, b, xc)
-                t1, t2 = tangent_basis(nrm)
-                k = len(rows)
-                rows.append((nrm @ Jc, prm.erp * depth / prm.dt, 0, -1, g, nrm))
-                rows.append((t1 @ Jc, 0.0, -1, k, g, mu))
-                rows.append((t2 @ Jc, 0.0, -1, k, g, mu))
-    # self-collision between the capsule geoms of bodies that are neither ancestor-related nor welded
-    # (PyBullet flags at robot_bases.py:119); friction = geom friction squared (Bullet multiplies)
+                touching.add(g)
+                cands.append(dict(cat=1, g=g, depth=best[0], nrm=best[1], xc=best[2], mu=best[3]))
     if prm.self_collision and hasattr(m, "pair_a"):
         for ga, gb in zip(m.pair_a, m.pair_b):
-            if len(rows) >= 3 * prm.max_contacts:
-                break
             ba, bb = m.geom_body[ga], m.geom_body[gb]
             a0 = kin["o"][ba] + kin["R"][ba] @ m.geom_p0[ga]
             a1 = kin["o"][ba] + kin["R"][ba] @ m.geom_p1[ga]
@@ -304,12 +302,67 @@ def constraint_rows(m, s, kin, prm):
                 # one contact point for both bodies (middle of the overlap): equal and opposite forces at
                 # the same point change neither the linear nor the angular momentum of the robot
                 xc = 0.5 * ((ca - m.geom_radius[ga] * nrm) + (cb + m.geom_radius[gb] * nrm))
-                Jd = point_jacobian(m, kin, ba, xc) - point_jacobian(m, kin, bb, xc)
-                t1, t2 = tangent_basis(nrm)
-                k = len(rows)
-                rows.append((nrm @ Jd, prm.erp * depth / prm.dt, 0, -1, -2))
-                rows.append((t1 @ Jd, 0.0, 3, k, -2))
-                rows.append((t2 @ Jd, 0.0, 3, k, -2))
+                cands.append(dict(cat=2, ba=ba, bb=bb, depth=depth, nrm=nrm, xc=xc))
+    return cands[:MAX_CANDIDATES], touching
+
+
+def depth_key(depth):
+    """The ranking key of the contact cap: the depth on a 2^-20 m grid (exact in float64: a power-of-two scaling and a floor)."""
+    return float(np.floor(depth * 1048576.0))
+
+
+def select_contacts(cands, max_contacts):
+    """The solver's contact cap: with more than `max_contacts` candidates the DEEPEST are kept (ties on depth_key's grid: the earlier candidate),
+    and the kept ones stay in candidate order — penetrating points of any kind go before speculative ones."""
+    if len(cands) <= max_contacts:
+        return list(cands)
+    # depths are compared on a 2^-20 m (0.95 um) grid: contact points that are equally deep by symmetry (a robot lying flat, two
+    # feet side by side) differ by round-off from one implementation to the next, and must not be ordered by that round-off
+    order = sorted(range(len(cands)), key=lambda i: (-depth_key(cands[i]["depth"]), i))
+    keep = sorted(order[:max_contacts])
+    return [cands[i] for i in keep]
+
+
+def constraint_rows(m, s, kin, prm, touching_out=None):
+    """Rows (J, bias, kind, partner, proxy, normal | mu): kind 0 = unilateral (lambda >= 0), 1/2 = ground friction rows whose
+    bound is friction * lambda[partner], -1 = friction row carrying its own coefficient, 3 = self-contact friction. bias is the
+    target velocity along the row. `touching_out` (a set) receives the proxies with a ground / terrain candidate."""
+    rows = []
+    n = 6 + len(m.joint_body)
+    cands, touching = contact_candidates(m, s, kin, prm)
+    if touching_out is not None:
+        touching_out |= touching
+    for c in select_contacts(cands, prm.max_contacts):
+        k = len(rows)
+        if c["cat"] == 0:
+            g = c["g"]
+            Jc = point_jacobian(m, kin, m.sph_body[g], c["xc"])
+            rows.append((Jc[2], contact_bias(c["depth"], prm), 0, -1, g, c["nrm"]))     # (.., proxy, contact normal)
+            if prm.sphere_friction is None:
+                rows.append((Jc[0], 0.0, 1, k, g))
+                rows.append((Jc[1], 0.0, 2, k, g))
+            else:
+                mu = prm.friction * prm.sphere_friction[g]
+                rows.append((Jc[0], 0.0, -1, k, g, mu))
+                rows.append((Jc[1], 0.0, -1, k, g, mu))
+        elif c["cat"] == 1:      # terrain: friction rows carry the box's own coefficient
+            g, nrm, mu = c["g"], c["nrm"], c["mu"]
+            if prm.sphere_friction is not None:
+                mu = mu * prm.sphere_friction[g]
+            Jc = point_jacobian(m, kin, m.sph_body[g], c["xc"])
+            t1, t2 = tangent_basis(nrm)
+            rows.append((nrm @ Jc, contact_bias(c["depth"], prm), 0, -1, g, nrm))
+            rows.append((t1 @ Jc, 0.0, -1, k, g, mu))
+            rows.append((t2 @ Jc, 0.0, -1, k, g, mu))
+        else:
+            # self-collision between the capsule geoms of bodies that are neither ancestor-related nor welded
+            # (PyBullet flags at robot_bases.py:119); friction = geom friction squared (Bullet multiplies)
+            nrm = c["nrm"]
+            Jd = point_jacobian(m, kin, c["ba"], c["xc"]) - point_jacobian(m, kin, c["bb"], c["xc"])
+            t1, t2 = tangent_basis(nrm)
+            rows.append((nrm @ Jd, contact_bias(c["depth"], prm), 0, -1, -2))
+            rows.append((t1 @ Jd, 0.0, 3, k, -2))
+            rows.append((t2 @ Jd, 0.0, 3, k, -2))
     for j in range(len(m.joint_body)):
         e = np.zeros(n)
         if s.q[j] < m.joint_lo[j]:
@@ -367,8 +420,8 @@ def substep(m, s, tau_motor, prm, out=None, ext=None):
     L = np.linalg.cholesky(M)
     solve = lambda rhs: np.linalg.solve(L.T, np.linalg.solve(L, rhs))
     u_star = u + prm.dt * solve(tau - h)
-    rows = constraint_rows(m, s, kin, prm)
     touching = set()
+    rows = constraint_rows(m, s, kin, prm, touching_out=touching)
     if rows:
         J = np.array([r[0] for r in rows])
         MinvJT = solve(J.T)
@@ -376,7 +429,6 @@ def substep(m, s, tau_motor, prm, out=None, ext=None):
         rhs = J @ u_star - np.array([r[1] for r in rows])
         lam = pgs(A, rhs, rows, (prm.friction, prm.self_friction), prm.iterations)
         u_star = u_star + MinvJT @ lam
-        touching = {r[4] for r in rows if r[2] == 0 and r[4] >= 0}
         if out is not None:
             out["lam"] = lam
     if out is not None:

@@ -25,7 +25,8 @@ class Params(C.Structure):
                 ("max_steps", C.c_int32), ("alive_z", C.c_double), ("alive_bonus", C.c_double), ("initial_z", C.c_double),
                 ("walk_target_x", C.c_double), ("walk_target_y", C.c_double), ("initial_z_from_state", C.c_int32),
                 ("floor_in_parts", C.c_int32), ("torque_f32", C.c_int32), ("height_f32", C.c_int32),
-                ("body_linear_damping", C.c_double), ("body_angular_damping", C.c_double), ("max_coordinate_velocity", C.c_double)]
+                ("body_linear_damping", C.c_double), ("body_angular_damping", C.c_double), ("max_coordinate_velocity", C.c_double),
+                ("contact_margin", C.c_double)]
 
 
 class State(C.Structure):
@@ -92,11 +93,19 @@ def make_model(m, motor_torque):
     return cm, table
 
 
+def margin_of(m):
+    """Contact margin of the preset a Model was loaded with (mjcf.PRESETS[...]["contact_margin"]; models recorded before the
+    field existed carry only the preset's name)."""
+    if hasattr(m, "contact_margin"):
+        return float(m.contact_margin)
+    return 0.02 if str(getattr(m, "preset", "mujoco")) == "bullet" else 0.0
+
+
 def world_of(m):
     """The world half of the preset a Model was loaded with (mjcf.PRESETS): body damping and the velocity clamp."""
     bd = getattr(m, "body_damping", (0.0, 0.0))
     return dict(body_linear_damping=float(bd[0]), body_angular_damping=float(bd[1]),
-                max_coordinate_velocity=float(getattr(m, "max_velocity", 0.0)))
+                max_coordinate_velocity=float(getattr(m, "max_velocity", 0.0)), contact_margin=margin_of(m))
 
 
 def humanoid_params(m, **over):

@@ -291,30 +291,33 @@ int wo_substep(const wo_model *m, const wo_params *prm, wo_state *s, const doubl
         FL(F_FMA, 1);
         y[d] = v + dt * x[d];
     }
-    /* ---- constraint detection: ground contacts of the collision spheres (sphere order, first maxc), then self-collision
-     *      pairs (pair order), then joint limits ---- */
+    /* ---- constraint detection: contact CANDIDATES in candidate order — ground plane per collision sphere (sphere order; inside
+     *      the contact margin: depth > -contact_margin), then self-collision pairs (pair order; penetration only) — at most
+     *      WO_MAX_CANDIDATES (later ones dropped); of those the maxc DEEPEST are kept (ties: the earlier candidate), in candidate
+     *      order (abd.select_contacts); then joint limits. touch = every sphere with a ground candidate, kept or not: what
+     *      getContactPoints reports (walker_base_env.py:57-63). Bias: abd.contact_bias. ---- */
     double cx[WO_MAX_CONTACTS][6], bias[WO_MAX_ROWS], Jh[WO_MAX_ROWS][WO_MAX_DOF];
     int csph[WO_MAX_CONTACTS][2], kind[WO_MAX_ROWS], partner[WO_MAX_ROWS];
-    int ncont = 0;
+    double qx[WO_MAX_CANDIDATES][6], qdepth[WO_MAX_CANDIDATES];
+    int qid[WO_MAX_CANDIDATES][2];
+    int ncand = 0;
     touch[0] = touch[1] = 0ull;
     for (int g = 0; g < m->ns; ++g) {
         const int b = m->sphere_body[g];
         const v3 xw = vadd(k.o[b], mulMv(k.R[b], ld3(t_sph_pos(m) + 3 * g)));
         FL(F_ADD, 1);
         const double depth = t_sph_r(m)[g] - xw.z;
-        if (depth > 0.0 && ncont < maxc) {
-            cx[ncont][0] = xw.x; cx[ncont][1] = xw.y; cx[ncont][2] = depth;
-            csph[ncont][0] = g; csph[ncont][1] = -1;
-            FL(F_MUL, 1); FL(F_DIV, 1);
-            bias[3 * ncont] = prm->erp * depth / dt; kind[3 * ncont] = 0; partner[3 * ncont] = -1;
-            bias[3 * ncont + 1] = 0.0; kind[3 * ncont + 1] = 1; partner[3 * ncont + 1] = 3 * ncont;
-            bias[3 * ncont + 2] = 0.0; kind[3 * ncont + 2] = 2; partner[3 * ncont + 2] = 3 * ncont;
+        if (depth > -prm->contact_margin) {
             touch[g >> 6] |= 1ull << (g & 63);
-            ++ncont;
+            if (ncand < WO_MAX_CANDIDATES) {
+                qx[ncand][0] = xw.x; qx[ncand][1] = xw.y; qx[ncand][2] = depth;
+                qid[ncand][0] = g; qid[ncand][1] = -1; qdepth[ncand] = depth;
+                ++ncand;
+            }
         }
     }
     if (prm->self_collision)
-        for (int pr = 0; pr < m->npairs && ncont < maxc; ++pr) {
+        for (int pr = 0; pr < m->npairs && ncand < WO_MAX_CANDIDATES; ++pr) {
             const int ga = m->pair_a[pr], gb = m->pair_b[pr], ba = m->geom_body[ga], bb = m->geom_body[gb];
             v3 ca, cb;
             segment_closest(vadd(k.o[ba], mulMv(k.R[ba], ld3(t_geom_p0(m) + 3 * ga))), vadd(k.o[ba], mulMv(k.R[ba], ld3(t_geom_p1(m) + 3 * ga))),
@@ -327,15 +330,30 @@ int wo_substep(const wo_model *m, const wo_params *prm, wo_state *s, const doubl
                 FL(F_DIV, 1);
                 const v3 nrm = vscale(1.0 / dist, dv);
                 const v3 xc = vscale(0.5, vadd(vsub(ca, vscale(ra, nrm)), vadd(cb, vscale(rb, nrm))));
-                cx[ncont][0] = xc.x; cx[ncont][1] = xc.y; cx[ncont][2] = xc.z; cx[ncont][3] = nrm.x; cx[ncont][4] = nrm.y; cx[ncont][5] = nrm.z;
-                csph[ncont][0] = ba; csph[ncont][1] = bb;
-                FL(F_MUL, 1); FL(F_DIV, 1);
-                bias[3 * ncont] = prm->erp * depth / dt; kind[3 * ncont] = 0; partner[3 * ncont] = -1;
-                bias[3 * ncont + 1] = 0.0; kind[3 * ncont + 1] = 3; partner[3 * ncont + 1] = 3 * ncont;
-                bias[3 * ncont + 2] = 0.0; kind[3 * ncont + 2] = 3; partner[3 * ncont + 2] = 3 * ncont;
-                ++ncont;
+                qx[ncand][0] = xc.x; qx[ncand][1] = xc.y; qx[ncand][2] = xc.z; qx[ncand][3] = nrm.x; qx[ncand][4] = nrm.y; qx[ncand][5] = nrm.z;
+                qid[ncand][0] = ba; qid[ncand][1] = bb; qdepth[ncand] = depth;
+                ++ncand;
             }
         }
+    int ncont = 0;
+    for (int c = 0; c < ncand; ++c) {
+        if (ncand > maxc) {                      /* rank among the candidates: deeper ones, and equally deep earlier ones — depths on
+                                                  * abd.depth_key's 2^-20 m grid, so that points equally deep by symmetry tie */
+            int rank = 0;
+            const double kc = floor(qdepth[c] * 1048576.0);
+            for (int o = 0; o < ncand; ++o) { const double ko = floor(qdepth[o] * 1048576.0); rank += (ko > kc) || (ko == kc && o < c); }
+            if (rank >= maxc) continue;
+        }
+        memcpy(cx[ncont], qx[c], sizeof(cx[ncont]));
+        csph[ncont][0] = qid[c][0]; csph[ncont][1] = qid[c][1];
+        const double depth = qdepth[c];
+        FL(F_MUL, 1); FL(F_DIV, 1);
+        bias[3 * ncont] = (depth >= 0.0 ? prm->erp * depth : depth) / dt; kind[3 * ncont] = 0; partner[3 * ncont] = -1;
+        const int fk = qid[c][1] == -1 ? 1 : 3;
+        bias[3 * ncont + 1] = 0.0; kind[3 * ncont + 1] = fk; partner[3 * ncont + 1] = 3 * ncont;
+        bias[3 * ncont + 2] = 0.0; kind[3 * ncont + 2] = fk == 1 ? 2 : 3; partner[3 * ncont + 2] = 3 * ncont;
+        ++ncont;
+    }
     int nr = 3 * ncont;
     for (int c = 0; c < ncont; ++c)
         for (int d = 0; d < n; ++d) {

@@ -11,6 +11,7 @@
 #define WO_MAX_GEOMS 24
 #define WO_MAX_PAIRS 128
 #define WO_MAX_CONTACTS 12
+#define WO_MAX_CANDIDATES 48       /* abd.MAX_CANDIDATES, walker.hip W_MAXCAND */
 #define WO_MAX_ROWS (3 * WO_MAX_CONTACTS + WO_MAX_JOINTS)
 
 typedef struct wo_model {            /* topology (mg_walker_topology) + one row of the model table (mg_walker_models) */
@@ -31,6 +32,7 @@ typedef struct wo_params {
     int32_t floor_in_parts, torque_f32, height_f32;
     double body_linear_damping, body_angular_damping;   /* btMultiBody velocity damping of every body (0.04 / 0.04 in the "bullet" preset) */
     double max_coordinate_velocity;                     /* btMultiBody's clamp of every generalized velocity (100 in the "bullet" preset; 0 = off) */
+    double contact_margin;                              /* Bullet's contact-breaking threshold (0.02 in the "bullet" preset; 0 = penetration only): abd.Params.contact_margin */
 } wo_params;
 
 typedef struct wo_state { double pos[3], rot[9], vel[3], omega[3], q[WO_MAX_JOINTS], qd[WO_MAX_JOINTS]; } wo_state;

@@ -272,3 +272,125 @@ def test_friction_cone_on_a_ramp(mu, slides):
             env.step(zero)
         along = (env.s.v - v0) @ np.array([np.cos(ang), 0.0, np.sin(ang)])
         assert along == pytest.approx(-9.8 * (np.sin(ang) - mu * np.cos(ang)), rel=0.25)
+
+
+# ---- contact margin (mg_walker_params.contact_margin; Bullet's contact-breaking threshold, walker_base_env.py:57-63 reads
+#      getContactPoints = every manifold point inside it) ---------------------------------------------------------------------
+def _margin_env(name, margin, lock=False):
+    from metagym_amd.metalocomotion import mjcf
+    m = MODELS[name]
+    if name == "humanoid":
+        m = mjcf.grounded(m)                    # standing on the floor instead of starting 9.3 cm inside it
+    if lock:                                    # a statue: every hinge held by its limit rows within +-0.005 rad
+        m = copy.deepcopy(m)
+        m.joint_lo, m.joint_hi = np.full_like(m.joint_lo, -0.005), np.full_like(m.joint_hi, 0.005)
+    nj = len(m.joint_lo)
+    prm = abd.Params(friction=0.8 * float(m.geom_friction), self_friction=float(m.geom_friction) ** 2, contact_margin=margin)
+    env = abd.WalkerEnv(m, prm=prm, motor_power=np.full(nj, 100.0) if name == "ant" else abd.HUMANOID_MOTOR_POWER, alive_z=-1.0,
+                        max_steps=10 ** 6, initial_z=None if name == "ant" else 0.8, torque_f32=name != "ant")
+    env.reset(np.zeros(nj))
+    return m, env
+
+
+def _lowest_surface(m, s):
+    kin = abd.kinematics(m, s)
+    return min((kin["o"][b] + kin["R"][b] @ m.sph_pos[g])[2] - m.sph_radius[g] for g, b in enumerate(m.sph_body))
+
+
+@pytest.mark.parametrize("name,lock", [("humanoid", True), ("humanoid", False)])
+def test_contact_margin_keeps_resting_foot_flags_on(name, lock):
+    """Zero action, humanoid started standing on the floor. lock=True: a statue (hinges held by their limit rows) that stands
+    on its two sphere feet and then topples about them; lock=False: the ragdoll, which folds and comes to rest on the floor
+    (a humanoid on two point feet cannot stand passively). With the 0.02 m margin both foot flags stay at 1 for >= 99 % of the
+    steps after settling and never toggle; without it (margin 0, the engine up to round 5) the same run toggles them — a contact
+    row and a flag only while a proxy penetrates. The rest height is the same to 1 mm."""
+    out = {}
+    for margin in (0.0, 0.02):
+        m, env = _margin_env(name, margin, lock)
+        flags = []
+        for t in range(200):
+            env.step(np.zeros(len(m.joint_lo), np.float32))
+            flags.append(env.feet_contact.copy())
+        settled = np.array(flags)[60:]
+        out[margin] = dict(all_on=float(settled.min(1).mean()), toggle=float(np.abs(np.diff(settled, axis=0)).sum() / settled[1:].size),
+                           lowest=_lowest_surface(m, env.s))
+    print(name, "lock" if lock else "ragdoll", {k: {kk: round(vv, 4) for kk, vv in v.items()} for k, v in out.items()})
+    assert out[0.02]["all_on"] >= 0.99 and out[0.02]["toggle"] <= 0.005
+    assert out[0.0]["toggle"] > 0.02 and out[0.0]["all_on"] < 0.95          # today's flicker, for the record
+    assert abs(out[0.02]["lowest"] - out[0.0]["lowest"]) < 1e-3 and abs(out[0.02]["lowest"]) < 5e-3
+
+
+def test_contact_margin_ant_rest_height_and_flags():
+    """The ant dropped from its reset pose (zero action) settles as a tripod (three feet down, one leg a few cm up). With the
+    margin every foot's flag is steady — on for >= 99 % of the settled steps for the three that carry it, off for the lifted one —
+    where the engine without margin flickers (a resting foot reads on ~2/3 of the time); the lowest proxy surface rests at the
+    same height to 1 mm."""
+    out = {}
+    for margin in (0.0, 0.02):
+        m, env = _margin_env("ant", margin)
+        flags = []
+        for t in range(220):
+            env.step(np.zeros(len(m.joint_lo), np.float32))
+            flags.append(env.feet_contact.copy())
+        settled = np.array(flags)[120:]
+        out[margin] = dict(per_foot=settled.mean(0), toggle=float(np.abs(np.diff(settled, axis=0)).sum() / settled[1:].size),
+                           lowest=_lowest_surface(m, env.s))
+    print("ant", out)
+    pf = out[0.02]["per_foot"]
+    assert np.all((pf >= 0.99) | (pf <= 0.01)) and int((pf >= 0.99).sum()) >= 3 and out[0.02]["toggle"] <= 0.005
+    pf0 = out[0.0]["per_foot"]
+    assert np.any((pf0 > 0.05) & (pf0 < 0.95)) and out[0.0]["toggle"] > 0.02          # today's flicker, for the record
+    assert abs(out[0.02]["lowest"] - out[0.0]["lowest"]) < 1e-3 and abs(out[0.02]["lowest"]) < 5e-3
+
+
+@pytest.mark.parametrize("name", ["humanoid", "ant"])
+def test_speculative_rows_never_add_energy(name):
+    """A separated contact point (0 < gap < margin) only gets an impulse when it would close more than its gap in this sub-step,
+    and that impulse slows the approach: over random configurations hovering inside the margin, with random velocities, the
+    kinetic energy after the solve never exceeds the kinetic energy of the unconstrained velocity, the multipliers are >= 0, and
+    no kept point ends the step approaching faster than gap / dt (5 PGS sweeps: to 5 % of that speed)."""
+    m = _frictionless_free(MODELS[name])
+    prm = abd.Params(contact_margin=0.02, self_collision=False)
+    rs = np.random.RandomState(5)
+    active = 0
+    for trial in range(40):
+        s = _random_state(m, 100 + trial, z=0.0)
+        s.v = np.array([rs.uniform(-1, 1), rs.uniform(-1, 1), rs.uniform(-6, 1)])
+        s.pos[2] -= _lowest_surface(m, s) - rs.uniform(0.001, 0.019)            # lowest proxy surface hovers inside the margin
+        M, h, kin, _ = abd.mass_matrix_and_bias(m, s)
+        rows = abd.constraint_rows(m, s, kin, prm)
+        assert rows and all(r[1] < 0.0 for r in rows if r[2] == 0)             # speculative rows only (limits are off)
+        u_star = s.u() + prm.dt * np.linalg.solve(M, -h)
+        J = np.array([r[0] for r in rows])
+        A = J @ np.linalg.solve(M, J.T)
+        lam = abd.pgs(A, J @ u_star - np.array([r[1] for r in rows]), rows, (prm.friction, prm.self_friction), prm.iterations)
+        u = u_star + np.linalg.solve(M, J.T @ lam)
+        normal = [i for i, r in enumerate(rows) if r[2] == 0]
+        assert all(lam[i] >= 0.0 for i in normal)
+        assert 0.5 * u @ M @ u <= 0.5 * u_star @ M @ u_star * (1 + 1e-12) + 1e-12
+        for i in normal:
+            closing_allowed = -rows[i][1]                                       # gap / dt
+            assert -(J[i] @ u) <= closing_allowed * 1.05 + 1e-9 or lam[i] > 0.0
+        active += int(any(lam[i] > 0.0 for i in normal))
+    assert active >= 10                                                         # the rows did act in a good share of the trials
+
+
+def test_contact_cap_keeps_the_deepest_candidates():
+    """More candidates than the solver's cap: the max_contacts DEEPEST are kept (ties to the earlier candidate), in candidate
+    order — not the first by index; `touching` still reports every proxy inside the margin."""
+    m = MODELS["humanoid"]
+    s = abd.State(m)
+    s.rot = abd.rodrigues(np.array([0.0, 1.0, 0.0]), -np.pi / 2) @ s.rot         # lying on its back: a dozen proxies within 5 cm of the lowest
+    s.pos[2] = 0.0
+    s.pos[2] -= _lowest_surface(m, s) + 0.03                                     # deepest proxy 3 cm inside the floor
+    prm = abd.Params(contact_margin=0.02, self_collision=False, max_contacts=6)
+    kin = abd.kinematics(m, s)
+    cands, touching = abd.contact_candidates(m, s, kin, prm)
+    assert len(cands) > 6 and touching == {c["g"] for c in cands}
+    kept = abd.select_contacts(cands, 6)
+    keys = sorted((abd.depth_key(c["depth"]) for c in cands), reverse=True)       # depths on the 2^-20 m ranking grid: the left and
+    assert sorted((abd.depth_key(c["depth"]) for c in kept), reverse=True) == keys[:6]   # right limbs' proxies tie here, by symmetry
+    assert [c["g"] for c in kept] == sorted(c["g"] for c in kept)                # candidate order
+    assert [c["g"] for c in kept] != [c["g"] for c in cands[:6]]                 # (the first six by index are another set)
+    rows = abd.constraint_rows(m, s, kin, prm)
+    assert [r[4] for r in rows if r[2] == 0 and r[4] >= 0] == [c["g"] for c in kept]

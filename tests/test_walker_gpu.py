@@ -439,6 +439,63 @@ def test_c4_grounded_configuration_sampled_against_oracle():
 
 
 @pytest.mark.parametrize("mapping", ["wave", "lane"])
+@pytest.mark.parametrize("margin", [0.02, 0.0])
+def test_contact_margin_and_deepest_first_cap_match_oracle(mapping, margin):
+    """mg_walker_params.contact_margin (ABI 7) and the solver's contact cap, both mappings against oracle/abd.py: humanoids laid
+    on their backs a little inside / on / above the floor — more than 12 contact candidates for most of them (the cap keeps the 12
+    DEEPEST, in candidate order), speculative rows for the hovering ones, feet flags from every proxy inside the margin. State to
+    1e-7 over 8 env steps, feet flags exactly; the oracle's own bookkeeping proves the cases were met."""
+    names = ["humanoid", "humanoid_tra_137"]
+    models = [MODELS[k] for k in names]
+    n = 8
+    env = _make("MetaHumanoidEnv", models, n, max_steps=1000, mapping=mapping, contact_margin=margin, contact_erp=0.1)   # (soft push-out: the pile-up lasts)
+    assert env.contact_margin == margin and env._params_c.contact_margin == margin
+    ids = env.task_id.cpu().numpy()
+    nj = env.n_joints
+    rs = np.random.RandomState(4)
+    noise = rs.uniform(-0.1, 0.1, (n, nj))
+    env.reset(joint_noise=noise)
+    Ry = abd.rodrigues(np.array([0.0, 1.0, 0.0]), -np.pi / 2)
+    lift = np.array([-0.08, -0.08, -0.10, -0.10, -0.03, 0.005, 0.012, 0.018])     # lowest proxy surface: inside ... above the floor
+    oenvs = []
+    for e in range(n):
+        m = models[ids[e]]
+        kw = world_kw(m)
+        kw["contact_margin"] = margin
+        o = abd.WalkerEnv(m, prm=abd.Params(friction=0.8 * float(m.geom_friction), self_friction=float(m.geom_friction) ** 2, erp=0.1, **kw),
+                          max_steps=1000)
+        o.reset(noise[e])
+        o.s.rot = Ry @ o.s.rot
+        o.s.pos[2] = 0.0
+        kin = abd.kinematics(m, o.s)
+        o.s.pos[2] = lift[e] - min((kin["o"][b] + kin["R"][b] @ m.sph_pos[g])[2] - m.sph_radius[g] for g, b in enumerate(m.sph_body))
+        oenvs.append(o)
+    env.rot.copy_(torch.as_tensor(np.stack([o.s.rot.reshape(9) for o in oenvs], 1), device=env.rot.device))
+    env.pos.copy_(torch.as_tensor(np.stack([o.s.pos for o in oenvs], 1), device=env.pos.device))
+    over_cap, speculative, worst = 0, 0, 0.0
+    for t in range(8):
+        a = rs.uniform(-0.3, 0.3, (n, nj)).astype(np.float32)
+        for e in range(n):                                  # what the oracle is about to see in the first sub-step of this step
+            kin = abd.kinematics(models[ids[e]], oenvs[e].s)
+            cands, _ = abd.contact_candidates(models[ids[e]], oenvs[e].s, kin, oenvs[e].prm)
+            over_cap += int(len(cands) > 12)
+            speculative += int(any(c["depth"] < 0.0 for c in cands))
+        env.step(torch.as_tensor(a))
+        q, pos, fc = env.q.cpu().numpy().T, env.pos.cpu().numpy().T, env.feet_contact.cpu().numpy().T
+        for e in range(n):
+            oenvs[e].step(a[e])
+            s = oenvs[e].s
+            worst = max(worst, np.abs(q[e] - s.q).max(), np.abs(pos[e] - s.pos).max())
+            assert np.allclose(q[e], s.q, rtol=0, atol=1e-7), (t, e, np.abs(q[e] - s.q).max())
+            assert np.allclose(pos[e], s.pos, rtol=0, atol=1e-7), (t, e)
+            assert np.array_equal(fc[e], oenvs[e].feet_contact), (t, e)
+    assert over_cap >= 4, over_cap
+    assert (speculative >= 8) if margin > 0 else (speculative == 0)
+    print(mapping, "margin", margin, "max |state diff| %.2e; env-steps starting with > 12 candidates: %d, with speculative ones: %d"
+          % (worst, over_cap, speculative))
+
+
+@pytest.mark.parametrize("mapping", ["wave", "lane"])
 def test_self_collision_matches_oracle(mapping):
     """Legs swung into each other (and an arm into the torso side) in mid-air: the capsule-capsule
     self-contact rows (robot_bases.py:119 flags) must act exactly like the oracle's — and switching

@@ -20,9 +20,20 @@ def load_models():
 
 def world_kw(m):
     """The world half of the preset a Model was loaded with (mjcf.PRESETS) as oracle/abd.Params keywords: btMultiBody's body
-    velocity damping and its clamp of the generalized velocities ("bullet": 0.04 / 0.04 and 100; "mujoco": off)."""
+    velocity damping, its clamp of the generalized velocities and the contact margin ("bullet": 0.04 / 0.04, 100 and 0.02 m;
+    "mujoco": off)."""
     bd = getattr(m, "body_damping", (0.0, 0.0))
-    return dict(body_damping=(float(bd[0]), float(bd[1])), max_velocity=float(getattr(m, "max_velocity", 0.0)))
+    return dict(body_damping=(float(bd[0]), float(bd[1])), max_velocity=float(getattr(m, "max_velocity", 0.0)),
+                contact_margin=margin_of(m))
+
+
+def margin_of(m):
+    """The preset's contact margin (mjcf.PRESETS[...]["contact_margin"]: Bullet's 0.02 m contact-breaking threshold in the "bullet"
+    world, 0 in the "mujoco" one). The recorded models predate the field and carry the preset's name only."""
+    if hasattr(m, "contact_margin"):
+        return float(m.contact_margin)
+    from metagym_amd.metalocomotion.mjcf import PRESETS
+    return float(PRESETS[preset_of(m)]["contact_margin"])
 
 
 def preset_of(m):
