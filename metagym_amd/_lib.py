@@ -128,7 +128,7 @@ class WalkerParams(C.Structure):
                 ("pd_kp_env", C.c_void_p), ("pd_kd_env", C.c_void_p), ("ext_wrench", C.c_void_p),
                 ("max_coordinate_velocity", C.c_double), ("terrain_id", C.c_void_p), ("n_terrain_tables", C.c_int32),
                 ("gravity_env", C.c_void_p), ("foot_friction_env", C.c_void_p), ("reset_pos", C.c_void_p), ("reset_rot", C.c_void_p),
-                ("contact_margin", C.c_double)]
+                ("contact_margin", C.c_double), ("sphere_margin_in_table", C.c_int32)]
 
 
 class JointMajor(object):

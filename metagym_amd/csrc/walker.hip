@@ -45,6 +45,7 @@ struct ModelRef {   // offsets into one task's table row
     const double *joint_anchor, *joint_axis, *joint_lo, *joint_hi, *joint_arm, *joint_damp, *joint_stiff, *motor;
     const double *sph_pos, *sph_r;
     const double *geom_p0, *geom_p1, *geom_r;
+    const double *sph_margin;     // per-proxy contact margins, behind geom_r in rows that carry them
 };
 
 __device__ __forceinline__ ModelRef model_ref(const mg_walker_topology &tp, const mg_walker_models &ms, int task) {
@@ -68,7 +69,8 @@ __device__ __forceinline__ ModelRef model_ref(const mg_walker_topology &tp, cons
     r.sph_r = p; p += ns;
     r.geom_p0 = p; p += 3 * tp.n_geoms;
     r.geom_p1 = p; p += 3 * tp.n_geoms;
-    r.geom_r = p;
+    r.geom_r = p; p += tp.n_geoms;
+    r.sph_margin = p;             // (only read when mg_walker_params.sphere_margin_in_table says the rows carry them)
     return r;
 }
 
@@ -327,7 +329,7 @@ __device__ void substep(const mg_walker_topology &tp, const ModelRef &m, const m
         const int b = tp.sphere_body[g];
         const V3 x = k.o[b] + mulMv(k.R[b], ld3(m.sph_pos + 3 * g));
         const double depth = m.sph_r[g] - x.z;
-        if (depth > -prm.contact_margin) {
+        if (depth > -(prm.sphere_margin_in_table ? m.sph_margin[g] : prm.contact_margin)) {
             touch_mask |= 1ull << g;                   // every proxy inside the margin: what getContactPoints reports
             if (ncand < LANE_MAXCAND) {
                 qx[ncand][0] = x.x; qx[ncand][1] = x.y; qx[ncand][2] = 0.0;
@@ -721,6 +723,8 @@ struct ModelW {   // one task's table row (layout: mg_walker_models in metagym_h
     __device__ __forceinline__ const double *geom_p0() const { return p + 25 * nb + 12 * nj + 4 * ns; }
     __device__ __forceinline__ const double *geom_p1() const { return p + 25 * nb + 12 * nj + 4 * ns + 3 * ng; }
     __device__ __forceinline__ const double *geom_r() const { return p + 25 * nb + 12 * nj + 4 * ns + 6 * ng; }
+    // per-proxy contact margins behind the capsules (rows that carry them: mg_walker_params.sphere_margin_in_table)
+    __device__ __forceinline__ const double *sph_margin() const { return p + 25 * nb + 12 * nj + 4 * ns + 7 * ng; }
 };
 
 // Sum over the 64 lanes without LDS: four DPP steps fold each 16-lane row (quad_perm xor-1, xor-2,
@@ -1335,7 +1339,6 @@ __device__ __forceinline__ void wave_substep(const mg_walker_topology &tp, const
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
     const int nchunk = GENERIC ? (ns + WV - 1) / WV : 1;
     const bool own_mu = GENERIC && prm.sphere_friction != nullptr;
-    const double margin = prm.contact_margin;
     const int cand_cap = min(W_MAXCAND, (maxr * n - 8 * m.ng) / 9);       // (mg_walker_step: = W_MAXCAND, or every possible candidate fits)
     double *cand = L.J + 8 * m.ng;                                        // [cand_cap][8]
     int *cand_id = reinterpret_cast<int *>(cand + 8 * cand_cap);          // [cand_cap][2]
@@ -1350,7 +1353,7 @@ __device__ __forceinline__ void wave_substep(const mg_walker_topology &tp, const
             const int b = L.sbody[g];
             const V3 xw = ldv(L.o, b) + mulMv(L.R + 9 * b, ld3(m.sph_pos() + 3 * g));
             depth = m.sph_r()[g] - xw.z;
-            hit = depth > -margin;
+            hit = depth > -(prm.sphere_margin_in_table ? m.sph_margin()[g] : prm.contact_margin);
             sx = xw.x; sy = xw.y;
         }
         const unsigned long long hits = __ballot(hit);
@@ -1372,11 +1375,12 @@ __device__ __forceinline__ void wave_substep(const mg_walker_topology &tp, const
     if (GENERIC && prm.n_terrain_boxes > 0)
         for (int ch = 0; ch < nchunk && ncand < cand_cap; ++ch) {
             const int g = ch * WV + lane;
-            double rad = 0.0, sx = 0.0, sy = 0.0, sz = 0.0;
+            double rad = 0.0, sx = 0.0, sy = 0.0, sz = 0.0, margin = 0.0;
             if (g < ns) {
                 const int b = L.sbody[g];
                 const V3 xw = ldv(L.o, b) + mulMv(L.R + 9 * b, ld3(m.sph_pos() + 3 * g));
                 rad = m.sph_r()[g];
+                margin = prm.sphere_margin_in_table ? m.sph_margin()[g] : prm.contact_margin;
                 sx = xw.x; sy = xw.y; sz = xw.z;
             }
             // x range of this chunk's proxies, radius included (y / z ranges as well were measured: they cull nothing more on the
@@ -2144,7 +2148,8 @@ int check_walker(const mg_walker_topology *tp, const mg_walker_models *ms, const
                                  "(sphere_foot is new in ABI 4: -1 = no foot, else a foot whose body carries the proxy)", g,
                                  tp->sphere_body[g], tp->sphere_foot[g], tp->foot_body[tp->sphere_foot[g]]);
     }
-    const int need = 25 * tp->n_bodies + 12 * tp->n_joints + 4 * tp->n_spheres + 7 * tp->n_geoms;
+    const int need = 25 * tp->n_bodies + 12 * tp->n_joints + 4 * tp->n_spheres + 7 * tp->n_geoms +
+                     (prm->sphere_margin_in_table ? tp->n_spheres : 0);
     if (!ms->table || ms->n_tasks < 1 || ms->model_stride < need)
         return mg::set_error(MG_ERR_BAD_SIZE, "walker model table: stride %d < %d", ms->model_stride, need);
     if (!st->task_id || !st->pos || !st->rot || !st->vel || !st->omega || !st->q || !st->qd || !st->potential ||

@@ -137,6 +137,43 @@ def rest_lowest_point(m):
     return float(min(z))
 
 
+CONTACT_BREAKING_THRESHOLD = 0.02      # Bullet's gContactBreakingThreshold
+
+
+def angular_motion_discs(m):
+    """Per collision proxy: btCollisionShape::getAngularMotionDisc() of the LINK the proxy belongs to — the radius of the bounding
+    sphere Bullet derives from the axis-aligned bounding box of the link's (compound) collision shape, plus the distance of that
+    box's centre from the shape's origin. Needed because Bullet's contact margin is RELATIVE by default:
+    btCollisionDispatcher is constructed with CD_USE_RELATIVE_CONTACT_BREAKING_THRESHOLD, so a manifold's breaking threshold is
+    min over the two shapes of gContactBreakingThreshold (0.02) x getAngularMotionDisc() — 2 % of the link's size, not 2 cm (the
+    ground plane's own disc is huge and never the minimum). A Model that carries `sph_disc` (the URDF loader computes it per
+    original link, in the link's inertial frame) is taken at its word; for MJCF models the link is the body, its capsule / sphere
+    geoms in the body frame (the `bullet` preset leaves the inertial frame at the body origin)."""
+    if hasattr(m, "sph_disc"):
+        return np.asarray(m.sph_disc, np.float64)
+    nb = len(m.body_parent)
+    lo, hi = np.full((nb, 3), np.inf), np.full((nb, 3), -np.inf)
+    for b, p0, p1, r in zip(m.geom_body, m.geom_p0, m.geom_p1, m.geom_radius):
+        lo[b] = np.minimum(lo[b], np.minimum(p0, p1) - r)
+        hi[b] = np.maximum(hi[b], np.maximum(p0, p1) + r)
+    disc = np.zeros(nb)
+    for b in range(nb):
+        if np.all(np.isfinite(lo[b])):
+            disc[b] = 0.5 * np.linalg.norm(hi[b] - lo[b]) + np.linalg.norm(0.5 * (hi[b] + lo[b]))
+    return disc[np.asarray(m.sph_body, int)]
+
+
+def contact_margins(m, contact_margin):
+    """Per-proxy contact margin in metres for `contact_margin` = a float (that margin for every proxy; 0 = penetration only) or
+    "relative" (Bullet's default rule: CONTACT_BREAKING_THRESHOLD x the link's angular motion disc)."""
+    ns = len(m.sph_body)
+    if isinstance(contact_margin, str):
+        if contact_margin != "relative":
+            raise ValueError("contact_margin must be a length in metres or 'relative', got %r" % (contact_margin,))
+        return CONTACT_BREAKING_THRESHOLD * angular_motion_discs(m)
+    return np.full(ns, float(contact_margin))
+
+
 def grounded(m, clearance=0.0):
     """A copy of `m` whose base starts `clearance` above the height at which its lowest collision proxy just touches z = 0 in the
     reset pose (negative: that far inside). The episode then begins STANDING on the floor instead of being ejected from it —
@@ -162,7 +199,7 @@ def _aabb_box_inertia(mass, geoms, com):
 # What each preset makes of the file; every entry can be overridden per call (load_mjcf keyword of the same name).
 PRESETS = {
     "bullet": dict(inertia="bullet_box", com="body_origin", armature="ignore", damping="ignore", stiffness="ignore",
-                   body_damping=(0.04, 0.04), max_velocity=100.0, contact_margin=0.02),
+                   body_damping=(0.04, 0.04), max_velocity=100.0, contact_margin="relative"),
     "mujoco": dict(inertia="geom", com="geom", armature="diagonal", damping="explicit", stiffness="spring",
                    body_damping=(0.0, 0.0), max_velocity=0.0, contact_margin=0.0),
 }
@@ -299,7 +336,7 @@ def load_mjcf(path_or_string, foot_names=("right_foot", "left_foot"), preset=Non
     # from their own `preset` / `body_damping` arguments, this copy records what the model was loaded for
     m.body_damping = np.array(opt["body_damping"], np.float64)
     m.max_velocity = np.array(float(opt["max_velocity"]))      # btMultiBody's m_maxCoordinateVelocity clamp (0 = off)
-    m.contact_margin = np.array(float(opt["contact_margin"]))  # Bullet's contact-breaking threshold (0 = penetration only)
+    m.contact_margin = np.array(opt["contact_margin"])         # the world's contact margin rule: metres, or "relative" (contact_margins)
     m.preset = np.array(DEFAULT_PRESET if preset is None else preset)
     m.sph_body = np.array([s[0] for s in spheres], np.int32)
     m.sph_pos = np.array([s[1] for s in spheres])

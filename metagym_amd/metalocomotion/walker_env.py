@@ -28,7 +28,7 @@ import torch
 from .. import _lib
 from ..spaces import Box
 from . import variants
-from .mjcf import DEFAULT_PRESET, Model, load_mjcf, preset_options
+from .mjcf import DEFAULT_PRESET, Model, contact_margins, load_mjcf, preset_options
 
 
 # The Bullet world parameters the reference sets (tests/test_walker_rules.py checks them against what its own scene code
@@ -37,11 +37,14 @@ from .mjcf import DEFAULT_PRESET, Model, load_mjcf, preset_options
 CONTACT_ERP, GRAVITY, GROUND_FRICTION = 0.9, 9.8, 0.8
 
 
-def pack_model(m, motor_torque):
-    """One row of the mg_walker_models table (layout documented in include/metagym_hip.h)."""
+def pack_model(m, motor_torque, margins=None):
+    """One row of the mg_walker_models table (layout documented in include/metagym_hip.h); `margins`: the per-proxy contact margins
+    that ride behind the capsules when mg_walker_params.sphere_margin_in_table is set."""
     parts = [m.body_pos, m.body_rot, m.body_mass, m.body_com, m.body_inertia, m.joint_anchor, m.joint_axis,
              m.joint_lo, m.joint_hi, m.joint_armature, m.joint_damping, m.joint_stiffness, motor_torque,
              m.sph_pos, m.sph_radius, m.geom_p0, m.geom_p1, m.geom_radius]
+    if margins is not None:
+        parts.append(margins)
     return np.concatenate([np.asarray(p, np.float64).reshape(-1) for p in parts])
 
 
@@ -88,13 +91,15 @@ class WalkerBatchEnv(object):
         if max_coordinate_velocity is None:
             max_coordinate_velocity = preset_options(self.preset)["max_velocity"]
         self.max_coordinate_velocity = float(max_coordinate_velocity)
-        #   contact_margin              Bullet's contact-breaking threshold (mg_walker_params.contact_margin): a proxy within it
-        #                               above the ground / a terrain box is a contact point — a speculative solver row and a
-        #                               feet_contact flag (walker_base_env.py:57-63 reads getContactPoints). 0.02 m in the
-        #                               'bullet' preset, 0 (penetration only) in the 'mujoco' one
+        #   contact_margin              Bullet's contact-breaking margin (mg_walker_params.contact_margin / sphere_margin): a proxy
+        #                               within it above the ground / a terrain box is a contact point — a speculative solver
+        #                               row and a feet_contact flag (walker_base_env.py:57-63 reads getContactPoints).
+        #                               "relative" = Bullet's default rule, 0.02 x the link's angular motion disc
+        #                               (mjcf.contact_margins; 3 - 8 mm on the humanoid) — the 'bullet' preset; a float = that many
+        #                               metres for every proxy; 0 (penetration only) in the 'mujoco' preset
         if contact_margin is None:
             contact_margin = preset_options(self.preset)["contact_margin"]
-        self.contact_margin = float(contact_margin)
+        self.contact_margin = contact_margin if isinstance(contact_margin, str) else float(contact_margin)
         self.per_proxy_friction = bool(per_proxy_friction)
         #   contact_erp                 0.9 for MetaLocomotion (scene_bases.py:55 setDefaultContactERP); a world that never calls it
         #                               keeps Bullet's default 0.2 (btContactSolverInfo::m_erp2) — the quadrupedal one
@@ -184,7 +189,9 @@ class WalkerBatchEnv(object):
         mp = np.full(nj, 100.0) if self.motor_power is None else np.asarray(self.motor_power, float)
         assert len(mp) == nj
         torque = mp * self.power                                   # humanoids.py:50-54, walker_base.py:26-29
-        table = np.stack([pack_model(m, torque) for m in models])
+        # Bullet's relative contact margin rule: every row carries its model's per-proxy margins
+        rel = isinstance(self.contact_margin, str)
+        table = np.stack([pack_model(m, torque, contact_margins(m, self.contact_margin) if rel else None) for m in models])
         N, dev = self.num_envs, self.device
         self._table = torch.from_numpy(table).to(dev).contiguous()
         ms = _lib.WalkerModels()
@@ -225,7 +232,7 @@ class WalkerBatchEnv(object):
             p.friction, p.sphere_friction = self.ground_friction * float(m0.geom_friction), None
         p.body_linear_damping, p.body_angular_damping = self.body_damping
         p.max_coordinate_velocity = self.max_coordinate_velocity
-        p.contact_margin = self.contact_margin
+        p.contact_margin, p.sphere_margin_in_table = (0.0, 1) if rel else (self.contact_margin, 0)
         p.alive_z, p.alive_bonus, p.dead_bonus = self.alive_z, self.alive_bonus, -1.0
         p.initial_z = float(self.initial_z if self.initial_z is not None else m0.body_pos[0][2])
         p.joints_at_limit_cost = -0.1                              # walker_base_env.py:22

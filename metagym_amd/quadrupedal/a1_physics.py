@@ -38,6 +38,11 @@ TOE_LINKS = ("FR_toe", "FL_toe", "RR_toe", "RL_toe")  # the child links of the a
 GRAVITY, GROUND_FRICTION, FOOT_FRICTION = 10.0, 5.0, 1.0   # locomotion_gym_env.py:251, :258, :338 + :408
 CONTACT_ERP = 0.2     # Bullet's default (btContactSolverInfo::m_erp2): unlike MetaLocomotion (scene_bases.py:55) the quadrupedal
 #                       reference never calls setDefaultContactERP
+CONTACT_MARGIN = "relative"   # Bullet's contact-breaking margin, its default RELATIVE rule (mg_walker_params.sphere_margin): 0.02 x the
+#                        link's angular motion disc — 0.7 mm for a 2 cm toe sphere, ~4 mm for a calf box. A proxy inside it is a contact
+#                        point of pybullet.getContactPoints — what a1.py:299-323 GetFootContacts / GetBadFootContacts and :325-356
+#                        GetFootContactsForce read — and a speculative row of the solver. (A flat 2 cm would make the calf boxes'
+#                        lower corners, 1.4 cm above the floor of a standing robot, "bad" contacts.)
 
 
 class _A1Walker(WalkerBatchEnv):
@@ -64,7 +69,7 @@ class A1Physics(object):
     def __init__(self, num_envs, urdf=None, device="cuda:0", model=None, foot_links=None, inertia="bullet_aabb", armature=0.0,
                  solver_iterations=23, fused=True, gravity=GRAVITY, ground_friction=GROUND_FRICTION, foot_friction=FOOT_FRICTION,
                  body_damping=(0.0, 0.0), init_motor_angles=INIT_MOTOR_ANGLES, contact_erp=CONTACT_ERP, base_mass_ratio=1.0,
-                 max_coordinate_velocity=100.0):
+                 max_coordinate_velocity=100.0, contact_margin=CONTACT_MARGIN):
         if (urdf is None) == (model is None):
             raise ValueError("A1Physics needs exactly one of urdf=<path or text> and model=<Model>")
         if model is not None:
@@ -107,7 +112,9 @@ class A1Physics(object):
                              solver_iterations=solver_iterations, self_collision=False, gravity=gravity,
                              ground_friction=ground_friction, body_damping=body_damping, per_proxy_friction=True,
                              contact_erp=contact_erp, foot_force=True, preset="mujoco",      # (preset: only read for defaults
-                             max_coordinate_velocity=max_coordinate_velocity)                # not given above; the Model is handed over)
+                             max_coordinate_velocity=max_coordinate_velocity,                # not given above; the Model is handed over)
+                             contact_margin=contact_margin)
+        self.contact_margin = contact_margin
         self.env.set_task([m])
         # (the MetaLocomotion "floor joins robot.parts after the first reset" rule only shapes the walker observation, which nothing
         # here reads: every reset is the one-launch kind from the start)

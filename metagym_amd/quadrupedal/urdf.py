@@ -152,6 +152,21 @@ def _link_inertia(link, mode):
     return Ri @ np.diag(diag) @ Ri.T
 
 
+def _link_disc(link):
+    """btCollisionShape::getAngularMotionDisc() of the link's compound collision shape (in the link's INERTIAL frame, where Bullet
+    keeps it): half the diagonal of the shapes' axis-aligned bounding box plus the distance of the box's centre from the origin.
+    Bullet's contact-breaking margin of the link is 0.02 x this (metalocomotion.mjcf.angular_motion_discs)."""
+    if not link["shapes"]:
+        return 0.0
+    Ri = link["Ri"]
+    lo, hi = np.full(3, np.inf), np.full(3, -np.inf)
+    for sh in link["shapes"]:
+        c = Ri.T @ (sh.p - link["pi"])
+        h = sh.aabb_half(Ri)
+        lo, hi = np.minimum(lo, c - h), np.maximum(hi, c + h)
+    return float(0.5 * np.linalg.norm(hi - lo) + np.linalg.norm(0.5 * (hi + lo)))
+
+
 def _link_principal(link, mode):
     """(diag[3], Rp): the link's local inertia DIAGONAL — what pybullet.getDynamicsInfo(...)[2] reports and
     changeDynamics(localInertiaDiagonal=) sets — and the rotation of its axes in the LINK frame, so that the tensor of
@@ -302,6 +317,7 @@ def load_urdf(path_or_string, foot_links=(), inertia="bullet_aabb", armature=0.0
     m.sph_radius = np.array([s[2] for s in sph])
     m.sph_link = np.array([s[3] for s in sph], np.int32)
     m.sph_friction = np.array([s[4] for s in sph])
+    m.sph_disc = np.array([_link_disc(links[link_order[s[3]]]) for s in sph])      # per proxy: its LINK's angular motion disc
     m.link_names = list(link_order)
     m.link_body = dict(link_body)
     m.link_frame = dict(link_frame)

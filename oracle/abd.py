@@ -171,9 +171,11 @@ class Params(object):
     def __init__(self, dt=0.005, substeps=4, iterations=5, erp=0.9, friction=0.8 * 0.8, power=0.41, max_contacts=12,
                  limit_erp=0.2, self_collision=True, self_friction=0.8 * 0.8, terrain=(), gravity=None, sphere_friction=None,
                  body_damping=(0.0, 0.0), max_velocity=0.0, contact_margin=0.0):
-        # Bullet's contact-breaking threshold (gContactBreakingThreshold = 0.02 m): a proxy within this distance ABOVE the ground or
-        # a terrain box is a contact point — a speculative solver row (contact_bias) and a feet_contact flag. 0 = penetration only
-        self.contact_margin = float(contact_margin)
+        # Bullet's contact-breaking margin: a proxy within this distance ABOVE the ground or a terrain box is a contact point — a
+        # speculative solver row (contact_bias) and a feet_contact flag. 0 = penetration only
+        #   (a scalar: that margin for every proxy; an array [n proxies]: per proxy, e.g. mjcf.contact_margins(m, "relative") —
+        #   Bullet's default is relative, 0.02 x the link's angular motion disc)
+        self.contact_margin = float(contact_margin) if np.ndim(contact_margin) == 0 else np.asarray(contact_margin, float)
         self.max_velocity = float(max_velocity)   # btMultiBody's m_maxCoordinateVelocity (100 in Bullet): clamp of every generalized
         #                                           velocity at the end of a sub-step (mg_walker_params.max_coordinate_velocity); 0 = off
         self.terrain = list(terrain)          # static boxes on top of the ground plane: (position[3], R[3,3] box->world, half_extents[3], mu)
@@ -263,15 +265,17 @@ def contact_candidates(m, s, kin, prm):
     via robot_bases.py:291-292: all manifold points within the contact-breaking margin), whether or not the solver's contact
     cap kept the point.
 
-    prm.contact_margin (mg_walker_params.contact_margin; Bullet's gContactBreakingThreshold = 0.02 m; 0 = penetration only):
-    a proxy is a ground / terrain candidate while depth > -margin. Self-collision pairs stay penetration-only."""
-    mg = float(getattr(prm, "contact_margin", 0.0))
+    prm.contact_margin (mg_walker_params.contact_margin / sphere_margin; 0 = penetration only; Bullet: 0.02 x the link's angular
+    motion disc, metalocomotion.mjcf.contact_margins): a proxy is a ground / terrain candidate while depth > -its margin.
+    Self-collision pairs stay penetration-only."""
+    mg_all = getattr(prm, "contact_margin", 0.0)
+    margin_of = (lambda g: float(mg_all)) if np.ndim(mg_all) == 0 else (lambda g: float(mg_all[g]))
     cands, touching = [], set()
     for g in range(len(m.sph_body)):
         b = m.sph_body[g]
         x = kin["o"][b] + kin["R"][b] @ m.sph_pos[g]
         depth = m.sph_radius[g] - x[2]
-        if depth > -mg:
+        if depth > -margin_of(g):
             touching.add(g)
             cands.append(dict(cat=0, g=g, depth=depth, xc=np.array([x[0], x[1], 0.0]), nrm=np.array([0.0, 0.0, 1.0])))
     if prm.terrain:
@@ -281,7 +285,7 @@ def contact_candidates(m, s, kin, prm):
             best = None
             for box in prm.terrain:
                 depth, nrm, xc = sphere_box(x, m.sph_radius[g], box)
-                if depth > -mg and (best is None or depth > best[0]):
+                if depth > -margin_of(g) and (best is None or depth > best[0]):
                     best = (depth, nrm, xc, box[3])
             if best is not None:
                 touching.add(g)

@@ -16,7 +16,8 @@ class Model(C.Structure):
     _fields_ = [("nb", C.c_int32), ("nj", C.c_int32), ("ns", C.c_int32), ("nf", C.c_int32), ("ng", C.c_int32), ("npairs", C.c_int32),
                 ("body_parent", C.c_int32 * MAX_BODIES), ("joint_body", C.c_int32 * MAX_JOINTS), ("sphere_body", C.c_int32 * MAX_SPHERES),
                 ("foot_body", C.c_int32 * MAX_FEET), ("geom_body", C.c_int32 * MAX_GEOMS),
-                ("pair_a", C.c_uint8 * MAX_PAIRS), ("pair_b", C.c_uint8 * MAX_PAIRS), ("table", C.POINTER(C.c_double))]
+                ("pair_a", C.c_uint8 * MAX_PAIRS), ("pair_b", C.c_uint8 * MAX_PAIRS), ("table", C.POINTER(C.c_double)),
+                ("sph_margin", C.POINTER(C.c_double))]
 
 
 class Params(C.Structure):
@@ -88,24 +89,30 @@ def make_model(m, motor_torque):
         arr = getattr(cm, name)
         for i, v in enumerate(src):
             arr[i] = int(v)
-    table = pack_table(m, motor_torque)
+    # the per-proxy contact margins of the world the model was loaded for ride behind the table (one array to keep alive)
+    margins = np.asarray(margins_of(m), np.float64)
+    table = np.ascontiguousarray(np.concatenate([pack_table(m, motor_torque), margins]))
     cm.table = table.ctypes.data_as(C.POINTER(C.c_double))
+    cm.sph_margin = C.cast(C.c_void_p(table.ctypes.data + 8 * (len(table) - len(margins))), C.POINTER(C.c_double))
     return cm, table
 
 
-def margin_of(m):
-    """Contact margin of the preset a Model was loaded with (mjcf.PRESETS[...]["contact_margin"]; models recorded before the
-    field existed carry only the preset's name)."""
-    if hasattr(m, "contact_margin"):
-        return float(m.contact_margin)
-    return 0.02 if str(getattr(m, "preset", "mujoco")) == "bullet" else 0.0
+def margins_of(m):
+    """Per-proxy contact margins of the preset a Model was loaded with (mjcf.PRESETS[...]["contact_margin"] through
+    mjcf.contact_margins; models recorded before the field existed carry only the preset's name)."""
+    from metagym_amd.metalocomotion import mjcf
+    rule = getattr(m, "contact_margin", None)
+    if rule is None:
+        rule = mjcf.PRESETS[str(getattr(m, "preset", "mujoco"))]["contact_margin"]
+    rule = rule.item() if hasattr(rule, "item") else rule
+    return mjcf.contact_margins(m, rule if isinstance(rule, str) else float(rule))
 
 
 def world_of(m):
     """The world half of the preset a Model was loaded with (mjcf.PRESETS): body damping and the velocity clamp."""
     bd = getattr(m, "body_damping", (0.0, 0.0))
     return dict(body_linear_damping=float(bd[0]), body_angular_damping=float(bd[1]),
-                max_coordinate_velocity=float(getattr(m, "max_velocity", 0.0)), contact_margin=margin_of(m))
+                max_coordinate_velocity=float(getattr(m, "max_velocity", 0.0)))
 
 
 def humanoid_params(m, **over):

@@ -307,7 +307,7 @@ int wo_substep(const wo_model *m, const wo_params *prm, wo_state *s, const doubl
         const v3 xw = vadd(k.o[b], mulMv(k.R[b], ld3(t_sph_pos(m) + 3 * g)));
         FL(F_ADD, 1);
         const double depth = t_sph_r(m)[g] - xw.z;
-        if (depth > -prm->contact_margin) {
+        if (depth > -(m->sph_margin ? m->sph_margin[g] : prm->contact_margin)) {
             touch[g >> 6] |= 1ull << (g & 63);
             if (ncand < WO_MAX_CANDIDATES) {
                 qx[ncand][0] = xw.x; qx[ncand][1] = xw.y; qx[ncand][2] = depth;

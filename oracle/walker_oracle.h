@@ -20,6 +20,7 @@ typedef struct wo_model {            /* topology (mg_walker_topology) + one row 
         geom_body[WO_MAX_GEOMS];
     uint8_t pair_a[WO_MAX_PAIRS], pair_b[WO_MAX_PAIRS];
     const double *table;
+    const double *sph_margin;        /* [ns] per-proxy contact margin (mjcf.contact_margins) or NULL: wo_params.contact_margin for all */
 } wo_model;
 
 typedef struct wo_params {
@@ -32,7 +33,7 @@ typedef struct wo_params {
     int32_t floor_in_parts, torque_f32, height_f32;
     double body_linear_damping, body_angular_damping;   /* btMultiBody velocity damping of every body (0.04 / 0.04 in the "bullet" preset) */
     double max_coordinate_velocity;                     /* btMultiBody's clamp of every generalized velocity (100 in the "bullet" preset; 0 = off) */
-    double contact_margin;                              /* Bullet's contact-breaking threshold (0.02 in the "bullet" preset; 0 = penetration only): abd.Params.contact_margin */
+    double contact_margin;                              /* contact margin of every proxy when wo_model.sph_margin is NULL (0 = penetration only): abd.Params.contact_margin */
 } wo_params;
 
 typedef struct wo_state { double pos[3], rot[9], vel[3], omega[3], q[WO_MAX_JOINTS], qd[WO_MAX_JOINTS]; } wo_state;

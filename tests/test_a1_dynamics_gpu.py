@@ -19,6 +19,13 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 
 
+def MARGINS(m):
+    """A1Physics' default contact margins (CONTACT_MARGIN = "relative": Bullet's 0.02 x the link's angular motion disc) per proxy
+    of the phys object's model `m`, for the oracle's Params."""
+    from metagym_amd.metalocomotion.mjcf import contact_margins
+    return contact_margins(m, "relative")
+
+
 def test_engine_with_per_robot_dynamics_matches_the_oracle_robot_by_robot():
     """Eight robots, eight drawn sets (masses, inertia diagonals, foot friction, gravity — the reference's ranges, gravity turned
     downwards so there are contacts; one robot keeps the upward one). Every 2 ms sub-step of every robot is replayed by oracle/abd.py on a
@@ -51,7 +58,7 @@ def test_engine_with_per_robot_dynamics_matches_the_oracle_robot_by_robot():
         else:
             assert np.array_equal(table[6, 12 * nb:13 * nb], m.body_mass) and np.array_equal(table[6, 16 * nb:25 * nb], np.asarray(m.body_inertia).reshape(-1))
         models.append(mk)
-        prms.append(abd.Params(dt=0.002, substeps=1, iterations=23, erp=0.2, friction=5.0, sphere_friction=mu, self_collision=False,
+        prms.append(abd.Params(contact_margin=MARGINS(m), dt=0.002, substeps=1, iterations=23, erp=0.2, friction=5.0, sphere_friction=mu, self_collision=False,
                                gravity=g, max_velocity=100.0))
     phys.reset(None)
     e = phys.env

@@ -19,6 +19,13 @@ from urdf_fixture import A1_LIKE_TOES, a1_like_urdf, model_to_urdf
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
+
+
+def MARGINS(m):
+    """A1Physics' default contact margins (CONTACT_MARGIN = "relative": Bullet's 0.02 x the link's angular motion disc) per proxy
+    of the phys object's model `m`, for the oracle's Params."""
+    from metagym_amd.metalocomotion.mjcf import contact_margins
+    return contact_margins(m, "relative")
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 STANDIN_XML = os.path.join(ROOT, "examples", "a1_standin", "a1_standin.xml")
 CALVES = ("FR_calf", "FL_calf", "RR_calf", "RL_calf")
@@ -34,8 +41,12 @@ def test_urdf_path_equals_mjcf_path_bit_for_bit(fused):
     for task in ("plane", "slopestair"):
         m = load_mjcf(STANDIN_XML, foot_names=CALVES, preset="mujoco")        # (its URDF twin carries the same armature 0.01)
         envs = []
-        for phys in (A1Physics(n, model=m, device=DEV, fused=fused),
-                     A1Physics(n, urdf=model_to_urdf(m), device=DEV, fused=fused, foot_links=CALVES, inertia="file", armature=0.01)):
+        # (one absolute contact margin for both: the default "relative" rule measures each LINK's size — the MJCF body with its
+        #  capsules about the body origin, the URDF link about its inertial frame — and the two loaders' numbers differ in the last
+        #  digits, which is not what this test is about)
+        for phys in (A1Physics(n, model=m, device=DEV, fused=fused, contact_margin=0.004),
+                     A1Physics(n, urdf=model_to_urdf(m), device=DEV, fused=fused, foot_links=CALVES, inertia="file", armature=0.01,
+                               contact_margin=0.004)):
             envs.append(metagym_amd.make("quadrupedal-v0", num_envs=n, physics=phys, device=DEV, ETG=1, ETG_w=w, ETG_b=np.zeros(3),
                                          task=task, control_latency=0.0057))
         o0, _ = envs[0].reset()
@@ -92,7 +103,7 @@ def test_urdf_robot_on_a_terrain_course_matches_the_oracle():
         rot[:, k] = np.array([[1, 0, 0], [0, c, -s_], [0, s_, c]]).reshape(9)       # rolled onto its side
     e.pos.copy_(torch.as_tensor(pos))
     e.rot.copy_(torch.as_tensor(rot))
-    prm = abd.Params(dt=0.002, substeps=1, iterations=23, erp=0.2, friction=5.0, sphere_friction=m.sph_friction,
+    prm = abd.Params(contact_margin=MARGINS(m), dt=0.002, substeps=1, iterations=23, erp=0.2, friction=5.0, sphere_friction=m.sph_friction,
                      self_collision=False, gravity=10.0, terrain=_oracle_boxes(boxes))
     target = np.array([0, 0.9, -1.8] * 4, float)
     log = torch.empty(1, 43, n, dtype=torch.float64, device=DEV)
@@ -115,8 +126,12 @@ def test_urdf_robot_on_a_terrain_course_matches_the_oracle():
                     np.abs(g["vel"][:, k] - s.v).max(), np.abs(g["omega"][:, k] - s.w).max(), np.abs(g["rot"][:, k] - s.rot.reshape(9)).max())
             worst = max(worst, d)
             # (round-off of the two kinematics orderings — the kernel composes the chain's transforms as a scan, the oracle
-            # body by body — amplified by contacts at box edges: 3e-9 seen, 3e-10 with the kernel's former body-by-body pass)
-            assert d < 2e-8, (t, k, d)
+            # body by body — amplified by contacts at box edges: 3e-9 seen, 3e-10 with the kernel's former body-by-body pass;
+            # round 6: with the contact margin the step has more discrete decisions (a proxy entering the margin, the deepest of two
+            # nearby boxes, clamps of speculative rows): next to one of them the ORACLE ITSELF turns a 1-ulp change of its input into
+            # 1.4e-7 within one sub-step (scripts/probe_margin_sensitivity.py, profiles/r06/walker_margin_sensitivity.txt; 5e-10
+            # without margin). 3.6e-8 / 2.6e-7 seen GPU vs oracle on the two terrain tests)
+            assert d < 1e-6, (t, k, d)
             o_feet = [float(any(m.sph_foot[g_] == f for g_ in touching)) for f in range(4)]
             o_bad = sum(1 for g_ in touching if m.sph_foot[g_] < 0)
             assert list(feet[:, k]) == o_feet and int(bad[k]) == o_bad, (t, k)
@@ -158,7 +173,7 @@ def test_two_courses_in_one_batch_match_the_oracle():
     pos[2] += 0.3
     e.pos.copy_(torch.as_tensor(pos))
     courses = [_oracle_boxes(boxes_a), _oracle_boxes(boxes_b), []]
-    prms = [abd.Params(dt=0.002, substeps=1, iterations=23, erp=0.2, friction=5.0, sphere_friction=m.sph_friction, self_collision=False,
+    prms = [abd.Params(contact_margin=MARGINS(m), dt=0.002, substeps=1, iterations=23, erp=0.2, friction=5.0, sphere_friction=m.sph_friction, self_collision=False,
                        gravity=10.0, terrain=c, max_velocity=100.0) for c in courses]
     target = np.array([0, 0.9, -1.8] * 4, float)
     rs = np.random.RandomState(1)
@@ -181,7 +196,7 @@ def test_two_courses_in_one_batch_match_the_oracle():
             d = max(np.abs(g["q"][:, k] - s.q).max(), np.abs(g["qd"][:, k] - s.qd).max(), np.abs(g["pos"][:, k] - s.pos).max(),
                     np.abs(g["vel"][:, k] - s.v).max(), np.abs(g["omega"][:, k] - s.w).max())
             worst = max(worst, d)
-            assert d < 2e-8, (t, k, d)
+            assert d < 1e-6, (t, k, d)         # (see the tolerance note in the single-course test)
             assert list(feet[:, k]) == [float(any(m.sph_foot[g_] == f for g_ in touching)) for f in range(4)], (t, k)
             assert int(bad[k]) == sum(1 for g_ in touching if m.sph_foot[g_] < 0), (t, k)
     zs = e.pos[2].cpu().numpy()
@@ -487,7 +502,7 @@ def test_external_push_on_the_engine_matches_the_oracle_and_newton():
     force, pos = rs.uniform(-40, 40, (n, 3)), rs.uniform(-0.2, 0.2, (n, 3))
     keys = ("pos", "rot", "vel", "omega", "q", "qd")
     st = {k: getattr(e, k).cpu().numpy() for k in keys}
-    prm = abd.Params(dt=0.002, substeps=1, iterations=23, erp=0.2, friction=5.0, sphere_friction=m.sph_friction, self_collision=False, gravity=0.0)
+    prm = abd.Params(contact_margin=MARGINS(m), dt=0.002, substeps=1, iterations=23, erp=0.2, friction=5.0, sphere_friction=m.sph_friction, self_collision=False, gravity=0.0)
     phys.apply_external_force(torch.as_tensor(force), torch.as_tensor(pos))
     tau = np.zeros((12, n))
     log = torch.empty(3, 43, n, dtype=torch.float64, device=DEV)

@@ -285,7 +285,8 @@ def _margin_env(name, margin, lock=False):
         m = copy.deepcopy(m)
         m.joint_lo, m.joint_hi = np.full_like(m.joint_lo, -0.005), np.full_like(m.joint_hi, 0.005)
     nj = len(m.joint_lo)
-    prm = abd.Params(friction=0.8 * float(m.geom_friction), self_friction=float(m.geom_friction) ** 2, contact_margin=margin)
+    from metagym_amd.metalocomotion.mjcf import contact_margins      # "relative": Bullet's own rule, 0.02 x the link's angular motion disc
+    prm = abd.Params(friction=0.8 * float(m.geom_friction), self_friction=float(m.geom_friction) ** 2, contact_margin=contact_margins(m, margin))
     env = abd.WalkerEnv(m, prm=prm, motor_power=np.full(nj, 100.0) if name == "ant" else abd.HUMANOID_MOTOR_POWER, alive_z=-1.0,
                         max_steps=10 ** 6, initial_z=None if name == "ant" else 0.8, torque_f32=name != "ant")
     env.reset(np.zeros(nj))
@@ -302,10 +303,11 @@ def test_contact_margin_keeps_resting_foot_flags_on(name, lock):
     """Zero action, humanoid started standing on the floor. lock=True: a statue (hinges held by their limit rows) that stands
     on its two sphere feet and then topples about them; lock=False: the ragdoll, which folds and comes to rest on the floor
     (a humanoid on two point feet cannot stand passively). With the 0.02 m margin both foot flags stay at 1 for >= 99 % of the
-    steps after settling and never toggle; without it (margin 0, the engine up to round 5) the same run toggles them — a contact
-    row and a flag only while a proxy penetrates. The rest height is the same to 1 mm."""
+    steps after settling and never toggle — and so they do with Bullet's own relative margin (0.02 x the link's size: 4.6 mm on
+    the foot); without it (margin 0, the engine up to round 5) the same run toggles them — a contact row and a flag only while a
+    proxy penetrates. The rest height is the same to 1 mm."""
     out = {}
-    for margin in (0.0, 0.02):
+    for margin in (0.0, 0.02, "relative"):
         m, env = _margin_env(name, margin, lock)
         flags = []
         for t in range(200):
@@ -315,9 +317,10 @@ def test_contact_margin_keeps_resting_foot_flags_on(name, lock):
         out[margin] = dict(all_on=float(settled.min(1).mean()), toggle=float(np.abs(np.diff(settled, axis=0)).sum() / settled[1:].size),
                            lowest=_lowest_surface(m, env.s))
     print(name, "lock" if lock else "ragdoll", {k: {kk: round(vv, 4) for kk, vv in v.items()} for k, v in out.items()})
-    assert out[0.02]["all_on"] >= 0.99 and out[0.02]["toggle"] <= 0.005
+    for margin in (0.02, "relative"):              # a flat 2 cm, and Bullet's relative rule (4.6 mm on the humanoid's feet)
+        assert out[margin]["all_on"] >= 0.99 and out[margin]["toggle"] <= 0.005, margin
+        assert abs(out[margin]["lowest"] - out[0.0]["lowest"]) < 1e-3 and abs(out[margin]["lowest"]) < 5e-3, margin
     assert out[0.0]["toggle"] > 0.02 and out[0.0]["all_on"] < 0.95          # today's flicker, for the record
-    assert abs(out[0.02]["lowest"] - out[0.0]["lowest"]) < 1e-3 and abs(out[0.02]["lowest"]) < 5e-3
 
 
 def test_contact_margin_ant_rest_height_and_flags():

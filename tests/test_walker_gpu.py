@@ -439,7 +439,7 @@ def test_c4_grounded_configuration_sampled_against_oracle():
 
 
 @pytest.mark.parametrize("mapping", ["wave", "lane"])
-@pytest.mark.parametrize("margin", [0.02, 0.0])
+@pytest.mark.parametrize("margin", ["relative", 0.02, 0.0])
 def test_contact_margin_and_deepest_first_cap_match_oracle(mapping, margin):
     """mg_walker_params.contact_margin (ABI 7) and the solver's contact cap, both mappings against oracle/abd.py: humanoids laid
     on their backs a little inside / on / above the floor — more than 12 contact candidates for most of them (the cap keeps the 12
@@ -449,7 +449,9 @@ def test_contact_margin_and_deepest_first_cap_match_oracle(mapping, margin):
     models = [MODELS[k] for k in names]
     n = 8
     env = _make("MetaHumanoidEnv", models, n, max_steps=1000, mapping=mapping, contact_margin=margin, contact_erp=0.1)   # (soft push-out: the pile-up lasts)
-    assert env.contact_margin == margin and env._params_c.contact_margin == margin
+    from metagym_amd.metalocomotion.mjcf import contact_margins
+    assert env.contact_margin == margin and env._params_c.contact_margin == (0.0 if margin == "relative" else margin)
+    assert env._params_c.sphere_margin_in_table == int(margin == "relative")       # Bullet's per-link rule: the margins ride in the model rows
     ids = env.task_id.cpu().numpy()
     nj = env.n_joints
     rs = np.random.RandomState(4)
@@ -461,7 +463,7 @@ def test_contact_margin_and_deepest_first_cap_match_oracle(mapping, margin):
     for e in range(n):
         m = models[ids[e]]
         kw = world_kw(m)
-        kw["contact_margin"] = margin
+        kw["contact_margin"] = contact_margins(m, margin)
         o = abd.WalkerEnv(m, prm=abd.Params(friction=0.8 * float(m.geom_friction), self_friction=float(m.geom_friction) ** 2, erp=0.1, **kw),
                           max_steps=1000)
         o.reset(noise[e])
@@ -490,7 +492,7 @@ def test_contact_margin_and_deepest_first_cap_match_oracle(mapping, margin):
             assert np.allclose(pos[e], s.pos, rtol=0, atol=1e-7), (t, e)
             assert np.array_equal(fc[e], oenvs[e].feet_contact), (t, e)
     assert over_cap >= 4, over_cap
-    assert (speculative >= 8) if margin > 0 else (speculative == 0)
+    assert (speculative >= 8) if margin != 0.0 else (speculative == 0)
     print(mapping, "margin", margin, "max |state diff| %.2e; env-steps starting with > 12 candidates: %d, with speculative ones: %d"
           % (worst, over_cap, speculative))
 

@@ -28,12 +28,15 @@ def world_kw(m):
 
 
 def margin_of(m):
-    """The preset's contact margin (mjcf.PRESETS[...]["contact_margin"]: Bullet's 0.02 m contact-breaking threshold in the "bullet"
-    world, 0 in the "mujoco" one). The recorded models predate the field and carry the preset's name only."""
-    if hasattr(m, "contact_margin"):
-        return float(m.contact_margin)
-    from metagym_amd.metalocomotion.mjcf import PRESETS
-    return float(PRESETS[preset_of(m)]["contact_margin"])
+    """The per-proxy contact margins of the preset's world (mjcf.PRESETS[...]["contact_margin"]: Bullet's relative rule — 0.02 x
+    the link's angular motion disc — in the "bullet" world, 0 in the "mujoco" one). The recorded models predate the field and
+    carry the preset's name only."""
+    from metagym_amd.metalocomotion import mjcf
+    rule = getattr(m, "contact_margin", None)
+    if rule is None:
+        rule = mjcf.PRESETS[preset_of(m)]["contact_margin"]
+    rule = rule.item() if hasattr(rule, "item") else rule
+    return mjcf.contact_margins(m, rule if isinstance(rule, str) else float(rule))
 
 
 def preset_of(m):
