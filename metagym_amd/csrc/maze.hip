@@ -799,7 +799,10 @@ typedef int mz_v3i __attribute__((ext_vector_type(3)));   // 12-byte pixel, stor
 // is VALU-bound (82 % busy). Pass A parks the widened record in LDS (ColRecLds) and the pixel pass reads it back with four
 // broadcast ds_read_b128; five waves per SIMD give the record's VGPR copy its registers (the cap is not what bounds the resident
 // waves: 4 / 5 / 6 measured alike). 64 x 64 x 65 536 envs: 0.913 -> 0.865 ms (profiles/r05/maze3d_small_frames.txt).
-template <int REC, bool STOCK, bool SMALL = false>
+// U8 (stock instantiations only): uint8 frames, known at compile time — the general kernel reads vk.obs_u8 at run time. Up to
+// round 5 uint8 frames always ran the GENERAL kernel, which is why the mode was no faster than int32 (its extra arithmetic cost
+// what the smaller frames saved).
+template <int REC, bool STOCK, bool SMALL = false, bool U8 = false>
 __global__ __launch_bounds__(MZ_BLOCK) __attribute__((amdgpu_waves_per_eu(SMALL ? 5 : 6))) void maze3d_step_kernel(mg_maze_tasks T, mg_maze_state st, ViewK vk,
                                                                int task_type, int max_steps, int continuous,
                                                                int pre_moved, int auto_reset, int n_envs,
@@ -946,7 +949,7 @@ __global__ __launch_bounds__(MZ_BLOCK) __attribute__((amdgpu_waves_per_eu(SMALL 
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         // column-major walk: column k's record is broadcast ONCE (v_readlane + converts; SMALL: read back from LDS) and then
         // reused by all V/64 row chunks; the per-row constants come from the LDS row table
-        const bool obs_u8 = !STOCK && vk.obs_u8;
+        const bool obs_u8 = STOCK ? U8 : (vk.obs_u8 != 0);
         const uint32_t px_bytes = obs_u8 ? 3u : 12u;
 #ifdef MG_MAZE3D_KNOCKOUT_PIXELS      /* timing experiment only: everything but the pixel loop */
         if (mine.w_span == 0x7fffffff) ((int *)obs)[e] = 1;
@@ -966,9 +969,27 @@ __global__ __launch_bounds__(MZ_BLOCK) __attribute__((amdgpu_waves_per_eu(SMALL 
         int p_r = 0, p_g = 0, p_b = 0;
         uint32_t p_off = 0;
         bool p_ok = false;
+        // uint8 frames (non-parity fast path: saturate to a byte): three byte stores per pixel. Round 6 also built the PACKED store
+        // the round-5 review asked for — a chunk of a column is 64 pixels x 3 bytes = 192 contiguous bytes; each lane packs its pixel
+        // into 24 bits, three DPP quad broadcasts bring a quad's four words to every lane, lane 4k stores the quad's 12 bytes as one
+        // buffer_store_dwordx3 (16 store requests per wave instead of 192; needs res_v % 4 == 0) — and measured it SLOWER: 262
+        // instead of 778 store instructions per wave, but 21 595 instead of 18 512 VALU instructions, 2.524 against 2.415 ms at
+        // 256 x 256 x 16 384 envs (int32 frames: 2.515 ms) and 0.956 against 0.922 ms at 64 x 64 x 65 536. The kernel is bound by VALU
+        // issue (17 % of a wave's cycles x ~5.5 resident waves per SIMD), not by its stores: profiles/r06/maze3d_uint8.txt. The
+        // packed path stays behind MG_MAZE3D_U8_PACKED=1 so that the measurement can be repeated; byte stores are the default.
+        const bool u8_packed = obs_u8 && (vk.V & 3) == 0 && vk.obs_u8 == 2;
+        const bool quad_lead = (lane & 3) == 0;
         auto flush = [&]() {
             const uint32_t o = p_ok ? p_off : 0x80000000u;      // (frames are < 2^31 bytes: res_h <= 32767, res_v <= 4095)
-            if (obs_u8) {      // non-parity fast path: saturate to a byte
+            if (u8_packed) {
+                const uint32_t w0 = (uint32_t)min(max(p_r, 0), 255) | ((uint32_t)min(max(p_g, 0), 255) << 8) | ((uint32_t)min(max(p_b, 0), 255) << 16);
+                const uint32_t w1 = (uint32_t)__builtin_amdgcn_mov_dpp((int)w0, 0x55, 0xf, 0xf, true);      // quad_perm [1,1,1,1]
+                const uint32_t w2 = (uint32_t)__builtin_amdgcn_mov_dpp((int)w0, 0xAA, 0xf, 0xf, true);      // quad_perm [2,2,2,2]
+                const uint32_t w3 = (uint32_t)__builtin_amdgcn_mov_dpp((int)w0, 0xFF, 0xf, 0xf, true);      // quad_perm [3,3,3,3]
+                mz_v3i v;          // bytes r0 g0 b0 r1 | g1 b1 r2 g2 | b2 r3 g3 b3 (only lane 4k's own w0 is pixel 4k's)
+                v.x = (int)(w0 | (w1 << 24)); v.y = (int)((w1 >> 8) | (w2 << 16)); v.z = (int)((w2 >> 16) | (w3 << 8));
+                __builtin_amdgcn_raw_buffer_store_b96(v, frame, quad_lead ? o : 0x80000000u, 0, 2);
+            } else if (obs_u8) {
                 __builtin_amdgcn_raw_buffer_store_b8((uint8_t)min(max(p_r, 0), 255), frame, o, 0, 2);
                 __builtin_amdgcn_raw_buffer_store_b8((uint8_t)min(max(p_g, 0), 255), frame, o + 1u, 0, 2);
                 __builtin_amdgcn_raw_buffer_store_b8((uint8_t)min(max(p_b, 0), 255), frame, o + 2u, 0, 2);
@@ -1248,7 +1269,8 @@ extern "C" int mg_maze3d_step(const mg_maze_tasks *T, const mg_maze_view *view, 
     vk.H = view->res_h;
     vk.V = view->res_v;
     vk.TS = view->tex_size;
-    vk.obs_u8 = view->obs_format == 1;
+    static const bool u8_pack = getenv("MG_MAZE3D_U8_PACKED") != nullptr;      // timing A/B only: the packed dwordx3 store (see flush())
+    vk.obs_u8 = view->obs_format == 1 ? (u8_pack ? 2 : 1) : 0;
     vk.max_vision = view->max_vision;
     {
         // div_by()'s correctly-rounded quotient (Markstein) needs a divisor whose significand is not all ones;
@@ -1330,7 +1352,11 @@ extern "C" int mg_maze3d_step(const mg_maze_tasks *T, const mg_maze_view *view, 
                                    reinterpret_cast<const void *>(maze3d_step_kernel<1, false, true>),
                                    reinterpret_cast<const void *>(maze3d_step_kernel<2, false, true>),
                                    reinterpret_cast<const void *>(maze3d_step_kernel<1, true, true>),
-                                   reinterpret_cast<const void *>(maze3d_step_kernel<2, true, true>)}) {
+                                   reinterpret_cast<const void *>(maze3d_step_kernel<2, true, true>),
+                                   reinterpret_cast<const void *>(maze3d_step_kernel<1, true, false, true>),
+                                   reinterpret_cast<const void *>(maze3d_step_kernel<2, true, false, true>),
+                                   reinterpret_cast<const void *>(maze3d_step_kernel<1, true, true, true>),
+                                   reinterpret_cast<const void *>(maze3d_step_kernel<2, true, true, true>)}) {
                 hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
                 if (e != hipSuccess) return mg::check_hip(e, "hipFuncSetAttribute(maze3d_step_kernel)");
             }
@@ -1350,7 +1376,7 @@ extern "C" int mg_maze3d_step(const mg_maze_tasks *T, const mg_maze_view *view, 
     bool stock = false;
     // the ABI is re-entrant — the environment is read once, not on every step
     static const bool force_generic = getenv("MG_MAZE3D_GENERIC") != nullptr;
-    if (view->uniform_cell_size > 0.0 && !vk.obs_u8 && !force_generic) {
+    if (view->uniform_cell_size > 0.0 && !force_generic) {
         const double cs = view->uniform_cell_size, ttc = vk.text_size / cs, inv_ttc = 1.0 / ttc;
         int e2;
         stock = frexp(cs, &e2) == 0.5 && frexp(ttc, &e2) == 0.5 && vk.text_size_pow2 && (vk.TS & (vk.TS - 1)) == 0 && inv_ttc >= 1.0 &&
@@ -1358,13 +1384,20 @@ extern "C" int mg_maze3d_step(const mg_maze_tasks *T, const mg_maze_view *view, 
     }
     // (MG_MAZE3D_NO_SMALL=1 keeps the general instantiation for one-wave frames too, for A/B timing; the frames are the same bit
     // for bit either way — same arithmetic, another route for the column record.)
-#define MG_MAZE3D_LAUNCH(REC_, STOCK_, SMALL_)                                                                                \
-    hipLaunchKernelGGL((maze3d_step_kernel<REC_, STOCK_, SMALL_>), dim3(n), dim3(n_waves * mg::WAVE), lds, (hipStream_t)stream, *T, *st, vk, \
+#define MG_MAZE3D_LAUNCH(REC_, STOCK_, SMALL_, U8_)                                                                           \
+    hipLaunchKernelGGL((maze3d_step_kernel<REC_, STOCK_, SMALL_, U8_>), dim3(n), dim3(n_waves * mg::WAVE), lds, (hipStream_t)stream, *T, *st, vk, \
                        task_type, max_steps, continuous, pre_moved, auto_reset, n, action, obs, reward, reward64, done)
 #define MG_MAZE3D_PICK(REC_)                                                                                                  \
     do {                                                                                                                      \
-        if (small) { if (stock) MG_MAZE3D_LAUNCH(REC_, true, true); else MG_MAZE3D_LAUNCH(REC_, false, true); }               \
-        else { if (stock) MG_MAZE3D_LAUNCH(REC_, true, false); else MG_MAZE3D_LAUNCH(REC_, false, false); }                  \
+        if (small) {                                                                                                          \
+            if (stock && vk.obs_u8) MG_MAZE3D_LAUNCH(REC_, true, true, true);                                                 \
+            else if (stock) MG_MAZE3D_LAUNCH(REC_, true, true, false);                                                        \
+            else MG_MAZE3D_LAUNCH(REC_, false, true, false);                                                                  \
+        } else {                                                                                                              \
+            if (stock && vk.obs_u8) MG_MAZE3D_LAUNCH(REC_, true, false, true);                                                \
+            else if (stock) MG_MAZE3D_LAUNCH(REC_, true, false, false);                                                       \
+            else MG_MAZE3D_LAUNCH(REC_, false, false, false);                                                                 \
+        }                                                                                                                     \
     } while (0)
     if (rec == 1) MG_MAZE3D_PICK(1); else MG_MAZE3D_PICK(2);
 #undef MG_MAZE3D_PICK

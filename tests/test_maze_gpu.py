@@ -667,6 +667,35 @@ def test_maze3d_uint8_fast_path_is_the_clamped_reference_frame():
     assert int(oa.max()) > 255          # the int32 frames really do exceed a byte
 
 
+@pytest.mark.parametrize("ident,res", [("meta-maze-discrete-3D-v0", (40, 100)), ("meta-maze-discrete-3D-v0", (24, 30)),
+                                       ("meta-maze-discrete-3D-v0", (64, 64)), ("meta-maze-continuous-3D-v0", (32, 132)),
+                                       ("meta-maze-discrete-3D-v0", (20, 256)), ("meta-maze-continuous-3D-v0", (33, 7))])
+def test_maze3d_uint8_packed_store_shapes(ident, res):
+    """The uint8 frames' packed store (round 6: a quad of lanes writes its 12 bytes as one dwordx3, csrc/maze.hip flush()) over
+    the shapes that decide its path: res_v a multiple of 4 with a ragged last 64-row chunk (100, 132), one chunk exactly (64),
+    four chunks (256), and heights that are not a multiple of 4 (30, 7: the byte-store path) — every byte equals
+    min(int32 frame, 255), discrete and continuous, small-frame and four-wave kernels."""
+    import metagym_amd
+    from metagym_amd.metamaze import MazeTaskSampler
+    tasks = [MazeTaskSampler(n=9, allow_loops=False, food_density=0.08, food_interval=4, seed=170 + s) for s in range(3)]
+    n = 24
+    mk = lambda dt: metagym_amd.make(ident, num_envs=n, device="cuda:0", max_steps=30, resolution=res, task_type="SURVIVAL", obs_dtype=dt)
+    a, b = mk(torch.int32), mk(torch.uint8)
+    a.set_task(tasks)
+    b.set_task(tasks)
+    oa, ob = a.reset(), b.reset()
+    assert ob.dtype == torch.uint8 and ob.shape == oa.shape and torch.equal(oa.clamp(0, 255).to(torch.uint8), ob)
+    g = torch.Generator().manual_seed(2)
+    for _ in range(5):
+        if "continuous" in ident:
+            act = torch.rand(n, 2, generator=g) * 2 - 1
+        else:
+            act = torch.randint(0, 4, (n,), generator=g, dtype=torch.int32)
+        oa, ra, da, _ = a.step(act)
+        ob, rb, db, _ = b.step(act)
+        assert torch.equal(oa.clamp(0, 255).to(torch.uint8), ob) and torch.equal(ra, rb) and torch.equal(da, db)
+
+
 def test_device_task_sampler_matches_reference_tasks_bit_exact(reference_textures):
     """mg_maze_sample_tasks (one wave per task, MT19937 streams on the device) against tasks drawn by the
     unmodified reference sampler: every field of every task, bit for bit (floats included)."""
