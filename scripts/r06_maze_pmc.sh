@@ -18,15 +18,15 @@ for V in discrete continuous; do
           --output-format csv -d $OUT/${V}_ta -o m -- $M --no-u8 --only $V > $OUT/${V}_ta.log 2>&1
   timeout 300 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum --output-format csv -d $OUT/${V}_tcc -o m -- $M --no-u8 --only $V > $OUT/${V}_tcc.log 2>&1
 done
-# uint8: packed (default) and byte stores (MG_MAZE3D_U8_BYTES=1); bench_maze prints int32 first, then uint8 — both kernels are in each trace
+# uint8: byte stores (default) and the packed store (MG_MAZE3D_U8_PACKED=1); bench_maze prints int32 first, then uint8 — both kernels are in each trace
 MG_MAZE3D_U8_PACKED=1 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/u8_packed_trace -o m -- $M --only discrete > $OUT/u8_packed_trace.log 2>&1
 MG_MAZE3D_U8_PACKED=1 timeout 300 rocprofv3 --pmc $SQ --output-format csv -d $OUT/u8_packed_sq -o m -- $M --only discrete > $OUT/u8_packed_sq.log 2>&1
-MG_MAZE3D_U8_PACKED=0 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/u8_bytes_trace -o m -- $M --only discrete > $OUT/u8_bytes_trace.log 2>&1
-MG_MAZE3D_U8_PACKED=0 timeout 300 rocprofv3 --pmc $SQ --output-format csv -d $OUT/u8_bytes_sq -o m -- $M --only discrete > $OUT/u8_bytes_sq.log 2>&1
-MG_MAZE3D_U8_PACKED=0 python scripts/bench_maze.py --skip2d --res 256 --only discrete > $OUT/bench_u8_bytes_256.jsonl 2>/dev/null
-MG_MAZE3D_U8_PACKED=0 python scripts/bench_maze.py --skip2d --res 64 --envs 65536 --only discrete > $OUT/bench_u8_bytes_64.jsonl 2>/dev/null
-python scripts/bench_maze.py --skip2d --res 256 --only discrete > $OUT/bench_u8_packed_256.jsonl 2>/dev/null
-python scripts/bench_maze.py --skip2d --res 64 --envs 65536 --only discrete > $OUT/bench_u8_packed_64.jsonl 2>/dev/null
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/u8_bytes_trace -o m -- $M --only discrete > $OUT/u8_bytes_trace.log 2>&1
+timeout 300 rocprofv3 --pmc $SQ --output-format csv -d $OUT/u8_bytes_sq -o m -- $M --only discrete > $OUT/u8_bytes_sq.log 2>&1
+python scripts/bench_maze.py --skip2d --res 256 --only discrete > $OUT/bench_u8_bytes_256.jsonl 2>/dev/null
+python scripts/bench_maze.py --skip2d --res 64 --envs 65536 --only discrete > $OUT/bench_u8_bytes_64.jsonl 2>/dev/null
+MG_MAZE3D_U8_PACKED=1 python scripts/bench_maze.py --skip2d --res 256 --only discrete > $OUT/bench_u8_packed_256.jsonl 2>/dev/null
+MG_MAZE3D_U8_PACKED=1 python scripts/bench_maze.py --skip2d --res 64 --envs 65536 --only discrete > $OUT/bench_u8_packed_64.jsonl 2>/dev/null
 # keep what travels back small: the per-dispatch counter CSVs and the stats, not the traces' event dumps
 find $OUT -name "*.csv" -size +3M -delete
 du -sh $OUT; ls $OUT
