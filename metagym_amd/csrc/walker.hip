@@ -793,6 +793,10 @@ __device__ unsigned long long mg_walker_phase_cycles[16];
         if (lane == 0) atomicAdd(&mg_walker_phase_cycles[i], ph_t1 - ph_t0);               \
         ph_t0 = ph_t1;                                                                    \
     } while (0)
+#elif defined(MG_WALKER_PHASE_MARKS)
+// Analysis builds only (scripts/isa_phase_regs.py): a comment line in the assembly at every phase boundary, nothing else
+#define PHASE_BEGIN() asm volatile("; MGPHASE begin")
+#define PHASE(i) asm volatile("; MGPHASE %0" ::"n"(i))
 #else
 #define PHASE_BEGIN() do { } while (0)
 #define PHASE(i) do { } while (0)
