@@ -1589,9 +1589,17 @@ __device__ __forceinline__ void wave_substep(const mg_walker_topology &tp, const
     // matrix from it)
     constexpr bool ASPACE = true;
 #ifndef MG_WALKER_NRA_BIG
-#define MG_WALKER_NRA_BIG 24      // (experiments: 18 frees 12 VGPRs under a 168-VGPR cap; more rows take the velocity-space sweep)
+#define MG_WALKER_NRA_BIG 42      // the tuned humanoid kernel (see below; experiments: 18 frees 12 VGPRs under a 168-VGPR cap)
 #endif
-    constexpr int NRA = NMAX <= 18 ? 30 : MG_WALKER_NRA_BIG;    // constraint rows the multiplier-space sweep keeps in registers (one row of A per lane)
+    // Constraint rows the multiplier-space sweep keeps in registers (one row of A per lane, 2 VGPRs per row); more rows take the
+    // velocity-space sweep. Round 6: with the contact margin a humanoid lying on the floor has 28 rows per sub-step on average (8.4
+    // contacts, profiles/r06/walker_flops.json), over the former 24 — the whole lying batch fell back to the ~25-operation chain per
+    // row. Measured on the lying C4_grounded batch / the airborne C4 batch (scripts/bench_walker.py, one MI355X):
+    //     24 rows (226 VGPRs) 1.241 / 0.582 ms    30: 1.197 / 0.584    36 (238): 1.111 - 1.123 / 0.586    42 (250): 1.025 - 1.040 / 0.588
+    //     48 (256, 2 spills): 1.013 / 0.595
+    // 42 rows: -17 % on the contact-rich batch for +1 % on the airborne one, no spill, still two waves per SIMD. The shape-generic
+    // 23-slot kernel stays at 24 (it spills from 30 on).
+    constexpr int NRA = NMAX <= 18 ? 30 : (GENERIC ? 24 : MG_WALKER_NRA_BIG);
     double w[NMAX];
     if (ASPACE) {
 #pragma unroll
