@@ -620,12 +620,14 @@ def secondary_workloads(dev, valu_insts_per_wave=None):
                                    "algorithmic_flop_per_env_step": e_flop, "flop_source": e_src,
                                    "constraint_rows_per_substep_counted": None if e_rec is None else e_rec.get("constraint_rows_per_substep"),
                                    "note": "same start, fused auto-reset: an episode ends when the torso sinks below 0.5 m (~44 steps), so "
-                                           "most of the mix is standing / folding robots whose resting contacts flicker"},
+                                           "most of the mix is standing / folding robots (round 6: Bullet's contact margin keeps their "
+                                           "resting contacts — and the solver rows — alive between sub-steps)"},
             "roofline": {"bound": "valu", "achieved": fl * n / s_lying / 1e12, "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": fl * n / s_lying / 1e12 / FP64_VALU_PEAK_TFLOPS, "algorithmic_flop_per_env_step": fl,
                          "flop_source": g_src if g_flop is not None else flop_src + " (the airborne rollout: no grounded count found)",
                          "flop_mix_per_env_step": g_mix, "achieved_hbm_gbs": byt * n / s_lying / 1e9,
                          "hbm_frac": byt * n / s_lying / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes_per_env_step": byt},
+            "contact_margin": "relative: 0.02 x the link's angular motion disc, Bullet's default rule (mjcf.contact_margins; round 6)",
             "note": "physics parity unpinned (PyBullet is not in the reference tree); under GPU parity against oracle/walker_oracle.c in "
                     "tests/test_walker_gpu.py::test_c4_grounded_configuration_sampled_against_oracle"}
     except Exception as e:

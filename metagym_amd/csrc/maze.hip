@@ -974,9 +974,10 @@ __global__ __launch_bounds__(MZ_BLOCK) __attribute__((amdgpu_waves_per_eu(SMALL 
         // into 24 bits, three DPP quad broadcasts bring a quad's four words to every lane, lane 4k stores the quad's 12 bytes as one
         // buffer_store_dwordx3 (16 store requests per wave instead of 192; needs res_v % 4 == 0) — and measured it SLOWER: 262
         // instead of 778 store instructions per wave, but 21 595 instead of 18 512 VALU instructions, 2.524 against 2.415 ms at
-        // 256 x 256 x 16 384 envs (int32 frames: 2.515 ms) and 0.956 against 0.922 ms at 64 x 64 x 65 536. The kernel is bound by VALU
-        // issue (17 % of a wave's cycles x ~5.5 resident waves per SIMD), not by its stores: profiles/r06/maze3d_uint8.txt. The
-        // packed path stays behind MG_MAZE3D_U8_PACKED=1 so that the measurement can be repeated; byte stores are the default.
+        // 256 x 256 x 16 384 envs (int32 frames: 2.515 ms) and 0.956 against 0.922 ms at 64 x 64 x 65 536. With the 4x smaller frames
+        // the store stream no longer limits the kernel, VALU issue does (floors 1.97 / 2.30 ms for the two variants):
+        // profiles/r06/maze3d_uint8.txt. The packed path stays behind MG_MAZE3D_U8_PACKED=1 so that the measurement can be repeated;
+        // byte stores are the default.
         const bool u8_packed = obs_u8 && (vk.V & 3) == 0 && vk.obs_u8 == 2;
         const bool quad_lead = (lane & 3) == 0;
         auto flush = [&]() {

@@ -581,7 +581,7 @@ def test_autoreset_full_size_sampled_against_oracle():
 
 
 def test_step_outputs_alias_unless_copy_outputs():
-    """DESIGN.md §7: step() returns the same four tensors every call (no allocation on the hot path, hipGraph-replayable);
+    """DESIGN.md §1: step() returns the same four tensors every call (no allocation on the hot path, hipGraph-replayable);
     `copy_outputs=True` gives fresh ones like the reference's fresh numpy arrays."""
     import metagym_amd
     a = torch.full((8, 4), 2.0, device="cuda:0")
