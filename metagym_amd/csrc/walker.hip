@@ -1377,7 +1377,7 @@ __device__ __forceinline__ void wave_substep(const mg_walker_topology &tp, const
     // x range misses the chunk's proxies are skipped by the whole wave); per proxy the deepest box, first on ties. Slots
     // after the ground contacts; the friction rows carry the contact's coefficient in their (otherwise zero) bias slot, kind -1.
     if (GENERIC && prm.n_terrain_boxes > 0)
-        for (int ch = 0; ch < nchunk && ncand < cand_cap; ++ch) {
+        for (int ch = 0; ch < nchunk; ++ch) {      // (every chunk, even with the candidate buffer full: `touch` counts every proxy inside its margin)
             const int g = ch * WV + lane;
             double rad = 0.0, sx = 0.0, sy = 0.0, sz = 0.0, margin = 0.0;
             if (g < ns) {
