@@ -64,6 +64,36 @@ DEF_KERNEL_D2D(k_cmp, I_CMP)
 #define I_BFE(k) asm volatile("v_bfe_u32 %0, %1, 8, 8" : "=v"(u[k]) : "v"(u[(k + 1) & 7]));
 #define I_MULLO(k) asm volatile("v_mul_lo_u32 %0, %1, %1" : "=v"(u[k]) : "v"(u[(k + 1) & 7]));
 #define I_MAD24(k) asm volatile("v_mad_u32_u24 %0, %1, %1, %1" : "=v"(u[k]) : "v"(u[(k + 1) & 7]));
+#define I_FMA32(k) asm volatile("v_fma_f32 %0, %1, %1, %0" : "+v"(f[k]) : "v"(f[(k + 1) & 7]));
+#define I_FMAC32(k) asm volatile("v_fmac_f32 %0, %1, %1" : "+v"(f[k]) : "v"(f[(k + 1) & 7]));
+#define I_MUL32(k) asm volatile("v_mul_f32 %0, %0, %1" : "+v"(f[k]) : "v"(f[(k + 1) & 7]));
+#define I_ADD32(k) asm volatile("v_add_f32 %0, %0, %1" : "+v"(f[k]) : "v"(f[(k + 1) & 7]));
+#define I_RCP32(k) asm volatile("v_rcp_f32 %0, %0" : "+v"(f[k]));
+#define I_SQRT32(k) asm volatile("v_sqrt_f32 %0, %0" : "+v"(f[k]));
+#define I_CNDMASK(k) asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(u[k]) : "v"(u[(k + 1) & 7]) : "vcc");
+#define I_ADDU32(k) asm volatile("v_add_u32 %0, %0, %1" : "+v"(u[k]) : "v"(u[(k + 1) & 7]));
+#define I_LSHLADD(k) asm volatile("v_lshl_add_u32 %0, %1, 1, %0" : "+v"(u[k]) : "v"(u[(k + 1) & 7]));
+#define I_MED3(k) asm volatile("v_med3_i32 %0, %0, 0, %1" : "+v"(u[k]) : "v"(u[(k + 1) & 7]));
+#define I_DPP(k) asm volatile("v_mov_b32_dpp %0, %1 quad_perm:[1,1,1,1] row_mask:0xf bank_mask:0xf bound_ctrl:1" : "=v"(u[k]) : "v"(u[(k + 1) & 7]));
+#define I_READLANE(k) asm volatile("v_readlane_b32 s20, %0, 3" ::"v"(u[k]) : "s20");
+#define I_SQRT64(k) asm volatile("v_sqrt_f64 %0, %0" : "+v"(a[k]));
+#define I_RSQ64(k) asm volatile("v_rsq_f64 %0, %0" : "+v"(a[k]));
+#define I_LDEXP64(k) asm volatile("v_ldexp_f64 %0, %0, 1" : "+v"(a[k]));
+DEF_KERNEL_CVT(k_fma_f32, I_FMA32)
+DEF_KERNEL_CVT(k_fmac_f32, I_FMAC32)
+DEF_KERNEL_CVT(k_mul_f32, I_MUL32)
+DEF_KERNEL_CVT(k_add_f32, I_ADD32)
+DEF_KERNEL_CVT(k_rcp_f32, I_RCP32)
+DEF_KERNEL_CVT(k_sqrt_f32, I_SQRT32)
+DEF_KERNEL_CVT(k_cndmask, I_CNDMASK)
+DEF_KERNEL_CVT(k_add_u32, I_ADDU32)
+DEF_KERNEL_CVT(k_lshl_add, I_LSHLADD)
+DEF_KERNEL_CVT(k_med3_i32, I_MED3)
+DEF_KERNEL_CVT(k_mov_dpp, I_DPP)
+DEF_KERNEL_CVT(k_readlane, I_READLANE)
+DEF_KERNEL_CVT(k_sqrt_f64, I_SQRT64)
+DEF_KERNEL_CVT(k_rsq_f64, I_RSQ64)
+DEF_KERNEL_CVT(k_ldexp_f64, I_LDEXP64)
 DEF_KERNEL_CVT(k_cvt_f64_u32, I_CVT_F64_U32)
 DEF_KERNEL_CVT(k_cvt_f64_i32, I_CVT_F64_I32)
 DEF_KERNEL_CVT(k_cvt_i32_f64, I_CVT_I32_F64)
@@ -105,5 +135,7 @@ int main() {
     RUN(k_fma); RUN(k_mul); RUN(k_add); RUN(k_floor); RUN(k_fract); RUN(k_rcp); RUN(k_max); RUN(k_cmp);
     RUN(k_cvt_f64_u32); RUN(k_cvt_f64_i32); RUN(k_cvt_i32_f64); RUN(k_cvt_u32_f64); RUN(k_cvt_f64_f32); RUN(k_cvt_f32_f64); RUN(k_cvt_f32_ub0);
     RUN(k_mov32); RUN(k_and32); RUN(k_bfe); RUN(k_mullo); RUN(k_mad24);
+    RUN(k_fma_f32); RUN(k_fmac_f32); RUN(k_mul_f32); RUN(k_add_f32); RUN(k_rcp_f32); RUN(k_sqrt_f32); RUN(k_cndmask); RUN(k_add_u32);
+    RUN(k_lshl_add); RUN(k_med3_i32); RUN(k_mov_dpp); RUN(k_readlane); RUN(k_sqrt_f64); RUN(k_rsq_f64); RUN(k_ldexp_f64);
     return 0;
 }
