@@ -240,3 +240,43 @@ def test_a1_like_robot_stands_on_its_toes_in_the_numpy_engine():
     kin = abd.kinematics(m, s)
     low = min((kin["o"][b] + kin["R"][b] @ m.sph_pos[g])[2] - m.sph_radius[g] for g, b in enumerate(m.sph_body))
     assert low > -2e-3
+
+
+def test_relative_contact_margins_follow_bullets_rule():
+    """mjcf.contact_margins(model, "relative") = Bullet's default contact-breaking threshold per LINK (DESIGN.md §3.4's table):
+    gContactBreakingThreshold (0.02) x btCollisionShape::getAngularMotionDisc() of the link's compound shape = half the diagonal of
+    the shapes' axis-aligned bounding box + the distance of the box's centre from the shape's origin — by hand for an A1-like
+    toe (a 2 cm sphere at the link origin: 0.02 x sqrt(3) x 0.02 = 0.69 mm) and calf (a 0.2 x 0.016 x 0.016 box centred 0.1 below the
+    link origin), per ORIGINAL link although the toe is merged into the calf's body; for an MJCF body from its capsules; and the
+    absolute forms."""
+    from metagym_amd.metalocomotion.mjcf import CONTACT_BREAKING_THRESHOLD, angular_motion_discs, contact_margins
+    m = load_urdf(a1_like_urdf(), foot_links=A1_LIKE_TOES, joint_order=MOTOR_NAMES)
+    rel = contact_margins(m, "relative")
+    assert rel.shape == (len(m.sph_body),) and np.array_equal(rel, CONTACT_BREAKING_THRESHOLD * angular_motion_discs(m))
+    toe = np.asarray(m.sph_foot) >= 0
+    assert toe.sum() == 4 and np.allclose(rel[toe], 0.02 * np.sqrt(3.0) * 0.02, rtol=1e-12)         # 0.69 mm
+    link_names = list(m.link_names)
+    calf = np.array([link_names[k] == "FR_lower" for k in m.sph_link])
+    assert calf.sum() == 8                                                                           # the box's corners
+    # the calf: box 0.2 x 0.016 x 0.016 turned so that its long axis is the link's z, centred at (0, 0, -0.1); inertial origin
+    # (0.0065, 0, -0.1073), no rotation: half diagonal |(0.008, 0.008, 0.1)| + |(-0.0065, 0, 0.0073)| = 0.11041 -> 2.21 mm
+    assert np.all(np.abs(rel[calf] - rel[calf][0]) < 1e-15)
+    by_hand = 0.02 * (np.linalg.norm([0.008, 0.008, 0.1]) + np.linalg.norm([-0.0065, 0.0, 0.0073]))
+    assert np.isclose(rel[calf][0], by_hand, rtol=1e-9), (rel[calf][0], by_hand)
+    # standing on its toes with the calves at 0.9 - 1.8 rad, a calf corner is ~1.4 cm above the floor: outside the calf's own margin,
+    # inside a flat 2 cm one — the reason the flat margin produced 8 "bad" contacts per standing robot (profiles/EXPERIMENTS.md)
+    assert rel[calf][0] < 0.014 < 0.02
+    # MJCF: the body is the link, geoms in the body frame
+    from walker_fixtures import load_models
+    h = load_models()["humanoid"]
+    d = angular_motion_discs(h)
+    lo, hi = np.full(3, np.inf), np.full(3, -np.inf)
+    b = int(h.sph_body[-1])
+    for gb, p0, p1, r in zip(h.geom_body, h.geom_p0, h.geom_p1, h.geom_radius):
+        if int(gb) == b:
+            lo, hi = np.minimum(lo, np.minimum(p0, p1) - r), np.maximum(hi, np.maximum(p0, p1) + r)
+    assert np.isclose(d[-1], 0.5 * np.linalg.norm(hi - lo) + np.linalg.norm(0.5 * (hi + lo)), rtol=1e-14)
+    assert 0.002 < contact_margins(h, "relative").min() and contact_margins(h, "relative").max() < 0.01
+    assert np.array_equal(contact_margins(h, 0.0), np.zeros(len(h.sph_body))) and np.array_equal(contact_margins(h, 0.02), np.full(len(h.sph_body), 0.02))
+    with pytest.raises(ValueError, match="relative"):
+        contact_margins(h, "bullet")
