@@ -1209,6 +1209,17 @@ def main(argv=None):
                                                  "valu_insts_per_wave": pmc["valu_insts_per_wave"], "waves_per_launch": waves,
                                                  "source": "this run: rocprofv3 --pmc SQ_INSTS_VALU SQ_WAVES child pass of the same "
                                                            "workload (last 24 launches), launch duration from the timed region"}
+                # round 6: "one instruction per 4 clk" is the nominal rate; the measured issue costs on gfx950 (scripts/ubench/f64_rates.hip:
+                # f64 FMA / MUL 5.4 - 5.7 clk, conversions 4.3, f32 2.3) weighted by this kernel's measured class mix
+                # (profiles/r06/valu_mix.json) give the pipe's real utilisation
+                try:
+                    vm = json.load(open(os.path.join(ROOT, "profiles", "r06", "valu_mix.json")))["kernels"]["quad"]
+                    cyc = float(vm["mean_issue_cycles_per_valu_instruction"])
+                    out["roofline"]["valu_issue"]["mean_issue_cycles_per_instruction_measured_mix"] = cyc
+                    out["roofline"]["valu_issue"]["pipe_utilisation_at_measured_costs"] = ach * cyc / (1024 * 2.4e9)
+                    out["roofline"]["valu_issue"]["mix_source"] = "profiles/r06/valu_mix.json (class counters) x profiles/r06/valu_issue_rates_gfx950.txt"
+                except Exception:
+                    pass
                 if ach / peak_issue > out["roofline"]["frac"]:
                     out["roofline"]["bound"] = "valu_issue"
                 out["roofline"]["bound_frac"] = max(ach / peak_issue, out["roofline"]["frac"])
